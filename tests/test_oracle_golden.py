@@ -1,0 +1,66 @@
+"""Pins the CPU oracle (oracle/fno3d_oracle.py) to golden vectors produced by the reference itself."""
+import torch
+
+from conftest import rel_l2
+from oracle import fno3d_oracle as O
+
+TOL = 2e-6   # fp32 vs fp32; the reference's own thread-count noise floor is 1.75e-7
+
+
+def _cfg(g):
+    return dict(modes=g.modes, n_layers=g.n_layers, shape_in=g.shape_in, shape_out=g.shape_out)
+
+
+def test_forward_eval(golden):
+    out, _ = O.fno3d_forward(golden.sd("sd0"), golden.t("x0"), training=False, **_cfg(golden))
+    assert rel_l2(out, golden.t("fwd_eval")) < TOL
+
+
+def test_forward_train_loss_grads(golden):
+    sd = golden.sd("sd0")
+    loss, pred, grads, _ = O.loss_and_grads(sd, golden.t("x0"), golden.t("y0"), **_cfg(golden))
+    assert rel_l2(pred, golden.t("fwd_train")) < TOL
+    assert abs(float(loss) - float(golden.z["loss0"])) < 1e-6 * abs(float(golden.z["loss0"]))
+    ref = golden.sd("grad0")
+    assert set(ref) == set(grads)
+    for k, g in grads.items():
+        if k.startswith("convs.") and k.endswith(".bias"):
+            # BatchNorm cancels a per-channel constant: the true gradient is 0, both sides hold ~1e-7 noise
+            assert float((g - ref[k]).abs().max()) < 1e-5, k
+        else:
+            assert rel_l2(g, ref[k]) < 2e-5, k
+
+
+def test_two_train_steps(golden):
+    sd = golden.sd("sd0")
+    batches = [(golden.t("x0"), golden.t("y0")), (golden.t("x1"), golden.t("y1"))]
+    losses = O.train_steps(sd, batches, lr0=golden.lr0, t_max=golden.t_max, **_cfg(golden))
+    assert abs(losses[1] - float(golden.z["loss1"])) < 2e-5 * abs(float(golden.z["loss1"]))
+    ref = golden.sd("sd2")
+    for k, v in ref.items():
+        if v.dtype in (torch.int64,):
+            assert int(sd[k]) == int(v), k
+        elif k.startswith("convs.") and k.endswith(".bias"):
+            # Adam turns the zero-gradient noise above into +-lr steps: only the step bound is defined
+            assert float((sd[k] - v).abs().max()) <= 2 * 2 * golden.lr0 * 1.01, k
+        elif "running_mean" in k:
+            assert rel_l2(sd[k], v) < 5e-3, k     # moves with the conv bias above
+        else:
+            # Adam divides by sqrt(v): elements whose gradient is rounding noise move by O(lr) either way
+            assert rel_l2(sd[k], v) < 1e-3, k
+
+
+def test_rollout(golden):
+    x = O.gaussian_preprocess(golden.t("x1"), *golden.norm()[:2])
+    cin, cout = golden.shape_in[-1], golden.shape_out[-1]
+    para = golden.t("x1")[..., cout:] if cin != cout else None
+    out = O.rollout(golden.sd("sd0"), x, 3, norm=golden.norm(), para_input=para, **_cfg(golden))
+    assert rel_l2(out, golden.t("rollout3")) < 1e-5
+
+
+def test_init_state_dict_matches_reference_layout(golden):
+    sd = O.init_state_dict(golden.modes, golden.n_layers, golden.width, golden.shape_in, golden.shape_out)
+    ref = golden.sd("sd0")
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape) and sd[k].dtype == ref[k].dtype, k
