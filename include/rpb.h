@@ -1,0 +1,113 @@
+/* rpb.h -- C ABI of librpb_hip.so: the MI355X (gfx950) kernels behind RealPDEBench's FNO3d hot path.
+ *
+ * Boundary contract:
+ *   - plain C, no torch / pybind types; device pointers are raw `float*` into caller-owned HBM;
+ *   - every function is stream-ordered on the `hipStream_t` passed as `void* stream`, never synchronises,
+ *     never allocates; scratch ("partial rows") is caller-allocated, sized by the `*_rows/_slots` queries;
+ *   - returns 0 on success, <0 on error (RPB_ERR_*); `rpb_last_error()` returns a thread-local message;
+ *   - fp32 everywhere (the reference is fp32; matrix work uses v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains).
+ *
+ * Tensor layouts (MI355X-first, not the reference's):
+ *   activations   [B][Tp][Hp][Wp][C]       channels-last, one cell = C contiguous floats (256 B at C=64)
+ *   spectra       [B][2 (re,im)][M][C]     planar complex, M = (2*m1)*(2*m2)*m3 retained modes
+ *   spectral W    [M][Ci][Co][2]           mode-major interleaved complex (reference: 4 x [Ci][Co][m1][m2][m3] c64)
+ *
+ * Each entry point names the reference code it replaces (paths relative to the reference repo root).
+ */
+#ifndef RPB_H
+#define RPB_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPB_OK 0
+#define RPB_ERR_ARG (-1)
+#define RPB_ERR_LAUNCH (-2)
+#define RPB_ERR_UNSUPPORTED (-3)
+
+const char* rpb_last_error(void);
+int rpb_abi_version(void);
+
+/* K1  lift + zero-pad.  realpdebench/model/fno.py:106-111 (get_grid :135-143, cat, fc0, permute, F.pad).
+ *     out[b,t,h,w,:] = fc0_w @ [x[b,t,h,w,:], gt[t], gh[h], gw[w]] + fc0_b inside T x H x W, 0 in the pad. */
+int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh, const float* gw, const float* fc0_w,
+                     const float* fc0_b, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp,
+                     void* stream);
+/*     autograd of the above w.r.t. fc0.{weight,bias}: part[rows][C*(Cin+3) + C], rows = rpb_lift_bwd_rows(). */
+int rpb_lift_bwd_rows(void);
+int rpb_lift_bwd(const float* g_out, const float* x, const float* gt, const float* gh, const float* gw, float* part,
+                 int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp, void* stream);
+
+/* K2/K4  one truncated-DFT stage: out[g][o][n] (+)= sum_k M[o][k] * in[g][k][n], n contiguous.
+ *     Replaces torch.fft.rfftn / torch.fft.irfftn of SpectralConv3d.forward (fno.py:48, :63) without ever
+ *     materialising the discarded 97 % of the spectrum (fno.py:51-60).  Inputs k >= k_valid are treated as 0. */
+int rpb_axis_gemm(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g_stride,
+                  long in_k_stride, long out_g_stride, long out_o_stride, int k_valid, int accumulate, void* stream);
+
+/* K3  per-mode complex channel contraction.  compl_mul3d / the four corner-block einsums, fno.py:41-43, 53-60,
+ *     and their autograd (dgrad: gX = gY conj(W); wgrad: gW = conj(X) gY). */
+int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream);
+int rpb_mode_contract_dgrad(const float* GY, const float* W, float* GX, int B, int M, int C, void* stream);
+int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, int M, int C, int accumulate,
+                            void* stream);
+
+/* K4+K5  last inverse-DFT stage fused with the 1x1x1 Conv3d, the `x1 + x2` add and the BatchNorm statistics.
+ *     fno.py:63 (W-axis c2r part of irfftn), :115 (Conv3d), :116 (add), batch statistics of :117.
+ *     out[cell][o] = sum_k GW[w(cell)][k] z2[g(cell)][k][o] + sum_i x[row(cell)][i] Wm(o,i) + bias[o]
+ *     transpose_w=0: Wm is [CO][KC] (forward); =1: Wm is [KC][CO] (dgrad).  z2 == NULL drops the spectral term.
+ *     gather=1: cells are padded cells and row(cell) is the cropped index (zero rows in the pad margin).
+ *     stats_part (optional): [rpb_cell_mix_stat_rows(...)][2][CO] partial sums of out and out^2. */
+long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec);
+int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+                 float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w, int gather, int T,
+                 int H, int W, int Tp, int Hp, int Wp_pad, void* stream);
+
+/*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
+ *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */
+long rpb_cell_wgrad_slots(long ncell, int CO, int CI);
+int rpb_cell_wgrad(const float* gs, const float* x, float* part, long ncell, int CO, int CI, int crop, int T, int H,
+                   int W, int Tp, int Hp, int Wp, void* stream);
+
+/* K6  BatchNorm3d (+ exact-erf GELU).  fno.py:117-119; training statistics include the padded cells. */
+int rpb_reduce_partials(const float* part, long rows, long L, float* out_f32, double* out_f64, double scale,
+                        int accumulate, void* stream);
+int rpb_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                    float* running_mean, float* running_var, int C, void* stream);
+int rpb_bn_eval_prep(const float* running_var, float eps, float* invstd, int C, void* stream);
+int rpb_bn_act_fwd(const float* s, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   float* y, long ncell, int C, int gelu, void* stream);
+int rpb_bn_bwd_rows(void);
+int rpb_bn_bwd_reduce(const float* s, const float* gy, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, float* part, long ncell, int C, int gelu, void* stream);
+int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, const float* sums, double count, float* gs, long ncell, int C, int gelu,
+                     void* stream);
+
+/* K7  crop + fc1 + GELU + fc2.  fno.py:121-125.  proj_bwd recomputes fc1 and emits gu = dL/d(fc1 pre-activation)
+ *     [ncrop][128] plus partial rows [rpb_proj_slots(...)][DO*128 + 128 + DO] for d fc2.weight, d fc1.bias, d fc2.bias. */
+long rpb_proj_slots(long ncrop, int C, int DO);
+int rpb_proj_fwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                 float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, void* stream);
+int rpb_proj_bwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                 const float* gout, float* gu, float* part, long ncrop, int C, int DO, int T, int H, int W, int Tp,
+                 int Hp, int Wp, void* stream);
+
+/*     MSE.  realpdebench/utils/metrics.py:11-13 + `.mean()` of train.py:328 and its gradient. */
+int rpb_mse_rows(void);
+int rpb_mse(const float* pred, const float* target, float* elem, float* gout, float* part, long n, float gscale,
+            void* stream);
+
+/* K8  Adam (torch.optim.Adam defaults, train.py:290,333; complex weights as 2 x fp32). */
+int rpb_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  long step, float gscale, void* stream);
+
+/* K9  rollout step glue.  realpdebench/eval.py:316-318 + data/data_normalizer.py:50-62. */
+int rpb_rollout_affine(const float* pred, const float* para, float* out, long ncell, int Cp, int Cx,
+                       const float* mean_t, const float* std_t, const float* mean_i, const float* std_i, void* stream);
+int rpb_channel_affine(const float* in, float* out, long n, int C, const float* mean, const float* stdv, int inverse,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPB_H */

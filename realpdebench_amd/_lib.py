@@ -1,0 +1,83 @@
+"""ctypes binding of ``csrc/librpb_hip.so`` (C ABI declared in ``include/rpb.h``).
+
+This is the stub a maintainer of the reference would add to call the MI355X path.
+Loading is lazy; a missing library is a hard error -- there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librpb_hip.so")
+
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+_T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
+
+# name -> (restype, argument codes)   p=pointer i=int l=long f=float d=double
+SIGNATURES = {
+    "rpb_last_error": (ctypes.c_char_p, ""),
+    "rpb_abi_version": (_I, ""),
+    "rpb_lift_pad_fwd": (_I, "ppppppp" + "iiiiiiiii" + "p"),
+    "rpb_lift_bwd_rows": (_I, ""),
+    "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
+    "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "p"),
+    "rpb_mode_contract_fwd": (_I, "ppp" + "iii" + "p"),
+    "rpb_mode_contract_dgrad": (_I, "ppp" + "iii" + "p"),
+    "rpb_mode_contract_wgrad": (_I, "ppp" + "iiii" + "p"),
+    "rpb_cell_mix_stat_rows": (_L, "liiiii"),
+    "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "p"),
+    "rpb_cell_wgrad_slots": (_L, "lii"),
+    "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "p"),
+    "rpb_reduce_partials": (_I, "p" + "ll" + "pp" + "d" + "i" + "p"),
+    "rpb_bn_finalize": (_I, "p" + "d" + "ff" + "pppp" + "i" + "p"),
+    "rpb_bn_eval_prep": (_I, "p" + "f" + "p" + "i" + "p"),
+    "rpb_bn_act_fwd": (_I, "pppppp" + "l" + "ii" + "p"),
+    "rpb_bn_bwd_rows": (_I, ""),
+    "rpb_bn_bwd_reduce": (_I, "ppppppp" + "l" + "ii" + "p"),
+    "rpb_bn_bwd_apply": (_I, "ppppppp" + "d" + "p" + "l" + "ii" + "p"),
+    "rpb_proj_slots": (_L, "lii"),
+    "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "p"),
+    "rpb_proj_bwd": (_I, "pppppppp" + "l" + "ii" + "iiiiii" + "p"),
+    "rpb_mse_rows": (_I, ""),
+    "rpb_mse": (_I, "ppppp" + "l" + "f" + "p"),
+    "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
+    "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
+    "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
+}
+
+_lib = None
+
+
+class RpbError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (once).  Raises if it has not been built -- no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RpbError(
+                f"{LIB_PATH} is missing: build it with `python -m realpdebench_amd.build` "
+                "(hipcc --offload-arch=gfx950).  realpdebench_amd has no CPU/eager fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = [_T[c] for c in args]
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Call an ``int``-returning entry point and turn a non-zero status into ``RpbError``."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RpbError(f"{name} failed ({rc}): {lib.rpb_last_error().decode()}")
+
+
+def query(name, *args):
+    v = getattr(load(), name)(*args)
+    if v < 0:
+        raise RpbError(f"{name}{args} unsupported")
+    return int(v)

@@ -1,0 +1,165 @@
+// K2/K4: truncated DFT stage = small dense real matrix applied along one strided axis.
+//
+//   out[g][o][n] = sum_k M[o][k] * in[g][k][n]        n contiguous, k/o strided, g = batch
+//
+// Replaces torch.fft.rfftn / irfftn in SpectralConv3d.forward (reference realpdebench/model/fno.py:48,63):
+// only the retained modes are ever produced, so the full [B,C,Tp,Hp,Wp/2+1] spectrum (97 % discarded
+// by fno.py:51-60) is never materialised.  Complex data is planar (re/im adjacent to the transformed
+// axis) so every stage -- forward, inverse and both adjoints -- is this one real kernel.
+//
+// Mapping: one wave owns OT o-tiles (32 rows each) x NV interleaved n-tiles (column j of n-tile v is
+// n = n0 + NV*j + v, so a lane loads/stores NV contiguous floats: 128/256/512 B per half-wave).
+// B operand (the data) is loaded straight from HBM in MFMA layout; A operand (the matrix) sits in LDS
+// as Mlds[k][o] (o contiguous -> conflict-free ds_read_b32).  Persistent grid, one item per wave.
+#include "rpb_common.h"
+
+template <int NV>
+struct VecN;
+template <>
+struct VecN<1> {
+    typedef float T;
+};
+template <>
+struct VecN<2> {
+    typedef f32x2 T;
+};
+template <>
+struct VecN<4> {
+    typedef f32x4 T;
+};
+
+template <int NV>
+__device__ __forceinline__ void load_vec(const float* p, bool ok, float (&v)[NV]) {
+    if (ok) {
+        typename VecN<NV>::T t = *reinterpret_cast<const typename VecN<NV>::T*>(p);
+        if constexpr (NV == 1) {
+            v[0] = t;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = t[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    }
+}
+
+template <int OT, int NV>
+__global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ M, int G, int K, int O, int N,
+                                                        long in_g, long in_k, long out_g, long out_o, int k_valid,
+                                                        int accumulate) {
+    extern __shared__ float Mlds[];   // [Kp][Op]
+    const int ot_total = (O + 31) / 32;
+    const int och = (ot_total + OT - 1) / OT;
+    const int Op = och * OT * 32;
+    const int Kp = (K + 1) & ~1;
+    for (int idx = threadIdx.x; idx < Kp * Op; idx += blockDim.x) {
+        const int k = idx / Op, o = idx - k * Op;
+        Mlds[idx] = (k < K && o < O) ? M[(long)o * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int nch = N / (32 * NV);
+    const long nitems = (long)G * nch * och;
+
+    for (long item = (long)blockIdx.x * waves + wave; item < nitems; item += (long)gridDim.x * waves) {
+        const int oc = (int)(item % och);
+        const long r = item / och;
+        const int nc = (int)(r % nch);
+        const long g = r / nch;
+        const int n0 = nc * 32 * NV + NV * col;
+        const float* ip = in + g * in_g + n0;
+        f32x16 acc[OT][NV];
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[a][v] = zero16();
+
+        const float* mrow = Mlds + oc * OT * 32 + col;
+#pragma unroll 4
+        for (int s = 0; s < (k_valid + 1) / 2; ++s) {   // inputs k >= k_valid are known zeros (layer-0 pad)
+            const int k = 2 * s + half;
+            float b[NV];
+            load_vec<NV>(ip + (long)k * in_k, k < k_valid, b);
+#pragma unroll
+            for (int a = 0; a < OT; ++a) {
+                const float av = mrow[k * Op + a * 32];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[a][v] = mfma32(av, b[v], acc[a][v]);
+            }
+        }
+        float* op = out + g * out_g + n0;
+#pragma unroll
+        for (int a = 0; a < OT; ++a) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int o = (oc * OT + a) * 32 + mfma_row(lane, rr);
+                if (o < O) {
+                    float* dst = op + (long)o * out_o;
+                    if constexpr (NV == 1) {
+                        dst[0] = accumulate ? dst[0] + acc[a][0][rr] : acc[a][0][rr];
+                    } else {
+                        typename VecN<NV>::T t;
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) t[v] = acc[a][v][rr];
+                        if (accumulate) {
+                            typename VecN<NV>::T old = *reinterpret_cast<typename VecN<NV>::T*>(dst);
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) t[v] += old[v];
+                        }
+                        *reinterpret_cast<typename VecN<NV>::T*>(dst) = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int OT, int NV>
+static int launch_axis(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g, long in_k,
+                       long out_g, long out_o, int k_valid, int accumulate, hipStream_t stream) {
+    const int ot_total = (O + 31) / 32;
+    const int och = (ot_total + OT - 1) / OT;
+    const int Op = och * OT * 32;
+    const int Kp = (K + 1) & ~1;
+    const size_t lds = (size_t)Kp * Op * sizeof(float);
+    RPB_REQUIRE(lds <= 160 * 1024, "axis_gemm: matrix %dx%d does not fit LDS", O, K);
+    (void)hipFuncSetAttribute((const void*)axis_gemm_kernel<OT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int waves = 4;
+    const long nitems = (long)G * (N / (32 * NV)) * och;
+    const int per_cu = lds > 0 ? (int)((160 * 1024) / lds) : 8;
+    long grid = (long)rpb_num_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const long need = (nitems + waves - 1) / waves;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((axis_gemm_kernel<OT, NV>), dim3((unsigned)grid), dim3(waves * 64), lds, stream, in, out, M, G, K,
+                       O, N, in_g, in_k, out_g, out_o, k_valid, accumulate);
+    RPB_CHECK_LAUNCH("axis_gemm");
+}
+
+extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g,
+                             long in_k, long out_g, long out_o, int k_valid, int accumulate, void* stream) {
+    RPB_REQUIRE(in && out && M, "axis_gemm: null pointer");
+    RPB_REQUIRE(G > 0 && K > 0 && O > 0 && N > 0, "axis_gemm: bad sizes G=%d K=%d O=%d N=%d", G, K, O, N);
+    RPB_REQUIRE(N % 32 == 0, "axis_gemm: N=%d must be a multiple of 32", N);
+    RPB_REQUIRE(k_valid >= 0 && k_valid <= K, "axis_gemm: k_valid=%d out of range", k_valid);
+    hipStream_t st = (hipStream_t)stream;
+    const int ot_total = (O + 31) / 32;
+    const int OT = ot_total >= 3 ? 3 : ot_total;
+    int NV = (N % 128 == 0) ? 4 : (N % 64 == 0) ? 2 : 1;
+    while (OT * NV > 6) NV >>= 1;
+    // 16-byte vector access needs aligned strides
+    if (NV == 4 && ((in_g | in_k | out_g | out_o) & 3)) NV = 2;
+    if (NV == 2 && ((in_g | in_k | out_g | out_o) & 1)) NV = 1;
+#define RPB_AX(OT_, NV_)                                                                                        \
+    if (OT == OT_ && NV == NV_)                                                                                 \
+        return launch_axis<OT_, NV_>(in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, st);
+    RPB_AX(1, 1) RPB_AX(1, 2) RPB_AX(1, 4) RPB_AX(2, 1) RPB_AX(2, 2) RPB_AX(3, 1) RPB_AX(3, 2)
+#undef RPB_AX
+    RPB_FAIL(RPB_ERR_UNSUPPORTED, "axis_gemm: no instantiation OT=%d NV=%d", OT, NV);
+}

@@ -1,0 +1,93 @@
+// Shared device/host helpers for the RealPDEBench MI355X (gfx950 / CDNA4) kernels.
+// Wave = 64 lanes everywhere.  fp32 matrix work uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------- errors
+#define RPB_OK 0
+#define RPB_ERR_ARG -1
+#define RPB_ERR_LAUNCH -2
+#define RPB_ERR_UNSUPPORTED -3
+
+extern thread_local char rpb_err_buf[512];
+
+#define RPB_FAIL(code, ...)                                      \
+    do {                                                         \
+        snprintf(rpb_err_buf, sizeof(rpb_err_buf), __VA_ARGS__); \
+        return (code);                                           \
+    } while (0)
+
+#define RPB_REQUIRE(cond, ...)                        \
+    do {                                              \
+        if (!(cond)) RPB_FAIL(RPB_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define RPB_CHECK_LAUNCH(name)                                                                   \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) RPB_FAIL(RPB_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_));   \
+        return RPB_OK;                                                                           \
+    } while (0)
+
+int rpb_num_cus();   // cached hipDeviceAttributeMultiprocessorCount of the current device
+
+// ---------------------------------------------------------------------------------- MFMA
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// D = A(32x2) * B(2x32) + C, one wave.  Lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
+// Lane l, register r of D holds D[row = 8*(r>>2) + 4*(l>>5) + (r&3)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int lane, int r) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu(x) = Phi(x) + x*phi(x)
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// padded-cell index -> cropped-cell index, or -1 when the cell lies in the zero-pad margin
+struct CropMap {
+    int T, H, W, Tp, Hp, Wp;
+};
+__device__ __forceinline__ long pad_to_crop(const CropMap& m, long p) {
+    int w = (int)(p % m.Wp);
+    long r = p / m.Wp;
+    int h = (int)(r % m.Hp);
+    r /= m.Hp;
+    int t = (int)(r % m.Tp);
+    long b = r / m.Tp;
+    if (w >= m.W || h >= m.H || t >= m.T) return -1;
+    return ((b * m.T + t) * m.H + h) * (long)m.W + w;
+}
+__device__ __forceinline__ long crop_to_pad(const CropMap& m, long q) {
+    int w = (int)(q % m.W);
+    long r = q / m.W;
+    int h = (int)(r % m.H);
+    r /= m.H;
+    int t = (int)(r % m.T);
+    long b = r / m.T;
+    return ((b * m.Tp + t) * m.Hp + h) * (long)m.Wp + w;
+}

@@ -1,0 +1,161 @@
+// K3: per-mode complex channel contraction of SpectralConv3d (reference fno.py:41-43, 53-60):
+//
+//   fwd    Y[b,o,m]  = sum_i X[b,i,m] * W[i,o,m]
+//   dgrad  gX[b,i,m] = sum_o gY[b,o,m] * conj(W[i,o,m])
+//   wgrad  gW[i,o,m] = sum_b conj(X[b,i,m]) * gY[b,o,m]
+//
+// MI355X layout (not the reference's): spectra are planar and mode-major-within-batch
+//   X, Y : [B][2 (re,im)][M][C]          (what the truncated-DFT stages produce / consume)
+// and the weights are stored MODE-MAJOR as interleaved complex
+//   W    : [M][Ci][Co][2]                (one contiguous Ci*Co*8 B tile per retained mode)
+// so one workgroup owns one mode, streams its 32 KB (C=64) weight tile exactly once with 512 B
+// coalesced rows, and keeps the [B][2][C] coefficient tile of that mode in LDS (broadcast reads).
+// At B=32 this kernel is a pure weight stream: 100.7 MB per layer against ~50 MB of coefficients.
+#include "rpb_common.h"
+
+#define MC_THREADS 256
+#define MC_BT 8   // batch entries accumulated per thread per pass
+
+// ---- forward and dgrad share the structure "out[b][n] = sum_k in[b][k] (*) W(k,n)"
+template <bool DGRAD>
+__global__ __launch_bounds__(MC_THREADS) void mode_contract_kernel(const float* __restrict__ X,
+                                                                   const float* __restrict__ Wt,
+                                                                   float* __restrict__ Y, int B, int M, int C) {
+    extern __shared__ float lds[];
+    const int m = blockIdx.x;
+    float* Xl = lds;                       // [B][2][C]
+    float* Wl = lds + (long)B * 2 * C;     // dgrad only: [Ci][Co+1] complex (padded: conflict-free b64 column reads)
+    const long plane = (long)M * C;
+    for (int idx = threadIdx.x; idx < B * 2 * C; idx += blockDim.x) {
+        const int c = idx % C, r = idx / C;            // r = b*2 + ri
+        Xl[idx] = X[(long)r * plane + (long)m * C + c];
+    }
+    const float* Wm = Wt + (long)m * C * C * 2;
+    if (DGRAD) {
+        for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) {
+            const int i = idx / C, o = idx - i * C;
+            const f32x2 w = *reinterpret_cast<const f32x2*>(Wm + (long)idx * 2);
+            *reinterpret_cast<f32x2*>(Wl + ((long)i * (C + 1) + o) * 2) = w;
+        }
+    }
+    __syncthreads();
+
+    const int n = threadIdx.x % C;          // output channel owned by this thread
+    const int bg = threadIdx.x / C;
+    const int nbg = blockDim.x / C;
+    for (int b0 = bg * MC_BT; b0 < B; b0 += nbg * MC_BT) {
+        float ar[MC_BT], ai[MC_BT];
+#pragma unroll
+        for (int j = 0; j < MC_BT; ++j) ar[j] = ai[j] = 0.f;
+        for (int k = 0; k < C; ++k) {
+            float wr, wi;
+            if (DGRAD) {                    // n = i, k = o : conj(W[i][o])
+                const f32x2 w = *reinterpret_cast<const f32x2*>(Wl + ((long)n * (C + 1) + k) * 2);
+                wr = w[0];
+                wi = -w[1];
+            } else {                        // n = o, k = i : W[i][o], 512 B coalesced row
+                const f32x2 w = *reinterpret_cast<const f32x2*>(Wm + ((long)k * C + n) * 2);
+                wr = w[0];
+                wi = w[1];
+            }
+#pragma unroll
+            for (int j = 0; j < MC_BT; ++j) {
+                const int b = b0 + j;
+                if (b < B) {
+                    const float xr = Xl[(b * 2 + 0) * C + k];
+                    const float xi = Xl[(b * 2 + 1) * C + k];
+                    ar[j] += xr * wr - xi * wi;
+                    ai[j] += xr * wi + xi * wr;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MC_BT; ++j) {
+            const int b = b0 + j;
+            if (b < B) {
+                Y[(long)(b * 2 + 0) * plane + (long)m * C + n] = ar[j];
+                Y[(long)(b * 2 + 1) * plane + (long)m * C + n] = ai[j];
+            }
+        }
+    }
+}
+
+// ---- wgrad: gW[m][i][o] = sum_b conj(X[b][i]) * gY[b][o]
+__global__ __launch_bounds__(MC_THREADS) void mode_wgrad_kernel(const float* __restrict__ X,
+                                                                const float* __restrict__ GY,
+                                                                float* __restrict__ GW, int B, int M, int C,
+                                                                int accumulate) {
+    extern __shared__ float lds[];
+    const int m = blockIdx.x;
+    float* Xl = lds;
+    float* Gl = lds + (long)B * 2 * C;
+    const long plane = (long)M * C;
+    for (int idx = threadIdx.x; idx < B * 2 * C; idx += blockDim.x) {
+        const int c = idx % C, r = idx / C;
+        const long off = (long)r * plane + (long)m * C + c;
+        Xl[idx] = X[off];
+        Gl[idx] = GY[off];
+    }
+    __syncthreads();
+    const int o = threadIdx.x % C;
+    const int ig = threadIdx.x / C;
+    const int nig = blockDim.x / C;
+    float* Gm = GW + (long)m * C * C * 2;
+    for (int i = ig; i < C; i += nig) {
+        float ar = 0.f, ai = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float xr = Xl[(b * 2 + 0) * C + i], xi = Xl[(b * 2 + 1) * C + i];
+            const float gr = Gl[(b * 2 + 0) * C + o], gi = Gl[(b * 2 + 1) * C + o];
+            ar += xr * gr + xi * gi;        // conj(x) * g
+            ai += xr * gi - xi * gr;
+        }
+        f32x2* dst = reinterpret_cast<f32x2*>(Gm + ((long)i * C + o) * 2);
+        if (accumulate) {
+            const f32x2 old = *dst;
+            ar += old[0];
+            ai += old[1];
+        }
+        f32x2 v = {ar, ai};
+        *dst = v;
+    }
+}
+
+static int mc_check(const void* a, const void* b, const void* c, int B, int M, int C) {
+    RPB_REQUIRE(a && b && c, "mode_contract: null pointer");
+    RPB_REQUIRE(B > 0 && M > 0, "mode_contract: bad sizes B=%d M=%d", B, M);
+    RPB_REQUIRE(C > 0 && C <= MC_THREADS && MC_THREADS % C == 0, "mode_contract: C=%d must divide %d", C, MC_THREADS);
+    return RPB_OK;
+}
+
+extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream) {
+    if (int e = mc_check(X, W, Y, B, M, C)) return e;
+    const size_t lds = (size_t)B * 2 * C * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_fwd: B*C too large for LDS");
+    (void)hipFuncSetAttribute((const void*)mode_contract_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((mode_contract_kernel<false>), dim3(M), dim3(MC_THREADS), lds, (hipStream_t)stream, X, W, Y, B,
+                       M, C);
+    RPB_CHECK_LAUNCH("mode_contract_fwd");
+}
+
+extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* GX, int B, int M, int C, void* stream) {
+    if (int e = mc_check(GY, W, GX, B, M, C)) return e;
+    const size_t lds = ((size_t)B * 2 * C + (size_t)C * (C + 1) * 2) * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_dgrad: tiles too large for LDS (B=%d C=%d)", B, C);
+    (void)hipFuncSetAttribute((const void*)mode_contract_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((mode_contract_kernel<true>), dim3(M), dim3(MC_THREADS), lds, (hipStream_t)stream, GY, W, GX, B,
+                       M, C);
+    RPB_CHECK_LAUNCH("mode_contract_dgrad");
+}
+
+extern "C" int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, int M, int C, int accumulate,
+                                       void* stream) {
+    if (int e = mc_check(X, GY, GW, B, M, C)) return e;
+    const size_t lds = (size_t)B * 4 * C * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_wgrad: B*C too large for LDS");
+    (void)hipFuncSetAttribute((const void*)mode_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mode_wgrad_kernel, dim3(M), dim3(MC_THREADS), lds, (hipStream_t)stream, X, GY, GW, B, M, C,
+                       accumulate);
+    RPB_CHECK_LAUNCH("mode_contract_wgrad");
+}

@@ -1,0 +1,476 @@
+// HBM-streaming kernels of the FNO3d step: lift+pad (K1), BatchNorm3d + GELU forward/backward (K6),
+// MSE, Adam (K8), rollout affine (K9) and the deterministic partial-sum reducers.
+// All are float4 / grid-stride; reductions go per-thread -> LDS -> one partial row per block and are
+// finished by rpb_reduce_partials* in fp64 (no atomics: bit-reproducible run to run).
+#include "rpb_common.h"
+
+#define PW_THREADS 256
+
+static inline int pw_grid(long work_items, int per_cu = 8) {
+    long g = (work_items + PW_THREADS - 1) / PW_THREADS;
+    const long cap = (long)rpb_num_cus() * per_cu;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------- K1 lift + pad
+// out[b,t,h,w,:] = fc0.weight @ [x[b,t,h,w,:], gt[t], gh[h], gw[w]] + fc0.bias  for t<T,h<H,w<W, else 0
+// (fno.py:106-111: get_grid, cat, fc0, permute, F.pad -- the permute disappears: we stay channels-last)
+#define LIFT_FMAX 24
+__global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                              const float* __restrict__ gh, const float* __restrict__ gw,
+                                                              const float* __restrict__ w0, const float* __restrict__ b0,
+                                                              float* __restrict__ out, long ncell_pad, int Cin, int C,
+                                                              CropMap cm) {
+    extern __shared__ float wl[];   // [F][C] transposed fc0.weight, then bias [C]
+    const int F = Cin + 3;
+    for (int idx = threadIdx.x; idx < F * C; idx += blockDim.x) {
+        const int j = idx / C, o = idx - j * C;
+        wl[idx] = w0[o * F + j];
+    }
+    for (int idx = threadIdx.x; idx < C; idx += blockDim.x) wl[F * C + idx] = b0[idx];
+    __syncthreads();
+    const int c4n = C >> 2;
+    const long total = ncell_pad * c4n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long cell = idx / c4n;
+        const int o = (int)(idx - cell * c4n) * 4;
+        const int w = (int)(cell % cm.Wp);
+        long r = cell / cm.Wp;
+        const int h = (int)(r % cm.Hp);
+        r /= cm.Hp;
+        const int t = (int)(r % cm.Tp);
+        const long b = r / cm.Tp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (w < cm.W && h < cm.H && t < cm.T) {
+            const float* xp = x + (((b * cm.T + t) * cm.H + h) * (long)cm.W + w) * Cin;
+            const float* bl = wl + F * C + o;
+            v[0] = bl[0]; v[1] = bl[1]; v[2] = bl[2]; v[3] = bl[3];
+            for (int j = 0; j < F; ++j) {
+                const float f = (j < Cin) ? xp[j] : (j == Cin ? gt[t] : (j == Cin + 1 ? gh[h] : gw[w]));
+                const float* wr = wl + j * C + o;
+                v[0] += f * wr[0]; v[1] += f * wr[1]; v[2] += f * wr[2]; v[3] += f * wr[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + cell * C + o) = v;
+    }
+}
+
+extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
+                                const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
+                                int Wp, void* stream) {
+    RPB_REQUIRE(x && gt && gh && gw && w0 && b0 && out, "lift_pad: null pointer");
+    RPB_REQUIRE(C % 4 == 0 && Cin + 3 <= LIFT_FMAX, "lift_pad: C=%d Cin=%d unsupported", C, Cin);
+    const long ncell = (long)B * Tp * Hp * Wp;
+    const size_t lds = ((size_t)(Cin + 3) * C + C) * 4;
+    hipLaunchKernelGGL(lift_pad_kernel, dim3(pw_grid(ncell * (C / 4))), dim3(PW_THREADS), lds, (hipStream_t)stream, x, gt,
+                       gh, gw, w0, b0, out, ncell, Cin, C, CropMap{T, H, W, Tp, Hp, Wp});
+    RPB_CHECK_LAUNCH("lift_pad");
+}
+
+// d fc0.weight[o][j] = sum_cells g[cell][o] * feat[cell][j],  d fc0.bias[o] = sum_cells g[cell][o]
+// part row layout: [C*F] weight grad (o*F + j) then [C] bias grad
+__global__ __launch_bounds__(PW_THREADS) void lift_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ gt, const float* __restrict__ gh,
+                                                              const float* __restrict__ gw, float* __restrict__ part,
+                                                              long ncrop, int Cin, int C, CropMap cm) {
+    extern __shared__ float red[];  // [nsub][C][F+1]
+    const int F = Cin + 3;
+    const int o = threadIdx.x % C, sub = threadIdx.x / C, nsub = blockDim.x / C;
+    float acc[LIFT_FMAX + 1];
+#pragma unroll
+    for (int j = 0; j <= LIFT_FMAX; ++j) acc[j] = 0.f;
+    if (sub < nsub) {
+        for (long q = (long)blockIdx.x * nsub + sub; q < ncrop; q += (long)gridDim.x * nsub) {
+            const int w = (int)(q % cm.W);
+            long r = q / cm.W;
+            const int h = (int)(r % cm.H);
+            r /= cm.H;
+            const int t = (int)(r % cm.T);
+            const long b = r / cm.T;
+            const long p = ((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp + w;
+            const float gv = g[p * C + o];
+            const float* xp = x + q * Cin;
+#pragma unroll
+            for (int j = 0; j < LIFT_FMAX; ++j) {
+                if (j < F) {
+                    const float f = (j < Cin) ? xp[j] : (j == Cin ? gt[t] : (j == Cin + 1 ? gh[h] : gw[w]));
+                    acc[j] += gv * f;
+                }
+            }
+            acc[LIFT_FMAX] += gv;
+        }
+#pragma unroll
+        for (int j = 0; j < LIFT_FMAX; ++j)
+            if (j < F) red[(sub * C + o) * (F + 1) + j] = acc[j];
+        red[(sub * C + o) * (F + 1) + F] = acc[LIFT_FMAX];
+    }
+    __syncthreads();
+    float* prow = part + (long)blockIdx.x * ((long)C * F + C);
+    for (int idx = threadIdx.x; idx < C * (F + 1); idx += blockDim.x) {
+        const int oo = idx / (F + 1), j = idx - oo * (F + 1);
+        float s = 0.f;
+        for (int k = 0; k < nsub; ++k) s += red[(k * C + oo) * (F + 1) + j];
+        if (j < F) prow[oo * F + j] = s;
+        else prow[C * F + oo] = s;
+    }
+}
+
+extern "C" int rpb_lift_bwd_rows() { return rpb_num_cus() * 4; }
+
+extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, const float* gh, const float* gw,
+                            float* part, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp,
+                            void* stream) {
+    RPB_REQUIRE(g && x && gt && gh && gw && part, "lift_bwd: null pointer");
+    RPB_REQUIRE(Cin + 3 <= LIFT_FMAX && C <= PW_THREADS && PW_THREADS % C == 0, "lift_bwd: C=%d Cin=%d unsupported", C, Cin);
+    const long ncrop = (long)B * T * H * W;
+    const int nsub = PW_THREADS / C;
+    const size_t lds = (size_t)nsub * C * (Cin + 4) * 4;
+    hipLaunchKernelGGL(lift_bwd_kernel, dim3(rpb_lift_bwd_rows()), dim3(PW_THREADS), lds, (hipStream_t)stream, g, x, gt,
+                       gh, gw, part, ncrop, Cin, C, CropMap{T, H, W, Tp, Hp, Wp});
+    RPB_CHECK_LAUNCH("lift_bwd");
+}
+
+// ---------------------------------------------------------------------------------- reducers
+// out[j] (+)= scale * sum_r part[r][j]   (fp64 accumulation)
+__global__ __launch_bounds__(PW_THREADS) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
+                                                                     float* __restrict__ outf, double* __restrict__ outd,
+                                                                     double scale, int accumulate) {
+    // block handles 64 columns; 4 row-groups
+    __shared__ double red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (j < L)
+        for (long r = rg; r < rows; r += 4) s += (double)part[r * L + j];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && j < L) {
+        const double v = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) * scale;
+        if (outd) outd[j] = accumulate ? outd[j] + v : v;
+        if (outf) outf[j] = accumulate ? (float)((double)outf[j] + v) : (float)v;
+    }
+}
+
+extern "C" int rpb_reduce_partials(const float* part, long rows, long L, float* outf, double* outd, double scale,
+                                   int accumulate, void* stream) {
+    RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0, "reduce_partials: bad arguments");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       part, rows, L, outf, outd, scale, accumulate);
+    RPB_CHECK_LAUNCH("reduce_partials");
+}
+
+// ---------------------------------------------------------------------------------- K6 BatchNorm3d (+GELU)
+// sums = [sum_c, sumsq_c] in fp64 over `count` cells (all ranks, after the optional SyncBN all-reduce).
+// Produces batch mean / invstd and updates the running statistics exactly like nn.BatchNorm3d(momentum=0.1):
+// biased variance to normalise, unbiased variance into running_var (fno.py:117).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * m);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+}
+
+extern "C" int rpb_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                               float* rmean, float* rvar, int C, void* stream) {
+    RPB_REQUIRE(sums && mean && invstd && count > 0 && C > 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, eps,
+                       momentum, mean, invstd, rmean, rvar, C);
+    RPB_CHECK_LAUNCH("bn_finalize");
+}
+
+__global__ void bn_eval_prep_kernel(const float* __restrict__ rvar, float eps, float* __restrict__ invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+extern "C" int rpb_bn_eval_prep(const float* rvar, float eps, float* invstd, int C, void* stream) {
+    RPB_REQUIRE(rvar && invstd && C > 0, "bn_eval_prep: bad arguments");
+    hipLaunchKernelGGL(bn_eval_prep_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, rvar, eps, invstd, C);
+    RPB_CHECK_LAUNCH("bn_eval_prep");
+}
+
+// y = act(gamma * (s - mean) * invstd + beta),  act = exact-erf GELU or identity (last layer, fno.py:118)
+template <bool GELU>
+__global__ __launch_bounds__(PW_THREADS) void bn_act_kernel(const float* __restrict__ s, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            long n4, int C) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const f32x4 v = reinterpret_cast<const f32x4*>(s)[idx];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z = (v[k] - mean[c + k]) * invstd[c + k] * gamma[c + k] + beta[c + k];
+            o[k] = GELU ? gelu_f(z) : z;
+        }
+        reinterpret_cast<f32x4*>(y)[idx] = o;
+    }
+}
+
+extern "C" int rpb_bn_act_fwd(const float* s, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* y, long ncell, int C, int gelu, void* stream) {
+    RPB_REQUIRE(s && mean && invstd && gamma && beta && y && C % 4 == 0, "bn_act_fwd: bad arguments");
+    const long n4 = ncell * (C / 4);
+    if (gelu)
+        hipLaunchKernelGGL(bn_act_kernel<true>, dim3(pw_grid(n4)), dim3(PW_THREADS), 0, (hipStream_t)stream, s, mean,
+                           invstd, gamma, beta, y, n4, C);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<false>, dim3(pw_grid(n4)), dim3(PW_THREADS), 0, (hipStream_t)stream, s, mean,
+                           invstd, gamma, beta, y, n4, C);
+    RPB_CHECK_LAUNCH("bn_act_fwd");
+}
+
+// backward pass 1: per-channel  sum gz  and  sum gz*shat,  gz = gy * act'(z)
+template <bool GELU>
+__global__ __launch_bounds__(PW_THREADS) void bn_bwd_reduce_kernel(const float* __restrict__ s,
+                                                                   const float* __restrict__ gy,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   float* __restrict__ part, long ncell, int C) {
+    extern __shared__ float red[];   // [nsub][2][C]
+    const int c4n = C >> 2;
+    const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = blockDim.x / c4n;
+    const int c = c4 * 4;
+    float mu[4], is[4], ga[4], be[4], a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k]; is[k] = invstd[c + k]; ga[k] = gamma[c + k]; be[k] = beta[c + k];
+    }
+    if (sub < nsub) {
+        for (long cell = (long)blockIdx.x * nsub + sub; cell < ncell; cell += (long)gridDim.x * nsub) {
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s + cell * C + c);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gy + cell * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sh = (sv[k] - mu[k]) * is[k];
+                const float gz = GELU ? gv[k] * gelu_grad_f(sh * ga[k] + be[k]) : gv[k];
+                a1[k] += gz;
+                a2[k] += gz * sh;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[(sub * 2 + 0) * C + c + k] = a1[k];
+            red[(sub * 2 + 1) * C + c + k] = a2[k];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * C; idx += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < nsub; ++k) t += red[k * 2 * C + idx];
+        part[(long)blockIdx.x * 2 * C + idx] = t;
+    }
+}
+
+extern "C" int rpb_bn_bwd_rows() { return rpb_num_cus() * 8; }
+
+extern "C" int rpb_bn_bwd_reduce(const float* s, const float* gy, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float* part, long ncell, int C, int gelu,
+                                 void* stream) {
+    RPB_REQUIRE(s && gy && mean && invstd && gamma && beta && part, "bn_bwd_reduce: null pointer");
+    RPB_REQUIRE(C % 4 == 0 && PW_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
+    const int nsub = PW_THREADS / (C / 4);
+    const size_t lds = (size_t)nsub * 2 * C * 4;
+    const int grid = rpb_bn_bwd_rows();
+    if (gelu)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, s, gy,
+                           mean, invstd, gamma, beta, part, ncell, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, s, gy,
+                           mean, invstd, gamma, beta, part, ncell, C);
+    RPB_CHECK_LAUNCH("bn_bwd_reduce");
+}
+
+// backward pass 2: gs = gamma*invstd * (gz - dbeta/N - shat * dgamma/N);  sums = [dbeta | dgamma] (fp32, global)
+template <bool GELU>
+__global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ s, const float* gy,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  const float* __restrict__ sums, float inv_count,
+                                                                  float* gs, long n4, int C) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const f32x4 sv = reinterpret_cast<const f32x4*>(s)[idx];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(gy)[idx];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float is = invstd[c + k], ga = gamma[c + k];
+            const float sh = (sv[k] - mean[c + k]) * is;
+            const float gz = GELU ? gv[k] * gelu_grad_f(sh * ga + beta[c + k]) : gv[k];
+            o[k] = ga * is * (gz - sums[c + k] * inv_count - sh * sums[C + c + k] * inv_count);
+        }
+        reinterpret_cast<f32x4*>(gs)[idx] = o;
+    }
+}
+
+extern "C" int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, const float* sums, double count, float* gs,
+                                long ncell, int C, int gelu, void* stream) {
+    RPB_REQUIRE(s && gy && mean && invstd && gamma && beta && sums && gs && C % 4 == 0, "bn_bwd_apply: bad arguments");
+    const long n4 = ncell * (C / 4);
+    const float ic = (float)(1.0 / count);
+    if (gelu)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(pw_grid(n4)), dim3(PW_THREADS), 0, (hipStream_t)stream, s, gy,
+                           mean, invstd, gamma, beta, sums, ic, gs, n4, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(pw_grid(n4)), dim3(PW_THREADS), 0, (hipStream_t)stream, s,
+                           gy, mean, invstd, gamma, beta, sums, ic, gs, n4, C);
+    RPB_CHECK_LAUNCH("bn_bwd_apply");
+}
+
+// ---------------------------------------------------------------------------------- MSE (metrics.py:11-13 + .mean())
+// elem = (pred-target)^2 (optional), gout = 2*(pred-target)*gscale, part[block] = sum elem
+__global__ __launch_bounds__(PW_THREADS) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                         float* __restrict__ elem, float* __restrict__ gout,
+                                                         float* __restrict__ part, long n, float gscale) {
+    __shared__ float red[PW_THREADS / 64];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - tgt[i];
+        const float e = d * d;
+        if (elem) elem[i] = e;
+        if (gout) gout[i] = 2.f * d * gscale;
+        acc += e;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < PW_THREADS / 64; ++k) t += red[k];
+        part[blockIdx.x] = t;
+    }
+}
+
+extern "C" int rpb_mse_rows() { return rpb_num_cus() * 4; }
+
+extern "C" int rpb_mse(const float* pred, const float* tgt, float* elem, float* gout, float* part, long n, float gscale,
+                       void* stream) {
+    RPB_REQUIRE(pred && tgt && part && n > 0, "mse: bad arguments");
+    hipLaunchKernelGGL(mse_kernel, dim3(rpb_mse_rows()), dim3(PW_THREADS), 0, (hipStream_t)stream, pred, tgt, elem, gout,
+                       part, n, gscale);
+    RPB_CHECK_LAUNCH("mse");
+}
+
+// ---------------------------------------------------------------------------------- K8 Adam
+// torch.optim.Adam defaults (train.py:290): complex parameters are updated as 2x fp32 (view_as_real).
+// lr / bias corrections are host scalars computed from the step count (no device sync, no .item()).
+__global__ __launch_bounds__(PW_THREADS) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long n,
+                                                          float gscale, float b1, float b2, float eps, float step_size,
+                                                          float inv_sqrt_bc2) {
+    const long n4 = n >> 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[idx];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[idx];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[idx];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[idx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gv[k] * gscale;
+            mv[k] = b1 * mv[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+            pv[k] -= step_size * (mv[k] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[idx] = pv;
+        reinterpret_cast<f32x4*>(m)[idx] = mv;
+        reinterpret_cast<f32x4*>(v)[idx] = vv;
+    }
+    // tail
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gk = g[i] * gscale;
+        const float mk = b1 * m[i] + (1.f - b1) * gk;
+        const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk;
+        v[i] = vk;
+        p[i] -= step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+    }
+}
+
+extern "C" int rpb_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, long step, float gscale, void* stream) {
+    RPB_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float isb2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(pw_grid((n + 3) / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, p, g, m, v, n,
+                       gscale, beta1, beta2, eps, step_size, isb2);
+    RPB_CHECK_LAUNCH("adam_step");
+}
+
+// ---------------------------------------------------------------------------------- K9 rollout affine
+// eval.py:316-318 between two autoregressive steps, with data_normalizer.py:50-62 arithmetic kept in the
+// reference's order:  t = p*std_t + mean_t ; [cat control channels] ; out = (t - mean_i)/std_i
+__global__ __launch_bounds__(PW_THREADS) void rollout_affine_kernel(const float* __restrict__ pred,
+                                                                    const float* __restrict__ para,
+                                                                    float* __restrict__ out, long ncell, int Cp, int Cx,
+                                                                    const float* __restrict__ mean_t,
+                                                                    const float* __restrict__ std_t,
+                                                                    const float* __restrict__ mean_i,
+                                                                    const float* __restrict__ std_i) {
+    const int Ct = Cp + Cx;
+    const long n = ncell * Ct;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long cell = i / Ct;
+        const int c = (int)(i - cell * Ct);
+        float t;
+        if (c < Cp) {
+            t = pred[cell * Cp + c];
+            if (mean_t) t = t * std_t[c] + mean_t[c];
+        } else {
+            t = para[cell * Cx + (c - Cp)];
+        }
+        out[i] = mean_i ? (t - mean_i[c]) / std_i[c] : t;
+    }
+}
+
+extern "C" int rpb_rollout_affine(const float* pred, const float* para, float* out, long ncell, int Cp, int Cx,
+                                  const float* mean_t, const float* std_t, const float* mean_i, const float* std_i,
+                                  void* stream) {
+    RPB_REQUIRE(pred && out && ncell > 0 && Cp > 0 && Cx >= 0, "rollout_affine: bad arguments");
+    RPB_REQUIRE(Cx == 0 || para, "rollout_affine: control channels requested without a source");
+    RPB_REQUIRE((mean_t == nullptr) == (std_t == nullptr) && (mean_i == nullptr) == (std_i == nullptr),
+                "rollout_affine: mean/std must come in pairs");
+    hipLaunchKernelGGL(rollout_affine_kernel, dim3(pw_grid(ncell * (Cp + Cx))), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       pred, para, out, ncell, Cp, Cx, mean_t, std_t, mean_i, std_i);
+    RPB_CHECK_LAUNCH("rollout_affine");
+}
+
+// per-channel normalise / denormalise of a channels-last tensor (GaussianNormalizer.preprocess/postprocess)
+__global__ __launch_bounds__(PW_THREADS) void channel_affine_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                    long n, int C, const float* __restrict__ mean,
+                                                                    const float* __restrict__ stdv, int inverse) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        out[i] = inverse ? in[i] * stdv[c] + mean[c] : (in[i] - mean[c]) / stdv[c];
+    }
+}
+extern "C" int rpb_channel_affine(const float* in, float* out, long n, int C, const float* mean, const float* stdv,
+                                  int inverse, void* stream) {
+    RPB_REQUIRE(in && out && mean && stdv && n > 0 && C > 0, "channel_affine: bad arguments");
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(pw_grid(n)), dim3(PW_THREADS), 0, (hipStream_t)stream, in, out, n, C,
+                       mean, stdv, inverse);
+    RPB_CHECK_LAUNCH("channel_affine");
+}
