@@ -69,8 +69,9 @@ int rpb_cell_wgrad(const float* gs, const float* x, float* part, long ncell, int
                    int W, int Tp, int Hp, int Wp, void* stream);
 
 /* K6  BatchNorm3d (+ exact-erf GELU).  fno.py:117-119; training statistics include the padded cells. */
-int rpb_reduce_partials(const float* part, long rows, long L, float* out_f32, double* out_f64, double scale,
-                        int accumulate, void* stream);
+/*     out[j] (+)= scale * sum_r part[r*row_stride + j], j < L, accumulated in fp64 (deterministic, no atomics). */
+int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, float* out_f32, double* out_f64,
+                        double scale, int accumulate, void* stream);
 int rpb_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, int C, void* stream);
 int rpb_bn_eval_prep(const float* running_var, float eps, float* invstd, int C, void* stream);

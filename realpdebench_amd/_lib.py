@@ -27,7 +27,7 @@ SIGNATURES = {
     "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "p"),
     "rpb_cell_wgrad_slots": (_L, "lii"),
     "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "p"),
-    "rpb_reduce_partials": (_I, "p" + "ll" + "pp" + "d" + "i" + "p"),
+    "rpb_reduce_partials": (_I, "p" + "lll" + "pp" + "d" + "i" + "p"),
     "rpb_bn_finalize": (_I, "p" + "d" + "ff" + "pppp" + "i" + "p"),
     "rpb_bn_eval_prep": (_I, "p" + "f" + "p" + "i" + "p"),
     "rpb_bn_act_fwd": (_I, "pppppp" + "l" + "ii" + "p"),

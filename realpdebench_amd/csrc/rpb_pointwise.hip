@@ -133,17 +133,18 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
 }
 
 // ---------------------------------------------------------------------------------- reducers
-// out[j] (+)= scale * sum_r part[r][j]   (fp64 accumulation)
+// out[j] (+)= scale * sum_r part[r*row_stride + j], j < L   (fp64 accumulation)
 __global__ __launch_bounds__(PW_THREADS) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
-                                                                     float* __restrict__ outf, double* __restrict__ outd,
-                                                                     double scale, int accumulate) {
+                                                                     long row_stride, float* __restrict__ outf,
+                                                                     double* __restrict__ outd, double scale,
+                                                                     int accumulate) {
     // block handles 64 columns; 4 row-groups
     __shared__ double red[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 64 + cl;
     double s = 0.0;
     if (j < L)
-        for (long r = rg; r < rows; r += 4) s += (double)part[r * L + j];
+        for (long r = rg; r < rows; r += 4) s += (double)part[r * row_stride + j];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && j < L) {
@@ -153,11 +154,11 @@ __global__ __launch_bounds__(PW_THREADS) void reduce_partials_kernel(const float
     }
 }
 
-extern "C" int rpb_reduce_partials(const float* part, long rows, long L, float* outf, double* outd, double scale,
-                                   int accumulate, void* stream) {
-    RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0, "reduce_partials: bad arguments");
+extern "C" int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, float* outf, double* outd,
+                                   double scale, int accumulate, void* stream) {
+    RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0 && row_stride >= L, "reduce_partials: bad arguments");
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(PW_THREADS), 0, (hipStream_t)stream,
-                       part, rows, L, outf, outd, scale, accumulate);
+                       part, rows, L, row_stride, outf, outd, scale, accumulate);
     RPB_CHECK_LAUNCH("reduce_partials");
 }
 

@@ -1,0 +1,415 @@
+"""FNO3d on MI355X -- drop-in for ``realpdebench.model.fno.FNO3d`` (reference realpdebench/model/fno.py:66-143).
+
+Same constructor, ``forward(x[B,T,H,W,C_in]) -> [B,T_out,H,W,C_out]``, ``train_loss`` and reference-named
+``state_dict``; everything between input and output runs in the HIP kernels of ``csrc/`` on channels-last
+activations.  Parameters live in ONE flat fp32 arena (``self.flat``) so Adam is a single launch and the
+data-parallel gradient all-reduce is a handful of large contiguous buckets; the spectral weights are kept
+mode-major ``[M][Ci][Co][2]`` (see ``dft.py``) and converted from / to the reference's four complex corner
+tensors only in ``state_dict`` / ``load_state_dict``.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..dft import SpectralPlan, mode_major_to_ref_weights, ref_weights_to_mode_major
+from .model import Model
+
+HID = 128              # fc1 width, fno.py:103
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+_ALIGN = 64            # floats: every parameter segment starts on a 256 B boundary
+
+
+class _Workspace:
+    """Device buffers for one (batch, mode) configuration; allocated once and reused every step."""
+
+    def __init__(self, model, B, training, device):
+        d = ops.Dims(B, *model.shape_in[:3], model.dim_in, model.width, model.padding)
+        self.d, self.training = d, training
+        C, L, plan = model.width, model.n_layers, model.plan
+        f = dict(device=device, dtype=torch.float32)
+        n_act = L + 1 if training else 2
+        self.A = [torch.empty(d.ncell, C, **f) for _ in range(n_act)]       # layer inputs / outputs
+        self.S = [torch.empty(d.ncell, C, **f) for _ in range(L if training else 1)]   # pre-BN
+        G1, N1 = B * d.Tp * d.Hp, 2 * plan.KW * C
+        self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
+        self.Y2 = torch.empty(B * d.Tp * 2 * plan.KH * plan.KW * C, **f)     # after H stage
+        self.Xh = [torch.empty(B * 2 * plan.M * C, **f) for _ in range(L if training else 1)]
+        self.Yh = torch.empty(B * 2 * plan.M * C, **f)
+        self.mean = torch.empty(L, C, **f)
+        self.invstd = torch.empty(L, C, **f)
+        self.stat_rows = ops.cell_mix_stat_rows(d.ncell, C, C, 2 * plan.KW, d.Wp, True)
+        self.stat_part = torch.empty(self.stat_rows * 2 * C, **f) if training else None
+        self.sums64 = torch.empty(2 * C, device=device, dtype=torch.float64)
+        self.out = torch.empty(d.ncrop, model.dim_out, **f)
+        if training:
+            self.G = [torch.empty(d.ncell, C, **f) for _ in range(2)]
+            self.gu = torch.empty(d.ncrop, HID, **f)
+            self.bn_rows = ops.bn_bwd_rows()
+            self.bn_part = torch.empty(self.bn_rows * 2 * C, **f)
+            self.bn_sums = torch.empty(2 * C, **f)
+            self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
+            self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
+            self.wg_rows_c = ops.cell_wgrad_slots(d.ncell, C, C)
+            self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
+            self.wg_part = torch.empty(max(self.wg_rows_c * (C * C + C), self.wg_rows_p * (HID * C + HID)), **f)
+            self.lift_rows = ops._lib.query("rpb_lift_bwd_rows")
+            F = model.dim_in + 3
+            self.lift_part = torch.empty(self.lift_rows * (C * F + C), **f)
+            self.tmp_b = torch.empty(HID, **f)
+            self.gout = torch.empty(d.ncrop, model.dim_out, **f)
+            self.mse_part = torch.empty(ops.mse_rows(), **f)
+            self.loss = torch.zeros(1, **f)
+
+
+class _FNO3dFunction(torch.autograd.Function):
+    """Autograd glue: forward / backward are single calls into the HIP pipeline (tensors are storage only)."""
+
+    @staticmethod
+    def forward(ctx, x, flat, model):
+        ws = model._workspace(x.shape[0], True, x.device)
+        out = model._forward_impl(x, ws, training=True)
+        ctx.model, ctx.ws, ctx.x = model, ws, x
+        return model._shape_output(out.clone(), x.shape[0])
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, ws = ctx.model, ctx.ws
+        g = model._unshape_grad(gout.contiguous(), ctx.x.shape[0])
+        gflat = torch.zeros_like(model.flat)
+        model._backward_impl(ctx.x, g, ws, gflat)
+        return None, gflat, None
+
+
+class FNO3d(Model):
+    def __init__(self, modes1, modes2, modes3, n_layers, width, shape_in, shape_out):
+        super().__init__()
+        self.modes1, self.modes2, self.modes3 = modes1, modes2, modes3
+        self.modes = (modes1, modes2, modes3)
+        self.width = width
+        self.n_layers = n_layers
+        self.shape_in = tuple(int(v) for v in shape_in)
+        self.shape_out = tuple(int(v) for v in shape_out)
+        self.dim_in = self.shape_in[-1]
+        self.r = self.shape_out[0] // self.shape_in[0]
+        self.dim_out = self.shape_out[-1] * self.r            # C_out * T_out / T_in, fno.py:86
+        self.padding = 6                                       # fno.py:87
+        if width % 32 != 0 or width > 128:
+            raise ValueError(f"MI355X FNO3d kernels need width in (32, 64, 96?, 128) multiples of 32, got {width}")
+        T, H, W = self.shape_in[:3]
+        self.plan = SpectralPlan(T + 6, H + 6, W + 6, self.modes)
+        M, C, F = self.plan.M, width, self.dim_in + 3
+
+        # ---- flat parameter arena
+        self._seg = OrderedDict()
+        off = 0
+
+        def seg(name, *shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            self._seg[name] = (off, n, tuple(shape))
+            off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+        seg("fc0.weight", C, F)
+        seg("fc0.bias", C)
+        for l in range(n_layers):
+            seg(f"spec.{l}", M, C, C, 2)
+            seg(f"convs.{l}.weight", C, C)
+            seg(f"convs.{l}.bias", C)
+            seg(f"bns.{l}.weight", C)
+            seg(f"bns.{l}.bias", C)
+        seg("fc1.weight", HID, C)
+        seg("fc1.bias", HID)
+        seg("fc2.weight", self.dim_out, HID)
+        seg("fc2.bias", self.dim_out)
+        self.flat = nn.Parameter(torch.zeros(off))
+        self.register_buffer("bn_running_mean", torch.zeros(n_layers, C))
+        self.register_buffer("bn_running_var", torch.ones(n_layers, C))
+        self.register_buffer("bn_num_batches_tracked", torch.zeros(n_layers, dtype=torch.long))
+        self.reset_parameters()
+        self._ws = {}
+        self._dev_cache = None
+        self.dp = None            # set by realpdebench_amd.dp.DataParallel (RCCL)
+
+    # ------------------------------------------------------------------ parameters
+    def reset_parameters(self):
+        """Same init family as the reference: nn.Linear / nn.Conv3d defaults, ``scale * U[0,1)`` spectral
+        weights (fno.py:30-38), BatchNorm weight 1 / bias 0."""
+        C = self.width
+        with torch.no_grad():
+            def uni(name, fan_in):
+                b = 1.0 / math.sqrt(fan_in)
+                self.pview(name).uniform_(-b, b)
+
+            uni("fc0.weight", self.dim_in + 3)
+            uni("fc0.bias", self.dim_in + 3)
+            scale = 1.0 / (C * C)
+            for l in range(self.n_layers):
+                self.pview(f"spec.{l}").uniform_(0, 1).mul_(scale)
+                uni(f"convs.{l}.weight", C)
+                uni(f"convs.{l}.bias", C)
+                self.pview(f"bns.{l}.weight").fill_(1.0)
+                self.pview(f"bns.{l}.bias").zero_()
+            uni("fc1.weight", C)
+            uni("fc1.bias", C)
+            uni("fc2.weight", HID)
+            uni("fc2.bias", HID)
+
+    def pview(self, name, flat=None):
+        off, n, shape = self._seg[name]
+        base = self.flat.data if flat is None else flat
+        return base[off:off + n].view(shape)
+
+    # ------------------------------------------------------------------ reference-compatible state dict
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = OrderedDict() if destination is None else destination
+        C = self.width
+        v = lambda n: self.pview(n).detach().clone()
+        sd[prefix + "fc0.weight"] = v("fc0.weight")
+        sd[prefix + "fc0.bias"] = v("fc0.bias")
+        for l in range(self.n_layers):
+            ws = mode_major_to_ref_weights(self.pview(f"spec.{l}").detach(), self.modes)
+            for k, w in enumerate(ws, start=1):
+                sd[prefix + f"spectral_convs.{l}.weights{k}"] = w
+        for l in range(self.n_layers):
+            sd[prefix + f"convs.{l}.weight"] = v(f"convs.{l}.weight").view(C, C, 1, 1, 1)
+            sd[prefix + f"convs.{l}.bias"] = v(f"convs.{l}.bias")
+        for l in range(self.n_layers):
+            sd[prefix + f"bns.{l}.weight"] = v(f"bns.{l}.weight")
+            sd[prefix + f"bns.{l}.bias"] = v(f"bns.{l}.bias")
+            sd[prefix + f"bns.{l}.running_mean"] = self.bn_running_mean[l].detach().clone()
+            sd[prefix + f"bns.{l}.running_var"] = self.bn_running_var[l].detach().clone()
+            sd[prefix + f"bns.{l}.num_batches_tracked"] = self.bn_num_batches_tracked[l].detach().clone()
+        for n in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            sd[prefix + n] = v(n)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        expected = set(self.state_dict().keys())
+        missing = expected - set(state_dict.keys())
+        unexpected = set(state_dict.keys()) - expected
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for FNO3d: missing {sorted(missing)}, "
+                               f"unexpected {sorted(unexpected)}")
+        dev = self.flat.device
+        with torch.no_grad():
+            def put(name, src):
+                dst = self.pview(name)
+                src = torch.as_tensor(src).to(dev)
+                if src.numel() != dst.numel():
+                    raise RuntimeError(f"size mismatch for {name}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                dst.copy_(src.reshape(dst.shape))
+
+            for n in ("fc0.weight", "fc0.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+                if n in state_dict:
+                    put(n, state_dict[n])
+            for l in range(self.n_layers):
+                keys = [f"spectral_convs.{l}.weights{k}" for k in (1, 2, 3, 4)]
+                if all(k in state_dict for k in keys):
+                    ws = [torch.as_tensor(state_dict[k]).to(torch.complex64) for k in keys]
+                    put(f"spec.{l}", ref_weights_to_mode_major(*ws))
+                for n in (f"convs.{l}.weight", f"convs.{l}.bias", f"bns.{l}.weight", f"bns.{l}.bias"):
+                    if n in state_dict:
+                        put(n, state_dict[n])
+                if f"bns.{l}.running_mean" in state_dict:
+                    self.bn_running_mean[l].copy_(torch.as_tensor(state_dict[f"bns.{l}.running_mean"]))
+                if f"bns.{l}.running_var" in state_dict:
+                    self.bn_running_var[l].copy_(torch.as_tensor(state_dict[f"bns.{l}.running_var"]))
+                if f"bns.{l}.num_batches_tracked" in state_dict:
+                    self.bn_num_batches_tracked[l] = int(state_dict[f"bns.{l}.num_batches_tracked"])
+        return torch.nn.modules.module._IncompatibleKeys(sorted(missing), sorted(unexpected))
+
+    def grads_as_state_dict(self, gflat):
+        """Flat gradient arena -> ``{reference parameter name: gradient}`` (complex for the spectral weights,
+        matching what autograd leaves in ``p.grad`` of the reference model)."""
+        C = self.width
+        out = OrderedDict()
+        g = lambda n: self.pview(n, gflat).detach().clone()
+        for n in ("fc0.weight", "fc0.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"):
+            out[n] = g(n)
+        for l in range(self.n_layers):
+            for k, w in enumerate(mode_major_to_ref_weights(self.pview(f"spec.{l}", gflat).detach(), self.modes), 1):
+                out[f"spectral_convs.{l}.weights{k}"] = w
+            out[f"convs.{l}.weight"] = g(f"convs.{l}.weight").view(C, C, 1, 1, 1)
+            for n in (f"convs.{l}.bias", f"bns.{l}.weight", f"bns.{l}.bias"):
+                out[n] = g(n)
+        return out
+
+    # ------------------------------------------------------------------ device-side constants
+    def _consts(self, device):
+        if self._dev_cache is None or self._dev_cache[0] != device:
+            T, H, W = self.shape_in[:3]
+            grids = tuple(torch.tensor(np.linspace(0, 1, n), dtype=torch.float).to(device) for n in (T, H, W))
+            plan = SpectralPlan(T + 6, H + 6, W + 6, self.modes, device=device)     # fno.py:135-143 grid in f64->f32
+            self._dev_cache = (device, grids, plan)
+            self._ws = {}
+        return self._dev_cache[1], self._dev_cache[2]
+
+    def _workspace(self, B, training, device):
+        key = (B, training, str(device))
+        if key not in self._ws:
+            self._consts(device)
+            self._ws[key] = _Workspace(self, B, training, device)
+        return self._ws[key]
+
+    # ------------------------------------------------------------------ spectral stages
+    def _spectral_forward_stages(self, x, ws, xh, mats, first_layer):
+        """x [cells][C] -> truncated spectrum xh [B][2][M][C] with stage matrices ``mats`` = (W, H, T)."""
+        d, p, C = ws.d, self.plan, self.width
+        m3, KH, KT = p.KW, p.KH, p.KT
+        MW, MH, MT = mats
+        N2, N3 = m3 * C, KH * m3 * C
+        ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
+                      k_valid=d.W if first_layer else None)
+        ops.axis_gemm(ws.Y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
+                      k_valid=2 * d.H if first_layer else None)
+        ops.axis_gemm(ws.Y2, xh, MT, d.B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3,
+                      k_valid=2 * d.T if first_layer else None)
+
+    def _spectral_inverse_stages(self, yh, ws, mats):
+        """yh [B][2][M][C] -> ws.Y1 = rows [B*Tp*Hp][2*m3][C] ready for the fused last stage (cell_mix)."""
+        d, p, C = ws.d, self.plan, self.width
+        m3, KH, KT = p.KW, p.KH, p.KT
+        MT, MH = mats
+        N2, N3 = m3 * C, KH * m3 * C
+        ops.axis_gemm(yh, ws.Y2, MT, d.B, 2 * KT, 2 * d.Tp, N3, 2 * KT * N3, N3, 2 * d.Tp * N3, N3)
+        ops.axis_gemm(ws.Y2, ws.Y1, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
+
+    # ------------------------------------------------------------------ forward / backward pipelines
+    def _forward_impl(self, x, ws, training):
+        d, C, L = ws.d, self.width, self.n_layers
+        grids, plan = self._consts(x.device)
+        P = self.pview
+        ops.lift_pad_fwd(x, grids, P("fc0.weight"), P("fc0.bias"), ws.A[0], d)
+        world = self.dp.world_size if (self.dp is not None and training) else 1
+        for l in range(L):
+            a_in = ws.A[l] if training else ws.A[l % 2]
+            a_out = ws.A[l + 1] if training else ws.A[(l + 1) % 2]
+            s = ws.S[l] if training else ws.S[0]
+            xh = ws.Xh[l] if training else ws.Xh[0]
+            self._spectral_forward_stages(a_in, ws, xh, (plan.FW, plan.FH, plan.FT), first_layer=(l == 0))
+            ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
+            self._spectral_inverse_stages(ws.Yh, ws, (plan.GT, plan.GH))
+            ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GW, s,
+                         ws.stat_part if training else None, d.ncell, C, C, 2 * plan.KW, d.Wp)
+            if training:
+                ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
+                if world > 1:
+                    self.dp.all_reduce_sum(ws.sums64)
+                ops.bn_finalize(ws.sums64, float(d.ncell) * world, BN_EPS, BN_MOMENTUM, ws.mean[l], ws.invstd[l],
+                                self.bn_running_mean[l], self.bn_running_var[l], C)
+                self.bn_num_batches_tracked[l] += 1
+                mean, invstd = ws.mean[l], ws.invstd[l]
+            else:
+                ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
+                mean, invstd = self.bn_running_mean[l], ws.invstd[l]
+            ops.bn_act_fwd(s, mean, invstd, P(f"bns.{l}.weight"), P(f"bns.{l}.bias"), a_out, d.ncell, C,
+                           gelu=(l < L - 1))                                      # fno.py:117-119
+        a_last = ws.A[L] if training else ws.A[L % 2]
+        ops.proj_fwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out)
+        return ws.out
+
+    def _backward_impl(self, x, gout, ws, gflat):
+        """gout [ncrop][DO] = dLoss/d(fc2 output); writes every parameter gradient into ``gflat``."""
+        d, C, L, DO = ws.d, self.width, self.n_layers, self.dim_out
+        grids, plan = self._consts(x.device)
+        P = self.pview
+        GP = lambda n: self.pview(n, gflat)
+        world = self.dp.world_size if self.dp is not None else 1
+        # ---- projection
+        ops.proj_bwd(ws.A[L], P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
+                     ws.proj_part, d, DO)
+        row = DO * HID + HID + DO
+        part = ws.proj_part.view(ws.proj_rows, row)
+        # partial row layout: [d fc2.weight | d fc1.bias | d fc2.bias]; the three segments are reduced separately
+        self._reduce_cols(part, 0, DO * HID, GP("fc2.weight"))
+        self._reduce_cols(part, DO * HID, HID, GP("fc1.bias"))
+        self._reduce_cols(part, DO * HID + HID, DO, GP("fc2.bias"))
+        ops.cell_wgrad(ws.gu, ws.A[L], ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6)
+        partp = ws.wg_part[:ws.wg_rows_p * (HID * C + HID)].view(ws.wg_rows_p, HID * C + HID)
+        self._reduce_cols(partp, 0, HID * C, GP("fc1.weight"))
+        g, g2 = ws.G
+        ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, None, d.ncell, HID, C, 0, 1, transpose_w=True,
+                     gather=True, crop6=d.crop6)
+        # ---- Fourier layers, last to first
+        for l in range(L - 1, -1, -1):
+            gelu = l < L - 1
+            gam, bet = P(f"bns.{l}.weight"), P(f"bns.{l}.bias")
+            ops.bn_bwd_reduce(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_part, d.ncell, C, gelu)
+            ops.reduce_partials(ws.bn_part, ws.bn_rows, 2 * C, out_f32=ws.bn_sums)
+            GP(f"bns.{l}.bias").copy_(ws.bn_sums[:C])          # local sums are this rank's d beta / d gamma
+            GP(f"bns.{l}.weight").copy_(ws.bn_sums[C:])
+            if world > 1:
+                self.dp.all_reduce_sum(ws.bn_sums)
+            ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world, g,
+                             d.ncell, C, gelu)
+            # 1x1 conv weight / bias gradient
+            ops.cell_wgrad(g, ws.A[l], ws.wg_part, d.ncell, C, C)
+            partc = ws.wg_part[:ws.wg_rows_c * (C * C + C)].view(ws.wg_rows_c, C * C + C)
+            self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
+            self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
+            # spectral branch: G^ = adjoint of the inverse stages applied to gs
+            self._spectral_forward_stages(g, ws, ws.Yh, (plan.GWt, plan.GHt, plan.GTt), first_layer=False)
+            ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
+            gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
+            ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
+            self._spectral_inverse_stages(gxh, ws, (plan.FTt, plan.FHt))
+            ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FWt, g2, None, d.ncell, C, C, 2 * plan.KW,
+                         d.Wp, transpose_w=True)
+            g, g2 = g2, g
+        # ---- lift
+        ops.lift_bwd(g, x, grids, ws.lift_part, d)
+        F = self.dim_in + 3
+        partl = ws.lift_part.view(ws.lift_rows, C * F + C)
+        self._reduce_cols(partl, 0, C * F, GP("fc0.weight"))
+        self._reduce_cols(partl, C * F, C, GP("fc0.bias"))
+
+    @staticmethod
+    def _reduce_cols(part2d, col0, ncols, out):
+        """out[:] = sum over rows of part2d[:, col0:col0+ncols]  (fp64 accumulate, HIP kernel)."""
+        rows, L = part2d.shape
+        ops.reduce_partials(part2d, rows, ncols, out_f32=out.view(-1), row_stride=L, col0=col0)
+
+    # ------------------------------------------------------------------ output reshape (fno.py:127-128)
+    def _shape_output(self, out, B):
+        T, H, W = self.shape_in[:3]
+        Co = self.shape_out[-1]
+        if self.r == 1:
+            return out.view(B, T, H, W, Co)
+        return out.view(B, T, H, W, Co, self.r).permute(0, 1, 5, 2, 3, 4).reshape(B, *self.shape_out)
+
+    def _unshape_grad(self, g, B):
+        T, H, W = self.shape_in[:3]
+        Co = self.shape_out[-1]
+        if self.r == 1:
+            return g.reshape(B * T * H * W, Co)
+        return g.view(B, T, self.r, H, W, Co).permute(0, 1, 3, 4, 5, 2).reshape(B * T * H * W, Co * self.r).contiguous()
+
+    # ------------------------------------------------------------------ Model protocol
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("realpdebench_amd.FNO3d runs on MI355X only: move the model and inputs to 'cuda' "
+                               "(there is no CPU fallback)")
+        if tuple(x.shape[1:]) != self.shape_in:
+            raise ValueError(f"expected input [B,{','.join(map(str, self.shape_in))}], got {tuple(x.shape)}")
+        return x.contiguous().float()
+
+    def forward(self, x):
+        x = self._check_input(x)
+        if torch.is_grad_enabled() and self.flat.requires_grad:
+            if not self.training:
+                raise NotImplementedError("gradients through eval-mode BatchNorm are not implemented; wrap "
+                                          "evaluation in torch.no_grad() as the reference does (train.py:345-361)")
+            return _FNO3dFunction.apply(x, self.flat, self)
+        ws = self._workspace(x.shape[0], self.training, x.device)
+        out = self._forward_impl(x, ws, training=self.training)
+        return self._shape_output(out.clone(), x.shape[0])
+
+    def train_loss(self, input, target):
+        """fno.py:131-133: elementwise ``mse_loss(pred, target)`` (callers take ``.mean()``)."""
+        pred = self.forward(input)
+        return (pred - target) ** 2

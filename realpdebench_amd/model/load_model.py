@@ -1,0 +1,26 @@
+"""Model registry with the reference's signature (realpdebench/model/load_model.py:4):
+``load_model(train_dataset, device='cpu', **kwargs)`` reads ``train_dataset[0]`` for the shapes and
+switches on ``kwargs['model_name']``.  Only the MI355X-native hot-path models are registered."""
+import logging
+
+
+def load_model(train_dataset, device="cpu", **kwargs):
+    model_name = kwargs["model_name"]
+    input, target = train_dataset[0]        # T, S, S, C   (load_model.py:7-9)
+    input_shape = tuple(input.shape)
+    output_shape = tuple(target.shape)
+    logging.info(f"Loading model {model_name} with input shape {input_shape} and output shape {output_shape}")
+    if model_name == "fno":
+        from .fno import FNO3d
+        model = FNO3d(
+            modes1=kwargs["modes1"],
+            modes2=kwargs["modes2"],
+            modes3=kwargs["modes3"],
+            n_layers=kwargs["n_layers"],
+            width=kwargs["width"],
+            shape_in=input_shape,
+            shape_out=output_shape,
+        ).to(device)
+    else:
+        raise ValueError(f"Model {model_name} not supported by the MI355X backend (supported: fno)")
+    return model

@@ -1,0 +1,152 @@
+"""Thin tensor-level wrappers over the C ABI (``include/rpb.h``).
+
+PyTorch-ROCm tensors are storage only: every wrapper checks device / dtype / contiguity, passes raw
+``data_ptr()``s plus the current HIP stream, and raises on any error.  No wrapper has a non-HIP path.
+"""
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=F32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.RpbError("realpdebench_amd ops need tensors on a HIP device (no CPU fallback exists)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.RpbError(f"expected contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+class Dims:
+    """Shape bundle of one FNO3d problem: unpadded (T,H,W), padded (Tp,Hp,Wp), channels."""
+
+    def __init__(self, B, T, H, W, Cin, C, pad):
+        self.B, self.T, self.H, self.W, self.Cin, self.C = B, T, H, W, Cin, C
+        self.Tp, self.Hp, self.Wp = T + pad, H + pad, W + pad
+        self.ncell = B * self.Tp * self.Hp * self.Wp
+        self.ncrop = B * T * H * W
+
+    @property
+    def crop6(self):
+        return (self.T, self.H, self.W, self.Tp, self.Hp, self.Wp)
+
+
+def lift_pad_fwd(x, grids, w0, b0, out, d):
+    _lib.call("rpb_lift_pad_fwd", _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(w0), _p(b0), _p(out),
+              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream())
+
+
+def lift_bwd(g, x, grids, part, d):
+    _lib.call("rpb_lift_bwd", _p(g), _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(part),
+              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream())
+
+
+def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False):
+    assert tuple(M.shape) == (O, K), (M.shape, O, K)
+    _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o,
+              K if k_valid is None else k_valid, int(accumulate), _stream())
+
+
+def mode_contract_fwd(X, W, Y, B, M, C):
+    _lib.call("rpb_mode_contract_fwd", _p(X), _p(W), _p(Y), B, M, C, _stream())
+
+
+def mode_contract_dgrad(GY, W, GX, B, M, C):
+    _lib.call("rpb_mode_contract_dgrad", _p(GY), _p(W), _p(GX), B, M, C, _stream())
+
+
+def mode_contract_wgrad(X, GY, GW, B, M, C, accumulate=False):
+    _lib.call("rpb_mode_contract_wgrad", _p(X), _p(GY), _p(GW), B, M, C, int(accumulate), _stream())
+
+
+def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec):
+    return _lib.query("rpb_cell_mix_stat_rows", ncell, KC, CO, K2, Wp, int(has_spec))
+
+
+def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
+             crop6=(0, 0, 0, 1, 1, 1)):
+    _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
+              int(transpose_w), int(gather), *crop6, _stream())
+
+
+def cell_wgrad_slots(ncell, CO, CI):
+    return _lib.query("rpb_cell_wgrad_slots", ncell, CO, CI)
+
+
+def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1)):
+    _lib.call("rpb_cell_wgrad", _p(gs), _p(x), _p(part), ncell, CO, CI, int(crop), *crop6, _stream())
+
+
+def reduce_partials(part, rows, L, out_f32=None, out_f64=None, scale=1.0, accumulate=False, row_stride=None,
+                    col0=0):
+    """out[j] (+)= scale * sum_r part[r*row_stride + col0 + j] for j < L."""
+    _lib.call("rpb_reduce_partials", _p(part) + 4 * col0, rows, L, L if row_stride is None else row_stride,
+              _p(out_f32), _p(out_f64, torch.float64), float(scale), int(accumulate), _stream())
+
+
+def bn_finalize(sums, count, eps, momentum, mean, invstd, rmean, rvar, C):
+    _lib.call("rpb_bn_finalize", _p(sums, torch.float64), float(count), eps, momentum, _p(mean), _p(invstd), _p(rmean),
+              _p(rvar), C, _stream())
+
+
+def bn_eval_prep(rvar, eps, invstd, C):
+    _lib.call("rpb_bn_eval_prep", _p(rvar), eps, _p(invstd), C, _stream())
+
+
+def bn_act_fwd(s, mean, invstd, gamma, beta, y, ncell, C, gelu):
+    _lib.call("rpb_bn_act_fwd", _p(s), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), ncell, C, int(gelu), _stream())
+
+
+def bn_bwd_rows():
+    return _lib.query("rpb_bn_bwd_rows")
+
+
+def bn_bwd_reduce(s, gy, mean, invstd, gamma, beta, part, ncell, C, gelu):
+    _lib.call("rpb_bn_bwd_reduce", _p(s), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(part), ncell, C,
+              int(gelu), _stream())
+
+
+def bn_bwd_apply(s, gy, mean, invstd, gamma, beta, sums, count, gs, ncell, C, gelu):
+    _lib.call("rpb_bn_bwd_apply", _p(s), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums), float(count),
+              _p(gs), ncell, C, int(gelu), _stream())
+
+
+def proj_slots(ncrop, C, DO):
+    return _lib.query("rpb_proj_slots", ncrop, C, DO)
+
+
+def proj_fwd(a, w1, b1, w2, b2, out, d, DO):
+    _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, _stream())
+
+
+def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO):
+    _lib.call("rpb_proj_bwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(gout), _p(gu), _p(part), d.ncrop, d.C, DO,
+              *d.crop6, _stream())
+
+
+def mse_rows():
+    return _lib.query("rpb_mse_rows")
+
+
+def mse(pred, target, elem, gout, part, n, gscale):
+    _lib.call("rpb_mse", _p(pred), _p(target), _p(elem), _p(gout), _p(part), n, float(gscale), _stream())
+
+
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale=1.0):
+    _lib.call("rpb_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, step, gscale, _stream())
+
+
+def rollout_affine(pred, para, out, ncell, Cp, Cx, mean_t, std_t, mean_i, std_i):
+    _lib.call("rpb_rollout_affine", _p(pred), _p(para), _p(out), ncell, Cp, Cx, _p(mean_t), _p(std_t), _p(mean_i),
+              _p(std_i), _stream())
+
+
+def channel_affine(inp, out, n, C, mean, std, inverse):
+    _lib.call("rpb_channel_affine", _p(inp), _p(out), n, C, _p(mean), _p(std), int(inverse), _stream())

@@ -1,0 +1,43 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rpb.h declares."""
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "rpb.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from realpdebench_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rpb.h but not exported by librpb_hip.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in realpdebench_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.rpb_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from realpdebench_amd.model.fno import FNO3d
+    m = FNO3d(2, 3, 3, 1, 32, (4, 8, 8, 2), (4, 8, 8, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 8, 8, 2))
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "realpdebench_amd")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(d, f)).read(), re.M):
+                bad.append(f)
+    assert not bad, bad

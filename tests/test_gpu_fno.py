@@ -1,0 +1,147 @@
+"""End-to-end parity of the MI355X FNO3d path (through the C ABI) against
+  * golden vectors generated from the reference itself (tests/golden/*.npz), and
+  * the CPU oracle on freshly seeded inputs at width 64,
+with the tolerance BASELINE.json states: fp32 Rel-L2 < 1e-5 on outputs (gradients: 5e-5, see per-assert notes).
+"""
+import pytest
+import torch
+
+from conftest import Golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+OUT_TOL = 1e-5
+GRAD_TOL = 5e-5
+
+
+def build(g, sd=None):
+    from realpdebench_amd.model.fno import FNO3d
+    m = FNO3d(*g.modes, g.n_layers, g.width, g.shape_in, g.shape_out)
+    m.load_state_dict(g.sd("sd0") if sd is None else sd)
+    return m.cuda()
+
+
+@pytest.fixture(params=["small_w32", "ctrl_w32"])
+def gold(request):
+    return Golden(request.param)
+
+
+def test_width_8_is_rejected_loudly():
+    from realpdebench_amd.model.fno import FNO3d
+    g = Golden("tiny_w8")
+    with pytest.raises(ValueError):
+        FNO3d(*g.modes, g.n_layers, g.width, g.shape_in, g.shape_out)
+
+
+def test_eval_forward_matches_reference(gold):
+    m = build(gold).eval()
+    with torch.no_grad():
+        out = m(gold.t("x0").cuda())
+    assert out.shape == gold.t("fwd_eval").shape
+    assert rel_l2(out.cpu(), gold.t("fwd_eval")) < OUT_TOL
+
+
+def test_train_forward_loss_grads_match_reference(gold):
+    m = build(gold).train()
+    x, y = gold.t("x0").cuda(), gold.t("y0").cuda()
+    elem = m.train_loss(x, y)                      # drop-in protocol: elementwise loss, caller takes .mean()
+    loss = elem.mean()
+    loss.backward()
+    assert abs(float(loss) - float(gold.z["loss0"])) < 1e-5 * abs(float(gold.z["loss0"]))
+    grads = m.grads_as_state_dict(m.flat.grad)
+    ref = gold.sd("grad0")
+    assert set(grads) == set(ref)
+    for k, gr in ref.items():
+        got = grads[k].cpu()
+        if k.startswith("convs.") and k.endswith(".bias"):
+            assert float((got - gr).abs().max()) < 1e-5, k      # true gradient is 0 (BatchNorm), both sides are noise
+        else:
+            assert rel_l2(got, gr) < GRAD_TOL, k
+    # running statistics were updated like nn.BatchNorm3d does (momentum 0.1, unbiased var)
+    with torch.no_grad():
+        m.eval()
+        sd = m.state_dict()
+    assert int(sd["bns.0.num_batches_tracked"]) == int(gold.sd("sd0")["bns.0.num_batches_tracked"]) + 1
+
+
+def test_two_fused_train_steps_match_reference(gold):
+    from realpdebench_amd.trainer import Trainer
+    m = build(gold)
+    tr = Trainer(m, lr=gold.lr0, num_update=gold.t_max, scheduler="cosine")
+    l0 = tr.step(gold.t("x0").cuda(), gold.t("y0").cuda()).clone()
+    l1 = tr.step(gold.t("x1").cuda(), gold.t("y1").cuda()).clone()
+    assert abs(float(l0) - float(gold.z["loss0"])) < 1e-5 * abs(float(gold.z["loss0"]))
+    assert abs(float(l1) - float(gold.z["loss1"])) < 5e-5 * abs(float(gold.z["loss1"]))
+    sd, ref = m.state_dict(), gold.sd("sd2")
+    for k, v in ref.items():
+        got = sd[k].cpu()
+        if v.dtype == torch.int64:
+            assert int(got) == int(v), k
+        elif k.startswith("convs.") and k.endswith(".bias"):
+            assert float((got - v).abs().max()) <= 2 * 2 * gold.lr0 * 1.01, k      # Adam on zero-gradient noise
+        elif "running_mean" in k:
+            assert rel_l2(got, v) < 5e-3, k
+        else:
+            assert rel_l2(got, v) < 1e-3, k                                         # see tests/test_oracle_golden.py
+
+
+def test_rollout_matches_reference(gold):
+    from realpdebench_amd.data_normalizer import GaussianNormalizer
+    from realpdebench_amd.rollout import autoregressive_rollout
+    m = build(gold)
+    mi, si, mt, st = gold.norm()
+    norm = GaussianNormalizer(mi, mt, si, st, "cuda")
+    raw = gold.t("x1")
+    cin, cout = gold.shape_in[-1], gold.shape_out[-1]
+    para = raw[..., cout:].contiguous() if cin != cout else None
+    x, _ = norm.preprocess(raw, gold.t("y1"))
+    out = autoregressive_rollout(m, x, 3, normalizer=norm, para_input=para)
+    assert rel_l2(out.cpu(), gold.t("rollout3")) < 2e-5       # three chained forwards
+
+
+@pytest.mark.parametrize("width,B", [(64, 2), (128, 1)])
+def test_against_oracle_wider(width, B):
+    """Width 64 / 128 (the reference's configs) vs the CPU oracle on seeded inputs: forward, loss and grads."""
+    from oracle import fno3d_oracle as O
+    from realpdebench_amd.model.fno import FNO3d
+    torch.manual_seed(7)
+    shape = (5, 14, 12, 2)
+    modes, L = (2, 4, 4), 2
+    sd = O.init_state_dict(modes, L, width, shape, shape, seed=3)
+    for l in range(L):
+        sd[f"bns.{l}.weight"] = torch.rand(width) + 0.5
+        sd[f"bns.{l}.bias"] = torch.randn(width) * 0.2
+    x, y = torch.randn(B, *shape), torch.randn(B, *shape)
+    loss, pred, grads, _ = O.loss_and_grads(sd, x, y, modes, L, shape, shape)
+    m = FNO3d(*modes, L, width, shape, shape)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    elem = m.train_loss(x.cuda(), y.cuda())
+    elem.mean().backward()
+    assert abs(float(elem.mean()) - float(loss)) < 1e-5 * float(loss)
+    got = m.grads_as_state_dict(m.flat.grad)
+    for k, gr in grads.items():
+        if k.startswith("convs.") and k.endswith(".bias"):
+            continue
+        assert rel_l2(got[k].cpu(), gr) < GRAD_TOL, k
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    ref, _ = O.fno3d_forward(sd, x, modes, L, shape, shape, training=False)
+    assert rel_l2(out.cpu(), ref) < OUT_TOL
+
+
+def test_state_dict_roundtrip_and_checkpoint(tmp_path, gold):
+    m = build(gold)
+    sd = m.state_dict()
+    ref = gold.sd("sd0")
+    assert list(sd.keys()) == list(ref.keys())             # reference key order and names
+    for k in ref:
+        assert sd[k].dtype == ref[k].dtype and tuple(sd[k].shape) == tuple(ref[k].shape), k
+        assert torch.equal(sd[k].cpu(), ref[k]), k
+    path = tmp_path / "model_0001.pth"
+    torch.save({"model_state_dict": {k: v.cpu() for k, v in sd.items()}, "train_losses": [1.0], "val_losses": {},
+                "iteration": 1, "best_iteration": 1, "best_val_loss": 0.5}, path)
+    m2 = build(gold, sd=gold.sd("sd2"))
+    meta = m2.load_checkpoint(str(path), "cuda")
+    assert meta["iteration"] == 1 and meta["best_val_loss"] == 0.5
+    assert torch.equal(m2.flat.data, m.flat.data)

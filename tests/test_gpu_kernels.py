@@ -1,0 +1,295 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against an fp64 PyTorch-CPU statement of the
+same operator (tolerance: fp32 round-off, Rel-L2 < 2e-6 unless stated)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from realpdebench_amd import ops as o
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return o
+
+
+def dev(t):
+    return t.float().cuda().contiguous()
+
+
+@pytest.mark.parametrize("G,K,O,N,kv", [
+    (5, 134, 32, 64, None), (3, 268, 48, 128, None), (2, 52, 16, 256, None), (2, 16, 52, 96, None),
+    (3, 48, 268, 64, None), (7, 32, 134, 32, None), (4, 7, 5, 32, None), (3, 40, 12, 64, 29), (2, 134, 32, 64, 128),
+])
+def test_axis_gemm(ops, G, K, O, N, kv):
+    torch.manual_seed(G * 1000 + K)
+    M = torch.randn(O, K, dtype=torch.float64)
+    x = torch.randn(G, K, N, dtype=torch.float64)
+    xx = x.clone()
+    if kv is not None:
+        xx[:, kv:] = 0
+    ref = torch.einsum("ok,gkn->gon", M, xx)
+    out = torch.full((G, O, N), float("nan"), device="cuda")
+    ops.axis_gemm(dev(x), out, dev(M), G, K, O, N, K * N, N, O * N, N, k_valid=kv)
+    assert rel_l2(out.cpu(), ref) < TOL
+    # accumulate
+    ops.axis_gemm(dev(x), out, dev(M), G, K, O, N, K * N, N, O * N, N, k_valid=kv, accumulate=True)
+    assert rel_l2(out.cpu(), 2 * ref) < TOL
+
+
+@pytest.mark.parametrize("B,M,C", [(3, 10, 32), (32, 6, 64), (5, 4, 128)])
+def test_mode_contract(ops, B, M, C):
+    torch.manual_seed(B + M + C)
+    X = torch.randn(B, 2, M, C, dtype=torch.float64)
+    W = torch.randn(M, C, C, 2, dtype=torch.float64)
+    G = torch.randn(B, 2, M, C, dtype=torch.float64)
+    xc, gc = torch.complex(X[:, 0], X[:, 1]), torch.complex(G[:, 0], G[:, 1])
+    wc = torch.view_as_complex(W)
+    y = torch.einsum("bmi,mio->bmo", xc, wc)
+    gx = torch.einsum("bmo,mio->bmi", gc, wc.conj())
+    gw = torch.einsum("bmi,bmo->mio", xc.conj(), gc)
+    planar = lambda z: torch.stack([z.real, z.imag], dim=1)
+    Y = torch.empty(B, 2, M, C, device="cuda")
+    ops.mode_contract_fwd(dev(X), dev(W), Y, B, M, C)
+    assert rel_l2(Y.cpu(), planar(y)) < TOL
+    if C <= 64 or B <= 8:
+        GX = torch.empty(B, 2, M, C, device="cuda")
+        ops.mode_contract_dgrad(dev(G), dev(W), GX, B, M, C)
+        assert rel_l2(GX.cpu(), planar(gx)) < TOL
+    GW = torch.empty(M, C, C, 2, device="cuda")
+    ops.mode_contract_wgrad(dev(X), dev(G), GW, B, M, C)
+    assert rel_l2(GW.cpu(), torch.view_as_real(gw)) < TOL
+
+
+@pytest.mark.parametrize("C,Wp,rows,K2", [(32, 18, 11, 8), (64, 134, 5, 32), (128, 22, 7, 6), (64, 13, 9, 7)])
+def test_cell_mix_spectral_conv_stats(ops, C, Wp, rows, K2):
+    torch.manual_seed(C + Wp)
+    ncell = rows * Wp
+    x = torch.randn(ncell, C, dtype=torch.float64)
+    Wc = torch.randn(C, C, dtype=torch.float64) / math.sqrt(C)
+    bias = torch.randn(C, dtype=torch.float64)
+    z2 = torch.randn(rows, K2, C, dtype=torch.float64)
+    GW = torch.randn(Wp, K2, dtype=torch.float64)
+    ref = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + x @ Wc.t() + bias
+    out = torch.empty(ncell, C, device="cuda")
+    nrows = ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True)
+    part = torch.zeros(nrows, 2, C, device="cuda")
+    ops.cell_mix(dev(x), dev(Wc), dev(bias), dev(z2), dev(GW), out, part, ncell, C, C, K2, Wp)
+    assert rel_l2(out.cpu(), ref) < TOL
+    s = part.double().sum(0).cpu()
+    assert rel_l2(s[0], ref.sum(0)) < 1e-5
+    assert rel_l2(s[1], (ref ** 2).sum(0)) < 1e-5
+    # dgrad flavour: transposed weight, no bias, no stats
+    ref2 = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + x @ Wc
+    ops.cell_mix(dev(x), dev(Wc), None, dev(z2), dev(GW), out, None, ncell, C, C, K2, Wp, transpose_w=True)
+    assert rel_l2(out.cpu(), ref2) < TOL
+
+
+def test_cell_mix_gather(ops):
+    torch.manual_seed(3)
+    B, T, H, W, pad, KC, CO = 2, 3, 5, 7, 2, 128, 64
+    Tp, Hp, Wp = T + pad, H + pad, W + pad
+    gu = torch.randn(B, T, H, W, KC, dtype=torch.float64)
+    Wm = torch.randn(KC, CO, dtype=torch.float64)
+    ref = torch.zeros(B, Tp, Hp, Wp, CO, dtype=torch.float64)
+    ref[:, :T, :H, :W] = gu @ Wm
+    out = torch.full((B * Tp * Hp * Wp, CO), float("nan"), device="cuda")
+    ops.cell_mix(dev(gu).view(-1, KC), dev(Wm), None, None, None, out, None, B * Tp * Hp * Wp, KC, CO, 0, 1,
+                 transpose_w=True, gather=True, crop6=(T, H, W, Tp, Hp, Wp))
+    assert rel_l2(out.cpu().view_as(ref), ref) < TOL
+
+
+@pytest.mark.parametrize("CO,CI,ncell", [(64, 64, 1000), (32, 32, 77), (128, 64, 650), (128, 128, 300), (64, 32, 33)])
+def test_cell_wgrad(ops, CO, CI, ncell):
+    torch.manual_seed(CO + CI)
+    gs = torch.randn(ncell, CO, dtype=torch.float64)
+    x = torch.randn(ncell, CI, dtype=torch.float64)
+    slots = ops.cell_wgrad_slots(ncell, CO, CI)
+    part = torch.full((slots, CO * CI + CO), float("nan"), device="cuda")
+    ops.cell_wgrad(dev(gs), dev(x), part, ncell, CO, CI)
+    got = part.double().sum(0).cpu()
+    assert rel_l2(got[:CO * CI].view(CO, CI), gs.t() @ x) < TOL
+    assert rel_l2(got[CO * CI:], gs.sum(0)) < TOL
+
+
+def test_cell_wgrad_crop(ops):
+    torch.manual_seed(5)
+    B, T, H, W, pad, CO, CI = 2, 3, 4, 9, 3, 128, 64
+    Tp, Hp, Wp = T + pad, H + pad, W + pad
+    gs = torch.randn(B, T, H, W, CO, dtype=torch.float64)
+    xp = torch.randn(B, Tp, Hp, Wp, CI, dtype=torch.float64)
+    ref = torch.einsum("bthwo,bthwi->oi", gs, xp[:, :T, :H, :W])
+    ncrop = B * T * H * W
+    slots = ops.cell_wgrad_slots(ncrop, CO, CI)
+    part = torch.zeros(slots, CO * CI + CO, device="cuda")
+    ops.cell_wgrad(dev(gs).view(-1, CO), dev(xp).view(-1, CI), part, ncrop, CO, CI, crop=True, crop6=(T, H, W, Tp, Hp, Wp))
+    assert rel_l2(part.double().sum(0).cpu()[:CO * CI].view(CO, CI), ref) < TOL
+
+
+@pytest.mark.parametrize("C,DO", [(64, 2), (32, 3), (128, 5), (64, 16)])
+def test_proj_fwd_bwd(ops, C, DO):
+    torch.manual_seed(C + DO)
+    B, T, H, W, pad = 2, 3, 6, 7, 2
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64)
+    w1 = (torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)).requires_grad_(True)
+    b1 = torch.randn(128, dtype=torch.float64, requires_grad=True)
+    w2 = (torch.randn(DO, 128, dtype=torch.float64) / 11).requires_grad_(True)
+    b2 = torch.randn(DO, dtype=torch.float64, requires_grad=True)
+    ac = a[:, :T, :H, :W].reshape(-1, C)
+    u = ac @ w1.t() + b1
+    u.retain_grad()
+    v = torch.nn.functional.gelu(u)
+    out_ref = v @ w2.t() + b2
+    gout = torch.randn_like(out_ref)
+    out_ref.backward(gout)
+    out = torch.empty(d.ncrop, DO, device="cuda")
+    A, W1, B1, W2, B2 = dev(a).view(-1, C), dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), dev(b2.detach())
+    ops.proj_fwd(A, W1, B1, W2, B2, out, d, DO)
+    assert rel_l2(out.cpu(), out_ref.detach()) < TOL
+    slots = ops.proj_slots(d.ncrop, C, DO)
+    part = torch.zeros(slots, DO * 128 + 128 + DO, device="cuda")
+    gu = torch.empty(d.ncrop, 128, device="cuda")
+    ops.proj_bwd(A, W1, B1, W2, B2, dev(gout), gu, part, d, DO)
+    assert rel_l2(gu.cpu(), u.grad) < 5e-6
+    s = part.double().sum(0).cpu()
+    assert rel_l2(s[:DO * 128].view(DO, 128), w2.grad) < 5e-6
+    assert rel_l2(s[DO * 128:DO * 128 + 128], b1.grad) < 5e-6
+    assert rel_l2(s[DO * 128 + 128:], b2.grad) < 5e-6
+
+
+def test_lift_fwd_bwd(ops):
+    torch.manual_seed(9)
+    B, T, H, W, Cin, C, pad = 2, 4, 5, 6, 3, 64, 6
+    d = ops.Dims(B, T, H, W, Cin, C, pad)
+    x = torch.randn(B, T, H, W, Cin, dtype=torch.float64)
+    grids = [torch.tensor(np.linspace(0, 1, n), dtype=torch.float) for n in (T, H, W)]
+    w0 = torch.randn(C, Cin + 3, dtype=torch.float64, requires_grad=True)
+    b0 = torch.randn(C, dtype=torch.float64, requires_grad=True)
+    grid = torch.stack([grids[0].double().view(1, T, 1, 1).expand(B, T, H, W),
+                        grids[1].double().view(1, 1, H, 1).expand(B, T, H, W),
+                        grids[2].double().view(1, 1, 1, W).expand(B, T, H, W)], dim=-1)
+    inner = torch.cat([x, grid], -1) @ w0.t() + b0
+    ref = torch.zeros(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64)
+    ref[:, :T, :H, :W] = inner.detach()
+    out = torch.full((d.ncell, C), float("nan"), device="cuda")
+    dg = [g.cuda() for g in grids]
+    ops.lift_pad_fwd(dev(x), dg, dev(w0.detach()), dev(b0.detach()), out, d)
+    assert rel_l2(out.cpu().view_as(ref), ref) < TOL
+    g = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64)
+    inner.backward(g[:, :T, :H, :W])
+    rows = ops._lib.query("rpb_lift_bwd_rows")
+    F = Cin + 3
+    part = torch.zeros(rows, C * F + C, device="cuda")
+    ops.lift_bwd(dev(g).view(-1, C), dev(x), dg, part, d)
+    s = part.double().sum(0).cpu()
+    assert rel_l2(s[:C * F].view(C, F), w0.grad) < TOL
+    assert rel_l2(s[C * F:], b0.grad) < TOL
+
+
+@pytest.mark.parametrize("gelu", [True, False])
+def test_batchnorm_fwd_bwd(ops, gelu):
+    torch.manual_seed(11)
+    ncell, C = 5000, 64
+    s = (torch.randn(ncell, C, dtype=torch.float64) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, dtype=torch.float64, requires_grad=True)
+    mean = s.mean(0)
+    var = ((s - mean) ** 2).mean(0)
+    z = (s - mean) / torch.sqrt(var + 1e-5) * gamma + beta
+    y = torch.nn.functional.gelu(z) if gelu else z
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    S = dev(s.detach())
+    sums = torch.stack([s.detach().sum(0), (s.detach() ** 2).sum(0)]).reshape(-1).cuda()
+    mean_d, invstd_d = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    ops.bn_finalize(sums, ncell, 1e-5, 0.1, mean_d, invstd_d, rm, rv, C)
+    assert rel_l2(mean_d.cpu(), mean.detach()) < TOL
+    assert rel_l2(invstd_d.cpu(), 1 / torch.sqrt(var.detach() + 1e-5)) < TOL
+    assert rel_l2(rm.cpu(), 0.1 * mean.detach()) < TOL
+    assert rel_l2(rv.cpu(), 0.9 + 0.1 * var.detach() * ncell / (ncell - 1)) < TOL
+    Y = torch.empty(ncell, C, device="cuda")
+    ops.bn_act_fwd(S, mean_d, invstd_d, dev(gamma.detach()), dev(beta.detach()), Y, ncell, C, gelu)
+    assert rel_l2(Y.cpu(), y.detach()) < TOL
+    rows = ops.bn_bwd_rows()
+    part = torch.zeros(rows, 2 * C, device="cuda")
+    GY = dev(gy)
+    ops.bn_bwd_reduce(S, GY, mean_d, invstd_d, dev(gamma.detach()), dev(beta.detach()), part, ncell, C, gelu)
+    sums32 = torch.empty(2 * C, device="cuda")
+    ops.reduce_partials(part, rows, 2 * C, out_f32=sums32)
+    assert rel_l2(sums32[:C].cpu(), beta.grad) < 5e-6
+    assert rel_l2(sums32[C:].cpu(), gamma.grad) < 5e-6
+    GS = torch.empty(ncell, C, device="cuda")
+    ops.bn_bwd_apply(S, GY, mean_d, invstd_d, dev(gamma.detach()), dev(beta.detach()), sums32, ncell, GS, ncell, C, gelu)
+    assert rel_l2(GS.cpu(), s.grad) < 5e-6
+    # eval-mode prep
+    inv = torch.empty(C, device="cuda")
+    ops.bn_eval_prep(rv, 1e-5, inv, C)
+    assert rel_l2(inv.cpu(), 1 / torch.sqrt(rv.cpu().double() + 1e-5)) < TOL
+
+
+def test_mse_adam_affine_reduce(ops):
+    torch.manual_seed(13)
+    n = 100003
+    p, t = torch.randn(n, dtype=torch.float64), torch.randn(n, dtype=torch.float64)
+    elem, gout = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    part = torch.zeros(ops.mse_rows(), device="cuda")
+    ops.mse(dev(p), dev(t), elem, gout, part, n, 1.0 / n)
+    loss = torch.empty(1, device="cuda")
+    ops.reduce_partials(part, part.numel(), 1, out_f32=loss, scale=1.0 / n)
+    assert rel_l2(elem.cpu(), (p - t) ** 2) < TOL
+    assert rel_l2(gout.cpu(), 2 * (p - t) / n) < TOL
+    assert abs(float(loss) - float(((p - t) ** 2).mean())) < 1e-6
+    # Adam vs torch.optim.Adam over 3 steps with changing lr
+    w = torch.randn(1003, dtype=torch.float32)
+    wt = w.clone().requires_grad_(True)
+    opt = torch.optim.Adam([wt], lr=1e-2)
+    P, M_, V = w.clone().cuda(), torch.zeros(1003, device="cuda"), torch.zeros(1003, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(1003)
+        lr = 1e-2 * (0.7 ** step)
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        wt.grad = g.clone()
+        opt.step()
+        ops.adam_step(P, g.cuda(), M_, V, 1003, lr, 0.9, 0.999, 1e-8, step)
+    assert rel_l2(P.cpu(), wt.detach()) < 1e-6
+    # rollout affine with control channels
+    ncell, Cp, Cx = 999, 3, 2
+    pred, para = torch.randn(ncell, Cp), torch.randn(ncell, Cx)
+    mt, st = torch.randn(Cp), torch.rand(Cp) + 0.5
+    mi, si = torch.randn(Cp + Cx), torch.rand(Cp + Cx) + 0.5
+    ref = (torch.cat([pred * st + mt, para], -1) - mi) / si
+    out = torch.empty(ncell, Cp + Cx, device="cuda")
+    ops.rollout_affine(dev(pred), dev(para), out, ncell, Cp, Cx, dev(mt), dev(st), dev(mi), dev(si))
+    assert rel_l2(out.cpu(), ref) < 1e-6
+    out2 = torch.empty(ncell, Cp, device="cuda")
+    ops.rollout_affine(dev(pred), None, out2, ncell, Cp, 0, None, None, None, None)
+    assert torch.equal(out2.cpu(), pred)
+    x = torch.randn(50, 7, 3)
+    o = torch.empty(50, 7, 3, device="cuda")
+    ops.channel_affine(dev(x), o, x.numel(), 3, dev(mt), dev(st), False)
+    assert rel_l2(o.cpu(), (x - mt) / st) < 1e-6
+    ops.channel_affine(dev(x), o, x.numel(), 3, dev(mt), dev(st), True)
+    assert rel_l2(o.cpu(), x * st + mt) < 1e-6
+    # strided partial reduction
+    part2 = torch.randn(37, 50)
+    o2 = torch.empty(20, device="cuda")
+    ops.reduce_partials(dev(part2), 37, 20, out_f32=o2, row_stride=50, col0=11)
+    assert rel_l2(o2.cpu(), part2[:, 11:31].double().sum(0)) < 1e-6
+
+
+def test_errors_are_loud(ops):
+    from realpdebench_amd._lib import RpbError
+    x = torch.zeros(4, 33, device="cuda")
+    with pytest.raises(RpbError):
+        ops.axis_gemm(x, x, torch.zeros(2, 2, device="cuda"), 1, 2, 2, 33, 66, 33, 66, 33)     # N % 32 != 0
+    with pytest.raises(RpbError):
+        ops.bn_eval_prep(torch.zeros(4), 1e-5, torch.zeros(4), 4)                                 # CPU tensor
