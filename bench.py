@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X FNO3d path (contract: see the task statement / DESIGN.md).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+One "step" = one full training iteration of the reference's hot loop (train.py:321-334: forward, MSE mean,
+backward, Adam, cosine LR) on a synthetic batch of BASELINE.json configs[1]: FNO3d cylinder-shaped
+[B=32/GPU, 20, 128, 128, 2], modes (4,12,16), width 64, 4 layers, fp32.  Inputs are resident in HBM when the
+timed region starts.  Rank 0 prints ONE JSON line with the whole-job samples/s, the roofline of the dominant
+kernel (HIP-event timed inside the timed region) and a CPU baseline (the oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA = fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--rollout-steps", type=int, default=10, help="N_autoregressive of configs/cylinder/fno.yaml")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(shape, modes, width, n_layers):
+    """Oracle (PyTorch-CPU restatement of the reference) timed on this box's host cores: ONE training step at
+    B=2 of the same shape (~10-20 s of CPU work)."""
+    from oracle import fno3d_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = 2
+    sd = O.init_state_dict(modes, n_layers, width, shape, shape, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(Bc, *shape, generator=g), torch.randn(Bc, *shape, generator=g)
+    t0 = time.time()
+    O.train_steps(sd, [(x, y)], modes, n_layers, shape, shape, lr0=1e-4, t_max=4000)
+    dt = time.time() - t0
+    return {"value": Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 train step (fwd+bwd+Adam) of the oracle at B={Bc}, same shape/model, {dt:.1f} s, no warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from realpdebench_amd import _lib
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.trainer import Trainer
+    from realpdebench_amd.rollout import autoregressive_rollout
+
+    shape, modes, width, L = (20, 128, 128, 2), (4, 12, 16), 64, 4
+    torch.manual_seed(0)
+    model = FNO3d(*modes, L, width, shape, shape).to(dev)
+    if world > 1:
+        from realpdebench_amd.dp import DataParallel
+        DataParallel(model)
+    trainer = Trainer(model, lr=1e-4, num_update=4000, scheduler="cosine")
+    B = a.batch
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(B, *shape, device=dev, generator=g)
+    y = torch.randn(B, *shape, device=dev, generator=g)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up with every launch timed: find the dominant kernel
+    _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
+    for _ in range(max(a.warmup, 1)):
+        trainer.step(x, y)
+    torch.cuda.synchronize()
+    warm = _lib.profile_summary()
+    dominant = max(warm, key=lambda k: warm[k]["total_ms"])
+    if a.profile_all and rank == 0:
+        tot = sum(v["total_ms"] for v in warm.values())
+        for k, v in sorted(warm.items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"{k:48s} calls/step {v['calls'] / max(a.warmup, 1):5.1f}  avg {v['avg_ms']:8.3f} ms  "
+                  f"{100 * v['total_ms'] / tot:5.1f}%  {v['bytes'] / v['avg_ms'] / 1e6:8.1f} GB/s  "
+                  f"{v['flops'] / v['avg_ms'] / 1e9:7.2f} TF/s", file=sys.stderr)
+
+    # ---- timed region: exactly K steps, only the dominant kernel carries HIP events
+    _lib.PROFILE, _lib.PROFILE_ONLY = {}, {dominant}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = trainer.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    dom = _lib.profile_summary()[dominant]
+    _lib.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = 1e3 * dt / a.steps
+    value = B * world * a.steps / dt
+
+    # ---- rollout metric (eval.py:311-321), replicas: no collective
+    rollout = None
+    if not a.no_rollout:
+        del trainer
+        model._ws = {}
+        torch.cuda.empty_cache()
+        autoregressive_rollout(model, x, 1)
+        barrier()
+        t0 = time.perf_counter()
+        autoregressive_rollout(model, x, a.rollout_steps)
+        barrier()
+        rt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([rt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rt = float(t)
+        rollout = {"value": B * world * shape[0] * a.rollout_steps / rt, "unit": "fields/s",
+                   "n_autoregressive": a.rollout_steps, "ms_per_forward": 1e3 * rt / a.rollout_steps}
+
+    if rank == 0:
+        ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
+        ach_tf = dom["flops"] / dom["avg_ms"] / 1e9
+        step_bytes = (6.238 * B + 4.03) * 1e9          # algorithmic bytes of one train step
+        line = {
+            "metric": "train-step samples/sec (+ autoregressive rollout fields/sec in 'rollout'), FNO cylinder 128^2",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FNO3d train step (fwd+MSE+bwd+Adam+cosine), cylinder-shaped [B,20,128,128,2] "
+                                   "-> padded 26x134x134, modes (4,12,16), width 64, 4 layers (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["calls"],
+                         "algorithmic_bytes_per_launch": dom["bytes"],
+                         "mfma_f32": {"achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                      "frac": ach_tf / MFMA_F32_PEAK_TF},
+                         "whole_step": {"algorithmic_bytes": step_bytes,
+                                        "achieved": step_bytes / (ms_per_step * 1e6), "unit": "GB/s",
+                                        "frac": step_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS}},
+            "rollout": rollout,
+            "loss": float(loss),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(shape, modes, width, L)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

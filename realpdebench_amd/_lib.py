@@ -68,12 +68,38 @@ def load():
     return _lib
 
 
-def call(name, *args):
-    """Call an ``int``-returning entry point and turn a non-zero status into ``RpbError``."""
+# ---- optional per-launch HIP-event timing (bench.py): PROFILE = {label: [(start, end, bytes, flops), ...]}
+PROFILE = None
+PROFILE_ONLY = None      # restrict timing to these labels (None = all)
+
+
+def call(name, *args, label=None, nbytes=0, flops=0):
+    """Call an ``int``-returning entry point and turn a non-zero status into ``RpbError``.
+
+    ``label`` / ``nbytes`` / ``flops`` describe the launch for the roofline bookkeeping: algorithmic HBM bytes and
+    floating-point operations of this launch."""
     lib = load()
+    prof = PROFILE is not None and (PROFILE_ONLY is None or (label or name) in PROFILE_ONLY)
+    if prof:
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(lib, name)(*args)
+    if prof:
+        e.record()
+        PROFILE.setdefault(label or name, []).append((s, e, nbytes, flops))
     if rc != 0:
         raise RpbError(f"{name} failed ({rc}): {lib.rpb_last_error().decode()}")
+
+
+def profile_summary():
+    """{label: dict(calls, total_ms, avg_ms, bytes, flops)} -- call after torch.cuda.synchronize()."""
+    out = {}
+    for label, recs in (PROFILE or {}).items():
+        ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+        out[label] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                          bytes=sum(r[2] for r in recs) / len(recs), flops=sum(r[3] for r in recs) / len(recs))
+    return out
 
 
 def query(name, *args):

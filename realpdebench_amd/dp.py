@@ -1,0 +1,79 @@
+"""Data parallelism for the FNO3d step: one process per GPU, trajectories sharded across ranks, gradients
+summed with RCCL (``torch.distributed`` backend "nccl" on ROCm) over xGMI.
+
+The reference has no distributed path at all (single process, realpdebench/train.py:63); this is new design:
+
+* the flat gradient arena is cut into per-layer buckets that become ready in reverse layer order during the
+  backward pass; each bucket's all-reduce is issued asynchronously the moment its last kernel is enqueued, so
+  RCCL (running on its own HIP stream) overlaps the remaining backward kernels.  For the cylinder config that is
+  4 buckets of 100.7 MB (one ``spectral_convs.{l}`` each) + 2 small ones;
+* BatchNorm3d uses global batch statistics (SyncBN): the fp64 per-channel (sum, sum-of-squares) and the backward
+  (sum gz, sum gz*shat) vectors are all-reduced on the compute stream (2*C numbers per layer), so an N-rank step
+  equals the 1-rank step on the concatenated batch;
+* the loss gradient is pre-scaled by 1/N_global, so the bucket reduction is a plain SUM.
+
+Everything here works on CPU tensors with the gloo backend too (tests/test_dp_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def layer_buckets(seg, n_layers, total):
+    """Contiguous [start, end) ranges of the flat arena in the order the backward pass completes them:
+    tail (fc1, fc2), layers L-1 .. 1, then head (fc0 + layer 0)."""
+    def start_of(name):
+        return seg[name][0]
+
+    cuts = [start_of(f"spec.{l}") for l in range(n_layers)] + [start_of("fc1.weight")]
+    buckets = [(cuts[-1], total)]
+    for l in range(n_layers - 1, 0, -1):
+        buckets.append((cuts[l], cuts[l + 1]))
+    buckets.append((0, cuts[1] if n_layers > 1 else cuts[-1]))
+    return buckets
+
+
+class DataParallel:
+    def __init__(self, model, process_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised before DataParallel (one process per GPU)")
+        self.model = model
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.buckets = layer_buckets(model._seg, model.n_layers, model.flat.numel())
+        self._works = []
+        self._next = 0
+        model.dp = self
+        self.sync_parameters()
+
+    def sync_parameters(self):
+        """Rank 0's weights and BatchNorm buffers become everyone's (the reference has one process: one init)."""
+        dist.broadcast(self.model.flat.data, src=0, group=self.group)
+        for b in (self.model.bn_running_mean, self.model.bn_running_var, self.model.bn_num_batches_tracked):
+            dist.broadcast(b, src=0, group=self.group)
+
+    # ---- small synchronous reductions (SyncBN statistics)
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- bucketed, overlapped gradient reduction
+    def begin_step(self, grad):
+        self._works, self._next = [], 0
+
+    def bucket_ready(self, grad):
+        """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete."""
+        s, e = self.buckets[self._next]
+        self._next += 1
+        self._works.append(dist.all_reduce(grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_step(self, grad):
+        while self._next < len(self.buckets):          # anything the backward pass did not announce
+            self.bucket_ready(grad)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    # ---- sharding of a global batch / dataset index (replaces shuffle=True of train.py:269 under DP)
+    def shard(self, n_items):
+        per = n_items // self.world_size
+        return range(self.rank * per, (self.rank + 1) * per)

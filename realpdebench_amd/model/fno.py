@@ -81,7 +81,12 @@ class _FNO3dFunction(torch.autograd.Function):
         model, ws = ctx.model, ctx.ws
         g = model._unshape_grad(gout.contiguous(), ctx.x.shape[0])
         gflat = torch.zeros_like(model.flat)
+        if model.dp is not None:            # caller took a local .mean(): average over ranks like DDP would
+            model.dp.begin_step(gflat)
         model._backward_impl(ctx.x, g, ws, gflat)
+        if model.dp is not None:
+            model.dp.finish_step(gflat)
+            gflat.div_(model.dp.world_size)
         return None, gflat, None
 
 
@@ -332,6 +337,8 @@ class FNO3d(Model):
         ops.cell_wgrad(ws.gu, ws.A[L], ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6)
         partp = ws.wg_part[:ws.wg_rows_p * (HID * C + HID)].view(ws.wg_rows_p, HID * C + HID)
         self._reduce_cols(partp, 0, HID * C, GP("fc1.weight"))
+        if self.dp is not None:
+            self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
         g, g2 = ws.G
         ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, None, d.ncell, HID, C, 0, 1, transpose_w=True,
                      gather=True, crop6=d.crop6)
@@ -355,6 +362,8 @@ class FNO3d(Model):
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
             self._spectral_forward_stages(g, ws, ws.Yh, (plan.GWt, plan.GHt, plan.GTt), first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
+            if self.dp is not None and l > 0:
+                self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward
             gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
             self._spectral_inverse_stages(gxh, ws, (plan.FTt, plan.FHt))

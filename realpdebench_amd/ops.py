@@ -40,30 +40,36 @@ class Dims:
 
 def lift_pad_fwd(x, grids, w0, b0, out, d):
     _lib.call("rpb_lift_pad_fwd", _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(w0), _p(b0), _p(out),
-              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream())
+              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream(),
+              label="lift_pad", nbytes=4 * (d.ncrop * d.Cin + d.ncell * d.C), flops=2 * d.ncrop * d.C * (d.Cin + 3))
 
 
 def lift_bwd(g, x, grids, part, d):
     _lib.call("rpb_lift_bwd", _p(g), _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(part),
-              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream())
+              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream(),
+              label="lift_bwd", nbytes=4 * d.ncrop * (d.Cin + d.C), flops=2 * d.ncrop * d.C * (d.Cin + 3))
 
 
-def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False):
+def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False, tag=""):
     assert tuple(M.shape) == (O, K), (M.shape, O, K)
-    _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o,
-              K if k_valid is None else k_valid, int(accumulate), _stream())
+    kv = K if k_valid is None else k_valid
+    _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o, kv, int(accumulate),
+              _stream(), label=f"axis_gemm[{tag}K{K}xO{O}]", nbytes=4 * G * N * (kv + O), flops=2 * G * N * kv * O)
 
 
 def mode_contract_fwd(X, W, Y, B, M, C):
-    _lib.call("rpb_mode_contract_fwd", _p(X), _p(W), _p(Y), B, M, C, _stream())
+    _lib.call("rpb_mode_contract_fwd", _p(X), _p(W), _p(Y), B, M, C, _stream(), label="mode_contract_fwd",
+              nbytes=8 * M * C * (C + 2 * B), flops=8 * B * M * C * C)
 
 
 def mode_contract_dgrad(GY, W, GX, B, M, C):
-    _lib.call("rpb_mode_contract_dgrad", _p(GY), _p(W), _p(GX), B, M, C, _stream())
+    _lib.call("rpb_mode_contract_dgrad", _p(GY), _p(W), _p(GX), B, M, C, _stream(), label="mode_contract_dgrad",
+              nbytes=8 * M * C * (C + 2 * B), flops=8 * B * M * C * C)
 
 
 def mode_contract_wgrad(X, GY, GW, B, M, C, accumulate=False):
-    _lib.call("rpb_mode_contract_wgrad", _p(X), _p(GY), _p(GW), B, M, C, int(accumulate), _stream())
+    _lib.call("rpb_mode_contract_wgrad", _p(X), _p(GY), _p(GW), B, M, C, int(accumulate), _stream(),
+              label="mode_contract_wgrad", nbytes=8 * M * C * (C + 2 * B), flops=8 * B * M * C * C)
 
 
 def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec):
@@ -72,8 +78,13 @@ def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec):
 
 def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
              crop6=(0, 0, 0, 1, 1, 1)):
+    spec, stats = z2 is not None, stats_part is not None
+    rows_in = (crop6[0] * crop6[1] * crop6[2] * (ncell // (crop6[3] * crop6[4] * crop6[5]))) if gather else ncell
     _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
-              int(transpose_w), int(gather), *crop6, _stream())
+              int(transpose_w), int(gather), *crop6, _stream(),
+              label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={int(stats)}]",
+              nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
+              flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
 
 
 def cell_wgrad_slots(ncell, CO, CI):
@@ -81,7 +92,8 @@ def cell_wgrad_slots(ncell, CO, CI):
 
 
 def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1)):
-    _lib.call("rpb_cell_wgrad", _p(gs), _p(x), _p(part), ncell, CO, CI, int(crop), *crop6, _stream())
+    _lib.call("rpb_cell_wgrad", _p(gs), _p(x), _p(part), ncell, CO, CI, int(crop), *crop6, _stream(),
+              label=f"cell_wgrad[CO{CO},CI{CI}]", nbytes=4 * ncell * (CO + CI), flops=2 * ncell * CO * CI)
 
 
 def reduce_partials(part, rows, L, out_f32=None, out_f64=None, scale=1.0, accumulate=False, row_stride=None,
@@ -101,7 +113,8 @@ def bn_eval_prep(rvar, eps, invstd, C):
 
 
 def bn_act_fwd(s, mean, invstd, gamma, beta, y, ncell, C, gelu):
-    _lib.call("rpb_bn_act_fwd", _p(s), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), ncell, C, int(gelu), _stream())
+    _lib.call("rpb_bn_act_fwd", _p(s), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(y), ncell, C, int(gelu), _stream(),
+              label=f"bn_act_fwd[gelu={int(gelu)}]", nbytes=8 * ncell * C, flops=12 * ncell * C)
 
 
 def bn_bwd_rows():
@@ -110,12 +123,13 @@ def bn_bwd_rows():
 
 def bn_bwd_reduce(s, gy, mean, invstd, gamma, beta, part, ncell, C, gelu):
     _lib.call("rpb_bn_bwd_reduce", _p(s), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(part), ncell, C,
-              int(gelu), _stream())
+              int(gelu), _stream(), label=f"bn_bwd_reduce[gelu={int(gelu)}]", nbytes=8 * ncell * C, flops=16 * ncell * C)
 
 
 def bn_bwd_apply(s, gy, mean, invstd, gamma, beta, sums, count, gs, ncell, C, gelu):
     _lib.call("rpb_bn_bwd_apply", _p(s), _p(gy), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums), float(count),
-              _p(gs), ncell, C, int(gelu), _stream())
+              _p(gs), ncell, C, int(gelu), _stream(), label=f"bn_bwd_apply[gelu={int(gelu)}]", nbytes=12 * ncell * C,
+              flops=20 * ncell * C)
 
 
 def proj_slots(ncrop, C, DO):
@@ -123,12 +137,14 @@ def proj_slots(ncrop, C, DO):
 
 
 def proj_fwd(a, w1, b1, w2, b2, out, d, DO):
-    _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, _stream())
+    _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, _stream(),
+              label="proj_fwd", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
 
 
 def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO):
     _lib.call("rpb_proj_bwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(gout), _p(gu), _p(part), d.ncrop, d.C, DO,
-              *d.crop6, _stream())
+              *d.crop6, _stream(), label="proj_bwd", nbytes=4 * d.ncrop * (d.C + DO + 128),
+              flops=2 * d.ncrop * 128 * (d.C + 2 * DO))
 
 
 def mse_rows():
@@ -140,7 +156,8 @@ def mse(pred, target, elem, gout, part, n, gscale):
 
 
 def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale=1.0):
-    _lib.call("rpb_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, step, gscale, _stream())
+    _lib.call("rpb_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, step, gscale, _stream(),
+              label="adam_step", nbytes=28 * n, flops=12 * n)
 
 
 def rollout_affine(pred, para, out, ncell, Cp, Cx, mean_t, std_t, mean_i, std_i):

@@ -111,7 +111,7 @@ def test_against_oracle_wider(width, B):
         sd[f"bns.{l}.weight"] = torch.rand(width) + 0.5
         sd[f"bns.{l}.bias"] = torch.randn(width) * 0.2
     x, y = torch.randn(B, *shape), torch.randn(B, *shape)
-    loss, pred, grads, _ = O.loss_and_grads(sd, x, y, modes, L, shape, shape)
+    loss, pred, grads, new_buf = O.loss_and_grads(sd, x, y, modes, L, shape, shape)
     m = FNO3d(*modes, L, width, shape, shape)
     m.load_state_dict(sd)
     m = m.cuda().train()
@@ -123,6 +123,10 @@ def test_against_oracle_wider(width, B):
         if k.startswith("convs.") and k.endswith(".bias"):
             continue
         assert rel_l2(got[k].cpu(), gr) < GRAD_TOL, k
+    sd.update(new_buf)          # the train-mode forward moved the running statistics on both sides
+    msd = m.state_dict()
+    for k in new_buf:
+        assert rel_l2(msd[k].cpu(), new_buf[k]) < 1e-5, k
     m.eval()
     with torch.no_grad():
         out = m(x.cuda())
