@@ -34,28 +34,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(shape, modes, width, n_layers):
-    """Oracle (PyTorch-CPU restatement of the reference) timed on this box's host cores: ONE training step at
-    B=2 of the same shape (~10-20 s of CPU work)."""
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_worker():
+    """Child process: the oracle (PyTorch-CPU restatement of the reference) does ONE training step at B=1."""
     from oracle import fno3d_oracle as O
-    cores = os.cpu_count() or 1
+    shape, modes, width, n_layers = (20, 128, 128, 2), (4, 12, 16), 64, 4
+    cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
-    Bc = 2
+    Bc = 1
     sd = O.init_state_dict(modes, n_layers, width, shape, shape, seed=0)
     g = torch.Generator().manual_seed(0)
     x, y = torch.randn(Bc, *shape, generator=g), torch.randn(Bc, *shape, generator=g)
     t0 = time.time()
     O.train_steps(sd, [(x, y)], modes, n_layers, shape, shape, lr0=1e-4, t_max=4000)
     dt = time.time() - t0
-    return {"value": Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step (fwd+bwd+Adam) of the oracle at B={Bc}, same shape/model, {dt:.1f} s, no warm-up"}
+    print(json.dumps({"value": Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"1 train step (fwd+bwd+Adam) of the CPU oracle at B={Bc}, same shape and model, "
+                                f"{dt:.1f} s, no warm-up"}))
+
+
+def cpu_baseline():
+    """Bounded: runs in a child process with a hard timeout so the default bench always finishes in minutes."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+                           text=True, timeout=300)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:        # timeout / parse error: report it, never hang the bench
+        return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"CPU oracle step did not finish within 300 s ({type(e).__name__})"}
 
 
 def main():
     a = parse()
+    if a.cpu_baseline_worker:
+        return cpu_baseline_worker()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,7 +195,7 @@ def main():
             "loss": float(loss),
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(shape, modes, width, L)
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

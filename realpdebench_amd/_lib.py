@@ -59,6 +59,9 @@ def load():
             raise RpbError(
                 f"{LIB_PATH} is missing: build it with `python -m realpdebench_amd.build` "
                 "(hipcc --offload-arch=gfx950).  realpdebench_amd has no CPU/eager fallback.")
+        # torch bundles its own libamdhip64: import it first so that this library binds to the SAME HIP runtime
+        # instance (two runtimes in one process cannot share streams / device pointers).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
