@@ -50,10 +50,11 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
                                                         long in_g, long in_k, long out_g, long out_o, int k_valid,
                                                         int accumulate) {
     extern __shared__ float Mlds[];   // [Kp][Op]
+    typedef typename VecN<NV>::T vec;
     const int ot_total = (O + 31) / 32;
     const int och = (ot_total + OT - 1) / OT;
     const int Op = och * OT * 32;
-    const int Kp = (K + 1) & ~1;
+    const int Kp = (K + 15) & ~15;                      // whole 8-step chunks; the pad rows are zero
     for (int idx = threadIdx.x; idx < Kp * Op; idx += blockDim.x) {
         const int k = idx / Op, o = idx - k * Op;
         Mlds[idx] = (k < K && o < O) ? M[(long)o * K + k] : 0.f;
@@ -61,39 +62,66 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> SGPR addressing
     const int waves = blockDim.x >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int nch = N / (32 * NV);
     const long nitems = (long)G * nch * och;
+    const int kch = (k_valid + 15) / 16;                // chunks of 8 MFMA steps (16 k) that hold non-zero input
 
     for (long item = (long)blockIdx.x * waves + wave; item < nitems; item += (long)gridDim.x * waves) {
         const int oc = (int)(item % och);
         const long r = item / och;
         const int nc = (int)(r % nch);
         const long g = r / nch;
-        const int n0 = nc * 32 * NV + NV * col;
-        const float* ip = in + g * in_g + n0;
+        const float* ip = in + g * in_g + (long)nc * 32 * NV;              // uniform
+        const long lane_in = (long)half * in_k + NV * col;
         f32x16 acc[OT][NV];
 #pragma unroll
         for (int a = 0; a < OT; ++a)
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[a][v] = zero16();
 
-        const float* mrow = Mlds + oc * OT * 32 + col;
-#pragma unroll 4
-        for (int s = 0; s < (k_valid + 1) / 2; ++s) {   // inputs k >= k_valid are known zeros (layer-0 pad)
-            const int k = 2 * s + half;
-            float b[NV];
-            load_vec<NV>(ip + (long)k * in_k, k < k_valid, b);
+        vec ba[8], bb[8];
+        const vec vz = {};
+        // chunk c covers k in [16c, 16c+16); lane (half) takes k = 16c + 2s + half
+        auto load_chunk = [&](int c, vec (&b)[8]) {
+            const float* cp = ip + (long)(16 * c) * in_k;                   // uniform
+            if (16 * c + 16 <= k_valid) {
 #pragma unroll
-            for (int a = 0; a < OT; ++a) {
-                const float av = mrow[k * Op + a * 32];
+                for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k);
+            } else {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) acc[a][v] = mfma32(av, b[v], acc[a][v]);
+                for (int s = 0; s < 8; ++s)
+                    b[s] = (16 * c + 2 * s + half < k_valid)
+                               ? *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k) : vz;
             }
+        };
+        auto compute_chunk = [&](int c, const vec (&b)[8]) {
+            const float* mp = Mlds + (16 * c + half) * Op + oc * OT * 32 + col;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int a = 0; a < OT; ++a) {
+                    const float av = mp[2 * s * Op + a * 32];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        float bv;
+                        if constexpr (NV == 1) bv = b[s];
+                        else bv = b[s][v];
+                        acc[a][v] = mfma32(av, bv, acc[a][v]);
+                    }
+                }
+            }
+        };
+        if (kch > 0) load_chunk(0, ba);
+        for (int c = 0; c < kch; c += 2) {
+            if (c + 1 < kch) load_chunk(c + 1, bb);
+            compute_chunk(c, ba);
+            if (c + 2 < kch) load_chunk(c + 2, ba);
+            if (c + 1 < kch) compute_chunk(c + 1, bb);
         }
-        float* op = out + g * out_g + n0;
+        float* op = out + g * out_g + (long)nc * 32 * NV + NV * col;
 #pragma unroll
         for (int a = 0; a < OT; ++a) {
 #pragma unroll
@@ -104,15 +132,15 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
                     if constexpr (NV == 1) {
                         dst[0] = accumulate ? dst[0] + acc[a][0][rr] : acc[a][0][rr];
                     } else {
-                        typename VecN<NV>::T t;
+                        vec t;
 #pragma unroll
                         for (int v = 0; v < NV; ++v) t[v] = acc[a][v][rr];
                         if (accumulate) {
-                            typename VecN<NV>::T old = *reinterpret_cast<typename VecN<NV>::T*>(dst);
+                            const vec old = *reinterpret_cast<vec*>(dst);
 #pragma unroll
                             for (int v = 0; v < NV; ++v) t[v] += old[v];
                         }
-                        *reinterpret_cast<typename VecN<NV>::T*>(dst) = t;
+                        *reinterpret_cast<vec*>(dst) = t;
                     }
                 }
             }
@@ -126,7 +154,7 @@ static int launch_axis(const float* in, float* out, const float* M, int G, int K
     const int ot_total = (O + 31) / 32;
     const int och = (ot_total + OT - 1) / OT;
     const int Op = och * OT * 32;
-    const int Kp = (K + 1) & ~1;
+    const int Kp = (K + 15) & ~15;
     const size_t lds = (size_t)Kp * Op * sizeof(float);
     RPB_REQUIRE(lds <= 160 * 1024, "axis_gemm: matrix %dx%d does not fit LDS", O, K);
     (void)hipFuncSetAttribute((const void*)axis_gemm_kernel<OT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -31,113 +31,254 @@ struct CellMixArgs {
     CropMap cm;
 };
 
-template <int NT, bool HAS_SPEC, bool STATS>
-__global__ __launch_bounds__(512) void cell_mix_kernel(CellMixArgs a) {
+#ifndef CM_MAX_THREADS
+#define CM_MAX_THREADS 768      // 12 waves per CU = 3 per SIMD -> <=168 VGPRs
+#endif
+#ifndef CM_PREF1
+#define CM_PREF1 0
+#endif
+#ifndef CM_UNROLL
+#define CM_UNROLL 8
+#endif
+#define CM_STR2(x) #x
+#define CM_STR(x) CM_STR2(x)
+#define CM_PRAGMA_UNROLL _Pragma(CM_STR(unroll CM_UNROLL))
+
+template <int N>
+struct VecT;
+template <>
+struct VecT<1> {
+    typedef float T;
+};
+template <>
+struct VecT<2> {
+    typedef f32x2 T;
+};
+template <>
+struct VecT<4> {
+    typedef f32x4 T;
+};
+template <int N>
+__device__ __forceinline__ float vget(const typename VecT<N>::T& v, int i) {
+    if constexpr (N == 1) return v;
+    else return v[i];
+}
+
+// NT   : output tiles of 32 channels (CO = 32*NT)
+// KC   : input channels (compile time: the K loops are fully unrolled so LDS reads are software-pipelined)
+// K2S  : spectral MFMA steps (2*K2S >= K2 rows of z2; 0 = no spectral term)
+// Software pipeline per wave: the x tile of the NEXT item and the z2 rows of THIS item are in flight in
+// registers while the 64..128 MFMAs of this item run, so HBM latency is hidden with 2 waves per SIMD.
+template <int NT, int KC, int K2S, bool STATS>
+__global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_kernel(CellMixArgs a) {
+    constexpr bool SPEC = K2S > 0;
+    constexpr int CO = NT * 32;
+    constexpr int XS = KC + 1;
+    constexpr int NX = KC / 8;                       // float4 loads per lane per tile
+    constexpr bool PREF1 = CM_PREF1 && NT <= 2;      // prefetch the second z2 row of a straddling tile too
+    typedef typename VecT<NT>::T vecb;
     extern __shared__ float lds[];
-    const int KC = a.KC, CO = a.CO, K2 = a.K2, Wp = a.Wp;
-    const int K2p = (K2 + 1) & ~1;
-    float* GWl = lds;                                         // [K2p][Wp]
-    float* Wl = GWl + (HAS_SPEC ? K2p * Wp : 0);              // [KC][CO]
+    const int K2 = a.K2, Wp = a.Wp;
+    float* GWl = lds;                                            // [2*K2S][Wp]
+    float* Wl = GWl + (SPEC ? 2 * K2S * Wp : 0);                 // [KC][32][NT]
+    // wave index / tile index are wave-uniform: keep them in SGPRs so that every global address below is
+    // "uniform base + small per-lane offset + immediate" (saves ~100 VGPRs of 64-bit addresses)
     const int waves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int XS = KC + 1;
-    float* xl = Wl + KC * CO + wave * 32 * XS;                // wave-private [32][KC+1]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float* xl = Wl + KC * CO + wave * 32 * XS;                   // wave-private [32][KC+1]
     int* srow = reinterpret_cast<int*>(Wl + KC * CO + waves * 32 * XS) + wave * 32;
 
-    if (HAS_SPEC)
-        for (int idx = threadIdx.x; idx < K2p * Wp; idx += blockDim.x) {
+    if (SPEC)
+        for (int idx = threadIdx.x; idx < 2 * K2S * Wp; idx += blockDim.x) {
             const int k = idx / Wp, w = idx - k * Wp;
             GWl[idx] = (k < K2) ? a.GW[w * K2 + k] : 0.f;
         }
     for (int idx = threadIdx.x; idx < KC * CO; idx += blockDim.x) {
-        const int k = idx / CO, n = idx - k * CO;
-        Wl[idx] = a.transpose_w ? a.Wm[idx] : a.Wm[(long)n * KC + k];
+        const int k = idx / CO, n = idx - k * CO;            // n = t*32 + col
+        const float v = a.transpose_w ? a.Wm[idx] : a.Wm[(long)n * KC + k];
+        Wl[(k * 32 + (n & 31)) * NT + (n >> 5)] = v;
     }
     __syncthreads();
 
     const int col = lane & 31, half = lane >> 5;
     const long ntiles = (a.ncell + 31) / 32;
-    float ssum[NT], ssq[NT];
+    const long tstride = (long)gridDim.x * waves;
+    const bool k2_exact = (K2 == 2 * K2S);
+    float ssum[NT], ssq[NT], bv[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = 0.f;
-    float bv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = a.bias ? a.bias[t * 32 + col] : 0.f;
+    for (int t = 0; t < NT; ++t) {
+        ssum[t] = ssq[t] = 0.f;
+        bv[t] = a.bias ? a.bias[t * 32 + col] : 0.f;
+    }
 
-    for (long tile = (long)blockIdx.x * waves + wave; tile < ntiles; tile += (long)gridDim.x * waves) {
+    f32x4 xr[NX];
+    auto issue_x = [&](long tile) {
         const long cell0 = tile * 32;
-        // ---- source row of each of the 32 cells (lane < 32 computes one)
-        if (lane < 32) {
-            const long c = cell0 + lane;
-            long r = -1;
-            if (c < a.ncell) r = a.gather ? pad_to_crop(a.cm, c) : c;
-            srow[lane] = (int)r;
+        if (a.gather) {
+            if (lane < 32) {
+                const long c = cell0 + lane;
+                srow[lane] = (c < a.ncell) ? (int)pad_to_crop(a.cm, c) : -1;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int idx = j * 64 + lane;
+                const int row = idx / (KC / 4), c4 = idx - row * (KC / 4);
+                const int sr = srow[row];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (sr >= 0) v = *reinterpret_cast<const f32x4*>(a.x + (long)sr * KC + 4 * c4);
+                xr[j] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            const float* base = a.x + cell0 * KC;                 // uniform
+            if (cell0 + 32 <= a.ncell) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) xr[j] = *reinterpret_cast<const f32x4*>(base + lane * 4 + j * 256);
+            } else {
+                const int lim = (int)(a.ncell - cell0) * KC;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const int off = lane * 4 + j * 256;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (off < lim) v = *reinterpret_cast<const f32x4*>(base + off);
+                    xr[j] = v;
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- stage x tile: 32 rows x KC floats, float4 per lane, coalesced
-        const int v4_per_row = KC >> 2;
-        for (int j = 0; j < (KC >> 3); ++j) {
-            const int idx = j * 64 + lane;
-            const int row = idx / v4_per_row, c4 = idx - row * v4_per_row;
-            const int sr = srow[row];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (sr >= 0) v = *reinterpret_cast<const f32x4*>(a.x + (long)sr * KC + 4 * c4);
-            float* d = xl + row * XS + 4 * c4;
-            d[0] = v[0];
-            d[1] = v[1];
-            d[2] = v[2];
-            d[3] = v[3];
+    };
+
+    long tile = (long)blockIdx.x * waves + wave;
+    if (tile < ntiles) issue_x(tile);
+    for (; tile < ntiles; tile += tstride) {
+        const long cell0 = tile * 32;
+        const bool full = cell0 + 32 <= a.ncell;                  // uniform
+        // ---- 1. registers -> wave-private transposing LDS tile
+        {
+            float* d0 = xl + (lane / (KC / 4)) * XS + 4 * (lane % (KC / 4));
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                float* d = d0 + j * (64 / (KC / 4)) * XS;         // 64 float4 = 256/KC rows further down
+                d[0] = xr[j][0];
+                d[1] = xr[j][1];
+                d[2] = xr[j][2];
+                d[3] = xr[j][3];
+            }
         }
+        // ---- 2. z2 rows of this tile -> registers (land while the conv MFMAs run)
+        float zr0[SPEC ? K2S : 1][NT], zr1[(SPEC && PREF1) ? K2S : 1][NT];
+        int g0 = 0, g1 = 0, myg = 0, myw = 0;
+        bool valid = false;
+        if (SPEC) {
+            const long mycell = cell0 + col;
+            valid = mycell < a.ncell;
+            g0 = (int)(cell0 / Wp);                               // uniform
+            long lastc = cell0 + 31;
+            if (lastc >= a.ncell) lastc = a.ncell - 1;
+            g1 = (int)(lastc / Wp);                               // uniform
+            const int w0 = (int)(cell0 - (long)g0 * Wp);          // uniform
+            myw = w0 + col;
+            myg = g0;
+            while (myw >= Wp) {
+                myw -= Wp;
+                ++myg;
+            }
+            const float* zp = a.z2 + (long)g0 * K2 * CO;          // uniform
+            const int lo = half * CO + col;
+            if (k2_exact) {
+#pragma unroll
+                for (int s = 0; s < K2S; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) zr0[s][t] = zp[lo + 2 * s * CO + t * 32];
+            } else {
+#pragma unroll
+                for (int s = 0; s < K2S; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) zr0[s][t] = (2 * s + half < K2) ? zp[lo + 2 * s * CO + t * 32] : 0.f;
+            }
+            if (PREF1 && g1 > g0) {
+                const float* zq = zp + (long)K2 * CO;
+#pragma unroll
+                for (int s = 0; s < K2S; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) zr1[s][t] = (2 * s + half < K2) ? zq[lo + 2 * s * CO + t * 32] : 0.f;
+            }
+        }
+        // ---- 3. next tile's x loads go out now and stay in flight during the MFMAs below
+        if (tile + tstride < ntiles) issue_x(tile + tstride);
         __builtin_amdgcn_wave_barrier();
 
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = zero16();
-
-        if (HAS_SPEC) {
-            const long mycell = cell0 + col;
-            const bool valid = mycell < a.ncell;
-            const int myg = (int)(mycell / Wp);
-            const int myw = (int)(mycell - (long)myg * Wp);
-            const int g0 = (int)(cell0 / Wp);
-            long lastc = cell0 + 31;
-            if (lastc >= a.ncell) lastc = a.ncell - 1;
-            const int g1 = (int)(lastc / Wp);
-            for (int gg = g0; gg <= g1; ++gg) {
+        // ---- 4. channel mixing: A = x tile (LDS, transposed read), B = W (LDS, NT values per read)
+        {
+            const float* ap = xl + col * XS + half;
+            const float* bp = Wl + (half * 32 + col) * NT;
+            CM_PRAGMA_UNROLL
+            for (int s = 0; s < KC / 2; ++s) {
+                const float av = ap[2 * s];
+                const vecb b = *reinterpret_cast<const vecb*>(bp + 2 * s * 32 * NT);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma32(av, vget<NT>(b, t), acc[t]);
+            }
+        }
+        // ---- 5. last inverse-DFT stage: A = GW[w(cell)][k] (LDS), B = z2 row (registers)
+        if (SPEC) {
+            {
+                const bool mine = valid && (myg == g0);
+                const float* gp = GWl + half * Wp + myw;
+#pragma unroll
+                for (int s = 0; s < K2S; ++s) {
+                    const float av = mine ? gp[2 * s * Wp] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma32(av, zr0[s][t], acc[t]);
+                }
+            }
+            for (int gg = g0 + 1; gg <= g1; ++gg) {            // tile straddles w-rows (rare beyond one)
                 const bool mine = valid && (myg == gg);
-                const float* zp = a.z2 + (long)gg * K2 * CO + col;
-#pragma unroll 4
-                for (int s = 0; s < K2p / 2; ++s) {
-                    const int k = 2 * s + half;
-                    const float av = mine ? GWl[k * Wp + myw] : 0.f;
+                const float* gp = GWl + half * Wp + myw;
+                const float* zq = a.z2 + (long)gg * K2 * CO;
+                const int lo = half * CO + col;
+                const bool pre = PREF1 && (gg == g0 + 1);
+                float zb[SPEC ? K2S : 1][NT];
+                if (!pre) {
+#pragma unroll
+                    for (int s = 0; s < K2S; ++s)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) zb[s][t] = (2 * s + half < K2) ? zq[lo + 2 * s * CO + t * 32] : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < K2S; ++s) {
+                    const float av = mine ? gp[2 * s * Wp] : 0.f;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float b = (k < K2) ? zp[(long)k * CO + t * 32] : 0.f;
+                        float b;
+                        if (PREF1) b = pre ? zr1[s][t] : zb[s][t];
+                        else b = zb[s][t];
                         acc[t] = mfma32(av, b, acc[t]);
                     }
                 }
             }
         }
-        // ---- channel mixing: A = x tile (LDS, transposed read), B = W (LDS)
-#pragma unroll 4
-        for (int s = 0; s < KC / 2; ++s) {
-            const int k = 2 * s + half;
-            const float av = xl[col * XS + k];
+        // ---- 6. epilogue: out[cell0 + row][t*32 + col], row = 8*(r>>2) + 4*half + (r&3)
+        {
+            float* ob = a.out + cell0 * CO;                       // uniform
+            const int lo = 4 * half * CO + col;
+            const int rows_left = (int)(a.ncell - cell0);         // only used on the tail tile
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma32(av, Wl[k * CO + t * 32 + col], acc[t]);
-        }
-        // ---- epilogue
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long c = cell0 + mfma_row(lane, r);
-                if (c < a.ncell) {
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 8 * (r >> 2) + (r & 3);
                     const float v = acc[t][r] + bv[t];
-                    a.out[c * CO + t * 32 + col] = v;
-                    if (STATS) {
-                        ssum[t] += v;
-                        ssq[t] += v * v;
+                    if (full || rr + 4 * half < rows_left) {
+                        ob[lo + rr * CO + t * 32] = v;
+                        if (STATS) {
+                            ssum[t] += v;
+                            ssq[t] += v * v;
+                        }
                     }
                 }
             }
@@ -158,23 +299,33 @@ __global__ __launch_bounds__(512) void cell_mix_kernel(CellMixArgs a) {
     }
 }
 
+static int cell_mix_k2s(int K2, bool spec) {
+    if (!spec) return 0;
+    if (K2 <= 16) return 8;
+    if (K2 <= 32) return 16;
+    return -1;
+}
+
 static size_t cell_mix_lds(int KC, int CO, int K2, int Wp, bool spec, int waves) {
-    const int K2p = (K2 + 1) & ~1;
-    return ((size_t)(spec ? K2p * Wp : 0) + (size_t)KC * CO + (size_t)waves * 32 * (KC + 1) + (size_t)waves * 32) * 4;
+    const int k2s = cell_mix_k2s(K2, spec);
+    return ((size_t)(spec ? 2 * k2s * Wp : 0) + (size_t)KC * CO + (size_t)waves * 32 * (KC + 1) + (size_t)waves * 32) * 4;
 }
 
 static int cell_mix_waves(int KC, int CO, int K2, int Wp, bool spec) {
-    for (int w = 8; w >= 1; w >>= 1)
-        if (cell_mix_lds(KC, CO, K2, Wp, spec, w) <= 160 * 1024) return w;
+    if (cell_mix_k2s(K2, spec) < 0) return 0;
+    const int wmax = (KC >= 128 ? 512 : CM_MAX_THREADS) / 64;
+    static const int cand[] = {16, 12, 8, 4, 2, 1};
+    for (int w : cand)
+        if (w <= wmax && cell_mix_lds(KC, CO, K2, Wp, spec, w) <= 160 * 1024) return w;
     return 0;
 }
 
-template <int NT, bool SPEC, bool STATS>
+template <int NT, int KC, int K2S, bool STATS>
 static int launch_cell_mix(const CellMixArgs& a, int waves, int grid, hipStream_t st) {
-    const size_t lds = cell_mix_lds(a.KC, a.CO, a.K2, a.Wp, SPEC, waves);
-    (void)hipFuncSetAttribute((const void*)cell_mix_kernel<NT, SPEC, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipLaunchKernelGGL((cell_mix_kernel<NT, SPEC, STATS>), dim3(grid), dim3(waves * 64), lds, st, a);
+    const size_t lds = cell_mix_lds(a.KC, a.CO, a.K2, a.Wp, K2S > 0, waves);
+    (void)hipFuncSetAttribute((const void*)cell_mix_kernel<NT, KC, K2S, STATS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((cell_mix_kernel<NT, KC, K2S, STATS>), dim3(grid), dim3(waves * 64), lds, st, a);
     RPB_CHECK_LAUNCH("cell_mix");
 }
 
@@ -194,10 +345,10 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
                             int gather, int T, int H, int W, int Tp, int Hp, int Wp_pad, void* stream) {
     RPB_REQUIRE(x && Wm && out, "cell_mix: null pointer");
     RPB_REQUIRE(ncell > 0 && ncell < (1L << 31), "cell_mix: ncell=%ld out of range", ncell);
-    RPB_REQUIRE(KC % 8 == 0 && KC > 0, "cell_mix: KC=%d must be a multiple of 8", KC);
+    RPB_REQUIRE(KC == 32 || KC == 64 || KC == 128, "cell_mix: KC=%d must be 32, 64 or 128", KC);
     RPB_REQUIRE(CO == 32 || CO == 64 || CO == 128, "cell_mix: CO=%d must be 32, 64 or 128", CO);
     const bool spec = z2 != nullptr;
-    if (spec) RPB_REQUIRE(GW && K2 > 0 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments");
+    if (spec) RPB_REQUIRE(GW && K2 > 0 && K2 <= 32 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments (K2=%d)", K2);
     const int waves = cell_mix_waves(KC, CO, K2, Wp, spec);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);
     CellMixArgs a;
@@ -209,13 +360,17 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     hipStream_t st = (hipStream_t)stream;
     const bool stats = stats_part != nullptr;
     const int NT = CO / 32;
-#define RPB_CM(NT_, S_, ST_) \
-    if (NT == NT_ && spec == S_ && stats == ST_) return launch_cell_mix<NT_, S_, ST_>(a, waves, grid, st);
-    RPB_CM(1, true, true) RPB_CM(1, true, false) RPB_CM(1, false, true) RPB_CM(1, false, false)
-    RPB_CM(2, true, true) RPB_CM(2, true, false) RPB_CM(2, false, true) RPB_CM(2, false, false)
-    RPB_CM(4, true, true) RPB_CM(4, true, false) RPB_CM(4, false, true) RPB_CM(4, false, false)
+    const int k2s = cell_mix_k2s(K2, spec);
+#define RPB_CM(NT_, KC_, K2S_, ST_) \
+    if (NT == NT_ && KC == KC_ && k2s == K2S_ && stats == ST_) return launch_cell_mix<NT_, KC_, K2S_, ST_>(a, waves, grid, st);
+    // square channel mixing (1x1x1 conv fwd / dgrad), with and without the spectral term
+    RPB_CM(1, 32, 8, true) RPB_CM(1, 32, 8, false) RPB_CM(1, 32, 16, true) RPB_CM(1, 32, 16, false) RPB_CM(1, 32, 0, false)
+    RPB_CM(2, 64, 8, true) RPB_CM(2, 64, 8, false) RPB_CM(2, 64, 16, true) RPB_CM(2, 64, 16, false) RPB_CM(2, 64, 0, false)
+    RPB_CM(4, 128, 8, true) RPB_CM(4, 128, 8, false) RPB_CM(4, 128, 16, true) RPB_CM(4, 128, 16, false) RPB_CM(4, 128, 0, false)
+    // fc1 dgrad (128 hidden -> C), gather into the padded layout
+    RPB_CM(1, 128, 0, false) RPB_CM(2, 128, 0, false)
 #undef RPB_CM
-    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_mix: unsupported configuration");
+    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_mix: unsupported configuration KC=%d CO=%d K2=%d stats=%d", KC, CO, K2, (int)stats);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad
@@ -232,18 +387,29 @@ struct WgradArgs {
     CropMap cm;
 };
 
-template <int NTO, int NTI>
+// Channel <-> MFMA index mapping: a lane loads NTO (resp. NTI) CONTIGUOUS channels of one cell with one vector
+// load (lane col -> channels col*NT .. col*NT+NT-1, i.e. a full 128/256/512 B line per half-wave), so MFMA tile `t`
+// holds the channels == t (mod NT): row i of o-tile `to` is channel i*NTO + to, column j of i-tile `ti` is channel
+// j*NTI + ti.  Half tiles (8 MFMA steps = 16 cells) are double-buffered in registers: the loads of the next half
+// are in flight while the MFMAs of the current half run.
+template <int CO, int CI>
 __global__ __launch_bounds__(512) void cell_wgrad_kernel(WgradArgs a) {
+    constexpr int NTI = CI / 32;
+    constexpr int NTO = (CO / 32) * NTI > 4 ? ((CO / 32) * NTI > 8 ? (CO / 32) / 4 : (CO / 32) / 2) : CO / 32;
+    static_assert(NTO >= 1 && NTO * NTI <= 4, "accumulator budget");
+    typedef typename VecT<NTO>::T veco;
+    typedef typename VecT<NTI>::T veci;
     const int waves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
-    const int CO = a.CO, CI = a.CI;
-    const int nroles = CO / (32 * NTO);
-    const long sid = (long)blockIdx.x * waves + wave;
+    constexpr int nroles = CO / (32 * NTO);
+    const long sid = (long)blockIdx.x * waves + wave;           // uniform
     const int role = (int)(sid % nroles);
     const long tslot = sid / nroles;
     const long ntslots = ((long)gridDim.x * waves) / nroles;
     const long ntiles = (a.ncell + 31) / 32;
+    const bool rowfast = !a.crop || (a.cm.W % 32 == 0);          // a tile never leaves its (b,t,h) row
 
     f32x16 acc[NTO][NTI];
 #pragma unroll
@@ -254,32 +420,62 @@ __global__ __launch_bounds__(512) void cell_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int o = 0; o < NTO; ++o) bsum[o] = 0.f;
 
-    for (long tile = tslot; tile < ntiles; tile += ntslots) {
-        const long cell0 = tile * 32;
-        long myrow = -1;
-        {
-            const long c = cell0 + col;
-            if (c < a.ncell) myrow = a.crop ? crop_to_pad(a.cm, c) : c;
-        }
-        const int myrow_i = (int)myrow;
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int j = 2 * s + half;
-            const long c = cell0 + j;
-            const int xr = __shfl(myrow_i, j, 64);
-            const bool ok = c < a.ncell;
-            float av[NTO], bx[NTI];
+    veco ga[8], gb[8];
+    veci xa[8], xb[8];
+    const veco zo = {};
+    const veci zi = {};
+
+    auto load_half = [&](long tile, int h, veco (&gv)[8], veci (&xv)[8]) {
+        const long cell0 = tile * 32 + h * 16;                   // uniform
+        const float* gp = a.gs + cell0 * CO + role * 32 * NTO;   // uniform
+        const int go = half * CO + col * NTO;                    // per-lane, tile-invariant
+        if (rowfast) {
+            const long xrow0 = a.crop ? crop_to_pad(a.cm, tile * 32) + h * 16 : cell0;     // uniform
+            const float* xp = a.x + xrow0 * CI;                  // uniform
+            const int xo = half * CI + col * NTI;
+            if (cell0 + 16 <= a.ncell) {
 #pragma unroll
-            for (int o = 0; o < NTO; ++o) av[o] = ok ? a.gs[c * CO + (role * NTO + o) * 32 + col] : 0.f;
+                for (int s = 0; s < 8; ++s) {
+                    gv[s] = *reinterpret_cast<const veco*>(gp + go + 2 * s * CO);
+                    xv[s] = *reinterpret_cast<const veci*>(xp + xo + 2 * s * CI);
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < NTI; ++i) bx[i] = ok ? a.x[(long)xr * CI + i * 32 + col] : 0.f;
+                for (int s = 0; s < 8; ++s) {
+                    const bool ok = cell0 + 2 * s + half < a.ncell;
+                    gv[s] = ok ? *reinterpret_cast<const veco*>(gp + go + 2 * s * CO) : zo;
+                    xv[s] = ok ? *reinterpret_cast<const veci*>(xp + xo + 2 * s * CI) : zi;
+                }
+            }
+        } else {
 #pragma unroll
-            for (int o = 0; o < NTO; ++o) {
-                bsum[o] += av[o];
-#pragma unroll
-                for (int i = 0; i < NTI; ++i) acc[o][i] = mfma32(av[o], bx[i], acc[o][i]);
+            for (int s = 0; s < 8; ++s) {
+                const long c = cell0 + 2 * s + half;
+                const bool ok = c < a.ncell;
+                gv[s] = ok ? *reinterpret_cast<const veco*>(gp + go + 2 * s * CO) : zo;
+                xv[s] = ok ? *reinterpret_cast<const veci*>(a.x + crop_to_pad(a.cm, c) * CI + col * NTI) : zi;
             }
         }
+    };
+    auto compute_half = [&](const veco (&gv)[8], const veci (&xv)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int o = 0; o < NTO; ++o) {
+                const float av = vget<NTO>(gv[s], o);
+                bsum[o] += av;
+#pragma unroll
+                for (int i = 0; i < NTI; ++i) acc[o][i] = mfma32(av, vget<NTI>(xv[s], i), acc[o][i]);
+            }
+    };
+
+    long tile = tslot;
+    if (tile < ntiles) load_half(tile, 0, ga, xa);
+    for (; tile < ntiles; tile += ntslots) {
+        load_half(tile, 1, gb, xb);
+        compute_half(ga, xa);
+        if (tile + ntslots < ntiles) load_half(tile + ntslots, 0, ga, xa);
+        compute_half(gb, xb);
     }
     float* part = a.part + tslot * ((long)CO * CI + CO);
 #pragma unroll
@@ -288,11 +484,11 @@ __global__ __launch_bounds__(512) void cell_wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < NTI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int orow = (role * NTO + o) * 32 + mfma_row(lane, r);
-                part[(long)orow * CI + i * 32 + col] = acc[o][i][r];
+                const int orow = role * 32 * NTO + mfma_row(lane, r) * NTO + o;
+                part[(long)orow * CI + col * NTI + i] = acc[o][i][r];
             }
         const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
-        if (half == 0) part[(long)CO * CI + (role * NTO + o) * 32 + col] = b;
+        if (half == 0) part[(long)CO * CI + role * 32 * NTO + col * NTO + o] = b;
     }
 }
 
@@ -317,8 +513,6 @@ extern "C" int rpb_cell_wgrad(const float* gs, const float* x, float* part, long
                               int T, int H, int W, int Tp, int Hp, int Wp, void* stream) {
     RPB_REQUIRE(gs && x && part, "cell_wgrad: null pointer");
     RPB_REQUIRE(ncell > 0 && ncell < (1L << 31), "cell_wgrad: ncell out of range");
-    RPB_REQUIRE((CO == 32 || CO == 64 || CO == 128) && (CI == 32 || CI == 64 || CI == 128),
-                "cell_wgrad: CO=%d CI=%d must each be 32, 64 or 128", CO, CI);
     int NTO, NTI;
     wgrad_shape(CO, CI, NTO, NTI);
     const int nroles = CO / (32 * NTO);
@@ -330,11 +524,11 @@ extern "C" int rpb_cell_wgrad(const float* gs, const float* x, float* part, long
     a.cm = CropMap{T, H, W, Tp, Hp, Wp};
     hipStream_t st = (hipStream_t)stream;
 #define RPB_WG(O_, I_)                                                                         \
-    if (NTO == O_ && NTI == I_) {                                                              \
+    if (CO == O_ && CI == I_) {                                                                \
         hipLaunchKernelGGL((cell_wgrad_kernel<O_, I_>), dim3(grid), dim3(512), 0, st, a);      \
         RPB_CHECK_LAUNCH("cell_wgrad");                                                        \
     }
-    RPB_WG(1, 1) RPB_WG(2, 1) RPB_WG(4, 1) RPB_WG(1, 2) RPB_WG(2, 2) RPB_WG(1, 4)
+    RPB_WG(32, 32) RPB_WG(64, 64) RPB_WG(128, 128) RPB_WG(128, 32) RPB_WG(128, 64) RPB_WG(64, 32)
 #undef RPB_WG
-    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_wgrad: unsupported NTO=%d NTI=%d", NTO, NTI);
+    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_wgrad: unsupported CO=%d CI=%d", CO, CI);
 }

@@ -82,24 +82,26 @@ __global__ __launch_bounds__(PW_THREADS) void lift_bwd_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j <= LIFT_FMAX; ++j) acc[j] = 0.f;
     if (sub < nsub) {
-        for (long q = (long)blockIdx.x * nsub + sub; q < ncrop; q += (long)gridDim.x * nsub) {
-            const int w = (int)(q % cm.W);
-            long r = q / cm.W;
-            const int h = (int)(r % cm.H);
-            r /= cm.H;
-            const int t = (int)(r % cm.T);
-            const long b = r / cm.T;
-            const long p = ((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp + w;
-            const float gv = g[p * C + o];
-            const float* xp = x + q * Cin;
+        const long nrows = ncrop / cm.W;                             // (b,t,h) rows of W cells
+        for (long row = blockIdx.x; row < nrows; row += gridDim.x) { // row decode is block-uniform (scalar ALU)
+            const int h = (int)(row % cm.H);
+            const long r2 = row / cm.H;
+            const int t = (int)(r2 % cm.T);
+            const long b = r2 / cm.T;
+            const long p0 = ((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp;
+            const float ft = gt[t], fh = gh[h];
+            for (int w = sub; w < cm.W; w += nsub) {
+                const float gv = g[(p0 + w) * C + o];
+                const float* xp = x + (row * cm.W + w) * Cin;
 #pragma unroll
-            for (int j = 0; j < LIFT_FMAX; ++j) {
-                if (j < F) {
-                    const float f = (j < Cin) ? xp[j] : (j == Cin ? gt[t] : (j == Cin + 1 ? gh[h] : gw[w]));
-                    acc[j] += gv * f;
+                for (int j = 0; j < LIFT_FMAX; ++j) {
+                    if (j < F) {
+                        const float f = (j < Cin) ? xp[j] : (j == Cin ? ft : (j == Cin + 1 ? fh : gw[w]));
+                        acc[j] += gv * f;
+                    }
                 }
+                acc[LIFT_FMAX] += gv;
             }
-            acc[LIFT_FMAX] += gv;
         }
 #pragma unroll
         for (int j = 0; j < LIFT_FMAX; ++j)
@@ -208,14 +210,24 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             long n4, int C) {
+    // the grid stride is a multiple of C/4, so every thread keeps ONE group of 4 channels: parameters live in registers
     const int c4n = C >> 2;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;
+    float mu[4], sc[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k];
+        sc[k] = invstd[c + k];
+        be[k] = beta[c + k];
+    }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    for (long idx = i0; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(s)[idx];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float z = (v[k] - mean[c + k]) * invstd[c + k] * gamma[c + k] + beta[c + k];
+            const float z = (v[k] - mu[k]) * sc[k] * ga[k] + be[k];
             o[k] = GELU ? gelu_f(z) : z;
         }
         reinterpret_cast<f32x4*>(y)[idx] = o;
@@ -224,7 +236,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_kernel(const float* __restr
 
 extern "C" int rpb_bn_act_fwd(const float* s, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, float* y, long ncell, int C, int gelu, void* stream) {
-    RPB_REQUIRE(s && mean && invstd && gamma && beta && y && C % 4 == 0, "bn_act_fwd: bad arguments");
+    RPB_REQUIRE(s && mean && invstd && gamma && beta && y && C % 4 == 0 && PW_THREADS % (C / 4) == 0,
+                "bn_act_fwd: bad arguments");
     const long n4 = ncell * (C / 4);
     if (gelu)
         hipLaunchKernelGGL(bn_act_kernel<true>, dim3(pw_grid(n4)), dim3(PW_THREADS), 0, (hipStream_t)stream, s, mean,
@@ -308,17 +321,27 @@ __global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_kernel(const float* _
                                                                   const float* __restrict__ sums, float inv_count,
                                                                   float* gs, long n4, int C) {
     const int c4n = C >> 2;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;
+    float mu[4], is[4], ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k];
+        is[k] = invstd[c + k];
+        ga[k] = gamma[c + k];
+        be[k] = beta[c + k];
+        m1[k] = sums[c + k] * inv_count;
+        m2[k] = sums[C + c + k] * inv_count;
+    }
+    for (long idx = i0; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const f32x4 sv = reinterpret_cast<const f32x4*>(s)[idx];
         const f32x4 gv = reinterpret_cast<const f32x4*>(gy)[idx];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float is = invstd[c + k], ga = gamma[c + k];
-            const float sh = (sv[k] - mean[c + k]) * is;
-            const float gz = GELU ? gv[k] * gelu_grad_f(sh * ga + beta[c + k]) : gv[k];
-            o[k] = ga * is * (gz - sums[c + k] * inv_count - sh * sums[C + c + k] * inv_count);
+            const float sh = (sv[k] - mu[k]) * is[k];
+            const float gz = GELU ? gv[k] * gelu_grad_f(sh * ga[k] + be[k]) : gv[k];
+            o[k] = ga[k] * is[k] * (gz - m1[k] - sh * m2[k]);
         }
         reinterpret_cast<f32x4*>(gs)[idx] = o;
     }
@@ -327,7 +350,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_kernel(const float* _
 extern "C" int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, const float* sums, double count, float* gs,
                                 long ncell, int C, int gelu, void* stream) {
-    RPB_REQUIRE(s && gy && mean && invstd && gamma && beta && sums && gs && C % 4 == 0, "bn_bwd_apply: bad arguments");
+    RPB_REQUIRE(s && gy && mean && invstd && gamma && beta && sums && gs && C % 4 == 0 && PW_THREADS % (C / 4) == 0,
+                "bn_bwd_apply: bad arguments");
     const long n4 = ncell * (C / 4);
     const float ic = (float)(1.0 / count);
     if (gelu)
