@@ -53,6 +53,25 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// ---------------------------------------------------------------------------------- buffer addressing
+// SRSRC ("buffer") accesses: 128-bit descriptor in SGPRs + ONE 32-bit per-lane offset + scalar/immediate offsets,
+// with hardware bounds checking (out-of-range lanes: loads return 0, stores are dropped).  Built per tile from
+// wave-uniform values, this replaces per-lane 64-bit address arithmetic and every tail predicate.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store_f32(float v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ float buf_load_f32(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// bytes of `rows_left` rows of `row_bytes` each, clipped to one tile of `tile_rows` rows
+__device__ __forceinline__ unsigned tile_bytes(long rows_left, int tile_rows, int row_bytes) {
+    return (unsigned)((rows_left < tile_rows ? (rows_left < 0 ? 0 : rows_left) : tile_rows) * row_bytes);
+}
+
 // ---------------------------------------------------------------------------------- math
 // Branch-free erf:  erf(x) = sign(x) * (1 - 2^(t*S(t))),  t = min(|x|, 4),  S = degree-8 weighted-minimax fit of
 // log2(erfc(t))/t (fitted offline against scipy in fp64; max |error| 9.5e-8 in fp32 arithmetic = the rounding of

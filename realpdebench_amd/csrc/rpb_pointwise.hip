@@ -136,21 +136,32 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
 
 // ---------------------------------------------------------------------------------- reducers
 // out[j] (+)= scale * sum_r part[r*row_stride + j], j < L   (fp64 accumulation)
-__global__ __launch_bounds__(PW_THREADS) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
-                                                                     long row_stride, float* __restrict__ outf,
-                                                                     double* __restrict__ outd, double scale,
-                                                                     int accumulate) {
-    // block handles 64 columns; 4 row-groups
-    __shared__ double red[4][64];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
+                                                               long row_stride, float* __restrict__ outf,
+                                                               double* __restrict__ outd, double scale,
+                                                               int accumulate) {
+    // block = 64 columns x 16 row groups; 4 independent fp64 chains per thread keep the loads pipelined
+    __shared__ double red[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (j < L)
-        for (long r = rg; r < rows; r += 4) s += (double)part[r * row_stride + j];
-    red[rg][cl] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (j < L) {
+        long r = rg;
+        for (; r + 48 < rows; r += 64) {
+            s0 += (double)part[r * row_stride + j];
+            s1 += (double)part[(r + 16) * row_stride + j];
+            s2 += (double)part[(r + 32) * row_stride + j];
+            s3 += (double)part[(r + 48) * row_stride + j];
+        }
+        for (; r < rows; r += 16) s0 += (double)part[r * row_stride + j];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && j < L) {
-        const double v = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) * scale;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cl];
+        v *= scale;
         if (outd) outd[j] = accumulate ? outd[j] + v : v;
         if (outf) outf[j] = accumulate ? (float)((double)outf[j] + v) : (float)v;
     }
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(PW_THREADS) void reduce_partials_kernel(const float
 extern "C" int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, float* outf, double* outd,
                                    double scale, int accumulate, void* stream) {
     RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0 && row_stride >= L, "reduce_partials: bad arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
                        part, rows, L, row_stride, outf, outd, scale, accumulate);
     RPB_CHECK_LAUNCH("reduce_partials");
 }

@@ -2,9 +2,10 @@
 // Replaces fno.py:121-125 (the crop `x[..., :-6, :-6, :-6]`, the permute, fc1, F.gelu, fc2).
 //
 // fc1 runs on v_mfma_f32_32x32x2_f32 (tile = 32 cropped cells x 128 hidden, K = C); fc2 is tiny
-// (DO = 2..16 outputs) so it is a lane-local dot product over the hidden index followed by a 32-lane
-// butterfly sum.  The activation tile is gathered from the padded tensor (crop fused into the load) and
-// transposed through a wave-private +1-padded LDS tile.
+// (DO = 2..16 outputs) so it is a lane-local dot product over the hidden index followed by a recursive-halving
+// butterfly over the 32 lanes that leaves exactly one (cell, output) sum per lane (31 shuffles instead of 160).
+// The activation tile is gathered from the padded tensor (crop fused into the load), prefetched one tile ahead
+// in registers and transposed through a wave-private +1-padded LDS tile.
 //
 // proj_bwd recomputes u = fc1 a + b1 instead of saving it (saves 5.4 GB of HBM traffic per step at
 // B=32), produces gu = (fc2^T g) * gelu'(u) for the downstream dgrad / wgrad kernels and accumulates
@@ -29,130 +30,202 @@ struct ProjArgs {
     CropMap cm;
 };
 
-template <bool BWD, int DOT>   // DOT = compile-time bound on DO (register arrays must be statically indexed)
+// v = gelu(u), d = gelu'(u) with ONE erf evaluation
+__device__ __forceinline__ void gelu_pair(float u, float& v, float& d) {
+    const float cdf = 0.5f * (1.0f + fast_erf(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+    v = u * cdf;
+    d = cdf + u * pdf;
+}
+
+// DOT = compile-time bound on DO (register arrays must be statically indexed); ROWFAST = W % 32 == 0, i.e. a
+// 32-cell tile never leaves its (b,t,h) row and the crop gather is one contiguous 32*C block (keeps the generic
+// gather path, with its per-lane 64-bit addresses, out of the hot instantiation's register budget)
+template <int C, bool BWD, int DOT, bool ROWFAST>
 __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
     extern __shared__ float lds[];
-    const int C = p.C, DO = p.DO;
+    constexpr int XS = C + 1;
+    constexpr int NX = C / 8;
+    const int DO = p.DO;
     const int waves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int col = lane & 31, half = lane >> 5;
-    const int XS = C + 1;
-    float* W1l = lds;                       // [C][HID]   B[k=i][n=hid] = w1[hid][i]
+    float* W1l = lds;                       // [C][32][4]   B[k=i][n=hid=t*32+col] = w1[hid][i], 4 tiles per 16 B read
     float* W2l = W1l + C * HID;             // [DO][HID]
     float* xl = W2l + DO * HID + wave * 32 * XS;
     int* srow = reinterpret_cast<int*>(W2l + DO * HID + waves * 32 * XS) + wave * 32;
 
     for (int idx = threadIdx.x; idx < C * HID; idx += blockDim.x) {
         const int k = idx / HID, n = idx - k * HID;
-        W1l[idx] = p.w1[(long)n * C + k];
+        W1l[(k * 32 + (n & 31)) * 4 + (n >> 5)] = p.w1[(long)n * C + k];
     }
     for (int idx = threadIdx.x; idx < DO * HID; idx += blockDim.x) W2l[idx] = p.w2[idx];
     __syncthreads();
 
-    float b1v[NTH];
+    float b1v[NTH], w2r[DOT][NTH];
 #pragma unroll
     for (int t = 0; t < NTH; ++t) b1v[t] = p.b1[t * 32 + col];
-
-    // backward accumulators (per lane: hidden index = t*32+col, rows of this lane's half)
-    float dw2[DOT][NTH], w2r[DOT][NTH];
-    float db1[NTH], db2[DOT];
+#pragma unroll
+    for (int j = 0; j < DOT; ++j)
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) w2r[j][t] = (j < DO) ? W2l[j * HID + t * 32 + col] : 0.f;
+    float dw2[BWD ? DOT : 1][NTH], db1[NTH], db2[BWD ? DOT : 1];
     if (BWD) {
 #pragma unroll
         for (int j = 0; j < DOT; ++j) {
             db2[j] = 0.f;
 #pragma unroll
-            for (int t = 0; t < NTH; ++t) {
-                dw2[j][t] = 0.f;
-                w2r[j][t] = (j < DO) ? W2l[j * HID + t * 32 + col] : 0.f;
-            }
+            for (int t = 0; t < NTH; ++t) dw2[j][t] = 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NTH; ++t) db1[t] = 0.f;
     }
 
     const long ntiles = (p.ncrop + 31) / 32;
-    for (long tile = (long)blockIdx.x * waves + wave; tile < ntiles; tile += (long)gridDim.x * waves) {
+    const long tstride = (long)gridDim.x * waves;
+
+    f32x4 xr[NX];
+    auto issue_x = [&](long tile) {
         const long q0 = tile * 32;
-        if (lane < 32) {
-            const long q = q0 + lane;
-            srow[lane] = (q < p.ncrop) ? (int)crop_to_pad(p.cm, q) : -1;
+        if (ROWFAST && q0 + 32 <= p.ncrop) {
+            const float* base = p.a + crop_to_pad(p.cm, q0) * C;            // uniform: 32 consecutive padded cells
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xr[j] = *reinterpret_cast<const f32x4*>(base + lane * 4 + j * 256);
+        } else {
+            if (lane < 32) {
+                const long q = q0 + lane;
+                srow[lane] = (q < p.ncrop) ? (int)crop_to_pad(p.cm, q) : -1;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int idx = j * 64 + lane;
+                const int row = idx / (C / 4), c4 = idx - row * (C / 4);
+                const int sr = srow[row];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (sr >= 0) v = *reinterpret_cast<const f32x4*>(p.a + (long)sr * C + 4 * c4);
+                xr[j] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        const int v4_per_row = C >> 2;
-        for (int j = 0; j < (C >> 3); ++j) {
-            const int idx = j * 64 + lane;
-            const int row = idx / v4_per_row, c4 = idx - row * v4_per_row;
-            const int sr = srow[row];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (sr >= 0) v = *reinterpret_cast<const f32x4*>(p.a + (long)sr * C + 4 * c4);
-            float* d = xl + row * XS + 4 * c4;
-            d[0] = v[0];
-            d[1] = v[1];
-            d[2] = v[2];
-            d[3] = v[3];
+    };
+
+    // forward: the next tile's x loads are prefetched in registers; backward: the epilogue needs the registers
+    // (prefetching there makes hipcc spill the prefetch buffer to scratch and serialise it: 9.5 ms vs ~5 ms)
+    constexpr bool PREFETCH_X = !BWD;
+    long tile = (long)blockIdx.x * waves + wave;
+    if (PREFETCH_X && tile < ntiles) issue_x(tile);
+    for (; tile < ntiles; tile += tstride) {
+        const long q0 = tile * 32;
+        const bool full = q0 + 32 <= p.ncrop;
+        if (!PREFETCH_X) issue_x(tile);
+        {
+            float* d0 = xl + (lane / (C / 4)) * XS + 4 * (lane % (C / 4));
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                float* d = d0 + j * (64 / (C / 4)) * XS;
+                d[0] = xr[j][0];
+                d[1] = xr[j][1];
+                d[2] = xr[j][2];
+                d[3] = xr[j][3];
+            }
         }
+        // backward: this tile's dLoss/dout rows go out before the MFMAs so their latency is hidden
+        float gpre[BWD ? 16 : 1][BWD ? DOT : 1];
+        if (BWD) {
+            // rows beyond ncrop are out of the descriptor's range and read as 0
+            const rsrc_t gr = make_rsrc(p.gout + q0 * DO, tile_bytes(p.ncrop - q0, 32, DO * 4));
+            const int vo = 4 * half * DO * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < DOT; ++j)
+                    gpre[r][j] = (j < DO) ? buf_load_f32(gr, vo, ((8 * (r >> 2) + (r & 3)) * DO + j) * 4) : 0.f;
+        }
+        if (PREFETCH_X && tile + tstride < ntiles) issue_x(tile + tstride);
         __builtin_amdgcn_wave_barrier();
 
         f32x16 acc[NTH];
 #pragma unroll
         for (int t = 0; t < NTH; ++t) acc[t] = zero16();
-#pragma unroll 2
-        for (int s = 0; s < C / 2; ++s) {
-            const int k = 2 * s + half;
-            const float av = xl[col * XS + k];
+        {
+            const float* ap = xl + col * XS + half;
+            const float* bp = W1l + (half * 32 + col) * 4;
+#pragma unroll 8
+            for (int s = 0; s < C / 2; ++s) {
+                const float av = ap[2 * s];
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 2 * s * 32 * 4);
 #pragma unroll
-            for (int t = 0; t < NTH; ++t) acc[t] = mfma32(av, W1l[k * HID + t * 32 + col], acc[t]);
+                for (int t = 0; t < NTH; ++t) acc[t] = mfma32(av, b[t], acc[t]);
+            }
         }
 
         if (!BWD) {
-            // v = gelu(u); out[row][j] = b2[j] + sum_hid v[row][hid] * w2[j][hid]
+            // out[row][j] = b2[j] + sum_hid gelu(u[row][hid]) * w2[j][hid]
+            constexpr int NVAL = 16 * DOT;
+            float val[NVAL];
 #pragma unroll
-            for (int t = 0; t < NTH; ++t)
+            for (int r = 0; r < 16; ++r) {
+                float v[NTH];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = gelu_f(acc[t][r] + b1v[t]);
-            for (int j = 0; j < DO; ++j) {
-                float w2v[NTH];
+                for (int t = 0; t < NTH; ++t) v[t] = gelu_f(acc[t][r] + b1v[t]);
 #pragma unroll
-                for (int t = 0; t < NTH; ++t) w2v[t] = W2l[j * HID + t * 32 + col];
-                const float bj = p.b2[j];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int j = 0; j < DOT; ++j) {
                     float s = 0.f;
 #pragma unroll
-                    for (int t = 0; t < NTH; ++t) s += acc[t][r] * w2v[t];
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-                    const long q = q0 + mfma_row(lane, r);
-                    if (col == 0 && q < p.ncrop) p.out[q * DO + j] = s + bj;
+                    for (int t = 0; t < NTH; ++t) s += v[t] * w2r[j][t];
+                    val[r * DOT + j] = s;
                 }
+            }
+            // recursive halving over the 32 lanes of each half-wave: afterwards a lane owns NVAL/32 complete sums
+            int base_idx = 0;
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                const int off = 16 >> step;
+                const int n = NVAL >> (step + 1);
+                const bool hi = (lane & off) != 0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    const float lo_v = val[i], hi_v = val[i + n];
+                    const float send = hi ? lo_v : hi_v;
+                    const float keep = hi ? hi_v : lo_v;
+                    val[i] = keep + __shfl_xor(send, off, 64);
+                }
+                base_idx += hi ? n : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NVAL / 32; ++i) {
+                const int idx = base_idx + i;
+                const int r = idx / DOT, j = idx - r * DOT;
+                const long q = q0 + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (j < DO && (full || q < p.ncrop)) p.out[q * DO + j] = val[i] + p.b2[j];
             }
         } else {
             // gu[row][hid] = (sum_j g[row][j] w2[j][hid]) * gelu'(u);  accumulate d w2, d b1, d b2
+            const rsrc_t ur = make_rsrc(p.gu + q0 * HID, tile_bytes(p.ncrop - q0, 32, HID * 4));
+            const int vo = (4 * half * HID + col) * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long q = q0 + mfma_row(lane, r);
-                const bool ok = q < p.ncrop;
                 float g[DOT];
 #pragma unroll
                 for (int j = 0; j < DOT; ++j) {
-                    g[j] = (ok && j < DO) ? p.gout[q * DO + j] : 0.f;
+                    g[j] = gpre[r][j];
                     db2[j] += g[j];
                 }
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) {
-                    const float u = acc[t][r] + b1v[t];
-                    const float v = gelu_f(u);
+                    float v, d;
+                    gelu_pair(acc[t][r] + b1v[t], v, d);
                     float gvs = 0.f;
 #pragma unroll
                     for (int j = 0; j < DOT; ++j) {
                         gvs += g[j] * w2r[j][t];
                         dw2[j][t] += g[j] * v;
                     }
-                    const float guv = gvs * gelu_grad_f(u);
-                    if (ok) {
-                        p.gu[q * HID + t * 32 + col] = guv;
-                        db1[t] += guv;
-                    }
+                    const float guv = gvs * d;          // rows past ncrop have g == 0 -> guv == 0 (and the store is dropped)
+                    buf_store_f32(guv, ur, vo, ((8 * (r >> 2) + (r & 3)) * HID + t * 32) * 4);
+                    db1[t] += guv;
                 }
             }
         }
@@ -200,27 +273,43 @@ extern "C" long rpb_proj_slots(long ncrop, int C, int DO) {
     return grid * waves;
 }
 
+template <int C, bool BWD, int DOT>
+static void proj_launch_t(ProjArgs& p, int grid, int waves, size_t lds, hipStream_t st) {
+    if (p.cm.W % 32 == 0) {
+        (void)hipFuncSetAttribute((const void*)proj_kernel<C, BWD, DOT, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((proj_kernel<C, BWD, DOT, true>), dim3(grid), dim3(waves * 64), lds, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)proj_kernel<C, BWD, DOT, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((proj_kernel<C, BWD, DOT, false>), dim3(grid), dim3(waves * 64), lds, st, p);
+    }
+}
+
+template <int C>
+static void proj_launch_c(bool bwd, ProjArgs& p, int grid, int waves, size_t lds, hipStream_t st) {
+    const int d = p.DO <= 2 ? 2 : p.DO <= 4 ? 4 : p.DO <= 8 ? 8 : 16;
+#define RPB_PJ(D_)                                                     \
+    if (d == D_) {                                                     \
+        if (bwd) proj_launch_t<C, true, D_>(p, grid, waves, lds, st);  \
+        else proj_launch_t<C, false, D_>(p, grid, waves, lds, st);     \
+    }
+    RPB_PJ(2) RPB_PJ(4) RPB_PJ(8) RPB_PJ(16)
+#undef RPB_PJ
+}
+
 static int proj_launch(bool bwd, ProjArgs& p, hipStream_t st) {
     RPB_REQUIRE(p.a && p.w1 && p.b1 && p.w2 && p.b2, "proj: null pointer");
-    RPB_REQUIRE(p.C % 8 == 0 && p.C >= 8 && p.C <= 256, "proj: C=%d unsupported", p.C);
+    RPB_REQUIRE(p.C == 32 || p.C == 64 || p.C == 128, "proj: C=%d must be 32, 64 or 128", p.C);
     RPB_REQUIRE(p.DO >= 1 && p.DO <= 16, "proj: fc2 out features %d not in [1,16]", p.DO);
     RPB_REQUIRE(p.ncrop > 0 && p.ncrop < (1L << 31), "proj: ncrop out of range");
     const int waves = proj_waves(p.C, p.DO);
     RPB_REQUIRE(waves > 0, "proj: does not fit LDS");
     const int grid = (int)(rpb_proj_slots(p.ncrop, p.C, p.DO) / waves);
     const size_t lds = proj_lds(p.C, p.DO, waves);
-#define RPB_PJ(B_, D_)                                                                                          \
-    {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)proj_kernel<B_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                            (int)lds);                                                                          \
-        hipLaunchKernelGGL((proj_kernel<B_, D_>), dim3(grid), dim3(waves * 64), lds, st, p);                    \
-    }
-    if (!bwd) RPB_PJ(false, 1)
-    else if (p.DO <= 2) RPB_PJ(true, 2)
-    else if (p.DO <= 4) RPB_PJ(true, 4)
-    else if (p.DO <= 8) RPB_PJ(true, 8)
-    else RPB_PJ(true, 16)
-#undef RPB_PJ
+    if (p.C == 32) proj_launch_c<32>(bwd, p, grid, waves, lds, st);
+    else if (p.C == 64) proj_launch_c<64>(bwd, p, grid, waves, lds, st);
+    else proj_launch_c<128>(bwd, p, grid, waves, lds, st);
     RPB_CHECK_LAUNCH("proj");
 }
 
