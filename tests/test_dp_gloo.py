@@ -1,0 +1,91 @@
+"""Data-parallel host logic on CPU with the gloo backend, world_size 2 (the N>1 path of bench.py / Trainer):
+parameter broadcast, per-layer bucket plan, overlapped bucket all-reduce == plain sum over ranks, SyncBN-style
+small reductions and batch sharding.  The HIP kernels themselves need a GPU; what is covered here is everything
+``realpdebench_amd.dp`` adds around them."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from realpdebench_amd.dp import DataParallel, layer_buckets
+from realpdebench_amd.model.fno import FNO3d
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(seed):
+    torch.manual_seed(seed)
+    return FNO3d(2, 3, 3, 3, 32, (4, 8, 8, 2), (4, 8, 8, 2))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _make_model(seed=100 + rank)             # different init per rank on purpose
+        model.bn_running_mean.fill_(float(rank + 1))
+        dp = DataParallel(model)
+        res = {}
+        # 1. rank 0's parameters and buffers were broadcast
+        ref = _make_model(seed=100)
+        res["bcast"] = bool(torch.equal(model.flat.data, ref.flat.data)) and float(model.bn_running_mean[0, 0]) == 1.0
+        # 2. bucketed gradient all-reduce: announce buckets in backward order, rest flushed by finish_step
+        g = torch.full_like(model.flat.data, float(rank + 1))
+        g[::7] = float(10 * (rank + 1))
+        dp.begin_step(g)
+        dp.bucket_ready(g)            # tail (fc1, fc2)
+        dp.bucket_ready(g)            # layer L-1
+        dp.finish_step(g)             # remaining layers + head
+        expect = torch.full_like(g, 3.0)
+        expect[::7] = 30.0
+        res["allreduce"] = bool(torch.equal(g, expect))
+        # 3. small synchronous reduction used for the BatchNorm statistics (fp64)
+        s = torch.tensor([1.0 + rank, 2.0], dtype=torch.float64)
+        dp.all_reduce_sum(s)
+        res["bn"] = s.tolist() == [3.0, 4.0]
+        res["shard"] = list(dp.shard(8))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_plan_covers_arena_in_backward_order():
+    m = _make_model(0)
+    total = m.flat.numel()
+    b = layer_buckets(m._seg, m.n_layers, total)
+    assert len(b) == m.n_layers + 1
+    # disjoint cover
+    cover = sorted(b)
+    assert cover[0][0] == 0 and cover[-1][1] == total
+    for (s0, e0), (s1, e1) in zip(cover, cover[1:]):
+        assert e0 == s1
+    # completion order of the backward pass: tail first, then layers L-1..1, then head (fc0 + layer 0)
+    assert b[0][0] == m._seg["fc1.weight"][0]
+    assert b[1][0] == m._seg[f"spec.{m.n_layers - 1}"][0]
+    assert b[-1][0] == 0 and b[-1][1] == m._seg["spec.1"][0]
+    # the spectral weights dominate each per-layer bucket
+    assert m._seg["spec.1"][1] > 0.9 * (b[2][1] - b[2][0])
+
+
+def test_dataparallel_world2_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        assert res[r]["bcast"], "parameters / buffers were not broadcast from rank 0"
+        assert res[r]["allreduce"], "bucketed all-reduce != sum over ranks"
+        assert res[r]["bn"]
+    assert res[0]["shard"] == [0, 1, 2, 3] and res[1]["shard"] == [4, 5, 6, 7]
