@@ -1,0 +1,136 @@
+"""``python -m realpdebench_amd.train --config configs/cylinder/fno.yaml`` -- the reference's training entrypoint
+(realpdebench/train.py) on the MI355X backend: same flags, same YAML merge, same checkpoint format.
+
+Differences, all on the hot path (train.py:321-342): the step is the fused ``Trainer.step`` (no per-step ``.item()``
+syncs; the loss is read back once per logging interval) and, when launched under ``torch.distributed.run`` with
+several processes, batches are sharded across GPUs and gradients reduced with RCCL (``dp.DataParallel``)."""
+import argparse
+import datetime
+import logging
+import os
+import time
+
+import torch
+from torch.utils.data import DataLoader
+
+from .data import make_datasets
+from .data_normalizer import GaussianNormalizer, IdentityNormalizer
+from .model import load_model
+from .trainer import Trainer
+from .utils import add_args_from_config, cycle, resolve_config, set_seed, setup_logging
+
+parser = argparse.ArgumentParser(description="Training Configurations")
+parser.add_argument("--config", type=str, default="configs/cylinder/fno.yaml")
+parser.add_argument("--gpu", type=int, default=0)
+parser.add_argument("--train_data_type", type=str, default="numerical", help="numerical | real")
+parser.add_argument("--is_finetune", action="store_true", help="enable finetuning mode")
+parser.add_argument("--dataset_factory", type=str, default=None, help="module:function -> (train, val, stats)")
+parser.add_argument("--max_updates", type=int, default=None, help="stop early (smoke runs); the schedule still uses num_update")
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    args.config = resolve_config(args.config)
+    args = add_args_from_config(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    if not torch.cuda.is_available():
+        raise SystemExit("realpdebench_amd.train needs an MI355X: there is no CPU fallback path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    set_seed(args.seed)
+
+    exp_path = os.path.join(args.results_path, args.model_name,
+                            f"{args.exp_name}_{args.train_data_type}_{args.is_finetune}",
+                            datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+    if rank == 0:
+        os.makedirs(exp_path, exist_ok=True)
+        setup_logging(exp_path)
+        logging.info(f"args: {args}")
+
+    train_dataset, val_dataset, stats = make_datasets(args)
+    per_rank_bs = args.train_batch_size // world
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=args.seed)
+    train_loader = cycle(DataLoader(train_dataset, batch_size=per_rank_bs, shuffle=sampler is None, sampler=sampler,
+                                    pin_memory=True, num_workers=args.num_workers, drop_last=True))
+    val_loader = DataLoader(val_dataset, batch_size=args.test_batch_size, shuffle=False, num_workers=args.num_workers)
+    if args.normalizer == "gaussian":
+        if stats is None:
+            raise ValueError("normalizer: gaussian needs (mean_in, mean_tgt, std_in, std_tgt) from the dataset factory")
+        normalizer = GaussianNormalizer(*stats, device=device)
+    elif args.normalizer == "none":
+        normalizer = IdentityNormalizer(device)
+    else:
+        raise ValueError(f"Normalizer {args.normalizer} not supported")
+
+    model = load_model(train_dataset, device=device, **vars(args))
+    if args.is_finetune:
+        model.load_checkpoint(args.checkpoint_path, device)
+        logging.info(f"Checkpoint {args.checkpoint_path} loaded.")
+    if world > 1:
+        from .dp import DataParallel
+        DataParallel(model)
+    trainer = Trainer(model, lr=args.lr, num_update=args.num_update, scheduler=args.scheduler,
+                      step_size=args.step_size, clip_grad_norm=args.clip_grad_norm)
+
+    n_iter = args.num_update if args.max_updates is None else min(args.num_update, args.max_updates)
+    every = max(1, int(args.num_update / 50))                       # train.py:344
+    all_train_losses, all_val_losses = [], {"normalized_mse": [], "rmse": [], "mae": [], "rel_l2_error": []}
+    best_val, best_it = float("inf"), 0
+    pending, start = [], time.time()
+    for iteration in range(1, n_iter + 1):
+        inp, tgt = next(train_loader)
+        inp, tgt = normalizer.preprocess(inp, tgt)
+        pending.append(trainer.step(inp, tgt).clone())              # device scalar, no sync
+        if iteration % every == 0 or iteration == n_iter:
+            all_train_losses += [float(v) for v in torch.cat(pending).cpu()]    # ONE sync per interval
+            pending = []
+            model.eval()
+            se = ae = ref2 = nmse = 0.0
+            cnt = 0
+            with torch.no_grad():
+                for vi, vt in val_loader:
+                    vi, vt = normalizer.preprocess(vi, vt)
+                    pred = model(vi)
+                    nmse += float(((pred - vt) ** 2).mean()) * vi.shape[0]
+                    _, p = normalizer.postprocess(vi, pred)
+                    _, t = normalizer.postprocess(vi, vt)
+                    se += float(((p - t) ** 2).sum())
+                    ae += float((p - t).abs().sum())
+                    ref2 += float((t ** 2).sum())
+                    cnt += t.numel()
+            n_val = len(val_loader.dataset)
+            rmse = (se / cnt) ** 0.5
+            all_val_losses["normalized_mse"].append(nmse / n_val)
+            all_val_losses["rmse"].append(rmse)
+            all_val_losses["mae"].append(ae / cnt)
+            all_val_losses["rel_l2_error"].append((se / max(ref2, 1e-30)) ** 0.5)
+            if rmse < best_val:
+                best_val, best_it = rmse, iteration
+            if rank == 0:
+                logging.info(f"Iteration {iteration}, train loss {sum(all_train_losses[-every:]) / every:.5f}, "
+                             f"val nmse {nmse / n_val:.5f}, rmse {rmse:.5f}, lr {trainer.current_lr():.3e}")
+                torch.save({"model_state_dict": model.state_dict(), "train_losses": all_train_losses,
+                            "val_losses": all_val_losses, "iteration": iteration, "best_iteration": best_it,
+                            "best_val_loss": best_val}, os.path.join(exp_path, f"model_{iteration:04d}.pth"))
+    torch.cuda.synchronize()
+    if rank == 0:
+        dt = time.time() - start
+        logging.info(f"Training complete, best iteration is {best_it}, time cost is {dt / 60:.2f} min "
+                     f"({n_iter * args.train_batch_size / dt:.1f} samples/s incl. validation)")
+        logging.info(f"Results saved at {exp_path}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return exp_path
+
+
+if __name__ == "__main__":
+    main()

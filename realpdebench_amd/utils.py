@@ -1,0 +1,47 @@
+"""Host glue with the reference's semantics (realpdebench/utils/utils.py): YAML -> args merge, seeding, logging."""
+import logging
+import os
+
+import numpy as np
+import torch
+import yaml
+
+
+def add_args_from_config(args):
+    """Every YAML key not already a CLI argument becomes ``args.<key>`` (utils.py:13-22)."""
+    existing = set(vars(args).keys())
+    with open(args.config, "r") as f:
+        config = yaml.safe_load(f)
+    for key, value in config.items():
+        if key not in existing:
+            setattr(args, key, value)
+    return args
+
+
+def resolve_config(path):
+    """Falls back to a package-relative path like the reference does (train.py:58-61)."""
+    if not os.path.exists(path):
+        cand = os.path.join(os.path.dirname(__file__), path)
+        if os.path.exists(cand):
+            return cand
+    return path
+
+
+def set_seed(seed):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def setup_logging(exp_path, is_train=True):
+    log_filename = os.path.join(exp_path, "training.log" if is_train else "eval.log")
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
+                        handlers=[logging.FileHandler(log_filename), logging.StreamHandler()], force=True)
+    logging.info(f"Logging initialized at {log_filename}")
+
+
+def cycle(iterable):
+    while True:
+        for x in iterable:
+            yield x
