@@ -41,8 +41,14 @@ int rpb_lift_bwd(const float* g_out, const float* x, const float* gt, const floa
 /* K2/K4  one truncated-DFT stage: out[g][o][n] (+)= sum_k M[o][k] * in[g][k][n], n contiguous.
  *     Replaces torch.fft.rfftn / torch.fft.irfftn of SpectralConv3d.forward (fno.py:48, :63) without ever
  *     materialising the discarded 97 % of the spectrum (fno.py:51-60).  Inputs k >= k_valid are treated as 0. */
+/*     Lazy activation (all `xf_*` argument groups below): when xf_mean != NULL the input tensor is the PRE-BatchNorm
+ *     output s of the producing layer and the kernel applies act(xf_gamma*(s-xf_mean)*xf_invstd+xf_beta), act = exact
+ *     GELU if xf_gelu else identity, per channel while loading -- fno.py:117-119 fused into the consumer, so the
+ *     normalised/activated tensor is never written to HBM.  For rpb_axis_gemm this requires N == channels. */
 int rpb_axis_gemm(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g_stride,
-                  long in_k_stride, long out_g_stride, long out_o_stride, int k_valid, int accumulate, void* stream);
+                  long in_k_stride, long out_g_stride, long out_o_stride, int k_valid, int accumulate,
+                  const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
+                  void* stream);
 
 /* K3  per-mode complex channel contraction.  compl_mul3d / the four corner-block einsums, fno.py:41-43, 53-60,
  *     and their autograd (dgrad: gX = gY conj(W); wgrad: gW = conj(X) gY). */
@@ -60,13 +66,15 @@ int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, i
 long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec);
 int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
                  float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w, int gather, int T,
-                 int H, int W, int Tp, int Hp, int Wp_pad, void* stream);
+                 int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean, const float* xf_invstd,
+                 const float* xf_gamma, const float* xf_beta, int xf_gelu, void* stream);
 
 /*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
  *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */
 long rpb_cell_wgrad_slots(long ncell, int CO, int CI);
 int rpb_cell_wgrad(const float* gs, const float* x, float* part, long ncell, int CO, int CI, int crop, int T, int H,
-                   int W, int Tp, int Hp, int Wp, void* stream);
+                   int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma,
+                   const float* xf_beta, int xf_gelu, void* stream);
 
 /* K6  BatchNorm3d (+ exact-erf GELU).  fno.py:117-119; training statistics include the padded cells. */
 /*     out[j] (+)= scale * sum_r part[r*row_stride + j], j < L, accumulated in fp64 (deterministic, no atomics). */
@@ -88,10 +96,12 @@ int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const f
  *     [ncrop][128] plus partial rows [rpb_proj_slots(...)][DO*128 + 128 + DO] for d fc2.weight, d fc1.bias, d fc2.bias. */
 long rpb_proj_slots(long ncrop, int C, int DO);
 int rpb_proj_fwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
-                 float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, void* stream);
+                 float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean,
+                 const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu, void* stream);
 int rpb_proj_bwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                  const float* gout, float* gu, float* part, long ncrop, int C, int DO, int T, int H, int W, int Tp,
-                 int Hp, int Wp, void* stream);
+                 int Hp, int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta,
+                 int xf_gelu, void* stream);
 
 /*     MSE.  realpdebench/utils/metrics.py:11-13 + `.mean()` of train.py:328 and its gradient. */
 int rpb_mse_rows(void);

@@ -19,14 +19,14 @@ SIGNATURES = {
     "rpb_lift_pad_fwd": (_I, "ppppppp" + "iiiiiiiii" + "p"),
     "rpb_lift_bwd_rows": (_I, ""),
     "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
-    "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "p"),
+    "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "ppppi" + "p"),
     "rpb_mode_contract_fwd": (_I, "ppp" + "iii" + "p"),
     "rpb_mode_contract_dgrad": (_I, "ppp" + "iii" + "p"),
     "rpb_mode_contract_wgrad": (_I, "ppp" + "iiii" + "p"),
     "rpb_cell_mix_stat_rows": (_L, "liiiii"),
-    "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "p"),
+    "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "ppppi" + "p"),
     "rpb_cell_wgrad_slots": (_L, "lii"),
-    "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "p"),
+    "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "ppppi" + "p"),
     "rpb_reduce_partials": (_I, "p" + "lll" + "pp" + "d" + "i" + "p"),
     "rpb_bn_finalize": (_I, "p" + "d" + "ff" + "pppp" + "i" + "p"),
     "rpb_bn_eval_prep": (_I, "p" + "f" + "p" + "i" + "p"),
@@ -35,8 +35,8 @@ SIGNATURES = {
     "rpb_bn_bwd_reduce": (_I, "ppppppp" + "l" + "ii" + "p"),
     "rpb_bn_bwd_apply": (_I, "ppppppp" + "d" + "p" + "l" + "ii" + "p"),
     "rpb_proj_slots": (_L, "lii"),
-    "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "p"),
-    "rpb_proj_bwd": (_I, "pppppppp" + "l" + "ii" + "iiiiii" + "p"),
+    "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "p"),
+    "rpb_proj_bwd": (_I, "pppppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "p"),
     "rpb_mse_rows": (_I, ""),
     "rpb_mse": (_I, "ppppp" + "l" + "f" + "p"),
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),

@@ -48,7 +48,7 @@ template <int OT, int NV>
 __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ M, int G, int K, int O, int N,
                                                         long in_g, long in_k, long out_g, long out_o, int k_valid,
-                                                        int accumulate) {
+                                                        int accumulate, XForm xf) {
     extern __shared__ float Mlds[];   // [Kp][Op]
     typedef typename VecN<NV>::T vec;
     const int ot_total = (O + 31) / 32;
@@ -84,6 +84,14 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
 
         vec ba[8], bb[8];
         const vec vz = {};
+        // lazy BatchNorm(+GELU) of the producing layer, applied to the data operand right before the MFMA
+        // (N == C here, so the n index IS the channel and a lane keeps its NV channels for the whole item)
+        const bool has_xf = xf.mean != nullptr;
+        XParam xp[NV];
+        if (has_xf) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xp[v] = xf_load(xf, nc * 32 * NV + NV * col + v);
+        }
         // chunk c covers k in [16c, 16c+16); lane (half) takes k = 16c + 2s + half
         auto load_chunk = [&](int c, vec (&b)[8]) {
             const float* cp = ip + (long)(16 * c) * in_k;                   // uniform
@@ -97,8 +105,18 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
                                ? *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k) : vz;
             }
         };
-        auto compute_chunk = [&](int c, const vec (&b)[8]) {
+        auto compute_chunk = [&](int c, vec (&b)[8]) {
             const float* mp = Mlds + (16 * c + half) * Op + oc * OT * 32 + col;
+            if (has_xf) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if constexpr (NV == 1) b[s] = xf_apply(b[s], xp[0], xf.gelu != 0);
+                    else {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) b[s][v] = xf_apply(b[s][v], xp[v], xf.gelu != 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -150,7 +168,7 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
 
 template <int OT, int NV>
 static int launch_axis(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g, long in_k,
-                       long out_g, long out_o, int k_valid, int accumulate, hipStream_t stream) {
+                       long out_g, long out_o, int k_valid, int accumulate, XForm xf, hipStream_t stream) {
     const int ot_total = (O + 31) / 32;
     const int och = (ot_total + OT - 1) / OT;
     const int Op = och * OT * 32;
@@ -166,13 +184,17 @@ static int launch_axis(const float* in, float* out, const float* M, int G, int K
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((axis_gemm_kernel<OT, NV>), dim3((unsigned)grid), dim3(waves * 64), lds, stream, in, out, M, G, K,
-                       O, N, in_g, in_k, out_g, out_o, k_valid, accumulate);
+                       O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf);
     RPB_CHECK_LAUNCH("axis_gemm");
 }
 
 extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g,
-                             long in_k, long out_g, long out_o, int k_valid, int accumulate, void* stream) {
+                             long in_k, long out_g, long out_o, int k_valid, int accumulate, const float* xf_mean,
+                             const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
+                             void* stream) {
     RPB_REQUIRE(in && out && M, "axis_gemm: null pointer");
+    const XForm xf{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
+    if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta && N <= 128, "axis_gemm: input transform needs all four vectors and N == channels");
     RPB_REQUIRE(G > 0 && K > 0 && O > 0 && N > 0, "axis_gemm: bad sizes G=%d K=%d O=%d N=%d", G, K, O, N);
     RPB_REQUIRE(N % 32 == 0, "axis_gemm: N=%d must be a multiple of 32", N);
     RPB_REQUIRE(k_valid >= 0 && k_valid <= K, "axis_gemm: k_valid=%d out of range", k_valid);
@@ -186,7 +208,7 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     if (NV == 2 && ((in_g | in_k | out_g | out_o) & 1)) NV = 1;
 #define RPB_AX(OT_, NV_)                                                                                        \
     if (OT == OT_ && NV == NV_)                                                                                 \
-        return launch_axis<OT_, NV_>(in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, st);
+        return launch_axis<OT_, NV_>(in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf, st);
     RPB_AX(1, 1) RPB_AX(1, 2) RPB_AX(1, 4) RPB_AX(2, 1) RPB_AX(2, 2) RPB_AX(3, 1) RPB_AX(3, 2)
 #undef RPB_AX
     RPB_FAIL(RPB_ERR_UNSUPPORTED, "axis_gemm: no instantiation OT=%d NV=%d", OT, NV);

@@ -29,6 +29,7 @@ struct CellMixArgs {
     int transpose_w;
     int gather;           // 1: out cells are padded cells, input row = pad_to_crop(cell) (zeros in the margin)
     CropMap cm;
+    XForm xf;             // lazy BatchNorm(+GELU) applied to x on its way into LDS
 };
 
 #ifndef CM_MAX_THREADS
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
         bv[t] = a.bias ? a.bias[t * 32 + col] : 0.f;
     }
 
+    const bool has_xf = a.xf.mean != nullptr;          // only used with the contiguous (non-gather) x layout
+    XParam xp4[4];
+    if (has_xf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xp4[k] = xf_load(a.xf, 4 * (lane % (KC / 4)) + k);
+    }
     f32x4 xr[NX];
     auto issue_x = [&](long tile) {
         const long cell0 = tile * 32;
@@ -154,9 +161,15 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
     for (; tile < ntiles; tile += tstride) {
         const long cell0 = tile * 32;
         const bool full = cell0 + 32 <= a.ncell;                  // uniform
-        // ---- 1. registers -> wave-private transposing LDS tile
+        // ---- 1. registers -> wave-private transposing LDS tile (lazy BN+GELU of the producer applied here)
         {
             float* d0 = xl + (lane / (KC / 4)) * XS + 4 * (lane % (KC / 4));
+            if (has_xf) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xr[j][k] = xf_apply(xr[j][k], xp4[k], a.xf.gelu != 0);
+            }
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 float* d = d0 + j * (64 / (KC / 4)) * XS;         // 64 float4 = 256/KC rows further down
@@ -342,8 +355,11 @@ extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int W
 
 extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW,
                             float* out, float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w,
-                            int gather, int T, int H, int W, int Tp, int Hp, int Wp_pad, void* stream) {
+                            int gather, int T, int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean,
+                            const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
+                            void* stream) {
     RPB_REQUIRE(x && Wm && out, "cell_mix: null pointer");
+    if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta && !gather, "cell_mix: bad input-transform arguments");
     RPB_REQUIRE(ncell > 0 && ncell < (1L << 31), "cell_mix: ncell=%ld out of range", ncell);
     RPB_REQUIRE(KC == 32 || KC == 64 || KC == 128, "cell_mix: KC=%d must be 32, 64 or 128", KC);
     RPB_REQUIRE(CO == 32 || CO == 64 || CO == 128, "cell_mix: CO=%d must be 32, 64 or 128", CO);
@@ -356,6 +372,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     a.ncell = ncell; a.KC = KC; a.CO = CO; a.K2 = spec ? K2 : 0; a.Wp = spec ? Wp : 1;
     a.transpose_w = transpose_w; a.gather = gather;
     a.cm = CropMap{T, H, W, Tp, Hp, Wp_pad};
+    a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     const int grid = (int)(rpb_cell_mix_stat_rows(ncell, KC, CO, K2, Wp, spec) / waves);
     hipStream_t st = (hipStream_t)stream;
     const bool stats = stats_part != nullptr;
@@ -385,6 +402,7 @@ struct WgradArgs {
     int CO, CI;
     int crop;          // 1: x row = crop_to_pad(cell)
     CropMap cm;
+    XForm xf;          // lazy BatchNorm(+GELU) applied to x before the MFMA
 };
 
 // Channel <-> MFMA index mapping: a lane loads NTO (resp. NTI) CONTIGUOUS channels of one cell with one vector
@@ -424,6 +442,12 @@ __global__ __launch_bounds__(512) void cell_wgrad_kernel(WgradArgs a) {
     veci xa[8], xb[8];
     const veco zo = {};
     const veci zi = {};
+    const bool has_xf = a.xf.mean != nullptr;
+    XParam xp[NTI];
+    if (has_xf) {
+#pragma unroll
+        for (int i = 0; i < NTI; ++i) xp[i] = xf_load(a.xf, col * NTI + i);
+    }
 
     auto load_half = [&](long tile, int h, veco (&gv)[8], veci (&xv)[8]) {
         const long cell0 = tile * 32 + h * 16;                   // uniform
@@ -457,16 +481,24 @@ __global__ __launch_bounds__(512) void cell_wgrad_kernel(WgradArgs a) {
             }
         }
     };
+    // NOTE: cells past ncell load gs == 0, so whatever the transform makes of their x never reaches dW
     auto compute_half = [&](const veco (&gv)[8], const veci (&xv)[8]) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < 8; ++s) {
+            float xt[NTI];
+#pragma unroll
+            for (int i = 0; i < NTI; ++i) {
+                xt[i] = vget<NTI>(xv[s], i);
+                if (has_xf) xt[i] = xf_apply(xt[i], xp[i], a.xf.gelu != 0);
+            }
 #pragma unroll
             for (int o = 0; o < NTO; ++o) {
                 const float av = vget<NTO>(gv[s], o);
                 bsum[o] += av;
 #pragma unroll
-                for (int i = 0; i < NTI; ++i) acc[o][i] = mfma32(av, vget<NTI>(xv[s], i), acc[o][i]);
+                for (int i = 0; i < NTI; ++i) acc[o][i] = mfma32(av, xt[i], acc[o][i]);
             }
+        }
     };
 
     long tile = tslot;
@@ -510,8 +542,10 @@ extern "C" long rpb_cell_wgrad_slots(long ncell, int CO, int CI) {
 }
 
 extern "C" int rpb_cell_wgrad(const float* gs, const float* x, float* part, long ncell, int CO, int CI, int crop,
-                              int T, int H, int W, int Tp, int Hp, int Wp, void* stream) {
+                              int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd,
+                              const float* xf_gamma, const float* xf_beta, int xf_gelu, void* stream) {
     RPB_REQUIRE(gs && x && part, "cell_wgrad: null pointer");
+    if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta, "cell_wgrad: bad input-transform arguments");
     RPB_REQUIRE(ncell > 0 && ncell < (1L << 31), "cell_wgrad: ncell out of range");
     int NTO, NTI;
     wgrad_shape(CO, CI, NTO, NTI);
@@ -522,6 +556,7 @@ extern "C" int rpb_cell_wgrad(const float* gs, const float* x, float* part, long
     WgradArgs a;
     a.gs = gs; a.x = x; a.part = part; a.ncell = ncell; a.CO = CO; a.CI = CI; a.crop = crop;
     a.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     hipStream_t st = (hipStream_t)stream;
 #define RPB_WG(O_, I_)                                                                         \
     if (CO == O_ && CI == I_) {                                                                \

@@ -99,6 +99,24 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Lazy activation: a layer output a = act(gamma * (s - mean) * invstd + beta) is never written to HBM; its consumers
+// read the pre-BatchNorm tensor s and apply this per-channel transform on load (fno.py:117-119 fused into :48,:115,:123).
+struct XForm {
+    const float* mean;      // nullptr => identity (plain tensor)
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    int gelu;
+};
+struct XParam {
+    float mu, is, ga, be;
+};
+__device__ __forceinline__ XParam xf_load(const XForm& x, int c) { return XParam{x.mean[c], x.invstd[c], x.gamma[c], x.beta[c]}; }
+__device__ __forceinline__ float xf_apply(float v, const XParam& p, bool gelu) {
+    const float z = (v - p.mu) * p.is * p.ga + p.be;
+    return gelu ? gelu_f(z) : z;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

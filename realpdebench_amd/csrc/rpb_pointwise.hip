@@ -70,50 +70,53 @@ extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh
 }
 
 // d fc0.weight[o][j] = sum_cells g[cell][o] * feat[cell][j],  d fc0.bias[o] = sum_cells g[cell][o]
-// part row layout: [C*F] weight grad (o*F + j) then [C] bias grad
+// part row layout: [C*F] weight grad (o*F + j) then [C] bias grad.
+// A block walks whole (b,t,h) rows (row decode is scalar); a thread owns 4 channels (one 16 B load per cell) and
+// every (256/(C/4))-th cell of the row, so 16 independent loads are in flight per thread group.
 __global__ __launch_bounds__(PW_THREADS) void lift_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                               const float* __restrict__ gt, const float* __restrict__ gh,
                                                               const float* __restrict__ gw, float* __restrict__ part,
                                                               long ncrop, int Cin, int C, CropMap cm) {
-    extern __shared__ float red[];  // [nsub][C][F+1]
+    extern __shared__ float red[];  // [nsub][F+1][C]
     const int F = Cin + 3;
-    const int o = threadIdx.x % C, sub = threadIdx.x / C, nsub = blockDim.x / C;
-    float acc[LIFT_FMAX + 1];
+    const int c4n = C >> 2;
+    const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = blockDim.x / c4n;
+    const int c = c4 * 4;
+    f32x4 acc[LIFT_FMAX + 1];
 #pragma unroll
-    for (int j = 0; j <= LIFT_FMAX; ++j) acc[j] = 0.f;
-    if (sub < nsub) {
-        const long nrows = ncrop / cm.W;                             // (b,t,h) rows of W cells
-        for (long row = blockIdx.x; row < nrows; row += gridDim.x) { // row decode is block-uniform (scalar ALU)
-            const int h = (int)(row % cm.H);
-            const long r2 = row / cm.H;
-            const int t = (int)(r2 % cm.T);
-            const long b = r2 / cm.T;
-            const long p0 = ((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp;
-            const float ft = gt[t], fh = gh[h];
-            for (int w = sub; w < cm.W; w += nsub) {
-                const float gv = g[(p0 + w) * C + o];
-                const float* xp = x + (row * cm.W + w) * Cin;
+    for (int j = 0; j <= LIFT_FMAX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long nrows = ncrop / cm.W;
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int h = (int)(row % cm.H);
+        const long r2 = row / cm.H;
+        const int t = (int)(r2 % cm.T);
+        const long b = r2 / cm.T;
+        const float* gp = g + (((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp) * C + c;
+        const float* xp = x + row * cm.W * Cin;
+        const float ft = gt[t], fh = gh[h];
+#pragma unroll 4
+        for (int w = sub; w < cm.W; w += nsub) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + (long)w * C);
 #pragma unroll
-                for (int j = 0; j < LIFT_FMAX; ++j) {
-                    if (j < F) {
-                        const float f = (j < Cin) ? xp[j] : (j == Cin ? ft : (j == Cin + 1 ? fh : gw[w]));
-                        acc[j] += gv * f;
-                    }
+            for (int j = 0; j < LIFT_FMAX; ++j) {
+                if (j < F) {
+                    const float f = (j < Cin) ? xp[w * Cin + j] : (j == Cin ? ft : (j == Cin + 1 ? fh : gw[w]));
+                    acc[j] += gv * f;
                 }
-                acc[LIFT_FMAX] += gv;
             }
+            acc[LIFT_FMAX] += gv;
         }
-#pragma unroll
-        for (int j = 0; j < LIFT_FMAX; ++j)
-            if (j < F) red[(sub * C + o) * (F + 1) + j] = acc[j];
-        red[(sub * C + o) * (F + 1) + F] = acc[LIFT_FMAX];
     }
+#pragma unroll
+    for (int j = 0; j < LIFT_FMAX; ++j)
+        if (j < F) *reinterpret_cast<f32x4*>(red + ((long)(sub * (F + 1) + j)) * C + c) = acc[j];
+    *reinterpret_cast<f32x4*>(red + ((long)(sub * (F + 1) + F)) * C + c) = acc[LIFT_FMAX];
     __syncthreads();
     float* prow = part + (long)blockIdx.x * ((long)C * F + C);
     for (int idx = threadIdx.x; idx < C * (F + 1); idx += blockDim.x) {
-        const int oo = idx / (F + 1), j = idx - oo * (F + 1);
+        const int j = idx / C, oo = idx - j * C;
         float s = 0.f;
-        for (int k = 0; k < nsub; ++k) s += red[(k * C + oo) * (F + 1) + j];
+        for (int k = 0; k < nsub; ++k) s += red[((long)(k * (F + 1) + j)) * C + oo];
         if (j < F) prow[oo * F + j] = s;
         else prow[C * F + oo] = s;
     }
@@ -125,10 +128,11 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
                             float* part, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp,
                             void* stream) {
     RPB_REQUIRE(g && x && gt && gh && gw && part, "lift_bwd: null pointer");
-    RPB_REQUIRE(Cin + 3 <= LIFT_FMAX && C <= PW_THREADS && PW_THREADS % C == 0, "lift_bwd: C=%d Cin=%d unsupported", C, Cin);
+    RPB_REQUIRE(Cin + 3 <= LIFT_FMAX && C % 4 == 0 && PW_THREADS % (C / 4) == 0, "lift_bwd: C=%d Cin=%d unsupported", C,
+                Cin);
     const long ncrop = (long)B * T * H * W;
-    const int nsub = PW_THREADS / C;
-    const size_t lds = (size_t)nsub * C * (Cin + 4) * 4;
+    const int nsub = PW_THREADS / (C / 4);
+    const size_t lds = (size_t)nsub * (Cin + 4) * C * 4;
     hipLaunchKernelGGL(lift_bwd_kernel, dim3(rpb_lift_bwd_rows()), dim3(PW_THREADS), lds, (hipStream_t)stream, g, x, gt,
                        gh, gw, part, ncrop, Cin, C, CropMap{T, H, W, Tp, Hp, Wp});
     RPB_CHECK_LAUNCH("lift_bwd");

@@ -28,6 +28,7 @@ struct ProjArgs {
     long ncrop;
     int C, DO;
     CropMap cm;
+    XForm xf;            // lazy BatchNorm of the last Fourier layer (no GELU there, fno.py:118)
 };
 
 // v = gelu(u), d = gelu'(u) with ONE erf evaluation
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
     const long ntiles = (p.ncrop + 31) / 32;
     const long tstride = (long)gridDim.x * waves;
 
+    const bool has_xf = p.xf.mean != nullptr;
+    XParam xp4[4];
+    if (has_xf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xp4[k] = xf_load(p.xf, 4 * (lane % (C / 4)) + k);
+    }
     f32x4 xr[NX];
     auto issue_x = [&](long tile) {
         const long q0 = tile * 32;
@@ -122,6 +129,12 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
         if (!PREFETCH_X) issue_x(tile);
         {
             float* d0 = xl + (lane / (C / 4)) * XS + 4 * (lane % (C / 4));
+            if (has_xf) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xr[j][k] = xf_apply(xr[j][k], xp4[k], p.xf.gelu != 0);
+            }
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 float* d = d0 + j * (64 / (C / 4)) * XS;
@@ -315,9 +328,11 @@ static int proj_launch(bool bwd, ProjArgs& p, hipStream_t st) {
 
 extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
                             float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp,
-                            void* stream) {
+                            const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta,
+                            int xf_gelu, void* stream) {
     RPB_REQUIRE(out, "proj_fwd: null out");
     ProjArgs p{};
+    p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
     return proj_launch(false, p, (hipStream_t)stream);
@@ -325,9 +340,11 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
 
 extern "C" int rpb_proj_bwd(const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
                             const float* gout, float* gu, float* part, long ncrop, int C, int DO, int T, int H, int W,
-                            int Tp, int Hp, int Wp, void* stream) {
+                            int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma,
+                            const float* xf_beta, int xf_gelu, void* stream) {
     RPB_REQUIRE(gout && gu && part, "proj_bwd: null pointer");
     ProjArgs p{};
+    p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.gu = gu; p.part = part;
     p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};

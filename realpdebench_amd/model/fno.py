@@ -32,9 +32,10 @@ class _Workspace:
         self.d, self.training = d, training
         C, L, plan = model.width, model.n_layers, model.plan
         f = dict(device=device, dtype=torch.float32)
-        n_act = L + 1 if training else 2
-        self.A = [torch.empty(d.ncell, C, **f) for _ in range(n_act)]       # layer inputs / outputs
-        self.S = [torch.empty(d.ncell, C, **f) for _ in range(L if training else 1)]   # pre-BN
+        # Lazy activations: a_{l+1} = act(BN(s_l)) is never materialised (its consumers transform s_l on load), so the
+        # step keeps the lifted input A0 and the pre-BatchNorm tensors S[l] only.  Eval ping-pongs two S buffers.
+        self.A0 = torch.empty(d.ncell, C, **f)
+        self.S = [torch.empty(d.ncell, C, **f) for _ in range(L if training else 2)]
         G1, N1 = B * d.Tp * d.Hp, 2 * plan.KW * C
         self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
         self.Y2 = torch.empty(B * d.Tp * 2 * plan.KH * plan.KW * C, **f)     # after H stage
@@ -262,14 +263,15 @@ class FNO3d(Model):
         return self._ws[key]
 
     # ------------------------------------------------------------------ spectral stages
-    def _spectral_forward_stages(self, x, ws, xh, mats, first_layer):
-        """x [cells][C] -> truncated spectrum xh [B][2][M][C] with stage matrices ``mats`` = (W, H, T)."""
+    def _spectral_forward_stages(self, x, ws, xh, mats, first_layer, xf=None):
+        """x [cells][C] -> truncated spectrum xh [B][2][M][C] with stage matrices ``mats`` = (W, H, T).
+        ``xf``: lazy BatchNorm(+GELU) of the producing layer, applied while the W stage loads ``x``."""
         d, p, C = ws.d, self.plan, self.width
         m3, KH, KT = p.KW, p.KH, p.KT
         MW, MH, MT = mats
         N2, N3 = m3 * C, KH * m3 * C
         ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
-                      k_valid=d.W if first_layer else None)
+                      k_valid=d.W if first_layer else None, xf=xf)
         ops.axis_gemm(ws.Y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
                       k_valid=2 * d.H if first_layer else None)
         ops.axis_gemm(ws.Y2, xh, MT, d.B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3,
@@ -285,22 +287,26 @@ class FNO3d(Model):
         ops.axis_gemm(ws.Y2, ws.Y1, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
 
     # ------------------------------------------------------------------ forward / backward pipelines
+    def _layer_xf(self, ws, l, training):
+        """Lazy-activation descriptor of layer ``l``'s output: (mean, invstd, gamma, beta, gelu)."""
+        mean = ws.mean[l] if training else self.bn_running_mean[l]
+        return (mean, ws.invstd[l], self.pview(f"bns.{l}.weight"), self.pview(f"bns.{l}.bias"), l < self.n_layers - 1)
+
     def _forward_impl(self, x, ws, training):
         d, C, L = ws.d, self.width, self.n_layers
         grids, plan = self._consts(x.device)
         P = self.pview
-        ops.lift_pad_fwd(x, grids, P("fc0.weight"), P("fc0.bias"), ws.A[0], d)
+        ops.lift_pad_fwd(x, grids, P("fc0.weight"), P("fc0.bias"), ws.A0, d)
         world = self.dp.world_size if (self.dp is not None and training) else 1
+        a_in, xf = ws.A0, None                   # layer input tensor and its lazy transform
         for l in range(L):
-            a_in = ws.A[l] if training else ws.A[l % 2]
-            a_out = ws.A[l + 1] if training else ws.A[(l + 1) % 2]
-            s = ws.S[l] if training else ws.S[0]
+            s = ws.S[l] if training else ws.S[l % 2]
             xh = ws.Xh[l] if training else ws.Xh[0]
-            self._spectral_forward_stages(a_in, ws, xh, (plan.FW, plan.FH, plan.FT), first_layer=(l == 0))
+            self._spectral_forward_stages(a_in, ws, xh, (plan.FW, plan.FH, plan.FT), first_layer=(l == 0), xf=xf)
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
             self._spectral_inverse_stages(ws.Yh, ws, (plan.GT, plan.GH))
             ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GW, s,
-                         ws.stat_part if training else None, d.ncell, C, C, 2 * plan.KW, d.Wp)
+                         ws.stat_part if training else None, d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
             if training:
                 ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
                 if world > 1:
@@ -308,14 +314,11 @@ class FNO3d(Model):
                 ops.bn_finalize(ws.sums64, float(d.ncell) * world, BN_EPS, BN_MOMENTUM, ws.mean[l], ws.invstd[l],
                                 self.bn_running_mean[l], self.bn_running_var[l], C)
                 self.bn_num_batches_tracked[l] += 1
-                mean, invstd = ws.mean[l], ws.invstd[l]
             else:
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
-                mean, invstd = self.bn_running_mean[l], ws.invstd[l]
-            ops.bn_act_fwd(s, mean, invstd, P(f"bns.{l}.weight"), P(f"bns.{l}.bias"), a_out, d.ncell, C,
-                           gelu=(l < L - 1))                                      # fno.py:117-119
-        a_last = ws.A[L] if training else ws.A[L % 2]
-        ops.proj_fwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out)
+            a_in, xf = s, self._layer_xf(ws, l, training)          # fno.py:117-119, applied by the next consumer
+        ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
+                     xf=xf)
         return ws.out
 
     def _backward_impl(self, x, gout, ws, gflat):
@@ -326,15 +329,16 @@ class FNO3d(Model):
         GP = lambda n: self.pview(n, gflat)
         world = self.dp.world_size if self.dp is not None else 1
         # ---- projection
-        ops.proj_bwd(ws.A[L], P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
-                     ws.proj_part, d, DO)
+        a_last, xf_last = ws.S[L - 1], self._layer_xf(ws, L - 1, True)
+        ops.proj_bwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
+                     ws.proj_part, d, DO, xf=xf_last)
         row = DO * HID + HID + DO
         part = ws.proj_part.view(ws.proj_rows, row)
         # partial row layout: [d fc2.weight | d fc1.bias | d fc2.bias]; the three segments are reduced separately
         self._reduce_cols(part, 0, DO * HID, GP("fc2.weight"))
         self._reduce_cols(part, DO * HID, HID, GP("fc1.bias"))
         self._reduce_cols(part, DO * HID + HID, DO, GP("fc2.bias"))
-        ops.cell_wgrad(ws.gu, ws.A[L], ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6)
+        ops.cell_wgrad(ws.gu, a_last, ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6, xf=xf_last)
         partp = ws.wg_part[:ws.wg_rows_p * (HID * C + HID)].view(ws.wg_rows_p, HID * C + HID)
         self._reduce_cols(partp, 0, HID * C, GP("fc1.weight"))
         if self.dp is not None:
@@ -354,8 +358,10 @@ class FNO3d(Model):
                 self.dp.all_reduce_sum(ws.bn_sums)
             ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world, g,
                              d.ncell, C, gelu)
-            # 1x1 conv weight / bias gradient
-            ops.cell_wgrad(g, ws.A[l], ws.wg_part, d.ncell, C, C)
+            # 1x1 conv weight / bias gradient (layer input = lazily activated output of layer l-1)
+            a_in = ws.A0 if l == 0 else ws.S[l - 1]
+            xf_in = None if l == 0 else self._layer_xf(ws, l - 1, True)
+            ops.cell_wgrad(g, a_in, ws.wg_part, d.ncell, C, C, xf=xf_in)
             partc = ws.wg_part[:ws.wg_rows_c * (C * C + C)].view(ws.wg_rows_c, C * C + C)
             self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))

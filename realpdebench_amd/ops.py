@@ -24,6 +24,14 @@ def _p(t, dtype=F32):
     return t.data_ptr()
 
 
+def _xf(xf):
+    """Lazy-activation argument group: ``None`` or ``(mean, invstd, gamma, beta, gelu)`` -> 5 C arguments."""
+    if xf is None:
+        return (None, None, None, None, 0)
+    mean, invstd, gamma, beta, gelu = xf
+    return (_p(mean), _p(invstd), _p(gamma), _p(beta), int(bool(gelu)))
+
+
 class Dims:
     """Shape bundle of one FNO3d problem: unpadded (T,H,W), padded (Tp,Hp,Wp), channels."""
 
@@ -50,11 +58,11 @@ def lift_bwd(g, x, grids, part, d):
               label="lift_bwd", nbytes=4 * d.ncrop * (d.Cin + d.C), flops=2 * d.ncrop * d.C * (d.Cin + 3))
 
 
-def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False, tag=""):
+def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False, tag="", xf=None):
     assert tuple(M.shape) == (O, K), (M.shape, O, K)
     kv = K if k_valid is None else k_valid
     _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o, kv, int(accumulate),
-              _stream(), label=f"axis_gemm[{tag}K{K}xO{O}]", nbytes=4 * G * N * (kv + O), flops=2 * G * N * kv * O)
+              *_xf(xf), _stream(), label=f"axis_gemm[{tag}K{K}xO{O}]", nbytes=4 * G * N * (kv + O), flops=2 * G * N * kv * O)
 
 
 def mode_contract_fwd(X, W, Y, B, M, C):
@@ -77,11 +85,11 @@ def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec):
 
 
 def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
-             crop6=(0, 0, 0, 1, 1, 1)):
+             crop6=(0, 0, 0, 1, 1, 1), xf=None):
     spec, stats = z2 is not None, stats_part is not None
     rows_in = (crop6[0] * crop6[1] * crop6[2] * (ncell // (crop6[3] * crop6[4] * crop6[5]))) if gather else ncell
     _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
-              int(transpose_w), int(gather), *crop6, _stream(),
+              int(transpose_w), int(gather), *crop6, *_xf(xf), _stream(),
               label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={int(stats)}]",
               nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
@@ -91,8 +99,8 @@ def cell_wgrad_slots(ncell, CO, CI):
     return _lib.query("rpb_cell_wgrad_slots", ncell, CO, CI)
 
 
-def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1)):
-    _lib.call("rpb_cell_wgrad", _p(gs), _p(x), _p(part), ncell, CO, CI, int(crop), *crop6, _stream(),
+def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1), xf=None):
+    _lib.call("rpb_cell_wgrad", _p(gs), _p(x), _p(part), ncell, CO, CI, int(crop), *crop6, *_xf(xf), _stream(),
               label=f"cell_wgrad[CO{CO},CI{CI}]", nbytes=4 * ncell * (CO + CI), flops=2 * ncell * CO * CI)
 
 
@@ -136,14 +144,15 @@ def proj_slots(ncrop, C, DO):
     return _lib.query("rpb_proj_slots", ncrop, C, DO)
 
 
-def proj_fwd(a, w1, b1, w2, b2, out, d, DO):
-    _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, _stream(),
+def proj_fwd(a, w1, b1, w2, b2, out, d, DO, xf=None):
+    _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, *_xf(xf),
+              _stream(),
               label="proj_fwd", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
 
 
-def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO):
+def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO, xf=None):
     _lib.call("rpb_proj_bwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(gout), _p(gu), _p(part), d.ncrop, d.C, DO,
-              *d.crop6, _stream(), label="proj_bwd", nbytes=4 * d.ncrop * (d.C + DO + 128),
+              *d.crop6, *_xf(xf), _stream(), label="proj_bwd", nbytes=4 * d.ncrop * (d.C + DO + 128),
               flops=2 * d.ncrop * 128 * (d.C + 2 * DO))
 
 

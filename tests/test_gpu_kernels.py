@@ -293,3 +293,62 @@ def test_errors_are_loud(ops):
         ops.axis_gemm(x, x, torch.zeros(2, 2, device="cuda"), 1, 2, 2, 33, 66, 33, 66, 33)     # N % 32 != 0
     with pytest.raises(RpbError):
         ops.bn_eval_prep(torch.zeros(4), 1e-5, torch.zeros(4), 4)                                 # CPU tensor
+
+
+def _xf_ref(x, mean, invstd, gamma, beta, gelu):
+    z = (x - mean) * invstd * gamma + beta
+    return torch.nn.functional.gelu(z) if gelu else z
+
+
+@pytest.mark.parametrize("gelu", [True, False])
+def test_lazy_activation_in_consumers(ops, gelu):
+    """Every consumer of a layer output applies BatchNorm(+GELU) on load (fno.py:117-119 fused): W-stage, cell_mix,
+    cell_wgrad and the projection must equal `op(act(bn(s)))` computed in fp64."""
+    torch.manual_seed(21)
+    C, Wp, rows, K2 = 64, 22, 9, 32
+    ncell = rows * Wp
+    s = torch.randn(ncell, C, dtype=torch.float64) * 1.5 + 0.3
+    mean, invstd = torch.randn(C, dtype=torch.float64) * 0.2, torch.rand(C, dtype=torch.float64) + 0.5
+    gamma, beta = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.3
+    a = _xf_ref(s, mean, invstd, gamma, beta, gelu)
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), gelu)
+    S = dev(s)
+    # W stage
+    M = torch.randn(32, Wp, dtype=torch.float64)
+    out = torch.empty(rows, 32, C, device="cuda")
+    ops.axis_gemm(S, out, dev(M), rows, Wp, 32, C, Wp * C, C, 32 * C, C, xf=xf)
+    assert rel_l2(out.cpu(), torch.einsum("ok,gkn->gon", M, a.view(rows, Wp, C))) < 3e-6
+    # cell_mix
+    Wc, bias = torch.randn(C, C, dtype=torch.float64) / 8, torch.randn(C, dtype=torch.float64)
+    z2, GW = torch.randn(rows, K2, C, dtype=torch.float64), torch.randn(Wp, K2, dtype=torch.float64)
+    ref = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + a @ Wc.t() + bias
+    o2 = torch.empty(ncell, C, device="cuda")
+    ops.cell_mix(S, dev(Wc), dev(bias), dev(z2), dev(GW), o2, None, ncell, C, C, K2, Wp, xf=xf)
+    assert rel_l2(o2.cpu(), ref) < 3e-6
+    # cell_wgrad
+    gs = torch.randn(ncell, C, dtype=torch.float64)
+    slots = ops.cell_wgrad_slots(ncell, C, C)
+    part = torch.zeros(slots, C * C + C, device="cuda")
+    ops.cell_wgrad(dev(gs), S, part, ncell, C, C, xf=xf)
+    assert rel_l2(part.double().sum(0).cpu()[:C * C].view(C, C), gs.t() @ a) < 3e-6
+    # projection (forward + gu of backward)
+    B, T, H, W, pad, DO = 1, 2, 4, 32, 2, 2
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    sp = torch.randn(d.ncell, C, dtype=torch.float64)
+    ap = _xf_ref(sp, mean, invstd, gamma, beta, gelu).view(B, d.Tp, d.Hp, d.Wp, C)[:, :T, :H, :W].reshape(-1, C)
+    w1 = (torch.randn(128, C, dtype=torch.float64) / 8).requires_grad_(True)
+    b1 = torch.randn(128, dtype=torch.float64)
+    w2, b2 = torch.randn(DO, 128, dtype=torch.float64) / 11, torch.randn(DO, dtype=torch.float64)
+    u = ap @ w1.t() + b1
+    u.retain_grad()
+    oref = torch.nn.functional.gelu(u) @ w2.t() + b2
+    gout = torch.randn_like(oref)
+    oref.backward(gout)
+    o3 = torch.empty(d.ncrop, DO, device="cuda")
+    args = (dev(sp), dev(w1.detach()), dev(b1), dev(w2), dev(b2))
+    ops.proj_fwd(*args, o3, d, DO, xf=xf)
+    assert rel_l2(o3.cpu(), oref.detach()) < 3e-6
+    gu = torch.empty(d.ncrop, 128, device="cuda")
+    pp = torch.zeros(ops.proj_slots(d.ncrop, C, DO), DO * 128 + 128 + DO, device="cuda")
+    ops.proj_bwd(*args, dev(gout), gu, pp, d, DO, xf=xf)
+    assert rel_l2(gu.cpu(), u.grad) < 5e-6
