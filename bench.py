@@ -92,8 +92,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("RPB_FORCE_DP") == "1"       # exercise the RCCL code path on a single rank
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from realpdebench_amd import _lib
@@ -104,7 +108,7 @@ def main():
     shape, modes, width, L = (20, 128, 128, 2), (4, 12, 16), 64, 4
     torch.manual_seed(0)
     model = FNO3d(*modes, L, width, shape, shape).to(dev)
-    if world > 1:
+    if world > 1 or force_dp:
         from realpdebench_amd.dp import DataParallel
         DataParallel(model)
     trainer = Trainer(model, lr=1e-4, num_update=4000, scheduler="cosine")
@@ -197,7 +201,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

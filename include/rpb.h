@@ -92,6 +92,16 @@ int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const f
                      const float* beta, const float* sums, double count, float* gs, long ncell, int C, int gelu,
                      void* stream);
 
+/*     Fused backward row pass of one Fourier layer (C = 32 or 64): BatchNorm(+GELU) backward apply -> gs (may alias
+ *     gy), adjoint W stage Y1[g][K2][C] = GWt gs, and the Conv3d weight/bias gradient partials -- one pass over
+ *     s, gy, x instead of three kernels (autograd of fno.py:115-119 + first stage of the autograd of fno.py:63).
+ *     part[rpb_bn_bwd_row_slots(G)][C*C + C]; G = B*Tp*Hp rows of Wp cells. */
+long rpb_bn_bwd_row_slots(int G);
+int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, float* gs, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, const float* sums, double count, int gelu,
+                   const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
+                   const float* GWt, float* Y1, float* part, int G, int Wp, int C, int K2, void* stream);
+
 /* K7  crop + fc1 + GELU + fc2.  fno.py:121-125.  proj_bwd recomputes fc1 and emits gu = dL/d(fc1 pre-activation)
  *     [ncrop][128] plus partial rows [rpb_proj_slots(...)][DO*128 + 128 + DO] for d fc2.weight, d fc1.bias, d fc2.bias. */
 long rpb_proj_slots(long ncrop, int C, int DO);

@@ -1,0 +1,231 @@
+// Fused backward "row" kernel of one Fourier layer (C = 32 or 64):
+//
+//   gs   = BatchNorm3d(+GELU) backward apply         (was rpb_bn_bwd_apply:  read s, gy        write gs)
+//   Y1   = GW^T gs   -- adjoint of the last inverse-DFT stage, i.e. the W stage of the spectral backward
+//                                                    (was rpb_axis_gemm:      read gs           write Y1)
+//   dWc += gs^T x,  dbc += sum gs                    (was rpb_cell_wgrad:     read gs, x)
+//
+// autograd of fno.py:115-119 + the first stage of the autograd of fno.py:63.  One pass reads s, gy, x once and
+// writes gs once: 4 activation passes instead of 6 per layer.  This works because all three consumers want gs in the
+// SAME register layout: "lane = channel pair, MFMA k index = cell" is the A operand of the weight-gradient MFMA and
+// the B operand of the DFT-stage MFMA (channels-last, read straight from HBM, no LDS staging).
+//
+// Work item = one w-row of Wp cells (the DFT runs along w); persistent waves; the three input streams are
+// double-buffered in registers 4 MFMA steps (8 cells) ahead through SRSRC descriptors (per-row bounds: the pad
+// steps of the last chunk read zeros and their stores are dropped by the hardware).
+#include "rpb_common.h"
+
+template <int N>
+struct RowVec;
+template <>
+struct RowVec<1> {
+    typedef float T;
+    typedef unsigned U;
+};
+template <>
+struct RowVec<2> {
+    typedef f32x2 T;
+    typedef unsigned U __attribute__((ext_vector_type(2)));
+};
+
+template <int NT>
+__device__ __forceinline__ typename RowVec<NT>::T row_load(rsrc_t r, int voff, int soff) {
+    if constexpr (NT == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    else return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <int NT>
+__device__ __forceinline__ void row_store(typename RowVec<NT>::T v, rsrc_t r, int voff, int soff) {
+    if constexpr (NT == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(typename RowVec<2>::U, v), r, voff, soff, 0);
+}
+template <int NT>
+__device__ __forceinline__ float rget(const typename RowVec<NT>::T& v, int i) {
+    if constexpr (NT == 1) return v;
+    else return v[i];
+}
+template <int NT>
+__device__ __forceinline__ void rset(typename RowVec<NT>::T& v, int i, float x) {
+    if constexpr (NT == 1) v = x;
+    else v[i] = x;
+}
+
+struct BwdRowArgs {
+    const float* s;        // [G*Wp][C] pre-BatchNorm output of this layer
+    const float* gy;       // [G*Wp][C] gradient w.r.t. the layer output
+    const float* x;        // [G*Wp][C] layer input (plain, or pre-BN of the previous layer with xf)
+    float* gs;             // [G*Wp][C] out (may alias gy)
+    const float* mean;     // BatchNorm of THIS layer
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* sums;     // [2C] global (sum gz | sum gz*shat)
+    float inv_count;
+    int gelu;
+    XForm xf;              // lazy activation of the layer input x
+    const float* GWt;      // [K2][Wp] adjoint W-stage matrix
+    float* Y1;             // [G][K2][C]
+    float* part;           // [nslots][C*C + C]
+    int G, Wp, K2;
+};
+
+template <int C>
+__global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
+    constexpr int NT = C / 32;
+    typedef typename RowVec<NT>::T vec;
+    extern __shared__ float Ml[];                      // [Kp][32]   Ml[k][o] = GWt[o][k]
+    const int Wp = a.Wp, K2 = a.K2;
+    const int nchunk = (Wp + 7) / 8;
+    const int Kp = nchunk * 8;
+    for (int idx = threadIdx.x; idx < Kp * 32; idx += blockDim.x) {
+        const int k = idx >> 5, o = idx & 31;
+        Ml[idx] = (k < Wp && o < K2) ? a.GWt[o * Wp + k] : 0.f;
+    }
+    __syncthreads();
+
+    const int waves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const long slot = (long)blockIdx.x * waves + wave;
+    const long nslots = (long)gridDim.x * waves;
+    const bool gelu = a.gelu != 0;
+    const bool has_xf = a.xf.mean != nullptr;
+
+    float mu[NT], is[NT], ga[NT], be[NT], m1[NT], m2[NT];
+    XParam xp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ch = col * NT + t;
+        mu[t] = a.mean[ch];
+        is[t] = a.invstd[ch];
+        ga[t] = a.gamma[ch];
+        be[t] = a.beta[ch];
+        m1[t] = a.sums[ch] * a.inv_count;
+        m2[t] = a.sums[C + ch] * a.inv_count;
+        if (has_xf) xp[t] = xf_load(a.xf, ch);
+    }
+    f32x16 dW[NT][NT];
+    float bsum[NT];
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+        bsum[o] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) dW[o][i] = zero16();
+    }
+
+    const int voff = (half * C + col * NT) * 4;
+    const unsigned row_bytes = (unsigned)Wp * C * 4;
+    vec sa[4], ya[4], xa[4], sb[4], yb[4], xb[4];
+
+    for (long g = slot; g < a.G; g += nslots) {
+        const long off = g * (long)Wp * C;
+        const rsrc_t rs = make_rsrc(a.s + off, row_bytes);
+        const rsrc_t ry = make_rsrc(a.gy + off, row_bytes);
+        const rsrc_t rx = make_rsrc(a.x + off, row_bytes);
+        const rsrc_t ro = make_rsrc(a.gs + off, row_bytes);
+        f32x16 accw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) accw[t] = zero16();
+
+        auto load_chunk = [&](int c, vec (&sv)[4], vec (&yv)[4], vec (&xv)[4]) {
+            // the whole row-relative offset goes through voffset: only voffset+imm is bounds-checked (soffset is not)
+            const int vo = voff + c * 8 * C * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sv[j] = row_load<NT>(rs, vo + 2 * j * C * 4, 0);
+                yv[j] = row_load<NT>(ry, vo + 2 * j * C * 4, 0);
+                xv[j] = row_load<NT>(rx, vo + 2 * j * C * 4, 0);
+            }
+        };
+        auto compute_chunk = [&](int c, const vec (&sv)[4], const vec (&yv)[4], const vec (&xv)[4]) {
+            const int vo = voff + c * 8 * C * 4;
+            const float* mp = Ml + (c * 8 + half) * 32 + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = c * 8 + 2 * j + half < Wp;
+                float gsv[NT], xt[NT];
+                vec gout;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float sh = (rget<NT>(sv[j], t) - mu[t]) * is[t];
+                    const float gyv = rget<NT>(yv[j], t);
+                    const float gz = gelu ? gyv * gelu_grad_f(sh * ga[t] + be[t]) : gyv;
+                    const float v = ga[t] * is[t] * (gz - m1[t] - sh * m2[t]);
+                    gsv[t] = valid ? v : 0.f;
+                    rset<NT>(gout, t, gsv[t]);
+                    const float xv0 = rget<NT>(xv[j], t);
+                    xt[t] = has_xf ? xf_apply(xv0, xp[t], a.xf.gelu != 0) : xv0;
+                }
+                row_store<NT>(gout, ro, vo + 2 * j * C * 4, 0);          // pad steps fall outside the descriptor
+                const float aw = mp[2 * j * 32];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) accw[t] = mfma32(aw, gsv[t], accw[t]);
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    bsum[o] += gsv[o];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) dW[o][i] = mfma32(gsv[o], xt[i], dW[o][i]);
+                }
+            }
+        };
+        load_chunk(0, sa, ya, xa);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load_chunk(c + 1, sb, yb, xb);
+            compute_chunk(c, sa, ya, xa);
+            if (c + 2 < nchunk) load_chunk(c + 2, sa, ya, xa);
+            if (c + 1 < nchunk) compute_chunk(c + 1, sb, yb, xb);
+        }
+        // Y1[g][o][channel]
+        float* yp = a.Y1 + g * (long)K2 * C + col * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = mfma_row(lane, r);
+            if (o < K2) {
+                vec v;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rset<NT>(v, t, accw[t][r]);
+                *reinterpret_cast<vec*>(yp + (long)o * C) = v;
+            }
+        }
+    }
+    float* part = a.part + slot * ((long)C * C + C);
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(long)(mfma_row(lane, r) * NT + o) * C + col * NT + i] = dW[o][i][r];
+        const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
+        if (half == 0) part[(long)C * C + col * NT + o] = b;
+    }
+}
+
+extern "C" long rpb_bn_bwd_row_slots(int G) {
+    long slots = (long)rpb_num_cus() * 8;
+    const long need = ((long)G + 7) / 8 * 8;
+    return slots < need ? slots : need;
+}
+
+extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, float* gs, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, const float* sums,
+                              double count, int gelu, const float* xf_mean, const float* xf_invstd,
+                              const float* xf_gamma, const float* xf_beta, int xf_gelu, const float* GWt, float* Y1,
+                              float* part, int G, int Wp, int C, int K2, void* stream) {
+    RPB_REQUIRE(s && gy && x && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part,
+                "bn_bwd_row: null pointer");
+    RPB_REQUIRE(C == 32 || C == 64, "bn_bwd_row: C=%d not supported by the fused kernel (use the unfused kernels)", C);
+    RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
+    RPB_REQUIRE((long)Wp * C * 4 < (1L << 31), "bn_bwd_row: row too long");
+    if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta, "bn_bwd_row: bad input-transform arguments");
+    BwdRowArgs a;
+    a.s = s; a.gy = gy; a.x = x; a.gs = gs; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
+    a.sums = sums; a.inv_count = (float)(1.0 / count); a.gelu = gelu;
+    a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
+    a.GWt = GWt; a.Y1 = Y1; a.part = part; a.G = G; a.Wp = Wp; a.K2 = K2;
+    const int grid = (int)(rpb_bn_bwd_row_slots(G) / 8);
+    const size_t lds = (size_t)((Wp + 7) / 8 * 8) * 32 * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 32) hipLaunchKernelGGL((bwd_row_kernel<32>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((bwd_row_kernel<64>), dim3(grid), dim3(512), lds, st, a);
+    RPB_CHECK_LAUNCH("bn_bwd_row");
+}

@@ -57,6 +57,8 @@ __device__ __forceinline__ f32x16 zero16() {
 // SRSRC ("buffer") accesses: 128-bit descriptor in SGPRs + ONE 32-bit per-lane offset + scalar/immediate offsets,
 // with hardware bounds checking (out-of-range lanes: loads return 0, stores are dropped).  Built per tile from
 // wave-uniform values, this replaces per-lane 64-bit address arithmetic and every tail predicate.
+// IMPORTANT: only voffset + the instruction's immediate are range-checked; soffset is NOT.  Anything that must be
+// clipped by the descriptor therefore goes through `voff` (constants added to it are folded into the immediate).
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);

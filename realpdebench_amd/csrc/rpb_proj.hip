@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
             for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int j = 0; j < DOT; ++j)
-                    gpre[r][j] = (j < DO) ? buf_load_f32(gr, vo, ((8 * (r >> 2) + (r & 3)) * DO + j) * 4) : 0.f;
+                    gpre[r][j] = (j < DO) ? buf_load_f32(gr, vo + ((8 * (r >> 2) + (r & 3)) * DO + j) * 4, 0) : 0.f;
         }
         if (PREFETCH_X && tile + tstride < ntiles) issue_x(tile + tstride);
         __builtin_amdgcn_wave_barrier();
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
                         dw2[j][t] += g[j] * v;
                     }
                     const float guv = gvs * d;          // rows past ncrop have g == 0 -> guv == 0 (and the store is dropped)
-                    buf_store_f32(guv, ur, vo, ((8 * (r >> 2) + (r & 3)) * HID + t * 32) * 4);
+                    buf_store_f32(guv, ur, vo + ((8 * (r >> 2) + (r & 3)) * HID + t * 32) * 4, 0);
                     db1[t] += guv;
                 }
             }

@@ -55,7 +55,9 @@ class _Workspace:
             self.bn_sums = torch.empty(2 * C, **f)
             self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
             self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
-            self.wg_rows_c = ops.cell_wgrad_slots(d.ncell, C, C)
+            self.fused_bwd = C <= 64             # rpb_bn_bwd_row: BN-backward apply + adjoint W stage + conv wgrad in one pass
+            self.wg_rows_c = (ops.bn_bwd_row_slots(B * d.Tp * d.Hp) if self.fused_bwd
+                              else ops.cell_wgrad_slots(d.ncell, C, C))
             self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
             self.wg_part = torch.empty(max(self.wg_rows_c * (C * C + C), self.wg_rows_p * (HID * C + HID)), **f)
             self.lift_rows = ops._lib.query("rpb_lift_bwd_rows")
@@ -270,8 +272,9 @@ class FNO3d(Model):
         m3, KH, KT = p.KW, p.KH, p.KT
         MW, MH, MT = mats
         N2, N3 = m3 * C, KH * m3 * C
-        ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
-                      k_valid=d.W if first_layer else None, xf=xf)
+        if MW is not None:                      # None: ws.Y1 was already produced (fused backward row kernel)
+            ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
+                          k_valid=d.W if first_layer else None, xf=xf)
         ops.axis_gemm(ws.Y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
                       k_valid=2 * d.H if first_layer else None)
         ops.axis_gemm(ws.Y2, xh, MT, d.B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3,
@@ -356,17 +359,23 @@ class FNO3d(Model):
             GP(f"bns.{l}.weight").copy_(ws.bn_sums[C:])
             if world > 1:
                 self.dp.all_reduce_sum(ws.bn_sums)
-            ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world, g,
-                             d.ncell, C, gelu)
-            # 1x1 conv weight / bias gradient (layer input = lazily activated output of layer l-1)
-            a_in = ws.A0 if l == 0 else ws.S[l - 1]
+            a_in = ws.A0 if l == 0 else ws.S[l - 1]          # layer input = lazily activated output of layer l-1
             xf_in = None if l == 0 else self._layer_xf(ws, l - 1, True)
-            ops.cell_wgrad(g, a_in, ws.wg_part, d.ncell, C, C, xf=xf_in)
+            if ws.fused_bwd:
+                # one pass: gs = BN/GELU backward (in place), Y1 = GW^T gs (adjoint W stage), conv wgrad partials
+                ops.bn_bwd_row(ws.S[l], g, a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
+                               float(d.ncell) * world, gelu, xf_in, plan.GWt, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
+                               d.Wp, C, 2 * plan.KW)
+            else:
+                ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world,
+                                 g, d.ncell, C, gelu)
+                ops.cell_wgrad(g, a_in, ws.wg_part, d.ncell, C, C, xf=xf_in)
             partc = ws.wg_part[:ws.wg_rows_c * (C * C + C)].view(ws.wg_rows_c, C * C + C)
             self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
-            self._spectral_forward_stages(g, ws, ws.Yh, (plan.GWt, plan.GHt, plan.GTt), first_layer=False)
+            self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GWt, plan.GHt, plan.GTt),
+                                          first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
             if self.dp is not None and l > 0:
                 self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward

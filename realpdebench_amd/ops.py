@@ -140,6 +140,18 @@ def bn_bwd_apply(s, gy, mean, invstd, gamma, beta, sums, count, gs, ncell, C, ge
               flops=20 * ncell * C)
 
 
+def bn_bwd_row_slots(G):
+    return _lib.query("rpb_bn_bwd_row_slots", G)
+
+
+def bn_bwd_row(s, gy, x, gs, mean, invstd, gamma, beta, sums, count, gelu, xf, GWt, Y1, part, G, Wp, C, K2):
+    ncell = G * Wp
+    _lib.call("rpb_bn_bwd_row", _p(s), _p(gy), _p(x), _p(gs), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
+              float(count), int(gelu), *_xf(xf), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, _stream(),
+              label=f"bn_bwd_row[C{C},gelu={int(gelu)}]", nbytes=4 * (4 * ncell * C + G * K2 * C),
+              flops=2 * ncell * C * (C + K2))
+
+
 def proj_slots(ncrop, C, DO):
     return _lib.query("rpb_proj_slots", ncrop, C, DO)
 

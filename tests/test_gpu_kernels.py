@@ -352,3 +352,43 @@ def test_lazy_activation_in_consumers(ops, gelu):
     pp = torch.zeros(ops.proj_slots(d.ncrop, C, DO), DO * 128 + 128 + DO, device="cuda")
     ops.proj_bwd(*args, dev(gout), gu, pp, d, DO, xf=xf)
     assert rel_l2(gu.cpu(), u.grad) < 5e-6
+
+
+@pytest.mark.parametrize("C,gelu,lazy_x", [(64, True, True), (64, False, False), (32, True, False)])
+def test_fused_bn_bwd_row(ops, C, gelu, lazy_x):
+    """rpb_bn_bwd_row == bn_bwd_apply + adjoint W stage + conv weight gradient, each stated in fp64."""
+    torch.manual_seed(31 + C)
+    G, Wp, K2 = 13, 22, 32 if C == 64 else 8
+    ncell = G * Wp
+    s = torch.randn(ncell, C, dtype=torch.float64) * 1.3 + 0.2
+    gy = torch.randn(ncell, C, dtype=torch.float64)
+    xs = torch.randn(ncell, C, dtype=torch.float64)
+    mean, invstd = s.mean(0), 1 / torch.sqrt(s.var(0, unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.3
+    sh = (s - mean) * invstd
+    z = sh * gamma + beta
+    if gelu:
+        zz = z.clone().requires_grad_(True)
+        torch.nn.functional.gelu(zz).backward(gy)
+        gz = zz.grad
+    else:
+        gz = gy
+    sums = torch.cat([gz.sum(0), (gz * sh).sum(0)])
+    gs_ref = gamma * invstd * (gz - sums[:C] / ncell - sh * sums[C:] / ncell)
+    pm, pi = torch.randn(C, dtype=torch.float64) * 0.1, torch.rand(C, dtype=torch.float64) + 0.5
+    pg, pb = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.2
+    x_ref = _xf_ref(xs, pm, pi, pg, pb, True) if lazy_x else xs
+    GWt = torch.randn(K2, Wp, dtype=torch.float64)
+    y1_ref = torch.einsum("ok,gkc->goc", GWt, gs_ref.view(G, Wp, C))
+    xf = (dev(pm), dev(pi), dev(pg), dev(pb), True) if lazy_x else None
+    g = dev(gy)
+    Y1 = torch.full((G, K2, C), float("nan"), device="cuda")
+    slots = ops.bn_bwd_row_slots(G)
+    part = torch.full((slots, C * C + C), float("nan"), device="cuda")
+    ops.bn_bwd_row(dev(s), g, dev(xs), g, dev(mean), dev(invstd), dev(gamma), dev(beta), dev(sums), ncell, gelu, xf,
+                   dev(GWt), Y1, part, G, Wp, C, K2)
+    assert rel_l2(g.cpu(), gs_ref) < 5e-6                       # in place over gy
+    assert rel_l2(Y1.cpu(), y1_ref) < 5e-6
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(tot[:C * C].view(C, C), gs_ref.t() @ x_ref) < 5e-6
+    assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
