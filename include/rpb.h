@@ -39,13 +39,14 @@ int rpb_lift_bwd(const float* g_out, const float* x, const float* gt, const floa
                  int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp, void* stream);
 
 /* K2/K4  one truncated-DFT stage: out[g][o][n] (+)= sum_k M[o][k] * in[g][k][n], n contiguous.
+ *     `Mt` is the stage matrix TRANSPOSED ([K][O] row-major) so that staging it into LDS is a coalesced copy.
  *     Replaces torch.fft.rfftn / torch.fft.irfftn of SpectralConv3d.forward (fno.py:48, :63) without ever
  *     materialising the discarded 97 % of the spectrum (fno.py:51-60).  Inputs k >= k_valid are treated as 0. */
 /*     Lazy activation (all `xf_*` argument groups below): when xf_mean != NULL the input tensor is the PRE-BatchNorm
  *     output s of the producing layer and the kernel applies act(xf_gamma*(s-xf_mean)*xf_invstd+xf_beta), act = exact
  *     GELU if xf_gelu else identity, per channel while loading -- fno.py:117-119 fused into the consumer, so the
  *     normalised/activated tensor is never written to HBM.  For rpb_axis_gemm this requires N == channels. */
-int rpb_axis_gemm(const float* in, float* out, const float* M, int G, int K, int O, int N, long in_g_stride,
+int rpb_axis_gemm(const float* in, float* out, const float* Mt, int G, int K, int O, int N, long in_g_stride,
                   long in_k_stride, long out_g_stride, long out_o_stride, int k_valid, int accumulate,
                   const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
                   void* stream);
@@ -60,14 +61,18 @@ int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, i
 /* K4+K5  last inverse-DFT stage fused with the 1x1x1 Conv3d, the `x1 + x2` add and the BatchNorm statistics.
  *     fno.py:63 (W-axis c2r part of irfftn), :115 (Conv3d), :116 (add), batch statistics of :117.
  *     out[cell][o] = sum_k GW[w(cell)][k] z2[g(cell)][k][o] + sum_i x[row(cell)][i] Wm(o,i) + bias[o]
+ *     (`GWt` is GW transposed: [K2][Wp] row-major)
  *     transpose_w=0: Wm is [CO][KC] (forward); =1: Wm is [KC][CO] (dgrad).  z2 == NULL drops the spectral term.
  *     gather=1: cells are padded cells and row(cell) is the cropped index (zero rows in the pad margin).
- *     stats_part (optional): [rpb_cell_mix_stat_rows(...)][2][CO] partial sums of out and out^2. */
-long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec);
-int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+ *     stats_part (optional): [rpb_cell_mix_stat_rows(...)][2][CO] partial sums of out and out^2; when bnb_s != NULL
+ *     the output is the gradient w.r.t. act(BN(bnb_s)) and the partials are instead (sum gz, sum gz*shat), the
+ *     first pass of that layer's BatchNorm backward (bnb_* = its mean, invstd, gamma, beta, gelu flag). */
+long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int bn_bwd_stats);
+int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out,
                  float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w, int gather, int T,
                  int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean, const float* xf_invstd,
-                 const float* xf_gamma, const float* xf_beta, int xf_gelu, void* stream);
+                 const float* xf_gamma, const float* xf_beta, int xf_gelu, const float* bnb_s, const float* bnb_mean,
+                 const float* bnb_invstd, const float* bnb_gamma, const float* bnb_beta, int bnb_gelu, void* stream);
 
 /*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
  *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */
@@ -95,12 +100,13 @@ int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const f
 /*     Fused backward row pass of one Fourier layer (C = 32 or 64): BatchNorm(+GELU) backward apply -> gs (may alias
  *     gy), adjoint W stage Y1[g][K2][C] = GWt gs, and the Conv3d weight/bias gradient partials -- one pass over
  *     s, gy, x instead of three kernels (autograd of fno.py:115-119 + first stage of the autograd of fno.py:63).
- *     part[rpb_bn_bwd_row_slots(G)][C*C + C]; G = B*Tp*Hp rows of Wp cells. */
+ *     part[rpb_bn_bwd_row_slots(G)][C*C + C]; G = B*Tp*Hp rows of Wp cells.  `M_wk` is the adjoint W-stage
+ *     matrix transposed, i.e. [Wp][K2] row-major. */
 long rpb_bn_bwd_row_slots(int G);
 int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, float* gs, const float* mean, const float* invstd,
                    const float* gamma, const float* beta, const float* sums, double count, int gelu,
                    const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
-                   const float* GWt, float* Y1, float* part, int G, int Wp, int C, int K2, void* stream);
+                   const float* M_wk, float* Y1, float* part, int G, int Wp, int C, int K2, void* stream);
 
 /* K7  crop + fc1 + GELU + fc2.  fno.py:121-125.  proj_bwd recomputes fc1 and emits gu = dL/d(fc1 pre-activation)
  *     [ncrop][128] plus partial rows [rpb_proj_slots(...)][DO*128 + 128 + DO] for d fc2.weight, d fc1.bias, d fc2.bias. */

@@ -1,6 +1,7 @@
 // K2/K4: truncated DFT stage = small dense real matrix applied along one strided axis.
 //
 //   out[g][o][n] = sum_k M[o][k] * in[g][k][n]        n contiguous, k/o strided, g = batch
+//   (the matrix argument is M^T, i.e. [K][O] row-major, so that staging it into LDS is a coalesced copy)
 //
 // Replaces torch.fft.rfftn / irfftn in SpectralConv3d.forward (reference realpdebench/model/fno.py:48,63):
 // only the retained modes are ever produced, so the full [B,C,Tp,Hp,Wp/2+1] spectrum (97 % discarded
@@ -44,7 +45,7 @@ __device__ __forceinline__ void load_vec(const float* p, bool ok, float (&v)[NV]
     }
 }
 
-template <int OT, int NV>
+template <int OT, int NV, bool XF>
 __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ M, int G, int K, int O, int N,
                                                         long in_g, long in_k, long out_g, long out_o, int k_valid,
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
     const int Kp = (K + 15) & ~15;                      // whole 8-step chunks; the pad rows are zero
     for (int idx = threadIdx.x; idx < Kp * Op; idx += blockDim.x) {
         const int k = idx / Op, o = idx - k * Op;
-        Mlds[idx] = (k < K && o < O) ? M[(long)o * K + k] : 0.f;
+        Mlds[idx] = (k < K && o < O) ? M[(long)k * O + o] : 0.f;     // M is passed TRANSPOSED ([K][O]): coalesced fill
     }
     __syncthreads();
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
         const vec vz = {};
         // lazy BatchNorm(+GELU) of the producing layer, applied to the data operand right before the MFMA
         // (N == C here, so the n index IS the channel and a lane keeps its NV channels for the whole item)
-        const bool has_xf = xf.mean != nullptr;
+        constexpr bool has_xf = XF;
         XParam xp[NV];
         if (has_xf) {
 #pragma unroll
@@ -175,7 +176,10 @@ static int launch_axis(const float* in, float* out, const float* M, int G, int K
     const int Kp = (K + 15) & ~15;
     const size_t lds = (size_t)Kp * Op * sizeof(float);
     RPB_REQUIRE(lds <= 160 * 1024, "axis_gemm: matrix %dx%d does not fit LDS", O, K);
-    (void)hipFuncSetAttribute((const void*)axis_gemm_kernel<OT, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (xf.mean)
+        (void)hipFuncSetAttribute((const void*)axis_gemm_kernel<OT, NV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else
+        (void)hipFuncSetAttribute((const void*)axis_gemm_kernel<OT, NV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int waves = 4;
     const long nitems = (long)G * (N / (32 * NV)) * och;
     const int per_cu = lds > 0 ? (int)((160 * 1024) / lds) : 8;
@@ -183,8 +187,12 @@ static int launch_axis(const float* in, float* out, const float* M, int G, int K
     const long need = (nitems + waves - 1) / waves;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((axis_gemm_kernel<OT, NV>), dim3((unsigned)grid), dim3(waves * 64), lds, stream, in, out, M, G, K,
-                       O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf);
+    if (xf.mean)
+        hipLaunchKernelGGL((axis_gemm_kernel<OT, NV, true>), dim3((unsigned)grid), dim3(waves * 64), lds, stream, in, out,
+                           M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf);
+    else
+        hipLaunchKernelGGL((axis_gemm_kernel<OT, NV, false>), dim3((unsigned)grid), dim3(waves * 64), lds, stream, in, out,
+                           M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf);
     RPB_CHECK_LAUNCH("axis_gemm");
 }
 
@@ -202,14 +210,14 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     const int ot_total = (O + 31) / 32;
     const int OT = ot_total >= 3 ? 3 : ot_total;
     int NV = (N % 128 == 0) ? 4 : (N % 64 == 0) ? 2 : 1;
-    while (OT * NV > 6) NV >>= 1;
+    while (OT * NV > 8) NV >>= 1;
     // 16-byte vector access needs aligned strides
     if (NV == 4 && ((in_g | in_k | out_g | out_o) & 3)) NV = 2;
     if (NV == 2 && ((in_g | in_k | out_g | out_o) & 1)) NV = 1;
 #define RPB_AX(OT_, NV_)                                                                                        \
     if (OT == OT_ && NV == NV_)                                                                                 \
         return launch_axis<OT_, NV_>(in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf, st);
-    RPB_AX(1, 1) RPB_AX(1, 2) RPB_AX(1, 4) RPB_AX(2, 1) RPB_AX(2, 2) RPB_AX(3, 1) RPB_AX(3, 2)
+    RPB_AX(1, 1) RPB_AX(1, 2) RPB_AX(1, 4) RPB_AX(2, 1) RPB_AX(2, 2) RPB_AX(2, 4) RPB_AX(3, 1) RPB_AX(3, 2)
 #undef RPB_AX
     RPB_FAIL(RPB_ERR_UNSUPPORTED, "axis_gemm: no instantiation OT=%d NV=%d", OT, NV);
 }

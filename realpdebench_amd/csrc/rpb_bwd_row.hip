@@ -62,7 +62,7 @@ struct BwdRowArgs {
     float inv_count;
     int gelu;
     XForm xf;              // lazy activation of the layer input x
-    const float* GWt;      // [K2][Wp] adjoint W-stage matrix
+    const float* GWt;      // adjoint W-stage matrix GW^T [K2][Wp], passed TRANSPOSED, i.e. as GW [Wp][K2]
     float* Y1;             // [G][K2][C]
     float* part;           // [nslots][C*C + C]
     int G, Wp, K2;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
     const int Kp = nchunk * 8;
     for (int idx = threadIdx.x; idx < Kp * 32; idx += blockDim.x) {
         const int k = idx >> 5, o = idx & 31;
-        Ml[idx] = (k < Wp && o < K2) ? a.GWt[o * Wp + k] : 0.f;
+        Ml[idx] = (k < Wp && o < K2) ? a.GWt[k * K2 + o] : 0.f;      // passed as [Wp][K2] = (GW^T)^T: coalesced fill
     }
     __syncthreads();
 

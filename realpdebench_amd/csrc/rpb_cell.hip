@@ -21,7 +21,7 @@ struct CellMixArgs {
     const float* Wm;      // transpose_w == 0: [CO][KC] (out = x W^T) ; == 1: [KC][CO] (out = x W)
     const float* bias;    // [CO] or null
     const float* z2;      // [G][K2][CO] or null
-    const float* GW;      // [Wp][K2]
+    const float* GW;      // [K2][Wp]  (transposed stage matrix)
     float* out;           // [ncell][CO]
     float* stats_part;    // [gridDim.x*waves][2][CO] or null
     long ncell;
@@ -30,6 +30,8 @@ struct CellMixArgs {
     int gather;           // 1: out cells are padded cells, input row = pad_to_crop(cell) (zeros in the margin)
     CropMap cm;
     XForm xf;             // lazy BatchNorm(+GELU) applied to x on its way into LDS
+    const float* bnb_s;   // STATS == 2: pre-BN tensor of the layer whose output gradient this launch produces
+    XForm bnb;            //             and that layer's BatchNorm (mean, invstd, gamma, beta, gelu)
 };
 
 #ifndef CM_MAX_THREADS
@@ -70,8 +72,11 @@ __device__ __forceinline__ float vget(const typename VecT<N>::T& v, int i) {
 // K2S  : spectral MFMA steps (2*K2S >= K2 rows of z2; 0 = no spectral term)
 // Software pipeline per wave: the x tile of the NEXT item and the z2 rows of THIS item are in flight in
 // registers while the 64..128 MFMAs of this item run, so HBM latency is hidden with 2 waves per SIMD.
-template <int NT, int KC, int K2S, bool STATS>
-__global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_kernel(CellMixArgs a) {
+// STATS: 0 none | 1 per-channel sum / sum-of-squares of the output (BatchNorm forward statistics) |
+//        2 the output is dL/d(act(BN(s))) of a layer: accumulate sum gz and sum gz*shat (gz = out * act'(z)), i.e. the
+//          first pass of the BatchNorm backward, fused into the kernel that produces the gradient
+template <int NT, int KC, int K2S, int STATS>
+__global__ __launch_bounds__((KC >= 128 || STATS == 2) ? 512 : CM_MAX_THREADS) void cell_mix_kernel(CellMixArgs a) {
     constexpr bool SPEC = K2S > 0;
     constexpr int CO = NT * 32;
     constexpr int XS = KC + 1;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
     if (SPEC)
         for (int idx = threadIdx.x; idx < 2 * K2S * Wp; idx += blockDim.x) {
             const int k = idx / Wp, w = idx - k * Wp;
-            GWl[idx] = (k < K2) ? a.GW[w * K2 + k] : 0.f;
+            GWl[idx] = (k < K2) ? a.GW[idx] : 0.f;            // GW is passed TRANSPOSED ([K2][Wp]): coalesced fill
         }
     for (int idx = threadIdx.x; idx < KC * CO; idx += blockDim.x) {
         const int k = idx / CO, n = idx - k * CO;            // n = t*32 + col
@@ -107,10 +112,12 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
     const long tstride = (long)gridDim.x * waves;
     const bool k2_exact = (K2 == 2 * K2S);
     float ssum[NT], ssq[NT], bv[NT];
+    XParam bp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         ssum[t] = ssq[t] = 0.f;
         bv[t] = a.bias ? a.bias[t * 32 + col] : 0.f;
+        if (STATS == 2) bp[t] = xf_load(a.bnb, t * 32 + col);
     }
 
     const bool has_xf = a.xf.mean != nullptr;          // only used with the contiguous (non-gather) x layout
@@ -218,6 +225,17 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
                     for (int t = 0; t < NT; ++t) zr1[s][t] = (2 * s + half < K2) ? zq[lo + 2 * s * CO + t * 32] : 0.f;
             }
         }
+        // ---- 2b. STATS == 2: this tile's pre-BN values (same positions as the outputs) for the BN-backward sums
+        float spre[STATS == 2 ? NT : 1][STATS == 2 ? 16 : 1];
+        if (STATS == 2) {
+            const rsrc_t sr = make_rsrc(a.bnb_s + cell0 * CO, tile_bytes(a.ncell - cell0, 32, CO * 4));
+            const int vo = (4 * half * CO + col) * 4;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    spre[t][r] = buf_load_f32(sr, vo + ((8 * (r >> 2) + (r & 3)) * CO + t * 32) * 4, 0);
+        }
         // ---- 3. next tile's x loads go out now and stay in flight during the MFMAs below
         if (tile + tstride < ntiles) issue_x(tile + tstride);
         __builtin_amdgcn_wave_barrier();
@@ -288,9 +306,14 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
                     const float v = acc[t][r] + bv[t];
                     if (full || rr + 4 * half < rows_left) {
                         ob[lo + rr * CO + t * 32] = v;
-                        if (STATS) {
+                        if (STATS == 1) {
                             ssum[t] += v;
                             ssq[t] += v * v;
+                        } else if (STATS == 2) {
+                            const float sh = (spre[t][r] - bp[t].mu) * bp[t].is;
+                            const float gz = a.bnb.gelu ? v * gelu_grad_f(sh * bp[t].ga + bp[t].be) : v;
+                            ssum[t] += gz;
+                            ssq[t] += gz * sh;
                         }
                     }
                 }
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(KC >= 128 ? 512 : CM_MAX_THREADS) void cell_mix_ker
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (STATS) {
+    if (STATS != 0) {
         float* part = a.stats_part + ((long)blockIdx.x * waves + wave) * 2 * CO;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -324,16 +347,16 @@ static size_t cell_mix_lds(int KC, int CO, int K2, int Wp, bool spec, int waves)
     return ((size_t)(spec ? 2 * k2s * Wp : 0) + (size_t)KC * CO + (size_t)waves * 32 * (KC + 1) + (size_t)waves * 32) * 4;
 }
 
-static int cell_mix_waves(int KC, int CO, int K2, int Wp, bool spec) {
+static int cell_mix_waves(int KC, int CO, int K2, int Wp, bool spec, bool bnb = false) {
     if (cell_mix_k2s(K2, spec) < 0) return 0;
-    const int wmax = (KC >= 128 ? 512 : CM_MAX_THREADS) / 64;
+    const int wmax = ((KC >= 128 || bnb) ? 512 : CM_MAX_THREADS) / 64;
     static const int cand[] = {16, 12, 8, 4, 2, 1};
     for (int w : cand)
         if (w <= wmax && cell_mix_lds(KC, CO, K2, Wp, spec, w) <= 160 * 1024) return w;
     return 0;
 }
 
-template <int NT, int KC, int K2S, bool STATS>
+template <int NT, int KC, int K2S, int STATS>
 static int launch_cell_mix(const CellMixArgs& a, int waves, int grid, hipStream_t st) {
     const size_t lds = cell_mix_lds(a.KC, a.CO, a.K2, a.Wp, K2S > 0, waves);
     (void)hipFuncSetAttribute((const void*)cell_mix_kernel<NT, KC, K2S, STATS>,
@@ -343,8 +366,8 @@ static int launch_cell_mix(const CellMixArgs& a, int waves, int grid, hipStream_
 }
 
 // number of [2][CO] stat partial rows cell_mix writes for this problem (== grid * waves)
-extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec) {
-    const int waves = cell_mix_waves(KC, CO, K2, Wp, has_spec != 0);
+extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int bn_bwd_stats) {
+    const int waves = cell_mix_waves(KC, CO, K2, Wp, has_spec != 0, bn_bwd_stats != 0);
     if (waves == 0) return -1;
     const long ntiles = (ncell + 31) / 32;
     long grid = rpb_num_cus();
@@ -357,7 +380,8 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
                             float* out, float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w,
                             int gather, int T, int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean,
                             const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
-                            void* stream) {
+                            const float* bnb_s, const float* bnb_mean, const float* bnb_invstd, const float* bnb_gamma,
+                            const float* bnb_beta, int bnb_gelu, void* stream) {
     RPB_REQUIRE(x && Wm && out, "cell_mix: null pointer");
     if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta && !gather, "cell_mix: bad input-transform arguments");
     RPB_REQUIRE(ncell > 0 && ncell < (1L << 31), "cell_mix: ncell=%ld out of range", ncell);
@@ -365,7 +389,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     RPB_REQUIRE(CO == 32 || CO == 64 || CO == 128, "cell_mix: CO=%d must be 32, 64 or 128", CO);
     const bool spec = z2 != nullptr;
     if (spec) RPB_REQUIRE(GW && K2 > 0 && K2 <= 32 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments (K2=%d)", K2);
-    const int waves = cell_mix_waves(KC, CO, K2, Wp, spec);
+    const int waves = cell_mix_waves(KC, CO, K2, Wp, spec, bnb_s != nullptr);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);
     CellMixArgs a;
     a.x = x; a.Wm = Wm; a.bias = bias; a.z2 = z2; a.GW = GW; a.out = out; a.stats_part = stats_part;
@@ -373,19 +397,24 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     a.transpose_w = transpose_w; a.gather = gather;
     a.cm = CropMap{T, H, W, Tp, Hp, Wp_pad};
     a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
-    const int grid = (int)(rpb_cell_mix_stat_rows(ncell, KC, CO, K2, Wp, spec) / waves);
+    a.bnb_s = bnb_s;
+    a.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu};
+    if (bnb_s) RPB_REQUIRE(stats_part && bnb_mean && bnb_invstd && bnb_gamma && bnb_beta, "cell_mix: BN-backward statistics need stats_part and all four vectors");
+    const int grid = (int)(rpb_cell_mix_stat_rows(ncell, KC, CO, K2, Wp, spec, bnb_s != nullptr) / waves);
     hipStream_t st = (hipStream_t)stream;
-    const bool stats = stats_part != nullptr;
+    const int stats = stats_part == nullptr ? 0 : (bnb_s ? 2 : 1);
     const int NT = CO / 32;
     const int k2s = cell_mix_k2s(K2, spec);
 #define RPB_CM(NT_, KC_, K2S_, ST_) \
     if (NT == NT_ && KC == KC_ && k2s == K2S_ && stats == ST_) return launch_cell_mix<NT_, KC_, K2S_, ST_>(a, waves, grid, st);
+#define RPB_CM3(NT_, KC_, K2S_) RPB_CM(NT_, KC_, K2S_, 0) RPB_CM(NT_, KC_, K2S_, 1) RPB_CM(NT_, KC_, K2S_, 2)
     // square channel mixing (1x1x1 conv fwd / dgrad), with and without the spectral term
-    RPB_CM(1, 32, 8, true) RPB_CM(1, 32, 8, false) RPB_CM(1, 32, 16, true) RPB_CM(1, 32, 16, false) RPB_CM(1, 32, 0, false)
-    RPB_CM(2, 64, 8, true) RPB_CM(2, 64, 8, false) RPB_CM(2, 64, 16, true) RPB_CM(2, 64, 16, false) RPB_CM(2, 64, 0, false)
-    RPB_CM(4, 128, 8, true) RPB_CM(4, 128, 8, false) RPB_CM(4, 128, 16, true) RPB_CM(4, 128, 16, false) RPB_CM(4, 128, 0, false)
-    // fc1 dgrad (128 hidden -> C), gather into the padded layout
-    RPB_CM(1, 128, 0, false) RPB_CM(2, 128, 0, false)
+    RPB_CM3(1, 32, 8) RPB_CM3(1, 32, 16) RPB_CM(1, 32, 0, 0)
+    RPB_CM3(2, 64, 8) RPB_CM3(2, 64, 16) RPB_CM(2, 64, 0, 0)
+    RPB_CM3(4, 128, 8) RPB_CM3(4, 128, 16) RPB_CM(4, 128, 0, 0)
+    // fc1 dgrad (128 hidden -> C), gather into the padded layout; STATS 2 = BN-backward sums of the last layer
+    RPB_CM(1, 128, 0, 0) RPB_CM(2, 128, 0, 0) RPB_CM(1, 128, 0, 2) RPB_CM(2, 128, 0, 2) RPB_CM(4, 128, 0, 2)
+#undef RPB_CM3
 #undef RPB_CM
     RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_mix: unsupported configuration KC=%d CO=%d K2=%d stats=%d", KC, CO, K2, (int)stats);
 }

@@ -50,8 +50,10 @@ class _Workspace:
         if training:
             self.G = [torch.empty(d.ncell, C, **f) for _ in range(2)]
             self.gu = torch.empty(d.ncrop, HID, **f)
-            self.bn_rows = ops.bn_bwd_rows()
-            self.bn_part = torch.empty(self.bn_rows * 2 * C, **f)
+            # BatchNorm-backward sums are produced by the kernels that write the gradient (cell_mix STATS=2)
+            self.bnb_rows_gather = ops.cell_mix_stat_rows(d.ncell, HID, C, 0, 1, False, True)
+            self.bnb_rows_conv = ops.cell_mix_stat_rows(d.ncell, C, C, 2 * plan.KW, d.Wp, True, True)
+            self.bn_part = torch.empty(max(self.bnb_rows_gather, self.bnb_rows_conv) * 2 * C, **f)
             self.bn_sums = torch.empty(2 * C, **f)
             self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
             self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
@@ -305,10 +307,10 @@ class FNO3d(Model):
         for l in range(L):
             s = ws.S[l] if training else ws.S[l % 2]
             xh = ws.Xh[l] if training else ws.Xh[0]
-            self._spectral_forward_stages(a_in, ws, xh, (plan.FW, plan.FH, plan.FT), first_layer=(l == 0), xf=xf)
+            self._spectral_forward_stages(a_in, ws, xh, (plan.FWt, plan.FHt, plan.FTt), first_layer=(l == 0), xf=xf)
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
-            self._spectral_inverse_stages(ws.Yh, ws, (plan.GT, plan.GH))
-            ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GW, s,
+            self._spectral_inverse_stages(ws.Yh, ws, (plan.GTt, plan.GHt))
+            ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s,
                          ws.stat_part if training else None, d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
             if training:
                 ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
@@ -347,14 +349,16 @@ class FNO3d(Model):
         if self.dp is not None:
             self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
         g, g2 = ws.G
-        ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, None, d.ncell, HID, C, 0, 1, transpose_w=True,
-                     gather=True, crop6=d.crop6)
+        # fc1 dgrad scattered into the padded layout; its epilogue also accumulates the BatchNorm-backward sums
+        # (sum gz, sum gz*shat) of the last Fourier layer, so no separate reduction pass reads g again
+        ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, ws.bn_part, d.ncell, HID, C, 0, 1, transpose_w=True,
+                     gather=True, crop6=d.crop6, bnb=(ws.S[L - 1],) + self._layer_xf(ws, L - 1, True))
+        ops.reduce_partials(ws.bn_part, ws.bnb_rows_gather, 2 * C, out_f32=ws.bn_sums)
         # ---- Fourier layers, last to first
         for l in range(L - 1, -1, -1):
             gelu = l < L - 1
             gam, bet = P(f"bns.{l}.weight"), P(f"bns.{l}.bias")
-            ops.bn_bwd_reduce(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_part, d.ncell, C, gelu)
-            ops.reduce_partials(ws.bn_part, ws.bn_rows, 2 * C, out_f32=ws.bn_sums)
+            # ws.bn_sums = (sum gz, sum gz*shat) of layer l, left by the kernel that produced g
             GP(f"bns.{l}.bias").copy_(ws.bn_sums[:C])          # local sums are this rank's d beta / d gamma
             GP(f"bns.{l}.weight").copy_(ws.bn_sums[C:])
             if world > 1:
@@ -364,7 +368,7 @@ class FNO3d(Model):
             if ws.fused_bwd:
                 # one pass: gs = BN/GELU backward (in place), Y1 = GW^T gs (adjoint W stage), conv wgrad partials
                 ops.bn_bwd_row(ws.S[l], g, a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
-                               float(d.ncell) * world, gelu, xf_in, plan.GWt, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
+                               float(d.ncell) * world, gelu, xf_in, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
                                d.Wp, C, 2 * plan.KW)
             else:
                 ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world,
@@ -374,16 +378,21 @@ class FNO3d(Model):
             self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
-            self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GWt, plan.GHt, plan.GTt),
+            self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GW, plan.GH, plan.GT),
                                           first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
             if self.dp is not None and l > 0:
                 self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward
             gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
-            self._spectral_inverse_stages(gxh, ws, (plan.FTt, plan.FHt))
-            ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FWt, g2, None, d.ncell, C, C, 2 * plan.KW,
-                         d.Wp, transpose_w=True)
+            self._spectral_inverse_stages(gxh, ws, (plan.FT, plan.FH))
+            if l > 0:      # g_x of layer l = gradient w.r.t. act(BN(s_{l-1})): also leave layer l-1's BN-backward sums
+                ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, ws.bn_part, d.ncell, C, C,
+                             2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True))
+                ops.reduce_partials(ws.bn_part, ws.bnb_rows_conv, 2 * C, out_f32=ws.bn_sums)
+            else:
+                ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW,
+                             d.Wp, transpose_w=True)
             g, g2 = g2, g
         # ---- lift
         ops.lift_bwd(g, x, grids, ws.lift_part, d)

@@ -58,8 +58,10 @@ def lift_bwd(g, x, grids, part, d):
               label="lift_bwd", nbytes=4 * d.ncrop * (d.Cin + d.C), flops=2 * d.ncrop * d.C * (d.Cin + 3))
 
 
-def axis_gemm(inp, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False, tag="", xf=None):
-    assert tuple(M.shape) == (O, K), (M.shape, O, K)
+def axis_gemm(inp, out, Mt, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, accumulate=False, tag="", xf=None):
+    """``Mt`` is the stage matrix transposed, ``[K, O]`` (out[g,o,n] = sum_k Mt[k,o] * in[g,k,n])."""
+    assert tuple(Mt.shape) == (K, O), (Mt.shape, K, O)
+    M = Mt
     kv = K if k_valid is None else k_valid
     _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o, kv, int(accumulate),
               *_xf(xf), _stream(), label=f"axis_gemm[{tag}K{K}xO{O}]", nbytes=4 * G * N * (kv + O), flops=2 * G * N * kv * O)
@@ -71,8 +73,17 @@ def mode_contract_fwd(X, W, Y, B, M, C):
 
 
 def mode_contract_dgrad(GY, W, GX, B, M, C):
-    _lib.call("rpb_mode_contract_dgrad", _p(GY), _p(W), _p(GX), B, M, C, _stream(), label="mode_contract_dgrad",
-              nbytes=8 * M * C * (C + 2 * B), flops=8 * B * M * C * C)
+    # the kernel keeps the [B][2][C] gradient tile and the padded [C][C+1] complex weight tile of a mode in LDS:
+    # at width 128 that caps the batch per launch, so larger batches go in batch-major slices (contiguous in X)
+    lds_cap = 160 * 1024 - C * (C + 1) * 8
+    bmax = max(1, lds_cap // (2 * C * 4))
+    b0 = 0
+    while b0 < B:
+        nb = min(bmax, B - b0)
+        off = b0 * 2 * M * C
+        _lib.call("rpb_mode_contract_dgrad", _p(GY) + 4 * off, _p(W), _p(GX) + 4 * off, nb, M, C, _stream(),
+                  label="mode_contract_dgrad", nbytes=8 * M * C * (C + 2 * nb), flops=8 * nb * M * C * C)
+        b0 += nb
 
 
 def mode_contract_wgrad(X, GY, GW, B, M, C, accumulate=False):
@@ -80,17 +91,20 @@ def mode_contract_wgrad(X, GY, GW, B, M, C, accumulate=False):
               label="mode_contract_wgrad", nbytes=8 * M * C * (C + 2 * B), flops=8 * B * M * C * C)
 
 
-def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec):
-    return _lib.query("rpb_cell_mix_stat_rows", ncell, KC, CO, K2, Wp, int(has_spec))
+def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec, bn_bwd_stats=False):
+    return _lib.query("rpb_cell_mix_stat_rows", ncell, KC, CO, K2, Wp, int(has_spec), int(bn_bwd_stats))
 
 
 def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
-             crop6=(0, 0, 0, 1, 1, 1), xf=None):
+             crop6=(0, 0, 0, 1, 1, 1), xf=None, bnb=None):
+    """``bnb`` = (s, mean, invstd, gamma, beta, gelu) of the layer whose output gradient this launch produces: the
+    stats partials then hold that layer's BatchNorm-backward sums (sum gz, sum gz*shat)."""
     spec, stats = z2 is not None, stats_part is not None
     rows_in = (crop6[0] * crop6[1] * crop6[2] * (ncell // (crop6[3] * crop6[4] * crop6[5]))) if gather else ncell
     _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
-              int(transpose_w), int(gather), *crop6, *_xf(xf), _stream(),
-              label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={int(stats)}]",
+              int(transpose_w), int(gather), *crop6, *_xf(xf),
+              *((None,) + _xf(None) if bnb is None else (_p(bnb[0]),) + _xf(bnb[1:])), _stream(),
+              label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={int(stats) + int(bnb is not None)}]",
               nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
 

@@ -36,14 +36,14 @@ def test_axis_gemm(ops, G, K, O, N, kv):
         xx[:, kv:] = 0
     ref = torch.einsum("ok,gkn->gon", M, xx)
     out = torch.full((G, O, N), float("nan"), device="cuda")
-    ops.axis_gemm(dev(x), out, dev(M), G, K, O, N, K * N, N, O * N, N, k_valid=kv)
+    ops.axis_gemm(dev(x), out, dev(M.t()), G, K, O, N, K * N, N, O * N, N, k_valid=kv)
     assert rel_l2(out.cpu(), ref) < TOL
     # accumulate
-    ops.axis_gemm(dev(x), out, dev(M), G, K, O, N, K * N, N, O * N, N, k_valid=kv, accumulate=True)
+    ops.axis_gemm(dev(x), out, dev(M.t()), G, K, O, N, K * N, N, O * N, N, k_valid=kv, accumulate=True)
     assert rel_l2(out.cpu(), 2 * ref) < TOL
 
 
-@pytest.mark.parametrize("B,M,C", [(3, 10, 32), (32, 6, 64), (5, 4, 128)])
+@pytest.mark.parametrize("B,M,C", [(3, 10, 32), (32, 6, 64), (5, 4, 128), (32, 3, 128)])
 def test_mode_contract(ops, B, M, C):
     torch.manual_seed(B + M + C)
     X = torch.randn(B, 2, M, C, dtype=torch.float64)
@@ -58,10 +58,9 @@ def test_mode_contract(ops, B, M, C):
     Y = torch.empty(B, 2, M, C, device="cuda")
     ops.mode_contract_fwd(dev(X), dev(W), Y, B, M, C)
     assert rel_l2(Y.cpu(), planar(y)) < TOL
-    if C <= 64 or B <= 8:
-        GX = torch.empty(B, 2, M, C, device="cuda")
-        ops.mode_contract_dgrad(dev(G), dev(W), GX, B, M, C)
-        assert rel_l2(GX.cpu(), planar(gx)) < TOL
+    GX = torch.empty(B, 2, M, C, device="cuda")
+    ops.mode_contract_dgrad(dev(G), dev(W), GX, B, M, C)          # width 128, B=32 goes in two batch slices
+    assert rel_l2(GX.cpu(), planar(gx)) < TOL
     GW = torch.empty(M, C, C, 2, device="cuda")
     ops.mode_contract_wgrad(dev(X), dev(G), GW, B, M, C)
     assert rel_l2(GW.cpu(), torch.view_as_real(gw)) < TOL
@@ -80,14 +79,14 @@ def test_cell_mix_spectral_conv_stats(ops, C, Wp, rows, K2):
     out = torch.empty(ncell, C, device="cuda")
     nrows = ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True)
     part = torch.zeros(nrows, 2, C, device="cuda")
-    ops.cell_mix(dev(x), dev(Wc), dev(bias), dev(z2), dev(GW), out, part, ncell, C, C, K2, Wp)
+    ops.cell_mix(dev(x), dev(Wc), dev(bias), dev(z2), dev(GW.t()), out, part, ncell, C, C, K2, Wp)
     assert rel_l2(out.cpu(), ref) < TOL
     s = part.double().sum(0).cpu()
     assert rel_l2(s[0], ref.sum(0)) < 1e-5
     assert rel_l2(s[1], (ref ** 2).sum(0)) < 1e-5
     # dgrad flavour: transposed weight, no bias, no stats
     ref2 = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + x @ Wc
-    ops.cell_mix(dev(x), dev(Wc), None, dev(z2), dev(GW), out, None, ncell, C, C, K2, Wp, transpose_w=True)
+    ops.cell_mix(dev(x), dev(Wc), None, dev(z2), dev(GW.t()), out, None, ncell, C, C, K2, Wp, transpose_w=True)
     assert rel_l2(out.cpu(), ref2) < TOL
 
 
@@ -316,14 +315,14 @@ def test_lazy_activation_in_consumers(ops, gelu):
     # W stage
     M = torch.randn(32, Wp, dtype=torch.float64)
     out = torch.empty(rows, 32, C, device="cuda")
-    ops.axis_gemm(S, out, dev(M), rows, Wp, 32, C, Wp * C, C, 32 * C, C, xf=xf)
+    ops.axis_gemm(S, out, dev(M.t()), rows, Wp, 32, C, Wp * C, C, 32 * C, C, xf=xf)
     assert rel_l2(out.cpu(), torch.einsum("ok,gkn->gon", M, a.view(rows, Wp, C))) < 3e-6
     # cell_mix
     Wc, bias = torch.randn(C, C, dtype=torch.float64) / 8, torch.randn(C, dtype=torch.float64)
     z2, GW = torch.randn(rows, K2, C, dtype=torch.float64), torch.randn(Wp, K2, dtype=torch.float64)
     ref = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + a @ Wc.t() + bias
     o2 = torch.empty(ncell, C, device="cuda")
-    ops.cell_mix(S, dev(Wc), dev(bias), dev(z2), dev(GW), o2, None, ncell, C, C, K2, Wp, xf=xf)
+    ops.cell_mix(S, dev(Wc), dev(bias), dev(z2), dev(GW.t()), o2, None, ncell, C, C, K2, Wp, xf=xf)
     assert rel_l2(o2.cpu(), ref) < 3e-6
     # cell_wgrad
     gs = torch.randn(ncell, C, dtype=torch.float64)
@@ -386,7 +385,7 @@ def test_fused_bn_bwd_row(ops, C, gelu, lazy_x):
     slots = ops.bn_bwd_row_slots(G)
     part = torch.full((slots, C * C + C), float("nan"), device="cuda")
     ops.bn_bwd_row(dev(s), g, dev(xs), g, dev(mean), dev(invstd), dev(gamma), dev(beta), dev(sums), ncell, gelu, xf,
-                   dev(GWt), Y1, part, G, Wp, C, K2)
+                   dev(GWt.t()), Y1, part, G, Wp, C, K2)
     assert rel_l2(g.cpu(), gs_ref) < 5e-6                       # in place over gy
     assert rel_l2(Y1.cpu(), y1_ref) < 5e-6
     tot = part.double().sum(0).cpu()

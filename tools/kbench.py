@@ -44,9 +44,9 @@ if "cell_mix" in which:
     nb = 4 * (2 * d.ncell * C + d.ncell // d.Wp * K2 * C)
     fl = 2 * d.ncell * C * (K2 + C)
     timeit("cell_mix fwd (spec+stats)",
-           lambda: ops.cell_mix(x, Wc, bias, z2, plan.GW, y, part, d.ncell, C, C, K2, d.Wp), nb, fl)
+           lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, part, d.ncell, C, C, K2, d.Wp), nb, fl)
     timeit("cell_mix bwd (spec)",
-           lambda: ops.cell_mix(x, Wc, None, z2, plan.FWt, y, None, d.ncell, C, C, K2, d.Wp, transpose_w=True), nb, fl)
+           lambda: ops.cell_mix(x, Wc, None, z2, plan.FW, y, None, d.ncell, C, C, K2, d.Wp, transpose_w=True), nb, fl)
     gu = torch.randn(d.ncrop, 128, **f)
     w1 = torch.randn(128, C, **f)
     timeit("cell_mix gather (fc1 dgrad)",
@@ -73,22 +73,22 @@ if "axis" in which:
     Xh = torch.randn(B * 2 * KT * N3, **f)
     G = B * d.Tp * d.Hp
     timeit("axis W fwd  K134xO32",
-           lambda: ops.axis_gemm(x, Y1, plan.FW, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C),
+           lambda: ops.axis_gemm(x, Y1, plan.FWt, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C),
            4 * G * C * (d.Wp + 2 * m3), 2 * G * C * d.Wp * 2 * m3)
     timeit("axis W fwd layer0 (k_valid=128)",
-           lambda: ops.axis_gemm(x, Y1, plan.FW, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C, k_valid=W),
+           lambda: ops.axis_gemm(x, Y1, plan.FWt, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C, k_valid=W),
            4 * G * C * (W + 2 * m3), 2 * G * C * W * 2 * m3)
     timeit("axis H fwd  K268xO48",
-           lambda: ops.axis_gemm(Y1, Y2, plan.FH, B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2),
+           lambda: ops.axis_gemm(Y1, Y2, plan.FHt, B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2),
            4 * B * d.Tp * N2 * (2 * d.Hp + 2 * KH), 2 * B * d.Tp * N2 * 2 * d.Hp * 2 * KH)
     timeit("axis T fwd  K52xO16",
-           lambda: ops.axis_gemm(Y2, Xh, plan.FT, B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3),
+           lambda: ops.axis_gemm(Y2, Xh, plan.FTt, B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3),
            4 * B * N3 * (2 * d.Tp + 2 * KT), 2 * B * N3 * 2 * d.Tp * 2 * KT)
     timeit("axis T inv  K16xO52",
-           lambda: ops.axis_gemm(Xh, Y2, plan.GT, B, 2 * KT, 2 * d.Tp, N3, 2 * KT * N3, N3, 2 * d.Tp * N3, N3),
+           lambda: ops.axis_gemm(Xh, Y2, plan.GTt, B, 2 * KT, 2 * d.Tp, N3, 2 * KT * N3, N3, 2 * d.Tp * N3, N3),
            4 * B * N3 * (2 * d.Tp + 2 * KT), 2 * B * N3 * 2 * d.Tp * 2 * KT)
     timeit("axis H inv  K48xO268",
-           lambda: ops.axis_gemm(Y2, Y1, plan.GH, B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2),
+           lambda: ops.axis_gemm(Y2, Y1, plan.GHt, B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2),
            4 * B * d.Tp * N2 * (2 * d.Hp + 2 * KH), 2 * B * d.Tp * N2 * 2 * d.Hp * 2 * KH)
 
 if "bn" in which:
