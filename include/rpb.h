@@ -134,6 +134,35 @@ int rpb_rollout_affine(const float* pred, const float* para, float* out, long nc
 int rpb_channel_affine(const float* in, float* out, long n, int C, const float* mean, const float* stdv, int inverse,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Transolver (Physics-Attention, structured 3-D mesh) -- forward path.  Tokens are channels-last rows [token][C].
+ * Reference: realpdebench/model/TRANSOLVER_libs/{Physics_Attention.py:148-176, Transolver_Structured_Mesh_3D.py:170-196}
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*     out = epilogue(A W^T): nn.Linear over tokens with fused bias / GELU / broadcast vector / residual
+ *     (Transolver_Structured_Mesh_3D.py:31-39,71-77) and, with conv=1, the two nn.Conv3d(C, C, 3, padding=1) of
+ *     Physics_Attention.py:154-157 as one implicit GEMM over the (Hc, Wc, Dc) mesh: W is [N][27*Ci] with
+ *     column = ((kh*3 + kw)*3 + kd)*Ci + ci.  K must be a multiple of 32. */
+int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
+                long M, int N, int K, int lda, int ldo, int act, int conv, int Hc, int Wc, int Dc, void* stream);
+/*     tiny-K linear (+GELU): preprocess.linear_pre, C_in -> 2*n_hidden (Transolver_Structured_Mesh_3D.py:27,32). */
+int rpb_tokens_lift(const float* x, const float* W, const float* b, float* out, long M, int K, int N, int act,
+                    void* stream);
+/*     nn.LayerNorm(C) per token, one wavefront per token (Transolver_Structured_Mesh_3D.py:56,60,68). */
+int rpb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out, long M, int C, float eps,
+                      void* stream);
+/*     slice weights (temperature softmax over G slices per head) + per-sample slice-token sums and norms
+ *     (Physics_Attention.py:158-162).  xf rows: fx_mid at column 0, x_mid at column heads*32.
+ *     tok_part [B*bps][heads*G*32], norm_part [B*bps][heads*G], bps = rpb_slice_blocks_per_sample(B). */
+int rpb_slice_blocks_per_sample(int B);
+int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, const float* temp, float* w_out, float* tok_part,
+                  float* norm_part, int B, int ntok, int heads, int G, int ldx, void* stream);
+/*     attention among the G slice tokens of every (sample, head) (Physics_Attention.py:164-171, eval mode). */
+int rpb_slice_attn(const float* tokS, const float* norm, const float* Wq, const float* Wk, const float* Wv, float* out,
+                   int BH, int G, void* stream);
+/*     deslice: out[m][h*32+c] = sum_g w[m][h][g] tok2[b][h][g][c] (Physics_Attention.py:173-175). */
+int rpb_deslice_fwd(const float* w, const float* tok2, float* out, int B, int ntok, int heads, int G, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

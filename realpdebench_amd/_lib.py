@@ -44,6 +44,13 @@ SIGNATURES = {
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
+    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "iiii" + "p"),
+    "rpb_tokens_lift": (_I, "pppp" + "l" + "iii" + "p"),
+    "rpb_layernorm_fwd": (_I, "pppp" + "l" + "i" + "f" + "p"),
+    "rpb_slice_blocks_per_sample": (_I, "i"),
+    "rpb_slice_fwd": (_I, "ppppppp" + "iiiii" + "p"),
+    "rpb_slice_attn": (_I, "pppppp" + "ii" + "p"),
+    "rpb_deslice_fwd": (_I, "ppp" + "iiii" + "p"),
 }
 
 _lib = None

@@ -1,0 +1,214 @@
+// Token GEMM on fp32 MFMA:  out[m][n] = epilogue( sum_k A(m,k) * W[n][k] )      (W in nn.Linear layout [N][K])
+//
+// Used by the Transolver path (reference realpdebench/model/TRANSOLVER_libs):
+//   * nn.Linear over tokens -- preprocess.linear_post, Attn.to_out, mlp.linear_pre/post, mlp2
+//     (Transolver_Structured_Mesh_3D.py:27-39,71-77), with bias / GELU / residual / broadcast-vector epilogues fused;
+//   * nn.Conv3d(256, 256, 3, padding=1) x2 of Physics_Attention_Structured_Mesh_3D (Physics_Attention.py:138-139,
+//     154-157) as ONE implicit GEMM: A(m, tap*Ci + ci) = x[neighbour(m, tap)][ci] (zero outside the mesh) gathered on
+//     the fly from the channels-last token tensor, N = 512 = both convolutions, K = 27*Ci.  The reference's
+//     permute(0,4,1,2,3) / permute(0,2,3,4,1) pairs around the convolutions disappear.
+//
+// Tiling: workgroup = WM x WN waves, each wave TM x TN MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32), K chunks of 32.
+// Both operands are staged through +1-padded LDS tiles ([row][BK+1], conflict-free transposed ds_read_b32); the next
+// chunk is prefetched into registers (float4, coalesced along k) while the current one is multiplied.
+#include "rpb_common.h"
+
+#define G_BK 32
+
+struct GemmArgs {
+    const float* A;        // [rows][lda]
+    const float* W;        // [N][K]
+    const float* bias;     // [N] or null
+    const float* addvec;   // [N] or null (e.g. the Transolver `placeholder`)
+    const float* residual; // [M][ldo] or null
+    float* out;            // [M][ldo]
+    long M;
+    int N, K, lda, ldo;
+    int act;               // 0 none, 1 exact GELU
+    // implicit 3x3x3 convolution over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
+    int conv, Hc, Wc, Dc;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
+    constexpr int XS = G_BK + 1;
+    constexpr int A4 = BM * (G_BK / 4) / NTHR;      // float4 loads per thread per chunk (A)
+    constexpr int W4 = BN * (G_BK / 4) / NTHR;      //                                   (W)
+    static_assert(A4 >= 1 && W4 >= 1, "tile too small for the thread count");
+    extern __shared__ float lds[];
+    float* Al = lds;                  // [BM][XS]
+    float* Wl = lds + BM * XS;        // [BN][XS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 31, half = lane >> 5;
+    const int ntn = (g.N + BN - 1) / BN;
+    const long tile_m = blockIdx.x / ntn;
+    const int tile_n = blockIdx.x % ntn;
+    const long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int Ci = g.conv ? g.K / 27 : g.K;
+
+    // per-thread rows of the A tile (fixed across chunks) and, for the convolution, their mesh coordinates
+    int arow[A4];          // row within tile
+    long am[A4];           // global token index (or -1)
+    int ah[A4], aw[A4], ad[A4];
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+        const int idx = tid + j * NTHR;
+        arow[j] = idx / (G_BK / 4);
+        const long m = m0 + arow[j];
+        am[j] = (m < g.M) ? m : -1;
+        if (g.conv && am[j] >= 0) {
+            const long per = (long)g.Hc * g.Wc * g.Dc;
+            long r = m % per;
+            ad[j] = (int)(r % g.Dc);
+            r /= g.Dc;
+            aw[j] = (int)(r % g.Wc);
+            ah[j] = (int)(r / g.Wc);
+        } else {
+            ah[j] = aw[j] = ad[j] = 0;
+        }
+    }
+    const int c4 = tid % (G_BK / 4);           // float4 column within the chunk (same for every j: NTHR % 8 == 0)
+
+    f32x4 pa[A4], pw[W4];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int nchunk = g.K / G_BK;
+
+    auto prefetch = [&](int ch) {
+        const int k0 = ch * G_BK;
+        int tap = 0, kk = k0;
+        int dh = 0, dw = 0, dd = 0;
+        long noff = 0;
+        if (g.conv) {
+            tap = k0 / Ci;
+            kk = k0 - tap * Ci;
+            dh = tap / 9 - 1;
+            dw = (tap / 3) % 3 - 1;
+            dd = tap % 3 - 1;
+            noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
+        }
+#pragma unroll
+        for (int j = 0; j < A4; ++j) {
+            f32x4 v = z4;
+            if (am[j] >= 0) {
+                if (g.conv) {
+                    const int hh = ah[j] + dh, ww = aw[j] + dw, d2 = ad[j] + dd;
+                    if (hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc)
+                        v = *reinterpret_cast<const f32x4*>(g.A + (am[j] + noff) * g.lda + kk + 4 * c4);
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(g.A + am[j] * g.lda + k0 + 4 * c4);
+                }
+            }
+            pa[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < W4; ++j) {
+            const int idx = tid + j * NTHR;
+            const int n = n0 + idx / (G_BK / 4);
+            pw[j] = (n < g.N) ? *reinterpret_cast<const f32x4*>(g.W + (long)n * g.K + k0 + 4 * c4) : z4;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = zero16();
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();                               // previous chunk's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < A4; ++j) {
+            float* d = Al + arow[j] * XS + 4 * c4;
+            d[0] = pa[j][0];
+            d[1] = pa[j][1];
+            d[2] = pa[j][2];
+            d[3] = pa[j][3];
+        }
+#pragma unroll
+        for (int j = 0; j < W4; ++j) {
+            const int idx = tid + j * NTHR;
+            float* d = Wl + (idx / (G_BK / 4)) * XS + 4 * c4;
+            d[0] = pw[j][0];
+            d[1] = pw[j][1];
+            d[2] = pw[j][2];
+            d[3] = pw[j][3];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) prefetch(ch + 1);          // in flight during the MFMAs below
+        const float* ap = Al + (wm * TM * 32 + col) * XS + half;
+        const float* bp = Wl + (wn * TN * 32 + col) * XS + half;
+#pragma unroll
+        for (int s = 0; s < G_BK / 2; ++s) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = ap[i * 32 * XS + 2 * s];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = bp[j * 32 * XS + 2 * s];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        }
+    }
+    // epilogue: bias, broadcast vector, activation, residual
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + col;
+        if (n >= g.N) continue;
+        const float badd = (g.bias ? g.bias[n] : 0.f);
+        const float vadd = (g.addvec ? g.addvec[n] : 0.f);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + (wm * TM + i) * 32 + mfma_row(lane, r);
+                if (m < g.M) {
+                    float v = acc[i][j][r] + badd;
+                    if (g.act == 1) v = gelu_f(v);
+                    v += vadd;
+                    if (g.residual) v += g.residual[m * g.ldo + n];
+                    g.out[m * g.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const size_t lds = (size_t)(BM + BN) * (G_BK + 1) * 4;
+    const long tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    RPB_REQUIRE(tiles > 0 && tiles < (1L << 31), "gemm: bad tile count");
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3((unsigned)tiles), dim3(WM * WN * 64), lds, st, g);
+    RPB_CHECK_LAUNCH("gemm_nt");
+}
+
+extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual,
+                           float* out, long M, int N, int K, int lda, int ldo, int act, int conv, int Hc, int Wc, int Dc,
+                           void* stream) {
+    RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
+    RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
+                N, K, G_BK);
+    RPB_REQUIRE(lda % 4 == 0 && ldo >= N, "gemm_nt: lda=%d must be a multiple of 4 and ldo=%d >= N", lda, ldo);
+    if (conv) {
+        RPB_REQUIRE(K % 27 == 0 && (K / 27) % G_BK == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
+                    "gemm_nt: bad convolution geometry");
+    }
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.addvec = addvec; g.residual = residual; g.out = out;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act;
+    g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64) return launch_gemm<2, 2, 2, 2>(g, st);      // 128 x 128 tile
+    if (N > 32) return launch_gemm<2, 2, 2, 1>(g, st);      // 128 x 64
+    return launch_gemm<4, 1, 1, 1>(g, st);                   // 128 x 32 (small heads, e.g. mlp2: 256 -> 3)
+}

@@ -21,6 +21,14 @@ def load_model(train_dataset, device="cpu", **kwargs):
             shape_in=input_shape,
             shape_out=output_shape,
         ).to(device)
+    elif model_name == "transolver":
+        from .transolver import Transolver
+        model = Transolver(                                   # load_model.py:145-152
+            space_dim=kwargs["space_dim"], n_layers=kwargs["n_layers"], n_hidden=kwargs["n_hidden"],
+            n_head=kwargs["n_head"], H=kwargs["H"], W=kwargs["W"], D=kwargs["D"], Time_Input=False, unified_pos=False,
+            fun_dim=kwargs["fun_dim"], out_dim=kwargs["out_dim"], ref=kwargs["ref"], dropout=kwargs["dropout"],
+            act=kwargs["act"], mlp_ratio=kwargs["mlp_ratio"], slice_num=kwargs["slice_num"],
+        ).to(device)
     else:
-        raise ValueError(f"Model {model_name} not supported by the MI355X backend (supported: fno)")
+        raise ValueError(f"Model {model_name} not supported by the MI355X backend (supported: fno, transolver)")
     return model

@@ -202,3 +202,43 @@ def rollout_affine(pred, para, out, ncell, Cp, Cx, mean_t, std_t, mean_i, std_i)
 
 def channel_affine(inp, out, n, C, mean, std, inverse):
     _lib.call("rpb_channel_affine", _p(inp), _p(out), n, C, _p(mean), _p(std), int(inverse), _stream())
+
+
+# ----------------------------------------------------------------------------- Transolver forward kernels
+def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None):
+    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A the implicit 3x3x3 im2col of a token tensor."""
+    hc, wc, dc = conv if conv else (0, 0, 0)
+    lda = (K // 27 if conv else K) if lda is None else lda
+    _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
+              N if ldo is None else ldo, int(act), int(conv is not None), hc, wc, dc, _stream(),
+              label=f"gemm_nt[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * (M * lda + M * N + N * K),
+              flops=2 * M * N * K)
+
+
+def tokens_lift(x, W, b, out, M, K, N, act):
+    _lib.call("rpb_tokens_lift", _p(x), _p(W), _p(b), _p(out), M, K, N, int(act), _stream(), label="tokens_lift",
+              nbytes=4 * M * (K + N), flops=2 * M * K * N)
+
+
+def layernorm_fwd(x, gamma, beta, out, M, C, eps=1e-5):
+    _lib.call("rpb_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), M, C, eps, _stream(), label="layernorm_fwd",
+              nbytes=8 * M * C, flops=8 * M * C)
+
+
+def slice_blocks_per_sample(B):
+    return _lib.query("rpb_slice_blocks_per_sample", B)
+
+
+def slice_fwd(xf, Ws, bs, temp, w_out, tok_part, norm_part, B, ntok, heads, G, ldx):
+    _lib.call("rpb_slice_fwd", _p(xf), _p(Ws), _p(bs), _p(temp), _p(w_out), _p(tok_part), _p(norm_part), B, ntok, heads,
+              G, ldx, _stream(), label="slice_fwd", nbytes=4 * B * ntok * (ldx + 2 * heads * G),
+              flops=2 * B * ntok * heads * G * 64)
+
+
+def slice_attn(tokS, norm, Wq, Wk, Wv, out, BH, G):
+    _lib.call("rpb_slice_attn", _p(tokS), _p(norm), _p(Wq), _p(Wk), _p(Wv), _p(out), BH, G, _stream(), label="slice_attn")
+
+
+def deslice_fwd(w, tok2, out, B, ntok, heads, G):
+    _lib.call("rpb_deslice_fwd", _p(w), _p(tok2), _p(out), B, ntok, heads, G, _stream(), label="deslice_fwd",
+              nbytes=4 * B * ntok * heads * (G + 32), flops=2 * B * ntok * heads * G * 32)

@@ -64,3 +64,21 @@ def test_init_state_dict_matches_reference_layout(golden):
     assert set(sd) == set(ref)
     for k in ref:
         assert tuple(sd[k].shape) == tuple(ref[k].shape) and sd[k].dtype == ref[k].dtype, k
+
+
+def _transolver_golden():
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "transolver_small.npz"))
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")}
+    cfg = {k[4:]: int(z[k]) if float(z[k]).is_integer() else float(z[k]) for k in z.files if k.startswith("cfg/")}
+    return sd, cfg, torch.from_numpy(np.array(z["x"])), torch.from_numpy(np.array(z["y"]))
+
+
+def test_transolver_oracle_forward_matches_reference():
+    from oracle import transolver_oracle as TO
+    sd, cfg, x, y = _transolver_golden()
+    out = TO.transolver_forward(sd, x, cfg["n_layers"], cfg["n_head"], cfg["H"], cfg["W"], cfg["D"])
+    assert out.shape == y.shape
+    assert rel_l2(out, y) < TOL
