@@ -143,20 +143,43 @@ int rpb_channel_affine(const float* in, float* out, long n, int C, const float* 
  *     (Transolver_Structured_Mesh_3D.py:31-39,71-77) and, with conv=1, the two nn.Conv3d(C, C, 3, padding=1) of
  *     Physics_Attention.py:154-157 as one implicit GEMM over the (Hc, Wc, Dc) mesh: W is [N][27*Ci] with
  *     column = ((kh*3 + kw)*3 + kd)*Ci + ci.  K must be a multiple of 32. */
+/*     act: 0 none | 1 exact GELU (pre_out, if given, receives the pre-activation for the backward pass) |
+ *          2 multiply by gelu'(aux[m][n]) (backward through a GELU; aux = that saved pre-activation). */
 int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
-                long M, int N, int K, int lda, int ldo, int act, int conv, int Hc, int Wc, int Dc, void* stream);
+                long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, int conv, int Hc,
+                int Wc, int Dc, void* stream);
+/*     weight gradients: part[rpb_gemm_tn_splits(M,N,K)][N*K + N] partials of dW[n][k] = sum_m G[m][n] A(m,k) and
+ *     db[n] = sum_m G[m][n] (autograd of the nn.Linear / nn.Conv3d weights above); conv=1 gathers A like rpb_gemm_nt. */
+int rpb_gemm_tn_splits(long M, int N, int K);
+int rpb_gemm_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, int conv, int Hc,
+                int Wc, int Dc, void* stream);
 /*     tiny-K linear (+GELU): preprocess.linear_pre, C_in -> 2*n_hidden (Transolver_Structured_Mesh_3D.py:27,32). */
 int rpb_tokens_lift(const float* x, const float* W, const float* b, float* out, long M, int K, int N, int act,
                     void* stream);
 /*     nn.LayerNorm(C) per token, one wavefront per token (Transolver_Structured_Mesh_3D.py:56,60,68). */
 int rpb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out, long M, int C, float eps,
                       void* stream);
+/*     its backward: gx = LN'(gy) (+ gadd, the residual branch's gradient); part[rpb_layernorm_bwd_rows(M)][2][C]
+ *     partials of (d gamma, d beta). */
+long rpb_layernorm_bwd_rows(long M);
+int rpb_layernorm_bwd(const float* x, const float* gamma, const float* gy, const float* gadd, float* gx, float* part,
+                      long M, int C, float eps, void* stream);
 /*     slice weights (temperature softmax over G slices per head) + per-sample slice-token sums and norms
  *     (Physics_Attention.py:158-162).  xf rows: fx_mid at column 0, x_mid at column heads*32.
  *     tok_part [B*bps][heads*G*32], norm_part [B*bps][heads*G], bps = rpb_slice_blocks_per_sample(B). */
 int rpb_slice_blocks_per_sample(int B);
+/*     w_in != NULL: skip the softmax, use the given weights and only produce the token sums of xf[:, :heads*32]
+ *     (that is the backward of deslice w.r.t. the slice tokens). */
 int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, const float* temp, float* w_out, float* tok_part,
-                  float* norm_part, int B, int ntok, int heads, int G, int ldx, void* stream);
+                  float* norm_part, int B, int ntok, int heads, int G, int ldx, const float* w_in, void* stream);
+/*     backward of slice + deslice w.r.t. the dual-convolution output: gxf[m] = [g_fx_mid | g_x_mid];
+ *     part[B*bps][G*32 + G + heads] partials of (d in_project_slice.weight, d in_project_slice.bias, d tau). */
+int rpb_slice_bwd(const float* xf, const float* w, const float* gox, const float* tok2, const float* gT, const float* gN,
+                  const float* Ws, const float* temp, float* gxf, float* part, int B, int ntok, int heads, int G,
+                  void* stream);
+/*     column sums (bias / placeholder gradients): part[rpb_colsum_rows()][N]. */
+int rpb_colsum_rows(void);
+int rpb_colsum(const float* x, float* part, long M, int N, int ld, void* stream);
 /*     attention among the G slice tokens of every (sample, head) (Physics_Attention.py:164-171, eval mode). */
 int rpb_slice_attn(const float* tokS, const float* norm, const float* Wq, const float* Wk, const float* Wv, float* out,
                    int BH, int G, void* stream);

@@ -44,11 +44,18 @@ SIGNATURES = {
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
-    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "iiii" + "p"),
+    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "pp" + "iiii" + "p"),
+    "rpb_gemm_tn_splits": (_I, "lii"),
+    "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
+    "rpb_layernorm_bwd_rows": (_L, "l"),
+    "rpb_layernorm_bwd": (_I, "pppppp" + "l" + "i" + "f" + "p"),
+    "rpb_slice_bwd": (_I, "pppppppppp" + "iiii" + "p"),
+    "rpb_colsum_rows": (_I, ""),
+    "rpb_colsum": (_I, "pp" + "l" + "ii" + "p"),
     "rpb_tokens_lift": (_I, "pppp" + "l" + "iii" + "p"),
     "rpb_layernorm_fwd": (_I, "pppp" + "l" + "i" + "f" + "p"),
     "rpb_slice_blocks_per_sample": (_I, "i"),
-    "rpb_slice_fwd": (_I, "ppppppp" + "iiiii" + "p"),
+    "rpb_slice_fwd": (_I, "ppppppp" + "iiiii" + "p" + "p"),
     "rpb_slice_attn": (_I, "pppppp" + "ii" + "p"),
     "rpb_deslice_fwd": (_I, "ppp" + "iiii" + "p"),
 }

@@ -24,7 +24,9 @@ struct GemmArgs {
     float* out;            // [M][ldo]
     long M;
     int N, K, lda, ldo;
-    int act;               // 0 none, 1 exact GELU
+    int act;               // 0 none, 1 exact GELU, 2 multiply by gelu'(aux[m][n]) (backward through a GELU)
+    const float* aux;      // act == 2: the saved pre-activation [M][ldo]
+    float* pre_out;        // act == 1: optional copy of the pre-activation (saved for the backward pass)
     // implicit 3x3x3 convolution over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
     int conv, Hc, Wc, Dc;
 };
@@ -170,7 +172,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                 const long m = m0 + (wm * TM + i) * 32 + mfma_row(lane, r);
                 if (m < g.M) {
                     float v = acc[i][j][r] + badd;
-                    if (g.act == 1) v = gelu_f(v);
+                    if (g.act == 1) {
+                        if (g.pre_out) g.pre_out[m * g.ldo + n] = v;
+                        v = gelu_f(v);
+                    } else if (g.act == 2) {
+                        v *= gelu_grad_f(g.aux[m * g.ldo + n]);
+                    }
                     v += vadd;
                     if (g.residual) v += g.residual[m * g.ldo + n];
                     g.out[m * g.ldo + n] = v;
@@ -193,9 +200,10 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
 }
 
 extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual,
-                           float* out, long M, int N, int K, int lda, int ldo, int act, int conv, int Hc, int Wc, int Dc,
-                           void* stream) {
+                           float* out, long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out,
+                           int conv, int Hc, int Wc, int Dc, void* stream) {
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
+    RPB_REQUIRE(act != 2 || aux, "gemm_nt: act=2 needs the saved pre-activation");
     RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
                 N, K, G_BK);
     RPB_REQUIRE(lda % 4 == 0 && ldo >= N, "gemm_nt: lda=%d must be a multiple of 4 and ldo=%d >= N", lda, ldo);
@@ -205,10 +213,152 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
     }
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.addvec = addvec; g.residual = residual; g.out = out;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act; g.aux = aux; g.pre_out = pre_out;
     g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64) return launch_gemm<2, 2, 2, 2>(g, st);      // 128 x 128 tile
     if (N > 32) return launch_gemm<2, 2, 2, 1>(g, st);      // 128 x 64
     return launch_gemm<4, 1, 1, 1>(g, st);                   // 128 x 32 (small heads, e.g. mlp2: 256 -> 3)
+}
+
+// ---------------------------------------------------------------------------------- TN GEMM (weight gradients)
+//   dW[n][k] = sum_m G[m][n] * A(m,k),   db[n] = sum_m G[m][n]          (autograd of nn.Linear / nn.Conv3d weights)
+// Both operands are "lane = channel" in HBM, exactly what the MFMA wants when the reduction index is the token:
+// they are loaded straight into registers (float2: channel pair col*2+t), no LDS.  Workgroup = 2x2 waves x (64x64) =
+// a 128 x 128 tile of dW; the token range is split across gridDim.y and each split writes a partial that
+// rpb_reduce_partials sums in fp64.  With conv=1, A(m, tap*Ci+ci) = x[neighbour(m,tap)][ci] (a 128-column k tile never
+// crosses a tap because Ci % 64 == 0 and every wave derives the tap from its own 64-column sub-tile).
+struct GemmTnArgs {
+    const float* G;      // [M][ldg]
+    const float* A;      // [M][lda]
+    float* part;         // [splits][N*K + N]
+    long M;
+    int N, K, ldg, lda;
+    int conv, Hc, Wc, Dc;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int col = lane & 31, half = lane >> 5;
+    const int tk = (g.K + 127) / 128;
+    const int tile_n = blockIdx.x / tk, tile_k = blockIdx.x % tk;
+    const int n0 = tile_n * 128 + wn * 64, k0 = tile_k * 128 + wk * 64;       // this wave's 64 x 64 sub-tile
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const long per = (g.M + nsplit - 1) / nsplit;
+    const long mb = (long)split * per;
+    long me = mb + per;
+    if (me > g.M) me = g.M;
+    const int Ci = g.conv ? g.K / 27 : g.K;
+    int tap = 0, kk0 = k0, dh = 0, dw = 0, dd = 0;
+    long noff = 0;
+    if (g.conv) {
+        tap = k0 / Ci;
+        kk0 = k0 - tap * Ci;
+        dh = tap / 9 - 1;
+        dw = (tap / 3) % 3 - 1;
+        dd = tap % 3 - 1;
+        noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
+    }
+    const bool n_ok0 = n0 + col * 2 < g.N, n_ok1 = n0 + col * 2 + 1 < g.N;      // N may be < 64 (e.g. mlp2: 3)
+    const bool k_ok0 = kk0 + col * 2 < (g.conv ? Ci : g.K), k_ok1 = kk0 + col * 2 + 1 < (g.conv ? Ci : g.K);
+    const long mesh = (long)g.Hc * g.Wc * g.Dc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[o][i] = zero16();
+    float bsum[2] = {0.f, 0.f};
+
+    f32x2 ga[8], gb[8], xa[8], xb[8];
+    auto load_half = [&](long m0, f32x2 (&gv)[8], f32x2 (&xv)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const long m = m0 + 2 * s + half;
+            f32x2 gq = {0.f, 0.f}, xq = {0.f, 0.f};
+            if (m < me) {
+                const float* gp = g.G + m * g.ldg + n0 + col * 2;
+                if (n_ok1) gq = *reinterpret_cast<const f32x2*>(gp);
+                else if (n_ok0) gq[0] = gp[0];
+                long row = m;
+                bool ok = true;
+                if (g.conv) {
+                    const long r = m % mesh;
+                    const int d0 = (int)(r % g.Dc), w0 = (int)((r / g.Dc) % g.Wc), h0 = (int)(r / ((long)g.Dc * g.Wc));
+                    const int hh = h0 + dh, ww = w0 + dw, d2 = d0 + dd;
+                    ok = hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
+                    row = m + noff;
+                }
+                if (ok) {
+                    const float* xp = g.A + row * g.lda + kk0 + col * 2;
+                    if (k_ok1) xq = *reinterpret_cast<const f32x2*>(xp);
+                    else if (k_ok0) xq[0] = xp[0];
+                }
+            }
+            gv[s] = gq;
+            xv[s] = xq;
+        }
+    };
+    auto compute_half = [&](const f32x2 (&gv)[8], const f32x2 (&xv)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                bsum[o] += gv[s][o];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[o][i] = mfma32(gv[s][o], xv[s][i], acc[o][i]);
+            }
+    };
+    long m = mb;
+    if (m < me) load_half(m, ga, xa);
+    for (; m < me; m += 32) {
+        load_half(m + 16, gb, xb);
+        compute_half(ga, xa);
+        if (m + 32 < me) load_half(m + 32, ga, xa);
+        compute_half(gb, xb);
+    }
+    float* part = g.part + (long)split * ((long)g.N * g.K + g.N);
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + mfma_row(lane, r) * 2 + o;
+                const int k = k0 + col * 2 + i;
+                if (n < g.N && k < g.K) part[(long)n * g.K + k] = acc[o][i][r];
+            }
+        if (tile_k == 0 && wk == 0) {
+            const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
+            const int n = n0 + col * 2 + o;
+            if (half == 0 && n < g.N) part[(long)g.N * g.K + n] = b;
+        }
+    }
+}
+
+extern "C" int rpb_gemm_tn_splits(long M, int N, int K) {
+    const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+    long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
+    const long cap = (M + 511) / 512;                 // at least 512 tokens per split
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, int conv,
+                           int Hc, int Wc, int Dc, void* stream) {
+    RPB_REQUIRE(G && A && part && M > 0 && N > 0 && K > 0, "gemm_tn: bad arguments");
+    RPB_REQUIRE(ldg % 2 == 0 && lda % 2 == 0, "gemm_tn: leading dimensions must be even (float2 loads)");
+    if (conv) RPB_REQUIRE(K % 27 == 0 && (K / 27) % 64 == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
+                          "gemm_tn: bad convolution geometry (Ci must be a multiple of 64)");
+    GemmTnArgs a;
+    a.G = G; a.A = A; a.part = part; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.lda = lda;
+    a.conv = conv; a.Hc = Hc; a.Wc = Wc; a.Dc = Dc;
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    const int splits = rpb_gemm_tn_splits(M, N, K);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("gemm_tn");
 }

@@ -112,7 +112,8 @@ extern "C" int rpb_layernorm_fwd(const float* x, const float* gamma, const float
 __global__ __launch_bounds__(TS_THREADS) void slice_fwd_kernel(const float* __restrict__ xf, const float* __restrict__ Ws,
                                                                const float* __restrict__ bs, const float* __restrict__ temp,
                                                                float* __restrict__ w_out, float* __restrict__ part,
-                                                               int ntok, int heads, int G, int ldx, int blocks_per_sample) {
+                                                               int ntok, int heads, int G, int ldx, int blocks_per_sample,
+                                                               const float* __restrict__ w_in) {
     extern __shared__ float lds[];
     const int C = heads * 32;
     float* Wsl = lds;                               // [G][33]
@@ -143,6 +144,12 @@ __global__ __launch_bounds__(TS_THREADS) void slice_fwd_kernel(const float* __re
             const int r = tid & 63;
             const bool ok = t0 + r < ntok;
             for (int h = tid >> 6; h < heads; h += TS_THREADS / 64) {
+                if (w_in) {        // weights given (backward of deslice): just stage them
+#pragma unroll
+                    for (int g = 0; g < 32; ++g)
+                        if (g < G) wl[(h * 64 + r) * G + g] = ok ? w_in[((base + t0 + r) * heads + h) * G + g] : 0.f;
+                    continue;
+                }
                 float xv[32];
                 const float* xp = xf + (base + t0 + r) * ldx + C + h * 32;
 #pragma unroll
@@ -228,8 +235,9 @@ extern "C" int rpb_slice_blocks_per_sample(int B) {
 }
 
 extern "C" int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, const float* temp, float* w_out,
-                             float* tok_part, float* norm_part, int B, int ntok, int heads, int G, int ldx, void* stream) {
-    RPB_REQUIRE(xf && Ws && bs && temp && w_out && tok_part && norm_part, "slice_fwd: null pointer");
+                             float* tok_part, float* norm_part, int B, int ntok, int heads, int G, int ldx,
+                             const float* w_in, void* stream) {
+    RPB_REQUIRE(xf && tok_part && (w_in || (Ws && bs && temp && w_out && norm_part)), "slice_fwd: null pointer");
     RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 1 && G <= 32 && (heads * G) <= TS_THREADS && TS_THREADS % (heads * G) == 0,
                 "slice_fwd: heads=%d G=%d unsupported (dim_head must be 32)", heads, G);
     const int bps = rpb_slice_blocks_per_sample(B);
@@ -238,10 +246,11 @@ extern "C" int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, 
     RPB_REQUIRE(lds <= 160 * 1024, "slice_fwd: LDS");
     (void)hipFuncSetAttribute((const void*)slice_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(slice_fwd_kernel, dim3(B * bps), dim3(TS_THREADS), lds, st, xf, Ws, bs, temp, w_out, tok_part, ntok,
-                       heads, G, ldx, bps);
+    hipLaunchKernelGGL(slice_fwd_kernel, dim3(B * bps), dim3(TS_THREADS), lds, st, xf, w_in ? xf : Ws, bs, temp, w_out,
+                       tok_part, ntok, heads, G, ldx, bps, w_in);
     const int HG = heads * G;
-    hipLaunchKernelGGL(slice_norm_kernel, dim3(B * bps), dim3(TS_THREADS), (size_t)(TS_THREADS / HG) * HG * 4, st, w_out,
+    if (!w_in)
+        hipLaunchKernelGGL(slice_norm_kernel, dim3(B * bps), dim3(TS_THREADS), (size_t)(TS_THREADS / HG) * HG * 4, st, w_out,
                        norm_part, ntok, HG, bps);
     RPB_CHECK_LAUNCH("slice_fwd");
 }
@@ -340,4 +349,271 @@ extern "C" int rpb_deslice_fwd(const float* w, const float* tok2, float* out, in
     hipLaunchKernelGGL(deslice_kernel, dim3(B * bps), dim3(TS_THREADS), (size_t)heads * G * 32 * 4, (hipStream_t)stream, w,
                        tok2, out, ntok, heads, G, bps);
     RPB_CHECK_LAUNCH("deslice");
+}
+
+
+// ---------------------------------------------------------------------------------- LayerNorm backward
+// gx = rstd * (gy*gamma - mean(gy*gamma) - xhat * mean(gy*gamma*xhat)) [+ gadd];  per-wave partials of
+// dgamma = sum gy*xhat and dbeta = sum gy  ->  part[nwaves][2][C].  mean / rstd are recomputed from x.
+template <int V>
+__global__ __launch_bounds__(TS_THREADS) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ gy, const float* gadd, float* gx,
+                                                                   float* __restrict__ part, long M, float eps) {
+    constexpr int C = 64 * V;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float ga[V], dg[V], db[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        ga[v] = gamma[v * 64 + lane];
+        dg[v] = db[v] = 0.f;
+    }
+    for (long m = wave; m < M; m += nwaves) {
+        float xv[V], gv[V], s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            xv[v] = x[m * C + v * 64 + lane];
+            gv[v] = gy[m * C + v * 64 + lane];
+            s += xv[v];
+        }
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            xv[v] -= mean;
+            q += xv[v] * xv[v];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            xv[v] *= rstd;                       // xhat
+            dg[v] += gv[v] * xv[v];
+            db[v] += gv[v];
+            gv[v] *= ga[v];                      // gy * gamma
+            s1 += gv[v];
+            s2 += gv[v] * xv[v];
+        }
+        s1 = wave_sum(s1) * (1.0f / C);
+        s2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float o = rstd * (gv[v] - s1 - xv[v] * s2);
+            if (gadd) o += gadd[m * C + v * 64 + lane];
+            gx[m * C + v * 64 + lane] = o;
+        }
+    }
+    if (wave < nwaves) {
+        float* pr = part + wave * 2 * C;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            pr[v * 64 + lane] = dg[v];
+            pr[C + v * 64 + lane] = db[v];
+        }
+    }
+}
+
+extern "C" long rpb_layernorm_bwd_rows(long M) {
+    long grid = (M + 3) / 4;
+    const long cap = (long)rpb_num_cus() * 8;
+    if (grid > cap) grid = cap;
+    return grid * (TS_THREADS / 64);
+}
+
+extern "C" int rpb_layernorm_bwd(const float* x, const float* gamma, const float* gy, const float* gadd, float* gx,
+                                 float* part, long M, int C, float eps, void* stream) {
+    RPB_REQUIRE(x && gamma && gy && gx && part && M > 0, "layernorm_bwd: bad arguments");
+    RPB_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "layernorm_bwd: C=%d must be a multiple of 64 up to 512", C);
+    const unsigned grid = (unsigned)(rpb_layernorm_bwd_rows(M) / (TS_THREADS / 64));
+    hipStream_t st = (hipStream_t)stream;
+#define RPB_LNB(V_) \
+    if (C == 64 * V_) hipLaunchKernelGGL((layernorm_bwd_kernel<V_>), dim3(grid), dim3(TS_THREADS), 0, st, x, gamma, gy, gadd, gx, part, M, eps);
+    RPB_LNB(1) RPB_LNB(2) RPB_LNB(3) RPB_LNB(4) RPB_LNB(5) RPB_LNB(6) RPB_LNB(7) RPB_LNB(8)
+#undef RPB_LNB
+    RPB_CHECK_LAUNCH("layernorm_bwd");
+}
+
+// ---------------------------------------------------------------------------------- slice backward
+// Per (token, head), with w the saved slice weights (softmax output), T2 = attention output tokens, gT = dL/d(tokS)
+// (slice-token sums, before the division by the norm), gN = dL/d(norm):
+//   gw[g]   = sum_c gox[c] T2[g][c]  +  sum_c fx[c] gT[g][c]  +  gN[g]
+//   gl[g]   = w[g] (gw[g] - sum_g' w[g'] gw[g'])                      gradient w.r.t. the temperature-scaled logits
+//   g_xmid  = (1/tau) sum_g gl[g] Ws[g][:],      g_fxmid = sum_g w[g] gT[g][:]
+//   dWs[g][c] += (1/tau) gl[g] xmid[c],  dbs[g] += (1/tau) gl[g],  dtau[h] += -(1/tau) sum_g gl[g] log w[g]
+// (sum_g gl = 0, so log-sum-exp drops out of dtau).  Output g_xf rows = [g_fxmid | g_xmid] = the gradient of the dual
+// convolution's output; partial row = [G*32 dWs | G dbs | heads dtau].
+__global__ __launch_bounds__(TS_THREADS) void slice_bwd_kernel(const float* __restrict__ xf, const float* __restrict__ w,
+                                                               const float* __restrict__ gox, const float* __restrict__ tok2,
+                                                               const float* __restrict__ gT, const float* __restrict__ gN,
+                                                               const float* __restrict__ Ws, const float* __restrict__ temp,
+                                                               float* __restrict__ gxf, float* __restrict__ part, int ntok,
+                                                               int heads, int G, int blocks_per_sample) {
+    extern __shared__ float lds[];
+    const int C = heads * 32;
+    float* Wsl = lds;                               // [G][33]
+    float* t2l = Wsl + G * 33;                      // [heads][G][33]
+    float* gtl = t2l + heads * G * 33;              // [heads][G][33]
+    float* gll = gtl + heads * G * 33;              // [heads][64][G]   scaled logit gradients of the tile
+    float* xml = gll + heads * 64 * G;              // [64][C + 1]      x_mid tile
+    float* red = xml + 64 * (C + 1);                // [G + heads] block sums of dbs, dtau
+    const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) Wsl[(idx >> 5) * 33 + (idx & 31)] = Ws[idx];
+    for (int idx = tid; idx < heads * G * 32; idx += blockDim.x) {
+        const int hg = idx >> 5, c = idx & 31;
+        t2l[hg * 33 + c] = tok2[(long)b * heads * G * 32 + idx];
+        gtl[hg * 33 + c] = gT[(long)b * heads * G * 32 + idx];
+    }
+    for (int idx = tid; idx < G + heads; idx += blockDim.x) red[idx] = 0.f;
+    __syncthreads();
+
+    const int pg = tid >> 5, pc = tid & 31;         // phase-2 role: slices pg, pg + 8, ... ; channel pc
+    float accW[4] = {0.f, 0.f, 0.f, 0.f};           // G <= 32 -> at most 4 slices per thread
+    const long base = (long)b * ntok;
+    for (int t0 = blk * 64; t0 < ntok; t0 += blocks_per_sample * 64) {
+        for (int idx = tid; idx < 64 * (C / 4); idx += blockDim.x) {           // stage the x_mid tile
+            const int r = idx / (C / 4), c4 = idx - r * (C / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t0 + r < ntok) v = *reinterpret_cast<const f32x4*>(xf + (base + t0 + r) * 2 * C + C + 4 * c4);
+            float* dst = xml + r * (C + 1) + 4 * c4;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        {
+            const int r = tid & 63;
+            const bool ok = t0 + r < ntok;
+            const long m = base + t0 + r;
+            for (int h = tid >> 6; h < heads; h += TS_THREADS / 64) {
+                float fxv[32], gov[32], wv[32], gw[32];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        a = *reinterpret_cast<const f32x4*>(xf + m * 2 * C + h * 32 + 4 * k);
+                        c = *reinterpret_cast<const f32x4*>(gox + m * C + h * 32 + 4 * k);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        fxv[4 * k + i] = a[i];
+                        gov[4 * k + i] = c[i];
+                    }
+                }
+                float dot = 0.f;
+#pragma unroll
+                for (int g = 0; g < 32; ++g) {
+                    float s = 0.f, wg = 0.f;
+                    if (g < G) {
+                        wg = ok ? w[(m * heads + h) * G + g] : 0.f;
+                        s = gN[((long)b * heads + h) * G + g];
+                        const float* t2 = t2l + (h * G + g) * 33;
+                        const float* gt = gtl + (h * G + g) * 33;
+#pragma unroll
+                        for (int c = 0; c < 32; ++c) s += gov[c] * t2[c] + fxv[c] * gt[c];
+                    }
+                    wv[g] = wg;
+                    gw[g] = s;
+                    dot += wg * s;
+                }
+                const float inv_t = 1.0f / fminf(fmaxf(temp[h], 0.1f), 5.0f);
+                float gfx[32], gxm[32], dtau = 0.f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) gfx[c] = gxm[c] = 0.f;
+#pragma unroll
+                for (int g = 0; g < 32; ++g) {
+                    if (g < G) {
+                        const float gl = wv[g] * (gw[g] - dot);            // d/d(scaled logit)
+                        const float glr = gl * inv_t;                       // d/d(raw logit)
+                        gll[(h * 64 + r) * G + g] = glr;
+                        if (wv[g] > 0.f) dtau -= gl * logf(wv[g]);
+                        const float* gt = gtl + (h * G + g) * 33;
+#pragma unroll
+                        for (int c = 0; c < 32; ++c) {
+                            gfx[c] += wv[g] * gt[c];
+                            gxm[c] += glr * Wsl[g * 33 + c];
+                        }
+                        if (ok) atomicAdd(&red[g], glr);
+                    }
+                }
+                if (ok) {
+                    atomicAdd(&red[G + h], dtau * inv_t);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        f32x4 a, c;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            a[i] = gfx[4 * k + i];
+                            c[i] = gxm[4 * k + i];
+                        }
+                        *reinterpret_cast<f32x4*>(gxf + m * 2 * C + h * 32 + 4 * k) = a;
+                        *reinterpret_cast<f32x4*>(gxf + m * 2 * C + C + h * 32 + 4 * k) = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2: dWs[g][c] += sum_{r,h} glr[h][r][g] * xmid[r][h*32+c]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = pg + 8 * q;
+            if (g < G) {
+                float s = 0.f;
+                for (int h = 0; h < heads; ++h)
+                    for (int r = 0; r < 64; ++r) s += gll[(h * 64 + r) * G + g] * xml[r * (C + 1) + h * 32 + pc];
+                accW[q] += s;
+            }
+        }
+        __syncthreads();
+    }
+    float* prow = part + (long)blockIdx.x * ((long)G * 32 + G + heads);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = pg + 8 * q;
+        if (g < G) prow[g * 32 + pc] = accW[q];
+    }
+    for (int idx = tid; idx < G + heads; idx += blockDim.x) prow[G * 32 + idx] = red[idx];
+}
+
+extern "C" int rpb_slice_bwd(const float* xf, const float* w, const float* gox, const float* tok2, const float* gT,
+                             const float* gN, const float* Ws, const float* temp, float* gxf, float* part, int B, int ntok,
+                             int heads, int G, void* stream) {
+    RPB_REQUIRE(xf && w && gox && tok2 && gT && gN && Ws && temp && gxf && part, "slice_bwd: null pointer");
+    RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 1 && G <= 32, "slice_bwd: heads=%d G=%d unsupported", heads, G);
+    const int bps = rpb_slice_blocks_per_sample(B);
+    const int C = heads * 32;
+    const size_t lds = ((size_t)G * 33 + 2 * (size_t)heads * G * 33 + (size_t)heads * 64 * G + (size_t)64 * (C + 1) + G + heads) * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "slice_bwd: LDS");
+    (void)hipFuncSetAttribute((const void*)slice_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(slice_bwd_kernel, dim3(B * bps), dim3(TS_THREADS), lds, (hipStream_t)stream, xf, w, gox, tok2, gT, gN,
+                       Ws, temp, gxf, part, ntok, heads, G, bps);
+    RPB_CHECK_LAUNCH("slice_bwd");
+}
+
+// column sums: out_part[block][n] = sum over this block's rows of x[m][n]  (bias / placeholder gradients)
+__global__ __launch_bounds__(TS_THREADS) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, long M,
+                                                            int N, int ld) {
+    extern __shared__ float red[];     // [nsub][N]
+    const int n4n = N / 4;
+    const int c4 = threadIdx.x % n4n, sub = threadIdx.x / n4n, nsub = blockDim.x / n4n;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (sub < nsub)
+        for (long m = (long)blockIdx.x * nsub + sub; m < M; m += (long)gridDim.x * nsub)
+            acc += *reinterpret_cast<const f32x4*>(x + m * ld + 4 * c4);
+    if (sub < nsub) *reinterpret_cast<f32x4*>(red + sub * N + 4 * c4) = acc;
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsub; ++k) s += red[k * N + n];
+        part[(long)blockIdx.x * N + n] = s;
+    }
+}
+
+extern "C" int rpb_colsum_rows(void) { return rpb_num_cus() * 4; }
+
+extern "C" int rpb_colsum(const float* x, float* part, long M, int N, int ld, void* stream) {
+    RPB_REQUIRE(x && part && M > 0 && N % 4 == 0 && N / 4 <= TS_THREADS && TS_THREADS % (N / 4) == 0 && ld % 4 == 0,
+                "colsum: N=%d unsupported", N);
+    const int nsub = TS_THREADS / (N / 4);
+    hipLaunchKernelGGL(colsum_kernel, dim3(rpb_colsum_rows()), dim3(TS_THREADS), (size_t)nsub * N * 4, (hipStream_t)stream, x,
+                       part, M, N, ld);
+    RPB_CHECK_LAUNCH("colsum");
 }

@@ -108,8 +108,10 @@ class Transolver(_ModelBase):
             self._wcat[i] = (key, w, b)
         return self._wcat[i][1], self._wcat[i][2]
 
+    # ------------------------------------------------------------------ forward (optionally saving for backward)
     @torch.no_grad()
-    def _forward_hip(self, x):
+    def _forward_hip(self, x, save=None):
+        """``save``: dict that receives every tensor the backward pass needs (training), or None (inference)."""
         B = x.shape[0]
         Cin, C, heads, G = x.shape[-1], self.n_hidden, self.n_head, self.slice_num
         ntok = x[0].numel() // Cin
@@ -118,29 +120,34 @@ class Transolver(_ModelBase):
         if Cin != self.in_dim:
             raise ValueError(f"expected {self.in_dim} input channels, got {Cin}")
         M = B * ntok
-        dev = x.device
-        f = dict(device=dev, dtype=torch.float32)
+        f = dict(device=x.device, dtype=torch.float32)
+        keep = save is not None
+        new = lambda *shape: torch.empty(*shape, **f)
         x2 = x.reshape(M, Cin)
         pre = self.preprocess
-        h1 = torch.empty(M, 2 * C, **f)
+        h1 = new(M, 2 * C)
         ops.tokens_lift(x2, pre.linear_pre[0].weight.data, pre.linear_pre[0].bias.data, h1, M, Cin, 2 * C, True)
-        fx = torch.empty(M, C, **f)
+        fx = new(M, C)
         ops.gemm_nt(h1, pre.linear_post.weight.data, fx, M, C, 2 * C, bias=pre.linear_post.bias.data,
                     addvec=self.placeholder.data)                     # Transolver_Structured_Mesh_3D.py:182-183
-        del h1
-        a = torch.empty(M, C, **f)
-        xf = torch.empty(M, 2 * C, **f)
-        w = torch.empty(M, heads * G, **f)
-        ox = torch.empty(M, C, **f)
-        hid = torch.empty(M, C * self.mlp_ratio, **f)
+        if keep:
+            save.update(x2=x2, h1=h1, B=B, ntok=ntok, M=M, blocks=[])
+        else:
+            del h1
+        a = new(M, C)
+        xf, w, ox = new(M, 2 * C), new(M, heads * G), new(M, C)
+        hid = new(M, C * self.mlp_ratio)
         bps = ops.slice_blocks_per_sample(B)
-        tok_part = torch.empty(B * bps, heads * G * 32, **f)
-        norm_part = torch.empty(B * bps, heads * G, **f)
-        tokS, norm = torch.empty(B, heads * G * 32, **f), torch.empty(B, heads * G, **f)
-        tok2 = torch.empty(B, heads * G * 32, **f)
+        tok_part, norm_part = new(B * bps, heads * G * 32), new(B * bps, heads * G)
+        tokS, norm, tok2 = new(B, heads * G * 32), new(B, heads * G), new(B, heads * G * 32)
         out = None
         for i, blk in enumerate(self.blocks):
             at = blk.Attn
+            st = {}
+            if keep:      # fresh buffers per block: everything below is read again by the backward pass
+                a, xf, w, ox, hid = new(M, C), new(M, 2 * C), new(M, heads * G), new(M, C), new(M, C * self.mlp_ratio)
+                tokS, norm, tok2 = new(B, heads * G * 32), new(B, heads * G), new(B, heads * G * 32)
+                st.update(fx0=fx, a1=a, xf=xf, w=w, tokS=tokS, norm=norm, tok2=tok2, ox=ox)
             ops.layernorm_fwd(fx, blk.ln_1.weight.data, blk.ln_1.bias.data, a, M, C)
             wcat, bcat = self._conv_cat(i)
             ops.gemm_nt(a, wcat, xf, M, 2 * C, 27 * C, bias=bcat, conv=(self.H, self.W, self.D))
@@ -151,30 +158,174 @@ class Transolver(_ModelBase):
                 ops.reduce_partials(norm_part[b * bps:(b + 1) * bps], bps, heads * G, out_f32=norm[b])
             ops.slice_attn(tokS, norm, at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data, tok2, B * heads, G)
             ops.deslice_fwd(w, tok2, ox, B, ntok, heads, G)
-            ops.gemm_nt(ox, at.to_out[0].weight.data, fx, M, C, C, bias=at.to_out[0].bias.data, residual=fx)
-            ops.layernorm_fwd(fx, blk.ln_2.weight.data, blk.ln_2.bias.data, a, M, C)
-            ops.gemm_nt(a, blk.mlp.linear_pre[0].weight.data, hid, M, C * self.mlp_ratio, C,
-                        bias=blk.mlp.linear_pre[0].bias.data, act=1)
-            ops.gemm_nt(hid, blk.mlp.linear_post.weight.data, fx, M, C, C * self.mlp_ratio,
-                        bias=blk.mlp.linear_post.bias.data, residual=fx)
+            fx1 = new(M, C) if keep else fx
+            ops.gemm_nt(ox, at.to_out[0].weight.data, fx1, M, C, C, bias=at.to_out[0].bias.data, residual=fx)
+            a2 = new(M, C) if keep else a
+            ops.layernorm_fwd(fx1, blk.ln_2.weight.data, blk.ln_2.bias.data, a2, M, C)
+            hpre = new(M, C * self.mlp_ratio) if keep else None
+            ops.gemm_nt(a2, blk.mlp.linear_pre[0].weight.data, hid, M, C * self.mlp_ratio, C,
+                        bias=blk.mlp.linear_pre[0].bias.data, act=1, pre_out=hpre)
+            fx2 = new(M, C) if keep else fx1
+            ops.gemm_nt(hid, blk.mlp.linear_post.weight.data, fx2, M, C, C * self.mlp_ratio,
+                        bias=blk.mlp.linear_post.bias.data, residual=fx1)
+            if keep:
+                st.update(fx1=fx1, a2=a2, hpre=hpre, hid=hid, fx2=fx2)
+            fx = fx2
             if blk.last_layer:
-                ops.layernorm_fwd(fx, blk.ln_3.weight.data, blk.ln_3.bias.data, a, M, C)
-                out = torch.empty(M, self.out_dim, **f)
-                ops.gemm_nt(a, blk.mlp2.weight.data, out, M, self.out_dim, C, bias=blk.mlp2.bias.data)
+                a3 = new(M, C) if keep else a
+                ops.layernorm_fwd(fx, blk.ln_3.weight.data, blk.ln_3.bias.data, a3, M, C)
+                out = new(M, self.out_dim)
+                ops.gemm_nt(a3, blk.mlp2.weight.data, out, M, self.out_dim, C, bias=blk.mlp2.bias.data)
+                if keep:
+                    st.update(a3=a3)
+            if keep:
+                save["blocks"].append(st)
         return out.reshape(*x.shape[:-1], self.out_dim)
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, G, A, M, N, K, ldg=None, lda=None, conv=None):
+        """(dW [N,K], db [N]) = (G^T A, colsum G) through the TN GEMM + fp64 partial reduction."""
+        splits = ops.gemm_tn_splits(M, N, K)
+        part = torch.empty(splits, N * K + N, device=G.device, dtype=torch.float32)
+        ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda, conv=conv)
+        dW = torch.empty(N, K, device=G.device, dtype=torch.float32)
+        db = torch.empty(N, device=G.device, dtype=torch.float32)
+        ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
+        ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
+        return dW, db
+
+    def _ln_bwd(self, x, ln, gy, gadd, M, C):
+        rows = ops.layernorm_bwd_rows(M)
+        part = torch.empty(rows, 2 * C, device=x.device, dtype=torch.float32)
+        gx = torch.empty(M, C, device=x.device, dtype=torch.float32)
+        ops.layernorm_bwd(x, ln.weight.data, gy, gadd, gx, part, M, C)
+        dgb = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ops.reduce_partials(part, rows, 2 * C, out_f32=dgb)
+        return gx, dgb[:C].clone(), dgb[C:].clone()
+
+    @torch.no_grad()
+    def _backward_hip(self, sv, g_out):
+        """Gradients of every parameter given dLoss/d(out) -- autograd of Transolver_Structured_Mesh_3D.py:170-196.
+        Returns {parameter: gradient}."""
+        C, heads, G, M, B, ntok = self.n_hidden, self.n_head, self.slice_num, sv["M"], sv["B"], sv["ntok"]
+        Hm = C * self.mlp_ratio
+        f = dict(device=g_out.device, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f)
+        T = lambda wt: wt.data.t().contiguous()
+        grads = {}
+        g = None
+        bps = ops.slice_blocks_per_sample(B)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk, st, at = self.blocks[i], sv["blocks"][i], self.blocks[i].Attn
+            if blk.last_layer:
+                od = self.out_dim
+                go = g_out.reshape(M, od).contiguous()
+                gpad = torch.zeros(M, (od + 3) // 4 * 4, **f)               # even leading dimension for float2 loads
+                gpad[:, :od] = go
+                grads[blk.mlp2.weight], grads[blk.mlp2.bias] = self._wgrad(gpad, st["a3"], M, od, C, ldg=gpad.shape[1])
+                ga3 = new(M, C)
+                ops.tokens_lift(go, T(blk.mlp2.weight), torch.zeros(C, **f), ga3, M, od, C, False)   # g_out @ W2
+                g, grads[blk.ln_3.weight], grads[blk.ln_3.bias] = self._ln_bwd(st["fx2"], blk.ln_3, ga3, None, M, C)
+            # ---- MLP (fx2 = fx1 + post(gelu(pre(LN2(fx1)))))
+            grads[blk.mlp.linear_post.weight], grads[blk.mlp.linear_post.bias] = self._wgrad(g, st["hid"], M, C, Hm)
+            ghp = new(M, Hm)
+            ops.gemm_nt(g, T(blk.mlp.linear_post.weight), ghp, M, Hm, C, act=2, aux=st["hpre"])
+            grads[blk.mlp.linear_pre[0].weight], grads[blk.mlp.linear_pre[0].bias] = self._wgrad(ghp, st["a2"], M, Hm, C)
+            ga2 = new(M, C)
+            ops.gemm_nt(ghp, T(blk.mlp.linear_pre[0].weight), ga2, M, C, Hm)
+            del ghp
+            g1, grads[blk.ln_2.weight], grads[blk.ln_2.bias] = self._ln_bwd(st["fx1"], blk.ln_2, ga2, g, M, C)
+            # ---- attention output projection (fx1 = fx0 + to_out(ox))
+            grads[at.to_out[0].weight], grads[at.to_out[0].bias] = self._wgrad(g1, st["ox"], M, C, C)
+            gox = new(M, C)
+            ops.gemm_nt(g1, T(at.to_out[0].weight), gox, M, C, C)
+            # ---- deslice backward w.r.t. the attended slice tokens: g_tok2 = sum_n w * g_ox
+            tp = new(B * bps, heads * G * 32)
+            ops.slice_fwd(gox, None, None, None, None, tp, None, B, ntok, heads, G, C, w_in=st["w"])
+            gtok2 = new(B, heads * G * 32)
+            for b in range(B):
+                ops.reduce_partials(tp[b * bps:(b + 1) * bps], bps, heads * G * 32, out_f32=gtok2[b])
+            # ---- 16-token attention backward on [B, heads, G, 32] tensors (a few thousand numbers per sample):
+            #      torch autograd on these tiny tensors is plumbing-scale glue, not a compute path
+            with torch.enable_grad():
+                tS = st["tokS"].view(B, heads, G, 32).detach().requires_grad_(True)
+                nm = st["norm"].view(B, heads, G).detach().requires_grad_(True)
+                wq, wk, wv = (p.detach().requires_grad_(True) for p in (at.to_q.weight, at.to_k.weight, at.to_v.weight))
+                tok = tS / (nm + 1e-5)[..., None]
+                q, k, v = tok @ wq.t(), tok @ wk.t(), tok @ wv.t()
+                o = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1) @ v
+                gT, gN, gq, gk, gv = torch.autograd.grad(o, (tS, nm, wq, wk, wv), gtok2.view(B, heads, G, 32))
+            grads[at.to_q.weight], grads[at.to_k.weight], grads[at.to_v.weight] = gq, gk, gv
+            # ---- slice + deslice backward w.r.t. the dual-convolution output
+            gxf = new(M, 2 * C)
+            sp = new(B * bps, G * 32 + G + heads)
+            temp = at.temperature.data.reshape(-1).contiguous()
+            ops.slice_bwd(st["xf"], st["w"], gox, st["tok2"], gT.contiguous().view(B, -1), gN.contiguous().view(B, -1),
+                          at.in_project_slice.weight.data, temp, gxf, sp, B, ntok, heads, G)
+            tot = new(G * 32 + G + heads)
+            ops.reduce_partials(sp, B * bps, G * 32 + G + heads, out_f32=tot)
+            grads[at.in_project_slice.weight] = tot[:G * 32].view(G, 32).clone()
+            grads[at.in_project_slice.bias] = tot[G * 32:G * 32 + G].clone()
+            inside = ((temp >= 0.1) & (temp <= 5.0)).float()                    # torch.clamp passes the gradient inside
+            grads[at.temperature] = (tot[G * 32 + G:] * inside).view(1, heads, 1, 1)
+            # ---- the two convolutions: weight gradient (TN implicit GEMM) and data gradient (flipped-tap implicit GEMM)
+            dWc, dbc = self._wgrad(gxf, st["a1"], M, 2 * C, 27 * C, conv=(self.H, self.W, self.D))
+            dWc = dWc.view(2 * C, 3, 3, 3, C).permute(0, 4, 1, 2, 3).contiguous()
+            grads[at.in_project_fx.weight], grads[at.in_project_x.weight] = dWc[:C].clone(), dWc[C:].clone()
+            grads[at.in_project_fx.bias], grads[at.in_project_x.bias] = dbc[:C].clone(), dbc[C:].clone()
+            wcat, _ = self._conv_cat(i)
+            wflip = wcat.view(2 * C, 27, C).flip(1).permute(2, 1, 0).reshape(C, 27 * 2 * C).contiguous()
+            ga1 = new(M, C)
+            ops.gemm_nt(gxf, wflip, ga1, M, C, 27 * 2 * C, conv=(self.H, self.W, self.D), lda=2 * C)
+            del gxf
+            g, grads[blk.ln_1.weight], grads[blk.ln_1.bias] = self._ln_bwd(st["fx0"], blk.ln_1, ga1, g1, M, C)
+        # ---- preprocess MLP (+ placeholder): fx0 = post(gelu(pre(x))) + placeholder
+        pre = self.preprocess
+        dW, db = self._wgrad(g, sv["h1"], M, C, 2 * C)
+        grads[pre.linear_post.weight], grads[pre.linear_post.bias], grads[self.placeholder] = dW, db, db.clone()
+        Cin = self.in_dim
+        h1pre = new(M, 2 * C)
+        ops.tokens_lift(sv["x2"], pre.linear_pre[0].weight.data, pre.linear_pre[0].bias.data, h1pre, M, Cin, 2 * C, False)
+        gh1 = new(M, 2 * C)
+        ops.gemm_nt(g, T(pre.linear_post.weight), gh1, M, 2 * C, C, act=2, aux=h1pre)
+        xpad = torch.zeros(M, (Cin + 3) // 4 * 4, **f)
+        xpad[:, :Cin] = sv["x2"]
+        grads[pre.linear_pre[0].weight], grads[pre.linear_pre[0].bias] = self._wgrad(gh1, xpad, M, 2 * C, Cin,
+                                                                                     lda=xpad.shape[1])
+        return grads
 
     def forward(self, x, fx=None, T=None):
         if fx is not None or T is not None:
             raise NotImplementedError("fx / T inputs are never used by the reference's train/eval loops")
         if not x.is_cuda:
             raise RuntimeError("realpdebench_amd.Transolver runs on MI355X only: there is no CPU fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("Transolver backward is not built yet (DESIGN.md section 9): call under "
-                                      "torch.no_grad() / model.eval() for inference and rollout")
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("training-mode dropout is part of the (unbuilt) training path; use model.eval()")
-        return self._forward_hip(x.contiguous().float())
+        x = x.contiguous().float()
+        params = [p for p in self.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if self.training and self.dropout_p > 0:
+                raise NotImplementedError("training-mode dropout masks are not implemented on the HIP path: construct the "
+                                          "model with dropout=0.0 to train (eval / rollout are unaffected)")
+            return _TransolverFunction.apply(x, self, *params)
+        return self._forward_hip(x)
 
     def train_loss(self, input, target):
-        pred = self.forward(input)            # raises under autograd, see forward()
+        """Transolver_Structured_Mesh_3D.py:198-201: elementwise (pred - target)**2 (callers take .mean())."""
+        pred = self.forward(input)
         return (pred - target) ** 2
+
+
+class _TransolverFunction(torch.autograd.Function):
+    """Autograd glue: one forward / backward call into the HIP pipelines above."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        sv = {}
+        out = model._forward_hip(x, save=sv)
+        ctx.model, ctx.sv, ctx.params = model, sv, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        grads = ctx.model._backward_hip(ctx.sv, g_out.contiguous().float())
+        ctx.sv = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -205,14 +205,52 @@ def channel_affine(inp, out, n, C, mean, std, inverse):
 
 
 # ----------------------------------------------------------------------------- Transolver forward kernels
-def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None):
-    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A the implicit 3x3x3 im2col of a token tensor."""
+def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
+            pre_out=None):
+    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A the implicit 3x3x3 im2col of a token tensor.
+    act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``)."""
     hc, wc, dc = conv if conv else (0, 0, 0)
     lda = (K // 27 if conv else K) if lda is None else lda
     _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
-              N if ldo is None else ldo, int(act), int(conv is not None), hc, wc, dc, _stream(),
+              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), int(conv is not None), hc, wc, dc, _stream(),
               label=f"gemm_nt[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * (M * lda + M * N + N * K),
               flops=2 * M * N * K)
+
+
+def gemm_tn_splits(M, N, K):
+    return _lib.query("rpb_gemm_tn_splits", M, N, K)
+
+
+def gemm_tn(G, A, part, M, N, K, ldg=None, lda=None, conv=None):
+    """part[splits][N*K + N]: partials of dW = G^T A(im2col) and db = colsum(G)."""
+    hc, wc, dc = conv if conv else (0, 0, 0)
+    _lib.call("rpb_gemm_tn", _p(G), _p(A), _p(part), M, N, K, N if ldg is None else ldg,
+              (K // 27 if conv else K) if lda is None else lda, int(conv is not None), hc, wc, dc, _stream(),
+              label=f"gemm_tn[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * M * (N + (K // 27 if conv else K)),
+              flops=2 * M * N * K)
+
+
+def layernorm_bwd_rows(M):
+    return _lib.query("rpb_layernorm_bwd_rows", M)
+
+
+def layernorm_bwd(x, gamma, gy, gadd, gx, part, M, C, eps=1e-5):
+    _lib.call("rpb_layernorm_bwd", _p(x), _p(gamma), _p(gy), _p(gadd), _p(gx), _p(part), M, C, eps, _stream(),
+              label="layernorm_bwd", nbytes=(12 + (4 if gadd is not None else 0)) * M * C, flops=16 * M * C)
+
+
+def slice_bwd(xf, w, gox, tok2, gT, gN, Ws, temp, gxf, part, B, ntok, heads, G):
+    _lib.call("rpb_slice_bwd", _p(xf), _p(w), _p(gox), _p(tok2), _p(gT), _p(gN), _p(Ws), _p(temp), _p(gxf), _p(part), B,
+              ntok, heads, G, _stream(), label="slice_bwd", nbytes=4 * B * ntok * heads * (32 * 5 + G),
+              flops=2 * B * ntok * heads * G * 32 * 5)
+
+
+def colsum_rows():
+    return _lib.query("rpb_colsum_rows")
+
+
+def colsum(x, part, M, N, ld=None):
+    _lib.call("rpb_colsum", _p(x), _p(part), M, N, N if ld is None else ld, _stream(), label="colsum", nbytes=4 * M * N)
 
 
 def tokens_lift(x, W, b, out, M, K, N, act):
@@ -229,9 +267,9 @@ def slice_blocks_per_sample(B):
     return _lib.query("rpb_slice_blocks_per_sample", B)
 
 
-def slice_fwd(xf, Ws, bs, temp, w_out, tok_part, norm_part, B, ntok, heads, G, ldx):
+def slice_fwd(xf, Ws, bs, temp, w_out, tok_part, norm_part, B, ntok, heads, G, ldx, w_in=None):
     _lib.call("rpb_slice_fwd", _p(xf), _p(Ws), _p(bs), _p(temp), _p(w_out), _p(tok_part), _p(norm_part), B, ntok, heads,
-              G, ldx, _stream(), label="slice_fwd", nbytes=4 * B * ntok * (ldx + 2 * heads * G),
+              G, ldx, _p(w_in), _stream(), label="slice_fwd", nbytes=4 * B * ntok * (ldx + 2 * heads * G),
               flops=2 * B * ntok * heads * G * 64)
 
 

@@ -117,7 +117,8 @@ def test_model_matches_reference_golden():
         y = m(torch.from_numpy(np.array(z["x"])).cuda())
     assert y.shape == z["y"].shape
     assert rel_l2(y.cpu(), torch.from_numpy(np.array(z["y"]))) < 1e-5
-    with pytest.raises(NotImplementedError):          # training path is not built: must be loud, never a fallback
+    m.train()                                        # dropout 0.1 in train mode has no HIP masks yet: must be loud
+    with pytest.raises(NotImplementedError):
         m.train_loss(torch.from_numpy(np.array(z["x"])).cuda(), y)
 
 
@@ -134,3 +135,38 @@ def test_model_reference_width_vs_oracle():
     with torch.no_grad():
         y = m.cuda()(x.cuda())
     assert rel_l2(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("n_hidden,heads,layers", [(64, 2, 2), (256, 8, 1)])
+def test_train_loss_gradients_vs_oracle_autograd(n_hidden, heads, layers):
+    """Every parameter gradient of `train_loss(...).mean().backward()` (drop-in protocol, HIP backward) against
+    PyTorch autograd through the CPU oracle (itself pinned to the reference)."""
+    from oracle import transolver_oracle as TO
+    from realpdebench_amd.model.transolver import Transolver
+    torch.manual_seed(5 + n_hidden)
+    H, W, D = 7, 6, 5
+    m = Transolver(space_dim=3, n_layers=layers, n_hidden=n_hidden, n_head=heads, fun_dim=0, out_dim=3, slice_num=16,
+                   mlp_ratio=4, H=H, W=W, D=D, dropout=0.0)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias") or "ln_" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        m.blocks[0].Attn.temperature.view(-1)[0] = 0.05          # below the clamp: zero gradient expected
+    x, y = torch.randn(2, D, W, H, 3), torch.randn(2, D, W, H, 3)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    loss_ref = ((TO.transolver_forward(sd, x, layers, heads, H, W, D) - y) ** 2).mean()
+    loss_ref.backward()
+    m = m.cuda().train()
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * float(loss_ref)
+    worst = {}
+    for n, p in m.named_parameters():
+        assert p.grad is not None, n
+        ref = sd[n].grad
+        if float(ref.norm()) < 1e-12:
+            assert float(p.grad.norm()) < 1e-9, n
+            continue
+        worst[n] = rel_l2(p.grad.cpu(), ref)
+    bad = {k: v for k, v in worst.items() if v > 1e-4}
+    assert not bad, bad
