@@ -150,7 +150,7 @@ int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* 
                 int Wc, int Dc, void* stream);
 /*     weight gradients: part[rpb_gemm_tn_splits(M,N,K)][N*K + N] partials of dW[n][k] = sum_m G[m][n] A(m,k) and
  *     db[n] = sum_m G[m][n] (autograd of the nn.Linear / nn.Conv3d weights above); conv=1 gathers A like rpb_gemm_nt. */
-int rpb_gemm_tn_splits(long M, int N, int K);
+int rpb_gemm_tn_splits(long M, int N, int K, int conv);
 int rpb_gemm_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, int conv, int Hc,
                 int Wc, int Dc, void* stream);
 /*     tiny-K linear (+GELU): preprocess.linear_pre, C_in -> 2*n_hidden (Transolver_Structured_Mesh_3D.py:27,32). */

@@ -45,7 +45,7 @@ SIGNATURES = {
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
     "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "pp" + "iiii" + "p"),
-    "rpb_gemm_tn_splits": (_I, "lii"),
+    "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
     "rpb_layernorm_bwd_rows": (_L, "l"),
     "rpb_layernorm_bwd": (_I, "pppppp" + "l" + "i" + "f" + "p"),

@@ -224,8 +224,8 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
 // ---------------------------------------------------------------------------------- TN GEMM (weight gradients)
 //   dW[n][k] = sum_m G[m][n] * A(m,k),   db[n] = sum_m G[m][n]          (autograd of nn.Linear / nn.Conv3d weights)
 // Both operands are "lane = channel" in HBM, exactly what the MFMA wants when the reduction index is the token:
-// they are loaded straight into registers (float2: channel pair col*2+t), no LDS.  Workgroup = 2x2 waves x (64x64) =
-// a 128 x 128 tile of dW; the token range is split across gridDim.y and each split writes a partial that
+// they are loaded straight into registers (G: float2 = channel pair col*2+t; A: float2/float4), no LDS.  Workgroup =
+// 2x2 waves x (64 x 64|128) = a 128 x 128|256 tile of dW; the token range is split across gridDim.y and each split writes a partial that
 // rpb_reduce_partials sums in fp64.  With conv=1, A(m, tap*Ci+ci) = x[neighbour(m,tap)][ci] (a 128-column k tile never
 // crosses a tap because Ci % 64 == 0 and every wave derives the tap from its own 64-column sub-tile).
 struct GemmTnArgs {
@@ -237,16 +237,35 @@ struct GemmTnArgs {
     int conv, Hc, Wc, Dc;
 };
 
+template <int N>
+struct TnVec;
+template <>
+struct TnVec<2> {
+    typedef f32x2 T;
+};
+template <>
+struct TnVec<4> {
+    typedef f32x4 T;
+};
+
+// NTI = k-tiles (of 32 channels) per wave: wave tile = 64 (n) x 32*NTI (k), workgroup = 2 x 2 waves.
+template <int NTI>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+    typedef typename TnVec<NTI>::T veci;
+    constexpr int WK = 32 * NTI;                       // k columns per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int col = lane & 31, half = lane >> 5;
-    const int tk = (g.K + 127) / 128;
-    const int tile_n = blockIdx.x / tk, tile_k = blockIdx.x % tk;
-    const int n0 = tile_n * 128 + wn * 64, k0 = tile_k * 128 + wk * 64;       // this wave's 64 x 64 sub-tile
+    const int tk = (g.K + 2 * WK - 1) / (2 * WK);
+    // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a CONTIGUOUS range of tiles.  The tk
+    // k-tiles of one n-tile re-read the same G rows (and neighbouring taps the same A rows): on one XCD they hit its L2
+    int tile = blockIdx.x;
+    if (gridDim.x % 8 == 0) tile = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    const int tile_n = tile / tk, tile_k = tile % tk;
+    const int n0 = tile_n * 128 + wn * 64, k0 = tile_k * 2 * WK + wk * WK;     // this wave's sub-tile
     const int nsplit = gridDim.y, split = blockIdx.y;
-    const long per = (g.M + nsplit - 1) / nsplit;
+    const long per = ((g.M + nsplit - 1) / nsplit + 31) / 32 * 32;
     const long mb = (long)split * per;
     long me = mb + per;
     if (me > g.M) me = g.M;
@@ -261,74 +280,112 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
         dd = tap % 3 - 1;
         noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
     }
+    const bool tap_ok = !g.conv || tap < 27;
     const bool n_ok0 = n0 + col * 2 < g.N, n_ok1 = n0 + col * 2 + 1 < g.N;      // N may be < 64 (e.g. mlp2: 3)
-    const bool k_ok0 = kk0 + col * 2 < (g.conv ? Ci : g.K), k_ok1 = kk0 + col * 2 + 1 < (g.conv ? Ci : g.K);
+    const int klim = g.conv ? Ci : g.K;
     const long mesh = (long)g.Hc * g.Wc * g.Dc;
+    const float inv_dc = g.conv ? 1.0f / g.Dc : 0.f, inv_wc = g.conv ? 1.0f / g.Wc : 0.f;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NTI];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[o][i] = zero16();
+        for (int i = 0; i < NTI; ++i) acc[o][i] = zero16();
     float bsum[2] = {0.f, 0.f};
 
-    f32x2 ga[8], gb[8], xa[8], xb[8];
-    auto load_half = [&](long m0, f32x2 (&gv)[8], f32x2 (&xv)[8]) {
+    f32x2 ga[8], gb[8];
+    veci xa[8], xb[8];
+    const veci zi = {};
+    // m0 is wave-uniform; the mesh coordinates of m0 + j (j < 32) follow from ONE scalar decomposition of m0 plus a
+    // division-free carry (float reciprocal of the small extents), instead of three integer divisions per load
+    // mesh coordinates of the first token of the current 32-token chunk, advanced incrementally (no divisions in the loop)
+    int c_d = 0, c_w = 0, c_h = 0;
+    if (g.conv) {
+        const long r = mb % mesh;
+        c_d = (int)(r % g.Dc);
+        c_w = (int)((r / g.Dc) % g.Wc);
+        c_h = (int)(r / ((long)g.Dc * g.Wc));
+    }
+    auto advance32 = [&]() {
+        if (!g.conv) return;
+        const int t = c_d + 32;
+        const int q = (int)((t + 0.5f) * inv_dc);
+        c_d = t - q * g.Dc;
+        const int w1 = c_w + q;
+        const int q2 = (int)((w1 + 0.5f) * inv_wc);
+        c_w = w1 - q2 * g.Wc;
+        c_h += q2;
+        while (c_h >= g.Hc) c_h -= g.Hc;
+    };
+    auto load_half = [&](long m0, int h, int d0, int w0, int h0, f32x2 (&gv)[8], veci (&xv)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const long m = m0 + 2 * s + half;
-            f32x2 gq = {0.f, 0.f}, xq = {0.f, 0.f};
+            const int j = h * 16 + 2 * s + half;
+            const long m = m0 + j;
+            f32x2 gq = {0.f, 0.f};
+            veci xq = zi;
             if (m < me) {
                 const float* gp = g.G + m * g.ldg + n0 + col * 2;
                 if (n_ok1) gq = *reinterpret_cast<const f32x2*>(gp);
                 else if (n_ok0) gq[0] = gp[0];
                 long row = m;
-                bool ok = true;
+                bool ok = tap_ok;
                 if (g.conv) {
-                    const long r = m % mesh;
-                    const int d0 = (int)(r % g.Dc), w0 = (int)((r / g.Dc) % g.Wc), h0 = (int)(r / ((long)g.Dc * g.Wc));
-                    const int hh = h0 + dh, ww = w0 + dw, d2 = d0 + dd;
-                    ok = hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
+                    const int t = d0 + j;
+                    const int q = (int)((t + 0.5f) * inv_dc);
+                    const int d2 = t - q * g.Dc + dd;
+                    const int w1 = w0 + q;
+                    const int q2 = (int)((w1 + 0.5f) * inv_wc);
+                    const int ww = w1 - q2 * g.Wc + dw;
+                    int hh = h0 + q2;
+                    if (hh >= g.Hc) hh -= g.Hc;                       // ran into the next sample
+                    hh += dh;
+                    ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
                     row = m + noff;
                 }
                 if (ok) {
-                    const float* xp = g.A + row * g.lda + kk0 + col * 2;
-                    if (k_ok1) xq = *reinterpret_cast<const f32x2*>(xp);
-                    else if (k_ok0) xq[0] = xp[0];
+                    const float* xp = g.A + row * g.lda + kk0 + col * NTI;
+                    if (kk0 + col * NTI + NTI <= klim) xq = *reinterpret_cast<const veci*>(xp);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < NTI; ++i)
+                            if (kk0 + col * NTI + i < klim) xq[i] = xp[i];
+                    }
                 }
             }
             gv[s] = gq;
             xv[s] = xq;
         }
     };
-    auto compute_half = [&](const f32x2 (&gv)[8], const f32x2 (&xv)[8]) {
+    auto compute_half = [&](const f32x2 (&gv)[8], const veci (&xv)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 bsum[o] += gv[s][o];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[o][i] = mfma32(gv[s][o], xv[s][i], acc[o][i]);
+                for (int i = 0; i < NTI; ++i) acc[o][i] = mfma32(gv[s][o], xv[s][i], acc[o][i]);
             }
     };
     long m = mb;
-    if (m < me) load_half(m, ga, xa);
+    if (m < me) load_half(m, 0, c_d, c_w, c_h, ga, xa);
     for (; m < me; m += 32) {
-        load_half(m + 16, gb, xb);
+        load_half(m, 1, c_d, c_w, c_h, gb, xb);
         compute_half(ga, xa);
-        if (m + 32 < me) load_half(m + 32, ga, xa);
+        advance32();
+        if (m + 32 < me) load_half(m + 32, 0, c_d, c_w, c_h, ga, xa);
         compute_half(gb, xb);
     }
     float* part = g.part + (long)split * ((long)g.N * g.K + g.N);
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NTI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + mfma_row(lane, r) * 2 + o;
-                const int k = k0 + col * 2 + i;
-                if (n < g.N && k < g.K) part[(long)n * g.K + k] = acc[o][i][r];
+                const int k = k0 + col * NTI + i;
+                if (n < g.N && k < g.K && kk0 + col * NTI + i < klim) part[(long)n * g.K + k] = acc[o][i][r];
             }
         if (tile_k == 0 && wk == 0) {
             const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
@@ -338,8 +395,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     }
 }
 
-extern "C" int rpb_gemm_tn_splits(long M, int N, int K) {
-    const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+static int gemm_tn_nti(int K, int conv) {
+    const int Ci = conv ? K / 27 : K;
+    return (Ci % 128 == 0) ? 4 : 2;
+}
+
+extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
+    const int wk2 = 64 * gemm_tn_nti(K, conv);
+    const long tiles = (long)((N + 127) / 128) * ((K + wk2 - 1) / wk2);
     long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
     const long cap = (M + 511) / 512;                 // at least 512 tokens per split
     if (s > cap) s = cap;
@@ -357,8 +420,12 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
     GemmTnArgs a;
     a.G = G; a.A = A; a.part = part; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.lda = lda;
     a.conv = conv; a.Hc = Hc; a.Wc = Wc; a.Dc = Dc;
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    const int splits = rpb_gemm_tn_splits(M, N, K);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+    const int nti = gemm_tn_nti(K, conv);
+    const int wk2 = 64 * nti;
+    RPB_REQUIRE(lda % nti == 0, "gemm_tn: lda=%d must be a multiple of %d", lda, nti);
+    const int tiles = ((N + 127) / 128) * ((K + wk2 - 1) / wk2);
+    const int splits = rpb_gemm_tn_splits(M, N, K, conv);
+    if (nti == 4) hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("gemm_tn");
 }

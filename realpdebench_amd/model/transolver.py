@@ -185,7 +185,7 @@ class Transolver(_ModelBase):
     # ------------------------------------------------------------------ backward
     def _wgrad(self, G, A, M, N, K, ldg=None, lda=None, conv=None):
         """(dW [N,K], db [N]) = (G^T A, colsum G) through the TN GEMM + fp64 partial reduction."""
-        splits = ops.gemm_tn_splits(M, N, K)
+        splits = ops.gemm_tn_splits(M, N, K, conv is not None)
         part = torch.empty(splits, N * K + N, device=G.device, dtype=torch.float32)
         ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda, conv=conv)
         dW = torch.empty(N, K, device=G.device, dtype=torch.float32)

@@ -217,8 +217,8 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
               flops=2 * M * N * K)
 
 
-def gemm_tn_splits(M, N, K):
-    return _lib.query("rpb_gemm_tn_splits", M, N, K)
+def gemm_tn_splits(M, N, K, conv=False):
+    return _lib.query("rpb_gemm_tn_splits", M, N, K, int(bool(conv)))
 
 
 def gemm_tn(G, A, part, M, N, K, ldg=None, lda=None, conv=None):
