@@ -146,8 +146,8 @@ int rpb_channel_affine(const float* in, float* out, long n, int C, const float* 
 /*     act: 0 none | 1 exact GELU (pre_out, if given, receives the pre-activation for the backward pass) |
  *          2 multiply by gelu'(aux[m][n]) (backward through a GELU; aux = that saved pre-activation). */
 int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
-                long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, int conv, int Hc,
-                int Wc, int Dc, void* stream);
+                long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask,
+                int conv, int Hc, int Wc, int Dc, void* stream);   /* mask: optional [M][ldo] inverted-dropout multiplier */
 /*     weight gradients: part[rpb_gemm_tn_splits(M,N,K)][N*K + N] partials of dW[n][k] = sum_m G[m][n] A(m,k) and
  *     db[n] = sum_m G[m][n] (autograd of the nn.Linear / nn.Conv3d weights above); conv=1 gathers A like rpb_gemm_nt. */
 int rpb_gemm_tn_splits(long M, int N, int K, int conv);
@@ -177,6 +177,8 @@ int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, const float
 int rpb_slice_bwd(const float* xf, const float* w, const float* gox, const float* tok2, const float* gT, const float* gN,
                   const float* Ws, const float* temp, float* gxf, float* part, int B, int ntok, int heads, int G,
                   void* stream);
+/*     out = a * b elementwise (dropout masks in the backward pass). */
+int rpb_mul(const float* a, const float* b, float* out, long n, void* stream);
 /*     column sums (bias / placeholder gradients): part[rpb_colsum_rows()][N]. */
 int rpb_colsum_rows(void);
 int rpb_colsum(const float* x, float* part, long M, int N, int ld, void* stream);

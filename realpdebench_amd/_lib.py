@@ -44,7 +44,8 @@ SIGNATURES = {
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
-    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "pp" + "iiii" + "p"),
+    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiii" + "p"),
+    "rpb_mul": (_I, "ppp" + "l" + "p"),
     "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
     "rpb_layernorm_bwd_rows": (_L, "l"),

@@ -27,6 +27,7 @@ struct GemmArgs {
     int act;               // 0 none, 1 exact GELU, 2 multiply by gelu'(aux[m][n]) (backward through a GELU)
     const float* aux;      // act == 2: the saved pre-activation [M][ldo]
     float* pre_out;        // act == 1: optional copy of the pre-activation (saved for the backward pass)
+    const float* mask;     // optional [M][ldo] multiplier applied before addvec/residual (inverted-dropout mask)
     // implicit 3x3x3 convolution over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
     int conv, Hc, Wc, Dc;
 };
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                     } else if (g.act == 2) {
                         v *= gelu_grad_f(g.aux[m * g.ldo + n]);
                     }
+                    if (g.mask) v *= g.mask[m * g.ldo + n];
                     v += vadd;
                     if (g.residual) v += g.residual[m * g.ldo + n];
                     g.out[m * g.ldo + n] = v;
@@ -201,7 +203,7 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual,
                            float* out, long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out,
-                           int conv, int Hc, int Wc, int Dc, void* stream) {
+                           const float* mask, int conv, int Hc, int Wc, int Dc, void* stream) {
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
     RPB_REQUIRE(act != 2 || aux, "gemm_nt: act=2 needs the saved pre-activation");
     RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
@@ -213,7 +215,7 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
     }
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.addvec = addvec; g.residual = residual; g.out = out;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act; g.aux = aux; g.pre_out = pre_out;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act; g.aux = aux; g.pre_out = pre_out; g.mask = mask;
     g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64) return launch_gemm<2, 2, 2, 2>(g, st);      // 128 x 128 tile

@@ -514,3 +514,15 @@ extern "C" int rpb_channel_affine(const float* in, float* out, long n, int C, co
                        mean, stdv, inverse);
     RPB_CHECK_LAUNCH("channel_affine");
 }
+
+// out = a * b elementwise (dropout-mask application in the Transolver backward)
+__global__ __launch_bounds__(PW_THREADS) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] * reinterpret_cast<const f32x4*>(b)[i];
+}
+extern "C" int rpb_mul(const float* a, const float* b, float* out, long n, void* stream) {
+    RPB_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "mul: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(mul_kernel, dim3(pw_grid(n / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, a, b, out, n / 4);
+    RPB_CHECK_LAUNCH("mul");
+}

@@ -93,6 +93,7 @@ class Transolver(_ModelBase):
                                      for i in range(n_layers)])
         self.placeholder = nn.Parameter((1.0 / n_hidden) * torch.rand(n_hidden))
         self._wcat = {}
+        self._mask_override = None      # tests: list of (attn_mask [B,h,G,G], out_mask [M,C]) per block, already scaled
 
     # fused, re-laid-out weight of the two convolutions: rows 0..C-1 = in_project_fx, C..2C-1 = in_project_x;
     # column = ((kh*3+kw)*3+kd)*Ci + ci  (what rpb_gemm_nt's implicit-GEMM loader walks)
@@ -156,10 +157,28 @@ class Transolver(_ModelBase):
             for b in range(B):            # per-sample finish of the block partials (deterministic fp64 sums)
                 ops.reduce_partials(tok_part[b * bps:(b + 1) * bps], bps, heads * G * 32, out_f32=tokS[b])
                 ops.reduce_partials(norm_part[b * bps:(b + 1) * bps], bps, heads * G, out_f32=norm[b])
-            ops.slice_attn(tokS, norm, at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data, tok2, B * heads, G)
+            amask = omask = None
+            if keep and self.training and self.dropout_p > 0:
+                # nn.Dropout(p) on the slice attention map and after to_out (Physics_Attention.py:169,144): inverted-
+                # dropout masks drawn with torch's device RNG (the stream necessarily differs from the reference's)
+                if self._mask_override is not None:
+                    amask, omask = self._mask_override[i]
+                else:
+                    keep_p = 1.0 - self.dropout_p
+                    amask = (torch.rand(B, heads, G, G, **f) < keep_p).float() / keep_p
+                    omask = (torch.rand(M, C, **f) < keep_p).float() / keep_p
+                # 16 x 16 attention with the mask: a few thousand numbers per sample (plumbing-scale torch glue)
+                tk = tokS.view(B, heads, G, 32) / (norm.view(B, heads, G) + 1e-5)[..., None]
+                q, k, v = tk @ at.to_q.weight.data.t(), tk @ at.to_k.weight.data.t(), tk @ at.to_v.weight.data.t()
+                tok2.copy_(((torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1) * amask) @ v).reshape(B, -1))
+            else:
+                ops.slice_attn(tokS, norm, at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data, tok2,
+                               B * heads, G)
             ops.deslice_fwd(w, tok2, ox, B, ntok, heads, G)
             fx1 = new(M, C) if keep else fx
-            ops.gemm_nt(ox, at.to_out[0].weight.data, fx1, M, C, C, bias=at.to_out[0].bias.data, residual=fx)
+            ops.gemm_nt(ox, at.to_out[0].weight.data, fx1, M, C, C, bias=at.to_out[0].bias.data, residual=fx, mask=omask)
+            if keep:
+                st.update(amask=amask, omask=omask)
             a2 = new(M, C) if keep else a
             ops.layernorm_fwd(fx1, blk.ln_2.weight.data, blk.ln_2.bias.data, a2, M, C)
             hpre = new(M, C * self.mlp_ratio) if keep else None
@@ -236,9 +255,13 @@ class Transolver(_ModelBase):
             del ghp
             g1, grads[blk.ln_2.weight], grads[blk.ln_2.bias] = self._ln_bwd(st["fx1"], blk.ln_2, ga2, g, M, C)
             # ---- attention output projection (fx1 = fx0 + to_out(ox))
-            grads[at.to_out[0].weight], grads[at.to_out[0].bias] = self._wgrad(g1, st["ox"], M, C, C)
+            g1m = g1
+            if st["omask"] is not None:                      # dropout after to_out: gradient flows through the same mask
+                g1m = new(M, C)
+                ops.mul(g1, st["omask"], g1m, M * C)
+            grads[at.to_out[0].weight], grads[at.to_out[0].bias] = self._wgrad(g1m, st["ox"], M, C, C)
             gox = new(M, C)
-            ops.gemm_nt(g1, T(at.to_out[0].weight), gox, M, C, C)
+            ops.gemm_nt(g1m, T(at.to_out[0].weight), gox, M, C, C)
             # ---- deslice backward w.r.t. the attended slice tokens: g_tok2 = sum_n w * g_ox
             tp = new(B * bps, heads * G * 32)
             ops.slice_fwd(gox, None, None, None, None, tp, None, B, ntok, heads, G, C, w_in=st["w"])
@@ -253,7 +276,10 @@ class Transolver(_ModelBase):
                 wq, wk, wv = (p.detach().requires_grad_(True) for p in (at.to_q.weight, at.to_k.weight, at.to_v.weight))
                 tok = tS / (nm + 1e-5)[..., None]
                 q, k, v = tok @ wq.t(), tok @ wk.t(), tok @ wv.t()
-                o = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1) @ v
+                attn = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1)
+                if st["amask"] is not None:
+                    attn = attn * st["amask"]
+                o = attn @ v
                 gT, gN, gq, gk, gv = torch.autograd.grad(o, (tS, nm, wq, wk, wv), gtok2.view(B, heads, G, 32))
             grads[at.to_q.weight], grads[at.to_k.weight], grads[at.to_v.weight] = gq, gk, gv
             # ---- slice + deslice backward w.r.t. the dual-convolution output
@@ -302,9 +328,6 @@ class Transolver(_ModelBase):
         x = x.contiguous().float()
         params = [p for p in self.parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            if self.training and self.dropout_p > 0:
-                raise NotImplementedError("training-mode dropout masks are not implemented on the HIP path: construct the "
-                                          "model with dropout=0.0 to train (eval / rollout are unaffected)")
             return _TransolverFunction.apply(x, self, *params)
         return self._forward_hip(x)
 

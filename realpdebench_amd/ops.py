@@ -205,14 +205,19 @@ def channel_affine(inp, out, n, C, mean, std, inverse):
 
 
 # ----------------------------------------------------------------------------- Transolver forward kernels
+def mul(a, b, out, n):
+    _lib.call("rpb_mul", _p(a), _p(b), _p(out), n, _stream(), label="mul", nbytes=12 * n)
+
+
 def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
-            pre_out=None):
+            pre_out=None, mask=None):
     """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A the implicit 3x3x3 im2col of a token tensor.
     act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``)."""
     hc, wc, dc = conv if conv else (0, 0, 0)
     lda = (K // 27 if conv else K) if lda is None else lda
     _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
-              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), int(conv is not None), hc, wc, dc, _stream(),
+              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), _p(mask), int(conv is not None), hc, wc, dc,
+              _stream(),
               label=f"gemm_nt[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * (M * lda + M * N + N * K),
               flops=2 * M * N * K)
 

@@ -20,26 +20,29 @@ def autoregressive_rollout(model, input, n_autoregressive, normalizer=None, para
     """``input``: pre-processed ``[B,T,H,W,C_in]`` on the device.  Returns normalised predictions
     ``[B, n*T_out, H, W, C_in]`` (control channels included, as in eval.py:321 before the ``[..., :-para_c]`` cut)."""
     model.eval()
-    x = model._check_input(input)
-    B = x.shape[0]
-    T_out, H, W, Cp = model.shape_out
-    Cin = model.dim_in
-    Cx = Cin - Cp
-    if (Cx > 0) != (para_input is not None):
-        raise ValueError("control channels and para_input must come together (eval.py:305-309)")
-    if model.shape_out[:3] != model.shape_in[:3]:
-        raise ValueError("autoregression needs T_out == T_in")
+    if not input.is_cuda:
+        raise RuntimeError("autoregressive_rollout runs on MI355X only: move the model and inputs to 'cuda'")
+    x = input.contiguous().float()
+    B, T, H, W, Cin = x.shape
     g = normalizer if isinstance(normalizer, GaussianNormalizer) else None
     if para_input is not None:
         para_input = para_input.to(x.device).contiguous().float()
-    out = torch.empty(B, n_autoregressive * T_out, H, W, Cin, device=x.device, dtype=torch.float32)
-    steps = out.view(B, n_autoregressive, T_out, H, W, Cin)
+    out = steps = nxt = None
     cur = x
-    nxt = torch.empty(B, T_out, H, W, Cin, device=x.device, dtype=torch.float32)
-    ncell = B * T_out * H * W
+    ncell = B * T * H * W
     for i in range(n_autoregressive):
-        p = model(cur)                                                   # [B,T,H,W,Cp]
-        ops.rollout_affine(p.reshape(ncell, Cp), para_input, nxt, ncell, Cp, Cx,
+        p = model(cur)                                                   # [B,T_out,H,W,Cp]
+        if i == 0:
+            Cp = p.shape[-1]
+            Cx = Cin - Cp
+            if tuple(p.shape[:4]) != (B, T, H, W):
+                raise ValueError("autoregression needs T_out == T_in (eval.py:314-319 feeds predictions back)")
+            if (Cx > 0) != (para_input is not None):
+                raise ValueError("control channels and para_input must come together (eval.py:305-309)")
+            out = torch.empty(B, n_autoregressive * T, H, W, Cin, device=x.device, dtype=torch.float32)
+            steps = out.view(B, n_autoregressive, T, H, W, Cin)
+            nxt = torch.empty(B, T, H, W, Cin, device=x.device, dtype=torch.float32)
+        ops.rollout_affine(p.reshape(ncell, Cp).contiguous(), para_input, nxt, ncell, Cp, Cx,
                            g.mean_targets[:Cp].contiguous() if g else None,
                            g.std_targets[:Cp].contiguous() if g else None,
                            g.mean_inputs[:Cin].contiguous() if g else None,

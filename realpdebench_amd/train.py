@@ -16,7 +16,7 @@ from torch.utils.data import DataLoader
 from .data import make_datasets
 from .data_normalizer import GaussianNormalizer, IdentityNormalizer
 from .model import load_model
-from .trainer import Trainer
+from .trainer import make_trainer
 from .utils import add_args_from_config, cycle, resolve_config, set_seed, setup_logging
 
 parser = argparse.ArgumentParser(description="Training Configurations")
@@ -75,11 +75,8 @@ def main(argv=None):
     if args.is_finetune:
         model.load_checkpoint(args.checkpoint_path, device)
         logging.info(f"Checkpoint {args.checkpoint_path} loaded.")
-    if world > 1:
-        from .dp import DataParallel
-        DataParallel(model)
-    trainer = Trainer(model, lr=args.lr, num_update=args.num_update, scheduler=args.scheduler,
-                      step_size=args.step_size, clip_grad_norm=args.clip_grad_norm)
+    trainer = make_trainer(model, lr=args.lr, num_update=args.num_update, scheduler=args.scheduler,
+                           step_size=args.step_size, clip_grad_norm=args.clip_grad_norm)   # wraps DP when world > 1
 
     n_iter = args.num_update if args.max_updates is None else min(args.num_update, args.max_updates)
     every = max(1, int(args.num_update / 50))                       # train.py:344

@@ -70,3 +70,63 @@ class Trainer:
         if extra:
             ck.update(extra)
         return ck
+
+
+class ProtocolTrainer:
+    """The reference's loop body verbatim in structure (train.py:323-334) for models without a flat arena
+    (Transolver): ``zero_grad``; ``train_loss(...).mean().backward()`` runs the HIP forward/backward through the model's
+    autograd Function; Adam + LR schedule are ``torch.optim`` (4 M parameters: off the critical path).  Under data
+    parallelism the gradients are averaged with one RCCL all-reduce per parameter after backward."""
+
+    def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0, dp_group=None):
+        self.model = model
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr)
+        if scheduler == "step":
+            self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=step_size, gamma=0.5)
+        elif scheduler == "cosine":
+            self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=num_update)
+        else:
+            raise ValueError(f"Scheduler {scheduler} not supported")
+        self.clip = float(clip_grad_norm or 0.0)
+        self.iteration = 0
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(dp_group)
+            for p in model.parameters():                         # one init for everyone, like the single-process reference
+                torch.distributed.broadcast(p.data, src=0, group=dp_group)
+        self.group = dp_group
+
+    def current_lr(self):
+        return self.opt.param_groups[0]["lr"]
+
+    def step(self, input, target):
+        self.model.train()
+        self.opt.zero_grad()
+        loss = self.model.train_loss(input, target).mean()
+        loss.backward()
+        if self.world > 1:
+            works = [torch.distributed.all_reduce(p.grad, group=self.group, async_op=True)
+                     for p in self.model.parameters() if p.grad is not None]
+            for w in works:
+                w.wait()
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    p.grad.div_(self.world)
+        if self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.opt.step()
+        self.sched.step()
+        self.iteration += 1
+        return loss.detach().reshape(1)
+
+
+def make_trainer(model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0):
+    """Fused arena trainer for FNO3d, protocol trainer for everything else."""
+    if hasattr(model, "flat"):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and model.dp is None:
+            from .dp import DataParallel
+            DataParallel(model)
+        return Trainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
+                       clip_grad_norm=clip_grad_norm)
+    return ProtocolTrainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
+                           clip_grad_norm=clip_grad_norm)

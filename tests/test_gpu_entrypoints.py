@@ -29,3 +29,24 @@ def test_train_then_eval(tmp_path):
     assert ck["train_losses"][-1] < ck["train_losses"][0] * 1.5          # finite and sane
     ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
     assert os.path.exists(os.path.join(exp, "eval.log"))
+
+
+def test_transolver_train_then_eval(tmp_path):
+    """Same entrypoints with model_name: transolver (ProtocolTrainer + HIP autograd path, dropout 0.1, 2-step rollout)."""
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd import train as tr
+    cfg = dict(exp_name="t", gpu=0, seed=0, results_path=str(tmp_path), dataset_name="synthetic", dataset_root="",
+               num_workers=0, normalizer="none", shape_in=[4, 6, 8, 3], shape_out=[4, 6, 8, 3], n_train=8, n_val=4,
+               model_name="transolver", space_dim=3, n_layers=2, n_hidden=64, n_head=2, H=8, W=6, D=4, fun_dim=0,
+               out_dim=3, ref=4, dropout=0.1, act="gelu", mlp_ratio=2, slice_num=16, checkpoint_path="", is_use_tb=None,
+               scheduler="cosine", step_size=10, num_update=100, train_batch_size=4, test_batch_size=4, lr=1e-3,
+               clip_grad_norm=0.0, N_autoregressive=2)
+    path = tmp_path / "ts.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = tr.main(["--config", str(path), "--max_updates", "6"])
+    ckpts = sorted(glob.glob(os.path.join(exp, "model_*.pth")))
+    ck = torch.load(ckpts[-1], map_location="cpu")
+    assert ck["iteration"] == 6 and "blocks.0.Attn.in_project_x.weight" in ck["model_state_dict"]
+    assert all(l == l and l < 1e3 for l in ck["train_losses"])                  # finite
+    assert ck["train_losses"][-1] < ck["train_losses"][0]                       # it learns something on 8 samples
+    ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])

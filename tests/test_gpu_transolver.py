@@ -117,9 +117,6 @@ def test_model_matches_reference_golden():
         y = m(torch.from_numpy(np.array(z["x"])).cuda())
     assert y.shape == z["y"].shape
     assert rel_l2(y.cpu(), torch.from_numpy(np.array(z["y"]))) < 1e-5
-    m.train()                                        # dropout 0.1 in train mode has no HIP masks yet: must be loud
-    with pytest.raises(NotImplementedError):
-        m.train_loss(torch.from_numpy(np.array(z["x"])).cuda(), y)
 
 
 def test_model_reference_width_vs_oracle():
@@ -137,8 +134,8 @@ def test_model_reference_width_vs_oracle():
     assert rel_l2(y.cpu(), ref) < 1e-5
 
 
-@pytest.mark.parametrize("n_hidden,heads,layers", [(64, 2, 2), (256, 8, 1)])
-def test_train_loss_gradients_vs_oracle_autograd(n_hidden, heads, layers):
+@pytest.mark.parametrize("n_hidden,heads,layers,drop", [(64, 2, 2, 0.0), (256, 8, 1, 0.0), (64, 2, 2, 0.1)])
+def test_train_loss_gradients_vs_oracle_autograd(n_hidden, heads, layers, drop):
     """Every parameter gradient of `train_loss(...).mean().backward()` (drop-in protocol, HIP backward) against
     PyTorch autograd through the CPU oracle (itself pinned to the reference)."""
     from oracle import transolver_oracle as TO
@@ -146,7 +143,7 @@ def test_train_loss_gradients_vs_oracle_autograd(n_hidden, heads, layers):
     torch.manual_seed(5 + n_hidden)
     H, W, D = 7, 6, 5
     m = Transolver(space_dim=3, n_layers=layers, n_hidden=n_hidden, n_head=heads, fun_dim=0, out_dim=3, slice_num=16,
-                   mlp_ratio=4, H=H, W=W, D=D, dropout=0.0)
+                   mlp_ratio=4, H=H, W=W, D=D, dropout=drop)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if n.endswith("bias") or "ln_" in n:
@@ -154,7 +151,13 @@ def test_train_loss_gradients_vs_oracle_autograd(n_hidden, heads, layers):
         m.blocks[0].Attn.temperature.view(-1)[0] = 0.05          # below the clamp: zero gradient expected
     x, y = torch.randn(2, D, W, H, 3), torch.randn(2, D, W, H, 3)
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
-    loss_ref = ((TO.transolver_forward(sd, x, layers, heads, H, W, D) - y) ** 2).mean()
+    masks = None
+    if drop > 0:          # same (pre-scaled) inverted-dropout masks on both sides: the RNG streams cannot be matched
+        ntk = H * W * D
+        masks = [((torch.rand(2, heads, 16, 16) < 1 - drop).float() / (1 - drop),
+                  (torch.rand(2 * ntk, n_hidden) < 1 - drop).float() / (1 - drop)) for _ in range(layers)]
+        m._mask_override = [(a.cuda(), b.cuda()) for a, b in masks]
+    loss_ref = ((TO.transolver_forward(sd, x, layers, heads, H, W, D, masks) - y) ** 2).mean()
     loss_ref.backward()
     m = m.cuda().train()
     loss = m.train_loss(x.cuda(), y.cuda()).mean()
