@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
+    ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -78,6 +79,52 @@ def cpu_baseline():
     except Exception as e:        # timeout / parse error: report it, never hang the bench
         return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
                 "sample": f"CPU oracle step did not finish within 300 s ({type(e).__name__})"}
+
+
+def bench_transolver(dev, B=4, steps=3):
+    """Transolver (configs/cylinder/trainsolver.yaml: 20x64x128x3 tokens -> mesh 128x64x20, hidden 256, 8 heads, 16
+    slices, 1 layer) -- train step through the drop-in protocol (HIP forward/backward + torch.optim.Adam) and eval
+    forward.  Reported next to the FNO headline; fp32 MFMA roofline (the two 3x3x3 convolutions are 83 % of the FLOPs)."""
+    from realpdebench_amd.model.transolver import Transolver
+    torch.manual_seed(0)
+    m = Transolver(space_dim=3, n_layers=1, n_hidden=256, n_head=8, fun_dim=0, out_dim=3, slice_num=16, mlp_ratio=4,
+                   H=128, W=64, D=20, dropout=0.1).to(dev)
+    x = torch.randn(B, 20, 64, 128, 3, device=dev)
+    y = torch.randn(B, 20, 64, 128, 3, device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=7e-4)
+
+    def step():
+        opt.zero_grad()
+        m.train_loss(x, y).mean().backward()
+        opt.step()
+
+    m.train()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / steps
+    m.eval()
+    with torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / steps
+    tokens = B * 20 * 64 * 128
+    flops_step = 3 * 8.56e6 * tokens              # SURVEY.md section 8(d): 8.56 MFLOP/token forward, x3 for a step
+    del m, opt
+    torch.cuda.empty_cache()
+    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
+            "forward_fields_per_s": B * 20 / t_fwd, "ms_per_forward": 1e3 * t_fwd,
+            "mfma_f32": {"achieved": flops_step / t_train / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops_step / t_train / 1e12 / MFMA_F32_PEAK_TF},
+            "config": "Transolver cylinder: tokens 20x64x128 -> mesh (128,64,20), n_hidden 256, 8 heads, 16 slices, "
+                      "1 layer, mlp_ratio 4, dropout 0.1, fp32"}
 
 
 def main():
@@ -173,6 +220,11 @@ def main():
         rollout = {"value": B * world * shape[0] * a.rollout_steps / rt, "unit": "fields/s",
                    "n_autoregressive": a.rollout_steps, "ms_per_forward": 1e3 * rt / a.rollout_steps}
 
+    # ---- secondary: Transolver (north_star's second model) at the reference's cylinder config, rank 0 / N=1 only
+    transolver = None
+    if not a.no_transolver and world == 1:
+        transolver = bench_transolver(dev)
+
     if rank == 0:
         ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
         ach_tf = dom["flops"] / dom["avg_ms"] / 1e9
@@ -196,6 +248,7 @@ def main():
                                         "achieved": step_bytes / (ms_per_step * 1e6), "unit": "GB/s",
                                         "frac": step_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS}},
             "rollout": rollout,
+            "transolver": transolver,
             "loss": float(loss),
         }
         if not a.no_cpu_baseline and world == 1:
