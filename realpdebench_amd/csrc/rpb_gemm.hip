@@ -286,7 +286,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     const bool n_ok0 = n0 + col * 2 < g.N, n_ok1 = n0 + col * 2 + 1 < g.N;      // N may be < 64 (e.g. mlp2: 3)
     const int klim = g.conv ? Ci : g.K;
     const long mesh = (long)g.Hc * g.Wc * g.Dc;
-    const float inv_dc = g.conv ? 1.0f / g.Dc : 0.f, inv_wc = g.conv ? 1.0f / g.Wc : 0.f;
 
     f32x16 acc[2][NTI];
 #pragma unroll
@@ -300,53 +299,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     const veci zi = {};
     // m0 is wave-uniform; the mesh coordinates of m0 + j (j < 32) follow from ONE scalar decomposition of m0 plus a
     // division-free carry (float reciprocal of the small extents), instead of three integer divisions per load
-    // mesh coordinates of the first token of the current 32-token chunk, advanced incrementally (no divisions in the loop)
-    int c_d = 0, c_w = 0, c_h = 0;
+    // A lane's tokens form ONE arithmetic progression mb + half, +2, +4, ... across steps, halves and chunks, so its
+    // mesh coordinates are carried incrementally (add 2 with carry): no divisions and ~10 VALU ops per load
+    int ld = 0, lw = 0, lh = 0;
     if (g.conv) {
-        const long r = mb % mesh;
-        c_d = (int)(r % g.Dc);
-        c_w = (int)((r / g.Dc) % g.Wc);
-        c_h = (int)(r / ((long)g.Dc * g.Wc));
+        const long r = (mb + half) % mesh;
+        ld = (int)(r % g.Dc);
+        lw = (int)((r / g.Dc) % g.Wc);
+        lh = (int)(r / ((long)g.Dc * g.Wc));
     }
-    auto advance32 = [&]() {
-        if (!g.conv) return;
-        const int t = c_d + 32;
-        const int q = (int)((t + 0.5f) * inv_dc);
-        c_d = t - q * g.Dc;
-        const int w1 = c_w + q;
-        const int q2 = (int)((w1 + 0.5f) * inv_wc);
-        c_w = w1 - q2 * g.Wc;
-        c_h += q2;
-        while (c_h >= g.Hc) c_h -= g.Hc;
-    };
-    auto load_half = [&](long m0, int h, int d0, int w0, int h0, f32x2 (&gv)[8], veci (&xv)[8]) {
+    auto load_half = [&](long m0, int h, f32x2 (&gv)[8], veci (&xv)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int j = h * 16 + 2 * s + half;
             const long m = m0 + j;
             f32x2 gq = {0.f, 0.f};
             veci xq = zi;
+            bool ok = tap_ok;
+            if (g.conv) {
+                const int hh = lh + dh, ww = lw + dw, d2 = ld + dd;
+                ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
+                ld += 2;                                             // advance this lane to its next token
+                while (ld >= g.Dc) {
+                    ld -= g.Dc;
+                    if (++lw >= g.Wc) {
+                        lw = 0;
+                        if (++lh >= g.Hc) lh = 0;
+                    }
+                }
+            }
             if (m < me) {
                 const float* gp = g.G + m * g.ldg + n0 + col * 2;
                 if (n_ok1) gq = *reinterpret_cast<const f32x2*>(gp);
                 else if (n_ok0) gq[0] = gp[0];
-                long row = m;
-                bool ok = tap_ok;
-                if (g.conv) {
-                    const int t = d0 + j;
-                    const int q = (int)((t + 0.5f) * inv_dc);
-                    const int d2 = t - q * g.Dc + dd;
-                    const int w1 = w0 + q;
-                    const int q2 = (int)((w1 + 0.5f) * inv_wc);
-                    const int ww = w1 - q2 * g.Wc + dw;
-                    int hh = h0 + q2;
-                    if (hh >= g.Hc) hh -= g.Hc;                       // ran into the next sample
-                    hh += dh;
-                    ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
-                    row = m + noff;
-                }
                 if (ok) {
-                    const float* xp = g.A + row * g.lda + kk0 + col * NTI;
+                    const float* xp = g.A + (m + noff) * g.lda + kk0 + col * NTI;
                     if (kk0 + col * NTI + NTI <= klim) xq = *reinterpret_cast<const veci*>(xp);
                     else {
 #pragma unroll
@@ -370,12 +357,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
             }
     };
     long m = mb;
-    if (m < me) load_half(m, 0, c_d, c_w, c_h, ga, xa);
+    if (m < me) load_half(m, 0, ga, xa);
     for (; m < me; m += 32) {
-        load_half(m, 1, c_d, c_w, c_h, gb, xb);
+        load_half(m, 1, gb, xb);                  // NOTE: load_half must be called in token order (lane state above)
         compute_half(ga, xa);
-        advance32();
-        if (m + 32 < me) load_half(m + 32, 0, c_d, c_w, c_h, ga, xa);
+        if (m + 32 < me) load_half(m + 32, 0, ga, xa);
         compute_half(gb, xb);
     }
     float* part = g.part + (long)split * ((long)g.N * g.K + g.N);
