@@ -229,6 +229,13 @@ def main():
         ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
         ach_tf = dom["flops"] / dom["avg_ms"] / 1e9
         step_bytes = (6.238 * B + 4.03) * 1e9          # algorithmic bytes of one train step
+        traffic = None                                  # HBM bytes per launch of the dominant kernel, from the committed
+        try:                                            # PMC request-size passes (bench.py cannot run rocprofv3 itself)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
+            if B == 32:
+                traffic = tj["bytes_per_launch"].get(dominant)
+        except Exception:
+            pass
         line = {
             "metric": "train-step samples/sec (+ autoregressive rollout fields/sec in 'rollout'), FNO cylinder 128^2",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -239,7 +246,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.txt" if traffic else None,
                          "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["calls"],
                          "algorithmic_bytes_per_launch": dom["bytes"],
                          "mfma_f32": {"achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",

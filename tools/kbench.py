@@ -31,7 +31,7 @@ def timeit(name, fn, nbytes, flops, iters=5):
     print(f"{name:40s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  {flops / ms / 1e9:7.2f} TF/s", flush=True)
 
 
-which = set(sys.argv[1:]) or {"cell_mix", "wgrad", "axis", "bn", "proj", "lift", "mode"}
+which = set(sys.argv[1:]) or {"cell_mix", "wgrad", "axis", "bn", "proj", "lift", "mode", "bwd_row"}
 x = torch.randn(d.ncell, C, **f)
 y = torch.empty(d.ncell, C, **f)
 
@@ -53,6 +53,19 @@ if "cell_mix" in which:
            lambda: ops.cell_mix(gu, w1, None, None, None, y, None, d.ncell, 128, C, 0, 1, transpose_w=True,
                                 gather=True, crop6=d.crop6),
            4 * (d.ncrop * 128 + d.ncell * C), 2 * d.ncrop * 128 * C)
+
+if "bwd_row" in which:
+    K2 = 2 * plan.KW
+    G = B * d.Tp * d.Hp
+    mean, invstd, gamma, beta = torch.zeros(C, **f), torch.ones(C, **f), torch.ones(C, **f), torch.zeros(C, **f)
+    sums = torch.zeros(2 * C, **f)
+    gy = torch.randn(d.ncell, C, **f)
+    Y1 = torch.empty(G * K2 * C, **f)
+    part = torch.empty(ops.bn_bwd_row_slots(G) * (C * C + C), **f)
+    xf = (mean, invstd, gamma, beta, True)
+    timeit("bn_bwd_row (gelu, lazy x)",
+           lambda: ops.bn_bwd_row(x, gy, y, gy, mean, invstd, gamma, beta, sums, d.ncell, True, xf, plan.GW, Y1, part, G,
+                                  d.Wp, C, K2), 4 * (4 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * (C + K2))
 
 if "wgrad" in which:
     slots = ops.cell_wgrad_slots(d.ncell, C, C)
