@@ -251,13 +251,15 @@ struct TnVec<4> {
 };
 
 // NTI = k-tiles (of 32 channels) per wave: wave tile = 64 (n) x 32*NTI (k), workgroup = 2 x 2 waves.
-template <int NTI>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+// WN = waves along n per workgroup (2 or 4): workgroup tile = 64*WN (n) x 64*NTI (k); the bigger tile halves the
+// re-reads of A (every n-tile streams the whole gathered activation tensor once per tap)
+template <int NTI, int WN>
+__global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     typedef typename TnVec<NTI>::T veci;
     constexpr int WK = 32 * NTI;                       // k columns per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave >> 1, wk = wave & 1;              // WN x 2 waves
     const int col = lane & 31, half = lane >> 5;
     const int tk = (g.K + 2 * WK - 1) / (2 * WK);
     // XCD-aware tile order: workgroup b runs on XCD b % 8, so give every XCD a CONTIGUOUS range of tiles.  The tk
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     int tile = blockIdx.x;
     if (gridDim.x % 8 == 0) tile = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
     const int tile_n = tile / tk, tile_k = tile % tk;
-    const int n0 = tile_n * 128 + wn * 64, k0 = tile_k * 2 * WK + wk * WK;     // this wave's sub-tile
+    const int n0 = tile_n * 64 * WN + wn * 64, k0 = tile_k * 2 * WK + wk * WK;     // this wave's sub-tile
     const int nsplit = gridDim.y, split = blockIdx.y;
     const long per = ((g.M + nsplit - 1) / nsplit + 31) / 32 * 32;
     const long mb = (long)split * per;
@@ -388,9 +390,12 @@ static int gemm_tn_nti(int K, int conv) {
     return (Ci % 128 == 0) ? 4 : 2;
 }
 
+static int gemm_tn_wn(int N) { return N > 128 ? 4 : 2; }
+
 extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
     const int wk2 = 64 * gemm_tn_nti(K, conv);
-    const long tiles = (long)((N + 127) / 128) * ((K + wk2 - 1) / wk2);
+    const int bn = 64 * gemm_tn_wn(N);
+    const long tiles = (long)((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
     long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
     const long cap = (M + 511) / 512;                 // at least 512 tokens per split
     if (s > cap) s = cap;
@@ -411,9 +416,13 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
     const int nti = gemm_tn_nti(K, conv);
     const int wk2 = 64 * nti;
     RPB_REQUIRE(lda % nti == 0, "gemm_tn: lda=%d must be a multiple of %d", lda, nti);
-    const int tiles = ((N + 127) / 128) * ((K + wk2 - 1) / wk2);
+    const int wn = gemm_tn_wn(N), bn = 64 * wn;
+    const int tiles = ((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
     const int splits = rpb_gemm_tn_splits(M, N, K, conv);
-    if (nti == 4) hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gemm_tn_kernel<2>, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (nti == 4 && wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
+    else if (nti == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
+    else if (wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
     RPB_CHECK_LAUNCH("gemm_tn");
 }
