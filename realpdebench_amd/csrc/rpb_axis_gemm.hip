@@ -68,84 +68,89 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
     const int col = lane & 31, half = lane >> 5;
     const int nch = N / (32 * NV);
     const long nitems = (long)G * nch * och;
-    const int kch = (k_valid + 15) / 16;                // chunks of 8 MFMA steps (16 k) that hold non-zero input
+    int kch = (k_valid + 15) / 16;                      // chunks of 8 MFMA steps (16 k) that hold non-zero input
+    if (kch < 1) kch = 1;                               // k_valid == 0: one all-masked chunk -> zeros are written
+    const long istride = (long)gridDim.x * waves;
+    const vec vz = {};
+    constexpr bool has_xf = XF;
 
-    for (long item = (long)blockIdx.x * waves + wave; item < nitems; item += (long)gridDim.x * waves) {
-        const int oc = (int)(item % och);
+    // The wave walks ONE flattened stream of (item, chunk) pairs with two register buffers in ping-pong: the first chunk
+    // of the next item is already in flight while the last chunk of the current item is multiplied and stored, so short
+    // items (the H / T stages: 3-17 chunks) do not expose a load latency per item.
+    struct Item {
+        const float* ip;   // uniform input base of the item
+        float* op;         // output base (lane part added at store time)
+        int oc, nc;
+    };
+    auto decode = [&](long item) {
+        Item it;
+        it.oc = (int)(item % och);
         const long r = item / och;
-        const int nc = (int)(r % nch);
+        it.nc = (int)(r % nch);
         const long g = r / nch;
-        const float* ip = in + g * in_g + (long)nc * 32 * NV;              // uniform
-        const long lane_in = (long)half * in_k + NV * col;
-        f32x16 acc[OT][NV];
+        it.ip = in + g * in_g + (long)it.nc * 32 * NV;
+        it.op = out + g * out_g + (long)it.nc * 32 * NV;
+        return it;
+    };
+    const long lane_in = (long)half * in_k + NV * col;
+    auto load_chunk = [&](const Item& it, int c, vec (&b)[8]) {
+        const float* cp = it.ip + (long)(16 * c) * in_k;                   // uniform
+        if (16 * c + 16 <= k_valid) {
 #pragma unroll
-        for (int a = 0; a < OT; ++a)
+            for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k);
+        } else {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) acc[a][v] = zero16();
-
-        vec ba[8], bb[8];
-        const vec vz = {};
-        // lazy BatchNorm(+GELU) of the producing layer, applied to the data operand right before the MFMA
-        // (N == C here, so the n index IS the channel and a lane keeps its NV channels for the whole item)
-        constexpr bool has_xf = XF;
-        XParam xp[NV];
-        if (has_xf) {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) xp[v] = xf_load(xf, nc * 32 * NV + NV * col + v);
+            for (int s = 0; s < 8; ++s)
+                b[s] = (16 * c + 2 * s + half < k_valid)
+                           ? *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k) : vz;
         }
-        // chunk c covers k in [16c, 16c+16); lane (half) takes k = 16c + 2s + half
-        auto load_chunk = [&](int c, vec (&b)[8]) {
-            const float* cp = ip + (long)(16 * c) * in_k;                   // uniform
-            if (16 * c + 16 <= k_valid) {
+    };
+    f32x16 acc[OT][NV];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k);
-            } else {
+    for (int a = 0; a < OT; ++a)
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    b[s] = (16 * c + 2 * s + half < k_valid)
-                               ? *reinterpret_cast<const vec*>(cp + lane_in + (long)(2 * s) * in_k) : vz;
-            }
-        };
-        auto compute_chunk = [&](int c, vec (&b)[8]) {
-            const float* mp = Mlds + (16 * c + half) * Op + oc * OT * 32 + col;
-            if (has_xf) {
+        for (int v = 0; v < NV; ++v) acc[a][v] = zero16();
+    XParam xp[NV];
+
+    auto compute_chunk = [&](const Item& it, int c, vec (&b)[8]) {
+        const float* mp = Mlds + (16 * c + half) * Op + it.oc * OT * 32 + col;
+        if (has_xf) {
+            // lazy BatchNorm(+GELU) of the producing layer on the data operand (N == C: the n index is the channel)
+            if (c == 0) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    if constexpr (NV == 1) b[s] = xf_apply(b[s], xp[0], xf.gelu != 0);
-                    else {
-#pragma unroll
-                        for (int v = 0; v < NV; ++v) b[s][v] = xf_apply(b[s][v], xp[v], xf.gelu != 0);
-                    }
-                }
+                for (int v = 0; v < NV; ++v) xp[v] = xf_load(xf, it.nc * 32 * NV + NV * col + v);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
+                if constexpr (NV == 1) b[s] = xf_apply(b[s], xp[0], xf.gelu != 0);
+                else {
 #pragma unroll
-                for (int a = 0; a < OT; ++a) {
-                    const float av = mp[2 * s * Op + a * 32];
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        float bv;
-                        if constexpr (NV == 1) bv = b[s];
-                        else bv = b[s][v];
-                        acc[a][v] = mfma32(av, bv, acc[a][v]);
-                    }
+                    for (int v = 0; v < NV; ++v) b[s][v] = xf_apply(b[s][v], xp[v], xf.gelu != 0);
                 }
             }
-        };
-        if (kch > 0) load_chunk(0, ba);
-        for (int c = 0; c < kch; c += 2) {
-            if (c + 1 < kch) load_chunk(c + 1, bb);
-            compute_chunk(c, ba);
-            if (c + 2 < kch) load_chunk(c + 2, ba);
-            if (c + 1 < kch) compute_chunk(c + 1, bb);
         }
-        float* op = out + g * out_g + (long)nc * 32 * NV + NV * col;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int a = 0; a < OT; ++a) {
+                const float av = mp[2 * s * Op + a * 32];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float bv;
+                    if constexpr (NV == 1) bv = b[s];
+                    else bv = b[s][v];
+                    acc[a][v] = mfma32(av, bv, acc[a][v]);
+                }
+            }
+        }
+    };
+    auto store_item = [&](const Item& it) {
+        float* op = it.op + NV * col;
 #pragma unroll
         for (int a = 0; a < OT; ++a) {
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
-                const int o = (oc * OT + a) * 32 + mfma_row(lane, rr);
+                const int o = (it.oc * OT + a) * 32 + mfma_row(lane, rr);
                 if (o < O) {
                     float* dst = op + (long)o * out_o;
                     if constexpr (NV == 1) {
@@ -163,7 +168,39 @@ __global__ __launch_bounds__(256) void axis_gemm_kernel(const float* __restrict_
                     }
                 }
             }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[a][v] = zero16();
         }
+    };
+
+    long item = (long)blockIdx.x * waves + wave;
+    if (item >= nitems) return;
+    Item cur = decode(item);
+    int c = 0;
+    vec ba[8], bb[8];
+    load_chunk(cur, 0, ba);
+    // one pipeline step: prefetch the successor (same item next chunk, or next item chunk 0) into `nb`, multiply `cb`
+    auto step = [&](vec (&cb)[8], vec (&nb)[8]) -> bool {
+        long nitem = item;
+        int ncnk = c + 1;
+        Item nxt = cur;
+        if (ncnk == kch) {
+            nitem = item + istride;
+            ncnk = 0;
+            if (nitem < nitems) nxt = decode(nitem);
+        }
+        const bool more = nitem < nitems;
+        if (more) load_chunk(nxt, ncnk, nb);
+        compute_chunk(cur, c, cb);
+        if (c == kch - 1) store_item(cur);
+        item = nitem;
+        c = ncnk;
+        cur = nxt;
+        return more;
+    };
+    while (true) {
+        if (!step(ba, bb)) break;
+        if (!step(bb, ba)) break;
     }
 }
 
@@ -208,8 +245,9 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     RPB_REQUIRE(k_valid >= 0 && k_valid <= K, "axis_gemm: k_valid=%d out of range", k_valid);
     hipStream_t st = (hipStream_t)stream;
     const int ot_total = (O + 31) / 32;
-    const int OT = ot_total >= 3 ? 3 : ot_total;
+    int OT = ot_total >= 3 ? 3 : ot_total;
     int NV = (N % 128 == 0) ? 4 : (N % 64 == 0) ? 2 : 1;
+    if (ot_total >= 3 && NV == 4) OT = 2;     // wide rows (512 B per half-wave) beat a third o-tile (measured: inverse H stage -9 %)
     while (OT * NV > 8) NV >>= 1;
     // 16-byte vector access needs aligned strides
     if (NV == 4 && ((in_g | in_k | out_g | out_o) & 3)) NV = 2;
