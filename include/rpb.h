@@ -108,16 +108,17 @@ int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, float* gs, c
                    const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu,
                    const float* M_wk, float* Y1, float* part, int G, int Wp, int C, int K2, void* stream);
 
-/* K7  crop + fc1 + GELU + fc2.  fno.py:121-125.  proj_bwd recomputes fc1 and emits gu = dL/d(fc1 pre-activation)
+/* K7  crop + fc1 + activation + fc2.  fno.py:121-125 (act = 0: exact GELU); the same head of the Galerkin
+ *     SpectralRegressor, galerkin_transformer_libs/model.py:626-633 (act = 1: SiLU).  proj_bwd recomputes fc1 and emits gu = dL/d(fc1 pre-activation)
  *     [ncrop][128] plus partial rows [rpb_proj_slots(...)][DO*128 + 128 + DO] for d fc2.weight, d fc1.bias, d fc2.bias. */
 long rpb_proj_slots(long ncrop, int C, int DO);
 int rpb_proj_fwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                  float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean,
-                 const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu, void* stream);
+                 const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu, int act, void* stream);
 int rpb_proj_bwd(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                  const float* gout, float* gu, float* part, long ncrop, int C, int DO, int T, int H, int W, int Tp,
                  int Hp, int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta,
-                 int xf_gelu, void* stream);
+                 int xf_gelu, int act, void* stream);
 
 /*     MSE.  realpdebench/utils/metrics.py:11-13 + `.mean()` of train.py:328 and its gradient. */
 int rpb_mse_rows(void);
@@ -144,7 +145,9 @@ int rpb_channel_affine(const float* in, float* out, long n, int C, const float* 
  *     Physics_Attention.py:154-157 as one implicit GEMM over the (Hc, Wc, Dc) mesh: W is [N][27*Ci] with
  *     column = ((kh*3 + kw)*3 + kd)*Ci + ci.  K must be a multiple of 32. */
 /*     act: 0 none | 1 exact GELU (pre_out, if given, receives the pre-activation for the backward pass) |
- *          2 multiply by gelu'(aux[m][n]) (backward through a GELU; aux = that saved pre-activation). */
+ *          2 multiply by gelu'(aux[m][n]) (backward through a GELU; aux = that saved pre-activation) |
+ *          3 ReLU (Galerkin FeedForward, galerkin_transformer_libs/layers.py:979-981) |
+ *          4 zero where aux[m][n] <= 0 (backward through that ReLU; aux = the saved ReLU output). */
 int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
                 long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask,
                 int conv, int Hc, int Wc, int Dc, void* stream);   /* mask: optional [M][ldo] inverted-dropout multiplier */
@@ -187,6 +190,29 @@ int rpb_slice_attn(const float* tokS, const float* norm, const float* Wq, const 
                    int BH, int G, void* stream);
 /*     deslice: out[m][h*32+c] = sum_g w[m][h][g] tok2[b][h][g][c] (Physics_Attention.py:173-175). */
 int rpb_deslice_fwd(const float* w, const float* tok2, float* out, int B, int ntok, int heads, int G, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Galerkin Transformer.  Token rows [token][256]; the dense products run on
+ * rpb_gemm_nt / rpb_gemm_tn, the spectral regressor on K2-K7 above.
+ * Reference: realpdebench/model/galerkin_transformer_libs/{layers.py:708-734,829-899,954-987, model.py:93-129,600-638}
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*     per-head LayerNorm of keys / values: rows of 4 heads x 64 channels, gamma/beta = the 4 nn.LayerNorm(64) affines
+ *     back to back (SimpleAttention norm_K / norm_V, layers.py:848-856, 921-935). */
+int rpb_headnorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* out, int ldo, long M, int C,
+                     float eps, void* stream);
+/*     its backward; part[rpb_headnorm_bwd_rows(M)][512] partials of (d gamma[256] | d beta[256]). */
+long rpb_headnorm_bwd_rows(long M);
+int rpb_headnorm_bwd(const float* x, int ldx, const float* gamma, const float* gy, int ldg, float* gx, int ldgx,
+                     float* part, long M, int C, float eps, void* stream);
+/*     SpectralRegressor.forward model.py:612-618 after the 256-wide token GEMM U = x fc.weight[:, :256]^T:
+ *     out[b,t,h,w,:] = U[token] + fc.weight[:, 256:259] (gt[t], gh[h], gw[w]) + fc.bias inside the mesh, 0 in the
+ *     6-cell pad; Wg = that [C][3] slice, contiguous. */
+int rpb_pad_grid_fwd(const float* U, const float* gt, const float* gh, const float* gw, const float* Wg,
+                     const float* bias, float* out, int B, int T, int H, int W, int C, int Tp, int Hp, int Wp,
+                     void* stream);
+/*     adjoint w.r.t. U: out[token][:] = g[padded cell of token][:]. */
+int rpb_crop_gather(const float* g, float* out, int B, int T, int H, int W, int C, int Tp, int Hp, int Wp, void* stream);
 
 #ifdef __cplusplus
 }

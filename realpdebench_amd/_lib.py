@@ -37,8 +37,8 @@ SIGNATURES = {
     "rpb_bn_bwd_row_slots": (_L, "i"),
     "rpb_bn_bwd_row": (_I, "ppppppppp" + "d" + "i" + "ppppi" + "ppp" + "iiii" + "p"),
     "rpb_proj_slots": (_L, "lii"),
-    "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "p"),
-    "rpb_proj_bwd": (_I, "pppppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "p"),
+    "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
+    "rpb_proj_bwd": (_I, "pppppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
     "rpb_mse_rows": (_I, ""),
     "rpb_mse": (_I, "ppppp" + "l" + "f" + "p"),
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
@@ -59,6 +59,11 @@ SIGNATURES = {
     "rpb_slice_fwd": (_I, "ppppppp" + "iiiii" + "p" + "p"),
     "rpb_slice_attn": (_I, "pppppp" + "ii" + "p"),
     "rpb_deslice_fwd": (_I, "ppp" + "iiii" + "p"),
+    "rpb_headnorm_fwd": (_I, "pipppi" + "l" + "i" + "f" + "p"),
+    "rpb_headnorm_bwd_rows": (_L, "l"),
+    "rpb_headnorm_bwd": (_I, "pippipip" + "l" + "i" + "f" + "p"),
+    "rpb_pad_grid_fwd": (_I, "ppppppp" + "iiiiiiii" + "p"),
+    "rpb_crop_gather": (_I, "pp" + "iiiiiiii" + "p"),
 }
 
 _lib = None

@@ -339,6 +339,7 @@ static int cell_mix_k2s(int K2, bool spec) {
     if (!spec) return 0;
     if (K2 <= 16) return 8;
     if (K2 <= 32) return 16;
+    if (K2 <= 40) return 20;            // Galerkin cylinder regressor: fourier_modes_y = 20
     return -1;
 }
 
@@ -388,7 +389,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     RPB_REQUIRE(KC == 32 || KC == 64 || KC == 128, "cell_mix: KC=%d must be 32, 64 or 128", KC);
     RPB_REQUIRE(CO == 32 || CO == 64 || CO == 128, "cell_mix: CO=%d must be 32, 64 or 128", CO);
     const bool spec = z2 != nullptr;
-    if (spec) RPB_REQUIRE(GW && K2 > 0 && K2 <= 32 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments (K2=%d)", K2);
+    if (spec) RPB_REQUIRE(GW && K2 > 0 && K2 <= 40 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments (K2=%d)", K2);
     const int waves = cell_mix_waves(KC, CO, K2, Wp, spec, bnb_s != nullptr);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);
     CellMixArgs a;
@@ -412,6 +413,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     RPB_CM3(1, 32, 8) RPB_CM3(1, 32, 16) RPB_CM(1, 32, 0, 0)
     RPB_CM3(2, 64, 8) RPB_CM3(2, 64, 16) RPB_CM(2, 64, 0, 0)
     RPB_CM3(4, 128, 8) RPB_CM3(4, 128, 16) RPB_CM(4, 128, 0, 0)
+    RPB_CM3(1, 32, 20) RPB_CM3(4, 128, 20)
     // fc1 dgrad (128 hidden -> C), gather into the padded layout; STATS 2 = BN-backward sums of the last layer
     RPB_CM(1, 128, 0, 0) RPB_CM(2, 128, 0, 0) RPB_CM(1, 128, 0, 2) RPB_CM(2, 128, 0, 2) RPB_CM(4, 128, 0, 2)
 #undef RPB_CM3

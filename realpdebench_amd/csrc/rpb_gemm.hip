@@ -24,8 +24,9 @@ struct GemmArgs {
     float* out;            // [M][ldo]
     long M;
     int N, K, lda, ldo;
-    int act;               // 0 none, 1 exact GELU, 2 multiply by gelu'(aux[m][n]) (backward through a GELU)
-    const float* aux;      // act == 2: the saved pre-activation [M][ldo]
+    int act;               // 0 none, 1 exact GELU, 2 multiply by gelu'(aux[m][n]) (backward through a GELU),
+                           // 3 ReLU (Galerkin FeedForward, layers.py:980), 4 zero where aux[m][n] <= 0 (backward through a ReLU)
+    const float* aux;      // act == 2: the saved pre-activation [M][ldo]; act == 4: the saved ReLU output
     float* pre_out;        // act == 1: optional copy of the pre-activation (saved for the backward pass)
     const float* mask;     // optional [M][ldo] multiplier applied before addvec/residual (inverted-dropout mask)
     // implicit 3x3x3 convolution over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
@@ -178,6 +179,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                         v = gelu_f(v);
                     } else if (g.act == 2) {
                         v *= gelu_grad_f(g.aux[m * g.ldo + n]);
+                    } else if (g.act == 3) {
+                        v = fmaxf(v, 0.f);
+                    } else if (g.act == 4) {
+                        v = g.aux[m * g.ldo + n] > 0.f ? v : 0.f;
                     }
                     if (g.mask) v *= g.mask[m * g.ldo + n];
                     v += vadd;
@@ -205,7 +210,8 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
                            float* out, long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out,
                            const float* mask, int conv, int Hc, int Wc, int Dc, void* stream) {
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
-    RPB_REQUIRE(act != 2 || aux, "gemm_nt: act=2 needs the saved pre-activation");
+    RPB_REQUIRE((act != 2 && act != 4) || aux, "gemm_nt: act=2/4 needs the saved activation tensor");
+    RPB_REQUIRE(act >= 0 && act <= 4, "gemm_nt: unknown act=%d", act);
     RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
                 N, K, G_BK);
     RPB_REQUIRE(lda % 4 == 0 && ldo >= N, "gemm_nt: lda=%d must be a multiple of 4 and ldo=%d >= N", lda, ldo);

@@ -29,6 +29,7 @@ struct ProjArgs {
     int C, DO;
     CropMap cm;
     XForm xf;            // lazy BatchNorm of the last Fourier layer (no GELU there, fno.py:118)
+    int act;             // 0: exact GELU (fno.py:124); 1: SiLU (Galerkin SpectralRegressor, model.py:631-632)
 };
 
 // v = gelu(u), d = gelu'(u) with ONE erf evaluation
@@ -39,10 +40,17 @@ __device__ __forceinline__ void gelu_pair(float u, float& v, float& d) {
     d = cdf + u * pdf;
 }
 
+// v = silu(u) = u * sigmoid(u), d = silu'(u) = sig * (1 + u * (1 - sig))
+__device__ __forceinline__ void silu_pair(float u, float& v, float& d) {
+    const float sig = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * u));
+    v = u * sig;
+    d = sig * (1.0f + u * (1.0f - sig));
+}
+
 // DOT = compile-time bound on DO (register arrays must be statically indexed); ROWFAST = W % 32 == 0, i.e. a
 // 32-cell tile never leaves its (b,t,h) row and the crop gather is one contiguous 32*C block (keeps the generic
 // gather path, with its per-lane 64-bit addresses, out of the hot instantiation's register budget)
-template <int C, bool BWD, int DOT, bool ROWFAST>
+template <int C, bool BWD, int DOT, bool ROWFAST, bool SILU>
 __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
     extern __shared__ float lds[];
     constexpr int XS = C + 1;
@@ -182,7 +190,14 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
             for (int r = 0; r < 16; ++r) {
                 float v[NTH];
 #pragma unroll
-                for (int t = 0; t < NTH; ++t) v[t] = gelu_f(acc[t][r] + b1v[t]);
+                for (int t = 0; t < NTH; ++t) {
+                    if (SILU) {
+                        float dd;
+                        silu_pair(acc[t][r] + b1v[t], v[t], dd);
+                    } else {
+                        v[t] = gelu_f(acc[t][r] + b1v[t]);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < DOT; ++j) {
                     float s = 0.f;
@@ -229,7 +244,8 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
 #pragma unroll
                 for (int t = 0; t < NTH; ++t) {
                     float v, d;
-                    gelu_pair(acc[t][r] + b1v[t], v, d);
+                    if (SILU) silu_pair(acc[t][r] + b1v[t], v, d);
+                    else gelu_pair(acc[t][r] + b1v[t], v, d);
                     float gvs = 0.f;
 #pragma unroll
                     for (int j = 0; j < DOT; ++j) {
@@ -286,16 +302,22 @@ extern "C" long rpb_proj_slots(long ncrop, int C, int DO) {
     return grid * waves;
 }
 
+template <int C, bool BWD, int DOT, bool ROWFAST, bool SILU>
+static void proj_launch_k(ProjArgs& p, int grid, int waves, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)proj_kernel<C, BWD, DOT, ROWFAST, SILU>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((proj_kernel<C, BWD, DOT, ROWFAST, SILU>), dim3(grid), dim3(waves * 64), lds, st, p);
+}
+
 template <int C, bool BWD, int DOT>
 static void proj_launch_t(ProjArgs& p, int grid, int waves, size_t lds, hipStream_t st) {
-    if (p.cm.W % 32 == 0) {
-        (void)hipFuncSetAttribute((const void*)proj_kernel<C, BWD, DOT, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((proj_kernel<C, BWD, DOT, true>), dim3(grid), dim3(waves * 64), lds, st, p);
+    const bool rowfast = p.cm.W % 32 == 0;
+    if (p.act) {
+        if (rowfast) proj_launch_k<C, BWD, DOT, true, true>(p, grid, waves, lds, st);
+        else proj_launch_k<C, BWD, DOT, false, true>(p, grid, waves, lds, st);
     } else {
-        (void)hipFuncSetAttribute((const void*)proj_kernel<C, BWD, DOT, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((proj_kernel<C, BWD, DOT, false>), dim3(grid), dim3(waves * 64), lds, st, p);
+        if (rowfast) proj_launch_k<C, BWD, DOT, true, false>(p, grid, waves, lds, st);
+        else proj_launch_k<C, BWD, DOT, false, false>(p, grid, waves, lds, st);
     }
 }
 
@@ -315,6 +337,7 @@ static int proj_launch(bool bwd, ProjArgs& p, hipStream_t st) {
     RPB_REQUIRE(p.a && p.w1 && p.b1 && p.w2 && p.b2, "proj: null pointer");
     RPB_REQUIRE(p.C == 32 || p.C == 64 || p.C == 128, "proj: C=%d must be 32, 64 or 128", p.C);
     RPB_REQUIRE(p.DO >= 1 && p.DO <= 16, "proj: fc2 out features %d not in [1,16]", p.DO);
+    RPB_REQUIRE(p.act == 0 || p.act == 1, "proj: act=%d must be 0 (GELU) or 1 (SiLU)", p.act);
     RPB_REQUIRE(p.ncrop > 0 && p.ncrop < (1L << 31), "proj: ncrop out of range");
     const int waves = proj_waves(p.C, p.DO);
     RPB_REQUIRE(waves > 0, "proj: does not fit LDS");
@@ -329,9 +352,10 @@ static int proj_launch(bool bwd, ProjArgs& p, hipStream_t st) {
 extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
                             float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp,
                             const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta,
-                            int xf_gelu, void* stream) {
+                            int xf_gelu, int act, void* stream) {
     RPB_REQUIRE(out, "proj_fwd: null out");
     ProjArgs p{};
+    p.act = act;
     p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -341,9 +365,10 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
 extern "C" int rpb_proj_bwd(const float* a, const float* w1, const float* b1, const float* w2, const float* b2,
                             const float* gout, float* gu, float* part, long ncrop, int C, int DO, int T, int H, int W,
                             int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma,
-                            const float* xf_beta, int xf_gelu, void* stream) {
+                            const float* xf_beta, int xf_gelu, int act, void* stream) {
     RPB_REQUIRE(gout && gu && part, "proj_bwd: null pointer");
     ProjArgs p{};
+    p.act = act;
     p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.gu = gu; p.part = part;
     p.ncrop = ncrop; p.C = C; p.DO = DO;

@@ -62,9 +62,7 @@ class _Workspace:
                               else ops.cell_wgrad_slots(d.ncell, C, C))
             self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
             self.wg_part = torch.empty(max(self.wg_rows_c * (C * C + C), self.wg_rows_p * (HID * C + HID)), **f)
-            self.lift_rows = ops._lib.query("rpb_lift_bwd_rows")
-            F = model.dim_in + 3
-            self.lift_part = torch.empty(self.lift_rows * (C * F + C), **f)
+            model._alloc_lift_ws(self, f)
             self.tmp_b = torch.empty(HID, **f)
             self.gout = torch.empty(d.ncrop, model.dim_out, **f)
             self.mse_part = torch.empty(ops.mse_rows(), **f)
@@ -301,7 +299,7 @@ class FNO3d(Model):
         d, C, L = ws.d, self.width, self.n_layers
         grids, plan = self._consts(x.device)
         P = self.pview
-        ops.lift_pad_fwd(x, grids, P("fc0.weight"), P("fc0.bias"), ws.A0, d)
+        self._lift_fwd(x, ws)
         world = self.dp.world_size if (self.dp is not None and training) else 1
         a_in, xf = ws.A0, None                   # layer input tensor and its lazy transform
         for l in range(L):
@@ -323,7 +321,7 @@ class FNO3d(Model):
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
             a_in, xf = s, self._layer_xf(ws, l, training)          # fno.py:117-119, applied by the next consumer
         ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
-                     xf=xf)
+                     xf=xf, act=self.proj_act)
         return ws.out
 
     def _backward_impl(self, x, gout, ws, gflat):
@@ -336,7 +334,7 @@ class FNO3d(Model):
         # ---- projection
         a_last, xf_last = ws.S[L - 1], self._layer_xf(ws, L - 1, True)
         ops.proj_bwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
-                     ws.proj_part, d, DO, xf=xf_last)
+                     ws.proj_part, d, DO, xf=xf_last, act=self.proj_act)
         row = DO * HID + HID + DO
         part = ws.proj_part.view(ws.proj_rows, row)
         # partial row layout: [d fc2.weight | d fc1.bias | d fc2.bias]; the three segments are reduced separately
@@ -394,12 +392,28 @@ class FNO3d(Model):
                 ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW,
                              d.Wp, transpose_w=True)
             g, g2 = g2, g
-        # ---- lift
-        ops.lift_bwd(g, x, grids, ws.lift_part, d)
-        F = self.dim_in + 3
+        self._lift_bwd(g, x, ws, gflat)
+
+    # ------------------------------------------------------------------ lift stage (overridden by the Galerkin regressor)
+    proj_act = 0           # activation between fc1 and fc2: 0 exact GELU (fno.py:124)
+
+    def _alloc_lift_ws(self, ws, f):
+        ws.lift_rows = ops._lib.query("rpb_lift_bwd_rows")
+        ws.lift_part = torch.empty(ws.lift_rows * (self.width * (self.dim_in + 3) + self.width), **f)
+
+    def _lift_fwd(self, x, ws):
+        """fno.py:106-111: ws.A0 = pad(fc0(cat(x, grid))), channels-last."""
+        grids, _ = self._consts(x.device)
+        ops.lift_pad_fwd(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)
+
+    def _lift_bwd(self, g, x, ws, gflat):
+        """g = dLoss/d(ws.A0) -> d fc0.weight, d fc0.bias."""
+        grids, _ = self._consts(x.device)
+        C, F = self.width, self.dim_in + 3
+        ops.lift_bwd(g, x, grids, ws.lift_part, ws.d)
         partl = ws.lift_part.view(ws.lift_rows, C * F + C)
-        self._reduce_cols(partl, 0, C * F, GP("fc0.weight"))
-        self._reduce_cols(partl, C * F, C, GP("fc0.bias"))
+        self._reduce_cols(partl, 0, C * F, self.pview("fc0.weight", gflat))
+        self._reduce_cols(partl, C * F, C, self.pview("fc0.bias", gflat))
 
     @staticmethod
     def _reduce_cols(part2d, col0, ncols, out):

@@ -1,0 +1,449 @@
+"""Galerkin Transformer (3-D) on MI355X -- drop-in for ``realpdebench.model.galerkin_transformer.GalerkinTransformer3d``
+(reference realpdebench/model/galerkin_transformer.py:11-206), built by ``load_model`` like
+``realpdebench/model/load_model.py:77-91`` for the model family every reference YAML selects
+(``configs/*/galerkin_transformer.yaml``): galerkin attention, one encoder layer without layer_norm, per-head
+LayerNorm on K and V, ``pos=None``, no down/up-scaler, ``ifft2`` decoder with one spectral layer and ``spacial_fc``.
+
+Pipeline (tokens channels-last ``[B*n][256]``, n = T*H*W):
+  downscaler Linear (rpb_tokens_lift) -> ONE Q|K|V GEMM (N = 768) -> per-head LayerNorm of K, V (rpb_headnorm) ->
+  per sample ``K^T V`` as a TN GEMM with fp64-reduced split partials -> 4 x (64 x 64) block-diagonal ``P / n`` ->
+  ``x + drop(Q P)`` as a token GEMM with the residual and dropout fused -> FeedForward: two token GEMMs (ReLU, dropout,
+  residual fused) -> SpectralRegressor: token GEMM + grid/bias/pad scatter, then the FNO3d kernels K2-K7 (truncated DFT
+  GEMM stages, mode contraction, 1x1 conv + BatchNorm statistics, crop + Linear + SiLU + Linear).
+The encoder's training backward mirrors it with the same kernels (dgrad = token GEMM on the transposed weight, wgrad =
+TN GEMM); there is no PyTorch fallback.
+
+``linear_attention`` applies ``F.dropout(p_attn)`` with the functional defaults p=0.5, training=True whatever the
+module mode (layers.py:730-731).  Here: training mode draws that p=0.5 mask; eval mode uses the deterministic
+expectation (no mask) unless ``eval_attn_dropout=True`` is set on the model.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .fno import FNO3d
+from .model import Model as _ModelBase
+
+_DK = 64          # head width the HIP kernels are built for (n_hidden 256 / n_head 4 in every reference YAML)
+
+
+class _Lin(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))          # nn.Linear defaults
+        bound = 1.0 / math.sqrt(fin)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Id(nn.Module):
+    """layers.py:21-40: the 'Identity' down-scaler is an nn.Linear named ``id``."""
+
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.id = _Lin(fin, fout)
+
+
+class _Attn(nn.Module):
+    def __init__(self, d_model, n_head, pos_dim, xavier_init, diagonal_weight, symmetric_init):
+        super().__init__()
+        self.linears = nn.ModuleList([_Lin(d_model, d_model) for _ in range(3)])
+        for lin in self.linears:                                       # layers.py:901-913
+            if xavier_init > 0:
+                nn.init.xavier_uniform_(lin.weight, gain=xavier_init)
+                if diagonal_weight > 0:
+                    lin.weight.data += diagonal_weight * torch.eye(d_model)
+                if symmetric_init:
+                    lin.weight.data += lin.weight.data.T.clone()
+                nn.init.constant_(lin.bias, 0)
+        self.norm_K = nn.ModuleList([_LN(d_model // n_head) for _ in range(n_head)])
+        self.norm_V = nn.ModuleList([_LN(d_model // n_head) for _ in range(n_head)])
+        if pos_dim > 0:
+            self.fc = _Lin(d_model + n_head * pos_dim, d_model)       # layers.py:825-826: allocated, unused with pos=None
+
+
+class _FF(nn.Module):
+    def __init__(self, d, hid):
+        super().__init__()
+        self.lr1, self.lr2 = _Lin(d, hid), _Lin(hid, d)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, d_model, n_head, ff, pos_dim, xavier_init, diagonal_weight, symmetric_init):
+        super().__init__()
+        self.attn = _Attn(d_model, n_head, pos_dim, xavier_init, diagonal_weight, symmetric_init)
+        self.ff = _FF(d_model, ff)
+
+
+class _RegressorCore(FNO3d):
+    """``SpectralRegressor`` (galerkin_transformer_libs/model.py:521-638) with one spectral layer IS one FNO3d block of
+    width ``freq_dim`` between a Linear(n_hidden+3 -> freq_dim) and a Linear-SiLU-Linear head, so it reuses FNO3d's
+    arena, workspace and forward / backward pipelines; only the lift differs: its input is the 256-wide token tensor,
+    hence a token GEMM plus the grid / bias / zero-pad scatter instead of the small-C_in lift kernel."""
+    proj_act = 1           # SiLU, model.py:631-632
+
+    def _wsplit(self):
+        Ch = self.dim_in
+        w = self.pview("fc0.weight")
+        return w[:, :Ch].contiguous(), w[:, Ch:].contiguous()
+
+    def _alloc_lift_ws(self, ws, f):
+        d, C = ws.d, self.width
+        ws.gU = torch.empty(d.ncrop, C, **f)
+        ws.gx = torch.empty(d.ncrop, self.dim_in, **f)
+        ws.lift_rows = ops._lib.query("rpb_lift_bwd_rows")
+        ws.lift_part = torch.empty(ws.lift_rows * (C * 3 + C), **f)
+        ws.d0 = ops.Dims(d.B, d.T, d.H, d.W, 0, C, self.padding)
+
+    def _lift_fwd(self, x, ws):
+        """model.py:612-618: ws.A0 = pad(fc(cat(x, grid))).  x: tokens [B*n][n_hidden]."""
+        grids, _ = self._consts(x.device)
+        d, C, Ch = ws.d, self.width, self.dim_in
+        if not hasattr(ws, "U"):
+            ws.U = torch.empty(d.ncrop, C, device=x.device, dtype=torch.float32)
+        Wx, Wg = self._wsplit()
+        ops.gemm_nt(x, Wx, ws.U, d.ncrop, C, Ch)
+        ops.pad_grid_fwd(ws.U, grids, Wg, self.pview("fc0.bias"), ws.A0, d)
+
+    def _lift_bwd(self, g, x, ws, gflat):
+        """g = dLoss/d(ws.A0): gradients of fc and, in ws.gx, of the encoder output tokens."""
+        grids, _ = self._consts(x.device)
+        d, C, Ch = ws.d, self.width, self.dim_in
+        Wx, _ = self._wsplit()
+        ops.crop_gather(g, ws.gU, d)
+        ops.lift_bwd(g, ws.gU, grids, ws.lift_part, ws.d0)            # C_in = 0: only the grid columns and the bias
+        partl = ws.lift_part.view(ws.lift_rows, C * 3 + C)
+        gw = self.pview("fc0.weight", gflat)
+        dWg = torch.empty(C, 3, device=g.device, dtype=torch.float32)
+        self._reduce_cols(partl, 0, C * 3, dWg)
+        self._reduce_cols(partl, C * 3, C, self.pview("fc0.bias", gflat))
+        dWx, _ = _wgrad(ws.gU, x, d.ncrop, C, Ch)
+        gw[:, :Ch].copy_(dWx)
+        gw[:, Ch:].copy_(dWg)
+        ops.gemm_nt(ws.gU, Wx.t().contiguous(), ws.gx, d.ncrop, Ch, C)
+
+
+def _wgrad(G, A, M, N, K, ldg=None, lda=None):
+    """(dW [N,K], db [N]) = (G^T A, colsum G): TN GEMM with split-token partials + fp64 reduction."""
+    base = G.t if isinstance(G, ops.Sub) else G
+    splits = ops.gemm_tn_splits(M, N, K)
+    part = torch.empty(splits, N * K + N, device=base.device, dtype=torch.float32)
+    ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
+    dW = torch.empty(N, K, device=base.device, dtype=torch.float32)
+    db = torch.empty(N, device=base.device, dtype=torch.float32)
+    ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
+    ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
+    return dW, db
+
+
+_REG_RENAME = (("regressor.fc0.", "regressor.fc."), ("regressor.spectral_convs.", "regressor.spectral_conv."),
+               ("regressor.fc1.", "regressor.regressor1."), ("regressor.fc2.", "regressor.regressor2."))
+
+
+class GalerkinTransformer3d(_ModelBase):
+    def __init__(self, **kwargs):
+        super().__init__()
+        cfg = dict(kwargs)
+        g = cfg.get
+        self.n_hidden, self.n_head = int(g("n_hidden", 256)), int(g("n_head", 4))
+        unsupported = []
+        if g("attention_type", "galerkin") != "galerkin":
+            unsupported.append(f"attention_type={g('attention_type')!r}")
+        if int(g("num_encoder_layers", 1)) != 1 or g("decoder_type", "ifft2") != "ifft2":
+            unsupported.append("num_encoder_layers != 1 or decoder_type != 'ifft2'")
+        if int(g("num_regressor_layers", 1)) != 1 or not g("spacial_fc", True) or int(g("spacial_dim", 3)) != 3:
+            unsupported.append("num_regressor_layers != 1 / spacial_fc False / spacial_dim != 3")
+        if g("layer_norm", False) or not g("attn_norm", True) or g("batch_norm", False) or g("return_attn_weight", False):
+            unsupported.append("layer_norm / attn_norm / batch_norm / return_attn_weight differ from the reference YAMLs")
+        if g("downscaler_size") or g("upscaler_size") or g("return_latent", False):
+            unsupported.append("down/up-scaler or return_latent")
+        if g("regressor_activation", "silu") not in (None, "silu"):
+            unsupported.append(f"regressor_activation={g('regressor_activation')!r}")
+        if self.n_hidden != 4 * _DK or self.n_head != 4:
+            unsupported.append(f"n_hidden={self.n_hidden}, n_head={self.n_head} (kernels: 4 heads x 64)")
+        if unsupported:
+            raise NotImplementedError("MI355X GalerkinTransformer3d covers the configuration family of the reference's "
+                                      "configs/*/galerkin_transformer.yaml; unsupported: " + "; ".join(unsupported))
+        self.shape_in = tuple(int(v) for v in cfg["shape_in"])
+        self.shape_out = tuple(int(v) for v in cfg["shape_out"])
+        self.node_feats, self.n_targets = int(cfg["node_feats"]), int(cfg["n_targets"])
+        self.dim_ff = int(g("dim_feedforward") or 2 * self.n_hidden)
+        if self.dim_ff % 32 or self.node_feats > 8:
+            raise NotImplementedError("dim_feedforward must be a multiple of 32 and node_feats <= 8")
+        self.norm_eps = float(g("norm_eps") or 1e-5)
+        drop = g("encoder_dropout")
+        self.p_enc = 0.05 if drop is None else float(drop)             # model.py:47, default(dropout, 0.05)
+        fd = g("ffn_dropout")
+        self.p_ffn = self.p_enc if fd is None else float(fd)
+        self.eval_attn_dropout = False
+        C = self.n_hidden
+        self.downscaler = _Id(self.node_feats, C)
+        self.encoder_layers = nn.ModuleList([_Encoder(C, self.n_head, self.dim_ff, int(g("pos_dim", 1)),
+                                                      float(g("xavier_init", 1e-2)), float(g("diagonal_weight", 1e-2)),
+                                                      bool(g("symmetric_init", False)))])
+        freq = int(g("freq_dim", 128))
+        T, H, W = self.shape_in[:3]
+        self.regressor = _RegressorCore(int(g("fourier_modes_t", 4)), int(g("fourier_modes_x", 4)),
+                                        int(g("fourier_modes_y", 4)), 1, freq, (T, H, W, C), self.shape_out)
+        self._mask_override = None      # tests: dict(attn=[B,4,64,64], d1=[M,C], ffn=[M,ff], d2=[M,C]), already scaled
+        self.__name__ = "GalerkinTransformer3D"
+
+    # ------------------------------------------------------------------ reference-compatible state dict
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = OrderedDict() if destination is None else destination
+        for name, p in self.named_parameters():
+            if not name.startswith("regressor."):
+                sd[prefix + name] = p if keep_vars else p.detach().clone()
+        for k, v in self.regressor.state_dict(prefix="regressor.").items():
+            for a, b in _REG_RENAME:
+                if k.startswith(a):
+                    k = b + k[len(a):]
+                    break
+            sd[prefix + k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        own = {n: p for n, p in self.named_parameters() if not n.startswith("regressor.")}
+        reg = {}
+        for k, v in state_dict.items():
+            if k.startswith("regressor."):
+                for a, b in _REG_RENAME:
+                    if k.startswith(b):
+                        k = a + k[len(b):]
+                        break
+                reg[k[len("regressor."):]] = v
+        expected = set(self.state_dict().keys())
+        missing, unexpected = sorted(expected - set(state_dict)), sorted(set(state_dict) - expected)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for GalerkinTransformer3d: missing {missing}, "
+                               f"unexpected {unexpected}")
+        with torch.no_grad():
+            for n, p in own.items():
+                if n in state_dict:
+                    src = torch.as_tensor(state_dict[n])
+                    if src.shape != p.shape:
+                        raise RuntimeError(f"size mismatch for {n}: {tuple(src.shape)} vs {tuple(p.shape)}")
+                    p.copy_(src)
+        self.regressor.load_state_dict(reg, strict=False)
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def grads_as_state_dict(self, grads):
+        """{parameter: gradient} from ``_backward_hip`` -> {reference parameter name: gradient}."""
+        out = OrderedDict()
+        for n, p in self.named_parameters():
+            if n.startswith("regressor.") or grads.get(p) is None:
+                continue
+            out[n] = grads[p]
+        for k, v in self.regressor.grads_as_state_dict(grads[self.regressor.flat]).items():
+            k = "regressor." + k
+            for a, b in _REG_RENAME:
+                if k.startswith(a):
+                    k = b + k[len(a):]
+                    break
+            out[k] = v
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def _masks(self, B, M, f):
+        """Inverted-dropout multipliers of this step (None = no dropout on that site)."""
+        if self._mask_override is not None:
+            return dict(self._mask_override)
+        mk = {}
+        bern = lambda shape, p: (torch.rand(*shape, **f) >= p).float() / (1.0 - p)
+        if self.training or self.eval_attn_dropout:
+            mk["attn"] = bern((B, self.n_head, _DK, _DK), 0.5)                  # layers.py:730-731 (functional defaults)
+        if self.training:
+            if self.p_enc > 0:
+                mk["d1"], mk["d2"] = bern((M, self.n_hidden), self.p_enc), bern((M, self.n_hidden), self.p_enc)
+            if self.p_ffn > 0:
+                mk["ffn"] = bern((M, self.dim_ff), self.p_ffn)
+        return mk
+
+    def _blockdiag(self, S, mask, n):
+        """[B,256,256] full K^T V (or its gradient) -> the 4 per-head 64x64 diagonal blocks / n (x dropout mask), zero
+        elsewhere.  256x256 numbers per sample: plumbing-scale torch glue."""
+        B, h = S.shape[0], self.n_head
+        blk = torch.diagonal(S.view(B, h, _DK, h, _DK), dim1=1, dim2=3).permute(0, 3, 1, 2) / n       # B h dk dk
+        if mask is not None:
+            blk = blk * mask
+        P = torch.zeros(B, h, _DK, h, _DK, device=S.device, dtype=torch.float32)
+        for i in range(h):
+            P[:, i, :, i, :] = blk[:, i]
+        return P.view(B, h * _DK, h * _DK)
+
+    @torch.no_grad()
+    def _forward_hip(self, x, save=None):
+        B = x.shape[0]
+        C, Cin, Fh = self.n_hidden, self.node_feats, self.dim_ff
+        n = x[0].numel() // Cin
+        M = B * n
+        f = dict(device=x.device, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f)
+        enc, at = self.encoder_layers[0], self.encoder_layers[0].attn
+        mk = self._masks(B, M, f)
+        x2 = x.reshape(M, Cin)
+        X0 = new(M, C)
+        ops.tokens_lift(x2, self.downscaler.id.weight.data, self.downscaler.id.bias.data, X0, M, Cin, C, False)
+        # ---- attention (layers.py:829-899): fused Q|K|V projection, per-head LayerNorm of K and V
+        Wqkv = torch.cat([l.weight.data for l in at.linears], 0)
+        bqkv = torch.cat([l.bias.data for l in at.linears], 0)
+        QKV = new(M, 3 * C)
+        ops.gemm_nt(X0, Wqkv, QKV, M, 3 * C, C, bias=bqkv)
+        gK, bK = torch.cat([m.weight.data for m in at.norm_K]), torch.cat([m.bias.data for m in at.norm_K])
+        gV, bV = torch.cat([m.weight.data for m in at.norm_V]), torch.cat([m.bias.data for m in at.norm_V])
+        KVn = new(M, 2 * C)
+        ops.headnorm_fwd(QKV, 3 * C, gK, bK, KVn, 2 * C, M, C, self.norm_eps, col0=C, ocol0=0)
+        ops.headnorm_fwd(QKV, 3 * C, gV, bV, KVn, 2 * C, M, C, self.norm_eps, col0=2 * C, ocol0=C)
+        # ---- scores = K^T V per sample (layers.py:723): TN GEMM over the n tokens, all head pairs (diagonal blocks kept)
+        S = new(B, C, C)
+        splits = ops.gemm_tn_splits(n, C, C)
+        part = new(splits, C * C + C)
+        for b in range(B):
+            ops.gemm_tn(ops.Sub(KVn, b * n * 2 * C), ops.Sub(KVn, b * n * 2 * C + C), part, n, C, C, ldg=2 * C, lda=2 * C)
+            ops.reduce_partials(part, splits, C * C, out_f32=S[b].view(-1), row_stride=C * C + C)
+        P = self._blockdiag(S, mk.get("attn"), n)                               # [B, C, C], p_attn of every head
+        PT = P.transpose(1, 2).contiguous()
+        # ---- x1 = x0 + drop(Q P)  (model.py:112-116)
+        X1 = new(M, C)
+        d1 = mk.get("d1")
+        for b in range(B):
+            r = slice(b * n, (b + 1) * n)
+            ops.gemm_nt(ops.Sub(QKV, b * n * 3 * C), PT[b], X1[r], n, C, C, residual=X0[r],
+                        mask=None if d1 is None else d1[r], lda=3 * C)
+        # ---- x2 = x1 + drop(lr2(drop(relu(lr1(x1)))))  (layers.py:979-987, model.py:120-121)
+        Hh = new(M, Fh)
+        ops.gemm_nt(X1, enc.ff.lr1.weight.data, Hh, M, Fh, C, bias=enc.ff.lr1.bias.data, act=3, mask=mk.get("ffn"))
+        X2 = new(M, C)
+        ops.gemm_nt(Hh, enc.ff.lr2.weight.data, X2, M, C, Fh, bias=enc.ff.lr2.bias.data, residual=X1, mask=mk.get("d2"))
+        # ---- spectral regressor (model.py:600-638)
+        reg = self.regressor
+        training = save is not None
+        ws = reg._workspace(B, training, x.device)
+        out = reg._forward_impl(X2, ws, training=training)
+        if save is not None:
+            save.update(x2=x2, X0=X0, QKV=QKV, KVn=KVn, P=P, X1=X1, Hh=Hh, X2=X2, mk=mk, ws=ws, B=B, n=n, M=M,
+                        Wqkv=Wqkv, gK=gK, gV=gV)
+        return reg._shape_output(out.clone(), B)
+
+    # ------------------------------------------------------------------ backward
+    @torch.no_grad()
+    def _backward_hip(self, sv, g_out):
+        """Gradients of every parameter given dLoss/d(out): autograd of galerkin_transformer.py:20-63."""
+        C, Fh, Cin = self.n_hidden, self.dim_ff, self.node_feats
+        B, n, M, mk = sv["B"], sv["n"], sv["M"], sv["mk"]
+        f = dict(device=g_out.device, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f)
+        T_ = lambda w: w.data.t().contiguous()
+        enc, at, reg, ws = self.encoder_layers[0], self.encoder_layers[0].attn, self.regressor, sv["ws"]
+        grads = {}
+        gflat = torch.zeros_like(reg.flat)
+        reg._backward_impl(sv["X2"], reg._unshape_grad(g_out, B), ws, gflat)
+        grads[reg.flat] = gflat
+        g = ws.gx                                                     # dLoss/dX2
+        # ---- FeedForward
+        g2 = g
+        if mk.get("d2") is not None:
+            g2 = new(M, C)
+            ops.mul(g, mk["d2"], g2, M * C)
+        grads[enc.ff.lr2.weight], grads[enc.ff.lr2.bias] = _wgrad(g2, sv["Hh"], M, C, Fh)
+        gH = new(M, Fh)
+        ops.gemm_nt(g2, T_(enc.ff.lr2.weight), gH, M, Fh, C, act=4, aux=sv["Hh"], mask=mk.get("ffn"))
+        grads[enc.ff.lr1.weight], grads[enc.ff.lr1.bias] = _wgrad(gH, sv["X1"], M, Fh, C)
+        gX1 = new(M, C)
+        ops.gemm_nt(gH, T_(enc.ff.lr1.weight), gX1, M, C, Fh, residual=g)
+        del gH
+        # ---- attention output: x1 = x0 + d1 * (Q P)
+        ga = gX1
+        if mk.get("d1") is not None:
+            ga = new(M, C)
+            ops.mul(gX1, mk["d1"], ga, M * C)
+        QKV, KVn, P = sv["QKV"], sv["KVn"], sv["P"]
+        dPf = new(B, C, C)
+        splits = ops.gemm_tn_splits(n, C, C)
+        part = new(splits, C * C + C)
+        for b in range(B):                                            # dP[i][j] = sum_m Q[m][i] ga[m][j]
+            ops.gemm_tn(ops.Sub(QKV, b * n * 3 * C), ga[b * n:(b + 1) * n], part, n, C, C, ldg=3 * C, lda=C)
+            ops.reduce_partials(part, splits, C * C, out_f32=dPf[b].view(-1), row_stride=C * C + C)
+        dS = self._blockdiag(dPf, mk.get("attn"), n)                  # gradient w.r.t. K^T V (masked, / n)
+        dST = dS.transpose(1, 2).contiguous()
+        gQKV, gKVn = new(M, 3 * C), new(M, 2 * C)
+        for b in range(B):
+            r = slice(b * n, (b + 1) * n)
+            ops.gemm_nt(ga[r], P[b], ops.Sub(gQKV, b * n * 3 * C), n, C, C, ldo=3 * C)                      # dQ = ga P^T
+            ops.gemm_nt(ops.Sub(KVn, b * n * 2 * C + C), dS[b], ops.Sub(gKVn, b * n * 2 * C), n, C, C,
+                        lda=2 * C, ldo=2 * C)                                                                # dKn = Vn dS^T
+            ops.gemm_nt(ops.Sub(KVn, b * n * 2 * C), dST[b], ops.Sub(gKVn, b * n * 2 * C + C), n, C, C,
+                        lda=2 * C, ldo=2 * C)                                                                # dVn = Kn dS
+        rows = ops.headnorm_bwd_rows(M)
+        hp = new(rows, 2 * C)
+        for which, norms, gam in ((0, at.norm_K, sv["gK"]), (1, at.norm_V, sv["gV"])):
+            ops.headnorm_bwd(QKV, 3 * C, gam, gKVn, 2 * C, gQKV, 3 * C, hp, M, C, self.norm_eps,
+                             col0=(1 + which) * C, gcol0=which * C, xcol0=(1 + which) * C)
+            dgb = new(2 * C)
+            ops.reduce_partials(hp, rows, 2 * C, out_f32=dgb)
+            for h, m in enumerate(norms):
+                grads[m.weight] = dgb[h * _DK:(h + 1) * _DK].clone()
+                grads[m.bias] = dgb[C + h * _DK:C + (h + 1) * _DK].clone()
+        del gKVn
+        dW, db = _wgrad(gQKV, sv["X0"], M, 3 * C, C)
+        for i, lin in enumerate(at.linears):
+            grads[lin.weight], grads[lin.bias] = dW[i * C:(i + 1) * C].clone(), db[i * C:(i + 1) * C].clone()
+        gX0 = new(M, C)
+        ops.gemm_nt(gQKV, sv["Wqkv"].t().contiguous(), gX0, M, C, 3 * C, residual=gX1)
+        del gQKV
+        # ---- down-scaler Linear(node_feats -> n_hidden)
+        xpad = torch.zeros(M, (Cin + 3) // 4 * 4, **f)
+        xpad[:, :Cin] = sv["x2"]
+        dW, db = _wgrad(gX0, xpad, M, C, Cin, lda=xpad.shape[1])
+        grads[self.downscaler.id.weight], grads[self.downscaler.id.bias] = dW, db
+        return grads
+
+    # ------------------------------------------------------------------ Model protocol
+    def forward(self, node, pos=None, grid=None, weight=None, boundary_value=None):
+        if pos is not None or grid is not None or weight is not None:
+            raise NotImplementedError("pos / grid / weight inputs are never used by the reference's train/eval loops")
+        if not node.is_cuda:
+            raise RuntimeError("realpdebench_amd.GalerkinTransformer3d runs on MI355X only: there is no CPU fallback")
+        if tuple(node.shape[1:]) != self.shape_in:
+            raise ValueError(f"expected input [B,{','.join(map(str, self.shape_in))}], got {tuple(node.shape)}")
+        x = node.contiguous().float()
+        params = list(self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if not self.training:
+                raise NotImplementedError("gradients through eval-mode BatchNorm are not implemented; wrap evaluation in "
+                                          "torch.no_grad() as the reference does (train.py:345-361)")
+            return _GalerkinFunction.apply(x, self, *params)
+        return self._forward_hip(x, save={} if self.training else None)
+
+    def train_loss(self, input, target):
+        """galerkin_transformer.py:65-67: elementwise mse_loss(pred, target) (callers take .mean())."""
+        pred = self.forward(input)
+        return (pred - target) ** 2
+
+
+class _GalerkinFunction(torch.autograd.Function):
+    """Autograd glue: one forward / backward call into the HIP pipelines above."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        sv = {}
+        out = model._forward_hip(x, save=sv)
+        ctx.model, ctx.sv, ctx.params = model, sv, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        grads = ctx.model._backward_hip(ctx.sv, g_out.contiguous().float())
+        ctx.sv = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -29,6 +29,15 @@ def load_model(train_dataset, device="cpu", **kwargs):
             fun_dim=kwargs["fun_dim"], out_dim=kwargs["out_dim"], ref=kwargs["ref"], dropout=kwargs["dropout"],
             act=kwargs["act"], mlp_ratio=kwargs["mlp_ratio"], slice_num=kwargs["slice_num"],
         ).to(device)
+    elif model_name == "galerkin_transformer":
+        from .galerkin_transformer import GalerkinTransformer3d
+        kwargs["node_feats"] = input_shape[-1]                # load_model.py:77-91
+        kwargs["n_targets"] = output_shape[-1]
+        kwargs["shape_in"] = input_shape
+        kwargs["shape_out"] = output_shape
+        kwargs.pop("config", None)
+        model = GalerkinTransformer3d(**kwargs).to(device)
     else:
-        raise ValueError(f"Model {model_name} not supported by the MI355X backend (supported: fno, transolver)")
+        raise ValueError(f"Model {model_name} not supported by the MI355X backend "
+                         "(supported: fno, transolver, galerkin_transformer)")
     return model

@@ -14,9 +14,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Sub:
+    """A row-major sub-block of a contiguous tensor: base tensor + element offset (the leading dimension travels in the
+    call's ``ld*`` argument).  Lets the token GEMMs read / write column ranges of e.g. the fused Q|K|V tensor in place."""
+
+    def __init__(self, t, offset):
+        self.t, self.offset = t, int(offset)
+
+
 def _p(t, dtype=F32):
     if t is None:
         return None
+    if isinstance(t, Sub):
+        return _p(t.t, dtype) + 4 * t.offset
     if not t.is_cuda:
         raise _lib.RpbError("realpdebench_amd ops need tensors on a HIP device (no CPU fallback exists)")
     if t.dtype != dtype or not t.is_contiguous():
@@ -170,15 +180,16 @@ def proj_slots(ncrop, C, DO):
     return _lib.query("rpb_proj_slots", ncrop, C, DO)
 
 
-def proj_fwd(a, w1, b1, w2, b2, out, d, DO, xf=None):
+def proj_fwd(a, w1, b1, w2, b2, out, d, DO, xf=None, act=0):
+    """act: 0 exact GELU (FNO head), 1 SiLU (Galerkin SpectralRegressor head)."""
     _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, *_xf(xf),
-              _stream(),
+              int(act), _stream(),
               label="proj_fwd", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
 
 
-def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO, xf=None):
+def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO, xf=None, act=0):
     _lib.call("rpb_proj_bwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(gout), _p(gu), _p(part), d.ncrop, d.C, DO,
-              *d.crop6, *_xf(xf), _stream(), label="proj_bwd", nbytes=4 * d.ncrop * (d.C + DO + 128),
+              *d.crop6, *_xf(xf), int(act), _stream(), label="proj_bwd", nbytes=4 * d.ncrop * (d.C + DO + 128),
               flops=2 * d.ncrop * 128 * (d.C + 2 * DO))
 
 
@@ -285,3 +296,29 @@ def slice_attn(tokS, norm, Wq, Wk, Wv, out, BH, G):
 def deslice_fwd(w, tok2, out, B, ntok, heads, G):
     _lib.call("rpb_deslice_fwd", _p(w), _p(tok2), _p(out), B, ntok, heads, G, _stream(), label="deslice_fwd",
               nbytes=4 * B * ntok * heads * (G + 32), flops=2 * B * ntok * heads * G * 32)
+
+
+# ----------------------------------------------------------------------------- Galerkin Transformer kernels
+def headnorm_fwd(x, ldx, gamma, beta, out, ldo, M, C, eps, col0=0, ocol0=0):
+    """Per-head LayerNorm(64) of columns [col0, col0+C) of the row-major token tensor ``x`` (leading dim ``ldx``)."""
+    _lib.call("rpb_headnorm_fwd", _p(x) + 4 * col0, ldx, _p(gamma), _p(beta), _p(out) + 4 * ocol0, ldo, M, C, eps,
+              _stream(), label="headnorm_fwd", nbytes=8 * M * C, flops=10 * M * C)
+
+
+def headnorm_bwd_rows(M):
+    return _lib.query("rpb_headnorm_bwd_rows", M)
+
+
+def headnorm_bwd(x, ldx, gamma, gy, ldg, gx, ldgx, part, M, C, eps, col0=0, gcol0=0, xcol0=0):
+    _lib.call("rpb_headnorm_bwd", _p(x) + 4 * col0, ldx, _p(gamma), _p(gy) + 4 * gcol0, ldg, _p(gx) + 4 * xcol0, ldgx,
+              _p(part), M, C, eps, _stream(), label="headnorm_bwd", nbytes=12 * M * C, flops=20 * M * C)
+
+
+def pad_grid_fwd(U, grids, Wg, bias, out, d):
+    _lib.call("rpb_pad_grid_fwd", _p(U), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(Wg), _p(bias), _p(out), d.B, d.T,
+              d.H, d.W, d.C, d.Tp, d.Hp, d.Wp, _stream(), label="pad_grid_fwd", nbytes=4 * d.C * (d.ncrop + d.ncell))
+
+
+def crop_gather(g, out, d):
+    _lib.call("rpb_crop_gather", _p(g), _p(out), d.B, d.T, d.H, d.W, d.C, d.Tp, d.Hp, d.Wp, _stream(),
+              label="crop_gather", nbytes=8 * d.C * d.ncrop)

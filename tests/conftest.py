@@ -57,3 +57,26 @@ class Golden:
 @pytest.fixture(params=GOLDEN_CASES)
 def golden(request):
     return Golden(request.param)
+
+
+def galerkin_golden():
+    """tests/golden/galerkin_small.npz (made by tests/golden/make_golden_galerkin.py) as torch tensors."""
+    z = np.load(os.path.join(GOLDEN_DIR, "galerkin_small.npz"))
+
+    def group(pre):
+        out = {}
+        for k in z.files:
+            if k.startswith(pre):
+                v = torch.from_numpy(np.array(z[k]))
+                if "spectral_conv" in k:
+                    v = torch.view_as_complex(v.contiguous())
+                out[k[len(pre):]] = v
+        return out
+
+    g = {"sd": group("sd/"), "grad": group("grad/"), "buf1": group("buf1/")}
+    for k in ("x", "target", "y_eval", "loss"):
+        g[k] = torch.from_numpy(np.array(z[k]))
+    g["heads"] = int(z["cfg/heads"])
+    g["modes"] = tuple(int(v) for v in z["cfg/modes"])
+    g["shape_out"] = tuple(int(v) for v in z["cfg/shape_out"])
+    return g

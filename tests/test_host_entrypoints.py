@@ -51,3 +51,32 @@ def test_lr_schedules_match_torch():
         Trainer(m, lr=1e-2, num_update=10, scheduler="linear")
     with pytest.raises(NotImplementedError):
         Trainer(m, lr=1e-2, num_update=10, clip_grad_norm=1.0)
+
+
+def test_galerkin_state_dict_contract_cpu():
+    """Reference checkpoint names / shapes / dtypes without a GPU: build on CPU, load the golden
+    state dict, read it back; a CPU forward must refuse loudly (no fallback)."""
+    import pytest
+    from conftest import galerkin_golden, rel_l2
+    from realpdebench_amd.model.load_model import load_model
+    g = galerkin_golden()
+    T, H, W, Cin = g["x"].shape[1:]
+
+    class DS:
+        def __getitem__(self, i):
+            return torch.zeros(T, H, W, Cin), torch.zeros(*g["shape_out"])
+
+    m = load_model(DS(), device="cpu", model_name="galerkin_transformer", n_hidden=256, n_head=4, dim_feedforward=256,
+                   freq_dim=32, fourier_modes_t=2, fourier_modes_x=3, fourier_modes_y=4, norm_eps=1e-7, pos_dim=1,
+                   attention_type="galerkin", num_encoder_layers=1, decoder_type="ifft2", num_regressor_layers=1,
+                   spacial_fc=True, spacial_dim=3, layer_norm=False, attn_norm=True, regressor_activation="silu")
+    assert set(m.state_dict()) == set(g["sd"])
+    m.load_state_dict(g["sd"])
+    sd = m.state_dict()
+    for k, v in g["sd"].items():
+        assert sd[k].shape == v.shape and sd[k].dtype == v.dtype, k
+        assert float(v.abs().max()) == 0 or rel_l2(sd[k], v) < 1e-7, k
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(g["x"])
+    with pytest.raises(NotImplementedError):
+        load_model(DS(), device="cpu", model_name="galerkin_transformer", attention_type="fourier")

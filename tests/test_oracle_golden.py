@@ -82,3 +82,24 @@ def test_transolver_oracle_forward_matches_reference():
     out = TO.transolver_forward(sd, x, cfg["n_layers"], cfg["n_head"], cfg["H"], cfg["W"], cfg["D"])
     assert out.shape == y.shape
     assert rel_l2(out, y) < TOL
+
+
+def test_galerkin_oracle_matches_reference():
+    """Eval forward, training-mode loss, every parameter gradient and the BatchNorm buffer update of the oracle against
+    vectors taken from the imported reference (tests/golden/make_golden_galerkin.py)."""
+    from conftest import galerkin_golden
+    from oracle import galerkin_oracle as GO
+    g = galerkin_golden()
+    out, _ = GO.galerkin_forward(g["sd"], g["x"], g["heads"], g["modes"], g["shape_out"])
+    assert out.shape == g["y_eval"].shape
+    assert rel_l2(out, g["y_eval"]) < TOL
+    loss, _, grads, buf = GO.loss_and_grads(g["sd"], g["x"], g["target"], g["heads"], g["modes"], g["shape_out"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert set(grads) == set(g["grad"])
+    for k, ref in g["grad"].items():
+        if k == "regressor.convs.0.bias":         # exactly cancelled by the BatchNorm that follows: rounding noise only
+            assert float(grads[k].abs().max()) < 1e-6
+            continue
+        assert rel_l2(grads[k], ref) < 2e-4, k
+    for k, ref in g["buf1"].items():
+        assert rel_l2(buf[k], ref) < TOL, k
