@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
     ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
+    ap.add_argument("--no-galerkin", action="store_true", help="skip the secondary Galerkin Transformer measurement")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -79,6 +80,59 @@ def cpu_baseline():
     except Exception as e:        # timeout / parse error: report it, never hang the bench
         return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
                 "sample": f"CPU oracle step did not finish within 300 s ({type(e).__name__})"}
+
+
+def bench_galerkin(dev, steps=3):
+    """Galerkin Transformer at the reference's configs/cylinder/galerkin_transformer.yaml (n = 20*64*128 tokens, hidden
+    256, freq_dim 128, modes (4,16,20), train_batch_size 16): train step through the drop-in protocol (HIP
+    forward/backward, dropout masks drawn, torch.optim.Adam) and eval forward.  Dense FLOPs per token forward:
+    2*(768*256 + 2*256*256 + 128*256) Linear + 2*2*256*64 head products = 0.79 MFLOP, x3 for a step; the spectral
+    regressor and the head products are HBM-bound."""
+    import yaml
+    from realpdebench_amd.model.galerkin_transformer import GalerkinTransformer3d
+    with open(os.path.join(ROOT, "realpdebench_amd", "configs", "cylinder", "galerkin_transformer.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    T, H, W, Cin = cfg["shape_in"]
+    B = int(cfg["train_batch_size"])
+    cfg.update(node_feats=Cin, n_targets=cfg["shape_out"][-1])
+    torch.manual_seed(0)
+    m = GalerkinTransformer3d(**cfg).to(dev)
+    x = torch.randn(B, T, H, W, Cin, device=dev)
+    y = torch.randn(B, *cfg["shape_out"], device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"])
+
+    def step():
+        opt.zero_grad()
+        m.train_loss(x, y).mean().backward()
+        opt.step()
+
+    m.train()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / steps
+    m.eval()
+    with torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / steps
+    tokens = B * T * H * W
+    flops_step = 3 * 0.79e6 * tokens
+    del m, opt
+    torch.cuda.empty_cache()
+    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
+            "forward_fields_per_s": B * cfg["shape_out"][0] / t_fwd, "ms_per_forward": 1e3 * t_fwd,
+            "mfma_f32": {"achieved": flops_step / t_train / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops_step / t_train / 1e12 / MFMA_F32_PEAK_TF},
+            "config": "configs/cylinder/galerkin_transformer.yaml: [16,20,64,128,3], n_hidden 256, 4 heads, freq_dim 128, "
+                      "modes (4,16,20), dropout 0.05 / attention 0.5"}
 
 
 def bench_transolver(dev, B=4, steps=3):
@@ -225,6 +279,10 @@ def main():
     if not a.no_transolver and world == 1:
         transolver = bench_transolver(dev)
 
+    galerkin = None
+    if not a.no_galerkin and world == 1:
+        galerkin = bench_galerkin(dev)
+
     if rank == 0:
         ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
         ach_tf = dom["flops"] / dom["avg_ms"] / 1e9
@@ -257,6 +315,7 @@ def main():
                                         "frac": step_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS}},
             "rollout": rollout,
             "transolver": transolver,
+            "galerkin_transformer": galerkin,
             "loss": float(loss),
         }
         if not a.no_cpu_baseline and world == 1:

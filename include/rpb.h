@@ -205,6 +205,15 @@ int rpb_headnorm_fwd(const float* x, int ldx, const float* gamma, const float* b
 long rpb_headnorm_bwd_rows(long M);
 int rpb_headnorm_bwd(const float* x, int ldx, const float* gamma, const float* gy, int ldg, float* gx, int ldgx,
                      float* part, long M, int C, float eps, void* stream);
+/*     linear_attention (layers.py:708-734) per sample b and head h (4 heads x 64 channels):
+ *     head_scores: part[chunk][b][h][i][j] = sum_{m in chunk} G[b,m][64h+i] A[b,m][64h+j]  (K^T V; also dP = Q^T g),
+ *     chunk < rpb_head_scores_chunks(B, n); rpb_reduce_partials(rows = chunks, L = B*4*64*64) finishes the sum.
+ *     head_apply: out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual  (Q (K^T V / n), its
+ *     dropout + residual of model.py:112-116 fused; with transposed Wm the three data gradients). */
+int rpb_head_scores_chunks(int B, long n);
+int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n, void* stream);
+int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual, int ldr,
+                   const float* mask, int ldm, int B, long n, void* stream);
 /*     SpectralRegressor.forward model.py:612-618 after the 256-wide token GEMM U = x fc.weight[:, :256]^T:
  *     out[b,t,h,w,:] = U[token] + fc.weight[:, 256:259] (gt[t], gh[h], gw[w]) + fc.bias inside the mesh, 0 in the
  *     6-cell pad; Wg = that [C][3] slice, contiguous. */

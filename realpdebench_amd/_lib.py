@@ -62,6 +62,9 @@ SIGNATURES = {
     "rpb_headnorm_fwd": (_I, "pipppi" + "l" + "i" + "f" + "p"),
     "rpb_headnorm_bwd_rows": (_L, "l"),
     "rpb_headnorm_bwd": (_I, "pippipip" + "l" + "i" + "f" + "p"),
+    "rpb_head_scores_chunks": (_I, "il"),
+    "rpb_head_scores": (_I, "pipip" + "il" + "p"),
+    "rpb_head_apply": (_I, "pippipipi" + "il" + "p"),
     "rpb_pad_grid_fwd": (_I, "ppppppp" + "iiiiiiii" + "p"),
     "rpb_crop_gather": (_I, "pp" + "iiiiiiii" + "p"),
 }

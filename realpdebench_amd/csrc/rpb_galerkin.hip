@@ -182,3 +182,200 @@ extern "C" int rpb_crop_gather(const float* g, float* out, int B, int T, int H, 
                        ncrop, C, CropMap{T, H, W, Tp, Hp, Wp});
     RPB_CHECK_LAUNCH("crop_gather");
 }
+
+// ---------------------------------------------------------------------------------- per-head products of the attention
+// linear_attention (layers.py:708-734) per sample and head: scores = K^T V (64 x 64, reduced over the n tokens) and
+// out = Q (scores / n).  Both are HBM-streaming (a head's 64 x 64 matrix against 256 B of each token), so they get
+// their own kernels instead of 256-wide dense GEMMs that would multiply the off-diagonal (cross-head) zeros.
+//
+// head_scores: part[chunk][b][h][i][j] = sum_{m in chunk} G[b,m][64h+i] * A[b,m][64h+j]   (TN product; also used for
+// the backward dP = Q^T g).  Workgroup = 4 waves = the 4 heads of one token chunk (so it streams whole 1 KB rows);
+// operands go straight from HBM into MFMA layout: a lane loads the channel PAIR (2c, 2c+1) of one token with one
+// float2 (256 B per half-wave), which makes MFMA tile t hold the channels == t (mod 2).  16-token halves are
+// double-buffered in registers.  rpb_reduce_partials finishes the sum over chunks in fp64.
+struct HeadScoreArgs {
+    const float* G;
+    const float* A;
+    float* part;
+    long n;
+    int ldg, lda, B;
+};
+
+__global__ __launch_bounds__(256) void head_scores_kernel(HeadScoreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const long per = ((a.n + nchunk - 1) / nchunk + 31) / 32 * 32;
+    const long mb = (long)chunk * per;
+    long me = mb + per;
+    if (me > a.n) me = a.n;
+    const float* gp = a.G + ((long)b * a.n) * a.ldg + h * 64 + col * 2;
+    const float* xp = a.A + ((long)b * a.n) * a.lda + h * 64 + col * 2;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[o][i] = zero16();
+    f32x2 ga[8], gb[8], xa[8], xb[8];
+    auto load_half = [&](long m0, int hh, f32x2 (&gv)[8], f32x2 (&xv)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const long m = m0 + hh * 16 + 2 * s + half;
+            f32x2 gq = {0.f, 0.f}, xq = {0.f, 0.f};
+            if (m < me) {
+                gq = *reinterpret_cast<const f32x2*>(gp + m * a.ldg);
+                xq = *reinterpret_cast<const f32x2*>(xp + m * a.lda);
+            }
+            gv[s] = gq;
+            xv[s] = xq;
+        }
+    };
+    auto compute_half = [&](const f32x2 (&gv)[8], const f32x2 (&xv)[8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[o][i] = mfma32(gv[s][o], xv[s][i], acc[o][i]);
+    };
+    long m = mb;
+    if (m < me) load_half(m, 0, ga, xa);
+    for (; m < me; m += 32) {
+        load_half(m, 1, gb, xb);
+        compute_half(ga, xa);
+        if (m + 32 < me) load_half(m + 32, 0, ga, xa);
+        compute_half(gb, xb);
+    }
+    float* part = a.part + (((long)chunk * a.B + b) * 4 + h) * 4096;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(mfma_row(lane, r) * 2 + o) * 64 + col * 2 + i] = acc[o][i][r];
+}
+
+extern "C" int rpb_head_scores_chunks(int B, long n) {
+    long c = ((long)rpb_num_cus() * 6 + B - 1) / (B > 0 ? B : 1);
+    const long cap = (n + 511) / 512;               // at least 512 tokens per chunk
+    if (c > cap) c = cap;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+extern "C" int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n,
+                               void* stream) {
+    RPB_REQUIRE(G && A && part && B > 0 && n > 0, "head_scores: bad arguments");
+    RPB_REQUIRE(ldg % 2 == 0 && lda % 2 == 0 && ldg >= 256 && lda >= 256, "head_scores: bad leading dimensions %d %d", ldg, lda);
+    HeadScoreArgs a{G, A, part, n, ldg, lda, B};
+    hipLaunchKernelGGL(head_scores_kernel, dim3(rpb_head_scores_chunks(B, n), B), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("head_scores");
+}
+
+// head_apply: out[b,m][64h+j] = (sum_i X[b,m][64h+i] * Wm[b][h][i][j]) * mask + residual.
+// Workgroup = 8 waves over one sample: wave w works on head w&3 and every second 32-token tile; the sample's four
+// 64x64 matrices sit in LDS in MFMA-B order, the activation tile goes registers -> wave-private +1-padded LDS tile ->
+// transposed reads (the cell_mix scheme), with the next tile's loads in flight during the 64 MFMAs of this one.
+struct HeadApplyArgs {
+    const float* X;
+    const float* Wm;
+    float* out;
+    const float* residual;
+    const float* mask;
+    long n;
+    int ldx, ldo, ldr, ldm;
+};
+
+#define HA_WAVES 8
+#define HA_XS 65
+
+__global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs a) {
+    extern __shared__ float lds[];
+    float* Wl = lds;                                   // [4 heads][64 k][32 col][2 tiles]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wave & 3, sub = wave >> 2;
+    float* xl = lds + 4 * 4096 + wave * 32 * HA_XS;    // wave-private [32][65]
+    const int col = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    const float* wsrc = a.Wm + (long)b * 4 * 4096;
+    for (int idx = threadIdx.x; idx < 4 * 4096; idx += blockDim.x) {
+        const int hh = idx >> 12, k = (idx >> 6) & 63, j = idx & 63;          // W[hh][k][j], coalesced read
+        Wl[hh * 4096 + (k * 32 + (j & 31)) * 2 + (j >> 5)] = wsrc[idx];
+    }
+    __syncthreads();
+    const long ntiles = (a.n + 31) / 32;
+    const long per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long t0 = (long)blockIdx.x * per;
+    long t1 = t0 + per;
+    if (t1 > ntiles) t1 = ntiles;
+    const float* xb = a.X + ((long)b * a.n) * a.ldx + h * 64;
+    const int lrow = lane >> 4, lc4 = (lane & 15) * 4;
+    f32x4 xr[8];
+    auto issue_x = [&](long tile) {
+        const long m0 = tile * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long m = m0 + j * 4 + lrow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.n) v = *reinterpret_cast<const f32x4*>(xb + m * a.ldx + lc4);
+            xr[j] = v;
+        }
+    };
+    long tile = t0 + sub;
+    if (tile < t1) issue_x(tile);
+    const float* wp = Wl + h * 4096 + (half * 32 + col) * 2;
+    for (; tile < t1; tile += 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float* d = xl + (j * 4 + lrow) * HA_XS + lc4;
+            d[0] = xr[j][0];
+            d[1] = xr[j][1];
+            d[2] = xr[j][2];
+            d[3] = xr[j][3];
+        }
+        if (tile + 2 < t1) issue_x(tile + 2);
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc[2] = {zero16(), zero16()};
+        const float* ap = xl + col * HA_XS + half;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float av = ap[2 * s];
+            const f32x2 bv = *reinterpret_cast<const f32x2*>(wp + 2 * s * 64);
+            acc[0] = mfma32(av, bv[0], acc[0]);
+            acc[1] = mfma32(av, bv[1], acc[1]);
+        }
+        const long m0 = tile * 32;
+        const long rowbase = (long)b * a.n + m0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = mfma_row(lane, r);
+                if (m0 + rr < a.n) {
+                    const int ch = h * 64 + t * 32 + col;
+                    float v = acc[t][r];
+                    if (a.mask) v *= a.mask[(rowbase + rr) * a.ldm + ch];
+                    if (a.residual) v += a.residual[(rowbase + rr) * a.ldr + ch];
+                    a.out[(rowbase + rr) * a.ldo + ch] = v;
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual,
+                              int ldr, const float* mask, int ldm, int B, long n, void* stream) {
+    RPB_REQUIRE(X && Wm && out && B > 0 && n > 0, "head_apply: bad arguments");
+    RPB_REQUIRE(ldx % 4 == 0 && ldx >= 256 && ldo >= 256, "head_apply: bad leading dimensions %d %d", ldx, ldo);
+    HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm};
+    const long ntiles = (n + 31) / 32;
+    long chunks = ((long)rpb_num_cus() * 2 + B - 1) / B;
+    if (chunks > (ntiles + 1) / 2) chunks = (ntiles + 1) / 2;
+    if (chunks < 1) chunks = 1;
+    const size_t lds = (size_t)(4 * 4096 + HA_WAVES * 32 * HA_XS) * 4;
+    (void)hipFuncSetAttribute((const void*)head_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(head_apply_kernel, dim3((unsigned)chunks, B), dim3(HA_WAVES * 64), lds, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("head_apply");
+}

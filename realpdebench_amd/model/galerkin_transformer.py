@@ -6,8 +6,8 @@ LayerNorm on K and V, ``pos=None``, no down/up-scaler, ``ifft2`` decoder with on
 
 Pipeline (tokens channels-last ``[B*n][256]``, n = T*H*W):
   downscaler Linear (rpb_tokens_lift) -> ONE Q|K|V GEMM (N = 768) -> per-head LayerNorm of K, V (rpb_headnorm) ->
-  per sample ``K^T V`` as a TN GEMM with fp64-reduced split partials -> 4 x (64 x 64) block-diagonal ``P / n`` ->
-  ``x + drop(Q P)`` as a token GEMM with the residual and dropout fused -> FeedForward: two token GEMMs (ReLU, dropout,
+  per (sample, head) ``K^T V / n`` (rpb_head_scores, fp64-reduced chunk partials) -> ``x + drop(Q P)`` with the 64x64
+  head matrices in LDS and the residual / dropout fused (rpb_head_apply) -> FeedForward: two token GEMMs (ReLU, dropout,
   residual fused) -> SpectralRegressor: token GEMM + grid/bias/pad scatter, then the FNO3d kernels K2-K7 (truncated DFT
   GEMM stages, mode contraction, 1x1 conv + BatchNorm statistics, crop + Linear + SiLU + Linear).
 The encoder's training backward mirrors it with the same kernels (dgrad = token GEMM on the transposed weight, wgrad =
@@ -260,7 +260,7 @@ class GalerkinTransformer3d(_ModelBase):
         if self._mask_override is not None:
             return dict(self._mask_override)
         mk = {}
-        bern = lambda shape, p: (torch.rand(*shape, **f) >= p).float() / (1.0 - p)
+        bern = lambda shape, p: torch.empty(*shape, **f).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         if self.training or self.eval_attn_dropout:
             mk["attn"] = bern((B, self.n_head, _DK, _DK), 0.5)                  # layers.py:730-731 (functional defaults)
         if self.training:
@@ -270,17 +270,17 @@ class GalerkinTransformer3d(_ModelBase):
                 mk["ffn"] = bern((M, self.dim_ff), self.p_ffn)
         return mk
 
-    def _blockdiag(self, S, mask, n):
-        """[B,256,256] full K^T V (or its gradient) -> the 4 per-head 64x64 diagonal blocks / n (x dropout mask), zero
-        elsewhere.  256x256 numbers per sample: plumbing-scale torch glue."""
-        B, h = S.shape[0], self.n_head
-        blk = torch.diagonal(S.view(B, h, _DK, h, _DK), dim1=1, dim2=3).permute(0, 3, 1, 2) / n       # B h dk dk
+    def _head_products(self, G, ldg, A, lda, B, n, mask):
+        """[B,4,64,64] = (G_h^T A_h) / n (x the attention-dropout mask): layers.py:723-731 and its backward."""
+        chunks = ops.head_scores_chunks(B, n)
+        L = B * self.n_head * _DK * _DK
+        part = torch.empty(chunks, L, device=self.regressor.flat.device, dtype=torch.float32)
+        ops.head_scores(G, ldg, A, lda, part, B, n)
+        S = torch.empty(B, self.n_head, _DK, _DK, device=part.device, dtype=torch.float32)
+        ops.reduce_partials(part, chunks, L, out_f32=S.view(-1), scale=1.0 / n)
         if mask is not None:
-            blk = blk * mask
-        P = torch.zeros(B, h, _DK, h, _DK, device=S.device, dtype=torch.float32)
-        for i in range(h):
-            P[:, i, :, i, :] = blk[:, i]
-        return P.view(B, h * _DK, h * _DK)
+            S.mul_(mask)                       # 64x64 numbers per head: plumbing-scale torch glue
+        return S
 
     @torch.no_grad()
     def _forward_hip(self, x, save=None):
@@ -305,22 +305,10 @@ class GalerkinTransformer3d(_ModelBase):
         KVn = new(M, 2 * C)
         ops.headnorm_fwd(QKV, 3 * C, gK, bK, KVn, 2 * C, M, C, self.norm_eps, col0=C, ocol0=0)
         ops.headnorm_fwd(QKV, 3 * C, gV, bV, KVn, 2 * C, M, C, self.norm_eps, col0=2 * C, ocol0=C)
-        # ---- scores = K^T V per sample (layers.py:723): TN GEMM over the n tokens, all head pairs (diagonal blocks kept)
-        S = new(B, C, C)
-        splits = ops.gemm_tn_splits(n, C, C)
-        part = new(splits, C * C + C)
-        for b in range(B):
-            ops.gemm_tn(ops.Sub(KVn, b * n * 2 * C), ops.Sub(KVn, b * n * 2 * C + C), part, n, C, C, ldg=2 * C, lda=2 * C)
-            ops.reduce_partials(part, splits, C * C, out_f32=S[b].view(-1), row_stride=C * C + C)
-        P = self._blockdiag(S, mk.get("attn"), n)                               # [B, C, C], p_attn of every head
-        PT = P.transpose(1, 2).contiguous()
-        # ---- x1 = x0 + drop(Q P)  (model.py:112-116)
+        # ---- p_attn = drop(K^T V / n) per sample and head (layers.py:723-731), x1 = x0 + drop(Q p_attn) (model.py:112-116)
+        P = self._head_products(ops.Sub(KVn, 0), 2 * C, ops.Sub(KVn, C), 2 * C, B, n, mk.get("attn"))
         X1 = new(M, C)
-        d1 = mk.get("d1")
-        for b in range(B):
-            r = slice(b * n, (b + 1) * n)
-            ops.gemm_nt(ops.Sub(QKV, b * n * 3 * C), PT[b], X1[r], n, C, C, residual=X0[r],
-                        mask=None if d1 is None else d1[r], lda=3 * C)
+        ops.head_apply(ops.Sub(QKV, 0), 3 * C, P, X1, C, B, n, residual=X0, ldr=C, mask=mk.get("d1"), ldm=C)
         # ---- x2 = x1 + drop(lr2(drop(relu(lr1(x1)))))  (layers.py:979-987, model.py:120-121)
         Hh = new(M, Fh)
         ops.gemm_nt(X1, enc.ff.lr1.weight.data, Hh, M, Fh, C, bias=enc.ff.lr1.bias.data, act=3, mask=mk.get("ffn"))
@@ -369,22 +357,12 @@ class GalerkinTransformer3d(_ModelBase):
             ga = new(M, C)
             ops.mul(gX1, mk["d1"], ga, M * C)
         QKV, KVn, P = sv["QKV"], sv["KVn"], sv["P"]
-        dPf = new(B, C, C)
-        splits = ops.gemm_tn_splits(n, C, C)
-        part = new(splits, C * C + C)
-        for b in range(B):                                            # dP[i][j] = sum_m Q[m][i] ga[m][j]
-            ops.gemm_tn(ops.Sub(QKV, b * n * 3 * C), ga[b * n:(b + 1) * n], part, n, C, C, ldg=3 * C, lda=C)
-            ops.reduce_partials(part, splits, C * C, out_f32=dPf[b].view(-1), row_stride=C * C + C)
-        dS = self._blockdiag(dPf, mk.get("attn"), n)                  # gradient w.r.t. K^T V (masked, / n)
-        dST = dS.transpose(1, 2).contiguous()
+        dS = self._head_products(ops.Sub(QKV, 0), 3 * C, ga, C, B, n, mk.get("attn"))      # dL/d(K^T V), masked, / n
         gQKV, gKVn = new(M, 3 * C), new(M, 2 * C)
-        for b in range(B):
-            r = slice(b * n, (b + 1) * n)
-            ops.gemm_nt(ga[r], P[b], ops.Sub(gQKV, b * n * 3 * C), n, C, C, ldo=3 * C)                      # dQ = ga P^T
-            ops.gemm_nt(ops.Sub(KVn, b * n * 2 * C + C), dS[b], ops.Sub(gKVn, b * n * 2 * C), n, C, C,
-                        lda=2 * C, ldo=2 * C)                                                                # dKn = Vn dS^T
-            ops.gemm_nt(ops.Sub(KVn, b * n * 2 * C), dST[b], ops.Sub(gKVn, b * n * 2 * C + C), n, C, C,
-                        lda=2 * C, ldo=2 * C)                                                                # dVn = Kn dS
+        tr = lambda w: w.transpose(-1, -2).contiguous()
+        ops.head_apply(ga, C, tr(P), ops.Sub(gQKV, 0), 3 * C, B, n)                                  # dQ  = g P^T
+        ops.head_apply(ops.Sub(KVn, C), 2 * C, tr(dS), ops.Sub(gKVn, 0), 2 * C, B, n)               # dKn = Vn dS^T
+        ops.head_apply(ops.Sub(KVn, 0), 2 * C, dS, ops.Sub(gKVn, C), 2 * C, B, n)                   # dVn = Kn dS
         rows = ops.headnorm_bwd_rows(M)
         hp = new(rows, 2 * C)
         for which, norms, gam in ((0, at.norm_K, sv["gK"]), (1, at.norm_V, sv["gV"])):
@@ -402,11 +380,18 @@ class GalerkinTransformer3d(_ModelBase):
         gX0 = new(M, C)
         ops.gemm_nt(gQKV, sv["Wqkv"].t().contiguous(), gX0, M, C, 3 * C, residual=gX1)
         del gQKV
-        # ---- down-scaler Linear(node_feats -> n_hidden)
-        xpad = torch.zeros(M, (Cin + 3) // 4 * 4, **f)
-        xpad[:, :Cin] = sv["x2"]
-        dW, db = _wgrad(gX0, xpad, M, C, Cin, lda=xpad.shape[1])
-        grads[self.downscaler.id.weight], grads[self.downscaler.id.bias] = dW, db
+        # ---- down-scaler Linear(node_feats -> n_hidden): skinny weight gradient = the FNO lift-backward reduction on the
+        #      unpadded token layout (pad 0); its three grid columns are not parameters here and are dropped
+        T, H, W = self.shape_in[:3]
+        grids, _ = reg._consts(g_out.device)
+        d_tok = ops.Dims(B, T, H, W, Cin, C, 0)
+        rows = ops._lib.query("rpb_lift_bwd_rows")
+        lp = new(rows, C * (Cin + 3) + C)
+        ops.lift_bwd(gX0, sv["x2"], grids, lp, d_tok)
+        dWf, db = new(C, Cin + 3), new(C)
+        ops.reduce_partials(lp, rows, C * (Cin + 3), out_f32=dWf.view(-1), row_stride=lp.shape[1])
+        ops.reduce_partials(lp, rows, C, out_f32=db, row_stride=lp.shape[1], col0=C * (Cin + 3))
+        grads[self.downscaler.id.weight], grads[self.downscaler.id.bias] = dWf[:, :Cin].contiguous(), db
         return grads
 
     # ------------------------------------------------------------------ Model protocol

@@ -322,3 +322,20 @@ def pad_grid_fwd(U, grids, Wg, bias, out, d):
 def crop_gather(g, out, d):
     _lib.call("rpb_crop_gather", _p(g), _p(out), d.B, d.T, d.H, d.W, d.C, d.Tp, d.Hp, d.Wp, _stream(),
               label="crop_gather", nbytes=8 * d.C * d.ncrop)
+
+
+def head_scores_chunks(B, n):
+    return _lib.query("rpb_head_scores_chunks", B, n)
+
+
+def head_scores(G, ldg, A, lda, part, B, n):
+    """part[chunks][B][4][64][64]: per-chunk partials of G_h^T A_h for every sample and head."""
+    _lib.call("rpb_head_scores", _p(G), ldg, _p(A), lda, _p(part), B, n, _stream(), label="head_scores",
+              nbytes=4 * B * n * 512, flops=2 * B * n * 4 * 64 * 64)
+
+
+def head_apply(X, ldx, Wm, out, ldo, B, n, residual=None, ldr=0, mask=None, ldm=0):
+    """out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual."""
+    _lib.call("rpb_head_apply", _p(X), ldx, _p(Wm), _p(out), ldo, _p(residual), ldr, _p(mask), ldm, B, n, _stream(),
+              label="head_apply", nbytes=4 * B * n * 256 * (2 + (residual is not None) + (mask is not None)),
+              flops=2 * B * n * 4 * 64 * 64)

@@ -50,3 +50,24 @@ def test_transolver_train_then_eval(tmp_path):
     assert all(l == l and l < 1e3 for l in ck["train_losses"])                  # finite
     assert ck["train_losses"][-1] < ck["train_losses"][0]                       # it learns something on 8 samples
     ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
+
+
+def test_galerkin_train_then_eval(tmp_path):
+    """Same entrypoints with model_name: galerkin_transformer (reference YAML key surface, reduced mesh / freq_dim)."""
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd import train as tr
+    with open(os.path.join(os.path.dirname(tr.__file__), "configs", "cylinder", "galerkin_transformer.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg.update(exp_name="g", results_path=str(tmp_path), shape_in=[4, 6, 8, 3], shape_out=[4, 6, 8, 3], n_train=8, n_val=4,
+               freq_dim=32, fourier_modes_t=2, fourier_modes_x=3, fourier_modes_y=4, num_update=100, train_batch_size=4,
+               test_batch_size=4, lr=1e-3, N_autoregressive=2)
+    path = tmp_path / "gk.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = tr.main(["--config", str(path), "--max_updates", "6"])
+    ckpts = sorted(glob.glob(os.path.join(exp, "model_*.pth")))
+    ck = torch.load(ckpts[-1], map_location="cpu")
+    assert ck["iteration"] == 6 and "regressor.spectral_conv.0.weights1" in ck["model_state_dict"]
+    assert ck["model_state_dict"]["regressor.spectral_conv.0.weights1"].dtype == torch.complex64
+    assert all(l == l and l < 1e3 for l in ck["train_losses"])
+    ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
+    assert os.path.exists(os.path.join(exp, "eval.log"))
