@@ -32,6 +32,23 @@ def layer_buckets(seg, n_layers, total):
     return buckets
 
 
+class StatsSync:
+    """SyncBN-only hook for models whose parameter gradients are reduced by the trainer after backward (the Galerkin
+    Transformer: its spectral regressor is an FNO block with a training-mode BatchNorm3d, galerkin_transformer_libs/
+    model.py:572,622): global-batch statistics forward and backward, no gradient buckets."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def bucket_ready(self, grad):
+        pass
+
+
 class DataParallel:
     def __init__(self, model, process_group=None):
         if not dist.is_initialized():

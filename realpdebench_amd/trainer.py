@@ -74,7 +74,7 @@ class Trainer:
 
 class ProtocolTrainer:
     """The reference's loop body verbatim in structure (train.py:323-334) for models without a flat arena
-    (Transolver): ``zero_grad``; ``train_loss(...).mean().backward()`` runs the HIP forward/backward through the model's
+    (Transolver, Galerkin Transformer): ``zero_grad``; ``train_loss(...).mean().backward()`` runs the HIP forward/backward through the model's
     autograd Function; Adam + LR schedule are ``torch.optim`` (4 M parameters: off the critical path).  Under data
     parallelism the gradients are averaged with one RCCL all-reduce per parameter after backward."""
 
@@ -92,8 +92,12 @@ class ProtocolTrainer:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(dp_group)
-            for p in model.parameters():                         # one init for everyone, like the single-process reference
+            for p in list(model.parameters()) + list(model.buffers()):   # one init for everyone, like the single-process reference
                 torch.distributed.broadcast(p.data, src=0, group=dp_group)
+            core = getattr(model, "regressor", None)
+            if core is not None and hasattr(core, "dp") and self.world > 1:
+                from .dp import StatsSync
+                core.dp = StatsSync(dp_group)                    # BatchNorm3d over the global batch (SyncBN)
         self.group = dp_group
 
     def current_lr(self):
