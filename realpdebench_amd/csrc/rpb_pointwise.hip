@@ -18,73 +18,112 @@ static inline int pw_grid(long work_items, int per_cu = 8) {
 // out[b,t,h,w,:] = fc0.weight @ [x[b,t,h,w,:], gt[t], gh[h], gw[w]] + fc0.bias  for t<T,h<H,w<W, else 0
 // (fno.py:106-111: get_grid, cat, fc0, permute, F.pad -- the permute disappears: we stay channels-last)
 #define LIFT_FMAX 24
+// A block walks whole (b,t,h) rows of the padded tensor: the row decode is scalar, the row's features (C_in inputs of
+// W cells + the three grid coordinates) are staged once in LDS, and a thread produces 4 channels (one 16 B store) of
+// every (256/(C/4))-th cell.  Rows in the pad margin are plain zero fills.  F = C_in + 3 is a template parameter (the
+// reference's datasets have C_in = 2, 3, 5, 16; other counts take the generic instantiation).
+template <int FT>
 __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __restrict__ x, const float* __restrict__ gt,
                                                               const float* __restrict__ gh, const float* __restrict__ gw,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
-                                                              float* __restrict__ out, long ncell_pad, int Cin, int C,
+                                                              float* __restrict__ out, long nrows_pad, int Cin, int C,
                                                               CropMap cm) {
-    extern __shared__ float wl[];   // [F][C] transposed fc0.weight, then bias [C]
-    const int F = Cin + 3;
+    extern __shared__ float wl[];   // [F][C] transposed fc0.weight, bias [C], then the feature row [W][Cin]
+    const int F = FT > 0 ? FT : Cin + 3;
+    float* xrow = wl + (F + 1) * C;
     for (int idx = threadIdx.x; idx < F * C; idx += blockDim.x) {
         const int j = idx / C, o = idx - j * C;
         wl[idx] = w0[o * F + j];
     }
     for (int idx = threadIdx.x; idx < C; idx += blockDim.x) wl[F * C + idx] = b0[idx];
-    __syncthreads();
     const int c4n = C >> 2;
-    const long total = ncell_pad * c4n;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long cell = idx / c4n;
-        const int o = (int)(idx - cell * c4n) * 4;
-        const int w = (int)(cell % cm.Wp);
-        long r = cell / cm.Wp;
-        const int h = (int)(r % cm.Hp);
-        r /= cm.Hp;
-        const int t = (int)(r % cm.Tp);
-        const long b = r / cm.Tp;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (w < cm.W && h < cm.H && t < cm.T) {
-            const float* xp = x + (((b * cm.T + t) * cm.H + h) * (long)cm.W + w) * Cin;
-            const float* bl = wl + F * C + o;
-            v[0] = bl[0]; v[1] = bl[1]; v[2] = bl[2]; v[3] = bl[3];
-            for (int j = 0; j < F; ++j) {
-                const float f = (j < Cin) ? xp[j] : (j == Cin ? gt[t] : (j == Cin + 1 ? gh[h] : gw[w]));
-                const float* wr = wl + j * C + o;
-                v[0] += f * wr[0]; v[1] += f * wr[1]; v[2] += f * wr[2]; v[3] += f * wr[3];
-            }
+    const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = blockDim.x / c4n;
+    const int o = c4 * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (long row = blockIdx.x; row < nrows_pad; row += gridDim.x) {
+        const int h = (int)(row % cm.Hp);
+        const long r2 = row / cm.Hp;
+        const int t = (int)(r2 % cm.Tp);
+        const long b = r2 / cm.Tp;
+        float* op = out + row * cm.Wp * C + o;
+        if (h >= cm.H || t >= cm.T) {                                   // uniform: whole row is padding
+            for (int w = sub; w < cm.Wp; w += nsub) *reinterpret_cast<f32x4*>(op + (long)w * C) = z4;
+            continue;
         }
-        *reinterpret_cast<f32x4*>(out + cell * C + o) = v;
+        __syncthreads();                                               // previous row's readers are done (and wl is filled)
+        const float* xp = x + (((b * cm.T + t) * cm.H + h) * (long)cm.W) * Cin;
+        for (int idx = threadIdx.x; idx < cm.W * Cin; idx += blockDim.x) xrow[idx] = xp[idx];
+        __syncthreads();
+        // row-constant part: bias + gt[t] * W[:, Cin] + gh[h] * W[:, Cin+1]
+        const int Ci = F - 3;
+        f32x4 base = *reinterpret_cast<const f32x4*>(wl + F * C + o);
+        base += *reinterpret_cast<const f32x4*>(wl + Ci * C + o) * gt[t];
+        base += *reinterpret_cast<const f32x4*>(wl + (Ci + 1) * C + o) * gh[h];
+        const f32x4 wwv = *reinterpret_cast<const f32x4*>(wl + (Ci + 2) * C + o);
+        for (int w = sub; w < cm.Wp; w += nsub) {
+            f32x4 v = z4;
+            if (w < cm.W) {
+                v = base + wwv * gw[w];
+#pragma unroll
+                for (int j = 0; j < (FT > 0 ? FT - 3 : LIFT_FMAX - 3); ++j)
+                    if (FT > 0 || j < Ci) v += *reinterpret_cast<const f32x4*>(wl + j * C + o) * xrow[w * Ci + j];
+            }
+            *reinterpret_cast<f32x4*>(op + (long)w * C) = v;
+        }
     }
+}
+
+template <int FT>
+static void lift_pad_launch(int grid, size_t lds, hipStream_t st, const float* x, const float* gt, const float* gh,
+                            const float* gw, const float* w0, const float* b0, float* out, long nrows, int Cin, int C,
+                            CropMap cm) {
+    hipLaunchKernelGGL(lift_pad_kernel<FT>, dim3(grid), dim3(PW_THREADS), lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C,
+                       cm);
 }
 
 extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
                                 const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
                                 int Wp, void* stream) {
     RPB_REQUIRE(x && gt && gh && gw && w0 && b0 && out, "lift_pad: null pointer");
-    RPB_REQUIRE(C % 4 == 0 && Cin + 3 <= LIFT_FMAX, "lift_pad: C=%d Cin=%d unsupported", C, Cin);
-    const long ncell = (long)B * Tp * Hp * Wp;
-    const size_t lds = ((size_t)(Cin + 3) * C + C) * 4;
-    hipLaunchKernelGGL(lift_pad_kernel, dim3(pw_grid(ncell * (C / 4))), dim3(PW_THREADS), lds, (hipStream_t)stream, x, gt,
-                       gh, gw, w0, b0, out, ncell, Cin, C, CropMap{T, H, W, Tp, Hp, Wp});
+    RPB_REQUIRE(C % 4 == 0 && PW_THREADS % (C / 4) == 0 && Cin >= 0 && Cin + 3 <= LIFT_FMAX, "lift_pad: C=%d Cin=%d unsupported", C, Cin);
+    const long nrows = (long)B * Tp * Hp;
+    const int F = Cin + 3;
+    const size_t lds = ((size_t)(F + 1) * C + (size_t)W * Cin) * 4;
+    long grid = (long)rpb_num_cus() * 8;
+    if (grid > nrows) grid = nrows;
+    const CropMap cm{T, H, W, Tp, Hp, Wp};
+    hipStream_t st = (hipStream_t)stream;
+    switch (F) {
+        case 5: lift_pad_launch<5>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+        case 6: lift_pad_launch<6>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+        case 8: lift_pad_launch<8>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+        case 19: lift_pad_launch<19>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+        default: lift_pad_launch<0>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+    }
     RPB_CHECK_LAUNCH("lift_pad");
 }
 
 // d fc0.weight[o][j] = sum_cells g[cell][o] * feat[cell][j],  d fc0.bias[o] = sum_cells g[cell][o]
 // part row layout: [C*F] weight grad (o*F + j) then [C] bias grad.
-// A block walks whole (b,t,h) rows (row decode is scalar); a thread owns 4 channels (one 16 B load per cell) and
-// every (256/(C/4))-th cell of the row, so 16 independent loads are in flight per thread group.
+// Same row walk as lift_pad: the feature row sits in LDS, a thread owns 4 channels (one 16 B load per cell) and every
+// (256/(C/4))-th cell of the row; the two row-constant grid features (t, h) are accumulated once per row from the
+// row's bias sum instead of once per cell.
+template <int FT>
 __global__ __launch_bounds__(PW_THREADS) void lift_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                               const float* __restrict__ gt, const float* __restrict__ gh,
                                                               const float* __restrict__ gw, float* __restrict__ part,
                                                               long ncrop, int Cin, int C, CropMap cm) {
-    extern __shared__ float red[];  // [nsub][F+1][C]
-    const int F = Cin + 3;
+    extern __shared__ float red[];  // [nsub][F+1][C], then the feature row [W][Cin]
+    const int F = FT > 0 ? FT : Cin + 3;
+    const int Ci = F - 3;
     const int c4n = C >> 2;
     const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = blockDim.x / c4n;
     const int c = c4 * 4;
-    f32x4 acc[LIFT_FMAX + 1];
+    float* xrow = red + (long)nsub * (F + 1) * C;
+    constexpr int NA = FT > 0 ? FT : LIFT_FMAX;
+    f32x4 acc[NA + 1];              // [0, Ci): inputs, Ci: t, Ci+1: h, Ci+2: w, NA: bias
 #pragma unroll
-    for (int j = 0; j <= LIFT_FMAX; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j <= NA; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long nrows = ncrop / cm.W;
     for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int h = (int)(row % cm.H);
@@ -93,24 +132,39 @@ __global__ __launch_bounds__(PW_THREADS) void lift_bwd_kernel(const float* __res
         const long b = r2 / cm.T;
         const float* gp = g + (((b * cm.Tp + t) * cm.Hp + h) * (long)cm.Wp) * C + c;
         const float* xp = x + row * cm.W * Cin;
-        const float ft = gt[t], fh = gh[h];
+        if (Ci > 0) {
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < cm.W * Ci; idx += blockDim.x) xrow[idx] = xp[idx];
+            __syncthreads();
+        }
+        f32x4 rs = {0.f, 0.f, 0.f, 0.f}, rw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int w = sub; w < cm.W; w += nsub) {
             const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + (long)w * C);
 #pragma unroll
-            for (int j = 0; j < LIFT_FMAX; ++j) {
-                if (j < F) {
-                    const float f = (j < Cin) ? xp[w * Cin + j] : (j == Cin ? ft : (j == Cin + 1 ? fh : gw[w]));
-                    acc[j] += gv * f;
-                }
-            }
-            acc[LIFT_FMAX] += gv;
+            for (int j = 0; j < NA - 3; ++j)
+                if (FT > 0 || j < Ci) acc[j] += gv * xrow[w * Ci + j];
+            rw += gv * gw[w];
+            rs += gv;
         }
+        if (FT > 0) {
+            acc[FT - 3] += rs * gt[t];
+            acc[FT - 2] += rs * gh[h];
+            acc[FT - 1] += rw;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                if (j == Ci) acc[j] += rs * gt[t];
+                else if (j == Ci + 1) acc[j] += rs * gh[h];
+                else if (j == Ci + 2) acc[j] += rw;
+            }
+        }
+        acc[NA] += rs;
     }
 #pragma unroll
-    for (int j = 0; j < LIFT_FMAX; ++j)
+    for (int j = 0; j < NA; ++j)
         if (j < F) *reinterpret_cast<f32x4*>(red + ((long)(sub * (F + 1) + j)) * C + c) = acc[j];
-    *reinterpret_cast<f32x4*>(red + ((long)(sub * (F + 1) + F)) * C + c) = acc[LIFT_FMAX];
+    *reinterpret_cast<f32x4*>(red + ((long)(sub * (F + 1) + F)) * C + c) = acc[NA];
     __syncthreads();
     float* prow = part + (long)blockIdx.x * ((long)C * F + C);
     for (int idx = threadIdx.x; idx < C * (F + 1); idx += blockDim.x) {
@@ -128,13 +182,27 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
                             float* part, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp,
                             void* stream) {
     RPB_REQUIRE(g && x && gt && gh && gw && part, "lift_bwd: null pointer");
-    RPB_REQUIRE(Cin + 3 <= LIFT_FMAX && C % 4 == 0 && PW_THREADS % (C / 4) == 0, "lift_bwd: C=%d Cin=%d unsupported", C,
+    RPB_REQUIRE(Cin >= 0 && Cin + 3 <= LIFT_FMAX && C % 4 == 0 && PW_THREADS % (C / 4) == 0, "lift_bwd: C=%d Cin=%d unsupported", C,
                 Cin);
     const long ncrop = (long)B * T * H * W;
     const int nsub = PW_THREADS / (C / 4);
-    const size_t lds = (size_t)nsub * (Cin + 4) * C * 4;
-    hipLaunchKernelGGL(lift_bwd_kernel, dim3(rpb_lift_bwd_rows()), dim3(PW_THREADS), lds, (hipStream_t)stream, g, x, gt,
-                       gh, gw, part, ncrop, Cin, C, CropMap{T, H, W, Tp, Hp, Wp});
+    const size_t lds = ((size_t)nsub * (Cin + 4) * C + (size_t)W * Cin) * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "lift_bwd: C=%d Cin=%d W=%d does not fit LDS", C, Cin, W);
+    const CropMap cm{T, H, W, Tp, Hp, Wp};
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = rpb_lift_bwd_rows();
+#define RPB_LB(FT_)                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)lift_bwd_kernel<FT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    hipLaunchKernelGGL(lift_bwd_kernel<FT_>, dim3(grid), dim3(PW_THREADS), lds, st, g, x, gt, gh, gw, part, ncrop, Cin, C, cm)
+    switch (Cin + 3) {
+        case 3: RPB_LB(3); break;
+        case 5: RPB_LB(5); break;
+        case 6: RPB_LB(6); break;
+        case 8: RPB_LB(8); break;
+        case 19: RPB_LB(19); break;
+        default: RPB_LB(0); break;
+    }
+#undef RPB_LB
     RPB_CHECK_LAUNCH("lift_bwd");
 }
 

@@ -32,3 +32,50 @@ def make_datasets(args):
                          "--dataset_factory module:function returning (train, val, stats) or use dataset_name: synthetic")
     return (SyntheticDataset(args.shape_in, args.shape_out, args.n_train, seed=args.seed),
             SyntheticDataset(args.shape_in, args.shape_out, args.n_val, seed=args.seed + 1), None)
+
+
+class DevicePrefetcher:
+    """Double-buffered asynchronous input pipeline (replaces the blocking ``.to(device)`` of
+    realpdebench/data/data_normalizer.py:50-55 on the critical path of train.py:323-327).
+
+    While step k runs on the compute stream, batch k+1 is copied from pinned host memory to HBM and normalised (the
+    per-channel affine HIP kernel) on a side HIP stream; ``next()`` only makes the compute stream wait on the event of the
+    batch it hands out.  ``loader`` is any iterator of CPU ``(input, target)`` batches (``pin_memory=True`` loaders copy
+    asynchronously; unpinned batches are pinned here first)."""
+
+    def __init__(self, loader, normalizer, device):
+        self.it = iter(loader)
+        self.normalizer = normalizer
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._next = None
+
+    def _load(self):
+        try:
+            inp, tgt = next(self.it)
+        except StopIteration:
+            return None
+        pin = lambda t: t if (t.is_cuda or t.is_pinned()) else t.pin_memory()
+        with torch.cuda.stream(self.stream):
+            inp = pin(inp).to(self.device, non_blocking=True)
+            tgt = pin(tgt).to(self.device, non_blocking=True)
+            inp, tgt = self.normalizer.preprocess(inp, tgt)          # HIP kernels, enqueued on the side stream
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return inp, tgt, ev
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            self._next = self._load()
+        if self._next is None:
+            raise StopIteration
+        inp, tgt, ev = self._next
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        inp.record_stream(cur)          # the caching allocator must not hand these blocks back to the side stream early
+        tgt.record_stream(cur)
+        self._next = self._load()       # batch k+1 starts moving before step k is even launched
+        return inp, tgt

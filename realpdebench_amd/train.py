@@ -13,7 +13,7 @@ import time
 import torch
 from torch.utils.data import DataLoader
 
-from .data import make_datasets
+from .data import DevicePrefetcher, make_datasets
 from .data_normalizer import GaussianNormalizer, IdentityNormalizer
 from .model import load_model
 from .trainer import make_trainer
@@ -83,9 +83,9 @@ def main(argv=None):
     all_train_losses, all_val_losses = [], {"normalized_mse": [], "rmse": [], "mae": [], "rel_l2_error": []}
     best_val, best_it = float("inf"), 0
     pending, start = [], time.time()
+    batches = DevicePrefetcher(train_loader, normalizer, device)     # async H2D + normalise on a side stream (row f1)
     for iteration in range(1, n_iter + 1):
-        inp, tgt = next(train_loader)
-        inp, tgt = normalizer.preprocess(inp, tgt)
+        inp, tgt = next(batches)
         pending.append(trainer.step(inp, tgt).clone())              # device scalar, no sync
         if iteration % every == 0 or iteration == n_iter:
             all_train_losses += [float(v) for v in torch.cat(pending).cpu()]    # ONE sync per interval

@@ -71,3 +71,22 @@ def test_galerkin_train_then_eval(tmp_path):
     assert all(l == l and l < 1e3 for l in ck["train_losses"])
     ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
     assert os.path.exists(os.path.join(exp, "eval.log"))
+
+
+def test_device_prefetcher_matches_blocking_path():
+    """Row f1: batches delivered through the side-stream prefetcher equal the blocking normaliser path, in order."""
+    from realpdebench_amd.data import DevicePrefetcher
+    from realpdebench_amd.data_normalizer import GaussianNormalizer
+    torch.manual_seed(0)
+    batches = [(torch.randn(3, 4, 6, 8, 3), torch.randn(3, 4, 6, 8, 3)) for _ in range(5)]
+    mean_i, mean_t = torch.randn(3), torch.randn(3)
+    std_i, std_t = torch.rand(3) + 0.5, torch.rand(3) + 0.5
+    norm = GaussianNormalizer(mean_i, mean_t, std_i, std_t, device="cuda")
+    got = []
+    for inp, tgt in DevicePrefetcher(iter(batches), norm, "cuda"):
+        got.append((inp * 1.0, tgt * 1.0))            # consume on the compute stream
+    torch.cuda.synchronize()
+    assert len(got) == len(batches)
+    for (gi, gt), (bi, bt) in zip(got, batches):
+        ri, rt = norm.preprocess(bi, bt)
+        assert torch.equal(gi, ri) and torch.equal(gt, rt)
