@@ -82,6 +82,17 @@ def cpu_baseline():
                 "sample": f"CPU oracle step did not finish within 300 s ({type(e).__name__})"}
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio, which is fully buffered on a pipe and would otherwise land AFTER
+    the JSON line when the process exits; push it out first so the JSON line is the last line of stdout."""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def bench_galerkin(dev, steps=3):
     """Galerkin Transformer at the reference's configs/cylinder/galerkin_transformer.yaml (n = 20*64*128 tokens, hidden
     256, freq_dim 128, modes (4,16,20), train_batch_size 16): train step through the drop-in protocol (HIP
@@ -282,6 +293,11 @@ def main():
     galerkin = None
     if not a.no_galerkin and world == 1:
         galerkin = bench_galerkin(dev)
+    if world > 1 or force_dp:
+        torch.cuda.synchronize()
+        _flush_c_stdio()                                    # every rank empties its C stdio buffer (RCCL banner) ...
+        dist.barrier()                                      # ... before rank 0 goes on to print the JSON line
+        dist.destroy_process_group()
 
     if rank == 0:
         ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
@@ -320,9 +336,9 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if world > 1 or force_dp:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        _flush_c_stdio()
+        print(json.dumps(line), flush=True)                 # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ The reference has no distributed path at all (single process, realpdebench/train
 * the flat gradient arena is cut into per-layer buckets that become ready in reverse layer order during the
   backward pass; each bucket's all-reduce is issued asynchronously the moment its last kernel is enqueued, so
   RCCL (running on its own HIP stream) overlaps the remaining backward kernels.  For the cylinder config that is
-  4 buckets of 100.7 MB (one ``spectral_convs.{l}`` each) + 2 small ones;
+  4 buckets of 100.7 MB (one ``spectral_convs.{l}`` each, layer 0's still ahead of ~3.5 ms of backward) + 2 small ones;
 * BatchNorm3d uses global batch statistics (SyncBN): the fp64 per-channel (sum, sum-of-squares) and the backward
   (sum gz, sum gz*shat) vectors are all-reduced on the compute stream (2*C numbers per layer), so an N-rank step
   equals the 1-rank step on the concatenated batch;
@@ -20,15 +20,16 @@ import torch.distributed as dist
 
 def layer_buckets(seg, n_layers, total):
     """Contiguous [start, end) ranges of the flat arena in the order the backward pass completes them:
-    tail (fc1, fc2), layers L-1 .. 1, then head (fc0 + layer 0)."""
+    tail (fc1, fc2), layers L-1 .. 0 (each complete right after its spectral weight gradient), then the small fc0 head,
+    so that the last 100 MB bucket still overlaps the tail of the backward pass (layer 0's data gradient + lift)."""
     def start_of(name):
         return seg[name][0]
 
     cuts = [start_of(f"spec.{l}") for l in range(n_layers)] + [start_of("fc1.weight")]
     buckets = [(cuts[-1], total)]
-    for l in range(n_layers - 1, 0, -1):
+    for l in range(n_layers - 1, -1, -1):
         buckets.append((cuts[l], cuts[l + 1]))
-    buckets.append((0, cuts[1] if n_layers > 1 else cuts[-1]))
+    buckets.append((0, cuts[0]))
     return buckets
 
 

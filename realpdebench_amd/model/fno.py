@@ -379,7 +379,7 @@ class FNO3d(Model):
             self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GW, plan.GH, plan.GT),
                                           first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
-            if self.dp is not None and l > 0:
+            if self.dp is not None:
                 self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward
             gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)

@@ -62,16 +62,17 @@ def test_bucket_plan_covers_arena_in_backward_order():
     m = _make_model(0)
     total = m.flat.numel()
     b = layer_buckets(m._seg, m.n_layers, total)
-    assert len(b) == m.n_layers + 1
+    assert len(b) == m.n_layers + 2
     # disjoint cover
     cover = sorted(b)
     assert cover[0][0] == 0 and cover[-1][1] == total
     for (s0, e0), (s1, e1) in zip(cover, cover[1:]):
         assert e0 == s1
-    # completion order of the backward pass: tail first, then layers L-1..1, then head (fc0 + layer 0)
+    # completion order of the backward pass: tail first, then layers L-1..0, then the small fc0 head
     assert b[0][0] == m._seg["fc1.weight"][0]
     assert b[1][0] == m._seg[f"spec.{m.n_layers - 1}"][0]
-    assert b[-1][0] == 0 and b[-1][1] == m._seg["spec.1"][0]
+    assert b[-2] == (m._seg["spec.0"][0], m._seg["spec.1"][0])
+    assert b[-1] == (0, m._seg["spec.0"][0])
     # the spectral weights dominate each per-layer bucket
     assert m._seg["spec.1"][1] > 0.9 * (b[2][1] - b[2][0])
 
