@@ -80,3 +80,24 @@ def test_galerkin_state_dict_contract_cpu():
         m(g["x"])
     with pytest.raises(NotImplementedError):
         load_model(DS(), device="cpu", model_name="galerkin_transformer", attention_type="fourier")
+
+
+def test_eval_metrics_matches_reference():
+    """Row f3: the truncated-DFT / GEMM-binned eval_metrics equals the reference's fftn + triple-loop implementation on
+    vectors generated from it (tests/golden/make_golden_metrics.py), incl. chunked batches and the c < 2 branch."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    from realpdebench_amd.metrics import eval_metrics
+    z = np.load(os.path.join(GOLDEN_DIR, "metrics_small.npz"))
+    for name in ("a", "b", "c"):
+        pred, tgt = torch.from_numpy(z[f"{name}/pred"]), torch.from_numpy(z[f"{name}/target"])
+        bs = int(z[f"{name}/bs"]) or None
+        vals = eval_metrics(pred, tgt, int(z[f"{name}/c"]), batch_size=bs)
+        ref = z[f"{name}/vals"]
+        assert len(vals) == 13
+        for i, (v, r) in enumerate(zip(vals, ref)):
+            if not np.isfinite(r):          # a 1-sample chunk makes R^2 = -inf in the reference too (0 batch variance)
+                assert float(v) == r, (name, i, float(v), r)
+                continue
+            assert abs(float(v) - r) <= 2e-5 * max(abs(r), 1e-3), (name, i, float(v), r)
