@@ -103,3 +103,27 @@ def test_galerkin_oracle_matches_reference():
         assert rel_l2(grads[k], ref) < 2e-4, k
     for k, ref in g["buf1"].items():
         assert rel_l2(buf[k], ref) < TOL, k
+
+
+def test_unet_oracle_matches_reference():
+    """Forward, loss and every parameter gradient of the U-Net oracle vs the imported reference
+    (tests/golden/make_golden_unet.py; the rotary embedding is restated on both sides -- parity unpinned for it)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    from oracle import unet_oracle as UO
+    z = np.load(os.path.join(GOLDEN_DIR, "unet_small.npz"))
+    sd = {k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")}
+    grads_ref = {k[5:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("grad/")}
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    pred = UO.unet_forward(sd, x)
+    assert rel_l2(pred, torch.from_numpy(z["pred"])) < TOL
+    loss, _, grads = UO.loss_and_grads(sd, x, y)
+    assert abs(float(loss) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+    shared = lambda k: k.replace(".rotary_emb.freqs", "")
+    assert {shared(k) for k in grads_ref} <= set(grads)
+    for k, ref in grads_ref.items():
+        if float(ref.abs().max()) < 1e-6:         # conv bias under a 1-channel-per-group GroupNorm: exactly cancelled
+            assert float(grads[k].abs().max()) < 1e-5, k
+            continue
+        assert rel_l2(grads[k], ref) < 2e-4, k
