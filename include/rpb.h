@@ -150,7 +150,11 @@ int rpb_channel_affine(const float* in, float* out, long n, int C, const float* 
  *          4 zero where aux[m][n] <= 0 (backward through that ReLU; aux = the saved ReLU output). */
 int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
                 long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask,
-                int conv, int Hc, int Wc, int Dc, void* stream);   /* mask: optional [M][ldo] inverted-dropout multiplier */
+                int conv, int Hc, int Wc, int Dc, int cls, void* stream);   /* mask: optional [M][ldo] inverted-dropout multiplier */
+/*     conv = 2 / 3: the U-Net's Downsample nn.Conv3d(C, C, (1,4,4), (1,2,2), (0,1,1)) (realpdebench/model/unet.py:166-167; rows =
+ *     output tokens, K = 16*Ci, k = (kh*4 + kw)*Ci + ci) and one output-parity class cls = 2*ph + pw of its Upsample
+ *     nn.ConvTranspose3d (unet.py:163-164; rows = input tokens, written to row (t, 2h+ph, 2w+pw), K = 4*Ci); the data gradient
+ *     of either is the other with the weights re-laid-out.  rpb_gemm_tn conv = 2 is the matching weight-gradient gather. */
 /*     weight gradients: part[rpb_gemm_tn_splits(M,N,K)][N*K + N] partials of dW[n][k] = sum_m G[m][n] A(m,k) and
  *     db[n] = sum_m G[m][n] (autograd of the nn.Linear / nn.Conv3d weights above); conv=1 gathers A like rpb_gemm_nt. */
 int rpb_gemm_tn_splits(long M, int N, int K, int conv);
@@ -211,9 +215,10 @@ int rpb_headnorm_bwd(const float* x, int ldx, const float* gamma, const float* g
  *     head_apply: out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual  (Q (K^T V / n), its
  *     dropout + residual of model.py:112-116 fused; with transposed Wm the three data gradients). */
 int rpb_head_scores_chunks(int B, long n);
-int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n, void* stream);
+int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n, int nheads, void* stream);
 int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual, int ldr,
-                   const float* mask, int ldm, int B, long n, void* stream);
+                   const float* mask, int ldm, int B, long n, int nheads, void* stream);
+/*     nheads = number of 64-channel heads per row (Galerkin: 4; the U-Net's spatial linear attention: 2). */
 /*     SpectralRegressor.forward model.py:612-618 after the 256-wide token GEMM U = x fc.weight[:, :256]^T:
  *     out[b,t,h,w,:] = U[token] + fc.weight[:, 256:259] (gt[t], gh[h], gw[w]) + fc.bias inside the mesh, 0 in the
  *     6-cell pad; Wg = that [C][3] slice, contiguous. */
@@ -222,6 +227,44 @@ int rpb_pad_grid_fwd(const float* U, const float* gt, const float* gh, const flo
                      void* stream);
 /*     adjoint w.r.t. U: out[token][:] = g[padded cell of token][:]. */
 int rpb_crop_gather(const float* g, float* out, int B, int T, int H, int W, int C, int Tp, int Hp, int Wp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * U-Net.  Channels-last tokens [B][T*H*W][C]; the 3x3x3 / strided / transposed
+ * convolutions and every nn.Linear / 1x1 convolution run on rpb_gemm_nt / rpb_gemm_tn.
+ * Reference: realpdebench/model/unet.py
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*     Block = conv -> GroupNorm(8) -> x*(scale+1)+shift -> SiLU (unet.py:193-208) as per-(sample, channel) passes:
+ *     chan_stats -> part[rpb_chan_blocks(B,n)][B][2][C] = (sum x, sum x^2); affine_silu_fwd: y = silu(x*A[b][c] + Bc[b][c]);
+ *     bwd_reduce -> part[...][B][2][C] = (sum dz*x, sum dz), dz = gy*silu'(x*A+Bc); bwd_apply: gx = dz*A + P + Q*x. */
+int rpb_chan_blocks(int B, long n);
+int rpb_chan_stats(const float* x, float* part, int B, long n, int C, void* stream);
+int rpb_affine_silu_fwd(const float* x, const float* A, const float* Bc, const float* res, float* y, int B, long n, int C,
+                        void* stream);   /* y = silu(x*A + Bc) (+ res) */
+int rpb_affine_silu_bwd_reduce(const float* x, const float* gy, const float* A, const float* Bc, float* part, int B, long n,
+                               int C, void* stream);
+int rpb_affine_silu_bwd_apply(const float* x, const float* gy, const float* A, const float* Bc, const float* P,
+                              const float* Q, float* gx, int B, long n, int C, void* stream);
+/*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
+int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
+/*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,
+ *     rotary tables [T][32], relative-position bias [4][T][T].  bwd: part[rpb_tattn_blocks(B*HW)*8][T*T] bias-gradient
+ *     partials, row r belongs to head r % 4. */
+int rpb_tattn_blocks(long nloc);
+int rpb_tattn_fwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, float* out, int B, int T,
+                  int HW, void* stream);
+int rpb_tattn_bwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, const float* go, float* gqkv,
+                  float* part, int B, int T, int HW, void* stream);
+/*     bottleneck softmax attention over the n <= 512 tokens of a frame (unet.py:455-457): qkv [F][n][384] ->
+ *     out [F][n][128], lse [F][4][n]; the backward recomputes the probabilities. */
+int rpb_sattn_fwd(const float* qkv, float* out, float* lse, int F, int n, void* stream);
+int rpb_sattn_bwd(const float* qkv, const float* o, const float* go, float* lse, float* gqkv, int F, int n, void* stream);
+/*     SpatialLinearAttention (unet.py:236-261): qe[m] = [softmax_d(q)*32^-1/2 | exp(k - kmax[f])] and its backward
+ *     (gqkv columns 0..255 from dqe = [d q' | d E'] and d Z[f][128]); rpb_col_reduce: per-frame column max (mode 0) /
+ *     sum (mode 1) partials part[rpb_chan_blocks(F,n)][F][C] of a strided token tensor. */
+int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, int n, void* stream);
+int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n, void* stream);
+int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream);
 
 #ifdef __cplusplus
 }

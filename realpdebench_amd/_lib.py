@@ -44,7 +44,7 @@ SIGNATURES = {
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
-    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiii" + "p"),
+    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiiii" + "p"),
     "rpb_mul": (_I, "ppp" + "l" + "p"),
     "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
@@ -63,8 +63,22 @@ SIGNATURES = {
     "rpb_headnorm_bwd_rows": (_L, "l"),
     "rpb_headnorm_bwd": (_I, "pippipip" + "l" + "i" + "f" + "p"),
     "rpb_head_scores_chunks": (_I, "il"),
-    "rpb_head_scores": (_I, "pipip" + "il" + "p"),
-    "rpb_head_apply": (_I, "pippipipi" + "il" + "p"),
+    "rpb_head_scores": (_I, "pipip" + "ili" + "p"),
+    "rpb_head_apply": (_I, "pippipipi" + "ili" + "p"),
+    "rpb_chan_blocks": (_I, "il"),
+    "rpb_chan_stats": (_I, "pp" + "ili" + "p"),
+    "rpb_affine_silu_fwd": (_I, "ppppp" + "ili" + "p"),
+    "rpb_affine_silu_bwd_reduce": (_I, "ppppp" + "ili" + "p"),
+    "rpb_affine_silu_bwd_apply": (_I, "ppppppp" + "ili" + "p"),
+    "rpb_im2col": (_I, "pp" + "iiiiiii" + "p"),
+    "rpb_tattn_blocks": (_I, "l"),
+    "rpb_tattn_fwd": (_I, "ppppp" + "iii" + "p"),
+    "rpb_tattn_bwd": (_I, "ppppppp" + "iii" + "p"),
+    "rpb_sattn_fwd": (_I, "ppp" + "ii" + "p"),
+    "rpb_sattn_bwd": (_I, "ppppp" + "ii" + "p"),
+    "rpb_linattn_prep_fwd": (_I, "ppp" + "ii" + "p"),
+    "rpb_linattn_prep_bwd": (_I, "pppp" + "ii" + "p"),
+    "rpb_col_reduce": (_I, "pip" + "ilii" + "p"),
     "rpb_pad_grid_fwd": (_I, "ppppppp" + "iiiiiiii" + "p"),
     "rpb_crop_gather": (_I, "pp" + "iiiiiiii" + "p"),
 }

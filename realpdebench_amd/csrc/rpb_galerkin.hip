@@ -198,7 +198,7 @@ struct HeadScoreArgs {
     const float* A;
     float* part;
     long n;
-    int ldg, lda, B;
+    int ldg, lda, B, nh;
 };
 
 __global__ __launch_bounds__(256) void head_scores_kernel(HeadScoreArgs a) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void head_scores_kernel(HeadScoreArgs a) {
         if (m + 32 < me) load_half(m + 32, 0, ga, xa);
         compute_half(gb, xb);
     }
-    float* part = a.part + (((long)chunk * a.B + b) * 4 + h) * 4096;
+    float* part = a.part + (((long)chunk * a.B + b) * a.nh + h) * 4096;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -264,12 +264,13 @@ extern "C" int rpb_head_scores_chunks(int B, long n) {
     return (int)c;
 }
 
-extern "C" int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n,
+extern "C" int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n, int nheads,
                                void* stream) {
     RPB_REQUIRE(G && A && part && B > 0 && n > 0, "head_scores: bad arguments");
-    RPB_REQUIRE(ldg % 2 == 0 && lda % 2 == 0 && ldg >= 256 && lda >= 256, "head_scores: bad leading dimensions %d %d", ldg, lda);
-    HeadScoreArgs a{G, A, part, n, ldg, lda, B};
-    hipLaunchKernelGGL(head_scores_kernel, dim3(rpb_head_scores_chunks(B, n), B), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_REQUIRE(nheads >= 1 && nheads <= 4, "head_scores: %d heads of 64 channels (1..4)", nheads);
+    RPB_REQUIRE(ldg % 2 == 0 && lda % 2 == 0 && ldg >= 64 * nheads && lda >= 64 * nheads, "head_scores: bad leading dimensions %d %d", ldg, lda);
+    HeadScoreArgs a{G, A, part, n, ldg, lda, B, nheads};
+    hipLaunchKernelGGL(head_scores_kernel, dim3(rpb_head_scores_chunks(B, n), B), dim3(64 * nheads), 0, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("head_scores");
 }
 
@@ -284,7 +285,7 @@ struct HeadApplyArgs {
     const float* residual;
     const float* mask;
     long n;
-    int ldx, ldo, ldr, ldm;
+    int ldx, ldo, ldr, ldm, nh;
 };
 
 #define HA_WAVES 8
@@ -292,15 +293,16 @@ struct HeadApplyArgs {
 
 __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs a) {
     extern __shared__ float lds[];
-    float* Wl = lds;                                   // [4 heads][64 k][32 col][2 tiles]
+    float* Wl = lds;                                   // [nh heads][64 k][32 col][2 tiles]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = wave & 3, sub = wave >> 2;
-    float* xl = lds + 4 * 4096 + wave * 32 * HA_XS;    // wave-private [32][65]
+    const int nh = a.nh;
+    const int h = wave % nh, sub = wave / nh, nsub = HA_WAVES / nh;      // nh in {1, 2, 4}
+    float* xl = lds + nh * 4096 + wave * 32 * HA_XS;   // wave-private [32][65]
     const int col = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;
-    const float* wsrc = a.Wm + (long)b * 4 * 4096;
-    for (int idx = threadIdx.x; idx < 4 * 4096; idx += blockDim.x) {
+    const float* wsrc = a.Wm + (long)b * nh * 4096;
+    for (int idx = threadIdx.x; idx < nh * 4096; idx += blockDim.x) {
         const int hh = idx >> 12, k = (idx >> 6) & 63, j = idx & 63;          // W[hh][k][j], coalesced read
         Wl[hh * 4096 + (k * 32 + (j & 31)) * 2 + (j >> 5)] = wsrc[idx];
     }
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
     long tile = t0 + sub;
     if (tile < t1) issue_x(tile);
     const float* wp = Wl + h * 4096 + (half * 32 + col) * 2;
-    for (; tile < t1; tile += 2) {
+    for (; tile < t1; tile += nsub) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float* d = xl + (j * 4 + lrow) * HA_XS + lc4;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
             d[2] = xr[j][2];
             d[3] = xr[j][3];
         }
-        if (tile + 2 < t1) issue_x(tile + 2);
+        if (tile + nsub < t1) issue_x(tile + nsub);
         __builtin_amdgcn_wave_barrier();
         f32x16 acc[2] = {zero16(), zero16()};
         const float* ap = xl + col * HA_XS + half;
@@ -366,15 +368,17 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
 }
 
 extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual,
-                              int ldr, const float* mask, int ldm, int B, long n, void* stream) {
+                              int ldr, const float* mask, int ldm, int B, long n, int nheads, void* stream) {
     RPB_REQUIRE(X && Wm && out && B > 0 && n > 0, "head_apply: bad arguments");
-    RPB_REQUIRE(ldx % 4 == 0 && ldx >= 256 && ldo >= 256, "head_apply: bad leading dimensions %d %d", ldx, ldo);
-    HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm};
+    RPB_REQUIRE(nheads == 1 || nheads == 2 || nheads == 4, "head_apply: %d heads of 64 channels (1, 2 or 4)", nheads);
+    RPB_REQUIRE(ldx % 4 == 0 && ldx >= 64 * nheads && ldo >= 64 * nheads, "head_apply: bad leading dimensions %d %d", ldx, ldo);
+    HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm, nheads};
     const long ntiles = (n + 31) / 32;
     long chunks = ((long)rpb_num_cus() * 2 + B - 1) / B;
-    if (chunks > (ntiles + 1) / 2) chunks = (ntiles + 1) / 2;
+    const int nsub = HA_WAVES / nheads;
+    if (chunks > (ntiles + nsub - 1) / nsub) chunks = (ntiles + nsub - 1) / nsub;
     if (chunks < 1) chunks = 1;
-    const size_t lds = (size_t)(4 * 4096 + HA_WAVES * 32 * HA_XS) * 4;
+    const size_t lds = (size_t)(nheads * 4096 + HA_WAVES * 32 * HA_XS) * 4;
     (void)hipFuncSetAttribute((const void*)head_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(head_apply_kernel, dim3((unsigned)chunks, B), dim3(HA_WAVES * 64), lds, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("head_apply");

@@ -29,8 +29,15 @@ struct GemmArgs {
     const float* aux;      // act == 2: the saved pre-activation [M][ldo]; act == 4: the saved ReLU output
     float* pre_out;        // act == 1: optional copy of the pre-activation (saved for the backward pass)
     const float* mask;     // optional [M][ldo] multiplier applied before addvec/residual (inverted-dropout mask)
-    // implicit 3x3x3 convolution over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
-    int conv, Hc, Wc, Dc;
+    // conv = 1: implicit 3x3x3 convolution (padding 1) over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
+    // conv = 2: nn.Conv3d(C, C, (1,4,4), stride (1,2,2), padding (0,1,1)) -- U-Net Downsample, unet.py:166-167: the INPUT
+    //           lives on the mesh (Hc, Wc, Dc) = (T, H, W), rows m enumerate the output mesh (T, H/2, W/2); K = 16*Ci,
+    //           k = (kh*4 + kw)*Ci + ci
+    // conv = 3: one output-parity class (ph, pw) = (cls >> 1, cls & 1) of nn.ConvTranspose3d(C, C, (1,4,4), (1,2,2),
+    //           (0,1,1)) -- U-Net Upsample, unet.py:163-164: rows m enumerate the INPUT mesh (T, H, W); output row
+    //           (t, 2h+ph, 2w+pw) of the (T, 2H, 2W) mesh; K = 4*Ci, k = (jh*2 + jw)*Ci + ci with input offsets
+    //           dh = ph ? (jh ? 0 : +1) : (jh ? -1 : 0)  (kernel rows kh = ph ? (0, 2) : (1, 3)), same for w
+    int conv, Hc, Wc, Dc, cls;
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
     const int tile_n = blockIdx.x % ntn;
     const long m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int Ci = g.conv ? g.K / 27 : g.K;
+    const int Ci = g.conv == 1 ? g.K / 27 : (g.conv == 2 ? g.K / 16 : (g.conv == 3 ? g.K / 4 : g.K));
 
     // per-thread rows of the A tile (fixed across chunks) and, for the convolution, their mesh coordinates
     int arow[A4];          // row within tile
@@ -64,8 +71,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         const int idx = tid + j * NTHR;
         arow[j] = idx / (G_BK / 4);
         const long m = m0 + arow[j];
-        am[j] = (m < g.M) ? m : -1;
-        if (g.conv && am[j] >= 0) {
+        am[j] = (m < g.M) ? m : -1;      // validity is tracked in arow_ok (a conv = 2 base token may be negative)
+        if (g.conv == 2 && am[j] >= 0) {                 // m over the output mesh (Hc, Wc/2, Dc/2)
+            const int Wo = g.Wc / 2, Do = g.Dc / 2;
+            const long per = (long)g.Hc * Wo * Do;
+            const long bb = m / per;
+            long r = m - bb * per;
+            const int dq = (int)(r % Do);
+            r /= Do;
+            const int wq = (int)(r % Wo);
+            const int hq = (int)(r / Wo);
+            ah[j] = hq;
+            aw[j] = 2 * wq - 1;
+            ad[j] = 2 * dq - 1;
+            am[j] = ((bb * g.Hc + hq) * g.Wc + aw[j]) * g.Dc + ad[j];     // token of tap (0,0); may be "negative-ish" only via the bounds-checked taps
+        } else if (g.conv && am[j] >= 0) {
             const long per = (long)g.Hc * g.Wc * g.Dc;
             long r = m % per;
             ad[j] = (int)(r % g.Dc);
@@ -76,6 +96,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
             ah[j] = aw[j] = ad[j] = 0;
         }
     }
+    bool arow_ok[A4];
+#pragma unroll
+    for (int j = 0; j < A4; ++j) arow_ok[j] = (m0 + arow[j]) < g.M;
     const int c4 = tid % (G_BK / 4);           // float4 column within the chunk (same for every j: NTHR % 8 == 0)
 
     f32x4 pa[A4], pw[W4];
@@ -90,15 +113,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         if (g.conv) {
             tap = k0 / Ci;
             kk = k0 - tap * Ci;
-            dh = tap / 9 - 1;
-            dw = (tap / 3) % 3 - 1;
-            dd = tap % 3 - 1;
+            if (g.conv == 1) {
+                dh = tap / 9 - 1;
+                dw = (tap / 3) % 3 - 1;
+                dd = tap % 3 - 1;
+            } else if (g.conv == 2) {                 // taps (kw', kd') of the (1,4,4) kernel, relative to tap (0,0)
+                dw = tap >> 2;
+                dd = tap & 3;
+            } else {                                  // transposed class: 2 x 2 taps
+                const int ph = g.cls >> 1, pw = g.cls & 1, jh = tap >> 1, jw = tap & 1;
+                dw = ph ? (jh ? 0 : 1) : (jh ? -1 : 0);
+                dd = pw ? (jw ? 0 : 1) : (jw ? -1 : 0);
+            }
             noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
         }
 #pragma unroll
         for (int j = 0; j < A4; ++j) {
             f32x4 v = z4;
-            if (am[j] >= 0) {
+            if (arow_ok[j]) {
                 if (g.conv) {
                     const int hh = ah[j] + dh, ww = aw[j] + dw, d2 = ad[j] + dd;
                     if (hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc)
@@ -171,8 +203,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long m = m0 + (wm * TM + i) * 32 + mfma_row(lane, r);
-                if (m < g.M) {
+                const long mi = m0 + (wm * TM + i) * 32 + mfma_row(lane, r);
+                if (mi < g.M) {
+                    long m = mi;
+                    if (g.conv == 3) {                       // (b, t, h, w) -> row (b, t, 2h+ph, 2w+pw) of the up-sampled mesh
+                        const long per = (long)g.Wc * g.Dc;
+                        const long bt = mi / per;
+                        const int r2 = (int)(mi - bt * per);
+                        const int hh = r2 / g.Dc, ww = r2 - hh * g.Dc;
+                        m = (bt * (2 * g.Wc) + 2 * hh + (g.cls >> 1)) * (2L * g.Dc) + 2 * ww + (g.cls & 1);
+                    }
                     float v = acc[i][j][r] + badd;
                     if (g.act == 1) {
                         if (g.pre_out) g.pre_out[m * g.ldo + n] = v;
@@ -208,21 +248,30 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual,
                            float* out, long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out,
-                           const float* mask, int conv, int Hc, int Wc, int Dc, void* stream) {
+                           const float* mask, int conv, int Hc, int Wc, int Dc, int cls, void* stream) {
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
     RPB_REQUIRE((act != 2 && act != 4) || aux, "gemm_nt: act=2/4 needs the saved activation tensor");
     RPB_REQUIRE(act >= 0 && act <= 4, "gemm_nt: unknown act=%d", act);
     RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
                 N, K, G_BK);
     RPB_REQUIRE(lda % 4 == 0 && ldo >= N, "gemm_nt: lda=%d must be a multiple of 4 and ldo=%d >= N", lda, ldo);
-    if (conv) {
+    RPB_REQUIRE(conv >= 0 && conv <= 3 && cls >= 0 && cls <= 3, "gemm_nt: bad conv=%d / cls=%d", conv, cls);
+    if (conv == 1) {
         RPB_REQUIRE(K % 27 == 0 && (K / 27) % G_BK == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
                     "gemm_nt: bad convolution geometry");
+    } else if (conv == 2) {
+        RPB_REQUIRE(K % 16 == 0 && (K / 16) % G_BK == 0 && Hc > 0 && Wc > 0 && Dc > 0 && Wc % 2 == 0 && Dc % 2 == 0 &&
+                        M % ((long)Hc * (Wc / 2) * (Dc / 2)) == 0,
+                    "gemm_nt: bad strided-convolution geometry");
+    } else if (conv == 3) {
+        RPB_REQUIRE(K % 4 == 0 && (K / 4) % G_BK == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
+                    "gemm_nt: bad transposed-convolution geometry");
+        RPB_REQUIRE(!aux && !pre_out && !mask && !residual, "gemm_nt: conv=3 supports the bias epilogue only");
     }
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.addvec = addvec; g.residual = residual; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act; g.aux = aux; g.pre_out = pre_out; g.mask = mask;
-    g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc;
+    g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc; g.cls = cls;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64) return launch_gemm<2, 2, 2, 2>(g, st);      // 128 x 128 tile
     if (N > 32) return launch_gemm<2, 2, 2, 1>(g, st);      // 128 x 64
@@ -279,18 +328,25 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     const long mb = (long)split * per;
     long me = mb + per;
     if (me > g.M) me = g.M;
-    const int Ci = g.conv ? g.K / 27 : g.K;
+    const int ntap = g.conv == 2 ? 16 : 27;
+    const int Ci = g.conv ? g.K / ntap : g.K;
     int tap = 0, kk0 = k0, dh = 0, dw = 0, dd = 0;
     long noff = 0;
     if (g.conv) {
         tap = k0 / Ci;
         kk0 = k0 - tap * Ci;
-        dh = tap / 9 - 1;
-        dw = (tap / 3) % 3 - 1;
-        dd = tap % 3 - 1;
-        noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
+        if (g.conv == 1) {
+            dh = tap / 9 - 1;
+            dw = (tap / 3) % 3 - 1;
+            dd = tap % 3 - 1;
+            noff = ((long)dh * g.Wc + dw) * g.Dc + dd;
+        } else {                       // conv = 2: (1,4,4) kernel, stride (1,2,2), padding (0,1,1); G rows = output tokens
+            dw = (tap >> 2) - 1;
+            dd = (tap & 3) - 1;
+        }
     }
-    const bool tap_ok = !g.conv || tap < 27;
+    const bool tap_ok = !g.conv || tap < ntap;
+    const int Wo = g.Wc / 2, Do = g.Dc / 2;              // conv = 2: output mesh (Hc, Wo, Do)
     const bool n_ok0 = n0 + col * 2 < g.N, n_ok1 = n0 + col * 2 + 1 < g.N;      // N may be < 64 (e.g. mlp2: 3)
     const int klim = g.conv ? Ci : g.K;
     const long mesh = (long)g.Hc * g.Wc * g.Dc;
@@ -310,11 +366,17 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     // A lane's tokens form ONE arithmetic progression mb + half, +2, +4, ... across steps, halves and chunks, so its
     // mesh coordinates are carried incrementally (add 2 with carry): no divisions and ~10 VALU ops per load
     int ld = 0, lw = 0, lh = 0;
-    if (g.conv) {
+    long lbt = 0;                                        // conv = 2: frame index b*T + t of this lane's token
+    if (g.conv == 1) {
         const long r = (mb + half) % mesh;
         ld = (int)(r % g.Dc);
         lw = (int)((r / g.Dc) % g.Wc);
         lh = (int)(r / ((long)g.Dc * g.Wc));
+    } else if (g.conv == 2) {
+        const long r = mb + half;
+        ld = (int)(r % Do);
+        lw = (int)((r / Do) % Wo);
+        lbt = r / ((long)Do * Wo);
     }
     auto load_half = [&](long m0, int h, f32x2 (&gv)[8], veci (&xv)[8]) {
 #pragma unroll
@@ -324,7 +386,8 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
             f32x2 gq = {0.f, 0.f};
             veci xq = zi;
             bool ok = tap_ok;
-            if (g.conv) {
+            long atok = m + noff;
+            if (g.conv == 1) {
                 const int hh = lh + dh, ww = lw + dw, d2 = ld + dd;
                 ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
                 ld += 2;                                             // advance this lane to its next token
@@ -335,13 +398,25 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
                         if (++lh >= g.Hc) lh = 0;
                     }
                 }
+            } else if (g.conv == 2) {
+                const int ww = 2 * lw + dw, d2 = 2 * ld + dd;
+                ok = ok && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
+                atok = (lbt * g.Wc + ww) * g.Dc + d2;
+                ld += 2;
+                while (ld >= Do) {
+                    ld -= Do;
+                    if (++lw >= Wo) {
+                        lw = 0;
+                        ++lbt;
+                    }
+                }
             }
             if (m < me) {
                 const float* gp = g.G + m * g.ldg + n0 + col * 2;
                 if (n_ok1) gq = *reinterpret_cast<const f32x2*>(gp);
                 else if (n_ok0) gq[0] = gp[0];
                 if (ok) {
-                    const float* xp = g.A + (m + noff) * g.lda + kk0 + col * NTI;
+                    const float* xp = g.A + atok * g.lda + kk0 + col * NTI;
                     if (kk0 + col * NTI + NTI <= klim) xq = *reinterpret_cast<const veci*>(xp);
                     else {
 #pragma unroll
@@ -392,7 +467,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
 }
 
 static int gemm_tn_nti(int K, int conv) {
-    const int Ci = conv ? K / 27 : K;
+    const int Ci = conv == 1 ? K / 27 : (conv == 2 ? K / 16 : K);
     return (Ci % 128 == 0) ? 4 : 2;
 }
 
@@ -414,8 +489,12 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
                            int Hc, int Wc, int Dc, void* stream) {
     RPB_REQUIRE(G && A && part && M > 0 && N > 0 && K > 0, "gemm_tn: bad arguments");
     RPB_REQUIRE(ldg % 2 == 0 && lda % 2 == 0, "gemm_tn: leading dimensions must be even (float2 loads)");
-    if (conv) RPB_REQUIRE(K % 27 == 0 && (K / 27) % 64 == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
-                          "gemm_tn: bad convolution geometry (Ci must be a multiple of 64)");
+    RPB_REQUIRE(conv >= 0 && conv <= 2, "gemm_tn: conv=%d", conv);
+    if (conv == 1) RPB_REQUIRE(K % 27 == 0 && (K / 27) % 64 == 0 && Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0,
+                               "gemm_tn: bad convolution geometry (Ci must be a multiple of 64)");
+    if (conv == 2) RPB_REQUIRE(K % 16 == 0 && (K / 16) % 64 == 0 && Hc > 0 && Wc > 0 && Dc > 0 && Wc % 2 == 0 && Dc % 2 == 0 &&
+                                   M % ((long)Hc * (Wc / 2) * (Dc / 2)) == 0,
+                               "gemm_tn: bad strided-convolution geometry (Ci must be a multiple of 64)");
     GemmTnArgs a;
     a.G = G; a.A = A; a.part = part; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.lda = lda;
     a.conv = conv; a.Hc = Hc; a.Wc = Wc; a.Dc = Dc;

@@ -1,0 +1,721 @@
+// HBM-streaming kernels of the U-Net path (reference realpdebench/model/unet.py), channels-last tokens [B][n][C]:
+//
+//   * GroupNorm(8) + time-conditioning scale/shift + SiLU of `Block` (unet.py:193-208) and their backward.
+//     Everything that depends on the group structure is a function of per-(sample, channel) numbers, so the kernels are
+//     group-agnostic "per-sample channel" passes and the B x C sized algebra between them is host glue:
+//       fwd : chan_stats  -> (sum x, sum x^2)[b][c]   => mean / invstd per (b, group) => A[b][c], Bc[b][c]
+//             affine_silu : y = silu(x * A[b][c] + Bc[b][c])
+//       bwd : affine_silu_bwd_reduce -> (sum dz*x, sum dz)[b][c],  dz = gy * silu'(x*A + Bc)
+//             => d gamma, d beta, d scale, d shift and, through mean/invstd(x), P[b][c], Q[b][c]
+//             affine_silu_bwd_apply : gx = dz * A[b][c] + P[b][c] + Q[b][c] * x
+//     Partials are one row per block, finished by rpb_reduce_partials in fp64 (deterministic, no atomics).
+#include "rpb_common.h"
+
+#define UN_THREADS 256
+
+struct ChanArgs {
+    const float* x;      // [B][n][C]
+    const float* gy;     // bwd
+    const float* A;      // [B][C]
+    const float* Bc;     // [B][C]
+    const float* P;      // [B][C]
+    const float* Q;      // [B][C]
+    const float* res;    // fwd: optional residual added after the SiLU (ResnetBlock identity shortcut)
+    float* out;          // fwd: y ; bwd apply: gx
+    float* part;         // [nblk][B][2][C]
+    long n;
+    int B, C;
+};
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * z)); }
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float sig = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * z));
+    return sig * (1.0f + z * (1.0f - sig));
+}
+
+// MODE 0: sums of x, x^2 | 1: y = silu(xA + Bc) | 2: sums of dz*x, dz | 3: gx = dz*A + P + Q*x
+template <int MODE>
+__global__ __launch_bounds__(UN_THREADS) void chan_kernel(ChanArgs a) {
+    __shared__ f32x4 red[2][UN_THREADS];
+    const int c4n = a.C >> 2;
+    const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = UN_THREADS / c4n;
+    const int b = blockIdx.y;
+    const long per = (a.n + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per;
+    long r1 = r0 + per;
+    if (r1 > a.n) r1 = a.n;
+    const long base = ((long)b * a.n) * a.C + 4 * c4;
+    f32x4 A4 = {0.f, 0.f, 0.f, 0.f}, B4 = A4, P4 = A4, Q4 = A4;
+    if (MODE != 0) {
+        A4 = *reinterpret_cast<const f32x4*>(a.A + (long)b * a.C + 4 * c4);
+        B4 = *reinterpret_cast<const f32x4*>(a.Bc + (long)b * a.C + 4 * c4);
+    }
+    if (MODE == 3) {
+        P4 = *reinterpret_cast<const f32x4*>(a.P + (long)b * a.C + 4 * c4);
+        Q4 = *reinterpret_cast<const f32x4*>(a.Q + (long)b * a.C + 4 * c4);
+    }
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll 4
+    for (long r = r0 + sub; r < r1; r += nsub) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a.x + base + r * a.C);
+        if (MODE == 0) {
+            s0 += x;
+            s1 += x * x;
+        } else if (MODE == 1) {
+            const f32x4 z = x * A4 + B4;
+            f32x4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = silu_f(z[k]);
+            if (a.res) y += *reinterpret_cast<const f32x4*>(a.res + base + r * a.C);
+            *reinterpret_cast<f32x4*>(a.out + base + r * a.C) = y;
+        } else {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gy + base + r * a.C);
+            const f32x4 z = x * A4 + B4;
+            f32x4 dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dz[k] = g[k] * silu_grad_f(z[k]);
+            if (MODE == 2) {
+                s0 += dz * x;
+                s1 += dz;
+            } else {
+                *reinterpret_cast<f32x4*>(a.out + base + r * a.C) = dz * A4 + P4 + Q4 * x;
+            }
+        }
+    }
+    if (MODE == 0 || MODE == 2) {
+        red[0][threadIdx.x] = s0;
+        red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (sub == 0) {
+            for (int k = 1; k < nsub; ++k) {
+                s0 += red[0][k * c4n + c4];
+                s1 += red[1][k * c4n + c4];
+            }
+            float* row = a.part + (((long)blockIdx.x * a.B + b) * 2) * a.C + 4 * c4;
+            *reinterpret_cast<f32x4*>(row) = s0;
+            *reinterpret_cast<f32x4*>(row + a.C) = s1;
+        }
+    }
+}
+
+extern "C" int rpb_chan_blocks(int B, long n) {
+    long g = ((long)rpb_num_cus() * 8 + B - 1) / (B > 0 ? B : 1);
+    const long cap = (n + 63) / 64;                  // at least 64 rows per block
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+static int chan_check(const ChanArgs& a) {
+    RPB_REQUIRE(a.x && a.B > 0 && a.n > 0, "chan kernels: bad arguments");
+    RPB_REQUIRE(a.C % 4 == 0 && a.C >= 4 && UN_THREADS % (a.C / 4) == 0, "chan kernels: C=%d must divide %d*4", a.C, UN_THREADS);
+    return RPB_OK;
+}
+
+/* (sum x, sum x^2) per (sample, channel): part[rpb_chan_blocks(B, n)][B][2][C]. */
+extern "C" int rpb_chan_stats(const float* x, float* part, int B, long n, int C, void* stream) {
+    ChanArgs a{};
+    a.x = x; a.part = part; a.B = B; a.n = n; a.C = C;
+    if (int e = chan_check(a)) return e;
+    RPB_REQUIRE(part, "chan_stats: null partial buffer");
+    hipLaunchKernelGGL(chan_kernel<0>, dim3(rpb_chan_blocks(B, n), B), dim3(UN_THREADS), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("chan_stats");
+}
+
+extern "C" int rpb_affine_silu_fwd(const float* x, const float* A, const float* Bc, const float* res, float* y, int B,
+                                   long n, int C, void* stream) {
+    ChanArgs a{};
+    a.x = x; a.A = A; a.Bc = Bc; a.res = res; a.out = y; a.B = B; a.n = n; a.C = C;
+    if (int e = chan_check(a)) return e;
+    RPB_REQUIRE(A && Bc && y, "affine_silu_fwd: null pointer");
+    hipLaunchKernelGGL(chan_kernel<1>, dim3(rpb_chan_blocks(B, n), B), dim3(UN_THREADS), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("affine_silu_fwd");
+}
+
+/* (sum dz*x, sum dz) per (sample, channel), dz = gy * silu'(x*A + Bc): part[rpb_chan_blocks(B, n)][B][2][C]. */
+extern "C" int rpb_affine_silu_bwd_reduce(const float* x, const float* gy, const float* A, const float* Bc, float* part,
+                                          int B, long n, int C, void* stream) {
+    ChanArgs a{};
+    a.x = x; a.gy = gy; a.A = A; a.Bc = Bc; a.part = part; a.B = B; a.n = n; a.C = C;
+    if (int e = chan_check(a)) return e;
+    RPB_REQUIRE(gy && A && Bc && part, "affine_silu_bwd_reduce: null pointer");
+    hipLaunchKernelGGL(chan_kernel<2>, dim3(rpb_chan_blocks(B, n), B), dim3(UN_THREADS), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("affine_silu_bwd_reduce");
+}
+
+extern "C" int rpb_affine_silu_bwd_apply(const float* x, const float* gy, const float* A, const float* Bc, const float* P,
+                                         const float* Q, float* gx, int B, long n, int C, void* stream) {
+    ChanArgs a{};
+    a.x = x; a.gy = gy; a.A = A; a.Bc = Bc; a.P = P; a.Q = Q; a.out = gx; a.B = B; a.n = n; a.C = C;
+    if (int e = chan_check(a)) return e;
+    RPB_REQUIRE(gy && A && Bc && P && Q && gx, "affine_silu_bwd_apply: null pointer");
+    hipLaunchKernelGGL(chan_kernel<3>, dim3(rpb_chan_blocks(B, n), B), dim3(UN_THREADS), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("affine_silu_bwd_apply");
+}
+
+// ---------------------------------------------------------------------------------- init_conv as im2col + token GEMM
+// nn.Conv3d(C_in, dim, 7, padding 3) (unet.py:404) has C_in = 2..16 input channels: too few for the implicit-GEMM gather
+// (32-channel chunks), so its im2col matrix col[m][tap*C_in + ci] (taps row-major over (dt, dh, dw), zero outside the
+// mesh, zero-padded to ldc columns) is materialised once per step and both the forward product and the weight
+// gradient are plain token GEMMs (rpb_gemm_nt / rpb_gemm_tn) on it.  The input needs no data gradient.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long M, int T,
+                                                     int H, int W, int Cin, int KS, int ldc) {
+    const int R = KS / 2, taps = KS * KS * KS;
+    const long total = M * ldc;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / ldc;
+        const int k = (int)(idx - m * ldc);
+        float v = 0.f;
+        if (k < taps * Cin) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int dw = tap % KS - R, dh = (tap / KS) % KS - R, dt = tap / (KS * KS) - R;
+            const int w = (int)(m % W);
+            long r = m / W;
+            const int h = (int)(r % H);
+            r /= H;
+            const int t = (int)(r % T);
+            const int tt = t + dt, hh = h + dh, ww = w + dw;
+            if (tt >= 0 && tt < T && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                v = x[(m + ((long)dt * H + dh) * W + dw) * Cin + ci];
+        }
+        col[idx] = v;
+    }
+}
+
+extern "C" int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream) {
+    RPB_REQUIRE(x && col && B > 0 && T > 0 && H > 0 && W > 0 && Cin > 0, "im2col: bad arguments");
+    RPB_REQUIRE(KS % 2 == 1 && ldc >= KS * KS * KS * Cin, "im2col: KS=%d must be odd and ldc=%d >= taps*Cin", KS, ldc);
+    const long M = (long)B * T * H * W;
+    long grid = (M * ldc + 255) / 256;
+    const long cap = (long)rpb_num_cus() * 32;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, col, M, T, H, W, Cin, KS, ldc);
+    RPB_CHECK_LAUNCH("im2col");
+}
+
+// ---------------------------------------------------------------------------------- temporal attention
+// Attention over the f = T frames of one spatial location (unet.py:280-356 under EinopsToAndFrom 'b c f h w' ->
+// 'b (h w) f c', :388): 4 heads x 32, q scaled by 32^-1/2, rotary position embedding on q and k, T5 relative-position
+// bias added to the logits, softmax.  qkv is the token tensor [B][T][HW][3*128] produced by the to_qkv GEMM.
+// A half-wave owns one (location, head) unit: lane i < T is query / key row i; rows live in +1-padded LDS tiles so both
+// "my row" (stride 33) and "everyone reads row j" (broadcast) accesses are conflict-free.  The backward recomputes the
+// probabilities, accumulates the bias gradient in registers across the units a wave walks (waves keep a fixed head) and
+// writes one partial row per half-wave.
+#define TA_TMAX 32
+#define TA_D 32
+#define TA_XS 33
+
+struct TAttnArgs {
+    const float* qkv;    // [B][T][HW][384]
+    const float* rcos;   // [T][32] rotary tables (angle[t][d] = t * freq[d/2])
+    const float* rsin;
+    const float* bias;   // [4][T][T]
+    float* out;          // fwd: [B][T][HW][128]
+    const float* go;     // bwd: gradient of out
+    float* gqkv;         // bwd: [B][T][HW][384]
+    float* part;         // bwd: [slots][T*T] bias-gradient partials; slot % 4 = head
+    long nloc;           // B * HW locations
+    int T, HW;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tattn_kernel(TAttnArgs a) {
+    extern __shared__ float lds[];
+    const int T = a.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hl = lane >> 5, i = lane & 31;                    // half-wave, row
+    const int head = wave;                                       // 4 waves = 4 heads
+    const int unit_lds = (BWD ? 4 * T * TA_XS + 2 * T * (T + 1) : 3 * T * TA_XS);
+    float* base = lds + (wave * 2 + hl) * unit_lds;
+    float* Ql = base;
+    float* Kl = Ql + T * TA_XS;
+    float* Vl = Kl + T * TA_XS;
+    float* Gl = Vl + T * TA_XS;                                   // BWD: go rows
+    float* Pl = Gl + T * TA_XS;                                   // BWD: [T][T+1] probabilities
+    float* Sl = Pl + T * (T + 1);                                 // BWD: [T][T+1] d logits
+    const float scale = 0.17677669529663687f;                     // 32^-1/2
+    float dbias[TA_TMAX];
+#pragma unroll
+    for (int j = 0; j < TA_TMAX; ++j) dbias[j] = 0.f;
+    const long nslot = (long)gridDim.x * 2;                       // half-waves per head
+    for (long loc = (long)blockIdx.x * 2 + hl; loc < a.nloc; loc += nslot) {
+        const long b = loc / a.HW;
+        const int hw = (int)(loc - b * a.HW);
+        // ---- stage raw q, k, v (and go) rows: 32 lanes x 1 float = one 128 B row per step
+        for (int t = 0; t < T; ++t) {
+            const long tok = (b * T + t) * a.HW + hw;
+            const float* src = a.qkv + tok * 384 + head * TA_D + i;
+            Ql[t * TA_XS + i] = src[0];
+            Kl[t * TA_XS + i] = src[128];
+            Vl[t * TA_XS + i] = src[256];
+            if (BWD) Gl[t * TA_XS + i] = a.go[tok * 128 + head * TA_D + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- rotary on q (with the 32^-1/2 scale) and k, in place: element (t, d) pairs with (t, d ^ 1)
+        for (int t = 0; t < T; ++t) {
+            const float c = a.rcos[t * TA_D + i], s = a.rsin[t * TA_D + i];
+            const float q0 = Ql[t * TA_XS + i], q1 = Ql[t * TA_XS + (i ^ 1)];
+            const float k0 = Kl[t * TA_XS + i], k1 = Kl[t * TA_XS + (i ^ 1)];
+            const float sg = (i & 1) ? 1.f : -1.f;                // rot(x)[2p] = -x[2p+1], rot(x)[2p+1] = x[2p]
+            __builtin_amdgcn_wave_barrier();
+            Ql[t * TA_XS + i] = (q0 * c + sg * q1 * s) * scale;
+            Kl[t * TA_XS + i] = k0 * c + sg * k1 * s;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- logits of my row, softmax
+        float p[TA_TMAX];
+        float mx = -3.0e38f;
+        if (i < T) {
+#pragma unroll
+            for (int j = 0; j < TA_TMAX; ++j) {
+                float s = -3.0e38f;
+                if (j < T) {
+                    s = a.bias[(head * T + i) * T + j];
+                    for (int d = 0; d < TA_D; ++d) s += Ql[i * TA_XS + d] * Kl[j * TA_XS + d];
+                }
+                p[j] = s;
+                mx = fmaxf(mx, s);
+            }
+            float z = 0.f;
+#pragma unroll
+            for (int j = 0; j < TA_TMAX; ++j) {
+                p[j] = (j < T) ? __expf(p[j] - mx) : 0.f;
+                z += p[j];
+            }
+            const float iz = 1.0f / z;
+#pragma unroll
+            for (int j = 0; j < TA_TMAX; ++j) p[j] *= iz;
+        }
+        if (!BWD) {
+            if (i < T) {
+                float* dst = a.out + ((b * T + i) * a.HW + hw) * 128 + head * TA_D;
+                for (int d0 = 0; d0 < TA_D; d0 += 4) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < TA_TMAX; ++j)
+                        if (j < T) {
+                            o[0] += p[j] * Vl[j * TA_XS + d0];
+                            o[1] += p[j] * Vl[j * TA_XS + d0 + 1];
+                            o[2] += p[j] * Vl[j * TA_XS + d0 + 2];
+                            o[3] += p[j] * Vl[j * TA_XS + d0 + 3];
+                        }
+                    *reinterpret_cast<f32x4*>(dst + d0) = o;
+                }
+            }
+        } else {
+            // ---- d logits of my row: dp_j = go_i . v_j ; ds_j = p_j (dp_j - sum_j' p_j' dp_j')
+            float ds[TA_TMAX];
+            if (i < T) {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < TA_TMAX; ++j) {
+                    float dp = 0.f;
+                    if (j < T)
+                        for (int d = 0; d < TA_D; ++d) dp += Gl[i * TA_XS + d] * Vl[j * TA_XS + d];
+                    ds[j] = dp;
+                    dot += p[j] * dp;
+                }
+#pragma unroll
+                for (int j = 0; j < TA_TMAX; ++j) {
+                    ds[j] = p[j] * (ds[j] - dot);
+                    dbias[j] += ds[j];
+                    if (j < T) {
+                        Pl[i * (T + 1) + j] = p[j];
+                        Sl[i * (T + 1) + j] = ds[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- row i of dq (rotated frame), dk, dv
+            float* gq = a.gqkv + ((b * T + (i < T ? i : 0)) * a.HW + hw) * 384 + head * TA_D;
+            // d v_i[d] = sum_r P[r][i] go_r[d] ; d k~_i[d] = sum_r dS[r][i] q~_r[d] ; d q~_i[d] = sum_j dS[i][j] k~_j[d]
+            // the rotation R_t is orthogonal: d q_i = scale * R_i^T d q~_i, d k_i = R_i^T d k~_i
+            if (i < T) {
+                for (int d = 0; d < TA_D; d += 2) {             // one rotary pair (d, d+1) at a time
+                    float dv0 = 0.f, dv1 = 0.f, dk0 = 0.f, dk1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+                    for (int r = 0; r < T; ++r) {
+                        const float pr = Pl[r * (T + 1) + i], sr = Sl[r * (T + 1) + i], si = Sl[i * (T + 1) + r];
+                        dv0 += pr * Gl[r * TA_XS + d];
+                        dv1 += pr * Gl[r * TA_XS + d + 1];
+                        dk0 += sr * Ql[r * TA_XS + d];
+                        dk1 += sr * Ql[r * TA_XS + d + 1];
+                        dq0 += si * Kl[r * TA_XS + d];
+                        dq1 += si * Kl[r * TA_XS + d + 1];
+                    }
+                    gq[256 + d] = dv0;
+                    gq[256 + d + 1] = dv1;
+                    // R^T (y0, y1) = (y0 c + y1 s, -y0 s + y1 c)
+                    const float c = a.rcos[i * TA_D + d], sn = a.rsin[i * TA_D + d];
+                    gq[d] = (dq0 * c + dq1 * sn) * scale;
+                    gq[d + 1] = (-dq0 * sn + dq1 * c) * scale;
+                    gq[128 + d] = dk0 * c + dk1 * sn;
+                    gq[128 + d + 1] = -dk0 * sn + dk1 * c;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (BWD && i < T) {
+        float* row = a.part + (((long)blockIdx.x * 2 + hl) * 4 + head) * T * T + i * T;
+#pragma unroll
+        for (int j = 0; j < TA_TMAX; ++j)
+            if (j < T) row[j] = dbias[j];
+    }
+}
+
+extern "C" int rpb_tattn_blocks(long nloc) {
+    long g = (nloc + 1) / 2;
+    const long cap = (long)rpb_num_cus() * 4;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+static int tattn_launch(bool bwd, TAttnArgs& a, hipStream_t st) {
+    RPB_REQUIRE(a.qkv && a.rcos && a.rsin && a.bias && a.nloc > 0 && a.HW > 0, "tattn: bad arguments");
+    RPB_REQUIRE(a.T >= 1 && a.T <= TA_TMAX, "tattn: T=%d frames, the kernel holds up to %d", a.T, TA_TMAX);
+    const int T = a.T;
+    const size_t unit = bwd ? 4 * T * TA_XS + 2 * T * (T + 1) : 3 * T * TA_XS;
+    const size_t lds = unit * 8 * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "tattn: T=%d does not fit LDS", T);
+    const int grid = rpb_tattn_blocks(a.nloc);
+    if (bwd) {
+        (void)hipFuncSetAttribute((const void*)tattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(tattn_kernel<true>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)tattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(tattn_kernel<false>, dim3(grid), dim3(256), lds, st, a);
+    }
+    RPB_CHECK_LAUNCH("tattn");
+}
+
+extern "C" int rpb_tattn_fwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, float* out, int B,
+                             int T, int HW, void* stream) {
+    RPB_REQUIRE(out, "tattn_fwd: null out");
+    TAttnArgs a{};
+    a.qkv = qkv; a.rcos = rcos; a.rsin = rsin; a.bias = bias; a.out = out; a.nloc = (long)B * HW; a.T = T; a.HW = HW;
+    return tattn_launch(false, a, (hipStream_t)stream);
+}
+
+/* part[rpb_tattn_blocks(B*HW) * 2 * 4][T*T]: row r belongs to head r % 4 (d bias[head] = sum of its rows). */
+extern "C" int rpb_tattn_bwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, const float* go,
+                             float* gqkv, float* part, int B, int T, int HW, void* stream) {
+    RPB_REQUIRE(go && gqkv && part, "tattn_bwd: null pointer");
+    TAttnArgs a{};
+    a.qkv = qkv; a.rcos = rcos; a.rsin = rsin; a.bias = bias; a.go = go; a.gqkv = gqkv; a.part = part;
+    a.nloc = (long)B * HW; a.T = T; a.HW = HW;
+    return tattn_launch(true, a, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------- bottleneck spatial attention
+// Softmax attention over the n = h*w tokens of one frame at the lowest resolution (unet.py:455-457: Attention under
+// EinopsToAndFrom 'b c f h w' -> 'b f (h w) c'; 4 heads x 32, q scaled, no rotary, no bias).  One workgroup per
+// (frame, head), one thread per token: K and V of the frame sit in LDS (n * 256 B) and every thread runs an online
+// softmax over them with its query row in registers (flash-attention style, nothing n x n is ever stored).  The forward
+// keeps the row log-sum-exp; the backward recomputes the probabilities twice -- thread = query for d q, then (Q and the
+// output gradient in LDS) thread = key for d k, d v.
+#define SA_D 32
+
+struct SAttnArgs {
+    const float* qkv;    // [F][n][384]
+    float* out;          // fwd: [F][n][128]
+    float* lse;          // [F][4][n] row log-sum-exp (natural log) of the scaled logits
+    const float* o;      // bwd: forward output
+    const float* go;     // bwd
+    float* gqkv;         // bwd: [F][n][384]
+    int n;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void sattn_kernel(SAttnArgs a) {
+    extern __shared__ float lds[];
+    const int n = a.n, i = threadIdx.x;
+    const int f = blockIdx.x >> 2, head = blockIdx.x & 3;
+    float* Kl = lds;                  // [n][32]   (bwd pass B: scaled Q)
+    float* Vl = lds + n * SA_D;       // [n][32]   (bwd pass B: gO)
+    float* Ll = Vl + n * SA_D;        // bwd pass B: [n] lse, [n] D
+    const float scale = 0.17677669529663687f;
+    const float* base = a.qkv + ((long)f * n) * 384 + head * SA_D;
+    for (int idx = threadIdx.x; idx < n * (SA_D / 4); idx += blockDim.x) {
+        const int r = idx >> 3, c = (idx & 7) * 4;
+        *reinterpret_cast<f32x4*>(Kl + r * SA_D + c) = *reinterpret_cast<const f32x4*>(base + (long)r * 384 + 128 + c);
+        *reinterpret_cast<f32x4*>(Vl + r * SA_D + c) = *reinterpret_cast<const f32x4*>(base + (long)r * 384 + 256 + c);
+    }
+    __syncthreads();
+    float q[SA_D];
+    const bool live = i < n;
+#pragma unroll
+    for (int d = 0; d < SA_D; ++d) q[d] = live ? base[(long)i * 384 + d] * scale : 0.f;
+    if (!BWD) {
+        float m = -3.0e38f, l = 0.f, o[SA_D];
+#pragma unroll
+        for (int d = 0; d < SA_D; ++d) o[d] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) s += q[d] * Kl[j * SA_D + d];
+            const float mn = fmaxf(m, s);
+            const float corr = __expf(m - mn), p = __expf(s - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) o[d] = o[d] * corr + p * Vl[j * SA_D + d];
+            m = mn;
+        }
+        if (live) {
+            const float il = 1.0f / l;
+            float* dst = a.out + ((long)f * n + i) * 128 + head * SA_D;
+#pragma unroll
+            for (int d = 0; d < SA_D; d += 4) {
+                f32x4 v = {o[d] * il, o[d + 1] * il, o[d + 2] * il, o[d + 3] * il};
+                *reinterpret_cast<f32x4*>(dst + d) = v;
+            }
+            a.lse[((long)f * 4 + head) * n + i] = m + __logf(l);
+        }
+    } else {
+        // ---- pass A: thread = query i -> d q_i
+        float g[SA_D], dq[SA_D];
+        float Di = 0.f;
+        const long orow = ((long)f * n + (live ? i : 0)) * 128 + head * SA_D;
+#pragma unroll
+        for (int d = 0; d < SA_D; ++d) {
+            g[d] = live ? a.go[orow + d] : 0.f;
+            Di += g[d] * (live ? a.o[orow + d] : 0.f);
+            dq[d] = 0.f;
+        }
+        const float lse = live ? a.lse[((long)f * 4 + head) * n + i] : 0.f;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) {
+                s += q[d] * Kl[j * SA_D + d];
+                dp += g[d] * Vl[j * SA_D + d];
+            }
+            const float ds = __expf(s - lse) * (dp - Di);
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) dq[d] += ds * Kl[j * SA_D + d];
+        }
+        float* gq = a.gqkv + ((long)f * n + (live ? i : 0)) * 384 + head * SA_D;
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < SA_D; d += 4) {
+                f32x4 v = {dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale};
+                *reinterpret_cast<f32x4*>(gq + d) = v;
+            }
+        }
+        // ---- pass B: thread = key j (= i): K/V rows to registers, LDS <- scaled Q, gO, lse, D
+        float kr[SA_D], vr[SA_D];
+#pragma unroll
+        for (int d = 0; d < SA_D; ++d) {
+            kr[d] = live ? Kl[i * SA_D + d] : 0.f;
+            vr[d] = live ? Vl[i * SA_D + d] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) {
+                Kl[i * SA_D + d] = q[d];
+                Vl[i * SA_D + d] = g[d];
+            }
+            Ll[i] = lse;
+            Ll[n + i] = Di;
+        }
+        __syncthreads();
+        float dk[SA_D], dv[SA_D];
+#pragma unroll
+        for (int d = 0; d < SA_D; ++d) dk[d] = dv[d] = 0.f;
+        for (int r = 0; r < n; ++r) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) {
+                s += Kl[r * SA_D + d] * kr[d];
+                dp += Vl[r * SA_D + d] * vr[d];
+            }
+            const float p = __expf(s - Ll[r]);
+            const float ds = p * (dp - Ll[n + r]);
+#pragma unroll
+            for (int d = 0; d < SA_D; ++d) {
+                dv[d] += p * Vl[r * SA_D + d];
+                dk[d] += ds * Kl[r * SA_D + d];
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < SA_D; d += 4) {
+                f32x4 v1 = {dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
+                f32x4 v2 = {dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
+                *reinterpret_cast<f32x4*>(gq + 128 + d) = v1;
+                *reinterpret_cast<f32x4*>(gq + 256 + d) = v2;
+            }
+        }
+    }
+}
+
+static int sattn_launch(bool bwd, SAttnArgs& a, int F, hipStream_t st) {
+    RPB_REQUIRE(a.qkv && a.lse && F > 0 && a.n > 0, "sattn: bad arguments");
+    RPB_REQUIRE(a.n <= 512, "sattn: %d tokens per frame, the kernel holds up to 512 (one thread per token, K/V in LDS)", a.n);
+    const size_t lds = ((size_t)2 * a.n * SA_D + 2 * a.n) * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "sattn: %d tokens per frame do not fit LDS", a.n);
+    const int threads = (a.n + 63) / 64 * 64;
+    if (bwd) {
+        (void)hipFuncSetAttribute((const void*)sattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(sattn_kernel<true>, dim3(F * 4), dim3(threads), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)sattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(sattn_kernel<false>, dim3(F * 4), dim3(threads), lds, st, a);
+    }
+    RPB_CHECK_LAUNCH("sattn");
+}
+
+extern "C" int rpb_sattn_fwd(const float* qkv, float* out, float* lse, int F, int n, void* stream) {
+    RPB_REQUIRE(out, "sattn_fwd: null out");
+    SAttnArgs a{};
+    a.qkv = qkv; a.out = out; a.lse = lse; a.n = n;
+    return sattn_launch(false, a, F, (hipStream_t)stream);
+}
+
+extern "C" int rpb_sattn_bwd(const float* qkv, const float* o, const float* go, float* lse, float* gqkv, int F, int n,
+                             void* stream) {
+    RPB_REQUIRE(o && go && gqkv, "sattn_bwd: null pointer");
+    SAttnArgs a{};
+    a.qkv = qkv; a.o = o; a.go = go; a.lse = lse; a.gqkv = gqkv; a.n = n;
+    return sattn_launch(true, a, F, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------- spatial linear attention
+// SpatialLinearAttention (unet.py:236-261) per frame f = (b, t) with n = h*w tokens, 4 heads x 32:
+//   q' = softmax_d(q) * 32^-1/2 ;  ksoft = softmax_n(k) ;  context[d][e] = sum_n ksoft[n][d] v[n][e] ;
+//   out[n][e] = sum_d context[d][e] q'[n][d]
+// ksoft = E / Z with E = exp(k - kmax[f][c]) and Z[f][c] = sum_n E, so the two token-sized tensors the dense kernels
+// need are q' and E: linattn_prep writes QE[m] = [q' (128) | E (128)] in one pass over the to_qkv output; the 32 x 32
+// per-head products run on rpb_head_scores / rpb_head_apply (the 128 channels taken as 2 x 64, the cross-head 32 x 32
+// blocks are discarded / zero-filled by the host), Z comes from rpb_chan_stats, kmax from rpb_chan_max.
+// Backward: with d q' and d E' (= head_apply(v, dS^T)) in dQE, d Z[f][c] from the host:
+//   d q = q' * (d q' - <q', d q'>_head / scale) ;  d k = (d E' + d Z) * E   (kmax is a constant shift of a softmax).
+struct LinPrepArgs {
+    const float* qkv;    // [F*n][384]
+    const float* kmax;   // [F][128]
+    float* qe;           // fwd out / bwd in: [F*n][256]
+    const float* dqe;    // bwd: [F*n][256]
+    const float* dz;     // bwd: [F][128]
+    float* gqkv;         // bwd: columns 0..255 of [F*n][384]
+    long M;
+    int n;
+};
+
+__device__ __forceinline__ float seg8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ float seg8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+
+// one wave per token: lanes 0..31 hold the 128 q channels (8 lanes = one 32-wide head), lanes 32..63 the 128 k channels
+template <bool BWD>
+__global__ __launch_bounds__(256) void linprep_kernel(LinPrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const bool isq = lane < 32;
+    const int c = (lane & 31) * 4;
+    const float scale = 0.17677669529663687f;
+    for (long m = (long)blockIdx.x * 4 + wave; m < a.M; m += (long)gridDim.x * 4) {
+        const long f = m / a.n;
+        if (!BWD) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.qkv + m * 384 + (isq ? 0 : 128) + c);
+            f32x4 o;
+            if (isq) {
+                const float mx = seg8_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __expf(v[k] - mx);
+                const float inv = scale / seg8_sum(o[0] + o[1] + o[2] + o[3]);
+                o = o * inv;
+            } else {
+                const f32x4 km = *reinterpret_cast<const f32x4*>(a.kmax + f * 128 + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __expf(v[k] - km[k]);
+            }
+            *reinterpret_cast<f32x4*>(a.qe + m * 256 + (isq ? 0 : 128) + c) = o;
+        } else {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(a.qe + m * 256 + (isq ? 0 : 128) + c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.dqe + m * 256 + (isq ? 0 : 128) + c);
+            f32x4 o;
+            if (isq) {
+                const float t = seg8_sum(y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]) * (1.0f / scale);
+                o = y * (g - t);
+            } else {
+                const f32x4 dz = *reinterpret_cast<const f32x4*>(a.dz + f * 128 + c);
+                o = (g + dz) * y;
+            }
+            *reinterpret_cast<f32x4*>(a.gqkv + m * 384 + (isq ? 0 : 128) + c) = o;
+        }
+    }
+}
+
+static int linprep_grid(long M) {
+    long g = (M + 3) / 4;
+    const long cap = (long)rpb_num_cus() * 8;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+extern "C" int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, int n, void* stream) {
+    RPB_REQUIRE(qkv && kmax && qe && F > 0 && n > 0, "linattn_prep_fwd: bad arguments");
+    LinPrepArgs a{};
+    a.qkv = qkv; a.kmax = kmax; a.qe = qe; a.M = (long)F * n; a.n = n;
+    hipLaunchKernelGGL(linprep_kernel<false>, dim3(linprep_grid(a.M)), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("linattn_prep_fwd");
+}
+
+extern "C" int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n,
+                                    void* stream) {
+    RPB_REQUIRE(qe && dqe && dz && gqkv && F > 0 && n > 0, "linattn_prep_bwd: bad arguments");
+    LinPrepArgs a{};
+    a.qe = const_cast<float*>(qe); a.dqe = dqe; a.dz = dz; a.gqkv = gqkv; a.M = (long)F * n; a.n = n;
+    hipLaunchKernelGGL(linprep_kernel<true>, dim3(linprep_grid(a.M)), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("linattn_prep_bwd");
+}
+
+// column maxima / sums of a strided token tensor per frame: part[rpb_chan_blocks(F, n)][F][C]
+// (the host finishes with a max / the fp64 partial reducer).  MODE 0 = max, 1 = sum.
+template <int MODE>
+__global__ __launch_bounds__(UN_THREADS) void colred_kernel(const float* __restrict__ x, float* __restrict__ part, long n,
+                                                            int F, int C, int ldx) {
+    __shared__ f32x4 red[UN_THREADS];
+    const int c4n = C >> 2;
+    const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = UN_THREADS / c4n;
+    const int f = blockIdx.y;
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per;
+    long r1 = r0 + per;
+    if (r1 > n) r1 = n;
+    const float init = MODE == 0 ? -3.0e38f : 0.f;
+    f32x4 acc = {init, init, init, init};
+    for (long r = r0 + sub; r < r1; r += nsub) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)f * n + r) * ldx + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = MODE == 0 ? fmaxf(acc[k], v[k]) : acc[k] + v[k];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sub == 0) {
+        for (int s = 1; s < nsub; ++s) {
+            const f32x4 o = red[s * c4n + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = MODE == 0 ? fmaxf(acc[k], o[k]) : acc[k] + o[k];
+        }
+        *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * F + f) * C + 4 * c4) = acc;
+    }
+}
+
+extern "C" int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream) {
+    RPB_REQUIRE(x && part && F > 0 && n > 0, "col_reduce: bad arguments");
+    RPB_REQUIRE(C % 4 == 0 && UN_THREADS % (C / 4) == 0 && ldx >= C && ldx % 4 == 0, "col_reduce: C=%d ldx=%d unsupported", C, ldx);
+    RPB_REQUIRE(mode == 0 || mode == 1, "col_reduce: mode 0 (max) or 1 (sum)");
+    const dim3 grid(rpb_chan_blocks(F, n), F);
+    if (mode == 0) hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(UN_THREADS), 0, (hipStream_t)stream, x, part, n, F, C, ldx);
+    else hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(UN_THREADS), 0, (hipStream_t)stream, x, part, n, F, C, ldx);
+    RPB_CHECK_LAUNCH("col_reduce");
+}

@@ -37,7 +37,11 @@ def load_model(train_dataset, device="cpu", **kwargs):
         kwargs["shape_out"] = output_shape
         kwargs.pop("config", None)
         model = GalerkinTransformer3d(**kwargs).to(device)
+    elif model_name == "unet":
+        from .unet import Unet3d
+        model = Unet3d(dim=input_shape[1], out_channels=output_shape[-1], dim_mults=kwargs["dim_mults"],   # load_model.py:47-58
+                       channels=input_shape[-1], in_time=input_shape[0], out_time=output_shape[0]).to(device)
     else:
         raise ValueError(f"Model {model_name} not supported by the MI355X backend "
-                         "(supported: fno, transolver, galerkin_transformer)")
+                         "(supported: fno, transolver, galerkin_transformer, unet)")
     return model

@@ -221,28 +221,34 @@ def mul(a, b, out, n):
 
 
 def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
-            pre_out=None, mask=None):
-    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A the implicit 3x3x3 im2col of a token tensor.
-    act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``)."""
+            pre_out=None, mask=None, conv_mode=1, cls=0):
+    """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A an implicit im2col of a token tensor:
+    ``conv_mode`` 1 = 3x3x3 padding 1, 2 = (1,4,4) stride (1,2,2) padding (0,1,1) (M = output tokens), 3 = parity class
+    ``cls`` of the matching transposed convolution (M = input tokens).
+    act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``); 3: ReLU; 4: ReLU'."""
     hc, wc, dc = conv if conv else (0, 0, 0)
-    lda = (K // 27 if conv else K) if lda is None else lda
+    mode = int(conv_mode) if conv else 0
+    taps = {0: 1, 1: 27, 2: 16, 3: 4}[mode]
+    lda = (K // taps) if lda is None else lda
     _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
-              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), _p(mask), int(conv is not None), hc, wc, dc,
+              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), _p(mask), mode, hc, wc, dc, int(cls),
               _stream(),
-              label=f"gemm_nt[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * (M * lda + M * N + N * K),
+              label=f"gemm_nt[N{N},K{K},conv={mode}]", nbytes=4 * (M * lda + M * N + N * K),
               flops=2 * M * N * K)
 
 
-def gemm_tn_splits(M, N, K, conv=False):
-    return _lib.query("rpb_gemm_tn_splits", M, N, K, int(bool(conv)))
+def gemm_tn_splits(M, N, K, conv=False, conv_mode=1):
+    return _lib.query("rpb_gemm_tn_splits", M, N, K, int(conv_mode) if conv else 0)
 
 
-def gemm_tn(G, A, part, M, N, K, ldg=None, lda=None, conv=None):
+def gemm_tn(G, A, part, M, N, K, ldg=None, lda=None, conv=None, conv_mode=1):
     """part[splits][N*K + N]: partials of dW = G^T A(im2col) and db = colsum(G)."""
     hc, wc, dc = conv if conv else (0, 0, 0)
+    mode = int(conv_mode) if conv else 0
+    taps = {0: 1, 1: 27, 2: 16}[mode]
     _lib.call("rpb_gemm_tn", _p(G), _p(A), _p(part), M, N, K, N if ldg is None else ldg,
-              (K // 27 if conv else K) if lda is None else lda, int(conv is not None), hc, wc, dc, _stream(),
-              label=f"gemm_tn[N{N},K{K},conv={int(conv is not None)}]", nbytes=4 * M * (N + (K // 27 if conv else K)),
+              (K // taps) if lda is None else lda, mode, hc, wc, dc, _stream(),
+              label=f"gemm_tn[N{N},K{K},conv={mode}]", nbytes=4 * M * (N + K // taps),
               flops=2 * M * N * K)
 
 
@@ -328,14 +334,84 @@ def head_scores_chunks(B, n):
     return _lib.query("rpb_head_scores_chunks", B, n)
 
 
-def head_scores(G, ldg, A, lda, part, B, n):
-    """part[chunks][B][4][64][64]: per-chunk partials of G_h^T A_h for every sample and head."""
-    _lib.call("rpb_head_scores", _p(G), ldg, _p(A), lda, _p(part), B, n, _stream(), label="head_scores",
-              nbytes=4 * B * n * 512, flops=2 * B * n * 4 * 64 * 64)
+def head_scores(G, ldg, A, lda, part, B, n, nheads=4):
+    """part[chunks][B][nheads][64][64]: per-chunk partials of G_h^T A_h for every sample and 64-channel head."""
+    _lib.call("rpb_head_scores", _p(G), ldg, _p(A), lda, _p(part), B, n, nheads, _stream(), label="head_scores",
+              nbytes=4 * B * n * 128 * nheads, flops=2 * B * n * nheads * 64 * 64)
 
 
-def head_apply(X, ldx, Wm, out, ldo, B, n, residual=None, ldr=0, mask=None, ldm=0):
+def head_apply(X, ldx, Wm, out, ldo, B, n, residual=None, ldr=0, mask=None, ldm=0, nheads=4):
     """out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual."""
-    _lib.call("rpb_head_apply", _p(X), ldx, _p(Wm), _p(out), ldo, _p(residual), ldr, _p(mask), ldm, B, n, _stream(),
-              label="head_apply", nbytes=4 * B * n * 256 * (2 + (residual is not None) + (mask is not None)),
-              flops=2 * B * n * 4 * 64 * 64)
+    _lib.call("rpb_head_apply", _p(X), ldx, _p(Wm), _p(out), ldo, _p(residual), ldr, _p(mask), ldm, B, n, nheads,
+              _stream(), label="head_apply",
+              nbytes=4 * B * n * 64 * nheads * (2 + (residual is not None) + (mask is not None)),
+              flops=2 * B * n * nheads * 64 * 64)
+
+
+# ----------------------------------------------------------------------------- U-Net kernels
+def chan_blocks(B, n):
+    return _lib.query("rpb_chan_blocks", B, n)
+
+
+def chan_stats(x, part, B, n, C):
+    _lib.call("rpb_chan_stats", _p(x), _p(part), B, n, C, _stream(), label="chan_stats", nbytes=4 * B * n * C)
+
+
+def affine_silu_fwd(x, A, Bc, y, B, n, C, res=None):
+    _lib.call("rpb_affine_silu_fwd", _p(x), _p(A), _p(Bc), _p(res), _p(y), B, n, C, _stream(), label="affine_silu_fwd",
+              nbytes=(8 + 4 * (res is not None)) * B * n * C)
+
+
+def affine_silu_bwd_reduce(x, gy, A, Bc, part, B, n, C):
+    _lib.call("rpb_affine_silu_bwd_reduce", _p(x), _p(gy), _p(A), _p(Bc), _p(part), B, n, C, _stream(),
+              label="affine_silu_bwd_reduce", nbytes=8 * B * n * C)
+
+
+def affine_silu_bwd_apply(x, gy, A, Bc, P, Q, gx, B, n, C):
+    _lib.call("rpb_affine_silu_bwd_apply", _p(x), _p(gy), _p(A), _p(Bc), _p(P), _p(Q), _p(gx), B, n, C, _stream(),
+              label="affine_silu_bwd_apply", nbytes=12 * B * n * C)
+
+
+def im2col(x, col, B, T, H, W, Cin, KS, ldc):
+    _lib.call("rpb_im2col", _p(x), _p(col), B, T, H, W, Cin, KS, ldc, _stream(), label="im2col",
+              nbytes=4 * B * T * H * W * (Cin + ldc))
+
+
+def tattn_blocks(nloc):
+    return _lib.query("rpb_tattn_blocks", nloc)
+
+
+def tattn_fwd(qkv, rcos, rsin, bias, out, B, T, HW):
+    _lib.call("rpb_tattn_fwd", _p(qkv), _p(rcos), _p(rsin), _p(bias), _p(out), B, T, HW, _stream(), label="tattn_fwd",
+              nbytes=4 * B * T * HW * 512, flops=4 * B * HW * 4 * T * T * 32)
+
+
+def tattn_bwd(qkv, rcos, rsin, bias, go, gqkv, part, B, T, HW):
+    _lib.call("rpb_tattn_bwd", _p(qkv), _p(rcos), _p(rsin), _p(bias), _p(go), _p(gqkv), _p(part), B, T, HW, _stream(),
+              label="tattn_bwd", nbytes=4 * B * T * HW * 896, flops=10 * B * HW * 4 * T * T * 32)
+
+
+def sattn_fwd(qkv, out, lse, F, n):
+    _lib.call("rpb_sattn_fwd", _p(qkv), _p(out), _p(lse), F, n, _stream(), label="sattn_fwd",
+              nbytes=4 * F * n * 512, flops=4 * F * 4 * n * n * 32)
+
+
+def sattn_bwd(qkv, o, go, lse, gqkv, F, n):
+    _lib.call("rpb_sattn_bwd", _p(qkv), _p(o), _p(go), _p(lse), _p(gqkv), F, n, _stream(), label="sattn_bwd",
+              nbytes=4 * F * n * 1024, flops=14 * F * 4 * n * n * 32)
+
+
+def linattn_prep_fwd(qkv, kmax, qe, F, n):
+    _lib.call("rpb_linattn_prep_fwd", _p(qkv), _p(kmax), _p(qe), F, n, _stream(), label="linattn_prep_fwd",
+              nbytes=4 * F * n * 512)
+
+
+def linattn_prep_bwd(qe, dqe, dz, gqkv, F, n):
+    _lib.call("rpb_linattn_prep_bwd", _p(qe), _p(dqe), _p(dz), _p(gqkv), F, n, _stream(), label="linattn_prep_bwd",
+              nbytes=4 * F * n * 768)
+
+
+def col_reduce(x, ldx, part, F, n, C, mode):
+    """mode 0: per-frame column max partials, 1: column sum partials -- part[chan_blocks(F, n)][F][C]."""
+    _lib.call("rpb_col_reduce", _p(x), ldx, _p(part), F, n, C, int(mode), _stream(), label="col_reduce",
+              nbytes=4 * F * n * C)

@@ -1,0 +1,154 @@
+"""U-Net on MI355X through the C ABI: the new implicit-GEMM gather modes and attention
+kernels vs fp64 PyTorch, and the whole model -- forward, loss, every parameter gradient -- vs the CPU oracle (which is pinned
+to vectors from the imported reference, tests/test_oracle_golden.py) at dim = 64 (the reference's ``dim = H`` rule)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from realpdebench_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.float().cuda().contiguous()
+
+
+def _model(T=2, H=64, W=16, C=3, seed=3):
+    from realpdebench_amd.model.unet import Unet3d
+    torch.manual_seed(seed)
+    m = Unet3d(dim=H, out_channels=C, dim_mults=[1, 2, 4], channels=C, in_time=T, out_time=T)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias") or n.endswith("gamma") or "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    return m
+
+
+def test_strided_and_transposed_conv_modes(ops):
+    torch.manual_seed(0)
+    B, T, H, W, C = 2, 2, 8, 12, 64
+    x = torch.randn(B, C, T, H, W, dtype=torch.float64)
+    wd, bd = torch.randn(C, C, 1, 4, 4, dtype=torch.float64) / 30, torch.randn(C, dtype=torch.float64)
+    from realpdebench_amd.model.unet import Unet3d
+    m = Unet3d(dim=64, out_channels=3, dim_mults=[1], channels=3, in_time=T, out_time=T)
+    tok = lambda t: dev(t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]))
+    # ---- strided conv
+    ref = F.conv3d(x, wd, bd, stride=(1, 2, 2), padding=(0, 1, 1))
+    Wd = dev(wd[:, :, 0].permute(0, 2, 3, 1).reshape(C, -1))
+    y = m._strided(tok(x), Wd, dev(bd), B, (T, H, W), C, C)
+    assert rel_l2(y.cpu(), tok(ref).cpu()) < 3e-6
+    # ---- its weight gradient (TN gather)
+    gy = torch.randn_like(ref)
+    from realpdebench_amd.model.unet import _wgrad
+    dW, db = _wgrad(tok(gy), tok(x), y.shape[0], C, 16 * C, conv=(T, H, W), conv_mode=2)
+    xr, wr = x.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+    F.conv3d(xr, wr, bd, stride=(1, 2, 2), padding=(0, 1, 1)).backward(gy)
+    assert rel_l2(dW.view(C, 4, 4, C).permute(0, 3, 1, 2).cpu(), wr.grad[:, :, 0]) < 1e-5
+    assert rel_l2(db.cpu(), gy.sum((0, 2, 3, 4))) < 1e-5
+    # ---- transposed conv (forward of Upsample == data gradient of the strided conv)
+    wu = torch.randn(C, C, 1, 4, 4, dtype=torch.float64) / 30
+    ref_u = F.conv_transpose3d(x, wu, bd, stride=(1, 2, 2), padding=(0, 1, 1))
+    cls = []
+    for ph in (0, 1):
+        for pw in (0, 1):
+            kh, kw = ((0, 2) if ph else (1, 3)), ((0, 2) if pw else (1, 3))
+            sub = wu[:, :, 0][:, :, list(kh)][:, :, :, list(kw)]
+            cls.append(sub.permute(1, 2, 3, 0).reshape(C, -1))
+    yu = m._transposed(tok(x), dev(torch.stack(cls)), dev(bd), B, (T, H, W), C, C)
+    assert rel_l2(yu.cpu(), tok(ref_u).cpu()) < 3e-6
+
+
+def test_temporal_and_bottleneck_attention_kernels(ops):
+    from oracle import unet_oracle as UO
+    torch.manual_seed(1)
+    B, T, HW = 2, 5, 7
+    qkv = torch.randn(B, T, HW, 384, dtype=torch.float64, requires_grad=True)
+    freqs = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).double()
+    bias = torch.randn(4, T, T, dtype=torch.float64, requires_grad=True)
+    x = qkv.permute(0, 2, 1, 3)                                        # b hw t c
+    q, k, v = (t.reshape(B, HW, T, 4, 32).transpose(-2, -3) for t in x.chunk(3, dim=-1))
+    q = UO.rotary(q * 32 ** -0.5, freqs)
+    k = UO.rotary(k, freqs)
+    attn = (q @ k.transpose(-1, -2) + bias).softmax(-1)
+    o = (attn @ v).transpose(-2, -3).reshape(B, HW, T, 128).permute(0, 2, 1, 3)      # b t hw c
+    go = torch.randn_like(o)
+    o.backward(go)
+    from realpdebench_amd.model.unet import _rotary_tables
+    rc, rs = _rotary_tables(freqs.float().cuda(), T)
+    out = torch.empty(B * T * HW, 128, device="cuda")
+    qd = dev(qkv.detach()).view(-1, 384)
+    ops.tattn_fwd(qd, rc, rs, dev(bias.detach()), out, B, T, HW)
+    assert rel_l2(out.cpu(), o.detach().reshape(-1, 128)) < 1e-5
+    gq = torch.empty_like(qd)
+    rows = ops.tattn_blocks(B * HW) * 8
+    part = torch.empty(rows, T * T, device="cuda")
+    ops.tattn_bwd(qd, rc, rs, dev(bias.detach()), dev(go).view(-1, 128), gq, part, B, T, HW)
+    assert rel_l2(gq.cpu(), qkv.grad.reshape(-1, 384)) < 2e-5
+    db = part.view(rows // 4, 4, T * T).double().sum(0).view(4, T, T).cpu()
+    assert rel_l2(db, bias.grad) < 2e-5
+    # ---- bottleneck softmax attention
+    Fr, n = 3, 70
+    qkv2 = torch.randn(Fr, n, 384, dtype=torch.float64, requires_grad=True)
+    q, k, v = (t.reshape(Fr, n, 4, 32).transpose(1, 2) for t in qkv2.chunk(3, dim=-1))
+    o2 = (((q * 32 ** -0.5) @ k.transpose(-1, -2)).softmax(-1) @ v).transpose(1, 2).reshape(Fr, n, 128)
+    go2 = torch.randn_like(o2)
+    o2.backward(go2)
+    q2 = dev(qkv2.detach()).view(-1, 384)
+    out2, lse = torch.empty(Fr * n, 128, device="cuda"), torch.empty(Fr * 4 * n, device="cuda")
+    ops.sattn_fwd(q2, out2, lse, Fr, n)
+    assert rel_l2(out2.cpu(), o2.detach().reshape(-1, 128)) < 1e-5
+    g2 = torch.empty_like(q2)
+    ops.sattn_bwd(q2, out2, dev(go2).view(-1, 128), lse, g2, Fr, n)
+    assert rel_l2(g2.cpu(), qkv2.grad.reshape(-1, 384)) < 2e-5
+
+
+def _oracle_sd(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def test_forward_matches_oracle():
+    from oracle import unet_oracle as UO
+    m = _model().cuda().eval()
+    x = torch.randn(2, 2, 64, 16, 3)
+    with torch.no_grad():
+        y = m(x.cuda())
+    ref = UO.unet_forward(_oracle_sd(m), x)
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu(), ref) < 2e-5
+
+
+def test_loss_and_gradients_match_oracle():
+    from oracle import unet_oracle as UO
+    m = _model(seed=5).cuda().train()
+    torch.manual_seed(9)
+    x, y = torch.randn(2, 2, 64, 16, 3), torch.randn(2, 2, 64, 16, 3)
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    loss_ref, _, grads_ref = UO.loss_and_grads(_oracle_sd(m), x, y)
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    named = dict(m.named_parameters())
+    worst = []
+    for k, ref in grads_ref.items():
+        g = named[k].grad
+        assert g is not None, k
+        err = rel_l2(g.cpu(), ref) if float(ref.abs().max()) > 1e-7 else float(g.abs().max())
+        worst.append((err, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 1e-3, worst[:8]
+
+
+def test_state_dict_roundtrip_with_reference_fixture():
+    """Reference-named keys / shapes load; the dim=8 fixture is too narrow for the MFMA tiles, so only the contract is checked."""
+    m = _model()
+    sd = m.state_dict()
+    m2 = _model(seed=4)
+    m2.load_state_dict(sd)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
