@@ -471,7 +471,7 @@ static int gemm_tn_nti(int K, int conv) {
     return (Ci % 128 == 0) ? 4 : 2;
 }
 
-static int gemm_tn_wn(int N) { return N > 128 ? 4 : 2; }
+static int gemm_tn_wn(int N) { return N > 128 ? 4 : (N > 64 ? 2 : 1); }      // waves along n: no idle half for N <= 64
 
 extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
     const int wk2 = 64 * gemm_tn_nti(K, conv);
@@ -506,8 +506,10 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
     const int splits = rpb_gemm_tn_splits(M, N, K, conv);
     hipStream_t st = (hipStream_t)stream;
     if (nti == 4 && wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
-    else if (nti == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
+    else if (nti == 4 && wn == 2) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
+    else if (nti == 4 && wn == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), dim3(tiles, splits), dim3(128), 0, st, a);
     else if (wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
+    else if (wn == 1) hipLaunchKernelGGL((gemm_tn_kernel<2, 1>), dim3(tiles, splits), dim3(128), 0, st, a);
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
     RPB_CHECK_LAUNCH("gemm_tn");
 }

@@ -676,7 +676,13 @@ class Unet3d(_ModelBase):
             for n, g in zip(names, gl):
                 if g is not None:
                     tp.pacc(n, g)
-        return tp.pg
+        # the closures on the tape reference the tape (cycles): release the saved activations now, not at the next GC run
+        pg = tp.pg
+        tp.ops.clear()
+        tp.g.clear()
+        tp.leaves.clear()
+        tp.glue = tp.out = None
+        return pg
 
     # ------------------------------------------------------------------ Model protocol
     def forward(self, x, cond=None, null_cond_prob=0.0, focus_present_mask=None, prob_focus_present=0.0):

@@ -90,3 +90,22 @@ def test_device_prefetcher_matches_blocking_path():
     for (gi, gt), (bi, bt) in zip(got, batches):
         ri, rt = norm.preprocess(bi, bt)
         assert torch.equal(gi, ri) and torch.equal(gt, rt)
+
+
+def test_unet_train_then_eval(tmp_path):
+    """Same entrypoints with model_name: unet (reference YAML key surface, reduced mesh; dim = H = 64)."""
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd import train as tr
+    with open(os.path.join(os.path.dirname(tr.__file__), "configs", "cylinder", "unet.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg.update(exp_name="u", results_path=str(tmp_path), shape_in=[2, 64, 16, 3], shape_out=[2, 64, 16, 3], n_train=4, n_val=2,
+               num_update=100, train_batch_size=2, test_batch_size=2, lr=1e-4, N_autoregressive=2)
+    path = tmp_path / "unet.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = tr.main(["--config", str(path), "--max_updates", "4"])
+    ckpts = sorted(glob.glob(os.path.join(exp, "model_*.pth")))
+    ck = torch.load(ckpts[-1], map_location="cpu")
+    assert ck["iteration"] == 4 and "downs.1.4.weight" in ck["model_state_dict"]
+    assert all(l == l and l < 1e3 for l in ck["train_losses"])
+    ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
+    assert os.path.exists(os.path.join(exp, "eval.log"))
