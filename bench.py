@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
     ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
     ap.add_argument("--no-galerkin", action="store_true", help="skip the secondary Galerkin Transformer measurement")
+    ap.add_argument("--no-unet", action="store_true", help="skip the secondary U-Net measurement")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -91,6 +92,56 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+
+
+def bench_unet(dev, steps=2):
+    """U-Net at the reference's configs/cylinder/unet.yaml ([12,20,64,128,3], dim = H = 64 -> 64/128/256 channels,
+    dim_mults [1,2,4]): train step through the drop-in protocol (HIP forward + taped HIP backward, torch.optim.Adam) and
+    eval forward.  fp32 MFMA roofline: SURVEY.md section 8(a8) measured 555 GFLOP forward per sample at 20x64x64 with
+    FlopCounterMode on the oracle; the cylinder mesh has twice the cells -> 1.11 TFLOP forward, x3 for a step."""
+    import yaml
+    from realpdebench_amd.model.unet import Unet3d
+    with open(os.path.join(ROOT, "realpdebench_amd", "configs", "cylinder", "unet.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    T, H, W, C = cfg["shape_in"]
+    B = int(cfg["train_batch_size"])
+    torch.manual_seed(0)
+    m = Unet3d(dim=H, out_channels=cfg["shape_out"][-1], dim_mults=cfg["dim_mults"], channels=C, in_time=T,
+               out_time=cfg["shape_out"][0]).to(dev)
+    x = torch.randn(B, T, H, W, C, device=dev)
+    y = torch.randn(B, *cfg["shape_out"], device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"])
+
+    def step():
+        opt.zero_grad()
+        m.train_loss(x, y).mean().backward()
+        opt.step()
+
+    m.train()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / steps
+    m.eval()
+    with torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / steps
+    flops_step = 3 * 1.11e12 * B
+    del m, opt
+    torch.cuda.empty_cache()
+    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
+            "forward_fields_per_s": B * cfg["shape_out"][0] / t_fwd, "ms_per_forward": 1e3 * t_fwd,
+            "mfma_f32": {"achieved": flops_step / t_train / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops_step / t_train / 1e12 / MFMA_F32_PEAK_TF},
+            "config": "configs/cylinder/unet.yaml: [12,20,64,128,3], dim 64, dim_mults [1,2,4], 4 heads x 32"}
 
 
 def bench_galerkin(dev, steps=3):
@@ -293,6 +344,9 @@ def main():
     galerkin = None
     if not a.no_galerkin and world == 1:
         galerkin = bench_galerkin(dev)
+    unet = None
+    if not a.no_unet and world == 1:
+        unet = bench_unet(dev)
     if world > 1 or force_dp:
         torch.cuda.synchronize()
         _flush_c_stdio()                                    # every rank empties its C stdio buffer (RCCL banner) ...
@@ -332,6 +386,7 @@ def main():
             "rollout": rollout,
             "transolver": transolver,
             "galerkin_transformer": galerkin,
+            "unet": unet,
             "loss": float(loss),
         }
         if not a.no_cpu_baseline and world == 1:
