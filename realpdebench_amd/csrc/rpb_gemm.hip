@@ -485,8 +485,11 @@ struct ConvWgArgs {
 
 #define CW_TOK 32
 
+// NO = co tiles of 32 per workgroup: 2 -> 64 x 576 block (352 registers, 1 wave/SIMD), 1 -> 32 x 576 (2 waves/SIMD)
+template <int NO>
 __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
-    __shared__ float Gs[CW_TOK][64];
+    constexpr int BN = 32 * NO;
+    __shared__ float Gs[CW_TOK][BN];
     __shared__ float Xs[3][CW_TOK + 2][64];
     __shared__ float Vm[3][3][CW_TOK];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
     const int kt = bx % 3;
     bx /= 3;
     const int cib = bx % ncb, cob = bx / ncb;
-    const int n0 = cob * 64, ci0 = cib * 64;
+    const int n0 = cob * BN, ci0 = cib * 64;
     const int nsplit = gridDim.y, split = blockIdx.y;
     const long per = ((a.M + nsplit - 1) / nsplit + CW_TOK - 1) / CW_TOK * CW_TOK;
     const long mb = (long)split * per;
@@ -505,18 +508,21 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
     if (me > a.M) me = a.M;
     const long HW = (long)a.H * a.W;
 
-    f32x16 acc[2][3][2];
+    f32x16 acc[NO][3][2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[o][k][c] = zero16();
-    float bsum[2] = {0.f, 0.f};
+    float bsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bsum[o] = 0.f;
     const bool do_bias = (cib == 0 && kt == 1 && kh == 1);
 
     // staging map: G tile = 512 float4, X tiles = 3 * 34 * 16 = 1632 float4 over 192 threads
-    constexpr int NG = (CW_TOK * 16 + 191) / 192;                     // 3
+    constexpr int G4 = BN / 4;                                        // float4 per G row
+    constexpr int NG = (CW_TOK * G4 + 191) / 192;
     constexpr int NXL = (3 * (CW_TOK + 2) * 16 + 191) / 192;          // 9
     f32x4 pg[NG], px[NXL];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -525,9 +531,9 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + j * 192;
             f32x4 v = z4;
-            if (idx < CW_TOK * 16) {
-                const long m = m0 + (idx >> 4);
-                if (m < me) v = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + n0 + (idx & 15) * 4);
+            if (idx < CW_TOK * G4) {
+                const long m = m0 + idx / G4;
+                if (m < me) v = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + n0 + (idx % G4) * 4);
             }
             pg[j] = v;
         }
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + j * 192;
-            if (idx < CW_TOK * 16) *reinterpret_cast<f32x4*>(&Gs[idx >> 4][(idx & 15) * 4]) = pg[j];
+            if (idx < CW_TOK * G4) *reinterpret_cast<f32x4*>(&Gs[idx / G4][(idx % G4) * 4]) = pg[j];
         }
 #pragma unroll
         for (int j = 0; j < NXL; ++j) {
@@ -579,26 +585,28 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
 #pragma unroll
         for (int s = 0; s < CW_TOK / 2; ++s) {
             const int tk = 2 * s + half;
-            const float a0 = Gs[tk][col], a1 = Gs[tk][32 + col];
-            if (do_bias) {
-                bsum[0] += a0;
-                bsum[1] += a1;
+            float av[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                av[o] = Gs[tk][o * 32 + col];
+                if (do_bias) bsum[o] += av[o];
             }
 #pragma unroll
             for (int k3 = 0; k3 < 3; ++k3) {
                 const float vm = Vm[kh][k3][tk];
                 const float b0 = Xs[kh][tk + k3][col] * vm, b1 = Xs[kh][tk + k3][32 + col] * vm;
-                acc[0][k3][0] = mfma32(a0, b0, acc[0][k3][0]);
-                acc[0][k3][1] = mfma32(a0, b1, acc[0][k3][1]);
-                acc[1][k3][0] = mfma32(a1, b0, acc[1][k3][0]);
-                acc[1][k3][1] = mfma32(a1, b1, acc[1][k3][1]);
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    acc[o][k3][0] = mfma32(av[o], b0, acc[o][k3][0]);
+                    acc[o][k3][1] = mfma32(av[o], b1, acc[o][k3][1]);
+                }
             }
         }
     }
     const long K = 27L * a.Ci;
     float* part = a.part + (long)split * ((long)a.Co * K + a.Co);
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < NO; ++o)
 #pragma unroll
         for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
@@ -611,15 +619,18 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
                 }
     if (do_bias) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
+        for (int o = 0; o < NO; ++o) {
             const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
             if (half == 0) part[(long)a.Co * K + n0 + o * 32 + col] = b;
         }
     }
 }
 
+#ifndef CW_NO
+#define CW_NO 2
+#endif
 static int conv3_wgrad_splits(long M, int Co, int Ci) {
-    const long tiles = (long)(Co / 64) * (Ci / 64) * 3;
+    const long tiles = (long)(Co / (32 * CW_NO)) * (Ci / 64) * 3;
     long s = ((long)rpb_num_cus() * 4 + tiles - 1) / tiles;
     const long cap = (M + 1023) / 1024;                               // at least 1024 tokens per split
     if (s > cap) s = cap;
@@ -666,7 +677,8 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
         RPB_REQUIRE(ldg % 4 == 0 && lda % 4 == 0, "gemm_tn: conv leading dimensions must be multiples of 4");
         ConvWgArgs c{G, A, part, M, N, K / 27, ldg, lda, Hc, Wc, Dc};
         const int sp = conv3_wgrad_splits(M, N, K / 27);
-        hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((N / 64) * (K / 27 / 64) * 3, sp), dim3(192), 0, (hipStream_t)stream, c);
+        hipLaunchKernelGGL(conv3_wgrad_kernel<CW_NO>, dim3((N / (32 * CW_NO)) * (K / 27 / 64) * 3, sp), dim3(192), 0,
+                           (hipStream_t)stream, c);
         RPB_CHECK_LAUNCH("gemm_tn(conv3)");
     }
     const int nti = gemm_tn_nti(K, conv);
