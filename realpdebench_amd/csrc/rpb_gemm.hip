@@ -40,7 +40,9 @@ struct GemmArgs {
     int conv, Hc, Wc, Dc, cls;
 };
 
-template <int WM, int WN, int TM, int TN>
+// CM = implicit-GEMM gather mode (GemmArgs::conv) as a compile-time constant: the plain and 3x3x3 instantiations carry none of
+// the strided / transposed index arithmetic
+template <int WM, int WN, int TM, int TN, int CM>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = WM * WN * 64;
     constexpr int XS = G_BK + 1;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
     const int tile_n = blockIdx.x % ntn;
     const long m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    const int Ci = g.conv == 1 ? g.K / 27 : (g.conv == 2 ? g.K / 16 : (g.conv == 3 ? g.K / 4 : g.K));
+    const int Ci = CM == 1 ? g.K / 27 : (CM == 2 ? g.K / 16 : (CM == 3 ? g.K / 4 : g.K));
 
     // per-thread rows of the A tile (fixed across chunks) and, for the convolution, their mesh coordinates
     int arow[A4];          // row within tile
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         arow[j] = idx / (G_BK / 4);
         const long m = m0 + arow[j];
         am[j] = (m < g.M) ? m : -1;      // validity is tracked in arow_ok (a conv = 2 base token may be negative)
-        if (g.conv == 2 && am[j] >= 0) {                 // m over the output mesh (Hc, Wc/2, Dc/2)
+        if (CM == 2 && am[j] >= 0) {                 // m over the output mesh (Hc, Wc/2, Dc/2)
             const int Wo = g.Wc / 2, Do = g.Dc / 2;
             const long per = (long)g.Hc * Wo * Do;
             const long bb = m / per;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
             aw[j] = 2 * wq - 1;
             ad[j] = 2 * dq - 1;
             am[j] = ((bb * g.Hc + hq) * g.Wc + aw[j]) * g.Dc + ad[j];     // token of tap (0,0); may be "negative-ish" only via the bounds-checked taps
-        } else if (g.conv && am[j] >= 0) {
+        } else if (CM && am[j] >= 0) {
             const long per = (long)g.Hc * g.Wc * g.Dc;
             long r = m % per;
             ad[j] = (int)(r % g.Dc);
@@ -110,14 +112,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         int tap = 0, kk = k0;
         int dh = 0, dw = 0, dd = 0;
         long noff = 0;
-        if (g.conv) {
+        if (CM) {
             tap = k0 / Ci;
             kk = k0 - tap * Ci;
-            if (g.conv == 1) {
+            if (CM == 1) {
                 dh = tap / 9 - 1;
                 dw = (tap / 3) % 3 - 1;
                 dd = tap % 3 - 1;
-            } else if (g.conv == 2) {                 // taps (kw', kd') of the (1,4,4) kernel, relative to tap (0,0)
+            } else if (CM == 2) {                 // taps (kw', kd') of the (1,4,4) kernel, relative to tap (0,0)
                 dw = tap >> 2;
                 dd = tap & 3;
             } else {                                  // transposed class: 2 x 2 taps
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int j = 0; j < A4; ++j) {
             f32x4 v = z4;
             if (arow_ok[j]) {
-                if (g.conv) {
+                if (CM) {
                     const int hh = ah[j] + dh, ww = aw[j] + dw, d2 = ad[j] + dd;
                     if (hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc)
                         v = *reinterpret_cast<const f32x4*>(g.A + (am[j] + noff) * g.lda + kk + 4 * c4);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                 const long mi = m0 + (wm * TM + i) * 32 + mfma_row(lane, r);
                 if (mi < g.M) {
                     long m = mi;
-                    if (g.conv == 3) {                       // (b, t, h, w) -> row (b, t, 2h+ph, 2w+pw) of the up-sampled mesh
+                    if (CM == 3) {                       // (b, t, h, w) -> row (b, t, 2h+ph, 2w+pw) of the up-sampled mesh
                         const long per = (long)g.Wc * g.Dc;
                         const long bt = mi / per;
                         const int r2 = (int)(mi - bt * per);
@@ -234,15 +236,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+template <int WM, int WN, int TM, int TN, int CM>
+static void launch_gemm_cm(const GemmArgs& g, unsigned tiles, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<WM, WN, TM, TN, CM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, CM>), dim3(tiles), dim3(WM * WN * 64), lds, st, g);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_gemm(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)(BM + BN) * (G_BK + 1) * 4;
     const long tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     RPB_REQUIRE(tiles > 0 && tiles < (1L << 31), "gemm: bad tile count");
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN>), dim3((unsigned)tiles), dim3(WM * WN * 64), lds, st, g);
+    switch (g.conv) {
+        case 0: launch_gemm_cm<WM, WN, TM, TN, 0>(g, (unsigned)tiles, lds, st); break;
+        case 1: launch_gemm_cm<WM, WN, TM, TN, 1>(g, (unsigned)tiles, lds, st); break;
+        case 2: launch_gemm_cm<WM, WN, TM, TN, 2>(g, (unsigned)tiles, lds, st); break;
+        default: launch_gemm_cm<WM, WN, TM, TN, 3>(g, (unsigned)tiles, lds, st); break;
+    }
     RPB_CHECK_LAUNCH("gemm_nt");
 }
 
@@ -308,7 +320,7 @@ struct TnVec<4> {
 // NTI = k-tiles (of 32 channels) per wave: wave tile = 64 (n) x 32*NTI (k), workgroup = 2 x 2 waves.
 // WN = waves along n per workgroup (2 or 4): workgroup tile = 64*WN (n) x 64*NTI (k); the bigger tile halves the
 // re-reads of A (every n-tile streams the whole gathered activation tensor once per tap)
-template <int NTI, int WN>
+template <int NTI, int WN, int CM>
 __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     typedef typename TnVec<NTI>::T veci;
     constexpr int WK = 32 * NTI;                       // k columns per wave
@@ -328,14 +340,14 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     const long mb = (long)split * per;
     long me = mb + per;
     if (me > g.M) me = g.M;
-    const int ntap = g.conv == 2 ? 16 : 27;
-    const int Ci = g.conv ? g.K / ntap : g.K;
+    const int ntap = CM == 2 ? 16 : 27;
+    const int Ci = CM ? g.K / ntap : g.K;
     int tap = 0, kk0 = k0, dh = 0, dw = 0, dd = 0;
     long noff = 0;
-    if (g.conv) {
+    if (CM) {
         tap = k0 / Ci;
         kk0 = k0 - tap * Ci;
-        if (g.conv == 1) {
+        if (CM == 1) {
             dh = tap / 9 - 1;
             dw = (tap / 3) % 3 - 1;
             dd = tap % 3 - 1;
@@ -345,10 +357,10 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
             dd = (tap & 3) - 1;
         }
     }
-    const bool tap_ok = !g.conv || tap < ntap;
+    const bool tap_ok = !CM || tap < ntap;
     const int Wo = g.Wc / 2, Do = g.Dc / 2;              // conv = 2: output mesh (Hc, Wo, Do)
     const bool n_ok0 = n0 + col * 2 < g.N, n_ok1 = n0 + col * 2 + 1 < g.N;      // N may be < 64 (e.g. mlp2: 3)
-    const int klim = g.conv ? Ci : g.K;
+    const int klim = CM ? Ci : g.K;
     const long mesh = (long)g.Hc * g.Wc * g.Dc;
 
     f32x16 acc[2][NTI];
@@ -367,12 +379,12 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
     // mesh coordinates are carried incrementally (add 2 with carry): no divisions and ~10 VALU ops per load
     int ld = 0, lw = 0, lh = 0;
     long lbt = 0;                                        // conv = 2: frame index b*T + t of this lane's token
-    if (g.conv == 1) {
+    if (CM == 1) {
         const long r = (mb + half) % mesh;
         ld = (int)(r % g.Dc);
         lw = (int)((r / g.Dc) % g.Wc);
         lh = (int)(r / ((long)g.Dc * g.Wc));
-    } else if (g.conv == 2) {
+    } else if (CM == 2) {
         const long r = mb + half;
         ld = (int)(r % Do);
         lw = (int)((r / Do) % Wo);
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
             veci xq = zi;
             bool ok = tap_ok;
             long atok = m + noff;
-            if (g.conv == 1) {
+            if (CM == 1) {
                 const int hh = lh + dh, ww = lw + dw, d2 = ld + dd;
                 ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
                 ld += 2;                                             // advance this lane to its next token
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
                         if (++lh >= g.Hc) lh = 0;
                     }
                 }
-            } else if (g.conv == 2) {
+            } else if (CM == 2) {
                 const int ww = 2 * lw + dw, d2 = 2 * ld + dd;
                 ok = ok && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
                 atok = (lbt * g.Wc + ww) * g.Dc + d2;
@@ -688,11 +700,20 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
     const int tiles = ((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
     const int splits = rpb_gemm_tn_splits(M, N, K, conv);
     hipStream_t st = (hipStream_t)stream;
-    if (nti == 4 && wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
-    else if (nti == 4 && wn == 2) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
-    else if (nti == 4 && wn == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 1>), dim3(tiles, splits), dim3(128), 0, st, a);
-    else if (wn == 4) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), dim3(tiles, splits), dim3(512), 0, st, a);
-    else if (wn == 1) hipLaunchKernelGGL((gemm_tn_kernel<2, 1>), dim3(tiles, splits), dim3(128), 0, st, a);
-    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3(tiles, splits), dim3(256), 0, st, a);
+#define RPB_TN(NTI_, WN_, CM_) hipLaunchKernelGGL((gemm_tn_kernel<NTI_, WN_, CM_>), dim3(tiles, splits), dim3(WN_ * 128), 0, st, a)
+#define RPB_TN_CM(NTI_, WN_)                      \
+    do {                                          \
+        if (conv == 0) RPB_TN(NTI_, WN_, 0);      \
+        else if (conv == 1) RPB_TN(NTI_, WN_, 1); \
+        else RPB_TN(NTI_, WN_, 2);                \
+    } while (0)
+    if (nti == 4 && wn == 4) RPB_TN_CM(4, 4);
+    else if (nti == 4 && wn == 2) RPB_TN_CM(4, 2);
+    else if (nti == 4 && wn == 1) RPB_TN_CM(4, 1);
+    else if (wn == 4) RPB_TN_CM(2, 4);
+    else if (wn == 1) RPB_TN_CM(2, 1);
+    else RPB_TN_CM(2, 2);
+#undef RPB_TN_CM
+#undef RPB_TN
     RPB_CHECK_LAUNCH("gemm_tn");
 }
