@@ -202,7 +202,7 @@ extern "C" int rpb_im2col(const float* x, float* col, int B, int T, int H, int W
 // writes one partial row per half-wave.
 #define TA_TMAX 32
 #define TA_D 32
-#define TA_XS 33
+#define TA_XS 36             // row stride in LDS: multiple of 4 so that rows are read with one ds_read_b128 per 4 channels
 
 struct TAttnArgs {
     const float* qkv;    // [B][T][HW][384]
@@ -217,12 +217,14 @@ struct TAttnArgs {
     int T, HW;
 };
 
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void tattn_kernel(TAttnArgs a) {
     extern __shared__ float lds[];
     const int T = a.T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hl = lane >> 5, i = lane & 31;                    // half-wave, row
+    const int hl = lane >> 5, i = lane & 31;                    // half-wave, row (and channel while staging)
     const int head = wave;                                       // 4 waves = 4 heads
     const int unit_lds = (BWD ? 4 * T * TA_XS + 2 * T * (T + 1) : 3 * T * TA_XS);
     float* base = lds + (wave * 2 + hl) * unit_lds;
@@ -233,6 +235,9 @@ __global__ __launch_bounds__(256) void tattn_kernel(TAttnArgs a) {
     float* Pl = Gl + T * TA_XS;                                   // BWD: [T][T+1] probabilities
     float* Sl = Pl + T * (T + 1);                                 // BWD: [T][T+1] d logits
     const float scale = 0.17677669529663687f;                     // 32^-1/2
+    const float sg = (i & 1) ? 1.f : -1.f;                        // rot(x)[2p] = -x[2p+1], rot(x)[2p+1] = x[2p]
+    const bool live = i < T;
+    const int ir = live ? i : 0;
     float dbias[TA_TMAX];
 #pragma unroll
     for (int j = 0; j < TA_TMAX; ++j) dbias[j] = 0.f;
@@ -240,121 +245,124 @@ __global__ __launch_bounds__(256) void tattn_kernel(TAttnArgs a) {
     for (long loc = (long)blockIdx.x * 2 + hl; loc < a.nloc; loc += nslot) {
         const long b = loc / a.HW;
         const int hw = (int)(loc - b * a.HW);
-        // ---- stage raw q, k, v (and go) rows: 32 lanes x 1 float = one 128 B row per step
+        // ---- stage rows: lane = channel (one 128 B row per load); rotary (+ the q scale) applied on the way in, the
+        //      partner channel d ^ 1 comes from the neighbouring lane
         for (int t = 0; t < T; ++t) {
             const long tok = (b * T + t) * a.HW + hw;
             const float* src = a.qkv + tok * 384 + head * TA_D + i;
-            Ql[t * TA_XS + i] = src[0];
-            Kl[t * TA_XS + i] = src[128];
+            const float c = a.rcos[t * TA_D + i], sn = a.rsin[t * TA_D + i];
+            const float q0 = src[0], k0 = src[128];
+            const float q1 = __shfl_xor(q0, 1, 64), k1 = __shfl_xor(k0, 1, 64);
+            Ql[t * TA_XS + i] = (q0 * c + sg * q1 * sn) * scale;
+            Kl[t * TA_XS + i] = k0 * c + sg * k1 * sn;
             Vl[t * TA_XS + i] = src[256];
             if (BWD) Gl[t * TA_XS + i] = a.go[tok * 128 + head * TA_D + i];
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- rotary on q (with the 32^-1/2 scale) and k, in place: element (t, d) pairs with (t, d ^ 1)
-        for (int t = 0; t < T; ++t) {
-            const float c = a.rcos[t * TA_D + i], s = a.rsin[t * TA_D + i];
-            const float q0 = Ql[t * TA_XS + i], q1 = Ql[t * TA_XS + (i ^ 1)];
-            const float k0 = Kl[t * TA_XS + i], k1 = Kl[t * TA_XS + (i ^ 1)];
-            const float sg = (i & 1) ? 1.f : -1.f;                // rot(x)[2p] = -x[2p+1], rot(x)[2p+1] = x[2p]
-            __builtin_amdgcn_wave_barrier();
-            Ql[t * TA_XS + i] = (q0 * c + sg * q1 * s) * scale;
-            Kl[t * TA_XS + i] = k0 * c + sg * k1 * s;
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- logits of my row, softmax
+        // ---- my query row in registers; logits against every key row (broadcast float4 reads); softmax
+        f32x4 q[TA_D / 4];
+#pragma unroll
+        for (int d4 = 0; d4 < TA_D / 4; ++d4) q[d4] = *reinterpret_cast<const f32x4*>(Ql + ir * TA_XS + 4 * d4);
         float p[TA_TMAX];
         float mx = -3.0e38f;
-        if (i < T) {
 #pragma unroll
-            for (int j = 0; j < TA_TMAX; ++j) {
-                float s = -3.0e38f;
-                if (j < T) {
-                    s = a.bias[(head * T + i) * T + j];
-                    for (int d = 0; d < TA_D; ++d) s += Ql[i * TA_XS + d] * Kl[j * TA_XS + d];
-                }
-                p[j] = s;
-                mx = fmaxf(mx, s);
+        for (int j = 0; j < TA_TMAX; ++j) {
+            float sc = -3.0e38f;
+            if (j < T) {
+                sc = a.bias[(head * T + ir) * T + j];
+#pragma unroll
+                for (int d4 = 0; d4 < TA_D / 4; ++d4)
+                    sc += dot4(q[d4], *reinterpret_cast<const f32x4*>(Kl + j * TA_XS + 4 * d4));
             }
-            float z = 0.f;
-#pragma unroll
-            for (int j = 0; j < TA_TMAX; ++j) {
-                p[j] = (j < T) ? __expf(p[j] - mx) : 0.f;
-                z += p[j];
-            }
-            const float iz = 1.0f / z;
-#pragma unroll
-            for (int j = 0; j < TA_TMAX; ++j) p[j] *= iz;
+            p[j] = sc;
+            mx = fmaxf(mx, sc);
         }
-        if (!BWD) {
-            if (i < T) {
-                float* dst = a.out + ((b * T + i) * a.HW + hw) * 128 + head * TA_D;
-                for (int d0 = 0; d0 < TA_D; d0 += 4) {
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        float z = 0.f;
 #pragma unroll
-                    for (int j = 0; j < TA_TMAX; ++j)
-                        if (j < T) {
-                            o[0] += p[j] * Vl[j * TA_XS + d0];
-                            o[1] += p[j] * Vl[j * TA_XS + d0 + 1];
-                            o[2] += p[j] * Vl[j * TA_XS + d0 + 2];
-                            o[3] += p[j] * Vl[j * TA_XS + d0 + 3];
-                        }
-                    *reinterpret_cast<f32x4*>(dst + d0) = o;
-                }
+        for (int j = 0; j < TA_TMAX; ++j) {
+            p[j] = (j < T) ? __expf(p[j] - mx) : 0.f;
+            z += p[j];
+        }
+        const float iz = 1.0f / z;
+#pragma unroll
+        for (int j = 0; j < TA_TMAX; ++j) p[j] *= iz;
+        if (!BWD) {
+            float* dst = a.out + ((b * T + ir) * a.HW + hw) * 128 + head * TA_D;
+            for (int d4 = 0; d4 < TA_D / 4; ++d4) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < TA_TMAX; ++j)
+                    if (j < T) o += *reinterpret_cast<const f32x4*>(Vl + j * TA_XS + 4 * d4) * p[j];
+                if (live) *reinterpret_cast<f32x4*>(dst + 4 * d4) = o;
             }
         } else {
             // ---- d logits of my row: dp_j = go_i . v_j ; ds_j = p_j (dp_j - sum_j' p_j' dp_j')
+            f32x4 g[TA_D / 4];
+#pragma unroll
+            for (int d4 = 0; d4 < TA_D / 4; ++d4) g[d4] = *reinterpret_cast<const f32x4*>(Gl + ir * TA_XS + 4 * d4);
             float ds[TA_TMAX];
-            if (i < T) {
-                float dot = 0.f;
+            float dot = 0.f;
 #pragma unroll
-                for (int j = 0; j < TA_TMAX; ++j) {
-                    float dp = 0.f;
-                    if (j < T)
-                        for (int d = 0; d < TA_D; ++d) dp += Gl[i * TA_XS + d] * Vl[j * TA_XS + d];
-                    ds[j] = dp;
-                    dot += p[j] * dp;
+            for (int j = 0; j < TA_TMAX; ++j) {
+                float dp = 0.f;
+                if (j < T) {
+#pragma unroll
+                    for (int d4 = 0; d4 < TA_D / 4; ++d4)
+                        dp += dot4(g[d4], *reinterpret_cast<const f32x4*>(Vl + j * TA_XS + 4 * d4));
                 }
+                ds[j] = dp;
+                dot += p[j] * dp;
+            }
 #pragma unroll
-                for (int j = 0; j < TA_TMAX; ++j) {
-                    ds[j] = p[j] * (ds[j] - dot);
-                    dbias[j] += ds[j];
-                    if (j < T) {
-                        Pl[i * (T + 1) + j] = p[j];
-                        Sl[i * (T + 1) + j] = ds[j];
-                    }
+            for (int j = 0; j < TA_TMAX; ++j) {
+                ds[j] = p[j] * (ds[j] - dot);
+                if (live) dbias[j] += ds[j];
+                if (live && j < T) {
+                    Pl[i * (T + 1) + j] = p[j];
+                    Sl[i * (T + 1) + j] = ds[j];
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- row i of dq (rotated frame), dk, dv
-            float* gq = a.gqkv + ((b * T + (i < T ? i : 0)) * a.HW + hw) * 384 + head * TA_D;
-            // d v_i[d] = sum_r P[r][i] go_r[d] ; d k~_i[d] = sum_r dS[r][i] q~_r[d] ; d q~_i[d] = sum_j dS[i][j] k~_j[d]
-            // the rotation R_t is orthogonal: d q_i = scale * R_i^T d q~_i, d k_i = R_i^T d k~_i
-            if (i < T) {
-                for (int d = 0; d < TA_D; d += 2) {             // one rotary pair (d, d+1) at a time
-                    float dv0 = 0.f, dv1 = 0.f, dk0 = 0.f, dk1 = 0.f, dq0 = 0.f, dq1 = 0.f;
-                    for (int r = 0; r < T; ++r) {
-                        const float pr = Pl[r * (T + 1) + i], sr = Sl[r * (T + 1) + i], si = Sl[i * (T + 1) + r];
-                        dv0 += pr * Gl[r * TA_XS + d];
-                        dv1 += pr * Gl[r * TA_XS + d + 1];
-                        dk0 += sr * Ql[r * TA_XS + d];
-                        dk1 += sr * Ql[r * TA_XS + d + 1];
-                        dq0 += si * Kl[r * TA_XS + d];
-                        dq1 += si * Kl[r * TA_XS + d + 1];
+            // ---- column i of P and dS in registers (p / q are dead by now)
+            float pc[TA_TMAX], sc2[TA_TMAX];
+#pragma unroll
+            for (int r = 0; r < TA_TMAX; ++r) {
+                pc[r] = (r < T) ? Pl[r * (T + 1) + ir] : 0.f;
+                sc2[r] = (r < T) ? Sl[r * (T + 1) + ir] : 0.f;
+            }
+            // d v_i = sum_r P[r][i] go_r ; d k~_i = sum_r dS[r][i] q~_r ; d q~_i = sum_j dS[i][j] k~_j ; the rotation R_t is
+            // orthogonal: d q_i = scale * R_i^T d q~_i, d k_i = R_i^T d k~_i with R^T (y0, y1) = (y0 c + y1 s, -y0 s + y1 c)
+            float* gq = a.gqkv + ((b * T + ir) * a.HW + hw) * 384 + head * TA_D;
+            for (int d4 = 0; d4 < TA_D / 4; ++d4) {
+                f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = dv, dq = dv;
+#pragma unroll
+                for (int r = 0; r < TA_TMAX; ++r)
+                    if (r < T) {
+                        dv += *reinterpret_cast<const f32x4*>(Gl + r * TA_XS + 4 * d4) * pc[r];
+                        dk += *reinterpret_cast<const f32x4*>(Ql + r * TA_XS + 4 * d4) * sc2[r];
+                        dq += *reinterpret_cast<const f32x4*>(Kl + r * TA_XS + 4 * d4) * ds[r];
                     }
-                    gq[256 + d] = dv0;
-                    gq[256 + d + 1] = dv1;
-                    // R^T (y0, y1) = (y0 c + y1 s, -y0 s + y1 c)
-                    const float c = a.rcos[i * TA_D + d], sn = a.rsin[i * TA_D + d];
-                    gq[d] = (dq0 * c + dq1 * sn) * scale;
-                    gq[d + 1] = (-dq0 * sn + dq1 * c) * scale;
-                    gq[128 + d] = dk0 * c + dk1 * sn;
-                    gq[128 + d + 1] = -dk0 * sn + dk1 * c;
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.rcos + ir * TA_D + 4 * d4);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.rsin + ir * TA_D + 4 * d4);
+                f32x4 oq, ok;
+                oq[0] = (dq[0] * c4[0] + dq[1] * s4[0]) * scale;
+                oq[1] = (-dq[0] * s4[0] + dq[1] * c4[0]) * scale;
+                oq[2] = (dq[2] * c4[2] + dq[3] * s4[2]) * scale;
+                oq[3] = (-dq[2] * s4[2] + dq[3] * c4[2]) * scale;
+                ok[0] = dk[0] * c4[0] + dk[1] * s4[0];
+                ok[1] = -dk[0] * s4[0] + dk[1] * c4[0];
+                ok[2] = dk[2] * c4[2] + dk[3] * s4[2];
+                ok[3] = -dk[2] * s4[2] + dk[3] * c4[2];
+                if (live) {
+                    *reinterpret_cast<f32x4*>(gq + 4 * d4) = oq;
+                    *reinterpret_cast<f32x4*>(gq + 128 + 4 * d4) = ok;
+                    *reinterpret_cast<f32x4*>(gq + 256 + 4 * d4) = dv;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (BWD && i < T) {
+    if (BWD && live) {
         float* row = a.part + (((long)blockIdx.x * 2 + hl) * 4 + head) * T * T + i * T;
 #pragma unroll
         for (int j = 0; j < TA_TMAX; ++j)
