@@ -485,8 +485,8 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
 // the convolution gradient at half the speed of the forward GEMM.  Here a workgroup owns a 64 (co) x [3 kh][3 kw][64 ci]
 // block of dW for one kt and a token split: per 32-token chunk it stages the G rows (8 KB) and, per kh, ONE run of 34
 // consecutive x rows (tokens m0-1 .. m0+32 shifted by (kt*H + kh)*W) that serves all three kw taps -- 34 KB of L2 traffic
-// for 3 x 192 MFMAs (69 flop/B).  Wave = kh; both MFMA operands are read from LDS "row = token, lanes across channels"
-// (conflict-free, no transposition); mesh-boundary validity is a 0/1 factor per (token, tap) applied to the x operand.
+// for 576 MFMAs (69 flop/B).  Both MFMA operands are read from LDS "row = token, lanes across channels" (conflict-free,
+// no transposition); mesh-boundary validity is a 0/1 factor per (token, tap) applied to the x operand.
 struct ConvWgArgs {
     const float* G;      // [M][ldg]
     const float* X;      // [M][ldx]
@@ -497,61 +497,55 @@ struct ConvWgArgs {
 
 #define CW_TOK 32
 
-// NO = co tiles of 32 per workgroup: 2 -> 64 x 576 block (352 registers, 1 wave/SIMD), 1 -> 32 x 576 (2 waves/SIMD)
-template <int NO>
-__global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
-    constexpr int BN = 32 * NO;
-    __shared__ float Gs[CW_TOK][BN];
+// Workgroup = 4 waves, one per (co half o, ci half c) of the 64 x 64 channel block; every wave accumulates all nine
+// (kh, kw) taps of its 32 x 32 sub-block (9 MFMA tiles = 144 accumulator registers), so all four SIMDs of the CU are busy
+// (a 3-wave "wave = kh" mapping with 64 x 192 wave tiles left one SIMD idle: 67-73 TF/s instead of 75-81).  The chunk tiles
+// are single-buffered on purpose: the double-buffered, one-barrier-per-chunk variant measured 4 % slower.
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
+    __shared__ float Gs[CW_TOK][64];
     __shared__ float Xs[3][CW_TOK + 2][64];
-    __shared__ float Vm[3][3][CW_TOK];
+    __shared__ float Vm[9][CW_TOK];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int kh = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = kh tap
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int o = wave & 1, c = wave >> 1;
     const int col = lane & 31, half = lane >> 5;
     const int ncb = a.Ci / 64;
     int bx = blockIdx.x;
     const int kt = bx % 3;
     bx /= 3;
     const int cib = bx % ncb, cob = bx / ncb;
-    const int n0 = cob * BN, ci0 = cib * 64;
+    const int n0 = cob * 64, ci0 = cib * 64;
     const int nsplit = gridDim.y, split = blockIdx.y;
     const long per = ((a.M + nsplit - 1) / nsplit + CW_TOK - 1) / CW_TOK * CW_TOK;
     const long mb = (long)split * per;
     long me = mb + per;
     if (me > a.M) me = a.M;
-    const long HW = (long)a.H * a.W;
 
-    f32x16 acc[NO][3][2];
+    f32x16 acc[9];
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[o][k][c] = zero16();
-    float bsum[NO];
-#pragma unroll
-    for (int o = 0; o < NO; ++o) bsum[o] = 0.f;
-    const bool do_bias = (cib == 0 && kt == 1 && kh == 1);
+    for (int k = 0; k < 9; ++k) acc[k] = zero16();
+    float bsum = 0.f;
+    const bool do_bias = (cib == 0 && kt == 1 && c == 0);
 
-    // staging map: G tile = 512 float4, X tiles = 3 * 34 * 16 = 1632 float4 over 192 threads
-    constexpr int G4 = BN / 4;                                        // float4 per G row
-    constexpr int NG = (CW_TOK * G4 + 191) / 192;
-    constexpr int NXL = (3 * (CW_TOK + 2) * 16 + 191) / 192;          // 9
+    // staging map: G tile = 512 float4, X tiles = 3 * 34 * 16 = 1632 float4 over 256 threads
+    constexpr int NG = (CW_TOK * 16 + 255) / 256;                     // 2
+    constexpr int NXL = (3 * (CW_TOK + 2) * 16 + 255) / 256;          // 7
     f32x4 pg[NG], px[NXL];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     auto prefetch = [&](long m0) {
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int idx = tid + j * 192;
+            const int idx = tid + j * 256;
             f32x4 v = z4;
-            if (idx < CW_TOK * G4) {
-                const long m = m0 + idx / G4;
-                if (m < me) v = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + n0 + (idx % G4) * 4);
+            if (idx < CW_TOK * 16) {
+                const long m = m0 + (idx >> 4);
+                if (m < me) v = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + n0 + (idx & 15) * 4);
             }
             pg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NXL; ++j) {
-            const int idx = tid + j * 192;
+            const int idx = tid + j * 256;
             f32x4 v = z4;
             if (idx < 3 * (CW_TOK + 2) * 16) {
                 const int k2 = idx / ((CW_TOK + 2) * 16), rem = idx - k2 * (CW_TOK + 2) * 16;
@@ -566,12 +560,12 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
         __syncthreads();                                              // previous chunk's LDS reads are done
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const int idx = tid + j * 192;
-            if (idx < CW_TOK * G4) *reinterpret_cast<f32x4*>(&Gs[idx / G4][(idx % G4) * 4]) = pg[j];
+            const int idx = tid + j * 256;
+            if (idx < CW_TOK * 16) *reinterpret_cast<f32x4*>(&Gs[idx >> 4][(idx & 15) * 4]) = pg[j];
         }
 #pragma unroll
         for (int j = 0; j < NXL; ++j) {
-            const int idx = tid + j * 192;
+            const int idx = tid + j * 256;
             if (idx < 3 * (CW_TOK + 2) * 16) {
                 const int k2 = idx / ((CW_TOK + 2) * 16), rem = idx - k2 * (CW_TOK + 2) * 16;
                 *reinterpret_cast<f32x4*>(&Xs[k2][rem >> 4][(rem & 15) * 4]) = px[j];
@@ -589,7 +583,7 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
 #pragma unroll
                 for (int k3 = 0; k3 < 3; ++k3) {
                     const int hh = h + k2 - 1, ww = w + k3 - 1;
-                    Vm[k2][k3][tid] = (okt && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? 1.f : 0.f;
+                    Vm[k2 * 3 + k3][tid] = (okt && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? 1.f : 0.f;
                 }
         }
         __syncthreads();
@@ -597,52 +591,35 @@ __global__ __launch_bounds__(192) void conv3_wgrad_kernel(ConvWgArgs a) {
 #pragma unroll
         for (int s = 0; s < CW_TOK / 2; ++s) {
             const int tk = 2 * s + half;
-            float av[NO];
+            const float av = Gs[tk][o * 32 + col];
+            if (do_bias) bsum += av;
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                av[o] = Gs[tk][o * 32 + col];
-                if (do_bias) bsum[o] += av[o];
-            }
+            for (int k2 = 0; k2 < 3; ++k2)
 #pragma unroll
-            for (int k3 = 0; k3 < 3; ++k3) {
-                const float vm = Vm[kh][k3][tk];
-                const float b0 = Xs[kh][tk + k3][col] * vm, b1 = Xs[kh][tk + k3][32 + col] * vm;
-#pragma unroll
-                for (int o = 0; o < NO; ++o) {
-                    acc[o][k3][0] = mfma32(av[o], b0, acc[o][k3][0]);
-                    acc[o][k3][1] = mfma32(av[o], b1, acc[o][k3][1]);
-                }
-            }
+                for (int k3 = 0; k3 < 3; ++k3)
+                    acc[k2 * 3 + k3] = mfma32(av, Xs[k2][tk + k3][c * 32 + col] * Vm[k2 * 3 + k3][tk], acc[k2 * 3 + k3]);
         }
     }
     const long K = 27L * a.Ci;
     float* part = a.part + (long)split * ((long)a.Co * K + a.Co);
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
+    for (int k2 = 0; k2 < 3; ++k2)
 #pragma unroll
         for (int k3 = 0; k3 < 3; ++k3)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + o * 32 + mfma_row(lane, r);
-                    const long k = ((long)(kt * 3 + kh) * 3 + k3) * a.Ci + ci0 + c * 32 + col;
-                    part[(long)n * K + k] = acc[o][k3][c][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + o * 32 + mfma_row(lane, r);
+                const long k = ((long)(kt * 3 + k2) * 3 + k3) * a.Ci + ci0 + c * 32 + col;
+                part[(long)n * K + k] = acc[k2 * 3 + k3][r];
+            }
     if (do_bias) {
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
-            if (half == 0) part[(long)a.Co * K + n0 + o * 32 + col] = b;
-        }
+        const float bb = bsum + __shfl_xor(bsum, 32, 64);
+        if (half == 0) part[(long)a.Co * K + n0 + o * 32 + col] = bb;
     }
 }
 
-#ifndef CW_NO
-#define CW_NO 2
-#endif
 static int conv3_wgrad_splits(long M, int Co, int Ci) {
-    const long tiles = (long)(Co / (32 * CW_NO)) * (Ci / 64) * 3;
+    const long tiles = (long)(Co / 64) * (Ci / 64) * 3;
     long s = ((long)rpb_num_cus() * 4 + tiles - 1) / tiles;
     const long cap = (M + 1023) / 1024;                               // at least 1024 tokens per split
     if (s > cap) s = cap;
@@ -659,7 +636,7 @@ static int gemm_tn_nti(int K, int conv) {
 static int gemm_tn_wn(int N) { return N > 128 ? 4 : (N > 64 ? 2 : 1); }      // waves along n: no idle half for N <= 64
 
 extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
-    if (conv == 1 && N % 64 == 0 && N < 512 && K % 27 == 0 && (K / 27) % 64 == 0) return conv3_wgrad_splits(M, N, K / 27);
+    if (conv == 1 && N % 64 == 0 && K % 27 == 0 && (K / 27) % 64 == 0) return conv3_wgrad_splits(M, N, K / 27);
     const int wk2 = 64 * gemm_tn_nti(K, conv);
     const int bn = 64 * gemm_tn_wn(N);
     const long tiles = (long)((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
@@ -684,13 +661,11 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
     GemmTnArgs a;
     a.G = G; a.A = A; a.part = part; a.M = M; a.N = N; a.K = K; a.ldg = ldg; a.lda = lda;
     a.conv = conv; a.Hc = Hc; a.Wc = Wc; a.Dc = Dc;
-    if (conv == 1 && N % 64 == 0 && N < 512) {          // LDS-tiled convolution weight gradient (the 256 x 256 register-operand
-                                                        // tile below is still ahead for N >= 512: Transolver's fused dual conv)
+    if (conv == 1 && N % 64 == 0) {                     // LDS-tiled convolution weight gradient
         RPB_REQUIRE(ldg % 4 == 0 && lda % 4 == 0, "gemm_tn: conv leading dimensions must be multiples of 4");
         ConvWgArgs c{G, A, part, M, N, K / 27, ldg, lda, Hc, Wc, Dc};
         const int sp = conv3_wgrad_splits(M, N, K / 27);
-        hipLaunchKernelGGL(conv3_wgrad_kernel<CW_NO>, dim3((N / (32 * CW_NO)) * (K / 27 / 64) * 3, sp), dim3(192), 0,
-                           (hipStream_t)stream, c);
+        hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((N / 64) * (K / 27 / 64) * 3, sp), dim3(256), 0, (hipStream_t)stream, c);
         RPB_CHECK_LAUNCH("gemm_tn(conv3)");
     }
     const int nti = gemm_tn_nti(K, conv);

@@ -14,7 +14,6 @@ The reference has no distributed path at all (single process, realpdebench/train
 
 Everything here works on CPU tensors with the gloo backend too (tests/test_dp_gloo.py).
 """
-import torch
 import torch.distributed as dist
 
 

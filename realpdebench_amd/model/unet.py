@@ -22,7 +22,6 @@ version-unpinned ``rotary_embedding_torch``; its published algorithm is restated
 that one function is unpinned, everything around it is pinned through ``oracle/unet_oracle.py``.
 """
 import math
-from collections import OrderedDict
 
 import torch
 import torch.nn as nn
