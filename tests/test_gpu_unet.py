@@ -152,3 +152,27 @@ def test_state_dict_roundtrip_with_reference_fixture():
     m2.load_state_dict(sd)
     for k, v in m2.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_control_channels_and_time_replication_vs_oracle():
+    """controlled_cylinder-like channel counts (5 in -> 3 out) and out_time = 2 * in_time (input replicated along time,
+    unet.py:520): forward and gradients vs the oracle."""
+    from oracle import unet_oracle as UO
+    from realpdebench_amd.model.unet import Unet3d
+    torch.manual_seed(12)
+    Tin, Tout, H, W = 2, 4, 64, 16
+    m = Unet3d(dim=H, out_channels=3, dim_mults=[1, 2, 4], channels=5, in_time=Tin, out_time=Tout).cuda()
+    x, y = torch.randn(1, Tin, H, W, 5), torch.randn(1, Tout, H, W, 3)
+    m.train()
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    sd = _oracle_sd(m)
+    loss_ref, pred_ref, grads_ref = UO.loss_and_grads(sd, x, y)
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    named = dict(m.named_parameters())
+    worst = max((rel_l2(named[k].grad.cpu(), g) if float(g.abs().max()) > 1e-7 else float(named[k].grad.abs().max()), k)
+                for k, g in grads_ref.items())
+    assert worst[0] < 1e-3, worst
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x.cuda()).cpu(), pred_ref) < 2e-5
