@@ -194,7 +194,72 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
         }
     }
-    // epilogue: bias, broadcast vector, activation, residual
+    // epilogue: bias, broadcast vector, activation, mask, residual.
+    // Fast path (N, ldo multiples of 4): every 32 x 32 accumulator tile goes through a wave-private LDS tile (the operand
+    // tiles are dead by now) so that a lane owns 4 CONSECUTIVE columns of a row: bias / aux / mask / residual are read
+    // and the result is written with 16 B per lane (a wave instruction covers 8 rows x 128 B) instead of 16 scalar,
+    // latency-serialised accesses per tile and operand.
+    const bool vec4 = (g.N % 4 == 0) && (g.ldo % 4 == 0);
+    if (vec4) {
+        __syncthreads();                                     // all waves are done with Al / Wl
+        float* tb = lds + wave * (32 * 36);                   // wave-private [32][36]
+        const int er = lane >> 3, ec = (lane & 7) * 4;        // row within a group of 8, first of my 4 columns
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + (wn * TN + j) * 32;
+            if (nb >= g.N) continue;
+            const int n = nb + ec;
+            const bool nok = n < g.N;
+            f32x4 badd = {0.f, 0.f, 0.f, 0.f}, vadd = badd;
+            if (nok && g.bias) badd = *reinterpret_cast<const f32x4*>(g.bias + n);
+            if (nok && g.addvec) vadd = *reinterpret_cast<const f32x4*>(g.addvec + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[mfma_row(lane, r) * 36 + col] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 8 + er;
+                    const long mi = m0 + (wm * TM + i) * 32 + row;
+                    if (mi < g.M && nok) {
+                        long m = mi;
+                        if (CM == 3) {                   // (b, t, h, w) -> row (b, t, 2h+ph, 2w+pw) of the up-sampled mesh
+                            const long per = (long)g.Wc * g.Dc;
+                            const long bt = mi / per;
+                            const int r2 = (int)(mi - bt * per);
+                            const int hh = r2 / g.Dc, ww = r2 - hh * g.Dc;
+                            m = (bt * (2 * g.Wc) + 2 * hh + (g.cls >> 1)) * (2L * g.Dc) + 2 * ww + (g.cls & 1);
+                        }
+                        const long off = m * g.ldo + n;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(tb + row * 36 + ec) + badd;
+                        if (g.act == 1) {
+                            if (g.pre_out) *reinterpret_cast<f32x4*>(g.pre_out + off) = v;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+                        } else if (g.act == 2) {
+                            const f32x4 ax = *reinterpret_cast<const f32x4*>(g.aux + off);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(ax[k]);
+                        } else if (g.act == 3) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        } else if (g.act == 4) {
+                            const f32x4 ax = *reinterpret_cast<const f32x4*>(g.aux + off);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = ax[k] > 0.f ? v[k] : 0.f;
+                        }
+                        if (g.mask) v = v * *reinterpret_cast<const f32x4*>(g.mask + off);
+                        v += vadd;
+                        if (g.residual) v += *reinterpret_cast<const f32x4*>(g.residual + off);
+                        *reinterpret_cast<f32x4*>(g.out + off) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + col;
