@@ -455,6 +455,10 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
         lw = (int)((r / Do) % Wo);
         lbt = r / ((long)Do * Wo);
     }
+    // running row pointers of this lane's token progression (mb + half, +2, +4, ...): one live 64-bit pointer per operand
+    // instead of a (m * ld) product per step -- the plain (CM = 0) instantiation spilled 64 registers without this
+    const float* gcur = g.G + (mb + half) * g.ldg + n0 + col * 2;
+    const float* xcur = g.A + (mb + half + noff) * g.lda + kk0 + col * NTI;
     auto load_half = [&](long m0, int h, f32x2 (&gv)[8], veci (&xv)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
             f32x2 gq = {0.f, 0.f};
             veci xq = zi;
             bool ok = tap_ok;
-            long atok = m + noff;
+            long atok = 0;
             if (CM == 1) {
                 const int hh = lh + dh, ww = lw + dw, d2 = ld + dd;
                 ok = ok && hh >= 0 && hh < g.Hc && ww >= 0 && ww < g.Wc && d2 >= 0 && d2 < g.Dc;
@@ -489,11 +493,11 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
                 }
             }
             if (m < me) {
-                const float* gp = g.G + m * g.ldg + n0 + col * 2;
+                const float* gp = gcur;
                 if (n_ok1) gq = *reinterpret_cast<const f32x2*>(gp);
                 else if (n_ok0) gq[0] = gp[0];
                 if (ok) {
-                    const float* xp = g.A + atok * g.lda + kk0 + col * NTI;
+                    const float* xp = (CM == 2) ? g.A + atok * g.lda + kk0 + col * NTI : xcur;
                     if (kk0 + col * NTI + NTI <= klim) xq = *reinterpret_cast<const veci*>(xp);
                     else {
 #pragma unroll
@@ -504,6 +508,8 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn_kernel(GemmTnArgs g) {
             }
             gv[s] = gq;
             xv[s] = xq;
+            gcur += 2 * g.ldg;
+            xcur += 2 * g.lda;
         }
     };
     auto compute_half = [&](const f32x2 (&gv)[8], const veci (&xv)[8]) {
@@ -693,6 +699,132 @@ static int conv3_wgrad_splits(long M, int Co, int Ci) {
     return (int)s;
 }
 
+
+// ---------------------------------------------------------------------------------- projection weight gradient, LDS-tiled
+//   dW[n][k] = sum_tok G[tok][n] * A[tok][k]   for small N x K (the U-Net / Galerkin projections: N, K in 64..384)
+// These are HBM-streaming problems (a token contributes N + K floats and 2*N*K flops): the register-operand kernel below
+// re-reads G once per k-tile column and runs them at 11-22 TF/s / 0.5 TB/s.  Here a workgroup owns the WHOLE N range and a
+// 64*WK-wide k block for one token split, so G and A are read once (grid.x = K / (64*WK) is 1 for K <= 128): per
+// 32-token chunk both row blocks are staged in LDS and every wave multiplies its NTW x 2 tiles.
+struct TnSmallArgs {
+    const float* G;      // [M][ldg]
+    const float* A;      // [M][lda]
+    float* part;         // [splits][N*K + N]
+    long M;
+    int N, K, ldg, lda;
+};
+
+template <int WN, int NTW>
+__global__ __launch_bounds__(256) void tn_small_kernel(TnSmallArgs a) {
+    constexpr int WK = 4 / WN, BN = WN * NTW * 32, BK = WK * 64;
+    __shared__ float Gs[CW_TOK][BN];
+    __shared__ float As[CW_TOK][BK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int col = lane & 31, half = lane >> 5;
+    const int k0 = blockIdx.x * BK;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const long per = ((a.M + nsplit - 1) / nsplit + CW_TOK - 1) / CW_TOK * CW_TOK;
+    const long mb = (long)split * per;
+    long me = mb + per;
+    if (me > a.M) me = a.M;
+    f32x16 acc[NTW][2];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i][0] = acc[i][1] = zero16();
+    float bsum[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) bsum[i] = 0.f;
+    const bool do_bias = (blockIdx.x == 0 && wk == 0);
+    constexpr int G4 = BN / 4, A4 = BK / 4;
+    constexpr int NGL = (CW_TOK * G4 + 255) / 256, NAL = (CW_TOK * A4 + 255) / 256;
+    f32x4 pg[NGL], pa[NAL];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](long m0) {
+#pragma unroll
+        for (int j = 0; j < NGL; ++j) {
+            const int idx = tid + j * 256;
+            f32x4 v = z4;
+            if (idx < CW_TOK * G4) {
+                const long m = m0 + idx / G4;
+                if (m < me) v = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + (idx % G4) * 4);
+            }
+            pg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NAL; ++j) {
+            const int idx = tid + j * 256;
+            f32x4 v = z4;
+            if (idx < CW_TOK * A4) {
+                const long m = m0 + idx / A4;
+                if (m < me) v = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + k0 + (idx % A4) * 4);
+            }
+            pa[j] = v;
+        }
+    };
+    if (mb < me) prefetch(mb);
+    for (long m0 = mb; m0 < me; m0 += CW_TOK) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NGL; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < CW_TOK * G4) *reinterpret_cast<f32x4*>(&Gs[idx / G4][(idx % G4) * 4]) = pg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NAL; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < CW_TOK * A4) *reinterpret_cast<f32x4*>(&As[idx / A4][(idx % A4) * 4]) = pa[j];
+        }
+        __syncthreads();
+        if (m0 + CW_TOK < me) prefetch(m0 + CW_TOK);
+#pragma unroll
+        for (int s = 0; s < CW_TOK / 2; ++s) {
+            const int tk = 2 * s + half;
+            const float b0 = As[tk][wk * 64 + col], b1 = As[tk][wk * 64 + 32 + col];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const float av = Gs[tk][(wn * NTW + i) * 32 + col];
+                if (do_bias) bsum[i] += av;
+                acc[i][0] = mfma32(av, b0, acc[i][0]);
+                acc[i][1] = mfma32(av, b1, acc[i][1]);
+            }
+        }
+    }
+    float* part = a.part + (long)split * ((long)a.N * a.K + a.N);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = (wn * NTW + i) * 32 + mfma_row(lane, r);
+                part[(long)n * a.K + k0 + wk * 64 + c * 32 + col] = acc[i][c][r];
+            }
+        if (do_bias) {
+            const float bb = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            if (half == 0) part[(long)a.N * a.K + (wn * NTW + i) * 32 + col] = bb;
+        }
+    }
+}
+
+// shapes served by tn_small_kernel: N in {64, 128, 256, 384}, K a multiple of the k block, K <= 384
+static bool tn_small_ok(int N, int K, int ldg, int lda) {
+    if (!(N == 64 || N == 128 || N == 256 || N == 384) || K > 384 || ldg % 4 || lda % 4) return false;
+    const int bk = (N == 64) ? 128 : 64;
+    return K % bk == 0;
+}
+
+static int tn_small_splits(long M, int N, int K) {
+    const int bk = (N == 64) ? 128 : 64;
+    const long tiles = K / bk;
+    long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
+    const long cap = (M + 1023) / 1024;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
 static int gemm_tn_nti(int K, int conv) {
     const int Ci = conv == 1 ? K / 27 : (conv == 2 ? K / 16 : K);
     return (Ci % 128 == 0) ? 4 : 2;
@@ -702,6 +834,7 @@ static int gemm_tn_wn(int N) { return N > 128 ? 4 : (N > 64 ? 2 : 1); }      // 
 
 extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
     if (conv == 1 && N % 64 == 0 && K % 27 == 0 && (K / 27) % 64 == 0) return conv3_wgrad_splits(M, N, K / 27);
+    if (conv == 0 && tn_small_ok(N, K, 4, 4)) return tn_small_splits(M, N, K);
     const int wk2 = 64 * gemm_tn_nti(K, conv);
     const int bn = 64 * gemm_tn_wn(N);
     const long tiles = (long)((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
@@ -732,6 +865,17 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
         const int sp = conv3_wgrad_splits(M, N, K / 27);
         hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((N / 64) * (K / 27 / 64) * 3, sp), dim3(256), 0, (hipStream_t)stream, c);
         RPB_CHECK_LAUNCH("gemm_tn(conv3)");
+    }
+    if (conv == 0 && tn_small_ok(N, K, 4, 4)) {         // LDS-tiled projection weight gradient: G and A are read once
+        RPB_REQUIRE(ldg % 4 == 0 && lda % 4 == 0, "gemm_tn: leading dimensions %d / %d must be multiples of 4 for N=%d K=%d", ldg, lda, N, K);
+        TnSmallArgs t{G, A, part, M, N, K, ldg, lda};
+        const int sp = tn_small_splits(M, N, K);
+        hipStream_t st2 = (hipStream_t)stream;
+        if (N == 64) hipLaunchKernelGGL((tn_small_kernel<2, 1>), dim3(K / 128, sp), dim3(256), 0, st2, t);
+        else if (N == 128) hipLaunchKernelGGL((tn_small_kernel<4, 1>), dim3(K / 64, sp), dim3(256), 0, st2, t);
+        else if (N == 256) hipLaunchKernelGGL((tn_small_kernel<4, 2>), dim3(K / 64, sp), dim3(256), 0, st2, t);
+        else hipLaunchKernelGGL((tn_small_kernel<4, 3>), dim3(K / 64, sp), dim3(256), 0, st2, t);
+        RPB_CHECK_LAUNCH("gemm_tn(small)");
     }
     const int nti = gemm_tn_nti(K, conv);
     const int wk2 = 64 * nti;

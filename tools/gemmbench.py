@@ -29,3 +29,10 @@ for N, K in ((384, 64), (128, 64), (128, 256), (64, 128), (64, 384), (32, 64), (
     A, W, out = torch.randn(M, K, **f), torch.randn(N, K, **f), torch.empty(M, N, **f)
     timeit(f"gemm_nt M={M} N={N} K={K}", lambda: ops.gemm_nt(A, W, out, M, N, K), 4 * M * (N + K), 2 * M * N * K)
     del A, W, out
+
+for N, K in ((768, 256), (256, 256), (384, 64), (64, 128), (1024, 256), (256, 1024)):
+    G, A = torch.randn(M, N, **f), torch.randn(M, K, **f)
+    splits = ops.gemm_tn_splits(M, N, K)
+    part = torch.empty(splits, N * K + N, **f)
+    timeit(f"gemm_tn M={M} N={N} K={K} sp={splits}", lambda: ops.gemm_tn(G, A, part, M, N, K), 4 * M * (N + K), 2 * M * N * K)
+    del G, A, part
