@@ -626,6 +626,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
             px[j] = v;
         }
     };
+    // mesh coordinates of "my" token (threads 0..31 own the chunk's tokens for the validity table): decoded once, then carried
+    // chunk to chunk with 32-bit adds -- the four 64-bit divisions per chunk kept the other waves waiting at the barrier
+    int vw = 0, vh = 0, vt = 0;
+    if (tid < CW_TOK) {
+        const long m = mb + tid;
+        vw = (int)(m % a.W);
+        const long r = m / a.W;
+        vh = (int)(r % a.H);
+        vt = (int)((r / a.H) % a.T);
+    }
     if (mb < me) prefetch(mb);
     for (long m0 = mb; m0 < me; m0 += CW_TOK) {
         __syncthreads();                                              // previous chunk's LDS reads are done
@@ -643,19 +653,22 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
             }
         }
         if (tid < CW_TOK) {                                           // validity of the 9 (kh, kw) taps of my token
-            const long m = m0 + tid;
-            const int w = (int)(m % a.W);
-            const long r = m / a.W;
-            const int h = (int)(r % a.H);
-            const int t = (int)((r / a.H) % a.T);
-            const bool okt = m < me && t + kt - 1 >= 0 && t + kt - 1 < a.T;
+            const bool okt = m0 + tid < me && vt + kt - 1 >= 0 && vt + kt - 1 < a.T;
 #pragma unroll
             for (int k2 = 0; k2 < 3; ++k2)
 #pragma unroll
                 for (int k3 = 0; k3 < 3; ++k3) {
-                    const int hh = h + k2 - 1, ww = w + k3 - 1;
+                    const int hh = vh + k2 - 1, ww = vw + k3 - 1;
                     Vm[k2 * 3 + k3][tid] = (okt && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? 1.f : 0.f;
                 }
+            vw += CW_TOK;                                             // my token of the next chunk: + 32 with carries
+            while (vw >= a.W) {
+                vw -= a.W;
+                if (++vh >= a.H) {
+                    vh = 0;
+                    if (++vt >= a.T) vt = 0;
+                }
+            }
         }
         __syncthreads();
         if (m0 + CW_TOK < me) prefetch(m0 + CW_TOK);                  // in flight during the MFMAs below
