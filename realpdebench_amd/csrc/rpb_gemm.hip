@@ -74,11 +74,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
         arow[j] = idx / (G_BK / 4);
         const long m = m0 + arow[j];
         am[j] = (m < g.M) ? m : -1;      // validity is tracked in arow_ok (a conv = 2 base token may be negative)
+        // row indices fit 32 bits (M < 2^31 is checked by the launcher): unsigned 32-bit divisions, not the 64-bit library ones
         if (CM == 2 && am[j] >= 0) {                 // m over the output mesh (Hc, Wc/2, Dc/2)
-            const int Wo = g.Wc / 2, Do = g.Dc / 2;
-            const long per = (long)g.Hc * Wo * Do;
-            const long bb = m / per;
-            long r = m - bb * per;
+            const unsigned Wo = g.Wc / 2, Do = g.Dc / 2;
+            const unsigned per = (unsigned)g.Hc * Wo * Do;
+            const unsigned mu = (unsigned)m;
+            const unsigned bb = mu / per;
+            unsigned r = mu - bb * per;
             const int dq = (int)(r % Do);
             r /= Do;
             const int wq = (int)(r % Wo);
@@ -86,14 +88,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
             ah[j] = hq;
             aw[j] = 2 * wq - 1;
             ad[j] = 2 * dq - 1;
-            am[j] = ((bb * g.Hc + hq) * g.Wc + aw[j]) * g.Dc + ad[j];     // token of tap (0,0); may be "negative-ish" only via the bounds-checked taps
+            am[j] = (((long)bb * g.Hc + hq) * g.Wc + aw[j]) * g.Dc + ad[j];     // token of tap (0,0); only dereferenced for in-bounds taps
         } else if (CM && am[j] >= 0) {
-            const long per = (long)g.Hc * g.Wc * g.Dc;
-            long r = m % per;
-            ad[j] = (int)(r % g.Dc);
-            r /= g.Dc;
-            aw[j] = (int)(r % g.Wc);
-            ah[j] = (int)(r / g.Wc);
+            const unsigned per = (unsigned)g.Hc * g.Wc * g.Dc;
+            unsigned r = (unsigned)m % per;
+            ad[j] = (int)(r % (unsigned)g.Dc);
+            r /= (unsigned)g.Dc;
+            aw[j] = (int)(r % (unsigned)g.Wc);
+            ah[j] = (int)(r / (unsigned)g.Wc);
         } else {
             ah[j] = aw[j] = ad[j] = 0;
         }
@@ -225,11 +227,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                     if (mi < g.M && nok) {
                         long m = mi;
                         if (CM == 3) {                   // (b, t, h, w) -> row (b, t, 2h+ph, 2w+pw) of the up-sampled mesh
-                            const long per = (long)g.Wc * g.Dc;
-                            const long bt = mi / per;
-                            const int r2 = (int)(mi - bt * per);
-                            const int hh = r2 / g.Dc, ww = r2 - hh * g.Dc;
-                            m = (bt * (2 * g.Wc) + 2 * hh + (g.cls >> 1)) * (2L * g.Dc) + 2 * ww + (g.cls & 1);
+                            const unsigned per = (unsigned)g.Wc * g.Dc;
+                            const unsigned bt = (unsigned)mi / per;
+                            const unsigned r2 = (unsigned)mi - bt * per;
+                            const unsigned hh = r2 / (unsigned)g.Dc, ww = r2 - hh * g.Dc;
+                            m = ((long)bt * (2 * g.Wc) + 2 * hh + (g.cls >> 1)) * (2L * g.Dc) + 2 * ww + (g.cls & 1);
                         }
                         const long off = m * g.ldo + n;
                         f32x4 v = *reinterpret_cast<const f32x4*>(tb + row * 36 + ec) + badd;
@@ -329,8 +331,8 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
     RPB_REQUIRE((act != 2 && act != 4) || aux, "gemm_nt: act=2/4 needs the saved activation tensor");
     RPB_REQUIRE(act >= 0 && act <= 4, "gemm_nt: unknown act=%d", act);
-    RPB_REQUIRE(M > 0 && N > 0 && K > 0 && K % G_BK == 0, "gemm_nt: bad sizes M=%ld N=%d K=%d (K must be a multiple of %d)", M,
-                N, K, G_BK);
+    RPB_REQUIRE(M > 0 && M < (1L << 31) && N > 0 && K > 0 && K % G_BK == 0,
+                "gemm_nt: bad sizes M=%ld N=%d K=%d (M < 2^31, K a multiple of %d)", M, N, K, G_BK);
     RPB_REQUIRE(lda % 4 == 0 && ldo >= N, "gemm_nt: lda=%d must be a multiple of 4 and ldo=%d >= N", lda, ldo);
     RPB_REQUIRE(conv >= 0 && conv <= 3 && cls >= 0 && cls <= 3, "gemm_nt: bad conv=%d / cls=%d", conv, cls);
     if (conv == 1) {
