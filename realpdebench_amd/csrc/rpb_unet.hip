@@ -157,38 +157,64 @@ extern "C" int rpb_affine_silu_bwd_apply(const float* x, const float* gy, const 
 // (32-channel chunks), so its im2col matrix col[m][tap*C_in + ci] (taps row-major over (dt, dh, dw), zero outside the
 // mesh, zero-padded to ldc columns) is materialised once per step and both the forward product and the weight
 // gradient are plain token GEMMs (rpb_gemm_nt / rpb_gemm_tn) on it.  The input needs no data gradient.
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long M, int T,
-                                                     int H, int W, int Cin, int KS, int ldc) {
-    const int R = KS / 2, taps = KS * KS * KS;
-    const long total = M * ldc;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long m = idx / ldc;
-        const int k = (int)(idx - m * ldc);
-        float v = 0.f;
-        if (k < taps * Cin) {
-            const int tap = k / Cin, ci = k - tap * Cin;
-            const int dw = tap % KS - R, dh = (tap / KS) % KS - R, dt = tap / (KS * KS) - R;
-            const int w = (int)(m % W);
-            long r = m / W;
-            const int h = (int)(r % H);
-            r /= H;
-            const int t = (int)(r % T);
-            const int tt = t + dt, hh = h + dh, ww = w + dw;
-            if (tt >= 0 && tt < T && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                v = x[(m + ((long)dt * H + dh) * W + dw) * Cin + ci];
+// A block walks a contiguous range of rows; a thread owns 4 fixed columns (one 16 B store per row) whose tap offsets are
+// decoded once, and the row's mesh coordinates advance by +1 with carries -- no divisions in the row loop.
+__global__ __launch_bounds__(320) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, long M, int T,
+                                                     int H, int W, int Cin, int KS, int ldc, int q0) {
+    const int R = KS / 2, ncol = KS * KS * KS * Cin;
+    const int q = q0 + threadIdx.x;                                  // my float4 column (a launch covers 320 of them)
+    const bool active = q < ldc / 4;
+    int dt[4], dh[4], dw[4];
+    long delta[4];
+    bool kok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        kok[e] = active && k < ncol;
+        const int tap = kok[e] ? k / Cin : 0, ci = kok[e] ? k - tap * Cin : 0;
+        dw[e] = tap % KS - R;
+        dh[e] = (tap / KS) % KS - R;
+        dt[e] = tap / (KS * KS) - R;
+        delta[e] = (((long)dt[e] * H + dh[e]) * W + dw[e]) * Cin + ci;
+    }
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per;
+    long r1 = r0 + per;
+    if (r1 > M) r1 = M;
+    if (r0 >= r1) return;
+    int w = (int)(r0 % W);
+    long r = r0 / W;
+    int h = (int)(r % H);
+    int t = (int)((r / H) % T);
+    for (long m = r0; m < r1; ++m) {
+        if (active) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tt = t + dt[e], hh = h + dh[e], ww = w + dw[e];
+                if (kok[e] && tt >= 0 && tt < T && hh >= 0 && hh < H && ww >= 0 && ww < W) v[e] = x[m * Cin + delta[e]];
+            }
+            *reinterpret_cast<f32x4*>(col + m * ldc + 4 * q) = v;
         }
-        col[idx] = v;
+        if (++w >= W) {
+            w = 0;
+            if (++h >= H) {
+                h = 0;
+                if (++t >= T) t = 0;
+            }
+        }
     }
 }
 
 extern "C" int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream) {
     RPB_REQUIRE(x && col && B > 0 && T > 0 && H > 0 && W > 0 && Cin > 0, "im2col: bad arguments");
-    RPB_REQUIRE(KS % 2 == 1 && ldc >= KS * KS * KS * Cin, "im2col: KS=%d must be odd and ldc=%d >= taps*Cin", KS, ldc);
+    RPB_REQUIRE(KS % 2 == 1 && ldc >= KS * KS * KS * Cin && ldc % 4 == 0, "im2col: KS=%d must be odd and ldc=%d >= taps*Cin, a multiple of 4", KS, ldc);
     const long M = (long)B * T * H * W;
-    long grid = (M * ldc + 255) / 256;
-    const long cap = (long)rpb_num_cus() * 32;
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, col, M, T, H, W, Cin, KS, ldc);
+    long grid = (long)rpb_num_cus() * 16;
+    if (grid > M) grid = M;
+    for (int q0 = 0; q0 < ldc / 4; q0 += 320)                        // 320 float4 columns per launch (C_in = 3: one launch)
+        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(320), 0, (hipStream_t)stream, x, col, M, T, H, W, Cin, KS,
+                           ldc, q0);
     RPB_CHECK_LAUNCH("im2col");
 }
 
