@@ -248,7 +248,7 @@ int rpb_affine_silu_bwd_apply(const float* x, const float* gy, const float* A, c
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
 int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
 /*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,
- *     rotary tables [T][32], relative-position bias [4][T][T].  bwd: part[rpb_tattn_blocks(B*HW)*8][T*T] bias-gradient
+ *     rotary tables [T][32], relative-position bias [4][T][T].  bwd: part[rpb_tattn_blocks(B*HW)*4][T*T] bias-gradient
  *     partials, row r belongs to head r % 4. */
 int rpb_tattn_blocks(long nloc);
 int rpb_tattn_fwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, float* out, int B, int T,

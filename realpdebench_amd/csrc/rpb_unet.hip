@@ -219,16 +219,22 @@ extern "C" int rpb_im2col(const float* x, float* col, int B, int T, int H, int W
 }
 
 // ---------------------------------------------------------------------------------- temporal attention
-// Attention over the f = T frames of one spatial location (unet.py:280-356 under EinopsToAndFrom 'b c f h w' ->
+// Attention over the f = T <= 32 frames of one spatial location (unet.py:280-356 under EinopsToAndFrom 'b c f h w' ->
 // 'b (h w) f c', :388): 4 heads x 32, q scaled by 32^-1/2, rotary position embedding on q and k, T5 relative-position
 // bias added to the logits, softmax.  qkv is the token tensor [B][T][HW][3*128] produced by the to_qkv GEMM.
-// A half-wave owns one (location, head) unit: lane i < T is query / key row i; rows live in +1-padded LDS tiles so both
-// "my row" (stride 33) and "everyone reads row j" (broadcast) accesses are conflict-free.  The backward recomputes the
-// probabilities, accumulates the bias gradient in registers across the units a wave walks (waves keep a fixed head) and
-// writes one partial row per half-wave.
-#define TA_TMAX 32
+//
+// One wave per (location, head) unit, every product on the fp32 MFMA with the T x 32 operands zero-padded to 32 x 32 in
+// +1-padded LDS tiles (a first VALU version with one lane per query row ran at 5 TF/s: 55 k cycles per unit):
+//   S^T = K Q^T is accumulated TRANSPOSED (row = key j, column = query i), so that a lane owns one query and the softmax
+//   over keys is a reduction over its 16 registers plus one cross-half shuffle;
+//   O = P V and d Q = dS K take P / dS straight from those registers as the MFMA A operand: at step s a lane supplies
+//   key j = row(s, half) and the B operand reads the matching V / K row (any bijection of the contraction index works);
+//   d K = dS^T Q and d V = P^T gO need the other orientation and go through LDS once.
+// The backward recomputes the probabilities, accumulates the bias gradient in registers across the units a wave walks
+// (waves keep a fixed head) and writes one partial row per wave.
 #define TA_D 32
-#define TA_XS 36             // row stride in LDS: multiple of 4 so that rows are read with one ds_read_b128 per 4 channels
+#define TA_XS 33
+#define TA_TILE (32 * TA_XS)
 
 struct TAttnArgs {
     const float* qkv;    // [B][T][HW][384]
@@ -238,178 +244,149 @@ struct TAttnArgs {
     float* out;          // fwd: [B][T][HW][128]
     const float* go;     // bwd: gradient of out
     float* gqkv;         // bwd: [B][T][HW][384]
-    float* part;         // bwd: [slots][T*T] bias-gradient partials; slot % 4 = head
+    float* part;         // bwd: [gridDim.x * 4][T*T] bias-gradient partials; row % 4 = head
     long nloc;           // B * HW locations
     int T, HW;
 };
-
-__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void tattn_kernel(TAttnArgs a) {
     extern __shared__ float lds[];
     const int T = a.T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hl = lane >> 5, i = lane & 31;                    // half-wave, row (and channel while staging)
-    const int head = wave;                                       // 4 waves = 4 heads
-    const int unit_lds = (BWD ? 4 * T * TA_XS + 2 * T * (T + 1) : 3 * T * TA_XS);
-    float* base = lds + (wave * 2 + hl) * unit_lds;
-    float* Ql = base;
-    float* Kl = Ql + T * TA_XS;
-    float* Vl = Kl + T * TA_XS;
-    float* Gl = Vl + T * TA_XS;                                   // BWD: go rows
-    float* Pl = Gl + T * TA_XS;                                   // BWD: [T][T+1] probabilities
-    float* Sl = Pl + T * (T + 1);                                 // BWD: [T][T+1] d logits
+    const int lane = threadIdx.x & 63;
+    const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 4 waves = 4 heads of one location
+    const int col = lane & 31, half = lane >> 5;
+    float* Ql = lds + head * (BWD ? 4 : 3) * TA_TILE;
+    float* Kl = Ql + TA_TILE;
+    float* Vl = Kl + TA_TILE;
+    float* Gl = Vl + TA_TILE;                                     // BWD: go rows
+    float* Pl = Vl;                                               // BWD: P^T  [j][i] -- takes V's tile once dP is done
+    float* Sl = Kl;                                               // BWD: dS^T [j][i] -- takes K's tile once dQ is done
+                                                                  // (4 tiles per wave = 68 KB per workgroup: 2 workgroups per CU)
+    for (int idx = lane; idx < (BWD ? 4 : 3) * TA_TILE; idx += 64) Ql[idx] = 0.f;     // rows t >= T stay zero
     const float scale = 0.17677669529663687f;                     // 32^-1/2
-    const float sg = (i & 1) ? 1.f : -1.f;                        // rot(x)[2p] = -x[2p+1], rot(x)[2p+1] = x[2p]
-    const bool live = i < T;
-    const int ir = live ? i : 0;
-    float dbias[TA_TMAX];
+    const float sg = (col & 1) ? 1.f : -1.f;                      // rot(x)[2p] = -x[2p+1], rot(x)[2p+1] = x[2p]
+    const bool qlive = col < T;                                   // my query column
+    int jrow[16];
+    float biasv[16];
 #pragma unroll
-    for (int j = 0; j < TA_TMAX; ++j) dbias[j] = 0.f;
-    const long nslot = (long)gridDim.x * 2;                       // half-waves per head
-    for (long loc = (long)blockIdx.x * 2 + hl; loc < a.nloc; loc += nslot) {
+    for (int r = 0; r < 16; ++r) {
+        jrow[r] = mfma_row(lane, r);
+        biasv[r] = (qlive && jrow[r] < T) ? a.bias[(head * T + col) * T + jrow[r]] : 0.f;
+    }
+    f32x16 dbias = zero16();
+    __builtin_amdgcn_wave_barrier();
+    for (long loc = blockIdx.x; loc < a.nloc; loc += gridDim.x) {
         const long b = loc / a.HW;
         const int hw = (int)(loc - b * a.HW);
-        // ---- stage rows: lane = channel (one 128 B row per load); rotary (+ the q scale) applied on the way in, the
-        //      partner channel d ^ 1 comes from the neighbouring lane
-        for (int t = 0; t < T; ++t) {
+        // ---- stage rows: lane = channel, the two half-waves take even / odd frames; rotary (+ the q scale) on the way in
+        for (int t = half; t < T; t += 2) {
             const long tok = (b * T + t) * a.HW + hw;
-            const float* src = a.qkv + tok * 384 + head * TA_D + i;
-            const float c = a.rcos[t * TA_D + i], sn = a.rsin[t * TA_D + i];
+            const float* src = a.qkv + tok * 384 + head * TA_D + col;
+            const float c = a.rcos[t * TA_D + col], sn = a.rsin[t * TA_D + col];
             const float q0 = src[0], k0 = src[128];
             const float q1 = __shfl_xor(q0, 1, 64), k1 = __shfl_xor(k0, 1, 64);
-            Ql[t * TA_XS + i] = (q0 * c + sg * q1 * sn) * scale;
-            Kl[t * TA_XS + i] = k0 * c + sg * k1 * sn;
-            Vl[t * TA_XS + i] = src[256];
-            if (BWD) Gl[t * TA_XS + i] = a.go[tok * 128 + head * TA_D + i];
+            Ql[t * TA_XS + col] = (q0 * c + sg * q1 * sn) * scale;
+            Kl[t * TA_XS + col] = k0 * c + sg * k1 * sn;
+            Vl[t * TA_XS + col] = src[256];
+            if (BWD) Gl[t * TA_XS + col] = a.go[tok * 128 + head * TA_D + col];
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- my query row in registers; logits against every key row (broadcast float4 reads); softmax
-        f32x4 q[TA_D / 4];
+        // ---- S^T[j][i] = sum_d K[j][d] Q[i][d]  (+ bias), softmax over j = my registers + the other half-wave
+        f32x16 p = zero16();
 #pragma unroll
-        for (int d4 = 0; d4 < TA_D / 4; ++d4) q[d4] = *reinterpret_cast<const f32x4*>(Ql + ir * TA_XS + 4 * d4);
-        float p[TA_TMAX];
+        for (int s = 0; s < 16; ++s) p = mfma32(Kl[col * TA_XS + 2 * s + half], Ql[col * TA_XS + 2 * s + half], p);
         float mx = -3.0e38f;
 #pragma unroll
-        for (int j = 0; j < TA_TMAX; ++j) {
-            float sc = -3.0e38f;
-            if (j < T) {
-                sc = a.bias[(head * T + ir) * T + j];
-#pragma unroll
-                for (int d4 = 0; d4 < TA_D / 4; ++d4)
-                    sc += dot4(q[d4], *reinterpret_cast<const f32x4*>(Kl + j * TA_XS + 4 * d4));
-            }
-            p[j] = sc;
-            mx = fmaxf(mx, sc);
+        for (int r = 0; r < 16; ++r) {
+            p[r] = (jrow[r] < T) ? p[r] + biasv[r] : -3.0e38f;
+            mx = fmaxf(mx, p[r]);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float z = 0.f;
 #pragma unroll
-        for (int j = 0; j < TA_TMAX; ++j) {
-            p[j] = (j < T) ? __expf(p[j] - mx) : 0.f;
-            z += p[j];
+        for (int r = 0; r < 16; ++r) {
+            p[r] = (jrow[r] < T) ? __expf(p[r] - mx) : 0.f;
+            z += p[r];
         }
+        z += __shfl_xor(z, 32, 64);
         const float iz = 1.0f / z;
 #pragma unroll
-        for (int j = 0; j < TA_TMAX; ++j) p[j] *= iz;
+        for (int r = 0; r < 16; ++r) p[r] *= iz;
         if (!BWD) {
-            float* dst = a.out + ((b * T + ir) * a.HW + hw) * 128 + head * TA_D;
-            for (int d4 = 0; d4 < TA_D / 4; ++d4) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            // ---- O[i][d] = sum_j P[i][j] V[j][d]: A = my P registers (key j = row(s, half)), B = the matching V row
+            f32x16 o = zero16();
 #pragma unroll
-                for (int j = 0; j < TA_TMAX; ++j)
-                    if (j < T) o += *reinterpret_cast<const f32x4*>(Vl + j * TA_XS + 4 * d4) * p[j];
-                if (live) *reinterpret_cast<f32x4*>(dst + 4 * d4) = o;
-            }
+            for (int s = 0; s < 16; ++s) o = mfma32(p[s], Vl[jrow[s] * TA_XS + col], o);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (jrow[r] < T) a.out[((b * T + jrow[r]) * a.HW + hw) * 128 + head * TA_D + col] = o[r];
         } else {
-            // ---- d logits of my row: dp_j = go_i . v_j ; ds_j = p_j (dp_j - sum_j' p_j' dp_j')
-            f32x4 g[TA_D / 4];
+            // ---- dP^T[j][i] = sum_d V[j][d] gO[i][d] ; dS = P (dP - sum_j P dP)
+            f32x16 ds = zero16();
 #pragma unroll
-            for (int d4 = 0; d4 < TA_D / 4; ++d4) g[d4] = *reinterpret_cast<const f32x4*>(Gl + ir * TA_XS + 4 * d4);
-            float ds[TA_TMAX];
+            for (int s = 0; s < 16; ++s) ds = mfma32(Vl[col * TA_XS + 2 * s + half], Gl[col * TA_XS + 2 * s + half], ds);
             float dot = 0.f;
 #pragma unroll
-            for (int j = 0; j < TA_TMAX; ++j) {
-                float dp = 0.f;
-                if (j < T) {
+            for (int r = 0; r < 16; ++r) dot += p[r] * ds[r];
+            dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
-                    for (int d4 = 0; d4 < TA_D / 4; ++d4)
-                        dp += dot4(g[d4], *reinterpret_cast<const f32x4*>(Vl + j * TA_XS + 4 * d4));
-                }
-                ds[j] = dp;
-                dot += p[j] * dp;
+            for (int r = 0; r < 16; ++r) {
+                ds[r] = p[r] * (ds[r] - dot);
+                if (qlive) dbias[r] += ds[r];
             }
+            // ---- d q~[i][d] = sum_j dS[i][j] k~[j][d]  (A = my dS registers, B = the matching K row)
+            f32x16 dq = zero16(), dk = zero16(), dv = zero16();
 #pragma unroll
-            for (int j = 0; j < TA_TMAX; ++j) {
-                ds[j] = p[j] * (ds[j] - dot);
-                if (live) dbias[j] += ds[j];
-                if (live && j < T) {
-                    Pl[i * (T + 1) + j] = p[j];
-                    Sl[i * (T + 1) + j] = ds[j];
-                }
+            for (int s = 0; s < 16; ++s) dq = mfma32(ds[s], Kl[jrow[s] * TA_XS + col], dq);
+            __builtin_amdgcn_wave_barrier();                      // K and V are dead: their tiles take dS^T and P^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Pl[jrow[r] * TA_XS + col] = p[r];
+                Sl[jrow[r] * TA_XS + col] = ds[r];
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- column i of P and dS in registers (p / q are dead by now)
-            float pc[TA_TMAX], sc2[TA_TMAX];
+            // ---- d k~[j][d] = sum_i dS[i][j] q~[i][d] ; d v[j][d] = sum_i P[i][j] gO[i][d]  (A from the transposed tiles)
 #pragma unroll
-            for (int r = 0; r < TA_TMAX; ++r) {
-                pc[r] = (r < T) ? Pl[r * (T + 1) + ir] : 0.f;
-                sc2[r] = (r < T) ? Sl[r * (T + 1) + ir] : 0.f;
+            for (int s = 0; s < 16; ++s) {
+                dk = mfma32(Sl[col * TA_XS + 2 * s + half], Ql[(2 * s + half) * TA_XS + col], dk);
+                dv = mfma32(Pl[col * TA_XS + 2 * s + half], Gl[(2 * s + half) * TA_XS + col], dv);
             }
-            // d v_i = sum_r P[r][i] go_r ; d k~_i = sum_r dS[r][i] q~_r ; d q~_i = sum_j dS[i][j] k~_j ; the rotation R_t is
-            // orthogonal: d q_i = scale * R_i^T d q~_i, d k_i = R_i^T d k~_i with R^T (y0, y1) = (y0 c + y1 s, -y0 s + y1 c)
-            float* gq = a.gqkv + ((b * T + ir) * a.HW + hw) * 384 + head * TA_D;
-            for (int d4 = 0; d4 < TA_D / 4; ++d4) {
-                f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = dv, dq = dv;
+            // the rotation R_t is orthogonal: d q = scale * R_t^T d q~, d k = R_t^T d k~ ; R^T (y0, y1) = (y0 c + y1 s, -y0 s + y1 c)
 #pragma unroll
-                for (int r = 0; r < TA_TMAX; ++r)
-                    if (r < T) {
-                        dv += *reinterpret_cast<const f32x4*>(Gl + r * TA_XS + 4 * d4) * pc[r];
-                        dk += *reinterpret_cast<const f32x4*>(Ql + r * TA_XS + 4 * d4) * sc2[r];
-                        dq += *reinterpret_cast<const f32x4*>(Kl + r * TA_XS + 4 * d4) * ds[r];
-                    }
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.rcos + ir * TA_D + 4 * d4);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.rsin + ir * TA_D + 4 * d4);
-                f32x4 oq, ok;
-                oq[0] = (dq[0] * c4[0] + dq[1] * s4[0]) * scale;
-                oq[1] = (-dq[0] * s4[0] + dq[1] * c4[0]) * scale;
-                oq[2] = (dq[2] * c4[2] + dq[3] * s4[2]) * scale;
-                oq[3] = (-dq[2] * s4[2] + dq[3] * c4[2]) * scale;
-                ok[0] = dk[0] * c4[0] + dk[1] * s4[0];
-                ok[1] = -dk[0] * s4[0] + dk[1] * c4[0];
-                ok[2] = dk[2] * c4[2] + dk[3] * s4[2];
-                ok[3] = -dk[2] * s4[2] + dk[3] * c4[2];
-                if (live) {
-                    *reinterpret_cast<f32x4*>(gq + 4 * d4) = oq;
-                    *reinterpret_cast<f32x4*>(gq + 128 + 4 * d4) = ok;
-                    *reinterpret_cast<f32x4*>(gq + 256 + 4 * d4) = dv;
+            for (int r = 0; r < 16; ++r) {
+                const int t = jrow[r];
+                const float nq = __shfl_xor(dq[r], 1, 64), nk = __shfl_xor(dk[r], 1, 64);
+                if (t < T) {
+                    const float c = a.rcos[t * TA_D + col], sn = a.rsin[t * TA_D + col];
+                    float* gq = a.gqkv + ((b * T + t) * a.HW + hw) * 384 + head * TA_D + col;
+                    gq[0] = (dq[r] * c - sg * nq * sn) * scale;
+                    gq[128] = dk[r] * c - sg * nk * sn;
+                    gq[256] = dv[r];
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (BWD && live) {
-        float* row = a.part + (((long)blockIdx.x * 2 + hl) * 4 + head) * T * T + i * T;
+    if (BWD && qlive) {
+        float* row = a.part + ((long)blockIdx.x * 4 + head) * T * T + col * T;
 #pragma unroll
-        for (int j = 0; j < TA_TMAX; ++j)
-            if (j < T) row[j] = dbias[j];
+        for (int r = 0; r < 16; ++r)
+            if (jrow[r] < T) row[jrow[r]] = dbias[r];
     }
 }
 
 extern "C" int rpb_tattn_blocks(long nloc) {
-    long g = (nloc + 1) / 2;
-    const long cap = (long)rpb_num_cus() * 4;
+    long g = nloc;
+    const long cap = (long)rpb_num_cus() * 6;
     if (g > cap) g = cap;
     return (int)(g < 1 ? 1 : g);
 }
 
 static int tattn_launch(bool bwd, TAttnArgs& a, hipStream_t st) {
     RPB_REQUIRE(a.qkv && a.rcos && a.rsin && a.bias && a.nloc > 0 && a.HW > 0, "tattn: bad arguments");
-    RPB_REQUIRE(a.T >= 1 && a.T <= TA_TMAX, "tattn: T=%d frames, the kernel holds up to %d", a.T, TA_TMAX);
-    const int T = a.T;
-    const size_t unit = bwd ? 4 * T * TA_XS + 2 * T * (T + 1) : 3 * T * TA_XS;
-    const size_t lds = unit * 8 * 4;
-    RPB_REQUIRE(lds <= 160 * 1024, "tattn: T=%d does not fit LDS", T);
+    RPB_REQUIRE(a.T >= 1 && a.T <= 32, "tattn: T=%d frames, the kernel holds up to 32", a.T);
+    const size_t lds = (size_t)(bwd ? 4 : 3) * TA_TILE * 4 * 4;
     const int grid = rpb_tattn_blocks(a.nloc);
     if (bwd) {
         (void)hipFuncSetAttribute((const void*)tattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -429,7 +406,7 @@ extern "C" int rpb_tattn_fwd(const float* qkv, const float* rcos, const float* r
     return tattn_launch(false, a, (hipStream_t)stream);
 }
 
-/* part[rpb_tattn_blocks(B*HW) * 2 * 4][T*T]: row r belongs to head r % 4 (d bias[head] = sum of its rows). */
+/* part[rpb_tattn_blocks(B*HW) * 4][T*T]: row r belongs to head r % 4 (d bias[head] = sum of its rows). */
 extern "C" int rpb_tattn_bwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, const float* go,
                              float* gqkv, float* part, int B, int T, int HW, void* stream) {
     RPB_REQUIRE(go && gqkv && part, "tattn_bwd: null pointer");

@@ -457,7 +457,7 @@ class Unet3d(_ModelBase):
         def bwd():
             go = tp.grad(o)
             gqkv = _new(M, 3 * HID, like=x)
-            rows = ops.tattn_blocks(B * H * W) * 8
+            rows = ops.tattn_blocks(B * H * W) * 4
             part = _new(rows, T * T, like=x)
             ops.tattn_bwd(qkv, rc, rs, bd, go, gqkv, part, B, T, H * W)
             tp.acc(qkv, gqkv)

@@ -87,7 +87,7 @@ def test_temporal_and_bottleneck_attention_kernels(ops):
     ops.tattn_fwd(qd, rc, rs, dev(bias.detach()), out, B, T, HW)
     assert rel_l2(out.cpu(), o.detach().reshape(-1, 128)) < 1e-5
     gq = torch.empty_like(qd)
-    rows = ops.tattn_blocks(B * HW) * 8
+    rows = ops.tattn_blocks(B * HW) * 4
     part = torch.empty(rows, T * T, device="cuda")
     ops.tattn_bwd(qd, rc, rs, dev(bias.detach()), dev(go).view(-1, 128), gq, part, B, T, HW)
     assert rel_l2(gq.cpu(), qkv.grad.reshape(-1, 384)) < 2e-5
