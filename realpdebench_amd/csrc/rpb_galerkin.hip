@@ -350,19 +350,25 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
         }
         const long m0 = tile * 32;
         const long rowbase = (long)b * a.n + m0;
+        // epilogue through the (dead) wave-private x tile: a lane then owns 4 consecutive channels of a row, so the mask /
+        // residual reads and the store are 16 B per lane (4 rows x 256 B per wave instruction)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = mfma_row(lane, r);
-                if (m0 + rr < a.n) {
-                    const int ch = h * 64 + t * 32 + col;
-                    float v = acc[t][r];
-                    if (a.mask) v *= a.mask[(rowbase + rr) * a.ldm + ch];
-                    if (a.residual) v += a.residual[(rowbase + rr) * a.ldr + ch];
-                    a.out[(rowbase + rr) * a.ldo + ch] = v;
-                }
+            for (int r = 0; r < 16; ++r) xl[mfma_row(lane, r) * HA_XS + t * 32 + col] = acc[t][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 4 + lrow;
+            if (m0 + rr < a.n) {
+                const float* sp = xl + rr * HA_XS + lc4;
+                f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+                const int ch = h * 64 + lc4;
+                if (a.mask) v = v * *reinterpret_cast<const f32x4*>(a.mask + (rowbase + rr) * a.ldm + ch);
+                if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + (rowbase + rr) * a.ldr + ch);
+                *reinterpret_cast<f32x4*>(a.out + (rowbase + rr) * a.ldo + ch) = v;
             }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -371,7 +377,8 @@ extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* o
                               int ldr, const float* mask, int ldm, int B, long n, int nheads, void* stream) {
     RPB_REQUIRE(X && Wm && out && B > 0 && n > 0, "head_apply: bad arguments");
     RPB_REQUIRE(nheads == 1 || nheads == 2 || nheads == 4, "head_apply: %d heads of 64 channels (1, 2 or 4)", nheads);
-    RPB_REQUIRE(ldx % 4 == 0 && ldx >= 64 * nheads && ldo >= 64 * nheads, "head_apply: bad leading dimensions %d %d", ldx, ldo);
+    RPB_REQUIRE(ldx % 4 == 0 && ldx >= 64 * nheads && ldo % 4 == 0 && ldo >= 64 * nheads && ldr % 4 == 0 && ldm % 4 == 0,
+                "head_apply: leading dimensions %d %d %d %d must be multiples of 4 and cover the heads", ldx, ldo, ldr, ldm);
     HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm, nheads};
     const long ntiles = (n + 31) / 32;
     long chunks = ((long)rpb_num_cus() * 2 + B - 1) / B;
