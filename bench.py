@@ -119,6 +119,7 @@ def bench_unet(dev, steps=2):
 
     m.train()
     step()
+    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -170,6 +171,7 @@ def bench_galerkin(dev, steps=3):
 
     m.train()
     step()
+    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -216,6 +218,7 @@ def bench_transolver(dev, B=4, steps=3):
 
     m.train()
     step()
+    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
