@@ -822,12 +822,14 @@ __global__ __launch_bounds__(256) void tn_small_kernel(TnSmallArgs a) {
     }
 }
 
-// shapes served by tn_small_kernel: N in {64, 128, 256, 384}, K a multiple of the k block, K <= 384, N*K <= 48 tiles
-// (256 x 256 and beyond run faster on the register-operand kernel: 100-121 TF/s)
+// shapes served by tn_small_kernel: N in {64, 128, 256, 384}, K a multiple of the k block; N = 64: K <= 1280, otherwise
+// K <= 384 and N*K <= 48 tiles (256 x 256 and beyond run faster on the register-operand kernel: 100-121 TF/s)
 static bool tn_small_ok(int N, int K, int ldg, int lda) {
-    if (!(N == 64 || N == 128 || N == 256 || N == 384) || K > 384 || (long)N * K > 49152 || ldg % 4 || lda % 4) return false;
+    if (!(N == 64 || N == 128 || N == 256 || N == 384) || ldg % 4 || lda % 4) return false;
     const int bk = (N == 64) ? 128 : 64;
-    return K % bk == 0;
+    if (K % bk) return false;
+    if (N == 64) return K <= 1280;                      // narrow G: re-reading it once per k block is cheap (U-Net init_conv: K = 1152)
+    return K <= 384 && (long)N * K <= 49152;
 }
 
 static int tn_small_splits(long M, int N, int K) {

@@ -272,7 +272,7 @@ class Unet3d(_ModelBase):
         elif kind == "init":           # [dim,Cin,k,k,k] -> [dim][ldc] with column = tap*Cin + ci, zero-padded
             k = d.shape[2]
             cols = k * k * k * d.shape[1]
-            ldc = (cols + 31) // 32 * 32
+            ldc = (cols + 127) // 128 * 128        # 128-column k blocks of the LDS-tiled weight-gradient kernel
             v = torch.zeros(d.shape[0], ldc, device=d.device)
             v[:, :cols] = d.permute(0, 2, 3, 4, 1).reshape(d.shape[0], cols)
         else:
