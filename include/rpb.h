@@ -68,6 +68,8 @@ int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, i
  *     the output is the gradient w.r.t. act(BN(bnb_s)) and the partials are instead (sum gz, sum gz*shat), the
  *     first pass of that layer's BatchNorm backward (bnb_* = its mean, invstd, gamma, beta, gelu flag). */
 long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int bn_bwd_stats);
+/*     bnb_s == NULL with the four bnb vectors given (and no stats_part): OUTPUT transform, the tile is stored as
+ *     act(BN(out)) -- eval mode, where the running statistics are known before the launch (fno.py:117-119). */
 int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out,
                  float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w, int gather, int T,
                  int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean, const float* xf_invstd,

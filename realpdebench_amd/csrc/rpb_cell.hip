@@ -113,11 +113,14 @@ __global__ __launch_bounds__((KC >= 128 || STATS == 2) ? 512 : CM_MAX_THREADS) v
     const bool k2_exact = (K2 == 2 * K2S);
     float ssum[NT], ssq[NT], bv[NT];
     XParam bp[NT];
+    // STATS == 0 with bnb vectors but no bnb_s: OUTPUT transform -- the tile is stored as act(BN(out)) (eval mode: the
+    // running statistics are known, so the activation is materialised once instead of lazily by both consumers)
+    const bool oxf = STATS == 0 && a.bnb_s == nullptr && a.bnb.mean != nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         ssum[t] = ssq[t] = 0.f;
         bv[t] = a.bias ? a.bias[t * 32 + col] : 0.f;
-        if (STATS == 2) bp[t] = xf_load(a.bnb, t * 32 + col);
+        if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, t * 32 + col);
     }
 
     const bool has_xf = a.xf.mean != nullptr;          // only used with the contiguous (non-gather) x layout
@@ -303,7 +306,8 @@ __global__ __launch_bounds__((KC >= 128 || STATS == 2) ? 512 : CM_MAX_THREADS) v
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = 8 * (r >> 2) + (r & 3);
-                    const float v = acc[t][r] + bv[t];
+                    float v = acc[t][r] + bv[t];
+                    if (STATS == 0 && oxf) v = xf_apply(v, bp[t], a.bnb.gelu != 0);
                     if (full || rr + 4 * half < rows_left) {
                         ob[lo + rr * CO + t * 32] = v;
                         if (STATS == 1) {
@@ -401,6 +405,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     a.bnb_s = bnb_s;
     a.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu};
     if (bnb_s) RPB_REQUIRE(stats_part && bnb_mean && bnb_invstd && bnb_gamma && bnb_beta, "cell_mix: BN-backward statistics need stats_part and all four vectors");
+    if (!bnb_s && bnb_mean) RPB_REQUIRE(!stats_part && bnb_invstd && bnb_gamma && bnb_beta, "cell_mix: the output transform needs all four vectors and no statistics");
     const int grid = (int)(rpb_cell_mix_stat_rows(ncell, KC, CO, K2, Wp, spec, bnb_s != nullptr) / waves);
     hipStream_t st = (hipStream_t)stream;
     const int stats = stats_part == nullptr ? 0 : (bnb_s ? 2 : 1);

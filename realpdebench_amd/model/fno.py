@@ -308,18 +308,24 @@ class FNO3d(Model):
             self._spectral_forward_stages(a_in, ws, xh, (plan.FWt, plan.FHt, plan.FTt), first_layer=(l == 0), xf=xf)
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
             self._spectral_inverse_stages(ws.Yh, ws, (plan.GTt, plan.GHt))
-            ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s,
-                         ws.stat_part if training else None, d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
             if training:
+                ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, ws.stat_part,
+                             d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
                 ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
                 if world > 1:
                     self.dp.all_reduce_sum(ws.sums64)
                 ops.bn_finalize(ws.sums64, float(d.ncell) * world, BN_EPS, BN_MOMENTUM, ws.mean[l], ws.invstd[l],
                                 self.bn_running_mean[l], self.bn_running_var[l], C)
                 self.bn_num_batches_tracked[l] += 1
+                a_in, xf = s, self._layer_xf(ws, l, True)          # fno.py:117-119, applied lazily by the next consumers
             else:
+                # eval: the running statistics are known before the launch, so BatchNorm (+GELU) is applied to the tile in
+                # cell_mix's epilogue and the next W stage / cell_mix / projection read plain activations (one erf per
+                # element instead of two)
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
-            a_in, xf = s, self._layer_xf(ws, l, training)          # fno.py:117-119, applied by the next consumer
+                ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, None, d.ncell, C, C,
+                             2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
+                a_in, xf = s, None
         ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
                      xf=xf, act=self.proj_act)
         return ws.out

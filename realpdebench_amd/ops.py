@@ -106,15 +106,21 @@ def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec, bn_bwd_stats=False):
 
 
 def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
-             crop6=(0, 0, 0, 1, 1, 1), xf=None, bnb=None):
+             crop6=(0, 0, 0, 1, 1, 1), xf=None, bnb=None, oxf=None):
     """``bnb`` = (s, mean, invstd, gamma, beta, gelu) of the layer whose output gradient this launch produces: the
-    stats partials then hold that layer's BatchNorm-backward sums (sum gz, sum gz*shat)."""
+    stats partials then hold that layer's BatchNorm-backward sums (sum gz, sum gz*shat).
+    ``oxf`` = (mean, invstd, gamma, beta, gelu): store act(BN(out)) instead of out (eval mode, no statistics)."""
+    tag = None
+    if oxf is not None:
+        assert bnb is None and stats_part is None
+        bnb, tag = (None,) + tuple(oxf), "oxf"
+
     spec, stats = z2 is not None, stats_part is not None
     rows_in = (crop6[0] * crop6[1] * crop6[2] * (ncell // (crop6[3] * crop6[4] * crop6[5]))) if gather else ncell
     _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
               int(transpose_w), int(gather), *crop6, *_xf(xf),
               *((None,) + _xf(None) if bnb is None else (_p(bnb[0]),) + _xf(bnb[1:])), _stream(),
-              label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={int(stats) + int(bnb is not None)}]",
+              label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={tag or int(stats) + int(bnb is not None)}]",
               nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
 
