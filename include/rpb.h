@@ -152,7 +152,10 @@ int rpb_channel_affine(const float* in, float* out, long n, int C, const float* 
  *          4 zero where aux[m][n] <= 0 (backward through that ReLU; aux = the saved ReLU output). */
 int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual, float* out,
                 long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask,
-                int conv, int Hc, int Wc, int Dc, int cls, void* stream);   /* mask: optional [M][ldo] inverted-dropout multiplier */
+                int conv, int Hc, int Wc, int Dc, int cls, long drop_seed, float drop_keep, void* stream);
+/*     mask: optional [M][ldo] inverted-dropout multiplier; or drop_keep in (0,1): the same nn.Dropout generated in the
+ *     epilogue by a counter-based RNG (Philox4x32-10) keyed on (drop_seed, element index m*ldo + n), so that the backward
+ *     pass regenerates it (rpb_dropout_mul, or the same seed on the data-gradient GEMM) and no mask tensor exists. */
 /*     conv = 2 / 3: the U-Net's Downsample nn.Conv3d(C, C, (1,4,4), (1,2,2), (0,1,1)) (realpdebench/model/unet.py:166-167; rows =
  *     output tokens, K = 16*Ci, k = (kh*4 + kw)*Ci + ci) and one output-parity class cls = 2*ph + pw of its Upsample
  *     nn.ConvTranspose3d (unet.py:163-164; rows = input tokens, written to row (t, 2h+ph, 2w+pw), K = 4*Ci); the data gradient
@@ -219,7 +222,9 @@ int rpb_headnorm_bwd(const float* x, int ldx, const float* gamma, const float* g
 int rpb_head_scores_chunks(int B, long n);
 int rpb_head_scores(const float* G, int ldg, const float* A, int lda, float* part, int B, long n, int nheads, void* stream);
 int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual, int ldr,
-                   const float* mask, int ldm, int B, long n, int nheads, void* stream);
+                   const float* mask, int ldm, int B, long n, int nheads, long drop_seed, float drop_keep, void* stream);
+/*     out = g * dropout_mask(seed, element index) on a dense tensor (backward of the in-kernel dropout). */
+int rpb_dropout_mul(const float* g, float* out, long n, long seed, float keep, void* stream);
 /*     nheads = number of 64-channel heads per row (Galerkin: 4; the U-Net's spatial linear attention: 2). */
 /*     SpectralRegressor.forward model.py:612-618 after the 256-wide token GEMM U = x fc.weight[:, :256]^T:
  *     out[b,t,h,w,:] = U[token] + fc.weight[:, 256:259] (gt[t], gh[h], gw[w]) + fc.bias inside the mesh, 0 in the

@@ -44,7 +44,7 @@ SIGNATURES = {
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
-    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiiii" + "p"),
+    "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiiii" + "lf" + "p"),
     "rpb_mul": (_I, "ppp" + "l" + "p"),
     "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
@@ -64,7 +64,8 @@ SIGNATURES = {
     "rpb_headnorm_bwd": (_I, "pippipip" + "l" + "i" + "f" + "p"),
     "rpb_head_scores_chunks": (_I, "il"),
     "rpb_head_scores": (_I, "pipip" + "ili" + "p"),
-    "rpb_head_apply": (_I, "pippipipi" + "ili" + "p"),
+    "rpb_head_apply": (_I, "pippipipi" + "ili" + "lf" + "p"),
+    "rpb_dropout_mul": (_I, "pp" + "l" + "lf" + "p"),
     "rpb_chan_blocks": (_I, "il"),
     "rpb_chan_stats": (_I, "pp" + "ili" + "p"),
     "rpb_affine_silu_fwd": (_I, "ppppp" + "ili" + "p"),

@@ -148,3 +148,42 @@ __device__ __forceinline__ long crop_to_pad(const CropMap& m, long q) {
     long b = r / m.T;
     return ((b * m.Tp + t) * m.Hp + h) * (long)m.Wp + w;
 }
+
+// ---------------------------------------------------------------------------------- in-kernel dropout
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the inverted-dropout multiplier of an element is a pure function
+// of (seed, element index) -- the forward epilogue and the backward pass regenerate the same mask instead of writing and
+// re-reading a mask tensor (nn.Dropout of the Galerkin / Transolver layers).  One call yields the 4 multipliers of the
+// float4 whose first element has linear index 4*q in the dense [rows][C] tensor the dropout applies to.
+struct DropSpec {
+    unsigned long long seed;
+    unsigned thr;        // keep iff random u32 < thr (= keep probability * 2^32); 0 = dropout disabled
+    float inv_keep;
+};
+__device__ __forceinline__ f32x4 dropout4(const DropSpec& d, unsigned long long q) {
+    unsigned c0 = (unsigned)q, c1 = (unsigned)(q >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    unsigned k0 = (unsigned)d.seed, k1 = (unsigned)(d.seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    f32x4 m;
+    m[0] = c0 < d.thr ? d.inv_keep : 0.f;
+    m[1] = c1 < d.thr ? d.inv_keep : 0.f;
+    m[2] = c2 < d.thr ? d.inv_keep : 0.f;
+    m[3] = c3 < d.thr ? d.inv_keep : 0.f;
+    return m;
+}
+static inline DropSpec make_drop(long seed, float keep) {
+    DropSpec d;
+    d.seed = (unsigned long long)seed;
+    d.thr = (keep > 0.f && keep < 1.f) ? (unsigned)((double)keep * 4294967296.0) : 0u;
+    d.inv_keep = d.thr ? 1.0f / keep : 1.0f;
+    return d;
+}

@@ -286,6 +286,7 @@ struct HeadApplyArgs {
     const float* mask;
     long n;
     int ldx, ldo, ldr, ldm, nh;
+    DropSpec drop;       // in-kernel dropout instead of `mask`: element index = row * (64*nh) + channel
 };
 
 #define HA_WAVES 8
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
                 f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
                 const int ch = h * 64 + lc4;
                 if (a.mask) v = v * *reinterpret_cast<const f32x4*>(a.mask + (rowbase + rr) * a.ldm + ch);
+                if (a.drop.thr) v = v * dropout4(a.drop, (unsigned long long)((rowbase + rr) * (64 * nh) + ch) >> 2);
                 if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + (rowbase + rr) * a.ldr + ch);
                 *reinterpret_cast<f32x4*>(a.out + (rowbase + rr) * a.ldo + ch) = v;
             }
@@ -374,12 +376,14 @@ __global__ __launch_bounds__(HA_WAVES * 64) void head_apply_kernel(HeadApplyArgs
 }
 
 extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* out, int ldo, const float* residual,
-                              int ldr, const float* mask, int ldm, int B, long n, int nheads, void* stream) {
+                              int ldr, const float* mask, int ldm, int B, long n, int nheads, long drop_seed,
+                              float drop_keep, void* stream) {
     RPB_REQUIRE(X && Wm && out && B > 0 && n > 0, "head_apply: bad arguments");
     RPB_REQUIRE(nheads == 1 || nheads == 2 || nheads == 4, "head_apply: %d heads of 64 channels (1, 2 or 4)", nheads);
     RPB_REQUIRE(ldx % 4 == 0 && ldx >= 64 * nheads && ldo % 4 == 0 && ldo >= 64 * nheads && ldr % 4 == 0 && ldm % 4 == 0,
                 "head_apply: leading dimensions %d %d %d %d must be multiples of 4 and cover the heads", ldx, ldo, ldr, ldm);
-    HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm, nheads};
+    HeadApplyArgs a{X, Wm, out, residual, mask, n, ldx, ldo, ldr, ldm, nheads, make_drop(drop_seed, drop_keep)};
+    if (a.drop.thr) RPB_REQUIRE(!mask, "head_apply: pass a mask tensor or a dropout seed, not both");
     const long ntiles = (n + 31) / 32;
     long chunks = ((long)rpb_num_cus() * 2 + B - 1) / B;
     const int nsub = HA_WAVES / nheads;
@@ -389,4 +393,21 @@ extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* o
     (void)hipFuncSetAttribute((const void*)head_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(head_apply_kernel, dim3((unsigned)chunks, B), dim3(HA_WAVES * 64), lds, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("head_apply");
+}
+
+// ---------------------------------------------------------------------------------- dropout regenerated in the backward pass
+// out[i] = g[i] * mask(seed, i) over a dense [rows][C] tensor: the gradient through an nn.Dropout whose forward mask was
+// generated in a GEMM / head_apply epilogue from the same (seed, element index).
+__global__ __launch_bounds__(256) void dropout_mul_kernel(const float* __restrict__ g, float* __restrict__ out, long n4,
+                                                          DropSpec d) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(g)[i] * dropout4(d, (unsigned long long)i);
+}
+
+extern "C" int rpb_dropout_mul(const float* g, float* out, long n, long seed, float keep, void* stream) {
+    RPB_REQUIRE(g && out && n > 0 && n % 4 == 0, "dropout_mul: n must be a positive multiple of 4");
+    RPB_REQUIRE(keep > 0.f && keep < 1.f, "dropout_mul: keep probability %f outside (0, 1)", (double)keep);
+    hipLaunchKernelGGL(dropout_mul_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, g, out, n / 4,
+                       make_drop(seed, keep));
+    RPB_CHECK_LAUNCH("dropout_mul");
 }

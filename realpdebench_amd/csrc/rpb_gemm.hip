@@ -29,6 +29,7 @@ struct GemmArgs {
     const float* aux;      // act == 2: the saved pre-activation [M][ldo]; act == 4: the saved ReLU output
     float* pre_out;        // act == 1: optional copy of the pre-activation (saved for the backward pass)
     const float* mask;     // optional [M][ldo] multiplier applied before addvec/residual (inverted-dropout mask)
+    DropSpec drop;         // or the same dropout regenerated in-kernel from (seed, element index m*ldo + n)
     // conv = 1: implicit 3x3x3 convolution (padding 1) over a (Hc, Wc, Dc) mesh, tokens row-major in (h, w, d); Ci = K / 27
     // conv = 2: nn.Conv3d(C, C, (1,4,4), stride (1,2,2), padding (0,1,1)) -- U-Net Downsample, unet.py:166-167: the INPUT
     //           lives on the mesh (Hc, Wc, Dc) = (T, H, W), rows m enumerate the output mesh (T, H/2, W/2); K = 16*Ci,
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmArgs g) {
                             for (int k = 0; k < 4; ++k) v[k] = ax[k] > 0.f ? v[k] : 0.f;
                         }
                         if (g.mask) v = v * *reinterpret_cast<const f32x4*>(g.mask + off);
+                        if (g.drop.thr) v = v * dropout4(g.drop, (unsigned long long)off >> 2);
                         v += vadd;
                         if (g.residual) v += *reinterpret_cast<const f32x4*>(g.residual + off);
                         *reinterpret_cast<f32x4*>(g.out + off) = v;
@@ -327,7 +329,8 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, const float* addvec, const float* residual,
                            float* out, long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out,
-                           const float* mask, int conv, int Hc, int Wc, int Dc, int cls, void* stream) {
+                           const float* mask, int conv, int Hc, int Wc, int Dc, int cls, long drop_seed, float drop_keep,
+                           void* stream) {
     RPB_REQUIRE(A && W && out, "gemm_nt: null pointer");
     RPB_REQUIRE((act != 2 && act != 4) || aux, "gemm_nt: act=2/4 needs the saved activation tensor");
     RPB_REQUIRE(act >= 0 && act <= 4, "gemm_nt: unknown act=%d", act);
@@ -351,6 +354,8 @@ extern "C" int rpb_gemm_nt(const float* A, const float* W, const float* bias, co
     g.A = A; g.W = W; g.bias = bias; g.addvec = addvec; g.residual = residual; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldo = ldo; g.act = act; g.aux = aux; g.pre_out = pre_out; g.mask = mask;
     g.conv = conv; g.Hc = Hc; g.Wc = Wc; g.Dc = Dc; g.cls = cls;
+    g.drop = make_drop(drop_seed, drop_keep);
+    if (g.drop.thr) RPB_REQUIRE(!mask && N % 4 == 0 && ldo % 4 == 0 && conv != 3, "gemm_nt: in-kernel dropout needs N, ldo multiples of 4 and no mask tensor");
     hipStream_t st = (hipStream_t)stream;
     if (N > 64) return launch_gemm<2, 2, 2, 2>(g, st);      // 128 x 128 tile
     if (N > 32) return launch_gemm<2, 2, 2, 1>(g, st);      // 128 x 64

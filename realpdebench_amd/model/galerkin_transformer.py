@@ -260,15 +260,38 @@ class GalerkinTransformer3d(_ModelBase):
         if self._mask_override is not None:
             return dict(self._mask_override)
         mk = {}
-        bern = lambda shape, p: torch.empty(*shape, **f).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
-        if self.training or self.eval_attn_dropout:
-            mk["attn"] = bern((B, self.n_head, _DK, _DK), 0.5)                  # layers.py:730-731 (functional defaults)
+        if self.training or self.eval_attn_dropout:                             # layers.py:730-731 (functional defaults)
+            mk["attn"] = torch.empty(B, self.n_head, _DK, _DK, **f).bernoulli_(0.5).mul_(2.0)
         if self.training:
+            # the three token-sized nn.Dropouts never exist as tensors: each site is a (seed, keep) pair, the mask is
+            # generated in the producing kernel's epilogue (Philox keyed on the element index) and regenerated in backward
+            seeds = torch.randint(0, 2 ** 62, (3,)).tolist()                    # host RNG: no device sync
             if self.p_enc > 0:
-                mk["d1"], mk["d2"] = bern((M, self.n_hidden), self.p_enc), bern((M, self.n_hidden), self.p_enc)
+                mk["d1"], mk["d2"] = (seeds[0], 1.0 - self.p_enc), (seeds[1], 1.0 - self.p_enc)
             if self.p_ffn > 0:
-                mk["ffn"] = bern((M, self.dim_ff), self.p_ffn)
+                mk["ffn"] = (seeds[2], 1.0 - self.p_ffn)
         return mk
+
+    @staticmethod
+    def _site(mk, key):
+        """A dropout site of this step -> (mask tensor | None, (seed, keep) | None)."""
+        v = mk.get(key)
+        if v is None:
+            return None, None
+        return (None, v) if isinstance(v, tuple) else (v, None)
+
+    @staticmethod
+    def _through_dropout(g, site, n):
+        """g * mask of a dropout site (backward through nn.Dropout); returns g itself when the site is off."""
+        m, d = site
+        if m is None and d is None:
+            return g
+        out = torch.empty_like(g)
+        if d is not None:
+            ops.dropout_mul(g, out, n, d[0], d[1])
+        else:
+            ops.mul(g, m, out, n)
+        return out
 
     def _head_products(self, G, ldg, A, lda, B, n, mask):
         """[B,4,64,64] = (G_h^T A_h) / n (x the attention-dropout mask): layers.py:723-731 and its backward."""
@@ -308,12 +331,15 @@ class GalerkinTransformer3d(_ModelBase):
         # ---- p_attn = drop(K^T V / n) per sample and head (layers.py:723-731), x1 = x0 + drop(Q p_attn) (model.py:112-116)
         P = self._head_products(ops.Sub(KVn, 0), 2 * C, ops.Sub(KVn, C), 2 * C, B, n, mk.get("attn"))
         X1 = new(M, C)
-        ops.head_apply(ops.Sub(QKV, 0), 3 * C, P, X1, C, B, n, residual=X0, ldr=C, mask=mk.get("d1"), ldm=C)
+        m1, dr1 = self._site(mk, "d1")
+        ops.head_apply(ops.Sub(QKV, 0), 3 * C, P, X1, C, B, n, residual=X0, ldr=C, mask=m1, ldm=C, drop=dr1)
         # ---- x2 = x1 + drop(lr2(drop(relu(lr1(x1)))))  (layers.py:979-987, model.py:120-121)
         Hh = new(M, Fh)
-        ops.gemm_nt(X1, enc.ff.lr1.weight.data, Hh, M, Fh, C, bias=enc.ff.lr1.bias.data, act=3, mask=mk.get("ffn"))
+        mf, drf = self._site(mk, "ffn")
+        ops.gemm_nt(X1, enc.ff.lr1.weight.data, Hh, M, Fh, C, bias=enc.ff.lr1.bias.data, act=3, mask=mf, drop=drf)
         X2 = new(M, C)
-        ops.gemm_nt(Hh, enc.ff.lr2.weight.data, X2, M, C, Fh, bias=enc.ff.lr2.bias.data, residual=X1, mask=mk.get("d2"))
+        m2, dr2 = self._site(mk, "d2")
+        ops.gemm_nt(Hh, enc.ff.lr2.weight.data, X2, M, C, Fh, bias=enc.ff.lr2.bias.data, residual=X1, mask=m2, drop=dr2)
         # ---- spectral regressor (model.py:600-638)
         reg = self.regressor
         training = save is not None
@@ -340,22 +366,17 @@ class GalerkinTransformer3d(_ModelBase):
         grads[reg.flat] = gflat
         g = ws.gx                                                     # dLoss/dX2
         # ---- FeedForward
-        g2 = g
-        if mk.get("d2") is not None:
-            g2 = new(M, C)
-            ops.mul(g, mk["d2"], g2, M * C)
+        g2 = self._through_dropout(g, self._site(mk, "d2"), M * C)
         grads[enc.ff.lr2.weight], grads[enc.ff.lr2.bias] = _wgrad(g2, sv["Hh"], M, C, Fh)
         gH = new(M, Fh)
-        ops.gemm_nt(g2, T_(enc.ff.lr2.weight), gH, M, Fh, C, act=4, aux=sv["Hh"], mask=mk.get("ffn"))
+        mf, drf = self._site(mk, "ffn")
+        ops.gemm_nt(g2, T_(enc.ff.lr2.weight), gH, M, Fh, C, act=4, aux=sv["Hh"], mask=mf, drop=drf)
         grads[enc.ff.lr1.weight], grads[enc.ff.lr1.bias] = _wgrad(gH, sv["X1"], M, Fh, C)
         gX1 = new(M, C)
         ops.gemm_nt(gH, T_(enc.ff.lr1.weight), gX1, M, C, Fh, residual=g)
         del gH
         # ---- attention output: x1 = x0 + d1 * (Q P)
-        ga = gX1
-        if mk.get("d1") is not None:
-            ga = new(M, C)
-            ops.mul(gX1, mk["d1"], ga, M * C)
+        ga = self._through_dropout(gX1, self._site(mk, "d1"), M * C)
         QKV, KVn, P = sv["QKV"], sv["KVn"], sv["P"]
         dS = self._head_products(ops.Sub(QKV, 0), 3 * C, ga, C, B, n, mk.get("attn"))      # dL/d(K^T V), masked, / n
         gQKV, gKVn = new(M, 3 * C), new(M, 2 * C)

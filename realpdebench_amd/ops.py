@@ -227,18 +227,19 @@ def mul(a, b, out, n):
 
 
 def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
-            pre_out=None, mask=None, conv_mode=1, cls=0):
+            pre_out=None, mask=None, conv_mode=1, cls=0, drop=None):
     """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A an implicit im2col of a token tensor:
     ``conv_mode`` 1 = 3x3x3 padding 1, 2 = (1,4,4) stride (1,2,2) padding (0,1,1) (M = output tokens), 3 = parity class
     ``cls`` of the matching transposed convolution (M = input tokens).
-    act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``); 3: ReLU; 4: ReLU'."""
+    act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``); 3: ReLU; 4: ReLU'.
+    ``mask``: inverted-dropout multiplier tensor, or ``drop=(seed, keep)``: the same dropout generated in the epilogue."""
     hc, wc, dc = conv if conv else (0, 0, 0)
     mode = int(conv_mode) if conv else 0
     taps = {0: 1, 1: 27, 2: 16, 3: 4}[mode]
     lda = (K // taps) if lda is None else lda
     _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
               N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), _p(mask), mode, hc, wc, dc, int(cls),
-              _stream(),
+              int(drop[0]) if drop else 0, float(drop[1]) if drop else 0.0, _stream(),
               label=f"gemm_nt[N{N},K{K},conv={mode}]", nbytes=4 * (M * lda + M * N + N * K),
               flops=2 * M * N * K)
 
@@ -346,10 +347,10 @@ def head_scores(G, ldg, A, lda, part, B, n, nheads=4):
               nbytes=4 * B * n * 128 * nheads, flops=2 * B * n * nheads * 64 * 64)
 
 
-def head_apply(X, ldx, Wm, out, ldo, B, n, residual=None, ldr=0, mask=None, ldm=0, nheads=4):
-    """out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual."""
+def head_apply(X, ldx, Wm, out, ldo, B, n, residual=None, ldr=0, mask=None, ldm=0, nheads=4, drop=None):
+    """out[b,m][64h+j] = (sum_i X[b,m][64h+i] Wm[b][h][i][j]) * mask + residual (``drop=(seed, keep)``: in-kernel mask)."""
     _lib.call("rpb_head_apply", _p(X), ldx, _p(Wm), _p(out), ldo, _p(residual), ldr, _p(mask), ldm, B, n, nheads,
-              _stream(), label="head_apply",
+              int(drop[0]) if drop else 0, float(drop[1]) if drop else 0.0, _stream(), label="head_apply",
               nbytes=4 * B * n * 64 * nheads * (2 + (residual is not None) + (mask is not None)),
               flops=2 * B * n * nheads * 64 * 64)
 
@@ -421,3 +422,8 @@ def col_reduce(x, ldx, part, F, n, C, mode):
     """mode 0: per-frame column max partials, 1: column sum partials -- part[chan_blocks(F, n)][F][C]."""
     _lib.call("rpb_col_reduce", _p(x), ldx, _p(part), F, n, C, int(mode), _stream(), label="col_reduce",
               nbytes=4 * F * n * C)
+
+
+def dropout_mul(g, out, n, seed, keep):
+    """out = g * inverted-dropout mask regenerated from (seed, element index): backward of the in-kernel dropout."""
+    _lib.call("rpb_dropout_mul", _p(g), _p(out), n, int(seed), float(keep), _stream(), label="dropout_mul", nbytes=8 * n)

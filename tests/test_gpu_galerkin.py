@@ -190,6 +190,34 @@ def test_train_with_dropout_masks_matches_oracle():
     _check_grads(m, grads_ref)
 
 
+def test_in_kernel_dropout_matches_oracle_with_extracted_masks(ops):
+    """Production dropout: no mask tensors, every site is a (seed, keep) pair expanded by Philox in the epilogues.  The masks
+    are extracted by pushing ones through rpb_dropout_mul with the same seeds and handed to the oracle explicitly."""
+    from oracle import galerkin_oracle as GO
+    g = galerkin_golden()
+    torch.manual_seed(17)
+    B, n = g["x"].shape[0], g["x"][0].numel() // g["x"].shape[-1]
+    M = B * n
+    sites = dict(d1=(123456789012345, 0.95), ffn=(987654321, 0.9), d2=(55, 0.8))
+    ones = torch.ones(M, 256, device="cuda")
+    masks = {}
+    for k, (seed, keep) in sites.items():
+        out = torch.empty_like(ones)
+        ops.dropout_mul(ones, out, M * 256, seed, keep)
+        frac = float((out > 0).float().mean())
+        assert abs(frac - keep) < 0.01 and torch.all((out == 0) | (out - 1.0 / keep).abs().lt(1e-6))
+        masks[k] = out.cpu().view(B, n, 256)
+    masks["attn"] = (torch.rand(B, 4, 64, 64) >= 0.5).float() * 2
+    loss_ref, _, grads_ref, _ = GO.loss_and_grads(g["sd"], g["x"], g["target"], g["heads"], g["modes"], g["shape_out"],
+                                                  masks=masks)
+    m = _model_from_golden(g).train()
+    m._mask_override = dict(sites, attn=masks["attn"].cuda())
+    loss = m.train_loss(g["x"].cuda(), g["target"].cuda()).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    _check_grads(m, grads_ref)
+
+
 def test_train_mode_draws_masks_and_runs():
     g = galerkin_golden()
     m = _model_from_golden(g).train()
