@@ -166,7 +166,8 @@ class Transolver(_ModelBase):
                 else:
                     keep_p = 1.0 - self.dropout_p
                     amask = (torch.rand(B, heads, G, G, **f) < keep_p).float() / keep_p
-                    omask = (torch.rand(M, C, **f) < keep_p).float() / keep_p
+                    # the token-sized mask after to_out never exists: (seed, keep) expanded by Philox in the GEMM epilogue
+                    omask = (int(torch.randint(0, 2 ** 62, (1,))), keep_p)
                 # 16 x 16 attention with the mask: a few thousand numbers per sample (plumbing-scale torch glue)
                 tk = tokS.view(B, heads, G, 32) / (norm.view(B, heads, G) + 1e-5)[..., None]
                 q, k, v = tk @ at.to_q.weight.data.t(), tk @ at.to_k.weight.data.t(), tk @ at.to_v.weight.data.t()
@@ -176,7 +177,8 @@ class Transolver(_ModelBase):
                                B * heads, G)
             ops.deslice_fwd(w, tok2, ox, B, ntok, heads, G)
             fx1 = new(M, C) if keep else fx
-            ops.gemm_nt(ox, at.to_out[0].weight.data, fx1, M, C, C, bias=at.to_out[0].bias.data, residual=fx, mask=omask)
+            ops.gemm_nt(ox, at.to_out[0].weight.data, fx1, M, C, C, bias=at.to_out[0].bias.data, residual=fx,
+                        mask=None if isinstance(omask, tuple) else omask, drop=omask if isinstance(omask, tuple) else None)
             if keep:
                 st.update(amask=amask, omask=omask)
             a2 = new(M, C) if keep else a
@@ -258,7 +260,10 @@ class Transolver(_ModelBase):
             g1m = g1
             if st["omask"] is not None:                      # dropout after to_out: gradient flows through the same mask
                 g1m = new(M, C)
-                ops.mul(g1, st["omask"], g1m, M * C)
+                if isinstance(st["omask"], tuple):
+                    ops.dropout_mul(g1, g1m, M * C, *st["omask"])
+                else:
+                    ops.mul(g1, st["omask"], g1m, M * C)
             grads[at.to_out[0].weight], grads[at.to_out[0].bias] = self._wgrad(g1m, st["ox"], M, C, C)
             gox = new(M, C)
             ops.gemm_nt(g1m, T(at.to_out[0].weight), gox, M, C, C)
