@@ -103,129 +103,143 @@ extern "C" int rpb_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 // ---------------------------------------------------------------------------------- slice: weights + token sums
-// Physics_Attention.py:158-162 for dim_head = 32, heads = C/32, G <= 32 slices:
+// Physics_Attention.py:158-162 for dim_head = 32, heads = C/32, G <= 32 slices (G % 4 == 0):
 //   w[m][h][g]   = softmax_g( (xmid[m][h*32:+32] . Ws[g] + bs[g]) / clamp(temp[h], 0.1, 5) )
 //   norm[b][h][g] = sum_{m in b} w,     tokS[b][h][g][c] = sum_{m in b} fx[m][h*32+c] * w[m][h][g]
 // xf: [M][ldx] rows holding fx_mid at column 0 and x_mid at column C (the dual convolution writes them side by side).
-// One block owns 64-token tiles of one sample; per tile: phase 1 = logits+softmax (thread = token x head group),
-// phase 2 = the [G x 64] . [64 x 32] token sums (thread = head x channel, G accumulators in registers).
-__global__ __launch_bounds__(TS_THREADS) void slice_fwd_kernel(const float* __restrict__ xf, const float* __restrict__ Ws,
-                                                               const float* __restrict__ bs, const float* __restrict__ temp,
-                                                               float* __restrict__ w_out, float* __restrict__ part,
-                                                               int ntok, int heads, int G, int ldx, int blocks_per_sample,
-                                                               const float* __restrict__ w_in) {
+// Wave = head, 32-token tiles, both products on the fp32 MFMA (a first VALU version spent an LDS read per FMA: 0.67 TB/s):
+//   logits^T[g][tok] = Ws x^T is accumulated transposed (row = slice, column = token) so that a lane owns one token and the
+//   softmax over slices is register-local (+ one cross-half shuffle); the weights go through a wave-private LDS tile once,
+//   which yields both the coalesced 16 B stores of w and the A operand (row = slice, k = token) of the token sums
+//   tokS[g][c] += w^T fx, whose accumulator lives in registers across the tiles a wave walks.
+#define SL_XS 33
+
+struct SliceArgs {
+    const float* xf;
+    const float* Ws;
+    const float* bs;
+    const float* temp;
+    float* w_out;
+    float* tok_part;      // [B*bps][heads*G*32]
+    float* norm_part;     // [B*bps][heads*G]
+    const float* w_in;    // given weights (backward of deslice): no logits, token sums of xf[:, 0:C] only
+    int ntok, heads, G, ldx, bps;
+};
+
+__global__ __launch_bounds__(512) void slice_fwd_kernel(SliceArgs a) {
     extern __shared__ float lds[];
-    const int C = heads * 32;
-    float* Wsl = lds;                               // [G][33]
-    float* wl = Wsl + G * 33;                       // [heads][64][G]
-    float* fl = wl + heads * 64 * G;                // [64][C + 1]
-    const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
-    for (int idx = threadIdx.x; idx < G * 32; idx += blockDim.x) Wsl[(idx >> 5) * 33 + (idx & 31)] = Ws[idx];
+    const int heads = a.heads, G = a.G, C = heads * 32;
+    float* Wsl = lds;                                            // [32][33] slice projection, rows g >= G zero
+    const int lane = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xl = lds + 32 * SL_XS + h * 3 * 32 * SL_XS;           // wave-private: x_mid tile [32 tok][33]
+    float* fl = xl + 32 * SL_XS;                                 //               fx tile    [32 tok][33]
+    float* wl = fl + 32 * SL_XS;                                 //               weights    [32 tok][33] (columns g >= G zero)
+    const int col = lane & 31, half = lane >> 5;
+    const int b = blockIdx.x / a.bps, blk = blockIdx.x % a.bps;
+    for (int idx = threadIdx.x; idx < 32 * SL_XS; idx += blockDim.x) {
+        const int g = idx / SL_XS, c = idx - g * SL_XS;
+        Wsl[idx] = (!a.w_in && g < G && c < 32) ? a.Ws[g * 32 + c] : 0.f;
+    }
+    for (int idx = lane; idx < 32 * SL_XS; idx += 64) wl[idx] = 0.f;
     __syncthreads();
-
-    const int tid = threadIdx.x;
-    const int ph = tid >> 5, pc = tid & 31;         // phase-2 role: head ph (if < heads), channel pc
-    float accT[32];
+    int jrow[16];
+    float bsv[16];
 #pragma unroll
-    for (int g = 0; g < 32; ++g) accT[g] = 0.f;
-
-    const long base = (long)b * ntok;
-    for (int t0 = blk * 64; t0 < ntok; t0 += blocks_per_sample * 64) {
-        // ---- stage fx tile (coalesced) : 64 tokens x C floats
-        for (int idx = tid; idx < 64 * (C / 4); idx += blockDim.x) {
-            const int r = idx / (C / 4), c4 = idx - r * (C / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + r < ntok) v = *reinterpret_cast<const f32x4*>(xf + (base + t0 + r) * ldx + 4 * c4);
-            float* dst = fl + r * (C + 1) + 4 * c4;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    for (int r = 0; r < 16; ++r) {
+        jrow[r] = mfma_row(lane, r);
+        bsv[r] = (!a.w_in && jrow[r] < G) ? a.bs[jrow[r]] : 0.f;
+    }
+    const float inv_t = a.w_in ? 1.f : 1.0f / fminf(fmaxf(a.temp[h], 0.1f), 5.0f);
+    f32x16 tacc = zero16(), nacc = zero16();
+    const long base = (long)b * a.ntok;
+    const int g4 = G >> 2;
+    for (int t0 = blk * 32; t0 < a.ntok; t0 += a.bps * 32) {
+        // ---- stage the head's x_mid and fx rows of the tile (128 B per token and tensor)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            const bool ok = t0 + row < a.ntok;
+            const float* rp = a.xf + (base + t0 + row) * a.ldx + h * 32 + c4;
+            f32x4 vf = {0.f, 0.f, 0.f, 0.f}, vx = vf;
+            if (ok) vf = *reinterpret_cast<const f32x4*>(rp);
+            if (ok && !a.w_in) vx = *reinterpret_cast<const f32x4*>(rp + C);
+            float* df = fl + row * SL_XS + c4;
+            df[0] = vf[0]; df[1] = vf[1]; df[2] = vf[2]; df[3] = vf[3];
+            if (!a.w_in) {
+                float* dx = xl + row * SL_XS + c4;
+                dx[0] = vx[0]; dx[1] = vx[1]; dx[2] = vx[2]; dx[3] = vx[3];
+            }
         }
-        // ---- phase 1: thread -> (token = tid & 63, heads hq, hq + 4, ...)
-        {
-            const int r = tid & 63;
-            const bool ok = t0 + r < ntok;
-            for (int h = tid >> 6; h < heads; h += TS_THREADS / 64) {
-                if (w_in) {        // weights given (backward of deslice): just stage them
+        if (a.w_in) {                                             // given weights -> wl[tok][g]
+            for (int idx = lane; idx < 32 * g4; idx += 64) {
+                const int row = idx / g4, q = idx - row * g4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t0 + row < a.ntok) v = *reinterpret_cast<const f32x4*>(a.w_in + ((base + t0 + row) * heads + h) * G + 4 * q);
+                float* d = wl + row * SL_XS + 4 * q;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            // ---- logits^T[g][tok] = sum_d Ws[g][d] x[tok][d]; softmax over g in my registers (+ the other half-wave)
+            f32x16 p = zero16();
 #pragma unroll
-                    for (int g = 0; g < 32; ++g)
-                        if (g < G) wl[(h * 64 + r) * G + g] = ok ? w_in[((base + t0 + r) * heads + h) * G + g] : 0.f;
-                    continue;
-                }
-                float xv[32];
-                const float* xp = xf + (base + t0 + r) * ldx + C + h * 32;
+            for (int s = 0; s < 16; ++s) p = mfma32(Wsl[col * SL_XS + 2 * s + half], xl[col * SL_XS + 2 * s + half], p);
+            const bool tok_ok = t0 + col < a.ntok;
+            float mx = -3.0e38f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) v = *reinterpret_cast<const f32x4*>(xp + 4 * k);
-                    xv[4 * k] = v[0]; xv[4 * k + 1] = v[1]; xv[4 * k + 2] = v[2]; xv[4 * k + 3] = v[3];
-                }
-                const float inv_t = 1.0f / fminf(fmaxf(temp[h], 0.1f), 5.0f);
-                float lg[32], mx = -3.0e38f;
+            for (int r = 0; r < 16; ++r) {
+                p[r] = (jrow[r] < G) ? (p[r] + bsv[r]) * inv_t : -3.0e38f;
+                mx = fmaxf(mx, p[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float z = 0.f;
 #pragma unroll
-                for (int g = 0; g < 32; ++g) {
-                    float s = -3.0e38f;
-                    if (g < G) {
-                        s = bs[g];
+            for (int r = 0; r < 16; ++r) {
+                p[r] = (jrow[r] < G) ? expf(p[r] - mx) : 0.f;
+                z += p[r];
+            }
+            z += __shfl_xor(z, 32, 64);
+            const float iz = tok_ok ? 1.0f / z : 0.f;
 #pragma unroll
-                        for (int k = 0; k < 32; ++k) s += xv[k] * Wsl[g * 33 + k];
-                        s *= inv_t;
-                    }
-                    lg[g] = s;
-                    mx = fmaxf(mx, s);
-                }
-                float den = 0.f;
-#pragma unroll
-                for (int g = 0; g < 32; ++g) {
-                    lg[g] = (g < G) ? expf(lg[g] - mx) : 0.f;
-                    den += lg[g];
-                }
-                const float inv = 1.0f / den;
-#pragma unroll
-                for (int g = 0; g < 32; ++g) {
-                    if (g < G) {
-                        const float wv = ok ? lg[g] * inv : 0.f;
-                        wl[(h * 64 + r) * G + g] = wv;
-                        if (ok) w_out[((base + t0 + r) * heads + h) * G + g] = wv;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                p[r] *= iz;
+                nacc[r] += p[r];
+                if (jrow[r] < G) wl[col * SL_XS + jrow[r]] = p[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- coalesced store of the tile's weights: 16 B per lane
+            for (int idx = lane; idx < 32 * g4; idx += 64) {
+                const int row = idx / g4, q = idx - row * g4;
+                if (t0 + row < a.ntok) {
+                    const float* sp = wl + row * SL_XS + 4 * q;
+                    const f32x4 v = {sp[0], sp[1], sp[2], sp[3]};
+                    *reinterpret_cast<f32x4*>(a.w_out + ((base + t0 + row) * heads + h) * G + 4 * q) = v;
                 }
             }
         }
-        __syncthreads();
-        // ---- phase 2: thread (head ph, channel pc): accT[g] += sum_r w[ph][r][g] * fx[r][ph*32+pc]
-        if (ph < heads) {
-            for (int r = 0; r < 64; ++r) {
-                const float f = fl[r * (C + 1) + ph * 32 + pc];
-                const float* wr = wl + (ph * 64 + r) * G;
+        // ---- token sums: tokS[g][c] += sum_tok w[tok][g] fx[tok][c]
 #pragma unroll
-                for (int g = 0; g < 32; ++g)
-                    if (g < G) accT[g] += wr[g] * f;
-            }
+        for (int s = 0; s < 16; ++s)
+            tacc = mfma32(wl[(2 * s + half) * SL_XS + col], fl[(2 * s + half) * SL_XS + col], tacc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* prow = a.tok_part + (long)blockIdx.x * ((long)heads * G * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (jrow[r] < G) prow[((long)h * G + jrow[r]) * 32 + col] = tacc[r];
+    if (!a.w_in) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                            // norm[g] = sum over my half-wave's 32 token columns
+            float v = nacc[r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            if (col == 0 && jrow[r] < G) a.norm_part[(long)blockIdx.x * heads * G + h * G + jrow[r]] = v;
         }
-        __syncthreads();
-    }
-    // partial row: [heads][G][32] token sums (the norms are a column sum of w, see slice_norm_kernel)
-    float* prow = part + (long)blockIdx.x * ((long)heads * G * 32);
-    if (ph < heads) {
-#pragma unroll
-        for (int g = 0; g < 32; ++g)
-            if (g < G) prow[((long)ph * G + g) * 32 + pc] = accT[g];
-    }
-}
-
-// norms: norm[b][h][g] = sum_m w[m][h][g]  -- a column sum of w_out (cheap second pass over the weights only)
-__global__ __launch_bounds__(TS_THREADS) void slice_norm_kernel(const float* __restrict__ w, float* __restrict__ part,
-                                                                int ntok, int HG, int blocks_per_sample) {
-    extern __shared__ float red[];   // [nsub][HG]
-    const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
-    const int c = threadIdx.x % HG, sub = threadIdx.x / HG, nsub = blockDim.x / HG;
-    float s = 0.f;
-    if (sub < nsub)
-        for (int t = blk * nsub + sub; t < ntok; t += blocks_per_sample * nsub) s += w[((long)b * ntok + t) * HG + c];
-    if (sub < nsub) red[sub * HG + c] = s;
-    __syncthreads();
-    if (threadIdx.x < HG) {
-        float t = 0.f;
-        for (int k = 0; k < nsub; ++k) t += red[k * HG + threadIdx.x];
-        part[(long)blockIdx.x * HG + threadIdx.x] = t;
     }
 }
 
@@ -238,20 +252,12 @@ extern "C" int rpb_slice_fwd(const float* xf, const float* Ws, const float* bs, 
                              float* tok_part, float* norm_part, int B, int ntok, int heads, int G, int ldx,
                              const float* w_in, void* stream) {
     RPB_REQUIRE(xf && tok_part && (w_in || (Ws && bs && temp && w_out && norm_part)), "slice_fwd: null pointer");
-    RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 1 && G <= 32 && (heads * G) <= TS_THREADS && TS_THREADS % (heads * G) == 0,
-                "slice_fwd: heads=%d G=%d unsupported (dim_head must be 32)", heads, G);
-    const int bps = rpb_slice_blocks_per_sample(B);
-    const int C = heads * 32;
-    const size_t lds = ((size_t)G * 33 + (size_t)heads * 64 * G + (size_t)64 * (C + 1)) * 4;
-    RPB_REQUIRE(lds <= 160 * 1024, "slice_fwd: LDS");
+    RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 4 && G <= 32 && G % 4 == 0 && ldx % 4 == 0,
+                "slice_fwd: heads=%d G=%d ldx=%d unsupported (dim_head 32, slice_num a multiple of 4 up to 32)", heads, G, ldx);
+    SliceArgs a{xf, Ws, bs, temp, w_out, tok_part, norm_part, w_in, ntok, heads, G, ldx, rpb_slice_blocks_per_sample(B)};
+    const size_t lds = (size_t)(32 * SL_XS + heads * 3 * 32 * SL_XS) * 4;
     (void)hipFuncSetAttribute((const void*)slice_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(slice_fwd_kernel, dim3(B * bps), dim3(TS_THREADS), lds, st, xf, w_in ? xf : Ws, bs, temp, w_out,
-                       tok_part, ntok, heads, G, ldx, bps, w_in);
-    const int HG = heads * G;
-    if (!w_in)
-        hipLaunchKernelGGL(slice_norm_kernel, dim3(B * bps), dim3(TS_THREADS), (size_t)(TS_THREADS / HG) * HG * 4, st, w_out,
-                       norm_part, ntok, HG, bps);
+    hipLaunchKernelGGL(slice_fwd_kernel, dim3(B * a.bps), dim3(heads * 64), lds, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("slice_fwd");
 }
 
@@ -443,147 +449,170 @@ extern "C" int rpb_layernorm_bwd(const float* x, const float* gamma, const float
 //   dWs[g][c] += (1/tau) gl[g] xmid[c],  dbs[g] += (1/tau) gl[g],  dtau[h] += -(1/tau) sum_g gl[g] log w[g]
 // (sum_g gl = 0, so log-sum-exp drops out of dtau).  Output g_xf rows = [g_fxmid | g_xmid] = the gradient of the dual
 // convolution's output; partial row = [G*32 dWs | G dbs | heads dtau].
-__global__ __launch_bounds__(TS_THREADS) void slice_bwd_kernel(const float* __restrict__ xf, const float* __restrict__ w,
-                                                               const float* __restrict__ gox, const float* __restrict__ tok2,
-                                                               const float* __restrict__ gT, const float* __restrict__ gN,
-                                                               const float* __restrict__ Ws, const float* __restrict__ temp,
-                                                               float* __restrict__ gxf, float* __restrict__ part, int ntok,
-                                                               int heads, int G, int blocks_per_sample) {
+__global__ __launch_bounds__(512) void slice_bwd_kernel(const float* __restrict__ xf, const float* __restrict__ w,
+                                                        const float* __restrict__ gox, const float* __restrict__ tok2,
+                                                        const float* __restrict__ gT, const float* __restrict__ gN,
+                                                        const float* __restrict__ Ws, const float* __restrict__ temp,
+                                                        float* __restrict__ gxf, float* __restrict__ part, int ntok,
+                                                        int heads, int G, int blocks_per_sample) {
+    // wave = head, 32-token tiles, every product on the fp32 MFMA; transposed accumulators (row = slice, column = token)
+    // keep the softmax Jacobian register-local.  B operands whose contraction index is the channel are read straight from
+    // global memory as 64 B per lane (the contraction order is free: step s of half-wave q contracts channel 16 q + s), the
+    // ones whose contraction index is the token as coalesced 128 B rows; only the slice weights and their logit gradients
+    // (both [32 tok][G]) pass through LDS, to be re-read as A operands.
     extern __shared__ float lds[];
-    const int C = heads * 32;
-    float* Wsl = lds;                               // [G][33]
-    float* t2l = Wsl + G * 33;                      // [heads][G][33]
-    float* gtl = t2l + heads * G * 33;              // [heads][G][33]
-    float* gll = gtl + heads * G * 33;              // [heads][64][G]   scaled logit gradients of the tile
-    float* xml = gll + heads * 64 * G;              // [64][C + 1]      x_mid tile
-    float* red = xml + 64 * (C + 1);                // [G + heads] block sums of dbs, dtau
+    const int C = heads * 32, GS = G + 1;
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Wsl = lds;                                           // [G][33]
+    float* t2l = Wsl + G * 33 + h * (2 * G * 33 + 2 * 32 * GS); // wave-private: tok2[h] [G][33]
+    float* gtl = t2l + G * 33;                                  //               gT[h]   [G][33]
+    float* wl = gtl + G * 33;                                   //               w tile  [32][GS]
+    float* gll = wl + 32 * GS;                                  //               raw-logit gradients [32][GS]
     const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < G * 32; idx += blockDim.x) Wsl[(idx >> 5) * 33 + (idx & 31)] = Ws[idx];
-    for (int idx = tid; idx < heads * G * 32; idx += blockDim.x) {
-        const int hg = idx >> 5, c = idx & 31;
-        t2l[hg * 33 + c] = tok2[(long)b * heads * G * 32 + idx];
-        gtl[hg * 33 + c] = gT[(long)b * heads * G * 32 + idx];
+    for (int idx = threadIdx.x; idx < G * 32; idx += blockDim.x) Wsl[(idx >> 5) * 33 + (idx & 31)] = Ws[idx];
+    for (int idx = lane; idx < G * 32; idx += 64) {
+        const long src = ((long)b * heads + h) * G * 32 + idx;
+        t2l[(idx >> 5) * 33 + (idx & 31)] = tok2[src];
+        gtl[(idx >> 5) * 33 + (idx & 31)] = gT[src];
     }
-    for (int idx = tid; idx < G + heads; idx += blockDim.x) red[idx] = 0.f;
     __syncthreads();
-
-    const int pg = tid >> 5, pc = tid & 31;         // phase-2 role: slices pg, pg + 8, ... ; channel pc
-    float accW[4] = {0.f, 0.f, 0.f, 0.f};           // G <= 32 -> at most 4 slices per thread
+    int jrow[16];
+    float gNv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        jrow[r] = mfma_row(lane, r);
+        gNv[r] = jrow[r] < G ? gN[((long)b * heads + h) * G + jrow[r]] : 0.f;
+    }
+    const bool arow = col < G;                                  // A operands with row = slice: rows >= G are zero
+    const int colg = arow ? col : G - 1;
+    const float inv_t = 1.0f / fminf(fmaxf(temp[h], 0.1f), 5.0f);
+    const int g4 = G >> 2, gh = G >> 1;
+    f32x16 wacc = zero16(), racc = zero16();
+    float dtau = 0.f;
     const long base = (long)b * ntok;
-    for (int t0 = blk * 64; t0 < ntok; t0 += blocks_per_sample * 64) {
-        for (int idx = tid; idx < 64 * (C / 4); idx += blockDim.x) {           // stage the x_mid tile
-            const int r = idx / (C / 4), c4 = idx - r * (C / 4);
+    for (int t0 = blk * 32; t0 < ntok; t0 += blocks_per_sample * 32) {
+        const bool ok = t0 + col < ntok;
+        const long m = base + t0 + col;
+        float gov[16], fxv[16], xmv[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+            if (ok) {
+                a = *reinterpret_cast<const f32x4*>(gox + m * C + h * 32 + half * 16 + 4 * k);
+                c = *reinterpret_cast<const f32x4*>(xf + m * 2 * C + h * 32 + half * 16 + 4 * k);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gov[4 * k + i] = a[i];
+                fxv[4 * k + i] = c[i];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int tr = t0 + 2 * s + half;
+            xmv[s] = tr < ntok ? xf[(base + tr) * 2 * C + C + h * 32 + col] : 0.f;
+        }
+        for (int idx = lane; idx < 32 * g4; idx += 64) {
+            const int row = idx / g4, q = idx - row * g4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + r < ntok) v = *reinterpret_cast<const f32x4*>(xf + (base + t0 + r) * 2 * C + C + 4 * c4);
-            float* dst = xml + r * (C + 1) + 4 * c4;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            if (t0 + row < ntok) v = *reinterpret_cast<const f32x4*>(w + ((base + t0 + row) * heads + h) * G + 4 * q);
+            float* d = wl + row * GS + 4 * q;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
-        {
-            const int r = tid & 63;
-            const bool ok = t0 + r < ntok;
-            const long m = base + t0 + r;
-            for (int h = tid >> 6; h < heads; h += TS_THREADS / 64) {
-                float fxv[32], gov[32], wv[32], gw[32];
+        __builtin_amdgcn_wave_barrier();
+        // ---- gw^T[g][tok] = gN[g] + sum_c tok2[g][c] go[tok][c] + gT[g][c] fx[tok][c]
+        f32x16 p = zero16();
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) {
-                        a = *reinterpret_cast<const f32x4*>(xf + m * 2 * C + h * 32 + 4 * k);
-                        c = *reinterpret_cast<const f32x4*>(gox + m * C + h * 32 + 4 * k);
-                    }
+        for (int s = 0; s < 16; ++s) {
+            const float a1 = t2l[colg * 33 + half * 16 + s], a2 = gtl[colg * 33 + half * 16 + s];
+            p = mfma32(arow ? a1 : 0.f, gov[s], p);
+            p = mfma32(arow ? a2 : 0.f, fxv[s], p);
+        }
+        float wv[16], dot = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        fxv[4 * k + i] = a[i];
-                        gov[4 * k + i] = c[i];
-                    }
-                }
-                float dot = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            wv[r] = jrow[r] < G ? wl[col * GS + jrow[r]] : 0.f;
+            p[r] += gNv[r];
+            dot += wv[r] * p[r];
+        }
+        dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
-                for (int g = 0; g < 32; ++g) {
-                    float s = 0.f, wg = 0.f;
-                    if (g < G) {
-                        wg = ok ? w[(m * heads + h) * G + g] : 0.f;
-                        s = gN[((long)b * heads + h) * G + g];
-                        const float* t2 = t2l + (h * G + g) * 33;
-                        const float* gt = gtl + (h * G + g) * 33;
+        for (int r = 0; r < 16; ++r) {
+            const float gl = wv[r] * (p[r] - dot);                // d / d(scaled logit)
+            const float glr = gl * inv_t;                          // d / d(raw logit)
+            if (wv[r] > 0.f) dtau -= gl * logf(wv[r]);
+            racc[r] += glr;
+            if (jrow[r] < G) gll[col * GS + jrow[r]] = glr;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- g_fx[tok][c] = sum_g w[tok][g] gT[g][c];  g_xmid[tok][c] = sum_g glr[tok][g] Ws[g][c]
+        f32x16 gfx = zero16(), gxm = zero16();
+        for (int s = 0; s < gh; ++s) {
+            gfx = mfma32(wl[col * GS + 2 * s + half], gtl[(2 * s + half) * 33 + col], gfx);
+            gxm = mfma32(gll[col * GS + 2 * s + half], Wsl[(2 * s + half) * 33 + col], gxm);
+        }
 #pragma unroll
-                        for (int c = 0; c < 32; ++c) s += gov[c] * t2[c] + fxv[c] * gt[c];
-                    }
-                    wv[g] = wg;
-                    gw[g] = s;
-                    dot += wg * s;
-                }
-                const float inv_t = 1.0f / fminf(fmaxf(temp[h], 0.1f), 5.0f);
-                float gfx[32], gxm[32], dtau = 0.f;
-#pragma unroll
-                for (int c = 0; c < 32; ++c) gfx[c] = gxm[c] = 0.f;
-#pragma unroll
-                for (int g = 0; g < 32; ++g) {
-                    if (g < G) {
-                        const float gl = wv[g] * (gw[g] - dot);            // d/d(scaled logit)
-                        const float glr = gl * inv_t;                       // d/d(raw logit)
-                        gll[(h * 64 + r) * G + g] = glr;
-                        if (wv[g] > 0.f) dtau -= gl * logf(wv[g]);
-                        const float* gt = gtl + (h * G + g) * 33;
-#pragma unroll
-                        for (int c = 0; c < 32; ++c) {
-                            gfx[c] += wv[g] * gt[c];
-                            gxm[c] += glr * Wsl[g * 33 + c];
-                        }
-                        if (ok) atomicAdd(&red[g], glr);
-                    }
-                }
-                if (ok) {
-                    atomicAdd(&red[G + h], dtau * inv_t);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        f32x4 a, c;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            a[i] = gfx[4 * k + i];
-                            c[i] = gxm[4 * k + i];
-                        }
-                        *reinterpret_cast<f32x4*>(gxf + m * 2 * C + h * 32 + 4 * k) = a;
-                        *reinterpret_cast<f32x4*>(gxf + m * 2 * C + C + h * 32 + 4 * k) = c;
-                    }
-                }
+        for (int r = 0; r < 16; ++r) {
+            if (t0 + jrow[r] < ntok) {
+                float* dst = gxf + (base + t0 + jrow[r]) * 2 * C + h * 32 + col;
+                dst[0] = gfx[r];
+                dst[C] = gxm[r];
             }
         }
-        __syncthreads();
-        // phase 2: dWs[g][c] += sum_{r,h} glr[h][r][g] * xmid[r][h*32+c]
+        // ---- dWs[g][c] += sum_tok glr[tok][g] xmid[tok][c]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int g = pg + 8 * q;
-            if (g < G) {
-                float s = 0.f;
-                for (int h = 0; h < heads; ++h)
-                    for (int r = 0; r < 64; ++r) s += gll[(h * 64 + r) * G + g] * xml[r * (C + 1) + h * 32 + pc];
-                accW[q] += s;
-            }
+        for (int s = 0; s < 16; ++s) {
+            const float a1 = gll[(2 * s + half) * GS + colg];
+            wacc = mfma32(arow ? a1 : 0.f, xmv[s], wacc);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    // ---- block sums in a fixed order (deterministic): each wave parks its partials in its own tiles
+    float* wpark = wl;                                            // [G][32]   (64 (G + 1) >= 32 G floats)
+    float* rpark = t2l;                                           // [G] + [1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (jrow[r] < G) wpark[jrow[r] * 32 + col] = wacc[r];
+        float v = racc[r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        if (col == 0 && jrow[r] < G) rpark[jrow[r]] = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dtau += __shfl_xor(dtau, o, 64);
+    if (lane == 0) rpark[G] = dtau * inv_t;
+    __syncthreads();
+    const int wstride = 2 * G * 33 + 2 * 32 * GS;
     float* prow = part + (long)blockIdx.x * ((long)G * 32 + G + heads);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int g = pg + 8 * q;
-        if (g < G) prow[g * 32 + pc] = accW[q];
+    const float* w0 = lds + G * 33 + 2 * G * 33;                 // wave 0's wl
+    const float* r0 = lds + G * 33;                               // wave 0's t2l
+    for (int idx = threadIdx.x; idx < G * 32; idx += blockDim.x) {
+        float sacc = 0.f;
+        for (int hh = 0; hh < heads; ++hh) sacc += w0[hh * wstride + idx];
+        prow[idx] = sacc;
     }
-    for (int idx = tid; idx < G + heads; idx += blockDim.x) prow[G * 32 + idx] = red[idx];
+    for (int idx = threadIdx.x; idx < G; idx += blockDim.x) {
+        float sacc = 0.f;
+        for (int hh = 0; hh < heads; ++hh) sacc += r0[hh * wstride + idx];
+        prow[G * 32 + idx] = sacc;
+    }
+    for (int idx = threadIdx.x; idx < heads; idx += blockDim.x) prow[G * 32 + G + idx] = r0[idx * wstride + G];
 }
 
 extern "C" int rpb_slice_bwd(const float* xf, const float* w, const float* gox, const float* tok2, const float* gT,
                              const float* gN, const float* Ws, const float* temp, float* gxf, float* part, int B, int ntok,
                              int heads, int G, void* stream) {
     RPB_REQUIRE(xf && w && gox && tok2 && gT && gN && Ws && temp && gxf && part, "slice_bwd: null pointer");
-    RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 1 && G <= 32, "slice_bwd: heads=%d G=%d unsupported", heads, G);
+    RPB_REQUIRE(heads >= 1 && heads <= 8 && G >= 4 && G <= 32 && G % 4 == 0, "slice_bwd: heads=%d G=%d unsupported", heads, G);
     const int bps = rpb_slice_blocks_per_sample(B);
-    const int C = heads * 32;
-    const size_t lds = ((size_t)G * 33 + 2 * (size_t)heads * G * 33 + (size_t)heads * 64 * G + (size_t)64 * (C + 1) + G + heads) * 4;
+    const size_t lds = ((size_t)G * 33 + (size_t)heads * (2 * G * 33 + 2 * 32 * (G + 1))) * 4;
     RPB_REQUIRE(lds <= 160 * 1024, "slice_bwd: LDS");
     (void)hipFuncSetAttribute((const void*)slice_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(slice_bwd_kernel, dim3(B * bps), dim3(TS_THREADS), lds, (hipStream_t)stream, xf, w, gox, tok2, gT, gN,
+    hipLaunchKernelGGL(slice_bwd_kernel, dim3(B * bps), dim3(heads * 64), lds, (hipStream_t)stream, xf, w, gox, tok2, gT, gN,
                        Ws, temp, gxf, part, ntok, heads, G, bps);
     RPB_CHECK_LAUNCH("slice_bwd");
 }
