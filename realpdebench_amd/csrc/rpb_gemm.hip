@@ -580,9 +580,14 @@ struct ConvWgArgs {
 // (a 3-wave "wave = kh" mapping with 64 x 192 wave tiles left one SIMD idle: 67-73 TF/s instead of 75-81).  The chunk tiles
 // are single-buffered on purpose: the double-buffered, one-barrier-per-chunk variant measured 4 % slower.
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
-    __shared__ float Gs[CW_TOK][64];
+    // Zero padding without per-MFMA masks: a tap (kt, kh, kw) of token (t, h, w) is valid iff t+kt-1, h+kh-1, w+kw-1 are in
+    // range.  The w condition depends on the token only -> three copies of the G tile (kw = 0: zero where w = 0, kw = 1: plain,
+    // kw = 2: zero where w = W-1).  Given it, the X row q = tok + shift has no carry out of w, and the t / h conditions
+    // become properties of the ROW (0 <= h_q - kh + 1 < H, 0 <= t_q - kt + 1 < T) -> invalid rows are simply not loaded.
+    // (The first version multiplied every B operand by a validity table: 2 LDS reads + 1 v_mul per MFMA, 91 TF/s.)
+    __shared__ float Gs[3][CW_TOK][64];
     __shared__ float Xs[3][CW_TOK + 2][64];
-    __shared__ float Vm[9][CW_TOK];
+    __shared__ int Rm[2][3 * (CW_TOK + 2)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int o = wave & 1, c = wave >> 1;
@@ -608,9 +613,10 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
     // staging map: G tile = 512 float4, X tiles = 3 * 34 * 16 = 1632 float4 over 256 threads
     constexpr int NG = (CW_TOK * 16 + 255) / 256;                     // 2
     constexpr int NXL = (3 * (CW_TOK + 2) * 16 + 255) / 256;          // 7
+    constexpr int NROW = 3 * (CW_TOK + 2);                            // 102 staged X rows
     f32x4 pg[NG], px[NXL];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    auto prefetch = [&](long m0) {
+    auto prefetch = [&](long m0, int buf) {
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + j * 256;
@@ -625,70 +631,81 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
         for (int j = 0; j < NXL; ++j) {
             const int idx = tid + j * 256;
             f32x4 v = z4;
-            if (idx < 3 * (CW_TOK + 2) * 16) {
+            if (idx < NROW * 16) {
                 const int k2 = idx / ((CW_TOK + 2) * 16), rem = idx - k2 * (CW_TOK + 2) * 16;
                 const long q = m0 - 1 + (rem >> 4) + ((long)(kt - 1) * a.H + (k2 - 1)) * a.W;
-                if (q >= 0 && q < a.M) v = *reinterpret_cast<const f32x4*>(a.X + q * a.ldx + ci0 + (rem & 15) * 4);
+                if (Rm[buf][idx >> 4] && q >= 0 && q < a.M) v = *reinterpret_cast<const f32x4*>(a.X + q * a.ldx + ci0 + (rem & 15) * 4);
             }
             px[j] = v;
         }
     };
-    // mesh coordinates of "my" token (threads 0..31 own the chunk's tokens for the validity table): decoded once, then carried
-    // chunk to chunk with 32-bit adds -- the four 64-bit divisions per chunk kept the other waves waiting at the barrier
-    int vw = 0, vh = 0, vt = 0;
-    if (tid < CW_TOK) {
-        const long m = mb + tid;
-        vw = (int)(m % a.W);
-        const long r = m / a.W;
-        vh = (int)(r % a.H);
-        vt = (int)((r / a.H) % a.T);
+    // mesh coordinates are decoded once (64-bit divisions) and then carried chunk to chunk with 32-bit adds:
+    //   threads 0..101 own one staged X row each (its t / h validity), every thread the w of its two G-tile tokens
+    int qw = 0, qh = 0, qt = 0;
+    const int rk2 = tid / (CW_TOK + 2);
+    if (tid < NROW) {
+        const long q = mb - 1 + (tid - rk2 * (CW_TOK + 2)) + ((long)(kt - 1) * a.H + (rk2 - 1)) * a.W + 3L * a.T * a.H * a.W;
+        qw = (int)(q % a.W);
+        const long r = q / a.W;
+        qh = (int)(r % a.H);
+        qt = (int)((r / a.H) % a.T);
     }
-    if (mb < me) prefetch(mb);
-    for (long m0 = mb; m0 < me; m0 += CW_TOK) {
+    auto row_mask = [&](int buf) {
+        if (tid < NROW) {
+            const int tt = qt - kt + 1, hh = qh - rk2 + 1;
+            Rm[buf][tid] = (tt >= 0 && tt < a.T && hh >= 0 && hh < a.H) ? 1 : 0;
+            qw += CW_TOK;                                             // the same slot of the next chunk: + 32 with carries
+            while (qw >= a.W) {
+                qw -= a.W;
+                if (++qh >= a.H) {
+                    qh = 0;
+                    if (++qt >= a.T) qt = 0;
+                }
+            }
+        }
+    };
+    int gw[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) gw[j] = (int)((mb + ((tid + j * 256) >> 4)) % a.W);
+    row_mask(0);
+    __syncthreads();
+    if (mb < me) prefetch(mb, 0);
+    int it = 0;
+    for (long m0 = mb; m0 < me; m0 += CW_TOK, ++it) {
         __syncthreads();                                              // previous chunk's LDS reads are done
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int idx = tid + j * 256;
-            if (idx < CW_TOK * 16) *reinterpret_cast<f32x4*>(&Gs[idx >> 4][(idx & 15) * 4]) = pg[j];
+            if (idx < CW_TOK * 16) {
+                *reinterpret_cast<f32x4*>(&Gs[0][idx >> 4][(idx & 15) * 4]) = gw[j] >= 1 ? pg[j] : z4;
+                *reinterpret_cast<f32x4*>(&Gs[1][idx >> 4][(idx & 15) * 4]) = pg[j];
+                *reinterpret_cast<f32x4*>(&Gs[2][idx >> 4][(idx & 15) * 4]) = gw[j] <= a.W - 2 ? pg[j] : z4;
+            }
+            gw[j] += CW_TOK;
+            while (gw[j] >= a.W) gw[j] -= a.W;
         }
 #pragma unroll
         for (int j = 0; j < NXL; ++j) {
             const int idx = tid + j * 256;
-            if (idx < 3 * (CW_TOK + 2) * 16) {
+            if (idx < NROW * 16) {
                 const int k2 = idx / ((CW_TOK + 2) * 16), rem = idx - k2 * (CW_TOK + 2) * 16;
                 *reinterpret_cast<f32x4*>(&Xs[k2][rem >> 4][(rem & 15) * 4]) = px[j];
             }
         }
-        if (tid < CW_TOK) {                                           // validity of the 9 (kh, kw) taps of my token
-            const bool okt = m0 + tid < me && vt + kt - 1 >= 0 && vt + kt - 1 < a.T;
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2)
-#pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3) {
-                    const int hh = vh + k2 - 1, ww = vw + k3 - 1;
-                    Vm[k2 * 3 + k3][tid] = (okt && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? 1.f : 0.f;
-                }
-            vw += CW_TOK;                                             // my token of the next chunk: + 32 with carries
-            while (vw >= a.W) {
-                vw -= a.W;
-                if (++vh >= a.H) {
-                    vh = 0;
-                    if (++vt >= a.T) vt = 0;
-                }
-            }
-        }
+        row_mask((it + 1) & 1);                                       // for the prefetch below
         __syncthreads();
-        if (m0 + CW_TOK < me) prefetch(m0 + CW_TOK);                  // in flight during the MFMAs below
+        if (m0 + CW_TOK < me) prefetch(m0 + CW_TOK, (it + 1) & 1);    // in flight during the MFMAs below
 #pragma unroll
         for (int s = 0; s < CW_TOK / 2; ++s) {
             const int tk = 2 * s + half;
-            const float av = Gs[tk][o * 32 + col];
-            if (do_bias) bsum += av;
+            const float a0 = Gs[0][tk][o * 32 + col], a1 = Gs[1][tk][o * 32 + col], a2 = Gs[2][tk][o * 32 + col];
+            if (do_bias) bsum += a1;
 #pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2)
-#pragma unroll
-                for (int k3 = 0; k3 < 3; ++k3)
-                    acc[k2 * 3 + k3] = mfma32(av, Xs[k2][tk + k3][c * 32 + col] * Vm[k2 * 3 + k3][tk], acc[k2 * 3 + k3]);
+            for (int k2 = 0; k2 < 3; ++k2) {
+                acc[k2 * 3 + 0] = mfma32(a0, Xs[k2][tk + 0][c * 32 + col], acc[k2 * 3 + 0]);
+                acc[k2 * 3 + 1] = mfma32(a1, Xs[k2][tk + 1][c * 32 + col], acc[k2 * 3 + 1]);
+                acc[k2 * 3 + 2] = mfma32(a2, Xs[k2][tk + 2][c * 32 + col], acc[k2 * 3 + 2]);
+            }
         }
     }
     const long K = 27L * a.Ci;
