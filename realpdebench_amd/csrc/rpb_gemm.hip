@@ -695,6 +695,13 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
         row_mask((it + 1) & 1);                                       // for the prefetch below
         __syncthreads();
         if (m0 + CW_TOK < me) prefetch(m0 + CW_TOK, (it + 1) & 1);    // in flight during the MFMAs below
+        // X rows tk + {0, 1, 2}: the kw = 2 operand of step s is the kw = 0 operand of step s + 1 (rows advance by 2)
+        float x0[3], x1[3];
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+            x0[k2] = Xs[k2][half][c * 32 + col];
+            x1[k2] = Xs[k2][half + 1][c * 32 + col];
+        }
 #pragma unroll
         for (int s = 0; s < CW_TOK / 2; ++s) {
             const int tk = 2 * s + half;
@@ -702,9 +709,12 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
             if (do_bias) bsum += a1;
 #pragma unroll
             for (int k2 = 0; k2 < 3; ++k2) {
-                acc[k2 * 3 + 0] = mfma32(a0, Xs[k2][tk + 0][c * 32 + col], acc[k2 * 3 + 0]);
-                acc[k2 * 3 + 1] = mfma32(a1, Xs[k2][tk + 1][c * 32 + col], acc[k2 * 3 + 1]);
-                acc[k2 * 3 + 2] = mfma32(a2, Xs[k2][tk + 2][c * 32 + col], acc[k2 * 3 + 2]);
+                const float x2 = Xs[k2][tk + 2][c * 32 + col];
+                acc[k2 * 3 + 0] = mfma32(a0, x0[k2], acc[k2 * 3 + 0]);
+                acc[k2 * 3 + 1] = mfma32(a1, x1[k2], acc[k2 * 3 + 1]);
+                acc[k2 * 3 + 2] = mfma32(a2, x2, acc[k2 * 3 + 2]);
+                x0[k2] = x2;
+                if (s + 1 < CW_TOK / 2) x1[k2] = Xs[k2][tk + 3][c * 32 + col];
             }
         }
     }
@@ -727,13 +737,27 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
 }
 
 static int conv3_wgrad_splits(long M, int Co, int Ci) {
+    // Equal-length MFMA-bound workgroups: a CU that receives one more of them than its neighbours sets the kernel time, so
+    // the split count is chosen to make tiles * splits (nearly) a multiple of the CU count (Transolver's 96 tiles x 11 splits
+    // = 4.1 per CU ran 5 rounds: 105 TF/s; x 8 = 3.0 per CU).
     const long tiles = (long)(Co / 64) * (Ci / 64) * 3;
-    long s = ((long)rpb_num_cus() * 4 + tiles - 1) / tiles;
+    const long ncu = rpb_num_cus();
+    long smax = (ncu * 4 + tiles - 1) / tiles;
     const long cap = (M + 1023) / 1024;                               // at least 1024 tokens per split
-    if (s > cap) s = cap;
-    if (s < 1) s = 1;
-    if (s > 512) s = 512;
-    return (int)s;
+    if (smax > cap) smax = cap;
+    if (smax < 1) smax = 1;
+    if (smax > 512) smax = 512;
+    long best = 1;
+    double best_fill = 0.0;
+    for (long sp = 1; sp <= smax; ++sp) {
+        const long blocks = tiles * sp, rounds = (blocks + ncu - 1) / ncu;
+        const double fill = (double)blocks / (double)(rounds * ncu);
+        if (fill >= best_fill) {
+            best_fill = fill;
+            best = sp;
+        }
+    }
+    return (int)best;
 }
 
 
