@@ -736,17 +736,15 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(ConvWgArgs a) {
     }
 }
 
-static int conv3_wgrad_splits(long M, int Co, int Ci) {
-    // Equal-length MFMA-bound workgroups: a CU that receives one more of them than its neighbours sets the kernel time, so
-    // the split count is chosen to make tiles * splits (nearly) a multiple of the CU count (Transolver's 96 tiles x 11 splits
-    // = 4.1 per CU ran 5 rounds: 105 TF/s; x 8 = 3.0 per CU).
-    const long tiles = (long)(Co / 64) * (Ci / 64) * 3;
+// Split count for equal-length workgroups: a CU that receives one more of them than its neighbours sets the kernel time, so
+// among 1..smax the count that makes tiles * splits (nearly) a multiple of the CU count wins, larger counts on ties
+// (Transolver's conv weight gradient: 96 tiles x 11 splits = 4.1 per CU ran 5 rounds at 105 TF/s; x 8 = 3.0 per CU: 124).
+static int balanced_splits(long tiles, long per_cu, long cap, long hard_max) {
     const long ncu = rpb_num_cus();
-    long smax = (ncu * 4 + tiles - 1) / tiles;
-    const long cap = (M + 1023) / 1024;                               // at least 1024 tokens per split
+    long smax = (ncu * per_cu + tiles - 1) / tiles;
     if (smax > cap) smax = cap;
+    if (smax > hard_max) smax = hard_max;
     if (smax < 1) smax = 1;
-    if (smax > 512) smax = 512;
     long best = 1;
     double best_fill = 0.0;
     for (long sp = 1; sp <= smax; ++sp) {
@@ -758,6 +756,10 @@ static int conv3_wgrad_splits(long M, int Co, int Ci) {
         }
     }
     return (int)best;
+}
+
+static int conv3_wgrad_splits(long M, int Co, int Ci) {
+    return balanced_splits((long)(Co / 64) * (Ci / 64) * 3, 4, (M + 1023) / 1024 /* >= 1024 tokens per split */, 512);
 }
 
 
@@ -880,13 +882,7 @@ static bool tn_small_ok(int N, int K, int ldg, int lda) {
 
 static int tn_small_splits(long M, int N, int K) {
     const int bk = (N == 64) ? 128 : 64;
-    const long tiles = K / bk;
-    long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
-    const long cap = (M + 1023) / 1024;
-    if (s > cap) s = cap;
-    if (s < 1) s = 1;
-    if (s > 1024) s = 1024;
-    return (int)s;
+    return balanced_splits(K / bk, 3, (M + 1023) / 1024, 1024);
 }
 
 static int gemm_tn_nti(int K, int conv) {
@@ -902,12 +898,7 @@ extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
     const int wk2 = 64 * gemm_tn_nti(K, conv);
     const int bn = 64 * gemm_tn_wn(N);
     const long tiles = (long)((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
-    long s = ((long)rpb_num_cus() * 3 + tiles - 1) / tiles;
-    const long cap = (M + 511) / 512;                 // at least 512 tokens per split
-    if (s > cap) s = cap;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
-    return (int)s;
+    return balanced_splits(tiles, 3, (M + 511) / 512 /* >= 512 tokens per split */, 256);
 }
 
 extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, int conv,
