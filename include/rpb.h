@@ -262,8 +262,8 @@ int rpb_tattn_fwd(const float* qkv, const float* rcos, const float* rsin, const 
                   int HW, void* stream);
 int rpb_tattn_bwd(const float* qkv, const float* rcos, const float* rsin, const float* bias, const float* go, float* gqkv,
                   float* part, int B, int T, int HW, void* stream);
-/*     bottleneck softmax attention over the n <= 512 tokens of a frame (unet.py:455-457): qkv [F][n][384] ->
- *     out [F][n][128], lse [F][4][n]; the backward recomputes the probabilities. */
+/*     bottleneck softmax attention over the n tokens of a frame (unet.py:455-457; any n, streaming MFMA kernel):
+ *     qkv [F][n][384] -> out [F][n][128], lse [F][4][n]; the backward recomputes the probabilities. */
 int rpb_sattn_fwd(const float* qkv, float* out, float* lse, int F, int n, void* stream);
 int rpb_sattn_bwd(const float* qkv, const float* o, const float* go, float* lse, float* gqkv, int F, int n, void* stream);
 /*     SpatialLinearAttention (unet.py:236-261): qe[m] = [softmax_d(q)*32^-1/2 | exp(k - kmax[f])] and its backward

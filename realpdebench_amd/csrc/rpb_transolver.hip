@@ -52,7 +52,7 @@ extern "C" int rpb_tokens_lift(const float* x, const float* W, const float* b, f
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm (one wave per token)
-// nn.LayerNorm(C, eps=1e-5) with C = 64*V floats per token (V = 1..8 => C up to 512); biased variance.
+// nn.LayerNorm(C, eps=1e-5) with C = 64*V floats per token (V = 1..8, 12, 16 => C up to 512, 768, 1024); biased variance.
 template <int V>
 __global__ __launch_bounds__(TS_THREADS) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ out,
@@ -90,14 +90,14 @@ __global__ __launch_bounds__(TS_THREADS) void layernorm_kernel(const float* __re
 extern "C" int rpb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out, long M, int C,
                                  float eps, void* stream) {
     RPB_REQUIRE(x && gamma && beta && out && M > 0, "layernorm: bad arguments");
-    RPB_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "layernorm: C=%d must be a multiple of 64 up to 512", C);
+    RPB_REQUIRE(C % 64 == 0 && C >= 64 && (C <= 512 || C == 768 || C == 1024), "layernorm: C=%d must be a multiple of 64 up to 512, 768 or 1024", C);
     long grid = (M + 3) / 4;
     const long cap = (long)rpb_num_cus() * 8;
     if (grid > cap) grid = cap;
     hipStream_t st = (hipStream_t)stream;
 #define RPB_LN(V_) \
     if (C == 64 * V_) hipLaunchKernelGGL((layernorm_kernel<V_>), dim3((unsigned)grid), dim3(TS_THREADS), 0, st, x, gamma, beta, out, M, eps);
-    RPB_LN(1) RPB_LN(2) RPB_LN(3) RPB_LN(4) RPB_LN(5) RPB_LN(6) RPB_LN(7) RPB_LN(8)
+    RPB_LN(1) RPB_LN(2) RPB_LN(3) RPB_LN(4) RPB_LN(5) RPB_LN(6) RPB_LN(7) RPB_LN(8) RPB_LN(12) RPB_LN(16)
 #undef RPB_LN
     RPB_CHECK_LAUNCH("layernorm");
 }
@@ -430,12 +430,12 @@ extern "C" long rpb_layernorm_bwd_rows(long M) {
 extern "C" int rpb_layernorm_bwd(const float* x, const float* gamma, const float* gy, const float* gadd, float* gx,
                                  float* part, long M, int C, float eps, void* stream) {
     RPB_REQUIRE(x && gamma && gy && gx && part && M > 0, "layernorm_bwd: bad arguments");
-    RPB_REQUIRE(C % 64 == 0 && C >= 64 && C <= 512, "layernorm_bwd: C=%d must be a multiple of 64 up to 512", C);
+    RPB_REQUIRE(C % 64 == 0 && C >= 64 && (C <= 512 || C == 768 || C == 1024), "layernorm_bwd: C=%d must be a multiple of 64 up to 512, 768 or 1024", C);
     const unsigned grid = (unsigned)(rpb_layernorm_bwd_rows(M) / (TS_THREADS / 64));
     hipStream_t st = (hipStream_t)stream;
 #define RPB_LNB(V_) \
     if (C == 64 * V_) hipLaunchKernelGGL((layernorm_bwd_kernel<V_>), dim3(grid), dim3(TS_THREADS), 0, st, x, gamma, gy, gadd, gx, part, M, eps);
-    RPB_LNB(1) RPB_LNB(2) RPB_LNB(3) RPB_LNB(4) RPB_LNB(5) RPB_LNB(6) RPB_LNB(7) RPB_LNB(8)
+    RPB_LNB(1) RPB_LNB(2) RPB_LNB(3) RPB_LNB(4) RPB_LNB(5) RPB_LNB(6) RPB_LNB(7) RPB_LNB(8) RPB_LNB(12) RPB_LNB(16)
 #undef RPB_LNB
     RPB_CHECK_LAUNCH("layernorm_bwd");
 }

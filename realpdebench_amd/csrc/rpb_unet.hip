@@ -418,12 +418,20 @@ extern "C" int rpb_tattn_bwd(const float* qkv, const float* rcos, const float* r
 
 // ---------------------------------------------------------------------------------- bottleneck spatial attention
 // Softmax attention over the n = h*w tokens of one frame at the lowest resolution (unet.py:455-457: Attention under
-// EinopsToAndFrom 'b c f h w' -> 'b f (h w) c'; 4 heads x 32, q scaled, no rotary, no bias).  One workgroup per
-// (frame, head), one thread per token: K and V of the frame sit in LDS (n * 256 B) and every thread runs an online
-// softmax over them with its query row in registers (flash-attention style, nothing n x n is ever stored).  The forward
-// keeps the row log-sum-exp; the backward recomputes the probabilities twice -- thread = query for d q, then (Q and the
-// output gradient in LDS) thread = key for d k, d v.
+// EinopsToAndFrom 'b c f h w' -> 'b f (h w) c'; 4 heads x 32, q scaled, no rotary, no bias), flash-attention style on the
+// fp32 MFMA for any n (nothing n x n is ever stored; the forward keeps the row log-sum-exp, the backward recomputes the
+// probabilities).  A wave owns 32 rows of one side, the other side streams through LDS in 64-row chunks:
+//   MODE 0 forward       own = queries, stream K / V:  S^T[key][query] = K Q^T, online softmax, O^T[d][query] += V^T P
+//   MODE 1 backward d q  own = queries, stream K / V:  P = exp(S^T - lse), dS = P (dP^T - D), dQ^T[d][query] += K^T dS
+//   MODE 2 backward d k, d v  own = keys, stream Q / gO:  S[query][key], dV^T[d][key] += gO^T P, dK^T[d][key] += Q^T dS
+// The transposed accumulators put "own" in the MFMA column = lane, so the softmax statistics (running max, sum, lse, D)
+// are per-lane scalars, and a D-layout register tile feeds the next MFMA as its B operand when the A operand reads row
+// mfma_row(lane, r) of the LDS tile (the contraction order of an MFMA chain is free).  Contractions over the head
+// dimension use d = 16 * half + s, so a lane's own-side operand is 64 contiguous bytes of its row.
 #define SA_D 32
+#define SA_XS 33
+#define SA_CH 64
+#define SA_NW 4
 
 struct SAttnArgs {
     const float* qkv;    // [F][n][384]
@@ -435,159 +443,205 @@ struct SAttnArgs {
     int n;
 };
 
-template <bool BWD>
-__global__ __launch_bounds__(512) void sattn_kernel(SAttnArgs a) {
-    extern __shared__ float lds[];
-    const int n = a.n, i = threadIdx.x;
+template <int MODE>
+__global__ __launch_bounds__(256) void sattn_kernel(SAttnArgs a) {
+    __shared__ float Al[SA_CH * SA_XS];        // MODE 0/1: K chunk      MODE 2: scaled Q chunk
+    __shared__ float Bl[SA_CH * SA_XS];        // MODE 0/1: V chunk      MODE 2: gO chunk
+    __shared__ float Ll[2][SA_CH];             // MODE 2: lse and D = gO . O of the chunk's queries
+    __shared__ float El[SA_NW][32 * SA_XS];    // wave-private epilogue transposition
+    const int n = a.n, tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = blockIdx.x >> 2, head = blockIdx.x & 3;
-    float* Kl = lds;                  // [n][32]   (bwd pass B: scaled Q)
-    float* Vl = lds + n * SA_D;       // [n][32]   (bwd pass B: gO)
-    float* Ll = Vl + n * SA_D;        // bwd pass B: [n] lse, [n] D
+    const int r0 = (blockIdx.y * SA_NW + wave) * 32;
     const float scale = 0.17677669529663687f;
-    const float* base = a.qkv + ((long)f * n) * 384 + head * SA_D;
-    for (int idx = threadIdx.x; idx < n * (SA_D / 4); idx += blockDim.x) {
-        const int r = idx >> 3, c = (idx & 7) * 4;
-        *reinterpret_cast<f32x4*>(Kl + r * SA_D + c) = *reinterpret_cast<const f32x4*>(base + (long)r * 384 + 128 + c);
-        *reinterpret_cast<f32x4*>(Vl + r * SA_D + c) = *reinterpret_cast<const f32x4*>(base + (long)r * 384 + 256 + c);
+    const float* qb = a.qkv + (long)f * n * 384 + head * SA_D;
+    const float* gob = MODE ? a.go + (long)f * n * 128 + head * SA_D : nullptr;
+    const float* ob = MODE ? a.o + (long)f * n * 128 + head * SA_D : nullptr;
+    const long lrow = ((long)f * 4 + head) * n;
+    const int own = r0 + col;
+    const bool live = own < n;
+    int jrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) jrow[r] = mfma_row(lane, r);
+
+    // ---- own-side operands: lane (col, half) holds head dims 16 * half + s of row `own`
+    float u[16], v[16];
+    float Di = 0.f, lse_own = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x, z = x;
+        if (live) {
+            x = *reinterpret_cast<const f32x4*>(qb + (long)own * 384 + (MODE == 2 ? 128 : 0) + 16 * half + 4 * k);
+            if (MODE == 2) y = *reinterpret_cast<const f32x4*>(qb + (long)own * 384 + 256 + 16 * half + 4 * k);
+            if (MODE == 1) {
+                y = *reinterpret_cast<const f32x4*>(gob + (long)own * 128 + 16 * half + 4 * k);
+                z = *reinterpret_cast<const f32x4*>(ob + (long)own * 128 + 16 * half + 4 * k);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[4 * k + i] = MODE == 2 ? x[i] : x[i] * scale;
+            v[4 * k + i] = y[i];
+            Di += y[i] * z[i];
+        }
     }
-    __syncthreads();
-    float q[SA_D];
-    const bool live = i < n;
+    if (MODE == 1) {
+        Di += __shfl_xor(Di, 32, 64);
+        lse_own = live ? a.lse[lrow + own] : 0.f;
+    }
+
+    float m = -3.0e38f, l = 0.f;
+    f32x16 acc0 = zero16(), acc1 = zero16();       // MODE 0: O^T;  MODE 1: dQ^T;  MODE 2: dK^T, dV^T
+    f32x4 pa[2], pb[2], po[2];
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch = [&](int c0) {
 #pragma unroll
-    for (int d = 0; d < SA_D; ++d) q[d] = live ? base[(long)i * 384 + d] * scale : 0.f;
-    if (!BWD) {
-        float m = -3.0e38f, l = 0.f, o[SA_D];
-#pragma unroll
-        for (int d = 0; d < SA_D; ++d) o[d] = 0.f;
-        for (int j = 0; j < n; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < SA_D; ++d) s += q[d] * Kl[j * SA_D + d];
-            const float mn = fmaxf(m, s);
-            const float corr = __expf(m - mn), p = __expf(s - mn);
-            l = l * corr + p;
-#pragma unroll
-            for (int d = 0; d < SA_D; ++d) o[d] = o[d] * corr + p * Vl[j * SA_D + d];
-            m = mn;
-        }
-        if (live) {
-            const float il = 1.0f / l;
-            float* dst = a.out + ((long)f * n + i) * 128 + head * SA_D;
-#pragma unroll
-            for (int d = 0; d < SA_D; d += 4) {
-                f32x4 v = {o[d] * il, o[d + 1] * il, o[d + 2] * il, o[d + 3] * il};
-                *reinterpret_cast<f32x4*>(dst + d) = v;
-            }
-            a.lse[((long)f * 4 + head) * n + i] = m + __logf(l);
-        }
-    } else {
-        // ---- pass A: thread = query i -> d q_i
-        float g[SA_D], dq[SA_D];
-        float Di = 0.f;
-        const long orow = ((long)f * n + (live ? i : 0)) * 128 + head * SA_D;
-#pragma unroll
-        for (int d = 0; d < SA_D; ++d) {
-            g[d] = live ? a.go[orow + d] : 0.f;
-            Di += g[d] * (live ? a.o[orow + d] : 0.f);
-            dq[d] = 0.f;
-        }
-        const float lse = live ? a.lse[((long)f * 4 + head) * n + i] : 0.f;
-        for (int j = 0; j < n; ++j) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < SA_D; ++d) {
-                s += q[d] * Kl[j * SA_D + d];
-                dp += g[d] * Vl[j * SA_D + d];
-            }
-            const float ds = __expf(s - lse) * (dp - Di);
-#pragma unroll
-            for (int d = 0; d < SA_D; ++d) dq[d] += ds * Kl[j * SA_D + d];
-        }
-        float* gq = a.gqkv + ((long)f * n + (live ? i : 0)) * 384 + head * SA_D;
-        if (live) {
-#pragma unroll
-            for (int d = 0; d < SA_D; d += 4) {
-                f32x4 v = {dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale};
-                *reinterpret_cast<f32x4*>(gq + d) = v;
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + j * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            const long r = c0 + row;
+            pa[j] = pb[j] = po[j] = z4;
+            if (r < n) {
+                if (MODE == 2) {
+                    pa[j] = *reinterpret_cast<const f32x4*>(qb + r * 384 + c4) * scale;
+                    pb[j] = *reinterpret_cast<const f32x4*>(gob + r * 128 + c4);
+                    po[j] = *reinterpret_cast<const f32x4*>(ob + r * 128 + c4);
+                } else {
+                    pa[j] = *reinterpret_cast<const f32x4*>(qb + r * 384 + 128 + c4);
+                    pb[j] = *reinterpret_cast<const f32x4*>(qb + r * 384 + 256 + c4);
+                }
             }
         }
-        // ---- pass B: thread = key j (= i): K/V rows to registers, LDS <- scaled Q, gO, lse, D
-        float kr[SA_D], vr[SA_D];
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < n; c0 += SA_CH) {
+        __syncthreads();                                            // the previous chunk's LDS reads are done
 #pragma unroll
-        for (int d = 0; d < SA_D; ++d) {
-            kr[d] = live ? Kl[i * SA_D + d] : 0.f;
-            vr[d] = live ? Vl[i * SA_D + d] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + j * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            float* da = Al + row * SA_XS + c4;
+            float* db = Bl + row * SA_XS + c4;
+            da[0] = pa[j][0]; da[1] = pa[j][1]; da[2] = pa[j][2]; da[3] = pa[j][3];
+            db[0] = pb[j][0]; db[1] = pb[j][1]; db[2] = pb[j][2]; db[3] = pb[j][3];
+            if (MODE == 2) {
+                float dd = pb[j][0] * po[j][0] + pb[j][1] * po[j][1] + pb[j][2] * po[j][2] + pb[j][3] * po[j][3];
+                dd += __shfl_xor(dd, 1, 64);
+                dd += __shfl_xor(dd, 2, 64);
+                dd += __shfl_xor(dd, 4, 64);
+                if ((tid & 7) == 0) {
+                    Ll[1][row] = dd;
+                    Ll[0][row] = (c0 + row < n) ? a.lse[lrow + c0 + row] : 3.0e38f;
+                }
+            }
         }
         __syncthreads();
-        if (live) {
+        if (c0 + SA_CH < n) prefetch(c0 + SA_CH);                   // in flight during the MFMAs below
 #pragma unroll
-            for (int d = 0; d < SA_D; ++d) {
-                Kl[i * SA_D + d] = q[d];
-                Vl[i * SA_D + d] = g[d];
+        for (int t = 0; t < SA_CH / 32; ++t) {
+            if (c0 + 32 * t >= n) break;
+            const float* At = Al + t * 32 * SA_XS;
+            const float* Bt = Bl + t * 32 * SA_XS;
+            f32x16 p = zero16();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) p = mfma32(At[col * SA_XS + 16 * half + s], u[s], p);
+            if (MODE == 0) {
+                float tmax = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (c0 + 32 * t + jrow[r] >= n) p[r] = -3.0e38f;
+                    tmax = fmaxf(tmax, p[r]);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mn = fmaxf(m, tmax);
+                const float corr = __expf(m - mn);
+                m = mn;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = __expf(p[r] - mn);
+                    psum += p[r];
+                    acc0[r] *= corr;
+                }
+                l = l * corr + psum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0 = mfma32(Bt[jrow[r] * SA_XS + col], p[r], acc0);
+            } else {
+                f32x16 dp = zero16();
+#pragma unroll
+                for (int s = 0; s < 16; ++s) dp = mfma32(Bt[col * SA_XS + 16 * half + s], v[s], dp);
+                if (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pr = (c0 + 32 * t + jrow[r] < n) ? __expf(p[r] - lse_own) : 0.f;
+                        p[r] = pr * (dp[r] - Di);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc0 = mfma32(At[jrow[r] * SA_XS + col], p[r], acc0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qi = 32 * t + jrow[r];
+                        const float pr = __expf(p[r] - Ll[0][qi]);
+                        dp[r] = pr * (dp[r] - Ll[1][qi]);
+                        p[r] = pr;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc0 = mfma32(At[jrow[r] * SA_XS + col], dp[r], acc0);      // dK^T += Q_s^T dS
+                        acc1 = mfma32(Bt[jrow[r] * SA_XS + col], p[r], acc1);       // dV^T += gO^T P
+                    }
+                }
             }
-            Ll[i] = lse;
-            Ll[n + i] = Di;
         }
-        __syncthreads();
-        float dk[SA_D], dv[SA_D];
+    }
+    // ---- epilogue: own-major rows through the wave's LDS tile, 16 B stores
+    float* Et = El[wave];
+    float mul = MODE == 1 ? scale : 1.f;
+    if (MODE == 0) {
+        const float lt = l + __shfl_xor(l, 32, 64);
+        mul = 1.0f / lt;
+        if (live && half == 0) a.lse[lrow + own] = m + __logf(lt);
+    }
+    float* dst = MODE == 0 ? a.out + (long)f * n * 128 + head * SA_D : a.gqkv + (long)f * n * 384 + head * SA_D + (MODE == 2 ? 128 : 0);
+    const int ldo = MODE == 0 ? 128 : 384;
 #pragma unroll
-        for (int d = 0; d < SA_D; ++d) dk[d] = dv[d] = 0.f;
-        for (int r = 0; r < n; ++r) {
-            float s = 0.f, dp = 0.f;
+    for (int pass = 0; pass < (MODE == 2 ? 2 : 1); ++pass) {
 #pragma unroll
-            for (int d = 0; d < SA_D; ++d) {
-                s += Kl[r * SA_D + d] * kr[d];
-                dp += Vl[r * SA_D + d] * vr[d];
-            }
-            const float p = __expf(s - Ll[r]);
-            const float ds = p * (dp - Ll[n + r]);
+        for (int r = 0; r < 16; ++r) Et[col * SA_XS + jrow[r]] = (pass ? acc1[r] : acc0[r]) * mul;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int d = 0; d < SA_D; ++d) {
-                dv[d] += p * Vl[r * SA_D + d];
-                dk[d] += ds * Kl[r * SA_D + d];
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int d = 0; d < SA_D; d += 4) {
-                f32x4 v1 = {dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
-                f32x4 v2 = {dv[d], dv[d + 1], dv[d + 2], dv[d + 3]};
-                *reinterpret_cast<f32x4*>(gq + 128 + d) = v1;
-                *reinterpret_cast<f32x4*>(gq + 256 + d) = v2;
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            if (r0 + row < n) {
+                const float* sp = Et + row * SA_XS + c4;
+                const f32x4 x = {sp[0], sp[1], sp[2], sp[3]};
+                *reinterpret_cast<f32x4*>(dst + (long)(r0 + row) * ldo + pass * 128 + c4) = x;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-static int sattn_launch(bool bwd, SAttnArgs& a, int F, hipStream_t st) {
-    RPB_REQUIRE(a.qkv && a.lse && F > 0 && a.n > 0, "sattn: bad arguments");
-    RPB_REQUIRE(a.n <= 512, "sattn: %d tokens per frame, the kernel holds up to 512 (one thread per token, K/V in LDS)", a.n);
-    const size_t lds = ((size_t)2 * a.n * SA_D + 2 * a.n) * 4;
-    RPB_REQUIRE(lds <= 160 * 1024, "sattn: %d tokens per frame do not fit LDS", a.n);
-    const int threads = (a.n + 63) / 64 * 64;
-    if (bwd) {
-        (void)hipFuncSetAttribute((const void*)sattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(sattn_kernel<true>, dim3(F * 4), dim3(threads), lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)sattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(sattn_kernel<false>, dim3(F * 4), dim3(threads), lds, st, a);
-    }
-    RPB_CHECK_LAUNCH("sattn");
+template <int MODE>
+static void sattn_launch(const SAttnArgs& a, int F, hipStream_t st) {
+    hipLaunchKernelGGL(sattn_kernel<MODE>, dim3(F * 4, (a.n + 32 * SA_NW - 1) / (32 * SA_NW)), dim3(64 * SA_NW), 0, st, a);
 }
 
 extern "C" int rpb_sattn_fwd(const float* qkv, float* out, float* lse, int F, int n, void* stream) {
-    RPB_REQUIRE(out, "sattn_fwd: null out");
+    RPB_REQUIRE(qkv && out && lse && F > 0 && n > 0, "sattn_fwd: bad arguments");
     SAttnArgs a{};
     a.qkv = qkv; a.out = out; a.lse = lse; a.n = n;
-    return sattn_launch(false, a, F, (hipStream_t)stream);
+    sattn_launch<0>(a, F, (hipStream_t)stream);
+    RPB_CHECK_LAUNCH("sattn_fwd");
 }
 
 extern "C" int rpb_sattn_bwd(const float* qkv, const float* o, const float* go, float* lse, float* gqkv, int F, int n,
                              void* stream) {
-    RPB_REQUIRE(o && go && gqkv, "sattn_bwd: null pointer");
+    RPB_REQUIRE(qkv && o && go && lse && gqkv && F > 0 && n > 0, "sattn_bwd: bad arguments");
     SAttnArgs a{};
     a.qkv = qkv; a.o = o; a.go = go; a.lse = lse; a.gqkv = gqkv; a.n = n;
-    return sattn_launch(true, a, F, (hipStream_t)stream);
+    sattn_launch<1>(a, F, (hipStream_t)stream);
+    sattn_launch<2>(a, F, (hipStream_t)stream);
+    RPB_CHECK_LAUNCH("sattn_bwd");
 }
 
 // ---------------------------------------------------------------------------------- spatial linear attention

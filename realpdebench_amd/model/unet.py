@@ -470,8 +470,6 @@ class Unet3d(_ModelBase):
         """Residual(PreNorm(softmax Attention over h*w)) at the bottleneck -- unet.py:455-457."""
         T, H, W = mesh
         M, Fr, n = B * T * H * W, B * T, H * W
-        if n > 512:
-            raise NotImplementedError(f"bottleneck attention over {n} tokens per frame (kernel limit 512)")
         y = self._chan_ln(tp, x, pre + "norm.gamma", M, C)
         qkv = self._linear(tp, y, pre + "fn.fn.to_qkv.weight", None, M, 3 * HID, C)
         o, lse = _new(M, HID, like=x), _new(Fr * HEADS * n, like=x)

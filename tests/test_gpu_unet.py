@@ -65,7 +65,7 @@ def test_strided_and_transposed_conv_modes(ops):
     assert rel_l2(yu.cpu(), tok(ref_u).cpu()) < 3e-6
 
 
-def test_temporal_and_bottleneck_attention_kernels(ops):
+def test_temporal_attention_kernel(ops):
     from oracle import unet_oracle as UO
     torch.manual_seed(1)
     B, T, HW = 2, 5, 7
@@ -93,8 +93,13 @@ def test_temporal_and_bottleneck_attention_kernels(ops):
     assert rel_l2(gq.cpu(), qkv.grad.reshape(-1, 384)) < 2e-5
     db = part.view(rows // 4, 4, T * T).double().sum(0).view(4, T, T).cpu()
     assert rel_l2(db, bias.grad) < 2e-5
-    # ---- bottleneck softmax attention
-    Fr, n = 3, 70
+
+
+@pytest.mark.parametrize("Fr,n", [(3, 70), (2, 512), (1, 1100)])
+def test_bottleneck_attention_kernels(ops, Fr, n):
+    """Flash-style MFMA attention over the h*w tokens of a frame (unet.py:455-457): ragged n, n = one full block of four
+    waves, and n beyond the 512 tokens a frame-in-LDS kernel could hold (the 256 x 256 fsi-shaped mesh has 4096)."""
+    torch.manual_seed(n)
     qkv2 = torch.randn(Fr, n, 384, dtype=torch.float64, requires_grad=True)
     q, k, v = (t.reshape(Fr, n, 4, 32).transpose(1, 2) for t in qkv2.chunk(3, dim=-1))
     o2 = (((q * 32 ** -0.5) @ k.transpose(-1, -2)).softmax(-1) @ v).transpose(1, 2).reshape(Fr, n, 128)
@@ -104,7 +109,9 @@ def test_temporal_and_bottleneck_attention_kernels(ops):
     out2, lse = torch.empty(Fr * n, 128, device="cuda"), torch.empty(Fr * 4 * n, device="cuda")
     ops.sattn_fwd(q2, out2, lse, Fr, n)
     assert rel_l2(out2.cpu(), o2.detach().reshape(-1, 128)) < 1e-5
-    g2 = torch.empty_like(q2)
+    lse_ref = torch.logsumexp((q * 32 ** -0.5) @ k.transpose(-1, -2), -1).detach()          # [Fr][4][n]
+    assert rel_l2(lse.view(Fr, 4, n).cpu(), lse_ref) < 1e-5
+    g2 = torch.full_like(q2, float("nan"))
     ops.sattn_bwd(q2, out2, dev(go2).view(-1, 128), lse, g2, Fr, n)
     assert rel_l2(g2.cpu(), qkv2.grad.reshape(-1, 384)) < 2e-5
 
@@ -168,6 +175,26 @@ def test_control_channels_and_time_replication_vs_oracle():
     loss.backward()
     sd = _oracle_sd(m)
     loss_ref, pred_ref, grads_ref = UO.loss_and_grads(sd, x, y)
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    named = dict(m.named_parameters())
+    worst = max((rel_l2(named[k].grad.cpu(), g) if float(g.abs().max()) > 1e-7 else float(named[k].grad.abs().max()), k)
+                for k, g in grads_ref.items())
+    assert worst[0] < 1e-3, worst
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x.cuda()).cpu(), pred_ref) < 2e-5
+
+
+def test_wide_mesh_bottleneck_beyond_512_tokens_vs_oracle():
+    """64 x 256 mesh: the bottleneck frame has 16 * 64 = 1024 tokens (the fsi-shaped 256 x 256 config has 4096), which the
+    streaming attention kernel must handle; forward, loss and gradients vs the oracle."""
+    from oracle import unet_oracle as UO
+    m = _model(T=2, H=64, W=256, seed=8).cuda().train()
+    torch.manual_seed(13)
+    x, y = torch.randn(1, 2, 64, 256, 3), torch.randn(1, 2, 64, 256, 3)
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    loss_ref, pred_ref, grads_ref = UO.loss_and_grads(_oracle_sd(m), x, y)
     assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
     named = dict(m.named_parameters())
     worst = max((rel_l2(named[k].grad.cpu(), g) if float(g.abs().max()) > 1e-7 else float(named[k].grad.abs().max()), k)
