@@ -252,6 +252,17 @@ int rpb_affine_silu_bwd_reduce(const float* x, const float* gy, const float* A, 
                                int C, void* stream);
 int rpb_affine_silu_bwd_apply(const float* x, const float* gy, const float* A, const float* Bc, const float* P,
                               const float* Q, float* gx, int B, long n, int C, void* stream);
+/*     3x3x3 convolution (padding 1) forward / data gradient on the bf16 MFMA with fp32-grade accuracy: fp32 operands are split
+ *     into three bf16 terms (hi + mid + lo = all 24 significand bits) and six bf16 x bf16 products per pair are accumulated in
+ *     fp32 (csrc/rpb_conv3x.hip).  Same contract as rpb_gemm_nt conv = 1 with a bias-only epilogue -- nn.Conv3d(Ci, Co, 3,
+ *     padding=1), realpdebench/model/transolver_libs/Physics_Attention.py:154-157, realpdebench/model/unet.py:196,201 (and their
+ *     autograd data gradient with flipped taps): rpb_split3 writes the planes P[3][M][C] (bf16) of x[M][ldx];
+ *     rpb_conv3x_wprep turns W[N][27*Ci] (tap-major rows, as rpb_gemm_nt takes them) into MFMA operand order
+ *     (3 * N * 27 * Ci bf16); rpb_conv3x computes out[M][ldo] = conv(P, Wz) + bias.  Ci % 64 == 0, N in {64, 128, 256 k}. */
+int rpb_split3(const float* x, void* planes, long M, int C, int ldx, void* stream);
+int rpb_conv3x_wprep(const float* W, void* Wz, int N, int Ci, void* stream);
+int rpb_conv3x(const void* planes, const void* Wz, const float* bias, float* out, long M, int N, int Ci, int ldo, int Hc, int Wc,
+               int Dc, void* stream);
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
 int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
 /*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,

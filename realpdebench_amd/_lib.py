@@ -66,6 +66,9 @@ SIGNATURES = {
     "rpb_head_scores": (_I, "pipip" + "ili" + "p"),
     "rpb_head_apply": (_I, "pippipipi" + "ili" + "lf" + "p"),
     "rpb_dropout_mul": (_I, "pp" + "l" + "lf" + "p"),
+    "rpb_split3": (_I, "pp" + "lii" + "p"),
+    "rpb_conv3x_wprep": (_I, "pp" + "ii" + "p"),
+    "rpb_conv3x": (_I, "pppp" + "liii" + "iii" + "p"),
     "rpb_chan_blocks": (_I, "il"),
     "rpb_chan_stats": (_I, "pp" + "ili" + "p"),
     "rpb_affine_silu_fwd": (_I, "ppppp" + "ili" + "p"),

@@ -379,6 +379,22 @@ def affine_silu_bwd_apply(x, gy, A, Bc, P, Q, gx, B, n, C):
               label="affine_silu_bwd_apply", nbytes=12 * B * n * C)
 
 
+def split3(x, planes, M, C, ldx=None):
+    """planes[3][M][C] (bf16 bit patterns in an int16 tensor) = hi / mid / lo terms of x[M][ldx]."""
+    _lib.call("rpb_split3", _p(x), _p(planes, torch.int16), M, C, C if ldx is None else ldx, _stream(), label="split3", nbytes=10 * M * C)
+
+
+def conv3x_wprep(W, Wz, N, Ci):
+    _lib.call("rpb_conv3x_wprep", _p(W), _p(Wz, torch.int16), N, Ci, _stream(), label="conv3x_wprep", nbytes=10 * N * 27 * Ci)
+
+
+def conv3x(planes, Wz, out, M, N, Ci, mesh, bias=None, ldo=None):
+    """out[M][ldo] = Conv3d(Ci, N, 3, padding=1)(tokens) + bias on the bf16 MFMA from split operands (fp32-grade accuracy)."""
+    hc, wc, dc = mesh
+    _lib.call("rpb_conv3x", _p(planes, torch.int16), _p(Wz, torch.int16), _p(bias), _p(out), M, N, Ci, N if ldo is None else ldo, hc, wc, dc, _stream(),
+              label=f"conv3x[N{N},Ci{Ci}]", nbytes=6 * M * Ci * 9 + 4 * M * N, flops=2 * M * N * 27 * Ci)
+
+
 def im2col(x, col, B, T, H, W, Cin, KS, ldc):
     _lib.call("rpb_im2col", _p(x), _p(col), B, T, H, W, Cin, KS, ldc, _stream(), label="im2col",
               nbytes=4 * B * T * H * W * (Cin + ldc))

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Split-bf16 3x3x3 convolution (rpb_conv3x) vs the exact-fp32 implicit GEMM (rpb_gemm_nt conv mode 1): accuracy against
+fp64 on a small mesh, and time at the Transolver (Ci 256 -> 512) and U-Net (64 -> 64, 256 -> 256) cylinder shapes."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from realpdebench_amd import ops  # noqa: E402
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def run(B, mesh, Ci, N, check, iters=3):
+    T, H, W = mesh
+    M = B * T * H * W
+    torch.manual_seed(0)
+    x = torch.randn(M, Ci, device="cuda")
+    w = torch.randn(N, 27 * Ci, device="cuda") / (27 * Ci) ** 0.5
+    bias = torch.randn(N, device="cuda")
+    planes = torch.empty(3 * M * Ci, dtype=torch.int16, device="cuda")
+    wz = torch.empty(3 * N * 27 * Ci, dtype=torch.int16, device="cuda")
+    y = torch.empty(M, N, device="cuda")
+    y32 = torch.empty(M, N, device="cuda")
+    ops.split3(x, planes, M, Ci)
+    ops.conv3x_wprep(w, wz, N, Ci)
+    ops.conv3x(planes, wz, y, M, N, Ci, mesh, bias=bias)
+    ops.gemm_nt(x, w, y32, M, N, 27 * Ci, bias=bias, conv=mesh)
+    torch.cuda.synchronize()
+    print(f"B={B} mesh={mesh} Ci={Ci} N={N}: conv3x vs fp32 path rel {rel(y, y32):.2e}", flush=True)
+    if check:
+        xr = x.view(B, T, H, W, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+        wr = w.view(N, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+        ref = F.conv3d(xr, wr, bias.double().cpu(), padding=1).permute(0, 2, 3, 4, 1).reshape(M, N)
+        print(f"   vs fp64: conv3x {rel(y.cpu(), ref):.2e}   exact-fp32 path {rel(y32.cpu(), ref):.2e}", flush=True)
+    for name, fn in (("split3", lambda: ops.split3(x, planes, M, Ci)),
+                     ("conv3x", lambda: ops.conv3x(planes, wz, y, M, N, Ci, mesh, bias=bias)),
+                     ("gemm_nt fp32", lambda: ops.gemm_nt(x, w, y32, M, N, 27 * Ci, bias=bias, conv=mesh))):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        print(f"   {name:14s} {ms:8.3f} ms   {2 * M * N * 27 * Ci / ms / 1e9:7.1f} TF/s (fp32-equivalent)", flush=True)
+
+
+run(2, (3, 5, 7), 64, 64, True)
+run(1, (4, 6, 40), 128, 128, True)
+run(1, (2, 9, 33), 64, 256, True)
+run(4, (20, 64, 128), 256, 512, False)
+run(12, (20, 64, 128), 64, 64, False)
+run(12, (20, 16, 32), 256, 256, False)
+run(12, (20, 32, 64), 128, 128, False)
