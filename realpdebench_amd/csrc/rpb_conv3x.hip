@@ -20,6 +20,11 @@
 #include "rpb_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: selects stay in registers (HIP's uint4 struct did not)
+template <int V>
+struct IC {
+    static constexpr int value = V;
+};
 
 #define CX_BM 128
 #define CX_ROWS (CX_BM + 2)
@@ -128,15 +133,20 @@ struct Conv3xArgs {
 };
 
 template <int WN>
-__global__ __launch_bounds__(256, 2) void conv3x_kernel(Conv3xArgs a) {
+__global__ __launch_bounds__(256, 1) void conv3x_kernel(Conv3xArgs a) {
     constexpr int KS = 4 / WN;
-    extern __shared__ uint4 lds4[];
-    uint4* As = lds4;                                                   // [3 planes][4 chunks][2 halves][CX_ROWS] x 16 B
-    unsigned char* rv = reinterpret_cast<unsigned char*>(lds4 + 24 * CX_ROWS);   // [9][CX_ROWS] row validity per (kt, kh)
+    extern __shared__ u32x4 lds4[];
+    // two stage buffers of [3 planes][4 chunks][2 halves][CX_ROWS] x 16 B, then [9][CX_ROWS] row validity per (kt, kh)
+    unsigned char* rv = reinterpret_cast<unsigned char*>(lds4 + 2 * 24 * CX_ROWS);
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = wave % WN, kp = wave / WN;
-    const long m0 = (long)blockIdx.x * CX_BM;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x walks the
+    // contiguous tile range [x * chunk, (x + 1) * chunk): the h +- 1 rows a tile stages are its neighbours' own rows and hit L2
+    const unsigned chunk = gridDim.x >> 3;
+    const long tile = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const long m0 = tile * CX_BM;
+    if (m0 >= a.M) return;
     const int n0 = blockIdx.y * (64 * WN) + nw * 64;
     const int NT = a.N >> 5, NCC = a.Ci >> 4;
     const unsigned uT = a.T, uH = a.H, uW = a.W;
@@ -164,61 +174,146 @@ __global__ __launch_bounds__(256, 2) void conv3x_kernel(Conv3xArgs a) {
     f32x16 acc[4][2];
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) acc[tm][0] = acc[tm][1] = zero16();
-    const uint4 z4 = {0u, 0u, 0u, 0u};
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
     const long MC = a.M * a.Ci;
 
-    for (int g = 0; g < 9; ++g) {
+    // One workgroup per CU, one wave per SIMD with the whole 512-register file, everything software-pipelined by hand:
+    //   * the next stage's 13 A loads per thread are issued (unconditionally: invalid rows read a dummy address and are zeroed on
+    //     the way into LDS) before the current stage's MFMAs and land in the other LDS buffer afterwards -- one barrier per stage;
+    //   * the B operands of the NEXT tap step (kw, then the next 16-channel chunk / stage) are requested before the 48 MFMAs of
+    //     the current one (left to itself the compiler put every load next to its use: an L2 latency per tap, 57 % MFMA busy).
+    constexpr int SPS = 4 / KS;                                        // my 16-channel chunks per stage
+    const int nc64 = a.Ci >> 6;
+    const uint16_t* wbase = a.Wz + ((long)(n0 >> 5) * 64 + lane) * 8;
+    const long wplane = (long)NT * 512;                                // bf16 elements between the planes of one (tap, chunk)
+    const long wchunk = 3 * wplane, wtap = (long)NCC * wchunk;
+    auto bload = [&](const uint16_t* src, u32x4 (&b)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) b[tn][p] = *reinterpret_cast<const u32x4*>(src + p * wplane + tn * 512);
+    };
+    u32x4 bc[2][3], bn[2][3];
+    const u32x4* As = lds4;
+    u32x4 ac[3], an[3];                                                 // A operands of the current / next 32-token row tile
+    auto lda = [&](int s, int kw, int tm, u32x4 (&av)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) av[p] = As[((p * 4 + s) * 2 + half) * CX_ROWS + tm * 32 + col + kw];
+    };
+    // one tap step = 4 row tiles x 12 MFMAs; the next tile's A operands (the next step's first tile when `more`) are read from
+    // LDS before the current tile's MFMAs are issued -- with one wave per SIMD nobody else hides that latency
+    auto tap_step = [&](int s, int kw, bool more) __attribute__((always_inline)) {                    // kw is a compile-time constant at every call site
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            if (tm < 3) lda(s, kw, tm + 1, an);
+            else if (more) lda(kw == 2 ? s + KS : s, kw == 2 ? 0 : kw + 1, 0, an);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((kw == 0 && wlo[tm]) || (kw == 2 && whi[tm])) ac[0] = ac[1] = ac[2] = z4;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, ac[0]), am = __builtin_bit_cast(bf16x8, ac[1]),
+                         al = __builtin_bit_cast(bf16x8, ac[2]);
+            const bf16x8 b0h = __builtin_bit_cast(bf16x8, bc[0][0]), b0m = __builtin_bit_cast(bf16x8, bc[0][1]),
+                         b0l = __builtin_bit_cast(bf16x8, bc[0][2]), b1h = __builtin_bit_cast(bf16x8, bc[1][0]),
+                         b1m = __builtin_bit_cast(bf16x8, bc[1][1]), b1l = __builtin_bit_cast(bf16x8, bc[1][2]);
+            // small terms first; the two co tiles alternate so consecutive MFMAs are independent
+            acc[tm][0] = mfma_bf16(al, b0h, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(al, b1h, acc[tm][1]);
+            acc[tm][0] = mfma_bf16(ah, b0l, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(ah, b1l, acc[tm][1]);
+            acc[tm][0] = mfma_bf16(am, b0m, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(am, b1m, acc[tm][1]);
+            acc[tm][0] = mfma_bf16(am, b0h, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(am, b1h, acc[tm][1]);
+            acc[tm][0] = mfma_bf16(ah, b0m, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(ah, b1m, acc[tm][1]);
+            acc[tm][0] = mfma_bf16(ah, b0h, acc[tm][0]);
+            acc[tm][1] = mfma_bf16(ah, b1h, acc[tm][1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ac[p] = an[p];
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bc[tn][p] = bn[tn][p];
+    };
+    // A staging registers: 13 x 16 B per thread, named individually (as an array indexed from helper lambdas they were demoted to
+    // scratch memory: load, wait, spill -- one exposed HBM latency per load)
+    constexpr int NLD = (CX_ROWS * 24 + 255) / 256;
+    static_assert(NLD == 13, "staging macros below are written for 13 loads per thread");
+#define CX_FOR13(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+#define CX_DECL(J) u32x4 sv##J = z4; bool ok##J = false;
+    CX_FOR13(CX_DECL)
+#define CX_LOAD(J)                                                                                            \
+    if constexpr (J >= j0 && J < j1) {                                                                        \
+        const int idx = tid + J * 256;                                                                        \
+        const int row = idx / 24, rem = idx - row * 24;                                                       \
+        const int p = rem >> 3, sh = rem & 7; /* sh = 2 * chunk + half: 8 x 16 B = one 128 B line */          \
+        ok##J = idx < CX_ROWS * 24 && rv[g * CX_ROWS + (row < CX_ROWS ? row : 0)];                            \
+        const long off = ok##J ? (long)p * MC + (rowbase + row) * a.Ci + c * 64 + sh * 8 : 0;                 \
+        sv##J = *reinterpret_cast<const u32x4*>(a.P + off);                                                   \
+    }
+#define CX_STORE(J)                                                                                           \
+    {                                                                                                         \
+        const int idx = tid + J * 256;                                                                        \
+        const int row = idx / 24, rem = idx - row * 24;                                                       \
+        if (idx < CX_ROWS * 24) dst[rem * CX_ROWS + row] = ok##J ? sv##J : z4;                                \
+    }
+    // loads j0 <= j < j1 of the 13 a thread contributes to stage (g, c)
+    auto stage_load = [&](int g, int c, auto j0c, auto j1c) __attribute__((always_inline)) {
+        constexpr int j0 = decltype(j0c)::value, j1 = decltype(j1c)::value;
         const int kt = g / 3, kh = g - kt * 3;
         const long rowbase = m0 - 1 + ((long)(kt - 1) * a.H + (kh - 1)) * a.W;
-        for (int c64 = 0; c64 < a.Ci; c64 += 64) {
-            __syncthreads();                                            // the previous stage's LDS reads are done
-            for (int idx = tid; idx < CX_ROWS * 24; idx += 256) {
-                const int row = idx / 24, rem = idx - row * 24;
-                const int p = rem >> 3, sh = rem & 7;                   // sh = 2 * chunk + half: 8 x 16 B = one 128 B line
-                uint4 v = z4;
-                if (rv[g * CX_ROWS + row])
-                    v = *reinterpret_cast<const uint4*>(a.P + (long)p * MC + (rowbase + row) * a.Ci + c64 + sh * 8);
-                As[(p * 8 + sh) * CX_ROWS + row] = v;
+        CX_FOR13(CX_LOAD)
+    };
+    auto stage_store = [&](u32x4* dst) __attribute__((always_inline)) { CX_FOR13(CX_STORE) };
+    bload(wbase + (long)kp * wchunk, bc);                               // (g 0, c 0, s = kp, kw 0)
+    stage_load(0, 0, IC<0>{}, IC<NLD>{});
+    stage_store(lds4);
+    __syncthreads();
+    int buf = 0;
+    constexpr int NST = 3 * SPS;                                        // tap steps per stage
+    for (int g = 0; g < 9; ++g) {
+        for (int c = 0; c < nc64; ++c) {
+            int gn = g, cn = c + 1;                                     // next stage
+            if (cn == nc64) {
+                cn = 0;
+                ++gn;
             }
-            __syncthreads();
-            for (int s = kp; s < 4; s += KS) {
-                const int cc = (c64 >> 4) + s;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int tap = g * 3 + kw;
-                    bf16x8 b[2][3];
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            b[tn][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-                                a.Wz + (((((long)tap * NCC + cc) * 3 + p) * NT + (n0 >> 5) + tn) * 64 + lane) * 8));
-#pragma unroll
-                    for (int tm = 0; tm < 4; ++tm) {
-                        uint4 av[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) av[p] = As[((p * 4 + s) * 2 + half) * CX_ROWS + tm * 32 + col + kw];
-                        if ((kw == 0 && wlo[tm]) || (kw == 2 && whi[tm])) av[0] = av[1] = av[2] = z4;
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[0]), am = __builtin_bit_cast(bf16x8, av[1]),
-                                     al = __builtin_bit_cast(bf16x8, av[2]);
-                        // small terms first; the two co tiles alternate so consecutive MFMAs are independent
-                        acc[tm][0] = mfma_bf16(al, b[0][0], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(al, b[1][0], acc[tm][1]);
-                        acc[tm][0] = mfma_bf16(ah, b[0][2], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(ah, b[1][2], acc[tm][1]);
-                        acc[tm][0] = mfma_bf16(am, b[0][1], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(am, b[1][1], acc[tm][1]);
-                        acc[tm][0] = mfma_bf16(am, b[0][0], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(am, b[1][0], acc[tm][1]);
-                        acc[tm][0] = mfma_bf16(ah, b[0][1], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(ah, b[1][1], acc[tm][1]);
-                        acc[tm][0] = mfma_bf16(ah, b[0][0], acc[tm][0]);
-                        acc[tm][1] = mfma_bf16(ah, b[1][0], acc[tm][1]);
-                    }
-                }
-            }
+            const bool more = gn < 9;
+            As = lds4 + buf * 24 * CX_ROWS;
+            lda(kp, 0, 0, ac);
+            // the next stage's A loads are spread over this stage's tap steps (13 MB at once from every CU of the chip in
+            // lock-step is a burst that the in-order vmcnt of the next B operands would have to wait out)
+#define CX_SI_BLOCK(SI)                                                                                        \
+    if constexpr (SI < SPS) {                                                                                  \
+        const int s = kp + SI * KS;                                                                            \
+        const uint16_t* w0 = wbase + (long)(g * 3) * wtap + (long)(c * 4 + s) * wchunk;                        \
+        bload(w0 + wtap, bn);                                                                                  \
+        if (more) stage_load(gn, cn, IC<(SI * 3 + 0) * NLD / NST>{}, IC<(SI * 3 + 1) * NLD / NST>{});          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        tap_step(s, 0, true);                                                                                  \
+        bload(w0 + 2 * wtap, bn);                                                                              \
+        if (more) stage_load(gn, cn, IC<(SI * 3 + 1) * NLD / NST>{}, IC<(SI * 3 + 2) * NLD / NST>{});          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        tap_step(s, 1, true);                                                                                  \
+        /* the step after (s, kw 2): next chunk of this stage, else the next stage's first chunk */            \
+        if (SI + 1 < SPS) bload(w0 + (long)KS * wchunk, bn);                                                   \
+        else if (more) bload(wbase + (long)(gn * 3) * wtap + (long)(cn * 4 + kp) * wchunk, bn);                \
+        if (more) stage_load(gn, cn, IC<(SI * 3 + 2) * NLD / NST>{}, IC<(SI * 3 + 3) * NLD / NST>{});          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        tap_step(s, 2, SI + 1 < SPS);                                                                          \
+    }
+            CX_SI_BLOCK(0) CX_SI_BLOCK(1) CX_SI_BLOCK(2) CX_SI_BLOCK(3)
+            if (more) stage_store(lds4 + (buf ^ 1) * 24 * CX_ROWS);
+            __syncthreads();                                            // everyone is done with buf and has filled buf ^ 1
+            buf ^= 1;
         }
     }
+#undef CX_SI_BLOCK
+#undef CX_STORE
+#undef CX_LOAD
+#undef CX_DECL
+#undef CX_FOR13
     // ---- K-split partial sums through LDS (one 32-token row tile at a time), then bias + store by the kp == 0 waves
     float* red = reinterpret_cast<float*>(lds4);                        // [(KS-1) * WN slots][2 tiles][16 regs][64 lanes]
 #pragma unroll
@@ -265,9 +360,12 @@ extern "C" int rpb_conv3x(const void* planes, const void* Wz, const float* bias,
     RPB_REQUIRE(Ci % 64 == 0 && (N == 64 || N == 128 || N % 256 == 0) && ldo >= N, "conv3x: N=%d Ci=%d unsupported (Ci %% 64, N = 64, 128 or a multiple of 256)", N, Ci);
     RPB_REQUIRE(Hc > 0 && Wc > 0 && Dc > 0 && M % ((long)Hc * Wc * Dc) == 0, "conv3x: bad mesh");
     Conv3xArgs a{(const uint16_t*)planes, (const uint16_t*)Wz, bias, out, M, N, Ci, ldo, Hc, Wc, Dc};
-    const size_t lds = (size_t)24 * CX_ROWS * 16 + 9 * CX_ROWS + 16;
-    const unsigned gx = (unsigned)((M + CX_BM - 1) / CX_BM);
+    const size_t lds = (size_t)2 * 24 * CX_ROWS * 16 + 9 * CX_ROWS + 16;
+    const unsigned gx = (unsigned)(((M + CX_BM - 1) / CX_BM + 7) / 8 * 8);
     hipStream_t st = (hipStream_t)stream;
+    (void)hipFuncSetAttribute((const void*)conv3x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv3x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv3x_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (N == 64) {
         hipLaunchKernelGGL(conv3x_kernel<1>, dim3(gx, 1), dim3(256), lds, st, a);
     } else if (N == 128) {
