@@ -151,7 +151,7 @@ class Transolver(_ModelBase):
                 st.update(fx0=fx, a1=a, xf=xf, w=w, tokS=tokS, norm=norm, tok2=tok2, ox=ox)
             ops.layernorm_fwd(fx, blk.ln_1.weight.data, blk.ln_1.bias.data, a, M, C)
             wcat, bcat = self._conv_cat(i)
-            ops.gemm_nt(a, wcat, xf, M, 2 * C, 27 * C, bias=bcat, conv=(self.H, self.W, self.D))
+            ops.conv3(a, wcat, xf, M, 2 * C, C, (self.H, self.W, self.D), bias=bcat)
             ops.slice_fwd(xf, at.in_project_slice.weight.data, at.in_project_slice.bias.data,
                           at.temperature.data.reshape(-1).contiguous(), w, tok_part, norm_part, B, ntok, heads, G, 2 * C)
             for b in range(B):            # per-sample finish of the block partials (deterministic fp64 sums)
@@ -307,7 +307,7 @@ class Transolver(_ModelBase):
             wcat, _ = self._conv_cat(i)
             wflip = wcat.view(2 * C, 27, C).flip(1).permute(2, 1, 0).reshape(C, 27 * 2 * C).contiguous()
             ga1 = new(M, C)
-            ops.gemm_nt(gxf, wflip, ga1, M, C, 27 * 2 * C, conv=(self.H, self.W, self.D), lda=2 * C)
+            ops.conv3(gxf, wflip, ga1, M, C, 2 * C, (self.H, self.W, self.D))
             del gxf
             g, grads[blk.ln_1.weight], grads[blk.ln_1.bias] = self._ln_bwd(st["fx0"], blk.ln_1, ga1, g1, M, C)
         # ---- preprocess MLP (+ placeholder): fx0 = post(gelu(pre(x))) + placeholder

@@ -315,7 +315,7 @@ class Unet3d(_ModelBase):
         """nn.Conv3d(Ci, Co, 3, padding=1) on the (T,H,W) mesh."""
         M = B * mesh[0] * mesh[1] * mesh[2]
         y = _new(M, Co, like=x)
-        ops.gemm_nt(x, self._w("conv3", name + ".weight"), y, M, Co, 27 * Ci, bias=self.p(name + ".bias").detach(), conv=mesh)
+        ops.conv3(x, self._w("conv3", name + ".weight"), y, M, Co, Ci, mesh, bias=self.p(name + ".bias").detach())
 
         def bwd():
             gy = tp.grad(y)
@@ -323,7 +323,7 @@ class Unet3d(_ModelBase):
             tp.pacc(name + ".weight", dW.view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3).contiguous())
             tp.pacc(name + ".bias", db)
             gx = _new(M, Ci, like=x)
-            ops.gemm_nt(gy, self._w("conv3_dgrad", name + ".weight"), gx, M, Ci, 27 * Co, conv=mesh)
+            ops.conv3(gy, self._w("conv3_dgrad", name + ".weight"), gx, M, Ci, Co, mesh)
             tp.acc(x, gx)
 
         tp.add(bwd)

@@ -3,6 +3,8 @@
 PyTorch-ROCm tensors are storage only: every wrapper checks device / dtype / contiguity, passes raw
 ``data_ptr()``s plus the current HIP stream, and raises on any error.  No wrapper has a non-HIP path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -393,6 +395,27 @@ def conv3x(planes, Wz, out, M, N, Ci, mesh, bias=None, ldo=None):
     hc, wc, dc = mesh
     _lib.call("rpb_conv3x", _p(planes, torch.int16), _p(Wz, torch.int16), _p(bias), _p(out), M, N, Ci, N if ldo is None else ldo, hc, wc, dc, _stream(),
               label=f"conv3x[N{N},Ci{Ci}]", nbytes=6 * M * Ci * 9 + 4 * M * N, flops=2 * M * N * 27 * Ci)
+
+
+CONV3_SPLIT = os.environ.get("RPB_CONV3_EXACT", "0") != "1"
+
+
+def conv3_split_ok(N, Ci):
+    return CONV3_SPLIT and Ci % 64 == 0 and (N in (64, 128) or N % 256 == 0)
+
+
+def conv3(x, W, out, M, N, Ci, mesh, bias=None, ldx=None):
+    """out[M][N] = Conv3d(Ci, N, 3, padding=1)(x tokens [M][ldx]) + bias with W[N][27*Ci] (tap-major rows) -- forward, or the
+    data gradient when W holds the flipped / transposed taps.  Shapes the split-bf16 kernel covers (Ci % 64 == 0, N = 64, 128
+    or 256 k) run on the bf16 MFMA from hi + mid + lo operands (csrc/rpb_conv3x.hip: fp32-grade accuracy, ~2x the fp32 MFMA
+    rate); everything else, or RPB_CONV3_EXACT=1, takes the exact-fp32 implicit GEMM (rpb_gemm_nt conv mode 1)."""
+    if not conv3_split_ok(N, Ci):
+        return gemm_nt(x, W, out, M, N, 27 * Ci, bias=bias, conv=mesh, lda=ldx)
+    planes = torch.empty(3 * M * Ci, dtype=torch.int16, device=out.device)
+    wz = torch.empty(3 * N * 27 * Ci, dtype=torch.int16, device=out.device)
+    split3(x, planes, M, Ci, ldx)
+    conv3x_wprep(W, wz, N, Ci)
+    conv3x(planes, wz, out, M, N, Ci, mesh, bias=bias)
 
 
 def im2col(x, col, B, T, H, W, Cin, KS, ldc):
