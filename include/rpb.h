@@ -263,6 +263,13 @@ int rpb_split3(const float* x, void* planes, long M, int C, int ldx, void* strea
 int rpb_conv3x_wprep(const float* W, void* Wz, int N, int Ci, void* stream);
 int rpb_conv3x(const void* planes, const void* Wz, const float* bias, float* out, long M, int N, int Ci, int ldo, int Hc, int Wc,
                int Dc, void* stream);
+/*     ... and its weight / bias gradient (autograd of the same nn.Conv3d): the contraction runs over tokens, so both tensors are
+ *     split into planes Pt[3][M/8][C][8] (runs of 8 tokens per channel; rpb_split3t; M % 8 == 0, C % 64 == 0); part[rpb_conv3x_wgrad_splits()][Co*27*Ci
+ *     + Co] receives per-split partials of dW[co][tap][ci] and db[co] in the layout of rpb_gemm_tn (finish with
+ *     rpb_reduce_partials).  Co % 64 == 0, Ci % 64 == 0, innermost mesh dimension % 8 == 0. */
+int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, void* stream);
+int rpb_conv3x_wgrad_splits(long M, int Co, int Ci);
+int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co, int Ci, int Hc, int Wc, int Dc, void* stream);
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
 int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
 /*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,

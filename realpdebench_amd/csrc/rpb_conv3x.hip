@@ -375,3 +375,303 @@ extern "C" int rpb_conv3x(const void* planes, const void* Wz, const float* bias,
     }
     RPB_CHECK_LAUNCH("conv3x");
 }
+
+// ====================================================================================== weight gradient
+// dW[co][tap][ci] = sum_tok G[tok][co] * X[tok + shift(tap)][ci] contracts over TOKENS, so the MFMA operands are runs of 8
+// consecutive tokens of one channel: both tensors are split into bf16 planes Pt[3][M/8][C][8] (rpb_split3t).
+// Requires W % 8 == 0 (every mesh of the reference's configs): an aligned group of 8 tokens then lies in one w-row, so
+//   * the t / h validity of a tap is a property of the whole X group -> invalid groups are zeroed when they are staged;
+//   * the w validity touches one element: for kw = 0 the first token of a G group that starts a w-row, for kw = 2 the last token
+//     of a group that ends one -> a single v_and on the A operand;
+//   * only the kw = 0 / 2 operands are misaligned (by one token): they are assembled from the aligned 16 B and one neighbouring
+//     dword with four v_alignbit.
+// A workgroup owns a 64 co x 64 ci tile of one kt (9 taps, 4 waves = co half x ci half, 144 accumulator registers each) for one
+// token split; grid.x = splits (a multiple of 8: split s always runs on XCD s % 8, so the 3 * Co/64 * Ci/64 tiles that stream the
+// same tokens share that XCD's L2), grid.y = tiles.  Chunks of 32 tokens are double-buffered in LDS (conflict-free row strides),
+// the next chunk's loads are in flight during the 108 MFMAs per wave of the current one.
+#define WX_KT 32
+#define WX_GROW 28                       // dwords per G^T row   (48 tok = 24 dwords + 4 pad: conflict-free b128 accesses)
+#define WX_XROW 20                       // dwords per X^T row   (32 tok = 16 dwords + 4 pad)
+#define WX_GS (3 * 64 * WX_GROW)         // dwords: [3 planes][64 co]
+#define WX_XS (9 * 64 * WX_XROW)         // dwords: [3 kh][3 planes][64 ci]
+#define WX_BUF (WX_GS + WX_XS)
+
+// x [M][ldx] fp32 -> Pt[3][M/8][C][8] bf16 (runs of 8 tokens per channel, channels next: the 16 B operands of 64 channels are
+// 1 KB contiguous, so a wave stages one token group of 64 channels with one coalesced load); block = 64 tokens x 64 channels
+__global__ __launch_bounds__(256) void split3t_kernel(const float* __restrict__ x, uint16_t* __restrict__ Pt, long M, int C,
+                                                      int ldx) {
+    __shared__ uint16_t tl[3][64][72];                                 // [plane][channel][token], rows padded to 144 B
+    const int tid = threadIdx.x;
+    const long m0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                       // 64 tokens x 16 float4
+        const int idx = tid + j * 256, tok = idx >> 4, c4 = (idx & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + tok < M) v = *reinterpret_cast<const f32x4*>(x + (m0 + tok) * ldx + c0 + c4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned h, md, lo;
+            split3(v[i], h, md, lo);
+            tl[0][c4 + i][tok] = (uint16_t)h;
+            tl[1][c4 + i][tok] = (uint16_t)md;
+            tl[2][c4 + i][tok] = (uint16_t)lo;
+        }
+    }
+    __syncthreads();
+    const long MG = M >> 3;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {                                       // 3 planes x 8 token groups x 64 channels (fastest: 1 KB runs)
+        const int idx = tid + j * 256, ch = idx & 63, g8 = (idx >> 6) & 7, p = idx >> 9;
+        if (m0 + g8 * 8 < M)
+            *reinterpret_cast<uint4*>(Pt + (((long)p * MG + (m0 >> 3) + g8) * C + c0 + ch) * 8) = *reinterpret_cast<const uint4*>(&tl[p][ch][g8 * 8]);
+    }
+}
+
+extern "C" int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, void* stream) {
+    RPB_REQUIRE(x && planes_t && M > 0 && M % 8 == 0 && C > 0 && C % 64 == 0 && ldx % 4 == 0 && ldx >= C,
+                "split3t: bad arguments (M=%ld C=%d ldx=%d; M %% 8, C %% 64)", M, C, ldx);
+    hipLaunchKernelGGL(split3t_kernel, dim3((unsigned)((M + 63) / 64), C / 64), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint16_t*)planes_t, M, C, ldx);
+    RPB_CHECK_LAUNCH("split3t");
+}
+
+struct WgxArgs {
+    const uint16_t* Gt;    // [3][M/8][Co][8] bf16 planes of the output gradient
+    const uint16_t* Xt;    // [3][M/8][Ci][8] bf16 planes of the input
+    float* part;           // [splits][Co * 27 * Ci + Co]
+    long M;
+    int Co, Ci, T, H, W;
+};
+
+__global__ __launch_bounds__(256, 1) void conv3x_wgrad_kernel(WgxArgs a) {
+    // The sum runs over u = the X token (so the X windows of the three kh are ALIGNED 32-token runs, no halo) and pairs it with
+    // G[u - (kw - 1)]: the one-token misalignment of kw = 0 / 2 is taken on the G side, whose shifted operands serve all three kh
+    // (24 v_alignbit per 16-token step instead of 72 when X carried it).
+    extern __shared__ unsigned ldsw[];                                  // 2 x WX_BUF dwords, then the group validity tables
+    int* Vt = reinterpret_cast<int*>(ldsw + 2 * WX_BUF);                // [2][12]: (kh, group of 8 tokens of the chunk)
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int o = wave & 1, c = wave >> 1;
+    const int ncb = a.Ci >> 6;
+    // tile order: co tile fastest -- the workgroups of one split that are resident together then stream the SAME X windows
+    // (one (ci tile, kt) pair is shared by all Co / 64 of them; with kt fastest every workgroup had its own stream: 30 % L2 hits)
+    int tile = blockIdx.y;
+    const int nob = a.Co >> 6;
+    const int cob = tile % nob;
+    tile /= nob;
+    const int kt = tile % 3, cib = tile / 3;
+    const int n0 = cob * 64, ci0 = cib * 64;
+    const int nsplit = gridDim.x, split = blockIdx.x;
+    const long per = ((a.M + nsplit - 1) / nsplit + WX_KT - 1) / WX_KT * WX_KT;
+    const long mb = (long)split * per;
+    long me = mb + per;
+    if (me > a.M) me = a.M;
+    const long tshift = (long)(kt - 1) * a.H * a.W;                     // token shift of this kt (the kh shift is added per window)
+    const long MG = a.M >> 3;
+
+    f32x16 acc[9], accb = zero16();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = zero16();
+    const bool do_bias = (cib == 0 && kt == 1 && c == 0);
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
+
+    // ---- X group validity (t / h neighbours inside the mesh), carried chunk to chunk by threads 0..11
+    int vh = 0, vt = 0, vw = 0;
+    const int vkh = tid >> 2, vgrp = tid & 3;
+    if (tid < 12) {
+        const long q = mb + vgrp * 8 + tshift + (long)(vkh - 1) * a.W + 3L * a.T * a.H * a.W;
+        vw = (int)(q % a.W);
+        const long r = q / a.W;
+        vh = (int)(r % a.H);
+        vt = (int)((r / a.H) % a.T);
+    }
+    auto group_mask = [&](int buf) __attribute__((always_inline)) {
+        if (tid < 12) {
+            const int tt = vt - kt + 1, hh = vh - vkh + 1;
+            Vt[buf * 12 + tid] = (tt >= 0 && tt < a.T && hh >= 0 && hh < a.H) ? 1 : 0;
+            vw += WX_KT;
+            while (vw >= a.W) {
+                vw -= a.W;
+                if (++vh >= a.H) {
+                    vh = 0;
+                    if (++vt >= a.T) vt = 0;
+                }
+            }
+        }
+    };
+
+    // ---- staging: 1152 G pieces (3 planes x 6 groups x 64 co) + 2304 X pieces (9 (kh, plane) x 4 groups x 64 ci) of 16 B over
+    // 256 threads = 14 per thread; a wave's 64 lanes are the 64 channels of one (plane, group): one coalesced 1 KB load.
+    // Per-thread constants of every piece are computed once; registers are named individually (see conv3x_kernel).
+#define WX_FOR14(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define WX_DECL(J)                                                                                             \
+    u32x4 sv##J = z4;                                                                                          \
+    bool ok##J = false;                                                                                        \
+    const uint16_t* pp##J; /* the piece of the next chunk to load; advances by st##J elements per chunk */     \
+    int qr##J, ds##J, vi##J, st##J; /* token offset rel. to t0, LDS dword offset, validity slot, 32 * C */     \
+    {                                                                                                          \
+        const int idx = tid + J * 256;                                                                         \
+        if (idx < 1152) {                                                                                      \
+            const int u = idx >> 6, ch = idx & 63, p = u / 6, grp = u - p * 6;                                 \
+            qr##J = grp * 8 - 8;                                                                               \
+            pp##J = a.Gt + ((long)p * MG * a.Co + n0 + ch) * 8 + ((mb + qr##J) >> 3) * (a.Co * 8L);            \
+            ds##J = (p * 64 + ch) * WX_GROW + grp * 4;                                                         \
+            vi##J = -1;                                                                                        \
+            st##J = a.Co * 32;                                                                                 \
+        } else {                                                                                               \
+            const int xi = idx - 1152, u = xi >> 6, ch = xi & 63, kp = u >> 2, grp = u & 3;                    \
+            const int kh = kp / 3, p = kp - kh * 3;                                                            \
+            qr##J = (int)(grp * 8 + tshift + (long)(kh - 1) * a.W);                                            \
+            pp##J = a.Xt + ((long)p * MG * a.Ci + ci0 + ch) * 8 + ((mb + qr##J) >> 3) * (a.Ci * 8L);           \
+            ds##J = WX_GS + (kp * 64 + ch) * WX_XROW + grp * 4;                                                \
+            vi##J = xi < 2304 ? kh * 4 + grp : -2;                                                             \
+            st##J = a.Ci * 32;                                                                                 \
+        }                                                                                                      \
+    }
+    WX_FOR14(WX_DECL)
+#define WX_LOAD(J)                                                                                             \
+    {                                                                                                          \
+        const long q = t0 + qr##J;                                                                             \
+        bool okp = vi##J != -2 && q >= 0 && q + 8 <= a.M;                                                      \
+        if (vi##J >= 0) okp = okp && Vt[vbuf * 12 + vi##J];                                                    \
+        sv##J = *reinterpret_cast<const u32x4*>(okp ? pp##J : a.Gt); /* selected at the store: no vmcnt here */ \
+        ok##J = okp;                                                                                           \
+        pp##J += st##J;                                                                                        \
+    }
+#define WX_STORE(J) \
+    if (vi##J != -2) *reinterpret_cast<u32x4*>(dst + ds##J) = ok##J ? sv##J : z4;
+    auto stage_load = [&](long t0, int vbuf) __attribute__((always_inline)) { WX_FOR14(WX_LOAD) };
+    auto stage_store = [&](unsigned* dst) __attribute__((always_inline)) { WX_FOR14(WX_STORE) };
+
+    // ---- one k-step = 16 tokens: 9 taps x 6 split products (+ 3 MFMAs against ones for the bias gradient)
+    int wg = (int)((mb + 8 * half) % a.W);                              // w of my first token group of the chunk
+    auto kstep = [&](const unsigned* buf, int ks) __attribute__((always_inline)) {
+        int wpos = wg + ks * 16;
+        while (wpos >= a.W) wpos -= a.W;
+        const unsigned m0 = wpos + 8 == a.W ? 0x0000FFFFu : 0xFFFFFFFFu;   // kw = 0 pairs X[u] with G[u + 1]: none for w_u = W - 1
+        const unsigned m2 = wpos == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;         // kw = 2 pairs X[u] with G[u - 1]: none for w_u = 0
+        u32x4 ga[3], g0[3], g2[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned* gr = buf + (p * 64 + o * 32 + col) * WX_GROW + 4 + ks * 8 + half * 4;   // window starts at t0 - 8
+            const u32x4 x = *reinterpret_cast<const u32x4*>(gr);
+            const unsigned xm = gr[-1], xn = gr[4];
+            ga[p] = x;
+            g0[p].x = __builtin_amdgcn_alignbit(x.y, x.x, 16);          // G[u + 1]
+            g0[p].y = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            g0[p].z = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+            g0[p].w = __builtin_amdgcn_alignbit(xn, x.w, 16) & m0;
+            g2[p].x = __builtin_amdgcn_alignbit(x.x, xm, 16) & m2;      // G[u - 1]
+            g2[p].y = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+            g2[p].z = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            g2[p].w = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) accb = mfma_bf16(__builtin_bit_cast(bf16x8, ga[p]), __builtin_bit_cast(bf16x8, ones), accb);
+        }
+        u32x4 xb[3][3];                                                 // all nine X operands of the step before its MFMAs
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                xb[kh][p] = *reinterpret_cast<const u32x4*>(buf + WX_GS + ((kh * 3 + p) * 64 + c * 32 + col) * WX_XROW + ks * 8 + half * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            // (A plane, B plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; the three kw taps alternate
+#define WX_MF(PA, PB)                                                                                                             \
+    acc[kh * 3 + 0] = mfma_bf16(__builtin_bit_cast(bf16x8, g0[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 0]);    \
+    acc[kh * 3 + 1] = mfma_bf16(__builtin_bit_cast(bf16x8, ga[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 1]);    \
+    acc[kh * 3 + 2] = mfma_bf16(__builtin_bit_cast(bf16x8, g2[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 2]);
+            WX_MF(2, 0) WX_MF(0, 2) WX_MF(1, 1) WX_MF(1, 0) WX_MF(0, 1) WX_MF(0, 0)
+#undef WX_MF
+        }
+    };
+
+    group_mask(0);
+    group_mask(1);
+    __syncthreads();
+    if (mb < me) {
+        stage_load(mb, 0);
+        stage_store(ldsw);
+    }
+    __syncthreads();
+    int it = 0;
+    for (long t0 = mb; t0 < me; t0 += WX_KT, ++it) {
+        const unsigned* cur = ldsw + (it & 1) * WX_BUF;
+#ifdef WX_EXP_NOSTAGE
+        const bool more = false;
+#else
+        const bool more = t0 + WX_KT < me;
+#endif
+        if (more) stage_load(t0 + WX_KT, (it + 1) & 1);                 // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(cur, 0);
+        kstep(cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef WX_EXP_NOSTORE
+        if (more && sv0.x == 0x12345u) stage_store(ldsw + ((it + 1) & 1) * WX_BUF);
+#else
+        if (more) stage_store(ldsw + ((it + 1) & 1) * WX_BUF);
+#endif
+        group_mask(it & 1);                                             // for chunk it + 2
+        wg += WX_KT;
+        while (wg >= a.W) wg -= a.W;
+        __syncthreads();
+    }
+#undef WX_STORE
+#undef WX_LOAD
+#undef WX_DECL
+#undef WX_FOR14
+    const long K = 27L * a.Ci;
+    float* part = a.part + (long)split * ((long)a.Co * K + a.Co);
+#pragma unroll
+    for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + o * 32 + mfma_row(lane, r);
+            const long k = ((long)(kt * 9 + k9)) * a.Ci + ci0 + c * 32 + col;
+            part[(long)n * K + k] = acc[k9][r];
+        }
+    if (do_bias && col == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(long)a.Co * K + n0 + o * 32 + mfma_row(lane, r)] = accb[r];
+    }
+}
+
+static int conv3x_wgrad_nsplit(long M, int Co, int Ci) {
+    // splits: a multiple of 8 (XCD affinity, see above) that makes workgroups per CU integral, >= 1024 tokens per split
+    const long tiles = (long)(Co / 64) * (Ci / 64) * 3, ncu = rpb_num_cus();
+    long cap = M / 1024;
+    if (cap < 8) cap = 8;
+    long best = 8;
+    double best_fill = 0.0;
+    for (long sp = 8; sp <= cap && sp * tiles <= 6 * ncu + 8 * tiles; sp += 8) {
+        const long blocks = tiles * sp, rounds = (blocks + ncu - 1) / ncu;
+        const double fill = (double)blocks / (double)(rounds * ncu);
+        if (fill >= best_fill) {
+            best_fill = fill;
+            best = sp;
+        }
+    }
+    return (int)best;
+}
+
+extern "C" int rpb_conv3x_wgrad_splits(long M, int Co, int Ci) { return conv3x_wgrad_nsplit(M, Co, Ci); }
+
+extern "C" int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co, int Ci, int Hc, int Wc, int Dc,
+                                void* stream) {
+    RPB_REQUIRE(Gt && Xt && part && M > 0 && M % 8 == 0 && M < (1L << 40), "conv3x_wgrad: bad arguments");
+    RPB_REQUIRE(Co % 64 == 0 && Ci % 64 == 0 && Dc % 8 == 0 && Dc >= 16, "conv3x_wgrad: Co=%d Ci=%d W=%d unsupported (Co, Ci %% 64; innermost mesh dimension %% 8)", Co, Ci, Dc);
+    RPB_REQUIRE(Hc > 0 && Wc > 0 && M % ((long)Hc * Wc * Dc) == 0, "conv3x_wgrad: bad mesh");
+    WgxArgs a{(const uint16_t*)Gt, (const uint16_t*)Xt, part, M, Co, Ci, Hc, Wc, Dc};
+    const size_t lds = (size_t)2 * WX_BUF * 4 + 2 * 12 * 4;
+    RPB_REQUIRE(lds <= 160 * 1024, "conv3x_wgrad: LDS");
+    (void)hipFuncSetAttribute((const void*)conv3x_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int sp = conv3x_wgrad_nsplit(M, Co, Ci);
+    hipLaunchKernelGGL(conv3x_wgrad_kernel, dim3(sp, (Co / 64) * (Ci / 64) * 3), dim3(256), lds, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("conv3x_wgrad");
+}

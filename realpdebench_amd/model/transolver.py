@@ -206,9 +206,13 @@ class Transolver(_ModelBase):
     # ------------------------------------------------------------------ backward
     def _wgrad(self, G, A, M, N, K, ldg=None, lda=None, conv=None):
         """(dW [N,K], db [N]) = (G^T A, colsum G) through the TN GEMM + fp64 partial reduction."""
-        splits = ops.gemm_tn_splits(M, N, K, conv is not None)
-        part = torch.empty(splits, N * K + N, device=G.device, dtype=torch.float32)
-        ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda, conv=conv)
+        if conv is not None:
+            part = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
+            splits = part.shape[0]
+        else:
+            splits = ops.gemm_tn_splits(M, N, K, False)
+            part = torch.empty(splits, N * K + N, device=G.device, dtype=torch.float32)
+            ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
         dW = torch.empty(N, K, device=G.device, dtype=torch.float32)
         db = torch.empty(N, device=G.device, dtype=torch.float32)
         ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)

@@ -397,7 +397,45 @@ def conv3x(planes, Wz, out, M, N, Ci, mesh, bias=None, ldo=None):
               label=f"conv3x[N{N},Ci{Ci}]", nbytes=6 * M * Ci * 9 + 4 * M * N, flops=2 * M * N * 27 * Ci)
 
 
+def split3t(x, planes_t, M, C, ldx=None):
+    """planes_t[3][M/8][C][8] (bf16 bit patterns): hi / mid / lo terms of x[M][ldx] in runs of 8 tokens per channel."""
+    _lib.call("rpb_split3t", _p(x), _p(planes_t, torch.int16), M, C, C if ldx is None else ldx, _stream(), label="split3t",
+              nbytes=10 * M * C)
+
+
+def conv3x_wgrad_splits(M, Co, Ci):
+    return _lib.query("rpb_conv3x_wgrad_splits", M, Co, Ci)
+
+
+def conv3x_wgrad(Gt, Xt, part, M, Co, Ci, mesh):
+    hc, wc, dc = mesh
+    _lib.call("rpb_conv3x_wgrad", _p(Gt, torch.int16), _p(Xt, torch.int16), _p(part), M, Co, Ci, hc, wc, dc, _stream(),
+              label=f"conv3x_wgrad[Co{Co},Ci{Ci}]", nbytes=6 * M * (Co + 3 * Ci), flops=2 * M * Co * 27 * Ci)
+
+
 CONV3_SPLIT = os.environ.get("RPB_CONV3_EXACT", "0") != "1"
+
+
+def conv3_wgrad_split_ok(Co, Ci, mesh, M):
+    return CONV3_SPLIT and Co % 64 == 0 and Ci % 64 == 0 and mesh[2] % 8 == 0 and mesh[2] >= 16 and M % 8 == 0
+
+
+def conv3_wgrad_parts(G, X, M, Co, Ci, mesh, ldg=None, ldx=None):
+    """Per-split partials [splits][Co*27*Ci + Co] of (dW, db) of Conv3d(Ci, Co, 3, padding=1): split-bf16 kernel where the shape
+    allows, else the exact-fp32 LDS-tiled kernel (rpb_gemm_tn conv mode 1)."""
+    K = 27 * Ci
+    if conv3_wgrad_split_ok(Co, Ci, mesh, M):
+        gt = torch.empty(3 * Co * M, dtype=torch.int16, device=G.device)
+        xt = torch.empty(3 * Ci * M, dtype=torch.int16, device=G.device)
+        split3t(G, gt, M, Co, ldg)
+        split3t(X, xt, M, Ci, ldx)
+        part = torch.empty(conv3x_wgrad_splits(M, Co, Ci), Co * K + Co, device=G.device)
+        conv3x_wgrad(gt, xt, part, M, Co, Ci, mesh)
+        return part
+    part = torch.empty(gemm_tn_splits(M, Co, K, conv=True), Co * K + Co, device=G.device)
+    gemm_tn(G, X, part, M, Co, K, ldg=ldg, lda=ldx, conv=mesh)
+    return part
+
 
 
 def conv3_split_ok(N, Ci):

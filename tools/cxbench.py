@@ -51,6 +51,58 @@ def run(B, mesh, Ci, N, check, iters=3):
         print(f"   {name:14s} {ms:8.3f} ms   {2 * M * N * 27 * Ci / ms / 1e9:7.1f} TF/s (fp32-equivalent)", flush=True)
 
 
+def run_wgrad(B, mesh, Ci, Co, check, iters=3):
+    T, H, W = mesh
+    M = B * T * H * W
+    torch.manual_seed(1)
+    x = torch.randn(M, Ci, device="cuda")
+    g = torch.randn(M, Co, device="cuda")
+    K = 27 * Ci
+
+    def finish(part):
+        dW = torch.empty(Co, K, device="cuda")
+        db = torch.empty(Co, device="cuda")
+        ops.reduce_partials(part, part.shape[0], Co * K, out_f32=dW.view(-1), row_stride=Co * K + Co)
+        ops.reduce_partials(part, part.shape[0], Co, out_f32=db, row_stride=Co * K + Co, col0=Co * K)
+        return dW, db
+
+    ops.CONV3_SPLIT = True
+    dW, db = finish(ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh))
+    ops.CONV3_SPLIT = False
+    dW32, db32 = finish(ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh))
+    torch.cuda.synchronize()
+    print(f"wgrad B={B} mesh={mesh} Ci={Ci} Co={Co}: split vs fp32 path dW {rel(dW, dW32):.2e} db {rel(db, db32):.2e}", flush=True)
+    if check:
+        xr = x.view(B, T, H, W, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+        gr = g.view(B, T, H, W, Co).permute(0, 4, 1, 2, 3).double().cpu()
+        wr = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        F.conv3d(xr, wr, br, padding=1).backward(gr)
+        ref = wr.grad.permute(0, 2, 3, 4, 1).reshape(Co, K)
+        print(f"   vs fp64: split dW {rel(dW.cpu(), ref):.2e} db {rel(db.cpu(), br.grad):.2e}   exact-fp32 path dW {rel(dW32.cpu(), ref):.2e}", flush=True)
+    for name, flag in (("wgrad split", True), ("wgrad fp32", False)):
+        ops.CONV3_SPLIT = flag
+        ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        print(f"   {name:14s} {ms:8.3f} ms   {2 * M * Co * K / ms / 1e9:7.1f} TF/s (fp32-equivalent, incl. splits)", flush=True)
+    ops.CONV3_SPLIT = True
+
+
+if os.environ.get("CX_WGRAD", "1") == "1":
+    run_wgrad(2, (3, 5, 16), 64, 64, True)
+    run_wgrad(1, (4, 6, 40), 128, 64, True)
+    run_wgrad(1, (2, 9, 24), 64, 128, True)
+    run_wgrad(4, (20, 64, 128), 256, 512, False)
+    run_wgrad(12, (20, 64, 128), 64, 64, False)
+    run_wgrad(12, (20, 16, 32), 256, 256, False)
+if os.environ.get("CX_FWD", "1") != "1":
+    sys.exit(0)
 run(2, (3, 5, 7), 64, 64, True)
 run(1, (4, 6, 40), 128, 128, True)
 run(1, (2, 9, 33), 64, 256, True)

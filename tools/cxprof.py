@@ -22,3 +22,9 @@ ops.conv3x_wprep(w, wz, N, Ci)
 for _ in range(2):
     ops.conv3x(planes, wz, y, M, N, Ci, mesh)
 torch.cuda.synchronize()
+if os.environ.get("CX_MODE") == "wgrad":
+    Co = N
+    g = torch.randn(M, Co, device="cuda")
+    for _ in range(2):
+        ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)
+    torch.cuda.synchronize()
