@@ -267,7 +267,9 @@ int rpb_conv3x(const void* planes, const void* Wz, const float* bias, float* out
  *     split into planes Pt[3][M/8][C][8] (runs of 8 tokens per channel; rpb_split3t; M % 8 == 0, C % 64 == 0); part[rpb_conv3x_wgrad_splits()][Co*27*Ci
  *     + Co] receives per-split partials of dW[co][tap][ci] and db[co] in the layout of rpb_gemm_tn (finish with
  *     rpb_reduce_partials).  Co % 64 == 0, Ci % 64 == 0, innermost mesh dimension % 8 == 0. */
-int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, void* stream);
+int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, int rev, int d0, int d1, int d2, void* stream);
+/*     rev != 0: planes in the token order of the reversed mesh (d2, d1, d0) of x's (d0, d1, d2) mesh -- pass the reversed mesh to
+ *     rpb_conv3x_wgrad and transpose the three tap axes of its result (for meshes whose innermost dimension is not % 8). */
 int rpb_conv3x_wgrad_splits(long M, int Co, int Ci);
 int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co, int Ci, int Hc, int Wc, int Dc, void* stream);
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */

@@ -69,7 +69,7 @@ SIGNATURES = {
     "rpb_split3": (_I, "pp" + "lii" + "p"),
     "rpb_conv3x_wprep": (_I, "pp" + "ii" + "p"),
     "rpb_conv3x": (_I, "pppp" + "liii" + "iii" + "p"),
-    "rpb_split3t": (_I, "pp" + "lii" + "p"),
+    "rpb_split3t": (_I, "pp" + "lii" + "iiii" + "p"),
     "rpb_conv3x_wgrad_splits": (_I, "lii"),
     "rpb_conv3x_wgrad": (_I, "ppp" + "lii" + "iii" + "p"),
     "rpb_chan_blocks": (_I, "il"),

@@ -398,8 +398,11 @@ extern "C" int rpb_conv3x(const void* planes, const void* Wz, const float* bias,
 
 // x [M][ldx] fp32 -> Pt[3][M/8][C][8] bf16 (runs of 8 tokens per channel, channels next: the 16 B operands of 64 channels are
 // 1 KB contiguous, so a wave stages one token group of 64 channels with one coalesced load); block = 64 tokens x 64 channels
+// rev: the planes are written in the token order of the REVERSED mesh (d2, d1, d0) -- a 3x3x3 convolution is symmetric in its
+// three axes, so a mesh whose innermost dimension is not a multiple of 8 (Transolver's 128 x 64 x 20) is handed to the weight
+// gradient kernel with its outermost one innermost, and the taps of the result are transposed back.
 __global__ __launch_bounds__(256) void split3t_kernel(const float* __restrict__ x, uint16_t* __restrict__ Pt, long M, int C,
-                                                      int ldx) {
+                                                      int ldx, int rev, int d0, int d1, int d2) {
     __shared__ uint16_t tl[3][64][72];                                 // [plane][channel][token], rows padded to 144 B
     const int tid = threadIdx.x;
     const long m0 = (long)blockIdx.x * 64;
@@ -408,7 +411,17 @@ __global__ __launch_bounds__(256) void split3t_kernel(const float* __restrict__ 
     for (int j = 0; j < 4; ++j) {                                       // 64 tokens x 16 float4
         const int idx = tid + j * 256, tok = idx >> 4, c4 = (idx & 15) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + tok < M) v = *reinterpret_cast<const f32x4*>(x + (m0 + tok) * ldx + c0 + c4);
+        long src = m0 + tok;
+        if (rev && src < M) {                                           // token (b, i2, i1, i0) of the reversed mesh <- (b, i0, i1, i2)
+            const long n = src;
+            const int i0 = (int)(n % d0);
+            long r = n / d0;
+            const int i1 = (int)(r % d1);
+            r /= d1;
+            const int i2 = (int)(r % d2);
+            src = (((r / d2) * d0 + i0) * d1 + i1) * d2 + i2;
+        }
+        if (m0 + tok < M) v = *reinterpret_cast<const f32x4*>(x + src * ldx + c0 + c4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned h, md, lo;
@@ -428,11 +441,13 @@ __global__ __launch_bounds__(256) void split3t_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, void* stream) {
+extern "C" int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, int rev, int d0, int d1, int d2,
+                           void* stream) {
     RPB_REQUIRE(x && planes_t && M > 0 && M % 8 == 0 && C > 0 && C % 64 == 0 && ldx % 4 == 0 && ldx >= C,
                 "split3t: bad arguments (M=%ld C=%d ldx=%d; M %% 8, C %% 64)", M, C, ldx);
+    if (rev) RPB_REQUIRE(d0 > 0 && d1 > 0 && d2 > 0 && M % ((long)d0 * d1 * d2) == 0, "split3t: bad mesh for the reversed token order");
     hipLaunchKernelGGL(split3t_kernel, dim3((unsigned)((M + 63) / 64), C / 64), dim3(256), 0, (hipStream_t)stream, x,
-                       (uint16_t*)planes_t, M, C, ldx);
+                       (uint16_t*)planes_t, M, C, ldx, rev, d0, d1, d2);
     RPB_CHECK_LAUNCH("split3t");
 }
 

@@ -206,8 +206,9 @@ class Transolver(_ModelBase):
     # ------------------------------------------------------------------ backward
     def _wgrad(self, G, A, M, N, K, ldg=None, lda=None, conv=None):
         """(dW [N,K], db [N]) = (G^T A, colsum G) through the TN GEMM + fp64 partial reduction."""
+        taps_rev = False
         if conv is not None:
-            part = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
+            part, taps_rev = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
             splits = part.shape[0]
         else:
             splits = ops.gemm_tn_splits(M, N, K, False)
@@ -217,6 +218,8 @@ class Transolver(_ModelBase):
         db = torch.empty(N, device=G.device, dtype=torch.float32)
         ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
         ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
+        if taps_rev:
+            dW = ops.conv3_taps_restore(dW, N, K // 27)
         return dW, db
 
     def _ln_bwd(self, x, ln, gy, gadd, M, C):

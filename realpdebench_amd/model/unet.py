@@ -47,8 +47,9 @@ def _reduce(part, rows, L, scale=1.0, f64=False):
 
 def _wgrad(G, A, M, N, K, conv=None, conv_mode=1, ldg=None, lda=None):
     """(dW [N,K], db [N]) = (G^T A(im2col), colsum G) through the TN GEMM + fp64 partial reduction."""
+    taps_rev = False
     if conv is not None and conv_mode == 1:
-        part = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
+        part, taps_rev = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
         splits = part.shape[0]
     else:
         splits = ops.gemm_tn_splits(M, N, K, conv is not None, conv_mode)
@@ -57,6 +58,8 @@ def _wgrad(G, A, M, N, K, conv=None, conv_mode=1, ldg=None, lda=None):
     dW, db = _new(N, K, like=G), _new(N, like=G)
     ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
     ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
+    if taps_rev:
+        dW = ops.conv3_taps_restore(dW, N, K // 27)
     return dW, db
 
 

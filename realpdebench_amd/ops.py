@@ -397,10 +397,12 @@ def conv3x(planes, Wz, out, M, N, Ci, mesh, bias=None, ldo=None):
               label=f"conv3x[N{N},Ci{Ci}]", nbytes=6 * M * Ci * 9 + 4 * M * N, flops=2 * M * N * 27 * Ci)
 
 
-def split3t(x, planes_t, M, C, ldx=None):
-    """planes_t[3][M/8][C][8] (bf16 bit patterns): hi / mid / lo terms of x[M][ldx] in runs of 8 tokens per channel."""
-    _lib.call("rpb_split3t", _p(x), _p(planes_t, torch.int16), M, C, C if ldx is None else ldx, _stream(), label="split3t",
-              nbytes=10 * M * C)
+def split3t(x, planes_t, M, C, ldx=None, rev_mesh=None):
+    """planes_t[3][M/8][C][8] (bf16 bit patterns): hi / mid / lo terms of x[M][ldx] in runs of 8 tokens per channel;
+    ``rev_mesh=(d0, d1, d2)``: in the token order of the reversed mesh (d2, d1, d0)."""
+    d0, d1, d2 = rev_mesh if rev_mesh else (0, 0, 0)
+    _lib.call("rpb_split3t", _p(x), _p(planes_t, torch.int16), M, C, C if ldx is None else ldx, 1 if rev_mesh else 0, d0, d1, d2,
+              _stream(), label="split3t", nbytes=10 * M * C)
 
 
 def conv3x_wgrad_splits(M, Co, Ci):
@@ -416,25 +418,40 @@ def conv3x_wgrad(Gt, Xt, part, M, Co, Ci, mesh):
 CONV3_SPLIT = os.environ.get("RPB_CONV3_EXACT", "0") != "1"
 
 
-def conv3_wgrad_split_ok(Co, Ci, mesh, M):
-    return CONV3_SPLIT and Co % 64 == 0 and Ci % 64 == 0 and mesh[2] % 8 == 0 and mesh[2] >= 16 and M % 8 == 0
+def conv3_wgrad_split_mode(Co, Ci, mesh, M):
+    """0: exact-fp32 kernel; 1: split-bf16 kernel; 2: split-bf16 kernel on the reversed mesh (innermost dimension not % 8)."""
+    if not (CONV3_SPLIT and Co % 64 == 0 and Ci % 64 == 0 and M % 8 == 0):
+        return 0
+    if mesh[2] % 8 == 0 and mesh[2] >= 16:
+        return 1
+    if mesh[0] % 8 == 0 and mesh[0] >= 16:
+        return 2
+    return 0
 
 
 def conv3_wgrad_parts(G, X, M, Co, Ci, mesh, ldg=None, ldx=None):
-    """Per-split partials [splits][Co*27*Ci + Co] of (dW, db) of Conv3d(Ci, Co, 3, padding=1): split-bf16 kernel where the shape
-    allows, else the exact-fp32 LDS-tiled kernel (rpb_gemm_tn conv mode 1)."""
+    """(part, taps_reversed): per-split partials [splits][Co*27*Ci + Co] of (dW, db) of Conv3d(Ci, Co, 3, padding=1): split-bf16
+    kernel where the shape allows, else the exact-fp32 LDS-tiled kernel (rpb_gemm_tn conv mode 1).  ``taps_reversed``: the
+    three tap axes of dW are in (kw, kh, kt) order (see ``conv3_taps_restore``)."""
     K = 27 * Ci
-    if conv3_wgrad_split_ok(Co, Ci, mesh, M):
+    mode = conv3_wgrad_split_mode(Co, Ci, mesh, M)
+    if mode:
         gt = torch.empty(3 * Co * M, dtype=torch.int16, device=G.device)
         xt = torch.empty(3 * Ci * M, dtype=torch.int16, device=G.device)
-        split3t(G, gt, M, Co, ldg)
-        split3t(X, xt, M, Ci, ldx)
+        rev = tuple(mesh) if mode == 2 else None
+        split3t(G, gt, M, Co, ldg, rev_mesh=rev)
+        split3t(X, xt, M, Ci, ldx, rev_mesh=rev)
         part = torch.empty(conv3x_wgrad_splits(M, Co, Ci), Co * K + Co, device=G.device)
-        conv3x_wgrad(gt, xt, part, M, Co, Ci, mesh)
-        return part
+        conv3x_wgrad(gt, xt, part, M, Co, Ci, tuple(mesh)[::-1] if mode == 2 else mesh)
+        return part, mode == 2
     part = torch.empty(gemm_tn_splits(M, Co, K, conv=True), Co * K + Co, device=G.device)
     gemm_tn(G, X, part, M, Co, K, ldg=ldg, lda=ldx, conv=mesh)
-    return part
+    return part, False
+
+
+def conv3_taps_restore(dW, Co, Ci):
+    """dW[Co][27*Ci] computed on the reversed mesh -> the (kt, kh, kw) tap order of the original one."""
+    return dW.view(Co, 3, 3, 3, Ci).permute(0, 3, 2, 1, 4).reshape(Co, 27 * Ci).contiguous()
 
 
 

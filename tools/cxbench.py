@@ -67,9 +67,12 @@ def run_wgrad(B, mesh, Ci, Co, check, iters=3):
         return dW, db
 
     ops.CONV3_SPLIT = True
-    dW, db = finish(ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh))
+    part, rev = ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)
+    dW, db = finish(part)
+    if rev:
+        dW = ops.conv3_taps_restore(dW, Co, Ci)
     ops.CONV3_SPLIT = False
-    dW32, db32 = finish(ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh))
+    dW32, db32 = finish(ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)[0])
     torch.cuda.synchronize()
     print(f"wgrad B={B} mesh={mesh} Ci={Ci} Co={Co}: split vs fp32 path dW {rel(dW, dW32):.2e} db {rel(db, db32):.2e}", flush=True)
     if check:
@@ -98,6 +101,8 @@ if os.environ.get("CX_WGRAD", "1") == "1":
     run_wgrad(2, (3, 5, 16), 64, 64, True)
     run_wgrad(1, (4, 6, 40), 128, 64, True)
     run_wgrad(1, (2, 9, 24), 64, 128, True)
+    run_wgrad(2, (16, 6, 5), 64, 64, True)
+    run_wgrad(4, (128, 64, 20), 256, 512, False)
     run_wgrad(4, (20, 64, 128), 256, 512, False)
     run_wgrad(12, (20, 64, 128), 64, 64, False)
     run_wgrad(12, (20, 16, 32), 256, 256, False)
