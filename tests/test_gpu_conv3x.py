@@ -1,0 +1,99 @@
+"""Split-bf16 3x3x3 convolution kernels (csrc/rpb_conv3x.hip) through the C ABI vs fp64 PyTorch: the bf16 MFMA path must be
+fp32-grade (every operand is hi + mid + lo = its full 24-bit significand, six of the nine cross products are kept), so the
+tolerances are the same 3e-6 the exact-fp32 implicit GEMM is held to (nn.Conv3d(Ci, Co, 3, padding=1) of
+Physics_Attention.py:154-157 / unet.py:196,201 and its autograd)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from realpdebench_amd import ops as o
+    return o
+
+
+def _bf16_to_f64(t):
+    return (t.to(torch.int32) << 16).view(torch.float32).double()
+
+
+def test_split3_reconstructs_every_significand_bit(ops):
+    torch.manual_seed(0)
+    M, C = 1000, 64
+    x = (torch.randn(M, C, device="cuda") * torch.logspace(-6, 6, C, device="cuda")).contiguous()
+    planes = torch.empty(3 * M * C, dtype=torch.int16, device="cuda")
+    ops.split3(x, planes, M, C)
+    p = planes.view(3, M, C)
+    rec = _bf16_to_f64(p[0]) + _bf16_to_f64(p[1]) + _bf16_to_f64(p[2])
+    err = ((rec - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max()
+    assert float(err) < 2.0 ** -23                       # the three bf16 terms carry all 24 significand bits
+    # token-run planes: same numbers in [M/8][C][8] order, also for the reversed mesh order
+    pt = torch.empty_like(planes)
+    ops.split3t(x, pt, M, C)
+    assert torch.equal(pt.view(3, M // 8, C, 8).permute(0, 1, 3, 2).reshape(3, M, C), p)
+    d0, d1, d2 = 10, 5, 20
+    ops.split3t(x, pt, M, C, rev_mesh=(d0, d1, d2))
+    xr = x.view(1, d0, d1, d2, C).permute(0, 3, 2, 1, 4).reshape(M, C).contiguous()
+    ops.split3(xr, planes, M, C)
+    assert torch.equal(pt.view(3, M // 8, C, 8).permute(0, 1, 3, 2).reshape(3, M, C), planes.view(3, M, C))
+
+
+@pytest.mark.parametrize("B,mesh,Ci,Co", [(2, (3, 5, 7), 64, 64), (1, (4, 6, 40), 128, 128), (1, (2, 9, 33), 64, 256),
+                                          (1, (5, 4, 13), 192, 512), (3, (2, 2, 2), 64, 64)])
+def test_conv3x_forward_vs_fp64(ops, B, mesh, Ci, Co):
+    T, H, W = mesh
+    M = B * T * H * W
+    torch.manual_seed(Ci + Co)
+    x = torch.randn(M, Ci, device="cuda")
+    w = torch.randn(Co, 27 * Ci, device="cuda") / (27 * Ci) ** 0.5
+    bias = torch.randn(Co, device="cuda")
+    y = torch.full((M, Co), float("nan"), device="cuda")
+    assert ops.conv3_split_ok(Co, Ci)
+    ops.conv3(x, w, y, M, Co, Ci, mesh, bias=bias)
+    xr = x.view(B, T, H, W, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+    wr = w.view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+    ref = F.conv3d(xr, wr, bias.double().cpu(), padding=1).permute(0, 2, 3, 4, 1).reshape(M, Co)
+    assert rel_l2(y.cpu(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("B,mesh,Ci,Co", [(2, (3, 5, 16), 64, 64), (1, (4, 6, 40), 128, 64), (1, (2, 9, 24), 64, 128),
+                                          (2, (16, 6, 5), 64, 64), (1, (3, 3, 32), 64, 192)])
+def test_conv3x_weight_gradient_vs_fp64(ops, B, mesh, Ci, Co):
+    """Also the mesh whose innermost dimension is not a multiple of 8 (reversed token order, Transolver's 128 x 64 x 20 case)."""
+    T, H, W = mesh
+    M = B * T * H * W
+    K = 27 * Ci
+    torch.manual_seed(Ci * 3 + Co)
+    x, g = torch.randn(M, Ci, device="cuda"), torch.randn(M, Co, device="cuda")
+    assert ops.conv3_wgrad_split_mode(Co, Ci, mesh, M) == (1 if W % 8 == 0 else 2)
+    part, rev = ops.conv3_wgrad_parts(g, x, M, Co, Ci, mesh)
+    dW, db = torch.empty(Co, K, device="cuda"), torch.empty(Co, device="cuda")
+    ops.reduce_partials(part, part.shape[0], Co * K, out_f32=dW.view(-1), row_stride=Co * K + Co)
+    ops.reduce_partials(part, part.shape[0], Co, out_f32=db, row_stride=Co * K + Co, col0=Co * K)
+    if rev:
+        dW = ops.conv3_taps_restore(dW, Co, Ci)
+    xr = x.view(B, T, H, W, Ci).permute(0, 4, 1, 2, 3).double().cpu()
+    gr = g.view(B, T, H, W, Co).permute(0, 4, 1, 2, 3).double().cpu()
+    wr = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xr, wr, br, padding=1).backward(gr)
+    assert rel_l2(dW.cpu(), wr.grad.permute(0, 2, 3, 4, 1).reshape(Co, K)) < 1e-6
+    assert rel_l2(db.cpu(), br.grad) < 1e-6
+
+
+def test_exact_fp32_switch_takes_the_fp32_mfma_path(ops, monkeypatch):
+    """RPB_CONV3_EXACT=1 (ops.CONV3_SPLIT False): the same entry points run the exact-fp32 implicit GEMM."""
+    monkeypatch.setattr(ops, "CONV3_SPLIT", False)
+    assert not ops.conv3_split_ok(64, 64) and ops.conv3_wgrad_split_mode(64, 64, (4, 8, 16), 512) == 0
+    B, (T, H, W), C = 1, (2, 4, 8), 64
+    M = B * T * H * W
+    x, w = torch.randn(M, C, device="cuda"), torch.randn(C, 27 * C, device="cuda") / 40
+    y = torch.empty(M, C, device="cuda")
+    ops.conv3(x, w, y, M, C, C, (T, H, W))
+    ref = F.conv3d(x.view(B, T, H, W, C).permute(0, 4, 1, 2, 3).double().cpu(),
+                   w.view(C, 3, 3, 3, C).permute(0, 4, 1, 2, 3).double().cpu(), padding=1).permute(0, 2, 3, 4, 1).reshape(M, C)
+    assert rel_l2(y.cpu(), ref) < 3e-6
