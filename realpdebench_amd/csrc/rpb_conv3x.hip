@@ -18,6 +18,7 @@
 // 128 token x 64 co tile (4 x 2 MFMA tiles, 128 accumulator registers); waves are spread over co first (WN of them) and the
 // remaining factor KS = 4 / WN splits the 16-channel chunks of a stage, reduced through LDS at the end.
 #include "rpb_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: selects stay in registers (HIP's uint4 struct did not)
@@ -657,6 +658,222 @@ __global__ __launch_bounds__(256, 1) void conv3x_wgrad_kernel(WgxArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------- weight gradient, X rows in an LDS ring
+// The three kh windows of a chunk are the same X rows W tokens apart: window kh of chunk i is window kh - 1 of the chunk W / 32
+// later.  When W % 32 == 0 and 2 W + 32 tokens of the 64 ci fit LDS (W <= 128), the X planes are kept in a ring over the tokens
+// [t0 - W, t0 + W + 32) and every chunk loads only its 32 NEW tokens: 8 instead of 14 staging pieces per thread (the staging
+// path, not the MFMA pipe, bounds the kernel above: 30 % L2 hits, 11 of its 29 ms).  The t / h validity of a group then
+// depends on the window that reads it, so it is applied to the B operand when it is read (v_and with 0 / ~0).
+struct WgrArgs {
+    const uint16_t* Gt;
+    const uint16_t* Xt;
+    float* part;
+    long M;
+    int Co, Ci, T, H, W;
+    int RL, RS;            // ring length in tokens (2 W + 32), row stride in dwords (RL / 2 + 4)
+};
+
+__global__ __launch_bounds__(256, 1) void conv3x_wgrad_ring_kernel(WgrArgs a) {
+    extern __shared__ unsigned ldsw[];
+    unsigned* Gs = ldsw;                                                // [3 planes][64 co][WX_GROW]: 48-token window at t0 - 8
+    unsigned* Xr = ldsw + WX_GS;                                        // [3 planes][64 ci][RS]: the ring
+    int* Vt = reinterpret_cast<int*>(Xr + 3 * 64 * a.RS);               // [2][12]
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int o = wave & 1, c = wave >> 1;
+    int tile = blockIdx.y;
+    const int nob = a.Co >> 6;
+    const int cob = tile % nob;
+    tile /= nob;
+    const int kt = tile % 3, cib = tile / 3;
+    const int n0 = cob * 64, ci0 = cib * 64;
+    const int nsplit = gridDim.x, split = blockIdx.x;
+    const long per = ((a.M + nsplit - 1) / nsplit + WX_KT - 1) / WX_KT * WX_KT;
+    const long mb = (long)split * per;
+    long me = mb + per;
+    if (me > a.M) me = a.M;
+    const long tshift = (long)(kt - 1) * a.H * a.W;
+    const long MG = a.M >> 3;
+    const int RL = a.RL, RS = a.RS;
+
+    f32x16 acc[9], accb = zero16();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = zero16();
+    const bool do_bias = (cib == 0 && kt == 1 && c == 0);
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+    // ---- X group validity per (kh, group of the chunk), carried chunk to chunk by threads 0..11 (as above)
+    int vh = 0, vt = 0, vw = 0;
+    const int vkh = tid >> 2, vgrp = tid & 3;
+    if (tid < 12) {
+        const long q = mb + vgrp * 8 + tshift + (long)(vkh - 1) * a.W + 3L * a.T * a.H * a.W;
+        vw = (int)(q % a.W);
+        const long r = q / a.W;
+        vh = (int)(r % a.H);
+        vt = (int)((r / a.H) % a.T);
+    }
+    auto group_mask = [&](int buf) __attribute__((always_inline)) {
+        if (tid < 12) {
+            const int tt = vt - kt + 1, hh = vh - vkh + 1;
+            Vt[buf * 12 + tid] = (tt >= 0 && tt < a.T && hh >= 0 && hh < a.H) ? -1 : 0;
+            vw += WX_KT;
+            while (vw >= a.W) {
+                vw -= a.W;
+                if (++vh >= a.H) {
+                    vh = 0;
+                    if (++vt >= a.T) vt = 0;
+                }
+            }
+        }
+    };
+
+    // ---- staging pieces per chunk: G 3 planes x 6 groups x 64 co = 1152 (J = 0..4), new X 3 planes x 4 groups x 64 ci = 768
+    // (J = 5..7); lanes = channels: one coalesced 1 KB load per wave and piece
+#define WR_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define WR_DECL(J)                                                                                             \
+    u32x4 sv##J = z4;                                                                                          \
+    bool ok##J = false;                                                                                        \
+    const uint16_t* pp##J;                                                                                     \
+    int qr##J, ds##J, st##J, kd##J; /* token offset rel. to t0, LDS dword offset (G) / row offset (X), 32 C, kind */ \
+    {                                                                                                          \
+        const int idx = tid + J * 256;                                                                         \
+        if (J < 5) {                                                                                           \
+            const int u = idx >> 6, ch = idx & 63, p = u / 6, grp = u - p * 6;                                 \
+            kd##J = idx < 1152 ? 0 : -1;                                                                       \
+            qr##J = grp * 8 - 8;                                                                               \
+            pp##J = a.Gt + ((long)p * MG * a.Co + n0 + ch) * 8 + ((mb + qr##J) >> 3) * (a.Co * 8L);            \
+            ds##J = (p * 64 + ch) * WX_GROW + grp * 4;                                                         \
+            st##J = a.Co * 32;                                                                                 \
+        } else {                                                                                               \
+            const int xi = idx - 5 * 256, u = xi >> 6, ch = xi & 63, p = u >> 2, grp = u & 3;                  \
+            kd##J = 1;                                                                                         \
+            qr##J = (int)(grp * 8 + tshift); /* + the ring offset of the chunk being loaded */                 \
+            pp##J = a.Xt + ((long)p * MG * a.Ci + ci0 + ch) * 8 + ((mb - a.W + qr##J) >> 3) * (a.Ci * 8L);     \
+            ds##J = (p * 64 + ch) * RS + grp * 4;                                                              \
+            st##J = a.Ci * 32;                                                                                 \
+        }                                                                                                      \
+    }
+    WR_FOR8(WR_DECL)
+    // load the pieces of the G window of chunk t0 (J < 5) and of the X tokens [xq, xq + 32) + tshift (J >= 5)
+#define WR_LOAD(J)                                                                                             \
+    {                                                                                                          \
+        const long q = (kd##J == 1 ? xq : t0) + qr##J;                                                         \
+        const bool okp = kd##J >= 0 && q >= 0 && q + 8 <= a.M && (kd##J == 1 ? xon : gon);                     \
+        sv##J = *reinterpret_cast<const u32x4*>(okp ? pp##J : a.Gt);                                           \
+        ok##J = okp;                                                                                           \
+        if (kd##J == 1 ? xon : gon) pp##J += st##J;                                                            \
+    }
+#define WR_STORE(J)                                                                                            \
+    if (kd##J == 0 && gon) *reinterpret_cast<u32x4*>(Gs + ds##J) = ok##J ? sv##J : z4;                         \
+    else if (kd##J == 1 && xon) *reinterpret_cast<u32x4*>(Xr + ds##J + (xpos >> 1)) = ok##J ? sv##J : z4;
+    auto stage_load = [&](long t0, long xq, bool gon, bool xon) __attribute__((always_inline)) { WR_FOR8(WR_LOAD) };
+    auto stage_store = [&](int xpos, bool gon, bool xon) __attribute__((always_inline)) { WR_FOR8(WR_STORE) };
+
+    int wg = (int)((mb + 8 * half) % a.W);
+    auto kstep = [&](int ks, int vb, int xp0, int xp1, int xp2) __attribute__((always_inline)) {
+        int wpos = wg + ks * 16;
+        while (wpos >= a.W) wpos -= a.W;
+        const unsigned m0 = wpos + 8 == a.W ? 0x0000FFFFu : 0xFFFFFFFFu;
+        const unsigned m2 = wpos == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;
+        u32x4 ga[3], g0[3], g2[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned* gr = Gs + (p * 64 + o * 32 + col) * WX_GROW + 4 + ks * 8 + half * 4;
+            const u32x4 x = *reinterpret_cast<const u32x4*>(gr);
+            const unsigned xm = gr[-1], xn = gr[4];
+            ga[p] = x;
+            g0[p].x = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+            g0[p].y = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            g0[p].z = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+            g0[p].w = __builtin_amdgcn_alignbit(xn, x.w, 16) & m0;
+            g2[p].x = __builtin_amdgcn_alignbit(x.x, xm, 16) & m2;
+            g2[p].y = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+            g2[p].z = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            g2[p].w = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) accb = mfma_bf16(__builtin_bit_cast(bf16x8, ga[p]), __builtin_bit_cast(bf16x8, ones), accb);
+        }
+        u32x4 xb[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int xp = kh == 0 ? xp0 : (kh == 1 ? xp1 : xp2);      // ring position (tokens) of window kh
+            const unsigned vm = (unsigned)Vt[vb * 12 + kh * 4 + ks * 2 + half];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                u32x4 x = *reinterpret_cast<const u32x4*>(Xr + (p * 64 + c * 32 + col) * RS + (xp >> 1) + ks * 8 + half * 4);
+                x.x &= vm; x.y &= vm; x.z &= vm; x.w &= vm;
+                xb[kh][p] = x;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#define WX_MF(PA, PB)                                                                                                             \
+    acc[kh * 3 + 0] = mfma_bf16(__builtin_bit_cast(bf16x8, g0[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 0]);    \
+    acc[kh * 3 + 1] = mfma_bf16(__builtin_bit_cast(bf16x8, ga[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 1]);    \
+    acc[kh * 3 + 2] = mfma_bf16(__builtin_bit_cast(bf16x8, g2[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 2]);
+            WX_MF(2, 0) WX_MF(0, 2) WX_MF(1, 1) WX_MF(1, 0) WX_MF(0, 1) WX_MF(0, 0)
+#undef WX_MF
+        }
+    };
+
+    // ---- prologue: validity of chunks 0 / 1, ring filled with the tokens [mb - W, mb + W + 32), G window of chunk 0
+    group_mask(0);
+    group_mask(1);
+    const int nfill = RL / WX_KT;
+    for (int f = 0; f < nfill; ++f) {
+        stage_load(mb, mb - a.W + (long)f * WX_KT, f == 0, true);
+        stage_store(f * WX_KT, f == 0, true);
+    }
+    __syncthreads();
+    // ring position of token u: (u - mb + W) mod RL; the chunk's windows start at xw + kh * W, the next new tokens go to xn
+    int xw = 0, xn = 0;                                                 // (t0 - mb) mod RL ; (t0 - mb + 2 W + 32) mod RL == xw
+    int it = 0;
+    for (long t0 = mb; t0 < me; t0 += WX_KT, ++it) {
+        const bool more = t0 + WX_KT < me;
+        // new X tokens of the NEXT chunk: [t0 + 32 + W, + 32); its G window starts at t0 + 32 - 8
+        if (more) stage_load(t0 + WX_KT, t0 + WX_KT + a.W, true, true);
+        __builtin_amdgcn_sched_barrier(0);
+        int xp1 = xw + a.W, xp2 = xw + 2 * a.W;
+        if (xp1 >= RL) xp1 -= RL;
+        if (xp2 >= RL) xp2 -= RL;
+        kstep(0, it & 1, xw, xp1, xp2);
+        kstep(1, it & 1, xw, xp1, xp2);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                // everyone is done with G, window 0 and the validity table
+        // the next chunk's new tokens overwrite this chunk's window 0: ring slot (xw + 2 W + 32) mod RL == xw
+        if (more) stage_store(xw, true, true);
+        group_mask(it & 1);                                             // for chunk it + 2
+        xw += WX_KT;
+        if (xw >= RL) xw -= RL;
+        wg += WX_KT;
+        while (wg >= a.W) wg -= a.W;
+        __syncthreads();
+    }
+    (void)xn;
+#undef WR_STORE
+#undef WR_LOAD
+#undef WR_DECL
+#undef WR_FOR8
+    const long K = 27L * a.Ci;
+    float* part = a.part + (long)split * ((long)a.Co * K + a.Co);
+#pragma unroll
+    for (int k9 = 0; k9 < 9; ++k9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + o * 32 + mfma_row(lane, r);
+            const long k = ((long)(kt * 9 + k9)) * a.Ci + ci0 + c * 32 + col;
+            part[(long)n * K + k] = acc[k9][r];
+        }
+    if (do_bias && col == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(long)a.Co * K + n0 + o * 32 + mfma_row(lane, r)] = accb[r];
+    }
+}
+
 static int conv3x_wgrad_nsplit(long M, int Co, int Ci) {
     // splits: a multiple of 8 (XCD affinity, see above) that makes workgroups per CU integral, >= 1024 tokens per split
     const long tiles = (long)(Co / 64) * (Ci / 64) * 3, ncu = rpb_num_cus();
@@ -687,6 +904,14 @@ extern "C" int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, lon
     RPB_REQUIRE(lds <= 160 * 1024, "conv3x_wgrad: LDS");
     (void)hipFuncSetAttribute((const void*)conv3x_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int sp = conv3x_wgrad_nsplit(M, Co, Ci);
+    const int RL = 2 * Dc + WX_KT, RS = RL / 2 + 4;
+    const size_t lds_ring = ((size_t)WX_GS + 3 * 64 * RS) * 4 + 2 * 12 * 4;
+    if (Dc % 32 == 0 && lds_ring <= 160 * 1024 && !getenv("RPB_WGRAD_NORING")) {      // X rows in an LDS ring: each loaded once
+        WgrArgs r{(const uint16_t*)Gt, (const uint16_t*)Xt, part, M, Co, Ci, Hc, Wc, Dc, RL, RS};
+        (void)hipFuncSetAttribute((const void*)conv3x_wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ring);
+        hipLaunchKernelGGL(conv3x_wgrad_ring_kernel, dim3(sp, (Co / 64) * (Ci / 64) * 3), dim3(256), lds_ring, (hipStream_t)stream, r);
+        RPB_CHECK_LAUNCH("conv3x_wgrad");
+    }
     hipLaunchKernelGGL(conv3x_wgrad_kernel, dim3(sp, (Co / 64) * (Ci / 64) * 3), dim3(256), lds, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("conv3x_wgrad");
 }
