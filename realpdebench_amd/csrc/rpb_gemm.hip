@@ -880,6 +880,60 @@ static bool tn_small_ok(int N, int K, int ldg, int lda) {
     return K <= 384 && (long)N * K <= 49152;
 }
 
+// ---------------------------------------------------------------------------------- weight gradient of a lift layer (K <= 4)
+//   dW[n][k] = sum_tok G[tok][n] * A[tok][k],  db[n] = sum_tok G[tok][n]   for K <= 4 input features (coordinates / channels of
+// the first nn.Linear): a pure stream over G (the MFMA kernels above spent 1.75 ms on 1.3 GB: one 32-wide k tile of zeros).
+// Thread = 4 consecutive columns, workgroup = TKT_ROWS row lanes x N/4 column groups; partial layout of rpb_gemm_tn.
+struct TnTinyArgs {
+    const float* G;
+    const float* A;
+    float* part;      // [gridDim.x][N*K + N]
+    long M;
+    int N, K, ldg, lda;
+};
+
+__global__ __launch_bounds__(256) void tn_tiny_kernel(TnTinyArgs a) {
+    extern __shared__ float red[];                                      // [nsub][(K + 1) * N]
+    const int n4n = a.N >> 2;
+    const int c4 = threadIdx.x % n4n, sub = threadIdx.x / n4n, nsub = blockDim.x / n4n;
+    f32x4 acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sub < nsub)
+        for (long m = (long)blockIdx.x * nsub + sub; m < a.M; m += (long)gridDim.x * nsub) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.G + m * a.ldg + 4 * c4);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a.A + m * a.lda);      // lda % 4 == 0, columns >= K are padding
+            acc[0] += g * x[0];
+            acc[1] += g * x[1];
+            acc[2] += g * x[2];
+            acc[3] += g * x[3];
+            acc[4] += g;
+        }
+    const int L = (a.K + 1) * a.N;
+    if (sub < nsub) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (k < a.K || k == 4) {
+                const int slot = k == 4 ? a.K : k;
+                *reinterpret_cast<f32x4*>(red + sub * L + slot * a.N + 4 * c4) = acc[k];
+            }
+    }
+    __syncthreads();
+    float* prow = a.part + (long)blockIdx.x * ((long)a.N * a.K + a.N);
+    for (int idx = threadIdx.x; idx < L; idx += blockDim.x) {
+        float sacc = 0.f;
+        for (int q = 0; q < nsub; ++q) sacc += red[q * L + idx];
+        const int slot = idx / a.N, n = idx - slot * a.N;
+        if (slot < a.K) prow[(long)n * a.K + slot] = sacc;
+        else prow[(long)a.N * a.K + n] = sacc;
+    }
+}
+
+static bool tn_tiny_ok(int N, int K, int ldg, int lda) {
+    return K <= 4 && N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0 && ldg % 4 == 0 && lda % 4 == 0 && lda >= 4;
+}
+static int tn_tiny_splits() { return rpb_num_cus() * 4; }
+
 static int tn_small_splits(long M, int N, int K) {
     const int bk = (N == 64) ? 128 : 64;
     return balanced_splits(K / bk, 3, (M + 1023) / 1024, 1024);
@@ -895,6 +949,7 @@ static int gemm_tn_wn(int N) { return N > 128 ? 4 : (N > 64 ? 2 : 1); }      // 
 extern "C" int rpb_gemm_tn_splits(long M, int N, int K, int conv) {
     if (conv == 1 && N % 64 == 0 && K % 27 == 0 && (K / 27) % 64 == 0) return conv3_wgrad_splits(M, N, K / 27);
     if (conv == 0 && tn_small_ok(N, K, 4, 4)) return tn_small_splits(M, N, K);
+    if (conv == 0 && K <= 4 && N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0) return tn_tiny_splits();
     const int wk2 = 64 * gemm_tn_nti(K, conv);
     const int bn = 64 * gemm_tn_wn(N);
     const long tiles = (long)((N + bn - 1) / bn) * ((K + wk2 - 1) / wk2);
@@ -920,6 +975,13 @@ extern "C" int rpb_gemm_tn(const float* G, const float* A, float* part, long M, 
         const int sp = conv3_wgrad_splits(M, N, K / 27);
         hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((N / 64) * (K / 27 / 64) * 3, sp), dim3(256), 0, (hipStream_t)stream, c);
         RPB_CHECK_LAUNCH("gemm_tn(conv3)");
+    }
+    if (conv == 0 && K <= 4 && N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0) {      // lift layers: stream G once
+        RPB_REQUIRE(tn_tiny_ok(N, K, ldg, lda), "gemm_tn: K=%d needs ldg %% 4 == 0 and lda %% 4 == 0 (lda >= 4, zero padding)", K);
+        TnTinyArgs t{G, A, part, M, N, K, ldg, lda};
+        const int nsub = 256 / (N / 4);
+        hipLaunchKernelGGL(tn_tiny_kernel, dim3(tn_tiny_splits()), dim3(256), (size_t)nsub * (K + 1) * N * 4, (hipStream_t)stream, t);
+        RPB_CHECK_LAUNCH("gemm_tn(tiny)");
     }
     if (conv == 0 && tn_small_ok(N, K, 4, 4)) {         // LDS-tiled projection weight gradient: G and A are read once
         RPB_REQUIRE(ldg % 4 == 0 && lda % 4 == 0, "gemm_tn: leading dimensions %d / %d must be multiples of 4 for N=%d K=%d", ldg, lda, N, K);
