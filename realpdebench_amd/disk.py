@@ -1,0 +1,320 @@
+"""On-disk trajectory reader: the reference's "V2" Hugging Face Arrow layout -> device-resident,
+normalised ``(input[B,T_in,H,W,C_in], target[B,T_out,H,W,C_out])`` batches, sharded over data-parallel ranks, with no Python
+worker processes.
+
+Reference behaviour mirrored here (file:line in /root/reference/realpdebench):
+  * layout and schema -- utils/convert_hdf5_to_hf.py:20-51: ``{root}/{scenario}/hf_dataset/{real|numerical}/`` written by
+    ``datasets.save_to_disk`` (Arrow IPC stream files listed in ``state.json``), one row per COMPLETE trajectory with
+    ``sim_id``, ``u`` / ``v`` / ``p`` as raw float32 bytes of shape ``(shape_t, shape_h, shape_w)``;
+    ``{split}_index_{type}.json`` = list of ``{"sim_id", "time_id"}`` in sample order;
+  * sample semantics -- data/fluid_hf_dataset.py:258-335: ``data[time_id : time_id + horizon, ::sub_s, ::sub_s]`` with
+    ``horizon = in_step + out_step * N_autoregressive``, channels (u, v, p), p = 0 for real data and with probability
+    ``mask_prob`` (one ``random.random()`` per sample) for numerical data, split at ``in_step``; ControlledCylinder appends the
+    numbers parsed from ``sim_id`` as constant input channels; test-mode and autoregressive filters of :208-246;
+  * normaliser statistics -- data/data_normalizer.py:64-95 (mean of per-sample means, mean of per-batch biased variances).
+
+MI355X-first design instead of ``torch.utils.data.DataLoader(num_workers=10)`` + ``datasets`` row decoding + ``np.stack``:
+the Arrow files are memory-mapped (``pyarrow``; a trajectory is a zero-copy float32 view), a sample's time window is ONE
+contiguous slab per channel at full resolution, so the host only memcpy's slabs into a pinned planar staging buffer (a single
+background thread; numpy releases the GIL) and everything else -- spatial sub-sampling, channel interleave to channels-last,
+pressure masking, parameter channels, the per-channel ``(x - mean) / std`` of data_normalizer.py:50-55, the input / target split --
+happens in one HBM pass of ``rpb_window_pack`` on a side HIP stream while the previous step computes.
+"""
+import json
+import os
+import queue
+import random
+import re
+import threading
+
+import numpy as np
+import torch
+
+SCENARIOS = {   # data/fluid_hf_dataset.py:341-349, 409-417, 477-485, 545-553
+    "cylinder": dict(file_name_pattern=r"(\d+)\.h5", condition_on_para=False),
+    "fsi": dict(file_name_pattern=r"(\d+)_([\d\.]+)_", condition_on_para=False),
+    "controlled_cylinder": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=True),
+    "foil": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=False),
+}
+
+
+class ArrowTrajectories:
+    """Zero-copy view of a ``datasets.save_to_disk`` directory: ``state.json`` lists Arrow IPC stream files; binary cells are
+    exposed as numpy views into the memory map (no ``datasets`` import, no row materialisation)."""
+
+    def __init__(self, path):
+        import pyarrow as pa
+        state_file = os.path.join(path, "state.json")
+        if not os.path.exists(state_file):
+            raise FileNotFoundError(f"HF Arrow trajectories not found: {path} (no state.json; the reference writes it with "
+                                    "`python -m realpdebench.utils.convert_hdf5_to_hf`)")
+        with open(state_file) as fh:
+            files = [d["filename"] for d in json.load(fh)["_data_files"]]
+        self._maps, self._tables = [], []
+        self._where = {}                                    # sim_id -> (table index, row)
+        for f in files:
+            mm = pa.memory_map(os.path.join(path, f), "r")
+            table = pa.ipc.open_stream(mm).read_all()
+            self._maps.append(mm)
+            self._tables.append(table)
+            ti = len(self._tables) - 1
+            for r, sid in enumerate(table.column("sim_id").to_pylist()):
+                self._where[sid] = (ti, r)
+
+    def __len__(self):
+        return len(self._where)
+
+    def sim_ids(self):
+        return list(self._where)
+
+    def has(self, name):
+        return name in self._tables[0].column_names
+
+    def _cell(self, sim_id, name):
+        ti, r = self._where[sim_id]
+        col = self._tables[ti].column(name)
+        for chunk in col.chunks:
+            if r < len(chunk):
+                return chunk[r]
+            r -= len(chunk)
+        raise IndexError(sim_id)
+
+    def shape(self, sim_id):
+        return tuple(int(self._cell(sim_id, k).as_py()) for k in ("shape_t", "shape_h", "shape_w"))
+
+    def array(self, sim_id, name):
+        """float32 ``[shape_t, shape_h, shape_w]`` view of a binary cell (read-only, backed by the memory map)."""
+        buf = self._cell(sim_id, name).as_buffer()
+        return np.frombuffer(buf, dtype=np.float32).reshape(self.shape(sim_id))
+
+
+class FluidWindows:
+    """The sample list of ``FluidHFDataset`` (same constructor vocabulary, same ordering and filters) exposing each sample as
+    contiguous full-resolution slabs; ``__getitem__`` reproduces the reference's CPU tensors exactly (a plain Dataset)."""
+
+    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.5, in_step=20, out_step=20,
+                 N_autoregressive=1, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2, noise_scale=0.0, **_ignored):
+        if dataset_name not in SCENARIOS:
+            raise ValueError(f"dataset_name={dataset_name!r}: fluid scenarios are {sorted(SCENARIOS)}")
+        spec = SCENARIOS[dataset_name]
+        self.dataset_name, self.dataset_type, self.mode, self.test_mode = dataset_name, dataset_type, mode, test_mode
+        self.file_name_pattern, self.condition_on_para = spec["file_name_pattern"], spec["condition_on_para"]
+        self.in_step = int(in_step)
+        self.out_step = int(out_step) * int(N_autoregressive)            # fluid_hf_dataset.py:109
+        self.N_autoregressive = int(N_autoregressive)
+        self.horizon = self.in_step + self.out_step
+        self.n_sim_frame = int(n_sim_frame)
+        self.sub_s = int(sub_s_real if dataset_type == "real" else sub_s_numerical)
+        self.mask_prob = float(mask_prob)
+        if noise_scale:
+            raise NotImplementedError("noise augmentation (fluid_hf_dataset.py:308-324) draws from torch's CPU generator; "
+                                      "apply it on the device batch instead")
+        self.dataset_dir = os.path.join(dataset_root, dataset_name)
+        hf_dir = os.path.join(self.dataset_dir, "hf_dataset")
+        index_path = os.path.join(hf_dir, f"{mode}_index_{dataset_type}.json")
+        if not os.path.exists(index_path):
+            raise FileNotFoundError(f"Index file not found: {index_path}")
+        self.store = ArrowTrajectories(os.path.join(hf_dir, dataset_type))
+        with open(index_path) as fh:
+            self._indices = json.load(fh)
+        if mode in ("val", "test") and test_mode != "all":
+            self._apply_test_mode_filter()
+        if mode in ("val", "test") and self.N_autoregressive > 1:       # fluid_hf_dataset.py:238-246
+            self._indices = [e for e in self._indices if e["time_id"] + self.horizon < self.n_sim_frame]
+        self.has_p = dataset_type != "real" and self.store.has("p")
+        self.n_para = re.compile(self.file_name_pattern).groups if self.condition_on_para else 0
+
+    def _apply_test_mode_filter(self):                                    # fluid_hf_dataset.py:182-236
+        def load(kind):
+            p = os.path.join(self.dataset_dir, f"{kind}_{self.dataset_type}.json")
+            if not os.path.exists(p):
+                raise FileNotFoundError(f"Missing JSON test params file: {p}")
+            with open(p) as fh:
+                return set(json.load(fh).keys())
+        ind, outd, remain = load("in_dist_test_params"), load("out_dist_test_params"), load("remain_params")
+        target = {"in_dist": ind, "out_dist": outd, "seen": remain, "unseen": ind | outd}.get(self.test_mode)
+        if target is None:
+            raise ValueError(f"Invalid test_mode: {self.test_mode}")
+        self._indices = [e for e in self._indices if e["sim_id"] in target]
+
+    def __len__(self):
+        return len(self._indices)
+
+    def parameters(self, sim_id):
+        """The numbers the reference appends as constant input channels (ControlledCylinder), else ``[]``."""
+        if not self.condition_on_para:
+            return []
+        return [float(g) for g in re.match(self.file_name_pattern, sim_id).groups()]
+
+    def full_shape(self, idx=0):
+        return self.store.shape(self._indices[idx]["sim_id"])
+
+    def out_shape(self, idx=0):
+        _, h, w = self.full_shape(idx)
+        return (len(range(0, h, self.sub_s)), len(range(0, w, self.sub_s)))
+
+    def slabs(self, idx):
+        """``(u, v, p or None, parameters)``: contiguous float32 views ``[horizon, H_full, W_full]`` of sample ``idx``.
+        The pressure decision consumes one ``random.random()`` for numerical data exactly like fluid_hf_dataset.py:290-296."""
+        e = self._indices[idx]
+        sid, t0 = e["sim_id"], int(e["time_id"])
+        u = self.store.array(sid, "u")[t0:t0 + self.horizon]
+        v = self.store.array(sid, "v")[t0:t0 + self.horizon]
+        p = None
+        if self.dataset_type != "real":
+            if not (random.random() < self.mask_prob):
+                p = self.store.array(sid, "p")[t0:t0 + self.horizon]
+        return u, v, p, self.parameters(sid)
+
+    def __getitem__(self, idx):
+        u, v, p, para = self.slabs(idx)
+        s = self.sub_s
+        u, v = u[:, ::s, ::s], v[:, ::s, ::s]
+        p = np.zeros_like(u) if p is None else p[:, ::s, ::s]
+        data = np.stack([u, v, p], axis=-1)
+        inp, out = torch.tensor(data[:self.in_step]), torch.tensor(data[self.in_step:])
+        if para:
+            inp = torch.cat([inp, torch.stack([x * torch.ones_like(inp[..., 0]) for x in para], dim=-1)], dim=-1)
+        return inp, out
+
+
+def compute_mean_std(windows, batch_size=512):
+    """GaussianNormalizer.compute_mean_std (data_normalizer.py:64-95) on the sample list, same batching and formulas."""
+    n, mi, mt, vi, vt = 0, 0.0, 0.0, 0.0, 0.0
+    for b0 in range(0, len(windows), batch_size):
+        items = [windows[i] for i in range(b0, min(b0 + batch_size, len(windows)))]
+        x, y = torch.stack([a for a, _ in items]), torch.stack([c for _, c in items])
+        b, c1, c2 = x.size(0), x.size(-1), y.size(-1)
+        x, y = x.view(b, -1, c1), y.view(b, -1, c2)
+        mi = mi + x.mean(dim=1).sum(0)
+        vi = vi + x.var(dim=(0, 1), unbiased=False) * b
+        mt = mt + y.mean(dim=1).sum(0)
+        vt = vt + y.var(dim=(0, 1), unbiased=False) * b
+        n += b
+    return mi / n, mt / n, (vi / n) ** 0.5, (vt / n) ** 0.5
+
+
+def batch_plan(n, batch, world, rank, shuffle, seed, epoch, drop_last=True):
+    """Sample indices of every batch of ``rank`` for one epoch: one seeded permutation per epoch, identical on all ranks;
+    rank r owns rows [r * batch, (r + 1) * batch) of each global batch of world * batch samples (replaces
+    DataLoader(shuffle=True) of train.py:269 and a DistributedSampler under data parallelism)."""
+    order = list(range(n))
+    if shuffle:
+        random.Random(seed * 1000003 + epoch).shuffle(order)
+    gb = batch * world
+    last = n - n % gb if drop_last else n
+    for g0 in range(0, last, gb):
+        mine = order[g0 + rank * batch: g0 + (rank + 1) * batch]
+        if mine:
+            yield mine
+
+
+class DiskBatchLoader:
+    """Iterator of device-resident, normalised ``(input, target)`` batches read from a ``FluidWindows`` sample list.
+
+    One background thread fills a ring of pinned planar staging buffers (``[B][3][horizon][H_full][W_full]``: three memcpy's per
+    sample); the consumer side enqueues the H2D copy and ``rpb_window_pack`` on a side stream and makes the compute stream wait
+    on that batch's event only -- the interface of ``DevicePrefetcher`` with the disk behind it.  Under data parallelism every
+    rank walks the same seeded permutation and takes its contiguous share of each global batch (no sampler processes).
+    ``stats`` = ``(mean_in, mean_tgt, std_in, std_tgt)`` or ``None`` (no normalisation); zero std is replaced by 1
+    (data_normalizer.py:47-48)."""
+
+    def __init__(self, windows, batch_size, device, stats=None, shuffle=True, seed=0, rank=0, world=1, drop_last=True,
+                 depth=2, epochs=None):
+        from . import ops
+        self.ops = ops
+        self.w, self.B, self.device = windows, int(batch_size), torch.device(device)
+        self.rank, self.world, self.shuffle, self.seed = rank, world, shuffle, seed
+        self.drop_last, self.epochs = drop_last, epochs
+        T_full, self.Hf, self.Wf = windows.full_shape()
+        self.H, self.W = windows.out_shape()
+        self.c_in, self.c_out = 3 + windows.n_para, 3
+        self.horizon, self.in_step = windows.horizon, windows.in_step
+        f = dict(device=self.device, dtype=torch.float32)
+        if stats is not None:
+            mi, mt, si, st = (torch.as_tensor(t, dtype=torch.float32).flatten() for t in stats)
+            fix = lambda s: torch.where(s == 0, torch.ones_like(s), s)
+            self.stats = (mi[:self.c_in].to(self.device), mt[:self.c_out].to(self.device),
+                          fix(si[:self.c_in]).to(self.device), fix(st[:self.c_out]).to(self.device))
+        else:
+            self.stats = (torch.zeros(self.c_in, **f), torch.zeros(self.c_out, **f), torch.ones(self.c_in, **f),
+                          torch.ones(self.c_out, **f))
+        self.stream = torch.cuda.Stream(self.device)
+        self._slots = [dict(host=torch.empty(self.B, 3, self.horizon, self.Hf, self.Wf, dtype=torch.float32).pin_memory(),
+                            flags=torch.zeros(self.B, 4 + max(windows.n_para, 1), dtype=torch.float32).pin_memory(),
+                            dev=torch.empty(self.B, 3, self.horizon, self.Hf, self.Wf, **f),
+                            dflags=torch.empty(self.B, 4 + max(windows.n_para, 1), **f), free=threading.Event())
+                       for _ in range(depth)]
+        for s in self._slots:
+            s["free"].set()
+        self._q = queue.Queue(maxsize=depth)
+        self._stop = False
+        self._thread = threading.Thread(target=self._producer, daemon=True)
+        self._thread.start()
+
+    def _batches(self):
+        epoch = 0
+        while self.epochs is None or epoch < self.epochs:
+            yield from batch_plan(len(self.w), self.B, self.world, self.rank, self.shuffle, self.seed, epoch, self.drop_last)
+            epoch += 1
+
+    def _producer(self):
+        try:
+            slot_i = 0
+            for idxs in self._batches():
+                slot = self._slots[slot_i % len(self._slots)]
+                slot_i += 1
+                slot["free"].wait()                                      # the consumer has enqueued this slot's previous copy ...
+                if self._stop:
+                    return
+                slot["free"].clear()
+                if slot.get("busy") is not None:
+                    slot["busy"].synchronize()                           # ... and that copy has left the pinned buffer
+                host, flags = slot["host"].numpy(), slot["flags"].numpy()
+                flags[:] = 0.0
+                for b, i in enumerate(idxs):
+                    u, v, p, para = self.w.slabs(i)
+                    np.copyto(host[b, 0], u)
+                    np.copyto(host[b, 1], v)
+                    if p is not None:
+                        np.copyto(host[b, 2], p)
+                        flags[b, 2] = 1.0
+                    flags[b, 0] = flags[b, 1] = 1.0
+                    for k, x in enumerate(para):
+                        flags[b, 4 + k] = x
+                self._q.put((slot, len(idxs)))
+            self._q.put(None)
+        except BaseException as exc:                                     # surface reader errors in the training loop
+            self._q.put(exc)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        slot, nb = item
+        f = dict(device=self.device, dtype=torch.float32)
+        inp = torch.empty(nb, self.in_step, self.H, self.W, self.c_in, **f)
+        tgt = torch.empty(nb, self.horizon - self.in_step, self.H, self.W, self.c_out, **f)
+        with torch.cuda.stream(self.stream):
+            slot["dev"].copy_(slot["host"], non_blocking=True)
+            slot["dflags"].copy_(slot["flags"], non_blocking=True)
+            self.ops.window_pack(slot["dev"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf, self.Wf,
+                                 self.w.sub_s, self.w.n_para, *self.stats)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        slot["busy"] = done
+        slot["free"].set()
+        torch.cuda.current_stream(self.device).wait_event(done)
+        inp.record_stream(torch.cuda.current_stream(self.device))
+        tgt.record_stream(torch.cuda.current_stream(self.device))
+        return inp, tgt
+
+    def close(self):
+        self._stop = True
+        for s in self._slots:
+            s["free"].set()

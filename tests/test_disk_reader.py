@@ -1,0 +1,122 @@
+"""On-disk reader against windows produced by the IMPORTED reference datasets
+(tests/golden/make_golden_disk.py -> tests/golden/disk_small/ + disk_small.npz): sample order, filters, slicing,
+sub-sampling, pressure masking (same ``random`` stream), parameter channels and normaliser statistics on the host side
+(CPU tests); the device batch path -- pinned slabs -> rpb_window_pack -- bit-exactly on the GPU."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from realpdebench_amd.disk import ArrowTrajectories, FluidWindows, batch_plan, compute_mean_std
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "golden", "disk_small")
+CASES = ["cyl_num_train", "cyl_num_train_masked", "cyl_real_val", "cyl_num_test_ar", "cyl_real_test_unseen", "ctl_num_train"]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "disk_small.npz"))
+
+
+def _windows(gold, key):
+    return FluidWindows(dataset_root=ROOT, **json.loads(str(gold[key + "/kw"])))
+
+
+def test_arrow_store_is_a_zero_copy_view():
+    st = ArrowTrajectories(os.path.join(ROOT, "cylinder", "hf_dataset", "numerical"))
+    assert sorted(st.sim_ids()) == ["100.h5", "200.h5", "300.h5"] and st.has("p")
+    u = st.array("200.h5", "u")
+    assert u.shape == st.shape("200.h5") == (14, 6, 8) and u.dtype == np.float32
+    assert not u.flags.writeable and not u.flags.owndata          # backed by the memory map, not a copy
+    assert u[3:9].flags.c_contiguous                               # a time window is one contiguous slab
+
+
+@pytest.mark.parametrize("key", CASES)
+def test_samples_match_the_reference_dataset(gold, key):
+    w = _windows(gold, key)
+    assert len(w) == int(gold[key + "/n"])
+    random.seed(1234)                                              # the reference draws one random.random() per numerical sample
+    items = [w[i] for i in range(len(w))]
+    assert torch.equal(torch.stack([a for a, _ in items]), torch.from_numpy(gold[key + "/inp"]))
+    assert torch.equal(torch.stack([b for _, b in items]), torch.from_numpy(gold[key + "/tgt"]))
+
+
+def test_normaliser_statistics_match_the_reference(gold):
+    w = _windows(gold, "cyl_num_train")
+    mi, mt, si, st = compute_mean_std(w, batch_size=4)
+    for got, key in ((mi, "mean_in"), (mt, "mean_tgt"), (si, "std_in"), (st, "std_tgt")):
+        # same formulas and batching; torch's CPU reductions may order the sums differently on another host: last-bit tolerance
+        assert torch.allclose(got, torch.from_numpy(gold["stats/" + key]), rtol=2e-6, atol=1e-7), key
+
+
+def test_missing_files_fail_loudly(gold):
+    with pytest.raises(FileNotFoundError):
+        FluidWindows("cylinder", ROOT, "numerical", "nosuchsplit")
+    with pytest.raises(ValueError):
+        FluidWindows("combustion", ROOT, "numerical", "train")
+    with pytest.raises(ValueError):
+        FluidWindows("cylinder", ROOT, "real", "test", test_mode="bogus")
+
+
+def test_rank_shards_partition_every_global_batch():
+    n, B, world = 37, 4, 3
+    for epoch in (0, 1):
+        per_rank = [list(batch_plan(n, B, world, r, True, 5, epoch)) for r in range(world)]
+        assert len({len(p) for p in per_rank}) == 1                  # every rank takes the same number of steps
+        seen = [i for p in per_rank for b in p for i in b]
+        assert len(seen) == len(set(seen)) == (n // (B * world)) * B * world
+        for step in range(len(per_rank[0])):                         # ranks' batches of one step are disjoint slices of one global batch
+            assert all(len(per_rank[r][step]) == B for r in range(world))
+    assert list(batch_plan(n, B, world, 0, True, 5, 0)) != list(batch_plan(n, B, world, 0, True, 5, 1))   # reshuffled per epoch
+    assert list(batch_plan(6, 4, 1, 0, False, 0, 0, drop_last=False)) == [[0, 1, 2, 3], [4, 5]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", CASES)
+def test_device_batches_equal_reference_windows(gold, key):
+    from realpdebench_amd.disk import DiskBatchLoader
+    w = _windows(gold, key)
+    B = 2
+    random.seed(1234)                                              # single producer thread, samples in index order: same mask stream
+    loader = DiskBatchLoader(w, B, "cuda", stats=None, shuffle=False, drop_last=False, epochs=1)
+    inps, tgts = zip(*[(a.cpu(), b.cpu()) for a, b in loader])
+    assert torch.equal(torch.cat(inps), torch.from_numpy(gold[key + "/inp"]))
+    assert torch.equal(torch.cat(tgts), torch.from_numpy(gold[key + "/tgt"]))
+
+
+@pytest.mark.gpu
+def test_device_batches_are_normalised_like_the_reference(gold):
+    from realpdebench_amd.disk import DiskBatchLoader
+    w = _windows(gold, "ctl_num_train")
+    torch.manual_seed(0)
+    stats = (torch.randn(5), torch.randn(3), torch.rand(5) + 0.5, torch.tensor([0.7, 0.0, 1.3]))   # a zero std -> 1
+    random.seed(1234)
+    loader = DiskBatchLoader(w, 3, "cuda", stats=stats, shuffle=False, epochs=1)
+    x = torch.cat([a.cpu() for a, _ in loader])
+    random.seed(1234)
+    loader = DiskBatchLoader(w, 3, "cuda", stats=stats, shuffle=False, epochs=1)
+    y = torch.cat([b.cpu() for _, b in loader])
+    st = torch.where(stats[3] == 0, torch.ones(3), stats[3])
+    assert torch.equal(x, (torch.from_numpy(gold["ctl_num_train/inp"]) - stats[0]) / stats[2])     # data_normalizer.py:50-55
+    assert torch.equal(y, (torch.from_numpy(gold["ctl_num_train/tgt"]) - stats[1]) / st)
+
+
+@pytest.mark.gpu
+def test_two_ranks_read_disjoint_halves_of_one_permutation(gold):
+    from realpdebench_amd.disk import DiskBatchLoader
+    w = _windows(gold, "cyl_real_val")                              # 6 samples
+    ref = torch.from_numpy(gold["cyl_real_val/inp"])
+    got = []
+    for rank in (0, 1):
+        loader = DiskBatchLoader(w, 1, "cuda", shuffle=True, seed=3, rank=rank, world=2, epochs=1)
+        got.append([a.cpu() for a, _ in loader])
+    plan = [list(batch_plan(6, 1, 2, r, True, 3, 0)) for r in (0, 1)]
+    assert len(got[0]) == len(got[1]) == 3
+    for r in (0, 1):
+        for step, idxs in enumerate(plan[r]):
+            assert torch.equal(got[r][step], ref[idxs])
+    assert not (set(i for b in plan[0] for i in b) & set(i for b in plan[1] for i in b))
