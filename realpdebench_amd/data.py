@@ -27,11 +27,43 @@ def make_datasets(args):
     if factory:
         mod, fn = factory.split(":")
         return getattr(importlib.import_module(mod), fn)(args)
-    if getattr(args, "dataset_name", "synthetic") != "synthetic":
-        raise ValueError(f"dataset_name={args.dataset_name!r}: dataset readers are outside this backend; pass "
-                         "--dataset_factory module:function returning (train, val, stats) or use dataset_name: synthetic")
+    name = getattr(args, "dataset_name", "synthetic")
+    if name != "synthetic":
+        from . import disk
+        if name not in disk.SCENARIOS:
+            raise ValueError(f"dataset_name={name!r}: the built-in on-disk reader covers {sorted(disk.SCENARIOS)} (the reference's "
+                             "V2 Arrow layout); pass --dataset_factory module:function returning (train, val, stats) otherwise")
+        return fluid_datasets(args)
     return (SyntheticDataset(args.shape_in, args.shape_out, args.n_train, seed=args.seed),
             SyntheticDataset(args.shape_in, args.shape_out, args.n_val, seed=args.seed + 1), None)
+
+
+def fluid_datasets(args):
+    """The three datasets of realpdebench/train.py:118-266 for a fluid scenario -- train (mode 'train', ``--train_data_type``,
+    mask_prob / noise_scale from the YAML), val (mode 'val', real data) and the normaliser's (mode 'train', numerical) -- as
+    ``disk.FluidWindows`` sample lists over the memory-mapped Arrow files, + the GaussianNormalizer statistics (read from /
+    written to ``{dataset_dir}/mean_std.pt`` like data_normalizer.py:22-34)."""
+    import logging
+    import os
+
+    from . import disk
+    kw = dict(dataset_name=args.dataset_name, dataset_root=args.dataset_root)
+    train = disk.FluidWindows(mode="train", dataset_type=getattr(args, "train_data_type", "numerical"),
+                              mask_prob=getattr(args, "mask_prob", 0.5), noise_scale=getattr(args, "noise_scale", 0.0), **kw)
+    val = disk.FluidWindows(mode="val", dataset_type="real", **kw)
+    stats = None
+    if getattr(args, "normalizer", "none") == "gaussian":
+        cache = os.path.join(train.dataset_dir, "mean_std.pt")
+        try:
+            stats = torch.load(cache, map_location="cpu", weights_only=True)
+        except Exception:
+            norm_set = disk.FluidWindows(mode="train", dataset_type="numerical", **kw)
+            stats = disk.compute_mean_std(norm_set, 512)
+            try:
+                torch.save(tuple(stats), cache)
+            except OSError as exc:
+                logging.info(f"normaliser statistics not cached ({exc})")
+    return train, val, stats
 
 
 class DevicePrefetcher:

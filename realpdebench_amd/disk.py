@@ -93,7 +93,8 @@ class FluidWindows:
     contiguous full-resolution slabs; ``__getitem__`` reproduces the reference's CPU tensors exactly (a plain Dataset)."""
 
     def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.5, in_step=20, out_step=20,
-                 N_autoregressive=1, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2, noise_scale=0.0, **_ignored):
+                 N_autoregressive=1, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2, noise_scale=0.0, noise_type="gaussian",
+                 **_ignored):
         if dataset_name not in SCENARIOS:
             raise ValueError(f"dataset_name={dataset_name!r}: fluid scenarios are {sorted(SCENARIOS)}")
         spec = SCENARIOS[dataset_name]
@@ -106,9 +107,10 @@ class FluidWindows:
         self.n_sim_frame = int(n_sim_frame)
         self.sub_s = int(sub_s_real if dataset_type == "real" else sub_s_numerical)
         self.mask_prob = float(mask_prob)
-        if noise_scale:
-            raise NotImplementedError("noise augmentation (fluid_hf_dataset.py:308-324) draws from torch's CPU generator; "
-                                      "apply it on the device batch instead")
+        self.noise_scale = float(noise_scale) if dataset_type == "numerical" else 0.0    # fluid_hf_dataset.py:308
+        self.noise_type = noise_type
+        if self.noise_scale > 0 and noise_type not in ("gaussian", "poisson"):
+            raise NotImplementedError(f"noise_type={noise_type!r}: only 'gaussian' / 'poisson' (fluid_hf_dataset.py:309-314)")
         self.dataset_dir = os.path.join(dataset_root, dataset_name)
         hf_dir = os.path.join(self.dataset_dir, "hf_dataset")
         index_path = os.path.join(hf_dir, f"{mode}_index_{dataset_type}.json")
@@ -173,6 +175,13 @@ class FluidWindows:
         p = np.zeros_like(u) if p is None else p[:, ::s, ::s]
         data = np.stack([u, v, p], axis=-1)
         inp, out = torch.tensor(data[:self.in_step]), torch.tensor(data[self.in_step:])
+        if self.noise_scale > 0:                                          # fluid_hf_dataset.py:308-314, same draws in the same order
+            if self.noise_type == "gaussian":
+                inp = inp + inp * torch.randn_like(inp) * self.noise_scale
+                out = out + out * torch.randn_like(out) * self.noise_scale
+            else:
+                inp = inp + torch.poisson(inp) * self.noise_scale
+                out = out + torch.poisson(out) * self.noise_scale
         if para:
             inp = torch.cat([inp, torch.stack([x * torch.ones_like(inp[..., 0]) for x in para], dim=-1)], dim=-1)
         return inp, out
@@ -303,6 +312,13 @@ class DiskBatchLoader:
         with torch.cuda.stream(self.stream):
             slot["dev"].copy_(slot["host"], non_blocking=True)
             slot["dflags"].copy_(slot["flags"], non_blocking=True)
+            if self.w.noise_scale > 0:
+                # x + x * N(0,1) * scale per element (fluid_hf_dataset.py:309-311), drawn on the device at full resolution before
+                # the sub-sampling: the same distribution per kept element, not the reference's CPU random stream
+                if self.w.noise_type != "gaussian":
+                    raise NotImplementedError("device batches support noise_type 'gaussian' only")
+                d = slot["dev"][:nb]
+                d.addcmul_(d, torch.randn_like(d), value=self.w.noise_scale)
             self.ops.window_pack(slot["dev"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf, self.Wf,
                                  self.w.sub_s, self.w.n_para, *self.stats)
             done = torch.cuda.Event()

@@ -59,8 +59,11 @@ def main(argv=None):
     if world > 1:
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=args.seed)
-    train_loader = cycle(DataLoader(train_dataset, batch_size=per_rank_bs, shuffle=sampler is None, sampler=sampler,
-                                    pin_memory=True, num_workers=args.num_workers, drop_last=True))
+    from .disk import DiskBatchLoader, FluidWindows
+    on_disk = isinstance(train_dataset, FluidWindows)
+    train_loader = None if on_disk else cycle(DataLoader(train_dataset, batch_size=per_rank_bs, shuffle=sampler is None,
+                                                         sampler=sampler, pin_memory=True, num_workers=args.num_workers,
+                                                         drop_last=True))
     val_loader = DataLoader(val_dataset, batch_size=args.test_batch_size, shuffle=False, num_workers=args.num_workers)
     if args.normalizer == "gaussian":
         if stats is None:
@@ -83,7 +86,11 @@ def main(argv=None):
     all_train_losses, all_val_losses = [], {"normalized_mse": [], "rmse": [], "mae": [], "rel_l2_error": []}
     best_val, best_it = float("inf"), 0
     pending, start = [], time.time()
-    batches = DevicePrefetcher(train_loader, normalizer, device)     # async H2D + normalise on a side stream (row f1)
+    if on_disk:       # row f2: memory-mapped Arrow slabs -> pinned staging -> rpb_window_pack (+ normaliser) on a side stream
+        batches = DiskBatchLoader(train_dataset, per_rank_bs, device, stats=stats if args.normalizer == "gaussian" else None,
+                                  shuffle=True, seed=args.seed, rank=rank, world=world)
+    else:
+        batches = DevicePrefetcher(train_loader, normalizer, device)     # async H2D + normalise on a side stream (row f1)
     for iteration in range(1, n_iter + 1):
         inp, tgt = next(batches)
         pending.append(trainer.step(inp, tgt).clone())              # device scalar, no sync
