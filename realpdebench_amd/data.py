@@ -21,7 +21,7 @@ class SyntheticDataset(Dataset):
         return torch.randn(*self.shape_in, generator=g), torch.randn(*self.shape_out, generator=g)
 
 
-def make_datasets(args):
+def make_datasets(args, for_eval=False):
     """Returns ``(train_dataset, val_dataset, normalizer_stats or None)``."""
     factory = getattr(args, "dataset_factory", None)
     if factory:
@@ -33,14 +33,15 @@ def make_datasets(args):
         if name not in disk.SCENARIOS:
             raise ValueError(f"dataset_name={name!r}: the built-in on-disk reader covers {sorted(disk.SCENARIOS)} (the reference's "
                              "V2 Arrow layout); pass --dataset_factory module:function returning (train, val, stats) otherwise")
-        return fluid_datasets(args)
+        return fluid_datasets(args, for_eval)
     return (SyntheticDataset(args.shape_in, args.shape_out, args.n_train, seed=args.seed),
             SyntheticDataset(args.shape_in, args.shape_out, args.n_val, seed=args.seed + 1), None)
 
 
-def fluid_datasets(args):
+def fluid_datasets(args, for_eval=False):
     """The three datasets of realpdebench/train.py:118-266 for a fluid scenario -- train (mode 'train', ``--train_data_type``,
-    mask_prob / noise_scale from the YAML), val (mode 'val', real data) and the normaliser's (mode 'train', numerical) -- as
+    mask_prob / noise_scale from the YAML), val (mode 'val', real data; ``for_eval``: the 'test' split with the rollout horizon
+    of realpdebench/eval.py:91-98) and the normaliser's (mode 'train', numerical) -- as
     ``disk.FluidWindows`` sample lists over the memory-mapped Arrow files, + the GaussianNormalizer statistics (read from /
     written to ``{dataset_dir}/mean_std.pt`` like data_normalizer.py:22-34)."""
     import logging
@@ -50,7 +51,11 @@ def fluid_datasets(args):
     kw = dict(dataset_name=args.dataset_name, dataset_root=args.dataset_root)
     train = disk.FluidWindows(mode="train", dataset_type=getattr(args, "train_data_type", "numerical"),
                               mask_prob=getattr(args, "mask_prob", 0.5), noise_scale=getattr(args, "noise_scale", 0.0), **kw)
-    val = disk.FluidWindows(mode="val", dataset_type="real", **kw)
+    if for_eval:        # realpdebench/eval.py:91-98: the test split of the real data, horizon = in_step + out_step * N_autoregressive
+        val = disk.FluidWindows(mode="test", dataset_type="real", N_autoregressive=getattr(args, "N_autoregressive", 1),
+                                test_mode=getattr(args, "test_mode", "all"), **kw)
+    else:
+        val = disk.FluidWindows(mode="val", dataset_type="real", **kw)
     stats = None
     if getattr(args, "normalizer", "none") == "gaussian":
         cache = os.path.join(train.dataset_dir, "mean_std.pt")

@@ -41,7 +41,7 @@ def main(argv=None):
     os.makedirs(exp_path, exist_ok=True)
     setup_logging(exp_path, is_train=False)
 
-    train_dataset, test_dataset, stats = make_datasets(args)
+    train_dataset, test_dataset, stats = make_datasets(args, for_eval=True)
     loader = DataLoader(test_dataset, batch_size=args.test_batch_size, shuffle=False, num_workers=args.num_workers)
     normalizer = GaussianNormalizer(*stats, device=device) if args.normalizer == "gaussian" else IdentityNormalizer(device)
     model = load_model(train_dataset, device=device, **vars(args))

@@ -141,6 +141,7 @@ def _write_v2_dataset(root, scenario="cylinder", n_sim=2, t_full=46, hw_real=(8,
 def test_train_from_the_on_disk_arrow_layout(tmp_path):
     """dataset_name: cylinder + dataset_root: the built-in reader feeds the trainer -- memory-mapped Arrow
     slabs, rpb_window_pack with the Gaussian normaliser fused, statistics cached as mean_std.pt like the reference."""
+    from realpdebench_amd import eval as ev
     from realpdebench_amd import train as tr
     root = tmp_path / "data"
     _write_v2_dataset(str(root))
@@ -153,5 +154,7 @@ def test_train_from_the_on_disk_arrow_layout(tmp_path):
     exp = tr.main(["--config", str(path), "--max_updates", "6", "--train_data_type", "numerical"])
     ck = torch.load(sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1], map_location="cpu")
     assert ck["iteration"] == 6 and all(l == l and l < 1e3 for l in ck["train_losses"])     # finite, normalised-scale losses
+    ev.main(["--config", str(path), "--checkpoint_path", sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1]])   # test split
+    assert os.path.exists(os.path.join(exp, "eval.log"))
     stats = torch.load(os.path.join(str(root), "cylinder", "mean_std.pt"), weights_only=True)
     assert len(stats) == 4 and stats[0].shape == (3,) and abs(float(stats[0][0]) - 0.5) < 0.05      # fields ~ N(0.5, 1)
