@@ -272,15 +272,17 @@ int rpb_split3t(const float* x, void* planes_t, long M, int C, int ldx, int rev,
  *     rpb_conv3x_wgrad and transpose the three tap axes of its result (for meshes whose innermost dimension is not % 8). */
 int rpb_conv3x_wgrad_splits(long M, int Co, int Ci);
 int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co, int Ci, int Hc, int Wc, int Dc, void* stream);
-/*     input pipeline: one pass from the full-resolution time slabs of (u, v, p) as they lie in
- *     the reference's Arrow cells -- planar [B][3][horizon][Hf][Wf] -- to the model's channels-last input [B][in_step][H][W][3 +
- *     n_para] and target [B][horizon - in_step][H][W][3]: spatial sub-sampling [::sub_s, ::sub_s], channel stack, pressure masking
- *     (flags[b][c] == 0 -> zeros), ControlledCylinder's parameter channels (flags[b][4 + k]) -- realpdebench/data/
- *     fluid_hf_dataset.py:280-335 -- and GaussianNormalizer.preprocess (data/data_normalizer.py:50-55) fused.  flags is
- *     [B][4 + max(n_para, 1)]. */
-int rpb_window_pack(const float* planar, const float* flags, float* inp, float* tgt, int B, int horizon, int in_step, int Hf,
-                    int Wf, int sub_s, int n_para, const float* mean_in, const float* mean_tgt, const float* std_in,
-                    const float* std_tgt, void* stream);
+/*     input pipeline: one pass from the full-resolution time slabs as they lie in the
+ *     reference's Arrow cells -- planar [B][Cp][horizon][Hf][Wf] ((u, v, p): Cp = 3; combustion's `observed`: Cp = 1) and an
+ *     optional channels-last cell cl [B][horizon][Hf][Wf][Cl] (combustion's 15 `numerical` channels) -- to the model's channels-last
+ *     input [B][in_step][H][W][Cp + Cl + n_para] and target [B][horizon - in_step][H][W][Cp + Cl]: spatial sub-sampling
+ *     [::sub_s, ::sub_s], channel stack, masking (flags[b][c] == 0 -> planar channel c is zeros, flags[b][3] == 0 -> the cl block is),
+ *     ControlledCylinder's parameter channels (flags[b][4 + k]) -- realpdebench/data/fluid_hf_dataset.py:280-335,
+ *     data/combustion_hf_dataset.py:268-320 -- and GaussianNormalizer.preprocess (data/data_normalizer.py:50-55) fused.
+ *     flags is [B][4 + max(n_para, 1)]. */
+int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
+                    int in_step, int Hf, int Wf, int sub_s, int n_para, int Cp, int Cl, const float* mean_in,
+                    const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream);
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
 int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
 /*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,

@@ -4,17 +4,20 @@
 #include "rpb_common.h"
 
 struct WindowPackArgs {
-    const float* planar;   // [B][3][horizon][Hf][Wf]  full-resolution time slabs of (u, v, p) as they lie in the Arrow cell
-    const float* flags;    // [B][4 + max(n_para, 1)]  [c] != 0: channel c present (else zeros: masked / real-data pressure);
+    const float* planar;   // [B][Cp][horizon][Hf][Wf]  full-resolution time slabs of the planar cells: (u, v, p) of the fluid
+                           //                           scenarios (Cp = 3), `observed` of combustion (Cp = 1)
+    const float* cl;       // [B][horizon][Hf][Wf][Cl]  channels-last cell (combustion's 15 `numerical` channels) or null
+    const float* flags;    // [B][4 + max(n_para, 1)]  [c] != 0, c < 3: planar channel c present (else zeros: masked / real-data
+                           //                          pressure); [3] != 0: the channels-last block is present;
                            //                          [4 + k]: k-th parameter parsed from sim_id (ControlledCylinder)
-    float* inp;            // [B][in_step][H][W][3 + n_para]
-    float* tgt;            // [B][horizon - in_step][H][W][3]
-    const float* mean_in;  // [3 + n_para]
-    const float* mean_tgt; // [3]
+    float* inp;            // [B][in_step][H][W][Cp + Cl + n_para]
+    float* tgt;            // [B][horizon - in_step][H][W][Cp + Cl]
+    const float* mean_in;  // [Cp + Cl + n_para]
+    const float* mean_tgt; // [Cp + Cl]
     const float* std_in;
     const float* std_tgt;
     long ntok;             // B * horizon * H * W
-    int horizon, in_step, Hf, Wf, H, W, sub_s, n_para, nflag;
+    int horizon, in_step, Hf, Wf, H, W, sub_s, n_para, nflag, Cp, Cl;
 };
 
 __global__ __launch_bounds__(256) void window_pack_kernel(WindowPackArgs a) {
@@ -26,33 +29,33 @@ __global__ __launch_bounds__(256) void window_pack_kernel(WindowPackArgs a) {
         r -= (long)t * a.H * a.W;
         const int h = (int)(r / a.W), w = (int)(r - (long)h * a.W);
         const float* fl = a.flags + b * a.nflag;
-        const float* src = a.planar + ((b * 3 * a.horizon + t) * (long)a.Hf + (long)h * a.sub_s) * a.Wf + (long)w * a.sub_s;
+        const long pix = (long)h * a.sub_s * a.Wf + (long)w * a.sub_s;                      // [::sub_s, ::sub_s]
+        const float* src = a.planar + (b * a.Cp * a.horizon + t) * (long)a.Hf * a.Wf + pix;
         const long cstride = (long)a.horizon * a.Hf * a.Wf;
-        float x[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = fl[c] != 0.f ? src[c * cstride] : 0.f;
-        if (t < a.in_step) {
-            const int C = 3 + a.n_para;
-            float* dst = a.inp + (((b * a.in_step + t) * a.H + h) * (long)a.W + w) * C;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dst[c] = (x[c] - a.mean_in[c]) / a.std_in[c];
-            for (int k = 0; k < a.n_para; ++k) dst[3 + k] = (fl[4 + k] - a.mean_in[3 + k]) / a.std_in[3 + k];
-        } else {
-            float* dst = a.tgt + (((b * (a.horizon - a.in_step) + (t - a.in_step)) * a.H + h) * (long)a.W + w) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dst[c] = (x[c] - a.mean_tgt[c]) / a.std_tgt[c];
-        }
+        const float* srcl = a.cl ? a.cl + ((b * a.horizon + t) * (long)a.Hf * a.Wf + pix) * a.Cl : nullptr;
+        const bool lon = a.cl && fl[3] != 0.f;
+        const bool is_in = t < a.in_step;
+        const int C = a.Cp + a.Cl + (is_in ? a.n_para : 0);
+        float* dst = is_in ? a.inp + (((b * a.in_step + t) * a.H + h) * (long)a.W + w) * C
+                           : a.tgt + (((b * (a.horizon - a.in_step) + (t - a.in_step)) * a.H + h) * (long)a.W + w) * C;
+        const float* mean = is_in ? a.mean_in : a.mean_tgt;
+        const float* sd = is_in ? a.std_in : a.std_tgt;
+        for (int c = 0; c < a.Cp; ++c) dst[c] = ((fl[c] != 0.f ? src[c * cstride] : 0.f) - mean[c]) / sd[c];
+        for (int c = 0; c < a.Cl; ++c) dst[a.Cp + c] = ((lon ? srcl[c] : 0.f) - mean[a.Cp + c]) / sd[a.Cp + c];
+        if (is_in)
+            for (int k = 0; k < a.n_para; ++k) dst[a.Cp + a.Cl + k] = (fl[4 + k] - mean[a.Cp + a.Cl + k]) / sd[a.Cp + a.Cl + k];
     }
 }
 
-extern "C" int rpb_window_pack(const float* planar, const float* flags, float* inp, float* tgt, int B, int horizon, int in_step,
-                               int Hf, int Wf, int sub_s, int n_para, const float* mean_in, const float* mean_tgt,
-                               const float* std_in, const float* std_tgt, void* stream) {
+extern "C" int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
+                               int in_step, int Hf, int Wf, int sub_s, int n_para, int Cp, int Cl, const float* mean_in,
+                               const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream) {
     RPB_REQUIRE(planar && flags && inp && tgt && mean_in && mean_tgt && std_in && std_tgt, "window_pack: null pointer");
+    RPB_REQUIRE(Cp >= 1 && Cp <= 3 && Cl >= 0 && (Cl == 0) == (cl == nullptr), "window_pack: Cp=%d Cl=%d (planar channels 1..3; a channels-last block iff Cl > 0)", Cp, Cl);
     RPB_REQUIRE(B > 0 && horizon > in_step && in_step > 0 && Hf > 0 && Wf > 0 && sub_s >= 1 && n_para >= 0 && n_para <= 8,
                 "window_pack: bad sizes (B=%d horizon=%d in_step=%d sub_s=%d n_para=%d)", B, horizon, in_step, sub_s, n_para);
     WindowPackArgs a;
-    a.planar = planar; a.flags = flags; a.inp = inp; a.tgt = tgt;
+    a.planar = planar; a.cl = cl; a.flags = flags; a.inp = inp; a.tgt = tgt; a.Cp = Cp; a.Cl = Cl;
     a.mean_in = mean_in; a.mean_tgt = mean_tgt; a.std_in = std_in; a.std_tgt = std_tgt;
     a.horizon = horizon; a.in_step = in_step; a.Hf = Hf; a.Wf = Wf; a.sub_s = sub_s; a.n_para = n_para;
     a.H = (Hf + sub_s - 1) / sub_s;                                      // len(range(0, Hf, sub_s)) = numpy's [::sub_s]

@@ -30,9 +30,10 @@ def make_datasets(args, for_eval=False):
     name = getattr(args, "dataset_name", "synthetic")
     if name != "synthetic":
         from . import disk
-        if name not in disk.SCENARIOS:
-            raise ValueError(f"dataset_name={name!r}: the built-in on-disk reader covers {sorted(disk.SCENARIOS)} (the reference's "
-                             "V2 Arrow layout); pass --dataset_factory module:function returning (train, val, stats) otherwise")
+        if name not in disk.SCENARIOS and name != "combustion":
+            raise ValueError(f"dataset_name={name!r}: the built-in on-disk reader covers {sorted(disk.SCENARIOS)} + combustion "
+                             "(the reference's V2 Arrow layout); pass --dataset_factory module:function returning "
+                             "(train, val, stats) otherwise")
         return fluid_datasets(args, for_eval)
     return (SyntheticDataset(args.shape_in, args.shape_out, args.n_train, seed=args.seed),
             SyntheticDataset(args.shape_in, args.shape_out, args.n_val, seed=args.seed + 1), None)
@@ -49,20 +50,21 @@ def fluid_datasets(args, for_eval=False):
 
     from . import disk
     kw = dict(dataset_name=args.dataset_name, dataset_root=args.dataset_root)
-    train = disk.FluidWindows(mode="train", dataset_type=getattr(args, "train_data_type", "numerical"),
-                              mask_prob=getattr(args, "mask_prob", 0.5), noise_scale=getattr(args, "noise_scale", 0.0), **kw)
+    extra = {"mask_prob": args.mask_prob} if hasattr(args, "mask_prob") else {}       # else the scenario's default (0.5 / 0.8)
+    train = disk.open_windows(mode="train", dataset_type=getattr(args, "train_data_type", "numerical"),
+                              noise_scale=getattr(args, "noise_scale", 0.0), **extra, **kw)
     if for_eval:        # realpdebench/eval.py:91-98: the test split of the real data, horizon = in_step + out_step * N_autoregressive
-        val = disk.FluidWindows(mode="test", dataset_type="real", N_autoregressive=getattr(args, "N_autoregressive", 1),
+        val = disk.open_windows(mode="test", dataset_type="real", N_autoregressive=getattr(args, "N_autoregressive", 1),
                                 test_mode=getattr(args, "test_mode", "all"), **kw)
     else:
-        val = disk.FluidWindows(mode="val", dataset_type="real", **kw)
+        val = disk.open_windows(mode="val", dataset_type="real", **kw)
     stats = None
     if getattr(args, "normalizer", "none") == "gaussian":
         cache = os.path.join(train.dataset_dir, "mean_std.pt")
         try:
             stats = torch.load(cache, map_location="cpu", weights_only=True)
         except Exception:
-            norm_set = disk.FluidWindows(mode="train", dataset_type="numerical", **kw)
+            norm_set = disk.open_windows(mode="train", dataset_type="numerical", **kw)
             stats = disk.compute_mean_std(norm_set, 512)
             try:
                 torch.save(tuple(stats), cache)

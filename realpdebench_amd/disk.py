@@ -1,6 +1,6 @@
 """On-disk trajectory reader: the reference's "V2" Hugging Face Arrow layout -> device-resident,
 normalised ``(input[B,T_in,H,W,C_in], target[B,T_out,H,W,C_out])`` batches, sharded over data-parallel ranks, with no Python
-worker processes.
+worker processes.  Fluid scenarios (cylinder, fsi, controlled_cylinder, foil) and combustion.
 
 Reference behaviour mirrored here (file:line in /root/reference/realpdebench):
   * layout and schema -- utils/convert_hdf5_to_hf.py:20-51: ``{root}/{scenario}/hf_dataset/{real|numerical}/`` written by
@@ -91,13 +91,14 @@ class ArrowTrajectories:
 class FluidWindows:
     """The sample list of ``FluidHFDataset`` (same constructor vocabulary, same ordering and filters) exposing each sample as
     contiguous full-resolution slabs; ``__getitem__`` reproduces the reference's CPU tensors exactly (a plain Dataset)."""
+    SPEC = None                                                           # subclasses outside SCENARIOS bring their own
 
     def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.5, in_step=20, out_step=20,
                  N_autoregressive=1, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2, noise_scale=0.0, noise_type="gaussian",
                  **_ignored):
-        if dataset_name not in SCENARIOS:
+        spec = self.SPEC or SCENARIOS.get(dataset_name)
+        if spec is None:
             raise ValueError(f"dataset_name={dataset_name!r}: fluid scenarios are {sorted(SCENARIOS)}")
-        spec = SCENARIOS[dataset_name]
         self.dataset_name, self.dataset_type, self.mode, self.test_mode = dataset_name, dataset_type, mode, test_mode
         self.file_name_pattern, self.condition_on_para = spec["file_name_pattern"], spec["condition_on_para"]
         self.in_step = int(in_step)
@@ -125,6 +126,7 @@ class FluidWindows:
             self._indices = [e for e in self._indices if e["time_id"] + self.horizon < self.n_sim_frame]
         self.has_p = dataset_type != "real" and self.store.has("p")
         self.n_para = re.compile(self.file_name_pattern).groups if self.condition_on_para else 0
+        self.Cp, self.Cl = 3, 0                                           # three planar cells (u, v, p), no channels-last cell
 
     def _apply_test_mode_filter(self):                                    # fluid_hf_dataset.py:182-236
         def load(kind):
@@ -156,8 +158,9 @@ class FluidWindows:
         return (len(range(0, h, self.sub_s)), len(range(0, w, self.sub_s)))
 
     def slabs(self, idx):
-        """``(u, v, p or None, parameters)``: contiguous float32 views ``[horizon, H_full, W_full]`` of sample ``idx``.
-        The pressure decision consumes one ``random.random()`` for numerical data exactly like fluid_hf_dataset.py:290-296."""
+        """``([u, v, p or None], None, parameters)``: contiguous float32 views ``[horizon, H_full, W_full]`` of sample ``idx``
+        (planar cells, channels-last cell, parameter channels).  The pressure decision consumes one ``random.random()`` for
+        numerical data exactly like fluid_hf_dataset.py:290-296."""
         e = self._indices[idx]
         sid, t0 = e["sim_id"], int(e["time_id"])
         u = self.store.array(sid, "u")[t0:t0 + self.horizon]
@@ -166,10 +169,10 @@ class FluidWindows:
         if self.dataset_type != "real":
             if not (random.random() < self.mask_prob):
                 p = self.store.array(sid, "p")[t0:t0 + self.horizon]
-        return u, v, p, self.parameters(sid)
+        return [u, v, p], None, self.parameters(sid)
 
     def __getitem__(self, idx):
-        u, v, p, para = self.slabs(idx)
+        (u, v, p), _, para = self.slabs(idx)
         s = self.sub_s
         u, v = u[:, ::s, ::s], v[:, ::s, ::s]
         p = np.zeros_like(u) if p is None else p[:, ::s, ::s]
@@ -185,6 +188,55 @@ class FluidWindows:
         if para:
             inp = torch.cat([inp, torch.stack([x * torch.ones_like(inp[..., 0]) for x in para], dim=-1)], dim=-1)
         return inp, out
+
+
+class CombustionWindows(FluidWindows):
+    """``CombustionHFDataset`` (data/combustion_hf_dataset.py): one planar cell ``observed`` [T, H, W] + one channels-last cell
+    ``numerical`` [T, H, W, 15] (numerical data only; zeros for real data and with probability ``mask_prob``), 16 channels."""
+    NUMERICAL_CHANNEL = 15                                                # combustion_hf_dataset.py:43
+    SPEC = dict(file_name_pattern=r"(.*)", condition_on_para=False)
+
+    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.8, in_step=20, out_step=20,
+                 N_autoregressive=1, n_sim_frame=2001, sub_s_real=2, sub_s_numerical=2, noise_scale=0.0, noise_type="gaussian",
+                 **_ignored):
+        if dataset_name != "combustion":
+            raise ValueError(f"dataset_name={dataset_name!r}: CombustionWindows reads the combustion scenario")
+        super().__init__(dataset_name, dataset_root, dataset_type, mode, test_mode=test_mode, mask_prob=mask_prob, in_step=in_step,
+                         out_step=out_step, N_autoregressive=N_autoregressive, n_sim_frame=n_sim_frame, sub_s_real=sub_s_real,
+                         sub_s_numerical=sub_s_numerical, noise_scale=noise_scale, noise_type=noise_type)
+        self.Cp, self.Cl, self.n_para = 1, self.NUMERICAL_CHANNEL, 0
+
+    def slabs(self, idx):
+        e = self._indices[idx]
+        sid, t0 = e["sim_id"], int(e["time_id"])
+        obs = self.store.array(sid, "observed")[t0:t0 + self.horizon]
+        num = None
+        if self.dataset_type != "real" and not (random.random() < self.mask_prob):       # combustion_hf_dataset.py:303-316
+            nch = int(self.store._cell(sid, "numerical_channels").as_py())
+            buf = self.store._cell(sid, "numerical").as_buffer()
+            num = np.frombuffer(buf, dtype=np.float32).reshape(*self.store.shape(sid), nch)[t0:t0 + self.horizon]
+        return [obs], num, []
+
+    def __getitem__(self, idx):
+        (obs,), num, _ = self.slabs(idx)
+        s = self.sub_s
+        data = torch.tensor(obs[:, ::s, ::s]).unsqueeze(-1)
+        rest = torch.zeros(*data.shape[:3], self.Cl) if num is None else torch.tensor(num[:, ::s, ::s])
+        data = torch.cat([data, rest], dim=-1)
+        inp, out = data[:self.in_step], data[self.in_step:]
+        if self.noise_scale > 0:
+            if self.noise_type == "gaussian":
+                inp = inp + inp * torch.randn_like(inp) * self.noise_scale
+                out = out + out * torch.randn_like(out) * self.noise_scale
+            else:
+                inp = inp + torch.poisson(inp) * self.noise_scale
+                out = out + torch.poisson(out) * self.noise_scale
+        return inp, out
+
+
+def open_windows(dataset_name, **kw):
+    """The sample list class of a scenario (realpdebench/train.py:81-266 picks the dataset class the same way)."""
+    return (CombustionWindows if dataset_name == "combustion" else FluidWindows)(dataset_name=dataset_name, **kw)
 
 
 def compute_mean_std(windows, batch_size=512):
@@ -237,7 +289,8 @@ class DiskBatchLoader:
         self.drop_last, self.epochs = drop_last, epochs
         T_full, self.Hf, self.Wf = windows.full_shape()
         self.H, self.W = windows.out_shape()
-        self.c_in, self.c_out = 3 + windows.n_para, 3
+        self.Cp, self.Cl = windows.Cp, windows.Cl
+        self.c_in, self.c_out = self.Cp + self.Cl + windows.n_para, self.Cp + self.Cl
         self.horizon, self.in_step = windows.horizon, windows.in_step
         f = dict(device=self.device, dtype=torch.float32)
         if stats is not None:
@@ -249,11 +302,16 @@ class DiskBatchLoader:
             self.stats = (torch.zeros(self.c_in, **f), torch.zeros(self.c_out, **f), torch.ones(self.c_in, **f),
                           torch.ones(self.c_out, **f))
         self.stream = torch.cuda.Stream(self.device)
-        self._slots = [dict(host=torch.empty(self.B, 3, self.horizon, self.Hf, self.Wf, dtype=torch.float32).pin_memory(),
-                            flags=torch.zeros(self.B, 4 + max(windows.n_para, 1), dtype=torch.float32).pin_memory(),
-                            dev=torch.empty(self.B, 3, self.horizon, self.Hf, self.Wf, **f),
-                            dflags=torch.empty(self.B, 4 + max(windows.n_para, 1), **f), free=threading.Event())
-                       for _ in range(depth)]
+        def slot():
+            d = dict(host=torch.empty(self.B, self.Cp, self.horizon, self.Hf, self.Wf, dtype=torch.float32).pin_memory(),
+                     flags=torch.zeros(self.B, 4 + max(windows.n_para, 1), dtype=torch.float32).pin_memory(),
+                     dev=torch.empty(self.B, self.Cp, self.horizon, self.Hf, self.Wf, **f),
+                     dflags=torch.empty(self.B, 4 + max(windows.n_para, 1), **f), free=threading.Event(), hostl=None, devl=None)
+            if self.Cl:
+                d["hostl"] = torch.empty(self.B, self.horizon, self.Hf, self.Wf, self.Cl, dtype=torch.float32).pin_memory()
+                d["devl"] = torch.empty(self.B, self.horizon, self.Hf, self.Wf, self.Cl, **f)
+            return d
+        self._slots = [slot() for _ in range(depth)]
         for s in self._slots:
             s["free"].set()
         self._q = queue.Queue(maxsize=depth)
@@ -280,15 +338,17 @@ class DiskBatchLoader:
                 if slot.get("busy") is not None:
                     slot["busy"].synchronize()                           # ... and that copy has left the pinned buffer
                 host, flags = slot["host"].numpy(), slot["flags"].numpy()
+                hostl = slot["hostl"].numpy() if slot["hostl"] is not None else None
                 flags[:] = 0.0
                 for b, i in enumerate(idxs):
-                    u, v, p, para = self.w.slabs(i)
-                    np.copyto(host[b, 0], u)
-                    np.copyto(host[b, 1], v)
-                    if p is not None:
-                        np.copyto(host[b, 2], p)
-                        flags[b, 2] = 1.0
-                    flags[b, 0] = flags[b, 1] = 1.0
+                    planar, cl, para = self.w.slabs(i)
+                    for c, arr in enumerate(planar):
+                        if arr is not None:
+                            np.copyto(host[b, c], arr)
+                            flags[b, c] = 1.0
+                    if cl is not None:
+                        np.copyto(hostl[b], cl)
+                        flags[b, 3] = 1.0
                     for k, x in enumerate(para):
                         flags[b, 4 + k] = x
                 self._q.put((slot, len(idxs)))
@@ -312,15 +372,18 @@ class DiskBatchLoader:
         with torch.cuda.stream(self.stream):
             slot["dev"].copy_(slot["host"], non_blocking=True)
             slot["dflags"].copy_(slot["flags"], non_blocking=True)
+            if slot["devl"] is not None:
+                slot["devl"].copy_(slot["hostl"], non_blocking=True)
             if self.w.noise_scale > 0:
                 # x + x * N(0,1) * scale per element (fluid_hf_dataset.py:309-311), drawn on the device at full resolution before
                 # the sub-sampling: the same distribution per kept element, not the reference's CPU random stream
                 if self.w.noise_type != "gaussian":
                     raise NotImplementedError("device batches support noise_type 'gaussian' only")
-                d = slot["dev"][:nb]
-                d.addcmul_(d, torch.randn_like(d), value=self.w.noise_scale)
-            self.ops.window_pack(slot["dev"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf, self.Wf,
-                                 self.w.sub_s, self.w.n_para, *self.stats)
+                for d in (slot["dev"][:nb], slot["devl"][:nb] if slot["devl"] is not None else None):
+                    if d is not None:
+                        d.addcmul_(d, torch.randn_like(d), value=self.w.noise_scale)
+            self.ops.window_pack(slot["dev"], slot["devl"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf,
+                                 self.Wf, self.w.sub_s, self.w.n_para, self.Cp, self.Cl, *self.stats)
             done = torch.cuda.Event()
             done.record(self.stream)
         slot["busy"] = done

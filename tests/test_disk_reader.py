@@ -10,11 +10,12 @@ import numpy as np
 import pytest
 import torch
 
-from realpdebench_amd.disk import ArrowTrajectories, FluidWindows, batch_plan, compute_mean_std
+from realpdebench_amd.disk import ArrowTrajectories, FluidWindows, batch_plan, compute_mean_std, open_windows
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "golden", "disk_small")
-CASES = ["cyl_num_train", "cyl_num_train_masked", "cyl_real_val", "cyl_num_test_ar", "cyl_real_test_unseen", "ctl_num_train"]
+CASES = ["cyl_num_train", "cyl_num_train_masked", "cyl_real_val", "cyl_num_test_ar", "cyl_real_test_unseen", "ctl_num_train",
+         "comb_num_train", "comb_real_test_ar"]
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +24,7 @@ def gold():
 
 
 def _windows(gold, key):
-    return FluidWindows(dataset_root=ROOT, **json.loads(str(gold[key + "/kw"])))
+    return open_windows(dataset_root=ROOT, **json.loads(str(gold[key + "/kw"])))
 
 
 def test_arrow_store_is_a_zero_copy_view():
@@ -94,6 +95,7 @@ def test_device_batches_are_normalised_like_the_reference(gold):
     w = _windows(gold, "ctl_num_train")
     torch.manual_seed(0)
     stats = (torch.randn(5), torch.randn(3), torch.rand(5) + 0.5, torch.tensor([0.7, 0.0, 1.3]))   # a zero std -> 1
+    assert (w.Cp, w.Cl, w.n_para) == (3, 0, 2)
     random.seed(1234)
     loader = DiskBatchLoader(w, 3, "cuda", stats=stats, shuffle=False, epochs=1)
     x = torch.cat([a.cpu() for a, _ in loader])
