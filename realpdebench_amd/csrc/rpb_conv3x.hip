@@ -618,21 +618,13 @@ __global__ __launch_bounds__(256, 1) void conv3x_wgrad_kernel(WgxArgs a) {
     int it = 0;
     for (long t0 = mb; t0 < me; t0 += WX_KT, ++it) {
         const unsigned* cur = ldsw + (it & 1) * WX_BUF;
-#ifdef WX_EXP_NOSTAGE
-        const bool more = false;
-#else
         const bool more = t0 + WX_KT < me;
-#endif
         if (more) stage_load(t0 + WX_KT, (it + 1) & 1);                 // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
         kstep(cur, 0);
         kstep(cur, 1);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef WX_EXP_NOSTORE
-        if (more && sv0.x == 0x12345u) stage_store(ldsw + ((it + 1) & 1) * WX_BUF);
-#else
         if (more) stage_store(ldsw + ((it + 1) & 1) * WX_BUF);
-#endif
         group_mask(it & 1);                                             // for chunk it + 2
         wg += WX_KT;
         while (wg >= a.W) wg -= a.W;
