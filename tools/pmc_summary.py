@@ -1,0 +1,14 @@
+#!/usr/bin/env python
+"""Average rocprofv3 --pmc counter values per kernel from a *_counter_collection.csv: pmc_summary.py FILE [substring]."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+sub = sys.argv[2] if len(sys.argv) > 2 else ""
+agg = collections.defaultdict(list)
+for r in rows:
+    if sub in r["Kernel_Name"]:
+        agg[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, c), v in sorted(agg.items()):
+    print(f"{k:60s} {c:28s} {sum(v) / len(v):16.0f}  x{len(v)}")
