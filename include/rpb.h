@@ -283,6 +283,14 @@ int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co
 int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
                     int in_step, int Hf, int Wf, int sub_s, int n_para, int Cp, int Cl, const float* mean_in,
                     const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream);
+/*     rpb_gemm_nt without the convolution modes on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip; fp32-grade: hi + mid +
+ *     lo, six products per fp32 product): out[M][ldo] = epilogue(A[M][lda] W^T) with W prepared once by rpb_gemm3x_wprep
+ *     (W[N][K] -> 3*N*K bf16 in MFMA operand order) and A split on its way into LDS (no extra pass).  Same epilogue arguments and
+ *     semantics as rpb_gemm_nt.  K % 64 == 0, N in {64, 128, 256 k}. */
+int rpb_gemm3x_wprep(const float* W, void* Wz, int N, int K, void* stream);
+int rpb_gemm3x(const float* A, const void* Wz, const float* bias, const float* addvec, const float* residual, float* out, long M,
+               int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask, long drop_seed,
+               float drop_keep, void* stream);
 /*     im2col of init_conv = nn.Conv3d(C_in, dim, KS, padding KS/2) (unet.py:404): col[m][tap*C_in + ci], ldc columns. */
 int rpb_im2col(const float* x, float* col, int B, int T, int H, int W, int Cin, int KS, int ldc, void* stream);
 /*     temporal attention over the T frames of a location (unet.py:280-356,388): qkv [B][T][HW][384], 4 heads x 32,

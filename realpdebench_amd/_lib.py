@@ -70,6 +70,8 @@ SIGNATURES = {
     "rpb_conv3x_wprep": (_I, "pp" + "ii" + "p"),
     "rpb_conv3x": (_I, "pppp" + "liii" + "iii" + "p"),
     "rpb_split3t": (_I, "pp" + "lii" + "iiii" + "p"),
+    "rpb_gemm3x_wprep": (_I, "pp" + "ii" + "p"),
+    "rpb_gemm3x": (_I, "pppppp" + "liiii" + "i" + "ppp" + "lf" + "p"),
     "rpb_conv3x_wgrad_splits": (_I, "lii"),
     "rpb_conv3x_wgrad": (_I, "ppp" + "lii" + "iii" + "p"),
     "rpb_window_pack": (_I, "ppppp" + "iiiiiiiii" + "pppp" + "p"),

@@ -228,19 +228,43 @@ def mul(a, b, out, n):
     _lib.call("rpb_mul", _p(a), _p(b), _p(out), n, _stream(), label="mul", nbytes=12 * n)
 
 
+GEMM_SPLIT = os.environ.get("RPB_GEMM_EXACT", "0") != "1"
+GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
+
+
+GEMM_SPLIT_MIN_K = 512                # measured: with K = 256 (4 LDS stages per 128-row tile) the epilogue of the one-wave-per-SIMD
+GEMM_SPLIT_MIN_N = 256                # kernel is as long as its MFMA phase and the fp32 kernel (2+ waves / SIMD) wins; K-split tiles too
+
+
+def gemm_split_ok(M, N, K, lda, ldo, conv):
+    return (GEMM_SPLIT and not conv and M >= GEMM_SPLIT_MIN_ROWS and K % 64 == 0 and K >= GEMM_SPLIT_MIN_K
+            and (N in (64, 128) or N % 256 == 0) and N >= GEMM_SPLIT_MIN_N and lda % 4 == 0 and ldo % 4 == 0)
+
+
 def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
             pre_out=None, mask=None, conv_mode=1, cls=0, drop=None):
     """out[M,N] = epilogue(A[M,K] @ W[N,K]^T); ``conv=(Hc,Wc,Dc)`` makes A an implicit im2col of a token tensor:
     ``conv_mode`` 1 = 3x3x3 padding 1, 2 = (1,4,4) stride (1,2,2) padding (0,1,1) (M = output tokens), 3 = parity class
     ``cls`` of the matching transposed convolution (M = input tokens).
     act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``); 3: ReLU; 4: ReLU'.
-    ``mask``: inverted-dropout multiplier tensor, or ``drop=(seed, keep)``: the same dropout generated in the epilogue."""
+    ``mask``: inverted-dropout multiplier tensor, or ``drop=(seed, keep)``: the same dropout generated in the epilogue.
+    Large plain GEMMs (K % 64 == 0, N = 64 / 128 / 256 k) run on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip:
+    fp32-grade accuracy, ~2x the fp32 MFMA rate); RPB_GEMM_EXACT=1 keeps everything on the exact-fp32 kernel."""
     hc, wc, dc = conv if conv else (0, 0, 0)
     mode = int(conv_mode) if conv else 0
     taps = {0: 1, 1: 27, 2: 16, 3: 4}[mode]
     lda = (K // taps) if lda is None else lda
+    ldo = N if ldo is None else ldo
+    if gemm_split_ok(M, N, K, lda, ldo, conv):
+        wsrc = W.t if isinstance(W, Sub) else W
+        wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
+        _lib.call("rpb_gemm3x_wprep", _p(W), _p(wz, torch.int16), N, K, _stream(), label="gemm3x_wprep", nbytes=10 * N * K)
+        _lib.call("rpb_gemm3x", _p(A), _p(wz, torch.int16), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda, ldo,
+                  int(act), _p(aux), _p(pre_out), _p(mask), int(drop[0]) if drop else 0, float(drop[1]) if drop else 0.0,
+                  _stream(), label=f"gemm3x[N{N},K{K}]", nbytes=4 * (M * lda + M * N + N * K), flops=2 * M * N * K)
+        return
     _lib.call("rpb_gemm_nt", _p(A), _p(W), _p(bias), _p(addvec), _p(residual), _p(out), M, N, K, lda,
-              N if ldo is None else ldo, int(act), _p(aux), _p(pre_out), _p(mask), mode, hc, wc, dc, int(cls),
+              ldo, int(act), _p(aux), _p(pre_out), _p(mask), mode, hc, wc, dc, int(cls),
               int(drop[0]) if drop else 0, float(drop[1]) if drop else 0.0, _stream(),
               label=f"gemm_nt[N{N},K{K},conv={mode}]", nbytes=4 * (M * lda + M * N + N * K),
               flops=2 * M * N * K)

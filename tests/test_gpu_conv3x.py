@@ -97,3 +97,40 @@ def test_exact_fp32_switch_takes_the_fp32_mfma_path(ops, monkeypatch):
     ref = F.conv3d(x.view(B, T, H, W, C).permute(0, 4, 1, 2, 3).double().cpu(),
                    w.view(C, 3, 3, 3, C).permute(0, 4, 1, 2, 3).double().cpu(), padding=1).permute(0, 2, 3, 4, 1).reshape(M, C)
     assert rel_l2(y.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 64, 64), (1000, 128, 192), (777, 256, 256), (130, 768, 64), (4100, 256, 1024)])
+def test_gemm3x_matches_fp64_and_the_fp32_kernel_epilogues(ops, monkeypatch, M, N, K):
+    """The split-bf16 dense GEMM (csrc/rpb_gemm3x.hip) behind ops.gemm_nt: every epilogue of rpb_gemm_nt, K-split variants
+    (N = 64, 128), ragged M; in-kernel dropout must drop the same elements as the exact-fp32 kernel (same Philox counters)."""
+    monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_ROWS", 0)
+    monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_K", 64)
+    monkeypatch.setattr(ops, "GEMM_SPLIT_MIN_N", 64)
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    bias, addv = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+    res, aux = torch.randn(M, N, device="cuda"), torch.randn(M, N, device="cuda")
+    ref = A.double().cpu() @ W.double().cpu().t()
+    assert ops.gemm_split_ok(M, N, K, K, N, None)
+    out, pre = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, W, out, M, N, K)
+    assert rel_l2(out.cpu(), ref) < 1e-6
+    ops.gemm_nt(A, W, out, M, N, K, bias=bias, act=1, pre_out=pre)                      # bias + GELU, pre-activation saved
+    z = ref + bias.double().cpu()
+    assert rel_l2(pre.cpu(), z) < 1e-6 and rel_l2(out.cpu(), F.gelu(z)) < 2e-6
+    ops.gemm_nt(A, W, out, M, N, K, act=2, aux=aux, residual=res)                       # * gelu'(aux) + residual
+    a64 = aux.double().cpu().requires_grad_(True)
+    F.gelu(a64).sum().backward()
+    assert rel_l2(out.cpu(), ref * a64.grad + res.double().cpu()) < 2e-6
+    ops.gemm_nt(A, W, out, M, N, K, bias=bias, act=3, addvec=addv)                      # ReLU + broadcast vector
+    assert rel_l2(out.cpu(), torch.relu(z) + addv.double().cpu()) < 1e-6
+    ops.gemm_nt(A, W, out, M, N, K, act=4, aux=aux)                                     # ReLU'
+    assert rel_l2(out.cpu(), torch.where(aux.double().cpu() > 0, ref, torch.zeros_like(ref))) < 1e-6
+    # in-kernel dropout: identical keep pattern and scale as the exact-fp32 kernel for the same (seed, keep)
+    ops.gemm_nt(A, W, out, M, N, K, bias=bias, drop=(1234, 0.7), residual=res)
+    monkeypatch.setattr(ops, "GEMM_SPLIT", False)
+    out32 = torch.empty_like(out)
+    ops.gemm_nt(A, W, out32, M, N, K, bias=bias, drop=(1234, 0.7), residual=res)
+    assert torch.equal((out - res) == 0, (out32 - res) == 0) or rel_l2(out.cpu(), out32.cpu()) < 2e-6
+    assert rel_l2(out.cpu(), out32.cpu()) < 2e-6

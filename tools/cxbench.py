@@ -97,6 +97,34 @@ def run_wgrad(B, mesh, Ci, Co, check, iters=3):
     ops.CONV3_SPLIT = True
 
 
+def run_gemm(M, N, K, iters=3):
+    torch.manual_seed(2)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    bias = torch.randn(N, device="cuda")
+    o1, o2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    for name, flag, o in (("gemm3x", True, o1), ("gemm_nt fp32", False, o2)):
+        ops.GEMM_SPLIT = flag
+        ops.gemm_nt(A, W, o, M, N, K, bias=bias, act=1)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            ops.gemm_nt(A, W, o, M, N, K, bias=bias, act=1)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        print(f"   {name:14s} M={M} N={N} K={K}: {ms:8.3f} ms   {2 * M * N * K / ms / 1e9:7.1f} TF/s-eq   "
+              f"{4 * M * (N + K) / ms / 1e6:7.0f} GB/s", flush=True)
+    ops.GEMM_SPLIT = True
+    print(f"   gemm3x vs fp32 kernel rel {rel(o1, o2):.2e}", flush=True)
+
+
+if os.environ.get("CX_GEMM", "0") == "1":
+    ops.GEMM_SPLIT_MIN_K = ops.GEMM_SPLIT_MIN_N = 64
+    for shp in ((2621440, 768, 256), (2621440, 256, 256), (2621440, 256, 768), (2621440, 128, 256), (655360, 1024, 256),
+                (655360, 256, 1024), (655360, 512, 256)):
+        run_gemm(*shp)
+    sys.exit(0)
 if os.environ.get("CX_WGRAD", "1") == "1":
     run_wgrad(2, (3, 5, 16), 64, 64, True)
     run_wgrad(1, (4, 6, 40), 128, 64, True)
