@@ -203,39 +203,50 @@ __global__ __launch_bounds__(256, 1) void conv3x_kernel(Conv3xArgs a) {
     };
     // one tap step = 4 row tiles x 12 MFMAs; the next tile's A operands (the next step's first tile when `more`) are read from
     // LDS before the current tile's MFMAs are issued -- with one wave per SIMD nobody else hides that latency
-    auto tap_step = [&](int s, int kw, bool more) __attribute__((always_inline)) {                    // kw is a compile-time constant at every call site
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            if (tm < 3) lda(s, kw, tm + 1, an);
-            else if (more) lda(kw == 2 ? s + KS : s, kw == 2 ? 0 : kw + 1, 0, an);
-            __builtin_amdgcn_sched_barrier(0);
-            if ((kw == 0 && wlo[tm]) || (kw == 2 && whi[tm])) ac[0] = ac[1] = ac[2] = z4;
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, ac[0]), am = __builtin_bit_cast(bf16x8, ac[1]),
-                         al = __builtin_bit_cast(bf16x8, ac[2]);
-            const bf16x8 b0h = __builtin_bit_cast(bf16x8, bc[0][0]), b0m = __builtin_bit_cast(bf16x8, bc[0][1]),
-                         b0l = __builtin_bit_cast(bf16x8, bc[0][2]), b1h = __builtin_bit_cast(bf16x8, bc[1][0]),
-                         b1m = __builtin_bit_cast(bf16x8, bc[1][1]), b1l = __builtin_bit_cast(bf16x8, bc[1][2]);
-            // small terms first; the two co tiles alternate so consecutive MFMAs are independent
-            acc[tm][0] = mfma_bf16(al, b0h, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(al, b1h, acc[tm][1]);
-            acc[tm][0] = mfma_bf16(ah, b0l, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(ah, b1l, acc[tm][1]);
-            acc[tm][0] = mfma_bf16(am, b0m, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(am, b1m, acc[tm][1]);
-            acc[tm][0] = mfma_bf16(am, b0h, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(am, b1h, acc[tm][1]);
-            acc[tm][0] = mfma_bf16(ah, b0m, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(ah, b1m, acc[tm][1]);
-            acc[tm][0] = mfma_bf16(ah, b0h, acc[tm][0]);
-            acc[tm][1] = mfma_bf16(ah, b1h, acc[tm][1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) ac[p] = an[p];
-        }
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bc[tn][p] = bn[tn][p];
+    // (the A tiles ping-pong between ac and an -- four tiles per step, so every step starts on ac -- and the B sets between bc and
+    // bn by step parity: no register copies)
+    auto mfma12 = [&](int tm, int kw, u32x4 (&av)[3], const u32x4 (&b)[2][3]) __attribute__((always_inline)) {
+        if ((kw == 0 && wlo[tm]) || (kw == 2 && whi[tm])) av[0] = av[1] = av[2] = z4;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[0]), am = __builtin_bit_cast(bf16x8, av[1]),
+                     al = __builtin_bit_cast(bf16x8, av[2]);
+        const bf16x8 b0h = __builtin_bit_cast(bf16x8, b[0][0]), b0m = __builtin_bit_cast(bf16x8, b[0][1]),
+                     b0l = __builtin_bit_cast(bf16x8, b[0][2]), b1h = __builtin_bit_cast(bf16x8, b[1][0]),
+                     b1m = __builtin_bit_cast(bf16x8, b[1][1]), b1l = __builtin_bit_cast(bf16x8, b[1][2]);
+        // small terms first; the two co tiles alternate so consecutive MFMAs are independent
+        acc[tm][0] = mfma_bf16(al, b0h, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(al, b1h, acc[tm][1]);
+        acc[tm][0] = mfma_bf16(ah, b0l, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(ah, b1l, acc[tm][1]);
+        acc[tm][0] = mfma_bf16(am, b0m, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(am, b1m, acc[tm][1]);
+        acc[tm][0] = mfma_bf16(am, b0h, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(am, b1h, acc[tm][1]);
+        acc[tm][0] = mfma_bf16(ah, b0m, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(ah, b1m, acc[tm][1]);
+        acc[tm][0] = mfma_bf16(ah, b0h, acc[tm][0]);
+        acc[tm][1] = mfma_bf16(ah, b1h, acc[tm][1]);
+    };
+    auto tap_step = [&](int s, int kw, bool more, const u32x4 (&b)[2][3]) __attribute__((always_inline)) {   // kw: compile-time constant
+        lda(s, kw, 1, an);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(0, kw, ac, b);
+        __builtin_amdgcn_sched_barrier(0);
+        lda(s, kw, 2, ac);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(1, kw, an, b);
+        __builtin_amdgcn_sched_barrier(0);
+        lda(s, kw, 3, an);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(2, kw, ac, b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) lda(kw == 2 ? s + KS : s, kw == 2 ? 0 : kw + 1, 0, ac);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(3, kw, an, b);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bsel = [&](auto pc) -> u32x4(&)[2][3] {
+        if constexpr (decltype(pc)::value) return bn;
+        else return bc;
     };
     // A staging registers: 13 x 16 B per thread, named individually (as an array indexed from helper lambdas they were demoted to
     // scratch memory: load, wait, spill -- one exposed HBM latency per load)
@@ -289,22 +300,28 @@ __global__ __launch_bounds__(256, 1) void conv3x_kernel(Conv3xArgs a) {
     if constexpr (SI < SPS) {                                                                                  \
         const int s = kp + SI * KS;                                                                            \
         const uint16_t* w0 = wbase + (long)(g * 3) * wtap + (long)(c * 4 + s) * wchunk;                        \
-        bload(w0 + wtap, bn);                                                                                  \
+        bload(w0 + wtap, bsel(IC<(SI * 3 + 1) & 1>{}));                                                        \
         if (more) stage_load(gn, cn, IC<(SI * 3 + 0) * NLD / NST>{}, IC<(SI * 3 + 1) * NLD / NST>{});          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        tap_step(s, 0, true);                                                                                  \
-        bload(w0 + 2 * wtap, bn);                                                                              \
+        tap_step(s, 0, true, bsel(IC<(SI * 3 + 0) & 1>{}));                                                    \
+        bload(w0 + 2 * wtap, bsel(IC<(SI * 3 + 2) & 1>{}));                                                    \
         if (more) stage_load(gn, cn, IC<(SI * 3 + 1) * NLD / NST>{}, IC<(SI * 3 + 2) * NLD / NST>{});          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        tap_step(s, 1, true);                                                                                  \
+        tap_step(s, 1, true, bsel(IC<(SI * 3 + 1) & 1>{}));                                                    \
         /* the step after (s, kw 2): next chunk of this stage, else the next stage's first chunk */            \
-        if (SI + 1 < SPS) bload(w0 + (long)KS * wchunk, bn);                                                   \
-        else if (more) bload(wbase + (long)(gn * 3) * wtap + (long)(cn * 4 + kp) * wchunk, bn);                \
+        if (SI + 1 < SPS) bload(w0 + (long)KS * wchunk, bsel(IC<(SI * 3 + 3) & 1>{}));                         \
+        else if (more) bload(wbase + (long)(gn * 3) * wtap + (long)(cn * 4 + kp) * wchunk, bsel(IC<(SI * 3 + 3) & 1>{})); \
         if (more) stage_load(gn, cn, IC<(SI * 3 + 2) * NLD / NST>{}, IC<(SI * 3 + 3) * NLD / NST>{});          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        tap_step(s, 2, SI + 1 < SPS);                                                                          \
+        tap_step(s, 2, SI + 1 < SPS, bsel(IC<(SI * 3 + 2) & 1>{}));                                            \
     }
             CX_SI_BLOCK(0) CX_SI_BLOCK(1) CX_SI_BLOCK(2) CX_SI_BLOCK(3)
+            if constexpr (NST & 1) {                                    // odd step count (N = 64): the next stage's first B set is in bn
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bc[tn][p] = bn[tn][p];
+            }
             if (more) stage_store(lds4 + (buf ^ 1) * 24 * CX_ROWS);
             __syncthreads();                                            // everyone is done with buf and has filled buf ^ 1
             buf ^= 1;
@@ -315,41 +332,48 @@ __global__ __launch_bounds__(256, 1) void conv3x_kernel(Conv3xArgs a) {
 #undef CX_LOAD
 #undef CX_DECL
 #undef CX_FOR13
-    // ---- K-split partial sums through LDS (one 32-token row tile at a time), then bias + store by the kp == 0 waves
-    float* red = reinterpret_cast<float*>(lds4);                        // [(KS-1) * WN slots][2 tiles][16 regs][64 lanes]
+    // ---- K-split partial sums through LDS in ONE round: the KS waves of a column group own the four 32-token row tiles round-robin
+    // (tile tm belongs to wave tm % KS); every wave parks its partials of the tiles it does not own, one barrier, every wave sums
+    // and stores its own tiles.  (A first version let the kp == 0 waves reduce and store all four tiles, one tile and two
+    // barriers at a time: measured 38 k of the 116 k cycles of a Ci = 64, N = 64 workgroup.)
+    float* red = reinterpret_cast<float*>(lds4);                        // [WN][4 tiles][KS - 1 sources][2 col tiles][16 regs][64 lanes]
+    if (KS > 1) {
+        __syncthreads();                                                // the last stage's LDS reads are done
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        if (KS > 1) {
-            __syncthreads();
-            if (kp > 0) {
-                float* slot = red + ((kp - 1) * WN + nw) * 2048;
+        for (int tm = 0; tm < 4; ++tm) {
+            const int owner = tm % KS;
+            if (kp != owner) {
+                const int rank = kp < owner ? kp : kp - 1;
+                float* slot = red + ((nw * 4 + tm) * (KS - 1) + rank) * 2048;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) slot[(tn * 16 + r) * 64 + lane] = acc[tm][tn][r];
             }
-            __syncthreads();
-            if (kp == 0) {
+        }
+        __syncthreads();
+    }
 #pragma unroll
-                for (int k2 = 1; k2 < KS; ++k2) {
-                    const float* slot = red + ((k2 - 1) * WN + nw) * 2048;
+    for (int tm = 0; tm < 4; ++tm) {
+        if (KS > 1 && kp != tm % KS) continue;
+        if (KS > 1) {
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
+            for (int k2 = 0; k2 < KS - 1; ++k2) {
+                const float* slot = red + ((nw * 4 + tm) * (KS - 1) + k2) * 2048;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[tm][tn][r] += slot[(tn * 16 + r) * 64 + lane];
-                }
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += slot[(tn * 16 + r) * 64 + lane];
             }
         }
-        if (kp == 0) {
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int n = n0 + tn * 32 + col;
-                const float bv = a.bias ? a.bias[n] : 0.f;
+        for (int tn = 0; tn < 2; ++tn) {
+            const int n = n0 + tn * 32 + col;
+            const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long m = m0 + tm * 32 + mfma_row(lane, r);
-                    if (m < a.M) a.out[m * a.ldo + n] = acc[tm][tn][r] + bv;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + tm * 32 + mfma_row(lane, r);
+                if (m < a.M) a.out[m * a.ldo + n] = acc[tm][tn][r] + bv;
             }
         }
     }
