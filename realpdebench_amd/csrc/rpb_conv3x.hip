@@ -787,50 +787,55 @@ __global__ __launch_bounds__(256, 1) void conv3x_wgrad_ring_kernel(WgrArgs a) {
     auto stage_store = [&](int xpos, bool gon, bool xon) __attribute__((always_inline)) { WR_FOR8(WR_STORE) };
 
     int wg = (int)((mb + 8 * half) % a.W);
-    auto kstep = [&](int ks, int vb, int xp0, int xp1, int xp2) __attribute__((always_inline)) {
+    // one k-step = 16 tokens, in two halves so that the operands of step i + 1 (LDS reads, alignbit / and fix-ups) are prepared
+    // in the same scheduling region as the 54 MFMAs of step i (in-kernel cycle counters: 5.8 k cycles per 32-token chunk for
+    // 3.5 k cycles of MFMA issue when every step first prepared and then multiplied)
+    struct Ops {
+        u32x4 ga[3], g0[3], g2[3], xb[3][3];
+    };
+    auto prep = [&](int ks, int vb, int xp0, int xp1, int xp2, Ops& o_) __attribute__((always_inline)) {
         int wpos = wg + ks * 16;
         while (wpos >= a.W) wpos -= a.W;
         const unsigned m0 = wpos + 8 == a.W ? 0x0000FFFFu : 0xFFFFFFFFu;
         const unsigned m2 = wpos == 0 ? 0xFFFF0000u : 0xFFFFFFFFu;
-        u32x4 ga[3], g0[3], g2[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned* gr = Gs + (p * 64 + o * 32 + col) * WX_GROW + 4 + ks * 8 + half * 4;
             const u32x4 x = *reinterpret_cast<const u32x4*>(gr);
             const unsigned xm = gr[-1], xn = gr[4];
-            ga[p] = x;
-            g0[p].x = __builtin_amdgcn_alignbit(x.y, x.x, 16);
-            g0[p].y = __builtin_amdgcn_alignbit(x.z, x.y, 16);
-            g0[p].z = __builtin_amdgcn_alignbit(x.w, x.z, 16);
-            g0[p].w = __builtin_amdgcn_alignbit(xn, x.w, 16) & m0;
-            g2[p].x = __builtin_amdgcn_alignbit(x.x, xm, 16) & m2;
-            g2[p].y = __builtin_amdgcn_alignbit(x.y, x.x, 16);
-            g2[p].z = __builtin_amdgcn_alignbit(x.z, x.y, 16);
-            g2[p].w = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+            o_.ga[p] = x;
+            o_.g0[p].x = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+            o_.g0[p].y = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            o_.g0[p].z = __builtin_amdgcn_alignbit(x.w, x.z, 16);
+            o_.g0[p].w = __builtin_amdgcn_alignbit(xn, x.w, 16) & m0;
+            o_.g2[p].x = __builtin_amdgcn_alignbit(x.x, xm, 16) & m2;
+            o_.g2[p].y = __builtin_amdgcn_alignbit(x.y, x.x, 16);
+            o_.g2[p].z = __builtin_amdgcn_alignbit(x.z, x.y, 16);
+            o_.g2[p].w = __builtin_amdgcn_alignbit(x.w, x.z, 16);
         }
-        if (do_bias) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) accb = mfma_bf16(__builtin_bit_cast(bf16x8, ga[p]), __builtin_bit_cast(bf16x8, ones), accb);
-        }
-        u32x4 xb[3][3];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int xp = kh == 0 ? xp0 : (kh == 1 ? xp1 : xp2);      // ring position (tokens) of window kh
+            const int xp = kh == 0 ? xp0 : (kh == 1 ? xp1 : xp2);
             const unsigned vm = (unsigned)Vt[vb * 12 + kh * 4 + ks * 2 + half];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 u32x4 x = *reinterpret_cast<const u32x4*>(Xr + (p * 64 + c * 32 + col) * RS + (xp >> 1) + ks * 8 + half * 4);
                 x.x &= vm; x.y &= vm; x.z &= vm; x.w &= vm;
-                xb[kh][p] = x;
+                o_.xb[kh][p] = x;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&](const Ops& o_) __attribute__((always_inline)) {
+        if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) accb = mfma_bf16(__builtin_bit_cast(bf16x8, o_.ga[p]), __builtin_bit_cast(bf16x8, ones), accb);
+        }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-#define WX_MF(PA, PB)                                                                                                             \
-    acc[kh * 3 + 0] = mfma_bf16(__builtin_bit_cast(bf16x8, g0[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 0]);    \
-    acc[kh * 3 + 1] = mfma_bf16(__builtin_bit_cast(bf16x8, ga[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 1]);    \
-    acc[kh * 3 + 2] = mfma_bf16(__builtin_bit_cast(bf16x8, g2[PA]), __builtin_bit_cast(bf16x8, xb[kh][PB]), acc[kh * 3 + 2]);
+#define WX_MF(PA, PB)                                                                                                                   \
+    acc[kh * 3 + 0] = mfma_bf16(__builtin_bit_cast(bf16x8, o_.g0[PA]), __builtin_bit_cast(bf16x8, o_.xb[kh][PB]), acc[kh * 3 + 0]);    \
+    acc[kh * 3 + 1] = mfma_bf16(__builtin_bit_cast(bf16x8, o_.ga[PA]), __builtin_bit_cast(bf16x8, o_.xb[kh][PB]), acc[kh * 3 + 1]);    \
+    acc[kh * 3 + 2] = mfma_bf16(__builtin_bit_cast(bf16x8, o_.g2[PA]), __builtin_bit_cast(bf16x8, o_.xb[kh][PB]), acc[kh * 3 + 2]);
             WX_MF(2, 0) WX_MF(0, 2) WX_MF(1, 1) WX_MF(1, 0) WX_MF(0, 1) WX_MF(0, 0)
 #undef WX_MF
         }
@@ -856,8 +861,13 @@ __global__ __launch_bounds__(256, 1) void conv3x_wgrad_ring_kernel(WgrArgs a) {
         int xp1 = xw + a.W, xp2 = xw + 2 * a.W;
         if (xp1 >= RL) xp1 -= RL;
         if (xp2 >= RL) xp2 -= RL;
-        kstep(0, it & 1, xw, xp1, xp2);
-        kstep(1, it & 1, xw, xp1, xp2);
+        Ops o0, o1;
+        prep(0, it & 1, xw, xp1, xp2, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        prep(1, it & 1, xw, xp1, xp2, o1);                              // same region as the MFMAs of step 0
+        mma(o0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(o1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                                // everyone is done with G, window 0 and the validity table
         // the next chunk's new tokens overwrite this chunk's window 0: ring slot (xw + 2 W + 32) mod RL == xw
