@@ -61,9 +61,11 @@ def test_conv3x_forward_vs_fp64(ops, B, mesh, Ci, Co):
 
 
 @pytest.mark.parametrize("B,mesh,Ci,Co", [(2, (3, 5, 16), 64, 64), (1, (4, 6, 40), 128, 64), (1, (2, 9, 24), 64, 128),
-                                          (2, (16, 6, 5), 64, 64), (1, (3, 3, 32), 64, 192)])
+                                          (2, (16, 6, 5), 64, 64), (1, (3, 3, 32), 64, 192), (2, (2, 3, 64), 64, 64),
+                                          (1, (2, 2, 128), 128, 64)])
 def test_conv3x_weight_gradient_vs_fp64(ops, B, mesh, Ci, Co):
-    """Also the mesh whose innermost dimension is not a multiple of 8 (reversed token order, Transolver's 128 x 64 x 20 case)."""
+    """Also the mesh whose innermost dimension is not a multiple of 8 (reversed token order, Transolver's 128 x 64 x 20 case) and
+    innermost sizes 32 / 64 / 128, which take the kernel that keeps the X rows in an LDS ring."""
     T, H, W = mesh
     M = B * T * H * W
     K = 27 * Ci
