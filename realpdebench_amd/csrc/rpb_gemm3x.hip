@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256, 1) void gemm3x_kernel(Gemm3xArgs a) {
 
     // epilogue scratch lives behind the two stage buffers (the next tile's first stage is already in one of them)
     float* red = reinterpret_cast<float*>(lds4 + 2 * 24 * G3_BM);       // [(KS-1) * WN slots][2 tiles][16 regs][64 lanes] <= 24 KB
-    float* tb = red + 6144 + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
     // ---- K-split partial sums through LDS, then the epilogue by the kp == 0 waves (wave-private [32][36] tile, 16 B per lane)
     auto reduce_tile = [&](f32x16& c0, f32x16& c1) __attribute__((always_inline)) {
@@ -209,53 +208,76 @@ __global__ __launch_bounds__(256, 1) void gemm3x_kernel(Gemm3xArgs a) {
             }
         }
     };
-    auto epilogue_tile = [&](const f32x16& cv, int tm, int tn) __attribute__((always_inline)) {
-        const int n = n0 + tn * 32 + ec;
-        f32x4 badd = zf, vadd = zf;
-        if (a.bias) badd = *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (a.addvec) vadd = *reinterpret_cast<const f32x4*>(a.addvec + n);
+    // Epilogue in two phases of four 32 x 32 tiles: the accumulators are parked in wave-private LDS tiles ([32][36] floats) and ONE
+    // rolled loop applies bias / activation / dropout / residual and stores 16 B per lane.  (Fully unrolled, the 32 copies of the
+    // activation + Philox code made the kernel 80 KB -- more than the 64 KB instruction cache two CUs share -- and an epilogue took
+    // 31 k cycles per tile; the kernel is ~25 KB now.)  Parking space: the stage buffer that does NOT hold the next tile's first
+    // stage (waves 0, 1) and the scratch area behind the buffers (waves 2, 3).
+    auto park = [&](float* pt, const f32x16& cv) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tb[mfma_row(lane, r) * 36 + col] = cv[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int r = 0; r < 16; ++r) pt[mfma_row(lane, r) * 36 + col] = cv[r];
+    };
+    auto epilogue_phase = [&](const float* pbase, int tm0) __attribute__((always_inline)) {   // tiles (tm0 + i / 2, i % 2), i = 0..3
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            const int ti = it >> 2, q = it & 3;
+            const int tm = tm0 + (ti >> 1), tn = ti & 1;
             const int row = q * 8 + er;
             const long m = m0 + tm * 32 + row;
-            if (m < a.M) {
-                const long off = m * a.ldo + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(tb + row * 36 + ec) + badd;
-                if (a.act == 1) {
-                    if (a.pre_out) *reinterpret_cast<f32x4*>(a.pre_out + off) = v;
+            if (m >= a.M) continue;
+            const int n = n0 + tn * 32 + ec;
+            const long off = m * a.ldo + n;
+            f32x4 v = *reinterpret_cast<const f32x4*>(pbase + ti * (32 * 36) + row * 36 + ec);
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.act == 1) {
+                if (a.pre_out) *reinterpret_cast<f32x4*>(a.pre_out + off) = v;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
-                } else if (a.act == 2) {
-                    const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + off);
+                for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+            } else if (a.act == 2) {
+                const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + off);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(ax[k]);
-                } else if (a.act == 3) {
+                for (int k = 0; k < 4; ++k) v[k] *= gelu_grad_f(ax[k]);
+            } else if (a.act == 3) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                } else if (a.act == 4) {
-                    const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + off);
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            } else if (a.act == 4) {
+                const f32x4 ax = *reinterpret_cast<const f32x4*>(a.aux + off);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = ax[k] > 0.f ? v[k] : 0.f;
-                }
-                if (a.mask) v = v * *reinterpret_cast<const f32x4*>(a.mask + off);
-                if (a.drop.thr) v = v * dropout4(a.drop, (unsigned long long)off >> 2);
-                v += vadd;
-                if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + off);
-                *reinterpret_cast<f32x4*>(a.out + off) = v;
+                for (int k = 0; k < 4; ++k) v[k] = ax[k] > 0.f ? v[k] : 0.f;
             }
+            if (a.mask) v = v * *reinterpret_cast<const f32x4*>(a.mask + off);
+            if (a.drop.thr) v = v * dropout4(a.drop, (unsigned long long)off >> 2);
+            if (a.addvec) v += *reinterpret_cast<const f32x4*>(a.addvec + n);
+            if (a.residual) v += *reinterpret_cast<const f32x4*>(a.residual + off);
+            *reinterpret_cast<f32x4*>(a.out + off) = v;
         }
-        __builtin_amdgcn_wave_barrier();
     };
-#define G3_TILE(TM)                              \
-    reduce_tile(acc[TM][0], acc[TM][1]);         \
-    if (kp == 0) {                               \
-        epilogue_tile(acc[TM][0], TM, 0);        \
-        epilogue_tile(acc[TM][1], TM, 1);        \
+#define G3_EPILOGUE                                                                                              \
+    {                                                                                                            \
+        reduce_tile(acc[0][0], acc[0][1]);                                                                       \
+        reduce_tile(acc[1][0], acc[1][1]);                                                                       \
+        reduce_tile(acc[2][0], acc[2][1]);                                                                       \
+        reduce_tile(acc[3][0], acc[3][1]);                                                                       \
+        if (KS > 1) __syncthreads(); /* the K-split slots (scratch area) are free again */                       \
+        float* pbase = wave < 2 ? reinterpret_cast<float*>(lds4 + (buf ^ 1) * 24 * G3_BM) + wave * (4 * 32 * 36)  \
+                                : red + (wave - 2) * (4 * 32 * 36);                                              \
+        if (kp == 0) {                                                                                           \
+            park(pbase + 0 * (32 * 36), acc[0][0]);                                                              \
+            park(pbase + 1 * (32 * 36), acc[0][1]);                                                              \
+            park(pbase + 2 * (32 * 36), acc[1][0]);                                                              \
+            park(pbase + 3 * (32 * 36), acc[1][1]);                                                              \
+            __builtin_amdgcn_wave_barrier();                                                                     \
+            epilogue_phase(pbase, 0);                                                                            \
+            __builtin_amdgcn_wave_barrier();                                                                     \
+            park(pbase + 0 * (32 * 36), acc[2][0]);                                                              \
+            park(pbase + 1 * (32 * 36), acc[2][1]);                                                              \
+            park(pbase + 2 * (32 * 36), acc[3][0]);                                                              \
+            park(pbase + 3 * (32 * 36), acc[3][1]);                                                              \
+            __builtin_amdgcn_wave_barrier();                                                                     \
+            epilogue_phase(pbase, 2);                                                                            \
+        }                                                                                                        \
+        __syncthreads(); /* parking space is a stage buffer: free it before the next tile's second stage lands */ \
     }
-#define G3_EPILOGUE G3_TILE(0) G3_TILE(1) G3_TILE(2) G3_TILE(3)
     bload(wbase + (long)kp * wchunk, bc);
     stage_load(m0, 0, G3IC<0>{}, G3IC<4>{});
     stage_store(lds4);
@@ -291,7 +313,6 @@ __global__ __launch_bounds__(256, 1) void gemm3x_kernel(Gemm3xArgs a) {
         G3_EPILOGUE
     }
 #undef G3_EPILOGUE
-#undef G3_TILE
 #undef G3_SI_BLOCK
 #undef G3_STORE
 #undef G3_LOAD

@@ -232,8 +232,8 @@ GEMM_SPLIT = os.environ.get("RPB_GEMM_EXACT", "0") != "1"
 GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
 
 
-GEMM_SPLIT_MIN_K = 512                # measured: with K = 256 (4 LDS stages per 128-row tile) the epilogue of the one-wave-per-SIMD
-GEMM_SPLIT_MIN_N = 256                # kernel is as long as its MFMA phase and the fp32 kernel (2+ waves / SIMD) wins; K-split tiles too
+GEMM_SPLIT_MIN_K = int(os.environ.get("RPB_GEMM_SPLIT_MIN_K", 256))                # K = 256 (4 LDS stages per 128-row tile): 110-117 vs 104-108 TF/s, larger K 145-160 vs 120-125;
+GEMM_SPLIT_MIN_N = 256                # the K-split tiles of N = 64 / 128 lose to the fp32 kernel (64 vs 96 TF/s)
 
 
 def gemm_split_ok(M, N, K, lda, ldo, conv):
