@@ -279,9 +279,10 @@ int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co
  *     [::sub_s, ::sub_s], channel stack, masking (flags[b][c] == 0 -> planar channel c is zeros, flags[b][3] == 0 -> the cl block is),
  *     ControlledCylinder's parameter channels (flags[b][4 + k]) -- realpdebench/data/fluid_hf_dataset.py:280-335,
  *     data/combustion_hf_dataset.py:268-320 -- and GaussianNormalizer.preprocess (data/data_normalizer.py:50-55) fused.
- *     flags is [B][4 + max(n_para, 1)]. */
+ *     flags is [B][4 + max(n_para, 1)].  rows_subsampled != 0: the staged slabs already hold every sub_s-th row (Hf = the
+ *     sub-sampled height; the host copies whole rows, which halves its traffic for sub_s = 2), only columns are strided. */
 int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
-                    int in_step, int Hf, int Wf, int sub_s, int n_para, int Cp, int Cl, const float* mean_in,
+                    int in_step, int Hf, int Wf, int sub_s, int rows_subsampled, int n_para, int Cp, int Cl, const float* mean_in,
                     const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream);
 /*     rpb_gemm_nt without the convolution modes on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip; fp32-grade: hi + mid +
  *     lo, six products per fp32 product): out[M][ldo] = epilogue(A[M][lda] W^T) with W prepared once by rpb_gemm3x_wprep

@@ -17,7 +17,7 @@ struct WindowPackArgs {
     const float* std_in;
     const float* std_tgt;
     long ntok;             // B * horizon * H * W
-    int horizon, in_step, Hf, Wf, H, W, sub_s, n_para, nflag, Cp, Cl;
+    int horizon, in_step, Hf, Wf, H, W, sub_s, sub_h, n_para, nflag, Cp, Cl;   // sub_h: row stride in the staged slab (1 if the host already kept every sub_s-th row)
 };
 
 __global__ __launch_bounds__(256) void window_pack_kernel(WindowPackArgs a) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void window_pack_kernel(WindowPackArgs a) {
         r -= (long)t * a.H * a.W;
         const int h = (int)(r / a.W), w = (int)(r - (long)h * a.W);
         const float* fl = a.flags + b * a.nflag;
-        const long pix = (long)h * a.sub_s * a.Wf + (long)w * a.sub_s;                      // [::sub_s, ::sub_s]
+        const long pix = (long)h * a.sub_h * a.Wf + (long)w * a.sub_s;                      // [::sub_s, ::sub_s]
         const float* src = a.planar + (b * a.Cp * a.horizon + t) * (long)a.Hf * a.Wf + pix;
         const long cstride = (long)a.horizon * a.Hf * a.Wf;
         const float* srcl = a.cl ? a.cl + ((b * a.horizon + t) * (long)a.Hf * a.Wf + pix) * a.Cl : nullptr;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void window_pack_kernel(WindowPackArgs a) {
 }
 
 extern "C" int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
-                               int in_step, int Hf, int Wf, int sub_s, int n_para, int Cp, int Cl, const float* mean_in,
+                               int in_step, int Hf, int Wf, int sub_s, int rows_subsampled, int n_para, int Cp, int Cl, const float* mean_in,
                                const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream) {
     RPB_REQUIRE(planar && flags && inp && tgt && mean_in && mean_tgt && std_in && std_tgt, "window_pack: null pointer");
     RPB_REQUIRE(Cp >= 1 && Cp <= 3 && Cl >= 0 && (Cl == 0) == (cl == nullptr), "window_pack: Cp=%d Cl=%d (planar channels 1..3; a channels-last block iff Cl > 0)", Cp, Cl);
@@ -58,7 +58,8 @@ extern "C" int rpb_window_pack(const float* planar, const float* cl, const float
     a.planar = planar; a.cl = cl; a.flags = flags; a.inp = inp; a.tgt = tgt; a.Cp = Cp; a.Cl = Cl;
     a.mean_in = mean_in; a.mean_tgt = mean_tgt; a.std_in = std_in; a.std_tgt = std_tgt;
     a.horizon = horizon; a.in_step = in_step; a.Hf = Hf; a.Wf = Wf; a.sub_s = sub_s; a.n_para = n_para;
-    a.H = (Hf + sub_s - 1) / sub_s;                                      // len(range(0, Hf, sub_s)) = numpy's [::sub_s]
+    a.sub_h = rows_subsampled ? 1 : sub_s;                               // Hf = rows present in the staged slab
+    a.H = rows_subsampled ? Hf : (Hf + sub_s - 1) / sub_s;               // len(range(0, Hf, sub_s)) = numpy's [::sub_s]
     a.W = (Wf + sub_s - 1) / sub_s;
     a.nflag = 4 + (n_para > 1 ? n_para : 1);
     a.ntok = (long)B * horizon * a.H * a.W;

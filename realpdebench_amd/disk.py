@@ -52,6 +52,8 @@ class ArrowTrajectories:
             files = [d["filename"] for d in json.load(fh)["_data_files"]]
         self._maps, self._tables = [], []
         self._where = {}                                    # sim_id -> (table index, row)
+        self._views, self._shapes = {}, {}                  # (sim_id, name) -> numpy view; cells never change, and locating one
+                                                            # through the chunk list costs ~2 ms (3 per sample, on the serial path)
         for f in files:
             mm = pa.memory_map(os.path.join(path, f), "r")
             table = pa.ipc.open_stream(mm).read_all()
@@ -80,12 +82,18 @@ class ArrowTrajectories:
         raise IndexError(sim_id)
 
     def shape(self, sim_id):
-        return tuple(int(self._cell(sim_id, k).as_py()) for k in ("shape_t", "shape_h", "shape_w"))
+        s = self._shapes.get(sim_id)
+        if s is None:
+            s = self._shapes[sim_id] = tuple(int(self._cell(sim_id, k).as_py()) for k in ("shape_t", "shape_h", "shape_w"))
+        return s
 
-    def array(self, sim_id, name):
-        """float32 ``[shape_t, shape_h, shape_w]`` view of a binary cell (read-only, backed by the memory map)."""
-        buf = self._cell(sim_id, name).as_buffer()
-        return np.frombuffer(buf, dtype=np.float32).reshape(self.shape(sim_id))
+    def array(self, sim_id, name, trailing=()):
+        """float32 ``[shape_t, shape_h, shape_w, *trailing]`` view of a binary cell (read-only, backed by the memory map)."""
+        a = self._views.get((sim_id, name))
+        if a is None:
+            buf = self._cell(sim_id, name).as_buffer()
+            a = self._views[(sim_id, name)] = np.frombuffer(buf, dtype=np.float32).reshape(*self.shape(sim_id), *trailing)
+        return a
 
 
 class FluidWindows:
@@ -212,9 +220,7 @@ class CombustionWindows(FluidWindows):
         obs = self.store.array(sid, "observed")[t0:t0 + self.horizon]
         num = None
         if self.dataset_type != "real" and not (random.random() < self.mask_prob):       # combustion_hf_dataset.py:303-316
-            nch = int(self.store._cell(sid, "numerical_channels").as_py())
-            buf = self.store._cell(sid, "numerical").as_buffer()
-            num = np.frombuffer(buf, dtype=np.float32).reshape(*self.store.shape(sid), nch)[t0:t0 + self.horizon]
+            num = self.store.array(sid, "numerical", trailing=(-1,))[t0:t0 + self.horizon]
         return [obs], num, []
 
     def __getitem__(self, idx):
@@ -287,8 +293,10 @@ class DiskBatchLoader:
         self.w, self.B, self.device = windows, int(batch_size), torch.device(device)
         self.rank, self.world, self.shuffle, self.seed = rank, world, shuffle, seed
         self.drop_last, self.epochs = drop_last, epochs
-        T_full, self.Hf, self.Wf = windows.full_shape()
+        T_full, hf, self.Wf = windows.full_shape()
         self.H, self.W = windows.out_shape()
+        self.Hf = self.H                       # the host keeps every sub_s-th ROW (whole rows: contiguous copies, 1 / sub_s of the bytes);
+                                               # the column stride is applied by rpb_window_pack
         self.Cp, self.Cl = windows.Cp, windows.Cl
         self.c_in, self.c_out = self.Cp + self.Cl + windows.n_para, self.Cp + self.Cl
         self.horizon, self.in_step = windows.horizon, windows.in_step
@@ -317,8 +325,8 @@ class DiskBatchLoader:
         self._q = queue.Queue(maxsize=depth)
         self._stop = False
         # slab -> pinned copies of one batch run on a small thread pool (numpy releases the GIL): measured on the 16-core GPU box
-        # (tools/diskbench.py, numerical cylinder data at 128 x 256, 15 MiB per sample) 199 samples/s with one thread, 335 with four
-        # (5.3 GB/s out of the page cache; more threads do not add); the sample order and the pressure-mask draws stay serial
+        # (tools/diskbench.py, numerical cylinder data at 128 x 256, 15 MiB per sample) 1.6 k samples/s with one thread, 5.1 k with four
+        # (page-cached data; eight threads 6.3 k, sixteen fewer); the sample order and the pressure-mask draws stay serial
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(copy_threads)))
         self._thread = threading.Thread(target=self._producer, daemon=True)
@@ -348,12 +356,13 @@ class DiskBatchLoader:
                 jobs = []
                 for b, i in enumerate(idxs):
                     planar, cl, para = self.w.slabs(i)                   # serial: consumes the `random` stream in sample order
+                    ss = self.w.sub_s
                     for c, arr in enumerate(planar):
                         if arr is not None:
-                            jobs.append(self._pool.submit(np.copyto, host[b, c], arr))
+                            jobs.append(self._pool.submit(np.copyto, host[b, c], arr[:, ::ss]))
                             flags[b, c] = 1.0
                     if cl is not None:
-                        jobs.append(self._pool.submit(np.copyto, hostl[b], cl))
+                        jobs.append(self._pool.submit(np.copyto, hostl[b], cl[:, ::ss]))
                         flags[b, 3] = 1.0
                     for k, x in enumerate(para):
                         flags[b, 4 + k] = x
@@ -391,7 +400,7 @@ class DiskBatchLoader:
                     if d is not None:
                         d.addcmul_(d, torch.randn_like(d), value=self.w.noise_scale)
             self.ops.window_pack(slot["dev"], slot["devl"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf,
-                                 self.Wf, self.w.sub_s, self.w.n_para, self.Cp, self.Cl, *self.stats)
+                                 self.Wf, self.w.sub_s, self.w.n_para, self.Cp, self.Cl, *self.stats, rows_subsampled=True)
             done = torch.cuda.Event()
             done.record(self.stream)
         slot["busy"] = done

@@ -498,11 +498,11 @@ def conv3(x, W, out, M, N, Ci, mesh, bias=None, ldx=None):
 
 
 def window_pack(planar, cl, flags, inp, tgt, B, horizon, in_step, Hf, Wf, sub_s, n_para, Cp, Cl, mean_in, mean_tgt, std_in,
-                std_tgt):
+                std_tgt, rows_subsampled=False):
     """Arrow time slabs (planar cells + optional channels-last cell) -> normalised channels-last (input, target) batch in one
     HBM pass (disk.DiskBatchLoader)."""
-    _lib.call("rpb_window_pack", _p(planar), _p(cl), _p(flags), _p(inp), _p(tgt), B, horizon, in_step, Hf, Wf, sub_s, n_para,
-              Cp, Cl, _p(mean_in), _p(mean_tgt), _p(std_in), _p(std_tgt), _stream(), label="window_pack",
+    _lib.call("rpb_window_pack", _p(planar), _p(cl), _p(flags), _p(inp), _p(tgt), B, horizon, in_step, Hf, Wf, sub_s,
+              int(rows_subsampled), n_para, Cp, Cl, _p(mean_in), _p(mean_tgt), _p(std_in), _p(std_tgt), _stream(), label="window_pack",
               nbytes=4 * (planar.numel() + (cl.numel() if cl is not None else 0) + inp.numel() + tgt.numel()))
 
 

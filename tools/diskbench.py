@@ -52,8 +52,8 @@ try:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         loader.close()
-        per = w.horizon * H * W * 3 * 4
-        print(f"copy threads {threads:2d}: {STEPS * B / dt:8.1f} samples/s   {STEPS * B * per / dt / 1e9:6.2f} GB/s host slabs -> pinned   "
+        per = w.horizon * (H // w.sub_s) * W * 3 * 4                    # every sub_s-th row of u, v, p (p only when not masked)
+        print(f"copy threads {threads:2d}: {STEPS * B / dt:8.1f} samples/s   {STEPS * B * per / dt / 1e9:6.2f} GB/s (upper bound: p is masked half the time) host rows -> pinned   "
               f"batch {tuple(x.shape)} / {tuple(y.shape)}")
 finally:
     shutil.rmtree(root, ignore_errors=True)
