@@ -284,6 +284,12 @@ int rpb_conv3x_wgrad(const void* Gt, const void* Xt, float* part, long M, int Co
 int rpb_window_pack(const float* planar, const float* cl, const float* flags, float* inp, float* tgt, int B, int horizon,
                     int in_step, int Hf, int Wf, int sub_s, int rows_subsampled, int n_para, int Cp, int Cl, const float* mean_in,
                     const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream);
+/*     combustion surrogate samples (realpdebench/data/combustion_surrogate_hf_dataset.py:213-243 +
+ *     data/data_normalizer.py:50-55 / :126-131): num [B][ntok][Cl] (the `numerical` windows, channels last) + para [B][n_para]
+ *     (numbers parsed from sim_id, appended as constant channels) -> inp [B][ntok][Cl + n_para]; real [B][ntok] -> tgt [B][ntok][1];
+ *     both (x - mean) / std per channel (RangeNormalizer: mean = 0, std = max). */
+int rpb_pair_pack(const float* num, const float* real, const float* para, float* inp, float* tgt, int B, long ntok, int Cl,
+                  int n_para, const float* mean_in, const float* mean_tgt, const float* std_in, const float* std_tgt, void* stream);
 /*     rpb_gemm_nt without the convolution modes on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip; fp32-grade: hi + mid +
  *     lo, six products per fp32 product): out[M][ldo] = epilogue(A[M][lda] W^T) with W prepared once by rpb_gemm3x_wprep
  *     (W[N][K] -> 3*N*K bf16 in MFMA operand order) and A split on its way into LDS (no extra pass).  Same epilogue arguments and

@@ -75,6 +75,7 @@ SIGNATURES = {
     "rpb_conv3x_wgrad_splits": (_I, "lii"),
     "rpb_conv3x_wgrad": (_I, "ppp" + "lii" + "iii" + "p"),
     "rpb_window_pack": (_I, "ppppp" + "iiiiiiiiii" + "pppp" + "p"),
+    "rpb_pair_pack": (_I, "ppppp" + "ilii" + "pppp" + "p"),
     "rpb_chan_blocks": (_I, "il"),
     "rpb_chan_stats": (_I, "pp" + "ili" + "p"),
     "rpb_affine_silu_fwd": (_I, "ppppp" + "ili" + "p"),

@@ -69,3 +69,48 @@ extern "C" int rpb_window_pack(const float* planar, const float* cl, const float
     hipLaunchKernelGGL(window_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     RPB_CHECK_LAUNCH("window_pack");
 }
+
+// Combustion surrogate samples (realpdebench/data/combustion_surrogate_hf_dataset.py:213-243): input = the channels-last
+// `numerical` window + one constant channel per number parsed from sim_id (gas ratio, equivalence ratio), target = the `real`
+// window with a singleton channel; both normalised ((x - mean) / std; a RangeNormalizer passes mean = 0, std = max) in the same pass.
+struct PairPackArgs {
+    const float* num;      // [B][ntok][Cl]
+    const float* real;     // [B][ntok]
+    const float* para;     // [B][n_para]
+    float* inp;            // [B][ntok][Cl + n_para]
+    float* tgt;            // [B][ntok][1]
+    const float* mean_in;  // [Cl + n_para]
+    const float* std_in;
+    const float* mean_tgt; // [1]
+    const float* std_tgt;
+    long ntok, total;      // T * H * W, B * ntok
+    int Cl, n_para;
+};
+
+__global__ __launch_bounds__(256) void pair_pack_kernel(PairPackArgs a) {
+    const int C = a.Cl + a.n_para;
+    // one thread per input element: consecutive lanes write consecutive floats of `inp`
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.total * C; i += (long)gridDim.x * blockDim.x) {
+        const long tok = i / C;
+        const int c = (int)(i - tok * C);
+        const float v = c < a.Cl ? a.num[tok * a.Cl + c] : a.para[(tok / a.ntok) * a.n_para + (c - a.Cl)];
+        a.inp[i] = (v - a.mean_in[c]) / a.std_in[c];
+        if (c == 0) a.tgt[tok] = (a.real[tok] - a.mean_tgt[0]) / a.std_tgt[0];
+    }
+}
+
+extern "C" int rpb_pair_pack(const float* num, const float* real, const float* para, float* inp, float* tgt, int B, long ntok, int Cl,
+                             int n_para, const float* mean_in, const float* mean_tgt, const float* std_in, const float* std_tgt,
+                             void* stream) {
+    RPB_REQUIRE(num && real && inp && tgt && mean_in && mean_tgt && std_in && std_tgt, "pair_pack: null pointer");
+    RPB_REQUIRE(B > 0 && ntok > 0 && Cl >= 1 && n_para >= 0 && n_para <= 8 && (n_para == 0 || para), "pair_pack: bad sizes (B=%d Cl=%d n_para=%d)",
+                B, Cl, n_para);
+    PairPackArgs a;
+    a.num = num; a.real = real; a.para = para; a.inp = inp; a.tgt = tgt; a.mean_in = mean_in; a.std_in = std_in;
+    a.mean_tgt = mean_tgt; a.std_tgt = std_tgt; a.ntok = ntok; a.total = (long)B * ntok; a.Cl = Cl; a.n_para = n_para;
+    long grid = (a.total * (Cl + n_para) + 255) / 256;
+    const long cap = (long)rpb_num_cus() * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(pair_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("pair_pack");
+}

@@ -43,3 +43,12 @@ class GaussianNormalizer:
     def postprocess(self, x, y):
         return (self._apply(x, self.mean_inputs, self.std_inputs, True),
                 self._apply(y, self.mean_targets, self.std_targets, True))
+
+
+class RangeNormalizer(GaussianNormalizer):
+    """data_normalizer.py:98-159: ``x / max|x|`` per channel (zero max -> 1) -- the affine kernel with shift 0, scale max."""
+
+    def __init__(self, max_inputs, max_targets, device):
+        z = lambda t: torch.zeros_like(torch.as_tensor(t, dtype=torch.float32).flatten())
+        super().__init__(z(max_inputs), z(max_targets), max_inputs, max_targets, device)
+        self.max_inputs, self.max_targets = self.std_inputs, self.std_targets

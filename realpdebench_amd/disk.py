@@ -240,6 +240,138 @@ class CombustionWindows(FluidWindows):
         return inp, out
 
 
+class ArrowRows:
+    """Row-addressed zero-copy view of a ``datasets.save_to_disk`` directory whose rows are samples (the surrogate layout):
+    ``cell(row, name)`` is a pyarrow scalar, ``array(row, name, shape)`` a float32 numpy view into the memory map (cached)."""
+
+    def __init__(self, path):
+        import pyarrow as pa
+        state_file = os.path.join(path, "state.json")
+        if not os.path.exists(state_file):
+            raise FileNotFoundError(f"HF Arrow rows not found: {path} (no state.json)")
+        with open(state_file) as fh:
+            files = [d["filename"] for d in json.load(fh)["_data_files"]]
+        self._maps, self._chunks, self._starts = [], {}, {}
+        tables = []
+        for f in files:
+            mm = pa.memory_map(os.path.join(path, f), "r")
+            self._maps.append(mm)
+            tables.append(pa.ipc.open_stream(mm).read_all())
+        self.column_names = tables[0].column_names
+        for name in self.column_names:                       # chunk lists once: walking them per access costs milliseconds
+            chunks = [c for t in tables for c in t.column(name).chunks]
+            self._chunks[name] = chunks
+            self._starts[name] = np.cumsum([0] + [len(c) for c in chunks])
+        self.n = int(self._starts[self.column_names[0]][-1])
+        self._views = {}
+
+    def __len__(self):
+        return self.n
+
+    def cell(self, row, name):
+        starts = self._starts[name]
+        k = int(np.searchsorted(starts, row, side="right")) - 1
+        return self._chunks[name][k][row - int(starts[k])]
+
+    def array(self, row, name, shape):
+        a = self._views.get((row, name))
+        if a is None:
+            a = self._views[(row, name)] = np.frombuffer(self.cell(row, name).as_buffer(), dtype=np.float32).reshape(shape)
+        return a
+
+
+class SurrogateWindows:
+    """The sample list of ``CombustionSurrogateHFDataset`` (data/combustion_surrogate_hf_dataset.py; same constructor vocabulary
+    minus the download switches): ``__getitem__`` IGNORES its index and draws ``(sim_id, time_id)`` with two ``random.choice``
+    calls (:214-215), input = the ``numerical`` window [T, H, W, C] + gas-ratio and equivalence-ratio channels parsed from
+    sim_id, target = the ``real`` window [T, H, W, 1]; ``__len__`` is the reference's epoch-sizing rule (:245-248)."""
+    SIM_ID_PATTERN = r"(\d+)NH3_(\d+\.?\d*)\.h5"
+    n_para = 2
+
+    def __init__(self, dataset_name, dataset_root, mode, train_ratio=0.8, step=20, n_sim_frame=40, n_sim_frame_test=2001,
+                 sub_s_real=1, sub_s_numerical=1, **_ignored):
+        if dataset_name != "combustion":
+            raise ValueError(f"SurrogateWindows only supports dataset_name='combustion', got {dataset_name!r}")
+        if mode not in ("train", "test"):
+            raise ValueError(f"mode must be 'train' or 'test', got {mode!r}")
+        self.dataset_name, self.dataset_root, self.mode = dataset_name, dataset_root, mode
+        self.train_ratio, self.step, self.n_sim_frame = float(train_ratio), int(step), int(n_sim_frame)
+        self.sub_s_real, self.sub_s_numerical = int(sub_s_real), int(sub_s_numerical)
+        self.dataset_dir = os.path.join(dataset_root, dataset_name)
+        hf_dir = os.path.join(self.dataset_dir, "hf_dataset")
+        arrow_path = os.path.join(hf_dir, "surrogate_train")
+        if not os.path.exists(arrow_path):
+            raise FileNotFoundError(f"HF Arrow surrogate dataset not found: {arrow_path} (the reference writes it with "
+                                    "`python -m realpdebench.utils.convert_hdf5_to_hf --include_surrogate_train`)")
+        self.real_dataset_path = self.numerical_dataset_path = arrow_path          # what train_surrogate.py:105 logs
+        meta_path = os.path.join(hf_dir, "surrogate_train_meta.json")
+        if os.path.exists(meta_path):                                               # :129-150
+            with open(meta_path) as fh:
+                meta = json.load(fh)
+            bad = [f"{k} (meta={meta.get(k)} vs init={getattr(self, k)})"
+                   for k in ("step", "n_sim_frame", "sub_s_real", "sub_s_numerical") if int(meta.get(k, getattr(self, k))) != getattr(self, k)]
+            if bad:
+                raise ValueError("Surrogate HF dataset meta does not match dataset init args: " + ", ".join(bad))
+        ids_path = os.path.join(hf_dir, "surrogate_train_sim_ids.txt")
+        if not os.path.exists(ids_path):
+            raise FileNotFoundError(f"Missing surrogate sim_id list: {ids_path}")
+        with open(ids_path) as fh:
+            self.sim_ids = [ln.strip() for ln in fh if ln.strip()]
+        if self.n_sim_frame <= self.step:
+            raise ValueError(f"n_sim_frame={self.n_sim_frame} must be > step={self.step}")
+        self.time_ids = list(range(self.n_sim_frame - self.step))
+        self.n_sim, self._n_time = len(self.sim_ids), len(self.time_ids)
+        self.rows = ArrowRows(arrow_path)
+        if len(self.rows) != self.n_sim * self._n_time:                             # :172-180
+            raise ValueError(f"Unexpected surrogate HF dataset size: len={len(self.rows)}, expected "
+                             f"{self.n_sim * self._n_time} (= n_sim={self.n_sim} x n_time={self._n_time})")
+        self._sim_idx = {sid: i for i, sid in enumerate(self.sim_ids)}
+        self._para = {}
+        for sid in self.sim_ids:
+            m = re.match(self.SIM_ID_PATTERN, sid)
+            if m is None:
+                raise ValueError(f"sim_id {sid!r} does not match expected pattern {self.SIM_ID_PATTERN!r}")
+            self._para[sid] = (float(int(m.group(1))), float(m.group(2)))
+        self._shapes = {}
+
+    def __len__(self):
+        if self.mode == "train":
+            return int(self.n_sim * self.n_sim_frame)
+        return int(self.n_sim * self.n_sim_frame / self.train_ratio * (1 - self.train_ratio))
+
+    def draw(self):
+        """One sample as views: ``(numerical [T, H, W, C], real [T, H, W], (gas_ratio, equivalence_ratio))``; consumes the
+        ``random`` stream exactly like the reference's ``__getitem__``."""
+        sid = random.choice(self.sim_ids)
+        tid = random.choice(self.time_ids)
+        row = self._sim_idx[sid] * self._n_time + tid
+        sh = self._shapes.get(row)
+        if sh is None:
+            g = lambda k: int(self.rows.cell(row, k).as_py())
+            if self.rows.cell(row, "sim_id").as_py() != sid or g("time_id") != tid:
+                raise RuntimeError(f"HF surrogate dataset ordering mismatch at row {row}: expected ({sid}, {tid})")
+            sh = self._shapes[row] = ((g("real_shape_t"), g("real_shape_h"), g("real_shape_w")),
+                                      (g("numerical_shape_t"), g("numerical_shape_h"), g("numerical_shape_w"), g("numerical_channels")))
+        return self.rows.array(row, "numerical", sh[1]), self.rows.array(row, "real", sh[0]), self._para[sid]
+
+    def __getitem__(self, idx):
+        num, real, para = self.draw()
+        num = torch.tensor(num, dtype=torch.float32)
+        extra = [torch.ones_like(num[..., [0]]) * p for p in para]
+        return torch.cat([num] + extra, dim=-1), torch.tensor(real, dtype=torch.float32).unsqueeze(-1)
+
+
+def compute_max(windows, batch_size=512):
+    """RangeNormalizer.compute_max (data_normalizer.py:140-159): per-channel max |x| over ``len(windows)`` samples."""
+    mi = mt = None
+    for b0 in range(0, len(windows), batch_size):
+        items = [windows[i] for i in range(b0, min(b0 + batch_size, len(windows)))]
+        x, y = torch.stack([a for a, _ in items]), torch.stack([c for _, c in items])
+        bi, bt = x.view(-1, x.size(-1)).abs().max(dim=0)[0], y.view(-1, y.size(-1)).abs().max(dim=0)[0]
+        mi, mt = (bi, bt) if mi is None else (torch.max(mi, bi), torch.max(mt, bt))
+    return mi, mt
+
+
 def open_windows(dataset_name, **kw):
     """The sample list class of a scenario (realpdebench/train.py:81-266 picks the dataset class the same way)."""
     return (CombustionWindows if dataset_name == "combustion" else FluidWindows)(dataset_name=dataset_name, **kw)
@@ -408,6 +540,113 @@ class DiskBatchLoader:
         torch.cuda.current_stream(self.device).wait_event(done)
         inp.record_stream(torch.cuda.current_stream(self.device))
         tgt.record_stream(torch.cuda.current_stream(self.device))
+        return inp, tgt
+
+    def close(self):
+        self._stop = True
+        for s in self._slots:
+            s["free"].set()
+        self._pool.shutdown(wait=False)
+
+
+class SurrogateBatchLoader:
+    """Device-resident, normalised ``(input, target)`` batches of a ``SurrogateWindows`` list: a background thread draws the
+    samples in order (the ``random`` stream of the reference's ``__getitem__``), copies the two Arrow cells of each into pinned
+    staging on a small thread pool, and the consumer side enqueues H2D + ``rpb_pair_pack`` (parameter channels + normaliser) on
+    a side stream.  ``affine`` = ``(shift_in, shift_tgt, scale_in, scale_tgt)``: a GaussianNormalizer's (mean, std), a
+    RangeNormalizer's (0, max), or ``None``.  Ranks of a data-parallel job seed ``random`` differently and draw independently
+    (every sample of this dataset is a fresh draw)."""
+
+    def __init__(self, windows, batch_size, device, affine=None, depth=3, copy_threads=4, batches=None):
+        from . import ops
+        self.ops, self.w, self.B, self.device = ops, windows, int(batch_size), torch.device(device)
+        num, real, _ = self._peek()
+        self.T, self.H, self.W, self.Cl = num.shape
+        self.c_in = self.Cl + windows.n_para
+        f = dict(device=self.device, dtype=torch.float32)
+        if affine is not None:
+            mi, mt, si, st = (torch.as_tensor(t, dtype=torch.float32).flatten() for t in affine)
+            fix = lambda s: torch.where(s == 0, torch.ones_like(s), s)
+            self.affine = (mi[:self.c_in].to(self.device), mt[:1].to(self.device), fix(si[:self.c_in]).to(self.device),
+                           fix(st[:1]).to(self.device))
+        else:
+            self.affine = (torch.zeros(self.c_in, **f), torch.zeros(1, **f), torch.ones(self.c_in, **f), torch.ones(1, **f))
+        self.stream = torch.cuda.Stream(self.device)
+        def slot():
+            return dict(num=torch.empty(self.B, self.T, self.H, self.W, self.Cl, dtype=torch.float32).pin_memory(),
+                        real=torch.empty(self.B, self.T, self.H, self.W, dtype=torch.float32).pin_memory(),
+                        para=torch.zeros(self.B, windows.n_para, dtype=torch.float32).pin_memory(),
+                        dnum=torch.empty(self.B, self.T, self.H, self.W, self.Cl, **f),
+                        dreal=torch.empty(self.B, self.T, self.H, self.W, **f), dpara=torch.empty(self.B, windows.n_para, **f),
+                        free=threading.Event())
+        self._slots = [slot() for _ in range(depth)]
+        for s in self._slots:
+            s["free"].set()
+        self._q = queue.Queue(maxsize=depth)
+        self._stop, self._batches = False, batches
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(copy_threads)))
+        self._thread = threading.Thread(target=self._producer, daemon=True)
+        self._thread.start()
+
+    def _peek(self):
+        state = random.getstate()                                       # shapes without disturbing the sample stream
+        try:
+            return self.w.draw()
+        finally:
+            random.setstate(state)
+
+    def _producer(self):
+        try:
+            k = 0
+            while self._batches is None or k < self._batches:
+                slot = self._slots[k % len(self._slots)]
+                k += 1
+                slot["free"].wait()
+                if self._stop:
+                    return
+                slot["free"].clear()
+                if slot.get("busy") is not None:
+                    slot["busy"].synchronize()
+                hn, hr, hp = slot["num"].numpy(), slot["real"].numpy(), slot["para"].numpy()
+                jobs = []
+                for b in range(self.B):
+                    num, real, para = self.w.draw()                      # serial: the reference's random.choice order
+                    jobs.append(self._pool.submit(np.copyto, hn[b], num))
+                    jobs.append(self._pool.submit(np.copyto, hr[b], real))
+                    hp[b] = para
+                for j in jobs:
+                    j.result()
+                self._q.put(slot)
+            self._q.put(None)
+        except BaseException as exc:
+            self._q.put(exc)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        slot = self._q.get()
+        if slot is None:
+            raise StopIteration
+        if isinstance(slot, BaseException):
+            raise slot
+        f = dict(device=self.device, dtype=torch.float32)
+        inp = torch.empty(self.B, self.T, self.H, self.W, self.c_in, **f)
+        tgt = torch.empty(self.B, self.T, self.H, self.W, 1, **f)
+        with torch.cuda.stream(self.stream):
+            for d, h in (("dnum", "num"), ("dreal", "real"), ("dpara", "para")):
+                slot[d].copy_(slot[h], non_blocking=True)
+            self.ops.pair_pack(slot["dnum"], slot["dreal"], slot["dpara"], inp, tgt, self.B, self.T * self.H * self.W, self.Cl,
+                               self.w.n_para, *self.affine)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        slot["busy"] = done
+        slot["free"].set()
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        inp.record_stream(cur)
+        tgt.record_stream(cur)
         return inp, tgt
 
     def close(self):

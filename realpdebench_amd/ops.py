@@ -506,6 +506,13 @@ def window_pack(planar, cl, flags, inp, tgt, B, horizon, in_step, Hf, Wf, sub_s,
               nbytes=4 * (planar.numel() + (cl.numel() if cl is not None else 0) + inp.numel() + tgt.numel()))
 
 
+def pair_pack(num, real, para, inp, tgt, B, ntok, Cl, n_para, mean_in, mean_tgt, std_in, std_tgt):
+    """Combustion surrogate batch: channels-last `numerical` windows + sim_id parameter channels -> normalised input, `real`
+    windows -> normalised single-channel target, one HBM pass (disk.SurrogateBatchLoader)."""
+    _lib.call("rpb_pair_pack", _p(num), _p(real), _p(para), _p(inp), _p(tgt), B, ntok, Cl, n_para, _p(mean_in), _p(mean_tgt),
+              _p(std_in), _p(std_tgt), _stream(), label="pair_pack", nbytes=4 * (num.numel() + real.numel() + inp.numel() + tgt.numel()))
+
+
 def im2col(x, col, B, T, H, W, Cin, KS, ldc):
     _lib.call("rpb_im2col", _p(x), _p(col), B, T, H, W, Cin, KS, ldc, _stream(), label="im2col",
               nbytes=4 * B * T * H * W * (Cin + ldc))

@@ -1,0 +1,132 @@
+"""``python -m realpdebench_amd.train_surrogate --config configs/combustion/surrogate_model/fno.yaml`` -- the reference's
+combustion surrogate trainer (realpdebench/train_surrogate.py: numerical 15 channels + 2 sim_id parameters -> the observed
+field) on the MI355X backend: same YAML keys, same loop (Adam + cosine / step schedule, a test pass and a checkpoint every 50
+iterations with the same metric names and checkpoint keys).
+
+On the hot path the step is the fused ``Trainer.step`` and batches come from ``disk.SurrogateBatchLoader`` (Arrow cells ->
+pinned staging -> ``rpb_pair_pack`` on a side stream); the loss is read back once per test interval, not three times per step
+(train_surrogate.py:159-166).  The reference reads Arrow data only behind ``--use_hf_dataset`` (its default is the HDF5 reader);
+this backend reads the Arrow layout only, the flag is accepted and ignored."""
+import argparse
+import datetime
+import logging
+import os
+import random
+import time
+
+import torch
+
+from .data_normalizer import GaussianNormalizer, IdentityNormalizer, RangeNormalizer
+from .disk import SurrogateBatchLoader, SurrogateWindows, compute_max, compute_mean_std
+from .model import load_model
+from .trainer import make_trainer
+from .utils import add_args_from_config, resolve_config, set_seed, setup_logging
+
+parser = argparse.ArgumentParser(description="Training Configurations")
+parser.add_argument("--config", type=str, default="configs/combustion/surrogate_model/fno.yaml")
+parser.add_argument("--gpu", type=int, default=0)
+parser.add_argument("--use_hf_dataset", action="store_true", help="accepted for CLI compatibility: Arrow is the only reader here")
+parser.add_argument("--max_updates", type=int, default=None, help="stop early (smoke runs); the schedule still uses num_update")
+parser.add_argument("--test_every", type=int, default=50, help="train_surrogate.py:171 hard-codes 50")
+parser.add_argument("--dataset_kwargs", type=str, default="{}", help="JSON of SurrogateWindows arguments (step, n_sim_frame ...)")
+
+
+def main(argv=None):
+    import json
+    args = parser.parse_args(argv)
+    args.config = resolve_config(args.config)
+    args = add_args_from_config(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("realpdebench_amd.train_surrogate needs an MI355X: there is no CPU fallback path")
+    torch.cuda.set_device(args.gpu)
+    device = torch.device("cuda", args.gpu)
+    set_seed(args.seed)
+    random.seed(args.seed)           # the sample draws use `random` (utils.set_seed of the reference seeds it too)
+
+    exp_path = os.path.join(args.results_path, args.model_name, args.exp_name,
+                            datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+    os.makedirs(exp_path, exist_ok=True)
+    setup_logging(exp_path)
+    logging.info(f"args: {args}")
+
+    dkw = json.loads(args.dataset_kwargs)
+    mk = lambda mode: SurrogateWindows(dataset_name=args.dataset_name, dataset_root=args.dataset_root, mode=mode, **dkw)
+    train_dataset, test_dataset, normalizer_dataset = mk("train"), mk("test"), mk("train")
+    logging.info(f"Data loaded from {train_dataset.real_dataset_path} and {train_dataset.numerical_dataset_path}")
+
+    if args.normalizer == "none":                                         # train_surrogate.py:107-114
+        normalizer, affine = IdentityNormalizer(device), None
+    elif args.normalizer == "gaussian":
+        stats = compute_mean_std(normalizer_dataset)
+        normalizer, affine = GaussianNormalizer(*stats, device=device), stats
+    elif args.normalizer == "range":
+        mx = compute_max(normalizer_dataset)
+        normalizer = RangeNormalizer(*mx, device=device)
+        affine = (torch.zeros_like(mx[0]), torch.zeros_like(mx[1]), mx[0], mx[1])
+    else:
+        raise ValueError(f"Normalizer {args.normalizer} not supported")
+
+    model = load_model(train_dataset, device=device, **vars(args))
+    logging.info(f"Number of parameters: {sum(p.numel() for p in model.parameters())}")
+    trainer = make_trainer(model, lr=args.lr, num_update=args.num_update, scheduler=args.scheduler, step_size=args.step_size,
+                           clip_grad_norm=args.clip_grad_norm)
+
+    n_iter = args.num_update if args.max_updates is None else min(args.num_update, args.max_updates)
+    batches = SurrogateBatchLoader(train_dataset, args.train_batch_size, device, affine=affine)
+    all_train_losses = []
+    all_test_losses = {"normalized_mse": [], "rmse": [], "mae": [], "rel_l2_error": []}
+    best_test_loss, best_iteration = float("inf"), 0
+    pending, start = [], time.time()
+    n_test_batches = -(-len(test_dataset) // args.test_batch_size)        # len(DataLoader(test_dataset, test_batch_size))
+    logging.info(f"Start training on {device}")
+    for iteration in range(1, n_iter + 1):
+        inp, tgt = next(batches)
+        pending.append(trainer.step(inp, tgt).clone())
+        if iteration % args.test_every == 0 or iteration == n_iter:
+            chunk = [float(v) for v in torch.cat(pending).cpu()]           # ONE sync per interval
+            all_train_losses += chunk
+            pending = []
+            model.eval()
+            nmse = se = ae = rel = 0.0
+            cnt = nsamp = 0
+            with torch.no_grad():
+                left = len(test_dataset)
+                for _ in range(n_test_batches):                            # train_surrogate.py:177-205
+                    items = [test_dataset[i] for i in range(min(args.test_batch_size, left))]
+                    left -= len(items)
+                    vi, vt = torch.stack([a for a, _ in items]), torch.stack([b for _, b in items])
+                    b = vi.size(0)
+                    vi, vt = normalizer.preprocess(vi, vt)
+                    pred = model(vi)
+                    nmse += float(((pred - vt) ** 2).mean())
+                    _, p = normalizer.postprocess(vi, pred)
+                    _, t = normalizer.postprocess(vi, vt)
+                    se += float(((p - t) ** 2).sum())
+                    ae += float((p - t).abs().sum())
+                    rel += float((torch.norm((p - t).reshape(b, -1), dim=1) / torch.norm(t.reshape(b, -1), dim=1)).sum())
+                    cnt += t.numel()
+                    nsamp += b
+            rmse = (se / cnt) ** 0.5
+            all_test_losses["normalized_mse"].append(nmse / n_test_batches)
+            all_test_losses["rmse"].append(rmse)
+            all_test_losses["mae"].append(ae / cnt)
+            all_test_losses["rel_l2_error"].append(rel / nsamp)
+            if rmse < best_test_loss:
+                best_iteration, best_test_loss = iteration, rmse
+            logging.info(f"\nIteration {iteration}, train loss: {sum(chunk) / len(chunk):.5f}")
+            logging.info("Validation results: \n" + f"normalized mse loss: {nmse / n_test_batches:.5f}, rmse: {rmse:.5f}, "
+                         f"mae: {ae / cnt:.5f}, rel l2 error: {rel / nsamp:.5f}")
+            torch.save({"model_state_dict": model.state_dict(), "train_losses": all_train_losses, "test_losses": all_test_losses,
+                        "iteration": iteration, "best_iteration": best_iteration, "best_test_loss": best_test_loss},
+                       os.path.join(exp_path, f"model_{iteration:04d}.pth"))
+    torch.cuda.synchronize()
+    batches.close()
+    dt = time.time() - start
+    logging.info(f"Training complete, best iteration is {best_iteration}, time cost is {dt / 60:.2f} min "
+                 f"({n_iter * args.train_batch_size / dt:.1f} samples/s incl. tests)")
+    logging.info(f"Results saved at {exp_path}")
+    return exp_path
+
+
+if __name__ == "__main__":
+    main()

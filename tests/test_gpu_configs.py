@@ -1,5 +1,6 @@
 """The reference's other FNO configurations run through the same HIP path (one fused train step + eval forward,
-checked against the oracle at B=1): fsi (width 128, modes 4/16/16) and combustion (16 input/output channels)."""
+checked against the oracle at B=1): fsi (width 128, modes 4/16/16), combustion (16 input/output channels), the combustion
+surrogate (17 -> 1 channels, train_surrogate.py)."""
 import pytest
 import torch
 
@@ -12,6 +13,7 @@ pytestmark = pytest.mark.gpu
     ("fsi", (20, 64, 64, 3), (20, 64, 64, 3), (4, 16, 16), 128),          # configs/fsi/fno.yaml
     ("combustion", (20, 64, 64, 16), (20, 64, 64, 16), (4, 16, 16), 64),  # configs/combustion/fno.yaml
     ("controlled", (10, 64, 128, 5), (10, 64, 128, 3), (4, 12, 16), 64),  # control channels in, 3 fields out
+    ("surrogate", (20, 32, 32, 17), (20, 32, 32, 1), (4, 16, 16), 64),    # configs/combustion/surrogate_model/fno.yaml: 15 + 2 -> 1
 ])
 def test_reference_fno_configs(name, shape_in, shape_out, modes, width):
     from oracle import fno3d_oracle as O

@@ -1,0 +1,126 @@
+"""Combustion surrogate path (the caller realpdebench/train_surrogate.py and its sample list
+data/combustion_surrogate_hf_dataset.py) against samples produced by the IMPORTED reference dataset
+(tests/golden/make_golden_surrogate.py -> tests/golden/surrogate_small/ + surrogate_small.npz): the random-draw sample stream and
+the epoch-sizing rule on the host (CPU tests); device batches, the range normaliser and the trainer entry point on the GPU."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from realpdebench_amd.disk import ArrowRows, SurrogateWindows, compute_max
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "golden", "surrogate_small")
+KW = dict(dataset_name="combustion", dataset_root=ROOT, step=3, n_sim_frame=5)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "surrogate_small.npz"))
+
+
+@pytest.mark.parametrize("mode", ["train", "test"])
+def test_samples_match_the_reference_dataset(gold, mode):
+    w = SurrogateWindows(mode=mode, **KW)
+    assert len(w) == int(gold[mode + "/n"])                          # 3 sims x 5 frames; test: x (1 - 0.8) / 0.8
+    random.seed(77)                                                  # two random.choice draws per sample, the index is ignored
+    items = [w[i] for i in range(10)]
+    assert torch.equal(torch.stack([a for a, _ in items]), torch.from_numpy(gold[mode + "/inp"]))
+    assert torch.equal(torch.stack([b for _, b in items]), torch.from_numpy(gold[mode + "/tgt"]))
+    assert items[0][0].shape == (3, 6, 6, 17) and items[0][1].shape == (3, 6, 6, 1)
+
+
+def test_rows_are_zero_copy_views():
+    rows = ArrowRows(os.path.join(ROOT, "combustion", "hf_dataset", "surrogate_train"))
+    assert len(rows) == 6 and rows.cell(3, "sim_id").as_py() == "40NH3_1.h5" and rows.cell(3, "time_id").as_py() == 1
+    a = rows.array(3, "numerical", (3, 6, 6, 15))
+    assert a.dtype == np.float32 and not a.flags.writeable and not a.flags.owndata
+    assert rows.array(3, "numerical", (3, 6, 6, 15)) is a           # cached
+
+
+def test_constructor_checks():
+    with pytest.raises(ValueError, match="only supports dataset_name='combustion'"):
+        SurrogateWindows(mode="train", **{**KW, "dataset_name": "cylinder"})
+    with pytest.raises(ValueError, match="mode must be"):
+        SurrogateWindows(mode="val", **KW)
+    with pytest.raises(ValueError, match="meta does not match"):      # the fixture was converted with step 3
+        SurrogateWindows(mode="train", **{**KW, "step": 2})
+    with pytest.raises(FileNotFoundError, match="surrogate dataset not found"):
+        SurrogateWindows(mode="train", **{**KW, "dataset_root": os.path.join(ROOT, "nowhere")})
+
+
+def test_compute_max_formula(gold):
+    w = SurrogateWindows(mode="train", **KW)
+    random.seed(77)
+    mi, mt = compute_max(w, batch_size=4)                             # 15 draws in batches of 4; the first 10 are the golden ones
+    random.seed(77)
+    items = [w[i] for i in range(15)]
+    x, y = torch.stack([a for a, _ in items]), torch.stack([b for _, b in items])
+    assert torch.equal(mi, x.view(-1, 17).abs().max(dim=0)[0]) and torch.equal(mt, y.view(-1, 1).abs().max(dim=0)[0])
+    assert torch.all(mi >= torch.from_numpy(gold["max_in"])) and mi[15] == 60.0 and mi[16] == 1.25
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_range_normaliser_matches_the_reference(gold):
+    from realpdebench_amd.data_normalizer import RangeNormalizer
+    rn = RangeNormalizer(torch.from_numpy(gold["max_in"]), torch.from_numpy(gold["max_tgt"]), device="cuda")
+    x, y = torch.from_numpy(gold["train/inp"]), torch.from_numpy(gold["train/tgt"])
+    px, py = rn.preprocess(x, y)
+    assert torch.equal(px.cpu(), torch.from_numpy(gold["range/pre_inp"])) and torch.equal(py.cpu(), torch.from_numpy(gold["range/pre_tgt"]))
+    qx, qy = rn.postprocess(px, py)
+    assert torch.equal(qx.cpu(), torch.from_numpy(gold["range/post_inp"])) and torch.equal(qy.cpu(), torch.from_numpy(gold["range/post_tgt"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["none", "gaussian", "range"])
+def test_device_batches_equal_the_sample_stream(gold, norm):
+    from realpdebench_amd.disk import SurrogateBatchLoader
+    w = SurrogateWindows(mode="train", **KW)
+    x, y = torch.from_numpy(gold["train/inp"]), torch.from_numpy(gold["train/tgt"])   # the first 10 draws after seed 77
+    if norm == "none":
+        affine, ex, ey = None, x, y
+    elif norm == "gaussian":
+        mi, si = x.reshape(-1, 17).mean(0), x.reshape(-1, 17).std(0)
+        si[15] = 0.0                                                                   # zero std -> 1 (data_normalizer.py:47-48)
+        mt, st = y.reshape(-1, 1).mean(0), y.reshape(-1, 1).std(0)
+        affine = (mi, mt, si, st)
+        ex, ey = (x - mi) / torch.where(si == 0, torch.ones_like(si), si), (y - mt) / st
+    else:
+        mx, my = torch.from_numpy(gold["max_in"]), torch.from_numpy(gold["max_tgt"])
+        affine = (torch.zeros(17), torch.zeros(1), mx, my)
+        ex, ey = torch.from_numpy(gold["range/pre_inp"]), torch.from_numpy(gold["range/pre_tgt"])
+    random.seed(77)
+    loader = SurrogateBatchLoader(w, 5, "cuda", affine=affine, batches=2)
+    got = list(loader)
+    loader.close()
+    assert len(got) == 2
+    gi, gt = torch.cat([a for a, _ in got]).cpu(), torch.cat([b for _, b in got]).cpu()
+    assert gi.shape == (10, 3, 6, 6, 17) and gt.shape == (10, 3, 6, 6, 1)
+    assert torch.equal(gi, ex) and torch.equal(gt, ey)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalizer", ["gaussian", "range"])
+def test_train_surrogate_entrypoint(tmp_path, normalizer):
+    import yaml
+    from realpdebench_amd import train_surrogate as ts
+    with open(os.path.join(os.path.dirname(ts.__file__), "configs", "combustion", "surrogate_model", "fno.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg.update(results_path=str(tmp_path), dataset_root=ROOT, modes1=2, modes2=3, modes3=3, n_layers=2, width=32, num_update=20,
+               train_batch_size=4, test_batch_size=2, lr=1e-3, normalizer=normalizer)
+    path = tmp_path / "fno.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = ts.main(["--config", str(path), "--use_hf_dataset", "--test_every", "10",
+                   "--dataset_kwargs", json.dumps(dict(step=3, n_sim_frame=5))])
+    files = sorted(f for f in os.listdir(exp) if f.endswith(".pth"))
+    assert files == ["model_0010.pth", "model_0020.pth"]
+    ck = torch.load(os.path.join(exp, files[-1]), weights_only=False)
+    assert set(ck) == {"model_state_dict", "train_losses", "test_losses", "iteration", "best_iteration", "best_test_loss"}
+    assert len(ck["train_losses"]) == 20 and all(np.isfinite(ck["train_losses"]))
+    assert set(ck["test_losses"]) == {"normalized_mse", "rmse", "mae", "rel_l2_error"} and len(ck["test_losses"]["rmse"]) == 2
+    assert ck["model_state_dict"]["fc0.weight"].shape == (32, 17 + 3) and ck["model_state_dict"]["fc2.weight"].shape[0] == 1
+    assert np.mean(ck["train_losses"][-5:]) < np.mean(ck["train_losses"][:5])      # 15 distinct windows: it fits them
