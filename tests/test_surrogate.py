@@ -124,3 +124,37 @@ def test_train_surrogate_entrypoint(tmp_path, normalizer):
     assert set(ck["test_losses"]) == {"normalized_mse", "rmse", "mae", "rel_l2_error"} and len(ck["test_losses"]["rmse"]) == 2
     assert ck["model_state_dict"]["fc0.weight"].shape == (32, 17 + 3) and ck["model_state_dict"]["fc2.weight"].shape[0] == 1
     assert np.mean(ck["train_losses"][-5:]) < np.mean(ck["train_losses"][:5])      # 15 distinct windows: it fits them
+
+
+@pytest.mark.gpu
+def test_train_surrogate_unet_config(tmp_path):
+    """configs/combustion/surrogate_model/unet.yaml (dim = H = 64, dim_mults [1, 2], 17 -> 1 channels) on a dataset written here
+    in the reference's surrogate layout."""
+    import yaml
+    from datasets import Dataset
+    from realpdebench_amd import train_surrogate as ts
+    step, nsf, H, W, C = 2, 4, 64, 64, 15
+    sims = ["20NH3_0.8.h5", "40NH3_1.h5"]
+    base = tmp_path / "data" / "combustion" / "hf_dataset"
+    base.mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    ints = ("time_id", "real_shape_t", "real_shape_h", "real_shape_w", "numerical_shape_t", "numerical_shape_h", "numerical_shape_w",
+            "numerical_channels")
+    rows = {k: [] for k in ("sim_id", "real", "numerical") + ints}
+    for sid in sims:
+        for t in range(nsf - step):
+            rows["sim_id"].append(sid)
+            rows["real"].append(rng.standard_normal((step, H, W), dtype=np.float32).tobytes())
+            rows["numerical"].append(rng.standard_normal((step, H, W, C), dtype=np.float32).tobytes())
+            for k, v in zip(ints, (t, step, H, W, step, H, W, C)):
+                rows[k].append(v)
+    Dataset.from_dict(rows).save_to_disk(str(base / "surrogate_train"))
+    (base / "surrogate_train_sim_ids.txt").write_text("".join(s + "\n" for s in sims))
+    with open(os.path.join(os.path.dirname(ts.__file__), "configs", "combustion", "surrogate_model", "unet.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg.update(results_path=str(tmp_path), dataset_root=str(tmp_path / "data"), num_update=4, normalizer="gaussian")
+    path = tmp_path / "unet.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = ts.main(["--config", str(path), "--test_every", "4", "--dataset_kwargs", json.dumps(dict(step=step, n_sim_frame=nsf))])
+    ck = torch.load(os.path.join(exp, "model_0004.pth"), weights_only=False)
+    assert len(ck["train_losses"]) == 4 and all(np.isfinite(ck["train_losses"])) and np.isfinite(ck["test_losses"]["rmse"][0])

@@ -55,5 +55,28 @@ try:
         per = w.horizon * (H // w.sub_s) * W * 3 * 4                    # every sub_s-th row of u, v, p (p only when not masked)
         print(f"copy threads {threads:2d}: {STEPS * B / dt:8.1f} samples/s   {STEPS * B * per / dt / 1e9:6.2f} GB/s (upper bound: p is masked half the time) host rows -> pinned   "
               f"batch {tuple(x.shape)} / {tuple(y.shape)}")
+    if os.environ.get("DB_TRAIN", "1") != "0":
+        # the fused FNO train step fed (a) by one resident batch, (b) by the reader: what the disk path costs end to end
+        from realpdebench_amd.model.fno import FNO3d
+        from realpdebench_amd.trainer import Trainer
+        shape = (w.in_step, H // w.sub_s, W // w.sub_s, 3)
+        model = FNO3d(4, 12, 16, 4, 64, shape, shape).cuda()
+        tr = Trainer(model, lr=1e-4, num_update=1000)
+        loader = disk.DiskBatchLoader(w, B, "cuda", stats=stats, shuffle=True, seed=0, depth=3, copy_threads=4)
+        x, y = next(loader)
+        def run(feed, n):
+            for _ in range(3):
+                tr.step(*feed())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                tr.step(*feed())
+            torch.cuda.synchronize()
+            return n * B / (time.perf_counter() - t0)
+        a = run(lambda: (x, y), STEPS)
+        b = run(lambda: next(loader), STEPS)
+        loader.close()
+        print(f"FNO3d train step, batch {B} x {shape}: {a:8.1f} samples/s from a resident batch, {b:8.1f} samples/s from the on-disk reader "
+              f"({100 * b / a:.1f} %)")
 finally:
     shutil.rmtree(root, ignore_errors=True)
