@@ -34,3 +34,55 @@ def test_reference_fno_configs(name, shape_in, shape_out, modes, width):
     for k in ("fc0.weight", "spectral_convs.0.weights1", "spectral_convs.1.weights4", "convs.1.weight", "fc1.weight",
               "fc2.weight", "bns.0.weight"):
         assert rel_l2(got[k].cpu(), grads[k]) < 1e-4, (name, k)
+
+
+def test_c4_transolver_foil_shape_vs_oracle():
+    """BASELINE.json configs[3] / SURVEY.md C4 at its real size (one sample: 20 x 64 x 64 = 81 920 tokens, n_hidden 256, 8 heads,
+    16 slices): at this size the 3x3x3 convolutions and the dense token GEMMs take the split-bf16 MFMA kernels, so this is the
+    end-to-end check that those are fp32-grade inside the model -- loss and every parameter gradient against autograd through
+    the CPU oracle (about half a minute of CPU time)."""
+    from oracle import transolver_oracle as TO
+    from realpdebench_amd import ops
+    from realpdebench_amd.model.transolver import Transolver
+    torch.manual_seed(21)
+    H, W, D, heads = 64, 64, 20, 8
+    assert ops.conv3_split_ok(512, 256) and ops.gemm_split_ok(H * W * D, 256, 1024, 1024, 256, None)
+    m = Transolver(space_dim=3, n_layers=1, n_hidden=256, n_head=heads, fun_dim=0, out_dim=3, slice_num=16, mlp_ratio=4,
+                   H=H, W=W, D=D, dropout=0.0)
+    x, y = torch.randn(1, D, W, H, 3), torch.randn(1, D, W, H, 3)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    loss_ref = ((TO.transolver_forward(sd, x, 1, heads, H, W, D, None) - y) ** 2).mean()
+    loss_ref.backward()
+    m = m.cuda().train()
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * float(loss_ref)
+    bad = {}
+    for n, p in m.named_parameters():
+        ref = sd[n].grad
+        if float(ref.norm()) < 1e-12:
+            continue
+        e = rel_l2(p.grad.cpu(), ref)
+        if e > 1e-4:
+            bad[n] = e
+    assert not bad, bad
+
+
+def test_c5_fno_combustion_volume_rollout():
+    """BASELINE.json configs[4] / SURVEY.md C5 shape: FNO3d on a 64^3 volume with the combustion channel count (16), modes
+    (4, 16, 16), width 64, 4 layers, 20 autoregressive steps (here in fp32, the path's arithmetic type).  The first two steps
+    are compared with the CPU oracle's rollout, all twenty must stay finite."""
+    from oracle import fno3d_oracle as O
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.rollout import autoregressive_rollout
+    torch.manual_seed(4)
+    shape, modes, L = (64, 64, 64, 16), (4, 16, 16), 4
+    sd = O.init_state_dict(modes, L, 64, shape, shape, seed=9)
+    x = torch.randn(1, *shape)
+    ref = O.rollout(sd, x, 2, modes, L, shape, shape)
+    m = FNO3d(*modes, L, 64, shape, shape)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    out = autoregressive_rollout(m, x.cuda(), 20)
+    assert out.shape == (1, 20 * 64, 64, 64, 16) and bool(torch.isfinite(out).all())
+    assert rel_l2(out[:, :2 * 64].cpu(), ref) < 2e-5

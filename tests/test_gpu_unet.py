@@ -203,3 +203,24 @@ def test_wide_mesh_bottleneck_beyond_512_tokens_vs_oracle():
     m.eval()
     with torch.no_grad():
         assert rel_l2(m(x.cuda()).cpu(), pred_ref) < 2e-5
+
+
+def test_c3_channel_widths_vs_oracle():
+    """BASELINE.json configs[2] / SURVEY.md C3 widths: ``dim = H = 256`` -> 256 / 512 / 1024 channels (convolutions with up to
+    2048 input channels after the skip concatenation), on a 256 x 32 mesh with two frames so that the CPU oracle's backward
+    stays at ~20 s; loss, prediction and every parameter gradient."""
+    from oracle import unet_oracle as UO
+    m = _model(T=2, H=256, W=32, seed=11).cuda().train()
+    torch.manual_seed(14)
+    x, y = torch.randn(1, 2, 256, 32, 3), torch.randn(1, 2, 256, 32, 3)
+    loss = m.train_loss(x.cuda(), y.cuda()).mean()
+    loss.backward()
+    loss_ref, pred_ref, grads_ref = UO.loss_and_grads(_oracle_sd(m), x, y)
+    assert abs(float(loss.detach()) - float(loss_ref)) < 2e-5 * abs(float(loss_ref))
+    named = dict(m.named_parameters())
+    worst = max((rel_l2(named[k].grad.cpu(), g) if float(g.abs().max()) > 1e-7 else float(named[k].grad.abs().max()), k)
+                for k, g in grads_ref.items())
+    assert worst[0] < 1e-3, worst
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x.cuda()).cpu(), pred_ref) < 2e-5
