@@ -526,11 +526,14 @@ class DiskBatchLoader:
             if self.w.noise_scale > 0:
                 # x + x * N(0,1) * scale per element (fluid_hf_dataset.py:309-311), drawn on the device at full resolution before
                 # the sub-sampling: the same distribution per kept element, not the reference's CPU random stream
-                if self.w.noise_type != "gaussian":
-                    raise NotImplementedError("device batches support noise_type 'gaussian' only")
+                # (poisson, :312-314: x + Poisson(x) * scale, same remark)
                 for d in (slot["dev"][:nb], slot["devl"][:nb] if slot["devl"] is not None else None):
-                    if d is not None:
+                    if d is None:
+                        continue
+                    if self.w.noise_type == "gaussian":
                         d.addcmul_(d, torch.randn_like(d), value=self.w.noise_scale)
+                    else:
+                        d.add_(torch.poisson(d), alpha=self.w.noise_scale)
             self.ops.window_pack(slot["dev"], slot["devl"], slot["dflags"], inp, tgt, nb, self.horizon, self.in_step, self.Hf,
                                  self.Wf, self.w.sub_s, self.w.n_para, self.Cp, self.Cl, *self.stats, rows_subsampled=True)
             done = torch.cuda.Event()

@@ -15,7 +15,8 @@ from realpdebench_amd.disk import ArrowTrajectories, FluidWindows, batch_plan, c
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "golden", "disk_small")
 CASES = ["cyl_num_train", "cyl_num_train_masked", "cyl_real_val", "cyl_num_test_ar", "cyl_real_test_unseen", "ctl_num_train",
-         "comb_num_train", "comb_real_test_ar"]
+         "comb_num_train", "comb_real_test_ar", "cyl_num_train_noise", "cyl_real_val_noise_ignored", "comb_num_train_noise",
+         "ctl_num_train_noise"]
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +42,7 @@ def test_samples_match_the_reference_dataset(gold, key):
     w = _windows(gold, key)
     assert len(w) == int(gold[key + "/n"])
     random.seed(1234)                                              # the reference draws one random.random() per numerical sample
+    torch.manual_seed(99)                                          # ... and, with noise_scale > 0, randn_like(input) then randn_like(output)
     items = [w[i] for i in range(len(w))]
     assert torch.equal(torch.stack([a for a, _ in items]), torch.from_numpy(gold[key + "/inp"]))
     assert torch.equal(torch.stack([b for _, b in items]), torch.from_numpy(gold[key + "/tgt"]))
@@ -77,7 +79,7 @@ def test_rank_shards_partition_every_global_batch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("key", CASES)
+@pytest.mark.parametrize("key", [k for k in CASES if not k.endswith("_noise")])    # device noise is another random stream: below
 def test_device_batches_equal_reference_windows(gold, key):
     from realpdebench_amd.disk import DiskBatchLoader
     w = _windows(gold, key)
@@ -122,3 +124,51 @@ def test_two_ranks_read_disjoint_halves_of_one_permutation(gold):
         for step, idxs in enumerate(plan[r]):
             assert torch.equal(got[r][step], ref[idxs])
     assert not (set(i for b in plan[0] for i in b) & set(i for b in plan[1] for i in b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key,clean", [("cyl_num_train_noise", None), ("comb_num_train_noise", "comb_num_train"),
+                                       ("ctl_num_train_noise", "ctl_num_train")])
+def test_device_gaussian_noise_has_the_reference_distribution(gold, key, clean):
+    """x + x * N(0, 1) * scale per element (fluid_hf_dataset.py:309-311): the device draws its own stream, so the check is the
+    distribution -- (noisy - clean) / clean is N(0, scale^2), masked channels stay exactly zero, parameter channels are not
+    perturbed (the reference appends them after the noise)."""
+    from realpdebench_amd.disk import DiskBatchLoader
+    kw = json.loads(str(gold[key + "/kw"]))
+    scale = kw["noise_scale"]
+    def batches(noise):
+        random.seed(1234)
+        torch.manual_seed(5)
+        w = open_windows(dataset_root=ROOT, **{**kw, "noise_scale": noise})
+        out = list(DiskBatchLoader(w, 3, "cuda", stats=None, shuffle=False, epochs=1))
+        return torch.cat([a.cpu() for a, _ in out]), torch.cat([b.cpu() for _, b in out]), w
+    xn, yn, w = batches(scale)
+    x0, y0, _ = batches(0.0)
+    nf = w.Cp + w.Cl                                               # field channels; the rest are parameter channels
+    assert torch.equal(xn[..., nf:], x0[..., nf:])
+    for a, b in ((xn[..., :nf], x0[..., :nf]), (yn, y0)):
+        assert torch.equal(a[b == 0], b[b == 0])                   # masked pressure / numerical block
+        r = ((a - b) / b)[b.abs() > 1e-3]
+        assert r.numel() > 300 and abs(float(r.mean())) < 4 * scale / r.numel() ** 0.5 + 1e-3
+        assert abs(float(r.std()) / scale - 1) < 0.12, (float(r.std()), scale)
+
+
+@pytest.mark.gpu
+def test_device_poisson_noise(tmp_path):
+    """x + Poisson(x) * scale (fluid_hf_dataset.py:312-314) on non-negative data written here in the reference's layout."""
+    from datasets import Dataset
+    from realpdebench_amd.disk import DiskBatchLoader
+    base = tmp_path / "cylinder" / "hf_dataset"
+    T, H, W, lam, scale = 12, 8, 16, 4.0, 0.5
+    rows = {"sim_id": ["100.h5"], "shape_t": [T], "shape_h": [H], "shape_w": [W]}
+    for k in ("u", "v", "p"):
+        rows[k] = [np.full((T, H, W), lam, dtype=np.float32).tobytes()]
+    Dataset.from_dict(rows).save_to_disk(str(base / "numerical"))
+    (base / "train_index_numerical.json").write_text(json.dumps([{"sim_id": "100.h5", "time_id": t} for t in range(6)]))
+    w = FluidWindows("cylinder", str(tmp_path), "numerical", "train", mask_prob=0.0, in_step=3, out_step=3, sub_s_numerical=1,
+                     noise_scale=scale, noise_type="poisson")
+    torch.manual_seed(2)
+    x = torch.cat([torch.cat([a, b], dim=1).cpu() for a, b in DiskBatchLoader(w, 3, "cuda", shuffle=False, epochs=1)])
+    k = (x - lam) / scale                                          # Poisson(lam) counts
+    assert torch.equal(k, k.round()) and float(k.min()) >= 0
+    assert abs(float(k.mean()) - lam) < 0.1 and abs(float(k.var()) - lam) < 0.3
