@@ -16,17 +16,20 @@ from .data_normalizer import GaussianNormalizer, IdentityNormalizer
 from .metrics import eval_metrics
 from .model import load_model
 from .rollout import autoregressive_rollout
-from .utils import add_args_from_config, resolve_config, set_seed, setup_logging
+from .utils import add_hf_compat_flags, add_args_from_config, check_hf_compat_flags, resolve_config, set_seed, setup_logging
 
 parser = argparse.ArgumentParser(description="Evaluation Configurations")
 parser.add_argument("--config", type=str, default="configs/cylinder/fno.yaml")
 parser.add_argument("--gpu", type=int, default=0)
+parser.add_argument("--train_data_type", type=str, default="numerical", help="numerical | real")
 parser.add_argument("--checkpoint_path", type=str, default=None)
 parser.add_argument("--dataset_factory", type=str, default=None)
+add_hf_compat_flags(parser)
 
 
 def main(argv=None):
     args = parser.parse_args(argv)
+    check_hf_compat_flags(args)
     args.config = resolve_config(args.config)
     cli_ckpt = args.checkpoint_path
     args = add_args_from_config(args)
@@ -48,38 +51,60 @@ def main(argv=None):
     if args.checkpoint_path:
         meta = model.load_checkpoint(args.checkpoint_path, device)                     # eval.py:284
         logging.info(f"Checkpoint {args.checkpoint_path} loaded (iteration {meta['iteration']}).")
-    n_ar = int(args.N_autoregressive)
-    se = ae = ref2 = nmse = 0.0
-    cnt = nb = 0
-    metric_rows = []
+    results, _, _ = evaluate(model, loader, normalizer, int(args.N_autoregressive), args.test_batch_size)
+    logging.info(f"Results saved at {exp_path}")
+    return results
+
+
+METRIC_NAMES = ("rmse", "mae", "rel l2 error", "r2", "ke error", "f error", "low f error", "mid f error", "high f error",
+                "rel low f error", "rel mid f error", "rel high f error", "freq error")
+
+
+def evaluate(model, loader, normalizer, n_ar, test_batch_size):
+    """The test loop of realpdebench/eval.py:286-365 on the device: returns ``(results, pred, target)`` with the
+    de-normalised rollout and targets of the whole split (``None`` when the targets cover a single step only)."""
+    device = next(model.parameters()).device
+    normalized_test_loss, n_batches, nb = 0.0, 0, 0
+    pred_list, target_list = [], []
+    unmeasured_c = None
+    T_tgt = None
     start = time.time()
+    logging.info(f"Start testing on {device}")
     for inp, tgt in loader:
+        b = inp.size(0)
+        T_tgt = tgt.shape[1]
+        if unmeasured_c is None:                                    # eval.py:297-302: all-zero target channels of the FIRST batch
+            unmeasured_c = sum(int(torch.all(tgt[..., c_] == 0)) for c_ in range(tgt.shape[-1]))
+        c = tgt.shape[-1] - unmeasured_c
         c_out = tgt.shape[-1]
-        para = inp[..., c_out:].contiguous() if inp.shape[-1] != c_out else None          # eval.py:305-309
+        para = inp[..., c_out:].contiguous() if inp.shape[-1] != c_out else None          # eval.py:304-308
         x, t = normalizer.preprocess(inp, tgt)
-        pred = autoregressive_rollout(model, x, n_ar, normalizer=normalizer, para_input=para)[..., :c_out]
-        t_roll = t if n_ar == 1 else None
-        if t_roll is not None:
-            nmse += float(((pred - t_roll) ** 2).mean()) * inp.shape[0]
-            _, p = normalizer.postprocess(x, pred.contiguous())
-            _, tt = normalizer.postprocess(x, t_roll)
-            se += float(((p - tt) ** 2).sum())
-            ae += float((p - tt).abs().sum())
-            ref2 += float((tt ** 2).sum())
-            cnt += tt.numel()
-            metric_rows.append(torch.stack(eval_metrics(p, tt, c_out)) * inp.shape[0])     # eval.py:327-333, on device
-        nb += inp.shape[0]
+        pred = autoregressive_rollout(model, x, n_ar, normalizer=normalizer, para_input=para)[..., :c_out].contiguous()
+        if pred.shape == t.shape:        # real test splits carry n_ar * T_out target frames; synthetic sets only T_out
+            normalized_test_loss += float(((pred[..., :c] - t[..., :c]) ** 2).reshape(b, -1).mean())       # eval.py:323
+            _, p = normalizer.postprocess(x, pred)
+            _, tt = normalizer.postprocess(x, t)
+            pred_list.append(p)                                     # stay in HBM: the metrics run on the device (row f3)
+            target_list.append(tt)
+        n_batches += 1
+        nb += b
     torch.cuda.synchronize()
     dt = time.time() - start
-    T_out = tuple(test_dataset[0][1].shape)[0]
+    T_out = (T_tgt // n_ar) if pred_list else T_tgt
     logging.info(f"rollout: {nb} trajectories x {n_ar} steps in {dt:.2f} s = {nb * T_out * n_ar / dt:.1f} fields/s")
-    if cnt:
-        logging.info(f"normalized mse {nmse / nb:.5f}, rmse {(se / cnt) ** 0.5:.5f}, mae {ae / cnt:.5f}, "
-                     f"rel l2 {(se / max(ref2, 1e-30)) ** 0.5:.5f}")
-        names = ("rmse", "mae", "rel_l2_error", "r2", "ke_error", "f_error", "low_f_error", "mid_f_error", "high_f_error",
-                 "rel_low_f_error", "rel_mid_f_error", "rel_high_f_error", "freq_error")
-        avg = torch.stack(metric_rows).sum(0) / nb
-        logging.info("eval_metrics (batch-weighted mean): " + ", ".join(f"{n} {float(v):.5g}" for n, v in zip(names, avg)))
+    if not pred_list:
+        logging.info("targets cover one step only: rollout timed, no metrics (a test split with N_autoregressive frames has them)")
+        return {}, None, None
+    normalized_test_loss /= n_batches
+    pred, target = torch.cat(pred_list, dim=0), torch.cat(target_list, dim=0)
+    eval_batch_size = test_batch_size if n_ar > 4 else pred.shape[0]                       # eval.py:346-349
+    vals = eval_metrics(pred, target, c, eval_batch_size)                                   # eval.py:350-352, on the device
+    logging.info("Test results: \n" + f"normalized mse loss: {normalized_test_loss:.5f}, "
+                 + ", ".join(f"{n}: {float(v):.5f}" for n, v in zip(METRIC_NAMES, vals)))
+    logging.info(f"Testing complete, time cost is {(time.time() - start) / 60:.2f} min")
+    results = dict(zip(("normalized_mse",) + METRIC_NAMES, [normalized_test_loss] + [float(v) for v in vals]))
+    results["evaluated_channels"] = c
+    return results, pred, target
 
 
 if __name__ == "__main__":

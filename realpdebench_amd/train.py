@@ -17,7 +17,7 @@ from .data import DevicePrefetcher, make_datasets
 from .data_normalizer import GaussianNormalizer, IdentityNormalizer
 from .model import load_model
 from .trainer import make_trainer
-from .utils import add_args_from_config, cycle, resolve_config, set_seed, setup_logging
+from .utils import add_hf_compat_flags, add_args_from_config, check_hf_compat_flags, cycle, resolve_config, set_seed, setup_logging
 
 parser = argparse.ArgumentParser(description="Training Configurations")
 parser.add_argument("--config", type=str, default="configs/cylinder/fno.yaml")
@@ -26,10 +26,12 @@ parser.add_argument("--train_data_type", type=str, default="numerical", help="nu
 parser.add_argument("--is_finetune", action="store_true", help="enable finetuning mode")
 parser.add_argument("--dataset_factory", type=str, default=None, help="module:function -> (train, val, stats)")
 parser.add_argument("--max_updates", type=int, default=None, help="stop early (smoke runs); the schedule still uses num_update")
+add_hf_compat_flags(parser)
 
 
 def main(argv=None):
     args = parser.parse_args(argv)
+    check_hf_compat_flags(args)
     args.config = resolve_config(args.config)
     args = add_args_from_config(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -20,7 +20,7 @@ from .data_normalizer import GaussianNormalizer, IdentityNormalizer, RangeNormal
 from .disk import SurrogateBatchLoader, SurrogateWindows, compute_max, compute_mean_std
 from .model import load_model
 from .trainer import make_trainer
-from .utils import add_args_from_config, resolve_config, set_seed, setup_logging
+from .utils import add_hf_compat_flags, add_args_from_config, check_hf_compat_flags, resolve_config, set_seed, setup_logging
 
 parser = argparse.ArgumentParser(description="Training Configurations")
 parser.add_argument("--config", type=str, default="configs/combustion/surrogate_model/fno.yaml")
@@ -29,11 +29,13 @@ parser.add_argument("--use_hf_dataset", action="store_true", help="accepted for 
 parser.add_argument("--max_updates", type=int, default=None, help="stop early (smoke runs); the schedule still uses num_update")
 parser.add_argument("--test_every", type=int, default=50, help="train_surrogate.py:171 hard-codes 50")
 parser.add_argument("--dataset_kwargs", type=str, default="{}", help="JSON of SurrogateWindows arguments (step, n_sim_frame ...)")
+add_hf_compat_flags(parser)
 
 
 def main(argv=None):
     import json
     args = parser.parse_args(argv)
+    check_hf_compat_flags(args)
     args.config = resolve_config(args.config)
     args = add_args_from_config(args)
     if not torch.cuda.is_available():

@@ -45,3 +45,21 @@ def cycle(iterable):
     while True:
         for x in iterable:
             yield x
+
+
+def add_hf_compat_flags(parser):
+    """The Arrow-reader switches of the reference's entrypoints (train.py:29-53, eval.py:30-54, train_surrogate.py:20-46).  This
+    backend always reads the Arrow layout, so ``--use_hf_dataset`` changes nothing; there is no network path, so
+    ``--hf_auto_download`` is refused by ``check_hf_compat_flags`` instead of being silently ignored."""
+    if not any(a.dest == "use_hf_dataset" for a in parser._actions):
+        parser.add_argument("--use_hf_dataset", action="store_true", help="accepted for CLI compatibility (Arrow is the only reader)")
+    parser.add_argument("--hf_auto_download", action="store_true", help="not supported: fetch the data with the reference's CLI")
+    parser.add_argument("--hf_repo_id", type=str, default="AI4Science-WestlakeU/RealPDEBench")
+    parser.add_argument("--hf_endpoint", type=str, default=None)
+    parser.add_argument("--hf_revision", type=str, default=None)
+
+
+def check_hf_compat_flags(args):
+    if getattr(args, "hf_auto_download", False):
+        raise SystemExit("--hf_auto_download: this backend has no download path; fetch the dataset with the reference "
+                         "(`realpdebench download --dataset-root ... --what hf_dataset`) and point dataset_root at it")

@@ -154,7 +154,51 @@ def test_train_from_the_on_disk_arrow_layout(tmp_path):
     exp = tr.main(["--config", str(path), "--max_updates", "6", "--train_data_type", "numerical"])
     ck = torch.load(sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1], map_location="cpu")
     assert ck["iteration"] == 6 and all(l == l and l < 1e3 for l in ck["train_losses"])     # finite, normalised-scale losses
-    ev.main(["--config", str(path), "--checkpoint_path", sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1]])   # test split
+    ckpt = sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1]
+    res = ev.main(["--config", str(path), "--checkpoint_path", ckpt, "--use_hf_dataset"])   # test split of the real data
     assert os.path.exists(os.path.join(exp, "eval.log"))
+    assert res["evaluated_channels"] == 2                           # real data has no pressure: eval.py:297-302 drops the all-zero channel
+    assert all(v == v for v in res.values()) and res["rmse"] > 0
+    _check_evaluate_against_a_plain_restatement(str(root), path, ckpt, res)
     stats = torch.load(os.path.join(str(root), "cylinder", "mean_std.pt"), weights_only=True)
     assert len(stats) == 4 and stats[0].shape == (3,) and abs(float(stats[0][0]) - 0.5) < 0.05      # fields ~ N(0.5, 1)
+
+
+def _check_evaluate_against_a_plain_restatement(root, cfg_path, ckpt, res):
+    """eval.evaluate vs the loop of realpdebench/eval.py:294-352 written out with plain torch ops on the same model and split."""
+    import argparse
+
+    from torch.utils.data import DataLoader
+
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd.data import make_datasets
+    from realpdebench_amd.data_normalizer import GaussianNormalizer
+    from realpdebench_amd.model import load_model
+    from realpdebench_amd.utils import add_args_from_config
+    args = add_args_from_config(argparse.Namespace(config=str(cfg_path), train_data_type="numerical"))
+    train_ds, test_ds, stats = make_datasets(args, for_eval=True)
+    model = load_model(train_ds, device="cuda", **vars(args))
+    model.load_checkpoint(ckpt, "cuda")
+    model.eval()
+    mi, mt, si, st = (t.cuda() for t in stats)
+    loss, preds, tgts = 0.0, [], []
+    loader = DataLoader(test_ds, batch_size=args.test_batch_size, shuffle=False)
+    with torch.no_grad():
+        for inp, tgt in loader:
+            x, t = (inp.cuda() - mi) / si, (tgt.cuda() - mt) / st
+            p = model(x)                                            # N_autoregressive = 1
+            p = (p * st + mt - mi) / si                             # eval.py:315-318: postprocess, then preprocess as an INPUT --
+                                                                    # the reference's rollout does this after the last step too
+            loss += float(((p[..., :2] - t[..., :2]) ** 2).reshape(inp.size(0), -1).mean())
+            preds.append(p * st + mt)
+            tgts.append(t * st + mt)
+    pred, target = torch.cat(preds)[..., :2], torch.cat(tgts)[..., :2]
+    b = pred.shape[0]
+    rmse = float(((pred - target) ** 2).mean().sqrt())
+    mae = float((pred - target).abs().mean())
+    rel = float((torch.norm((pred - target).reshape(b, -1), dim=1) / torch.norm(target.reshape(b, -1), dim=1)).mean())
+    r2 = float(1 - ((pred - target) ** 2).sum() / ((target - target.mean(0, keepdim=True)) ** 2).sum())
+    for k, v in (("normalized_mse", loss / len(loader)), ("rmse", rmse), ("mae", mae), ("rel l2 error", rel), ("r2", r2)):
+        assert abs(res[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, res[k], v)
+    res2, p2, t2 = ev.evaluate(model, loader, GaussianNormalizer(*stats, device="cuda"), 1, args.test_batch_size)
+    assert torch.allclose(p2[..., :2], pred, rtol=1e-5, atol=1e-5) and abs(res2["rmse"] - res["rmse"]) < 1e-7
