@@ -29,6 +29,32 @@ parser.add_argument("--max_updates", type=int, default=None, help="stop early (s
 add_hf_compat_flags(parser)
 
 
+VAL_KEYS = ("rmse", "mae", "rel_l2_error", "r2", "ke_error", "f_error", "low_f_error", "mid_f_error", "high_f_error",
+            "rel_low_f_error", "rel_mid_f_error", "rel_high_f_error", "freq_error")
+
+
+@torch.no_grad()
+def validate(model, val_loader, normalizer):
+    """The validation pass of realpdebench/train.py:344-373: one forward per batch, the normalised MSE over the measured channels
+    (all-zero target channels of the first batch are skipped: real data has no pressure) as the mean of per-batch means, and
+    ``eval_metrics`` once over the de-normalised, concatenated split -- on the device (``realpdebench_amd.metrics``)."""
+    from .metrics import eval_metrics
+    model.eval()
+    nmse, preds, tgts, c = 0.0, [], [], None
+    for vi, vt in val_loader:
+        b = vi.size(0)
+        if c is None:
+            c = vt.shape[-1] - sum(int(torch.all(vt[..., k] == 0)) for k in range(vt.shape[-1]))
+        vi, vt = normalizer.preprocess(vi, vt)
+        pred = model(vi)
+        nmse += float(((pred[..., :c] - vt[..., :c]) ** 2).reshape(b, -1).mean())
+        _, p = normalizer.postprocess(vi, pred)
+        _, t = normalizer.postprocess(vi, vt)
+        preds.append(p)
+        tgts.append(t)
+    return nmse / len(val_loader), eval_metrics(torch.cat(preds), torch.cat(tgts), c)
+
+
 def main(argv=None):
     args = parser.parse_args(argv)
     check_hf_compat_flags(args)
@@ -85,7 +111,7 @@ def main(argv=None):
 
     n_iter = args.num_update if args.max_updates is None else min(args.num_update, args.max_updates)
     every = max(1, int(args.num_update / 50))                       # train.py:344
-    all_train_losses, all_val_losses = [], {"normalized_mse": [], "rmse": [], "mae": [], "rel_l2_error": []}
+    all_train_losses, all_val_losses = [], {k: [] for k in ("normalized_mse",) + VAL_KEYS}        # train.py:303-319
     best_val, best_it = float("inf"), 0
     pending, start = [], time.time()
     if on_disk:       # row f2: memory-mapped Arrow slabs -> pinned staging -> rpb_window_pack (+ normaliser) on a side stream
@@ -99,31 +125,18 @@ def main(argv=None):
         if iteration % every == 0 or iteration == n_iter:
             all_train_losses += [float(v) for v in torch.cat(pending).cpu()]    # ONE sync per interval
             pending = []
-            model.eval()
-            se = ae = ref2 = nmse = 0.0
-            cnt = 0
-            with torch.no_grad():
-                for vi, vt in val_loader:
-                    vi, vt = normalizer.preprocess(vi, vt)
-                    pred = model(vi)
-                    nmse += float(((pred - vt) ** 2).mean()) * vi.shape[0]
-                    _, p = normalizer.postprocess(vi, pred)
-                    _, t = normalizer.postprocess(vi, vt)
-                    se += float(((p - t) ** 2).sum())
-                    ae += float((p - t).abs().sum())
-                    ref2 += float((t ** 2).sum())
-                    cnt += t.numel()
-            n_val = len(val_loader.dataset)
-            rmse = (se / cnt) ** 0.5
-            all_val_losses["normalized_mse"].append(nmse / n_val)
-            all_val_losses["rmse"].append(rmse)
-            all_val_losses["mae"].append(ae / cnt)
-            all_val_losses["rel_l2_error"].append((se / max(ref2, 1e-30)) ** 0.5)
+            nmse, vals = validate(model, val_loader, normalizer)
+            all_val_losses["normalized_mse"].append(nmse)
+            for k, v in zip(VAL_KEYS, vals):
+                all_val_losses[k].append(float(v))
+            rmse = float(vals[0])
             if rmse < best_val:
                 best_val, best_it = rmse, iteration
             if rank == 0:
-                logging.info(f"Iteration {iteration}, train loss {sum(all_train_losses[-every:]) / every:.5f}, "
-                             f"val nmse {nmse / n_val:.5f}, rmse {rmse:.5f}, lr {trainer.current_lr():.3e}")
+                logging.info(f"\nIteration {iteration}, train loss: {sum(all_train_losses[-every:]) / every:.5f} "
+                             f"(lr {trainer.current_lr():.3e})")
+                logging.info("Validation results: \n" + f"normalized mse loss: {nmse:.5f}, "
+                             + ", ".join(f"{k.replace('_', ' ')}: {float(v):.5f}" for k, v in zip(VAL_KEYS, vals)))
                 torch.save({"model_state_dict": model.state_dict(), "train_losses": all_train_losses,
                             "val_losses": all_val_losses, "iteration": iteration, "best_iteration": best_it,
                             "best_val_loss": best_val}, os.path.join(exp_path, f"model_{iteration:04d}.pth"))

@@ -25,6 +25,12 @@ def test_train_then_eval(tmp_path):
     ck = torch.load(ckpts[-1], map_location="cpu")
     assert set(ck) == {"model_state_dict", "train_losses", "val_losses", "iteration", "best_iteration", "best_val_loss"}
     assert ck["iteration"] == 4 and len(ck["train_losses"]) == 4
+    assert set(ck["val_losses"]) == {"normalized_mse", "rmse", "mae", "rel_l2_error", "r2", "ke_error", "f_error", "low_f_error",
+                                     "mid_f_error", "high_f_error", "rel_low_f_error", "rel_mid_f_error", "rel_high_f_error",
+                                     "freq_error"}                   # train.py:303-319
+    assert all(len(v) == len(ck["val_losses"]["rmse"]) >= 1 for v in ck["val_losses"].values())
+    assert all(x == x for k in ("normalized_mse", "rmse", "mae", "rel_l2_error", "r2") for x in ck["val_losses"][k])
+    # (the Fourier band means are over empty bin ranges on a 4 x 12 x 10 grid -- NaN in the reference as well)
     assert ck["model_state_dict"]["spectral_convs.0.weights1"].dtype == torch.complex64
     assert ck["train_losses"][-1] < ck["train_losses"][0] * 1.5          # finite and sane
     ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
