@@ -43,7 +43,8 @@ def main(argv=None):
     torch.cuda.set_device(args.gpu)
     device = torch.device("cuda", args.gpu)
     set_seed(args.seed)
-    random.seed(args.seed)           # the sample draws use `random` (utils.set_seed of the reference seeds it too)
+    random.seed(args.seed)           # the sample draws use `random`, which the reference's set_seed leaves unseeded: seeded here
+                                     # so that a run is reproducible
 
     exp_path = os.path.join(args.results_path, args.model_name, args.exp_name,
                             datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
