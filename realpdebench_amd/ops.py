@@ -87,7 +87,8 @@ def mode_contract_fwd(X, W, Y, B, M, C):
 def mode_contract_dgrad(GY, W, GX, B, M, C):
     # the kernel keeps the [B][2][C] gradient tile and the padded [C][C+1] complex weight tile of a mode in LDS:
     # at width 128 that caps the batch per launch, so larger batches go in batch-major slices (contiguous in X)
-    lds_cap = 160 * 1024 - C * (C + 1) * 8
+    # (widths that are multiples of 32 take the 32-row-chunk kernel: a [32][C+1] weight tile)
+    lds_cap = 160 * 1024 - (32 if C % 32 == 0 else C) * (C + 1) * 8
     bmax = max(1, lds_cap // (2 * C * 4))
     b0 = 0
     while b0 < B:
