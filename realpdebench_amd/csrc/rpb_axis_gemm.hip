@@ -220,7 +220,10 @@ static int launch_axis(const float* in, float* out, const float* M, int G, int K
     const int waves = 4;
     const long nitems = (long)G * (N / (32 * NV)) * och;
     const int per_cu = lds > 0 ? (int)((160 * 1024) / lds) : 8;
-    long grid = (long)rpb_num_cus() * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    // workgroups per CU: the light variants (<= 84 registers: the W stage, K = 134 -> O = 32) gain 13 % from six instead of four
+    // (their waves sit on s_waitcnt ~40 % of the time, profiles/r01_pmc_axis_gemm.txt); the T stages (OT * NV = 4) lose 10 %
+    const int cap = (OT * NV <= 2) ? 6 : 4;
+    long grid = (long)rpb_num_cus() * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
     const long need = (nitems + waves - 1) / waves;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
