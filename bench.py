@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X FNO3d path (contract: see the task statement / DESIGN.md).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N>1: either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (WORLD_SIZE set: this
+process is one rank) or started plainly as ``python bench.py --gpus N``: it then re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1, one per GPU over RCCL, and the ranks' JSON line is this run's line.
 
 One "step" = one full training iteration of the reference's hot loop (train.py:321-334: forward, MSE mean,
 backward, Adam, cosine LR) on a synthetic batch of BASELINE.json configs[1]: FNO3d cylinder-shaped
@@ -37,9 +41,28 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
     ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
     ap.add_argument("--no-galerkin", action="store_true", help="skip the secondary Galerkin Transformer measurement")
-    ap.add_argument("--no-unet", action="store_true", help="skip the secondary U-Net measurement")
+    ap.add_argument("--no-unet", action="store_true", help="skip the secondary U-Net measurements (cylinder YAML and C3 mesh)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage FNO rollout (BASELINE.json configs[4])")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` without a launcher: spawn the N ranks ourselves (one process per GPU, RCCL)."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    share = os.environ.get("RPB_BENCH_SHARE_GPU") == "1"      # plumbing test on a 1-GPU box: ranks share cuda:0 over gloo
+    if n_vis < a.gpus and not share:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_vis} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def usable_cores():
@@ -55,34 +78,52 @@ def usable_cores():
 
 
 def cpu_baseline_worker():
-    """Child process: the oracle (PyTorch-CPU restatement of the reference) does two training steps at B=1."""
+    """Child process: SURVEY.md section 8(d) / BASELINE.md section 3 -- the CPU oracle (PyTorch-CPU restatement of the
+    reference, pinned to reference vectors) runs BASELINE.json configs[0] exactly: B=4, [20,128,128,2], modes (4,12,16),
+    width 64, 4 layers; 1 warm-up + 3 timed train steps (zero_grad -> fwd -> MSE mean -> bwd -> Adam -> cosine), then a
+    10-step autoregressive rollout.  One JSON line per finished part, so a timeout still leaves the train number."""
     from oracle import fno3d_oracle as O
+    from realpdebench_amd.synthetic import normal_batch
     shape, modes, width, n_layers = (20, 128, 128, 2), (4, 12, 16), 64, 4
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
-    Bc = 1
+    Bc, nsteps = 4, 3
     sd = O.init_state_dict(modes, n_layers, width, shape, shape, seed=0)
-    g = torch.Generator().manual_seed(0)
-    nsteps = 2                                              # ~12-15 s of CPU work on the GPU box's 16 usable cores
-    batches = [(torch.randn(Bc, *shape, generator=g), torch.randn(Bc, *shape, generator=g)) for _ in range(nsteps)]
-    t0 = time.time()
-    O.train_steps(sd, batches, modes, n_layers, shape, shape, lr0=1e-4, t_max=4000)
-    dt = time.time() - t0
-    print(json.dumps({"value": nsteps * Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                      "sample": f"{nsteps} train steps (fwd+bwd+Adam) of the CPU oracle at B={Bc}, same shape and model, "
-                                f"{dt:.1f} s, no warm-up"}))
+    batches = [(normal_batch(10 + 2 * i, Bc, *shape), normal_batch(11 + 2 * i, Bc, *shape)) for i in range(nsteps + 1)]
+    stamps = []
+    O.train_steps(sd, batches, modes, n_layers, shape, shape, lr0=1e-4, t_max=4000, stamps=stamps)   # step 0 = warm-up
+    times = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
+    res = {"value": Bc / (sum(times) / nsteps), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "best_samples_per_s": Bc / min(times),
+           "sample": f"BASELINE.json configs[0]: CPU oracle, B={Bc}, 1 warm-up + {nsteps} timed train steps "
+                     f"(fwd+MSE+bwd+Adam+cosine), mean {sum(times) / nsteps:.1f} s/step, min {min(times):.1f} s"}
+    print(json.dumps(res), flush=True)
+    n_ar = 10
+    with torch.no_grad():
+        t0 = time.time()
+        O.rollout(sd, batches[0][0], n_ar, modes, n_layers, shape, shape)
+        rt = time.time() - t0
+    res["rollout"] = {"value": Bc * shape[0] * n_ar / rt, "unit": "fields/s", "n_autoregressive": n_ar,
+                      "sample": f"{n_ar}-step autoregressive rollout at B={Bc}, {rt:.1f} s"}
+    print(json.dumps(res), flush=True)
 
 
-def cpu_baseline():
-    """Bounded: runs in a child process with a hard timeout so the default bench always finishes in minutes."""
+def cpu_baseline(timeout=480):
+    """Bounded: runs in a child process with a hard timeout so the default bench always finishes in minutes; whatever part
+    of the sample finished before the timeout is reported."""
     import subprocess
+    out = ""
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
-                           text=True, timeout=300)
-        return json.loads(r.stdout.strip().splitlines()[-1])
-    except Exception as e:        # timeout / parse error: report it, never hang the bench
-        return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
-                "sample": f"CPU oracle step did not finish within 300 s ({type(e).__name__})"}
+                           text=True, timeout=timeout)
+        out = r.stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    if lines:
+        return json.loads(lines[-1])
+    return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
+            "sample": f"CPU oracle sample (configs[0], B=4) did not finish one part within {timeout} s"}
 
 
 def _flush_c_stdio():
@@ -96,190 +137,248 @@ def _flush_c_stdio():
         pass
 
 
-def _conv_model_roofline(achieved_tf):
-    """Transolver / U-Net: 70-83 % of the FLOPs are 3x3x3 convolutions, which run on the bf16 MFMA from split fp32 operands
-    (hi + mid + lo, six bf16 products per fp32 product, fp32 accumulate: csrc/rpb_conv3x.hip); the rest is fp32 MFMA.
-    ``achieved`` counts algorithmic (fp32) FLOPs of the whole step; the two peaks bracket what a step can reach."""
-    return {"achieved": achieved_tf, "unit": "TFLOP/s (fp32-equivalent)", "peak_f32_mfma": MFMA_F32_PEAK_TF,
-            "peak_split_bf16": MFMA_BF16_PEAK_TF / 6.0, "frac_of_f32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TF,
-            "frac_of_split_bf16_peak": achieved_tf / (MFMA_BF16_PEAK_TF / 6.0),
-            "conv_arith": "RPB_CONV3_EXACT=1" if os.environ.get("RPB_CONV3_EXACT") == "1" else "split-bf16 (fp32-grade)"}
+SPLIT_BF16_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0      # one fp32-grade product = six bf16 MFMA products (csrc/rpb_conv3x.hip)
+SPLIT_LABELS = ("conv3x", "gemm3x", "conv3x_wgrad")
+
+
+def pipe_rooflines(summary, steps):
+    """Per-kernel MEASURED work of one profiled train step (HIP events around every launch; flops / algorithmic bytes are
+    the per-launch figures ops.py attaches), grouped by the pipe that executes it: split-bf16 MFMA (fp32-grade convolutions and
+    token GEMMs), fp32 MFMA, and HBM-bound kernels (no matrix work).  Fractions are against the pipe actually used."""
+    pipes = {"split_bf16_mfma": [0.0, 0.0, 0.0], "f32_mfma": [0.0, 0.0, 0.0], "hbm": [0.0, 0.0, 0.0]}
+    for label, v in summary.items():
+        fam = label.split("[")[0]
+        ai = v["flops"] / max(v["bytes"], 1.0)
+        pipe = "split_bf16_mfma" if fam in SPLIT_LABELS else ("f32_mfma" if ai > 8.0 else "hbm")
+        p = pipes[pipe]
+        p[0] += v["total_ms"] / steps
+        p[1] += v["flops"] * v["calls"] / steps
+        p[2] += v["bytes"] * v["calls"] / steps
+    tot = sum(p[0] for p in pipes.values())
+    out = {"kernel_ms_per_step": tot}
+    for name, (ms, fl, by) in pipes.items():
+        if ms <= 0:
+            continue
+        e = {"ms_per_step": ms, "share_of_kernel_time": ms / tot}
+        if name == "hbm":
+            e.update(achieved=by / ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by / ms / 1e6 / HBM_PEAK_GBS)
+        else:
+            peak = SPLIT_BF16_PEAK_TF if name == "split_bf16_mfma" else MFMA_F32_PEAK_TF
+            e.update(achieved=fl / ms / 1e9, peak=peak, unit="TFLOP/s (fp32-equivalent)" if name == "split_bf16_mfma" else "TFLOP/s",
+                     frac=fl / ms / 1e9 / peak, flops_per_step=fl)
+        out[name] = e
+    return out
+
+
+def bench_model(dev, make_model, x, y, lr, steps, config, exact_line=False, forward=True):
+    """Train step (the reference's loop body through realpdebench_amd.trainer.make_trainer) and eval forward of one of the
+    secondary models; one extra step runs with HIP events around every launch for the measured per-pipe rooflines."""
+    from realpdebench_amd import _lib, ops
+    from realpdebench_amd.trainer import make_trainer
+    torch.manual_seed(0)
+    m = make_model().to(dev)
+    tr = make_trainer(m, lr=lr, num_update=4000)
+    B = x.shape[0]
+
+    def timed(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    timed(2)                                # two warm-up steps: the first one pays allocator growth and code loading
+    t_train = timed(steps)
+    _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
+    timed(1)
+    prof = _lib.profile_summary()
+    _lib.PROFILE = None
+    res = {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
+           "trainer": type(tr).__name__, "roofline": pipe_rooflines(prof, 1),
+           "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30, "config": config}
+    if exact_line:                          # the same step with every convolution / GEMM on the exact-fp32 MFMA kernels
+        ops.CONV3_SPLIT, ops.GEMM_SPLIT = False, False
+        try:
+            timed(1)
+            res["exact_f32_ms_per_step"] = 1e3 * timed(steps)
+        finally:
+            ops.CONV3_SPLIT, ops.GEMM_SPLIT = True, True
+    if forward:
+        m.eval()
+        with torch.no_grad():
+            m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m(x)
+            torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t0) / steps
+        res.update(forward_fields_per_s=B * y.shape[1] / t_fwd, ms_per_forward=1e3 * t_fwd)
+    del m, tr
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    return res
+
+
+def _yaml(*path):
+    import yaml
+    with open(os.path.join(ROOT, "realpdebench_amd", "configs", *path)) as fh:
+        return yaml.safe_load(fh)
 
 
 def bench_unet(dev, steps=2):
-    """U-Net at the reference's configs/cylinder/unet.yaml ([12,20,64,128,3], dim = H = 64 -> 64/128/256 channels,
-    dim_mults [1,2,4]): train step through the drop-in protocol (HIP forward + taped HIP backward, torch.optim.Adam) and
-    eval forward.  fp32 MFMA roofline: SURVEY.md section 8(a8) measured 555 GFLOP forward per sample at 20x64x64 with
-    FlopCounterMode on the oracle; the cylinder mesh has twice the cells -> 1.11 TFLOP forward, x3 for a step."""
-    import yaml
+    """U-Net at the reference's configs/cylinder/unet.yaml ([12,20,64,128,3], dim = H = 64 -> 64/128/256 channels)."""
     from realpdebench_amd.model.unet import Unet3d
-    with open(os.path.join(ROOT, "realpdebench_amd", "configs", "cylinder", "unet.yaml")) as fh:
-        cfg = yaml.safe_load(fh)
+    cfg = _yaml("cylinder", "unet.yaml")
     T, H, W, C = cfg["shape_in"]
     B = int(cfg["train_batch_size"])
-    torch.manual_seed(0)
-    m = Unet3d(dim=H, out_channels=cfg["shape_out"][-1], dim_mults=cfg["dim_mults"], channels=C, in_time=T,
-               out_time=cfg["shape_out"][0]).to(dev)
     x = torch.randn(B, T, H, W, C, device=dev)
     y = torch.randn(B, *cfg["shape_out"], device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"])
+    return bench_model(dev, lambda: Unet3d(dim=H, out_channels=cfg["shape_out"][-1], dim_mults=cfg["dim_mults"], channels=C,
+                                           in_time=T, out_time=cfg["shape_out"][0]), x, y, cfg["lr"], steps,
+                       "configs/cylinder/unet.yaml: [12,20,64,128,3], dim 64, dim_mults [1,2,4], 4 heads x 32",
+                       exact_line=True)
 
-    def step():
-        opt.zero_grad()
-        m.train_loss(x, y).mean().backward()
-        opt.step()
 
-    m.train()
-    step()
-    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    t_train = (time.perf_counter() - t0) / steps
-    m.eval()
-    with torch.no_grad():
-        m(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            m(x)
-        torch.cuda.synchronize()
-    t_fwd = (time.perf_counter() - t0) / steps
-    flops_step = 3 * 1.11e12 * B
-    del m, opt
-    torch.cuda.empty_cache()
-    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
-            "forward_fields_per_s": B * cfg["shape_out"][0] / t_fwd, "ms_per_forward": 1e3 * t_fwd,
-            "mfma": _conv_model_roofline(flops_step / t_train / 1e12),
-            "config": "configs/cylinder/unet.yaml: [12,20,64,128,3], dim 64, dim_mults [1,2,4], 4 heads x 32"}
+def bench_unet_c3(dev, steps=1):
+    """BASELINE.json configs[2] mesh: U-Net on the fsi-shaped 20 x 256 x 256 sample, dim = H = 256 (load_model.py:52) ->
+    256/512/1024 channels.  One sample is what fp32 allows: B=1 peaks at ~115 GiB, so the configuration's B=16 per GPU is out
+    of reach of a 288 GB device in fp32 (for the reference as well); reported as measured, with its memory footprint."""
+    from realpdebench_amd.model.unet import Unet3d
+    x = torch.randn(1, 20, 256, 256, 3, device=dev)
+    y = torch.randn(1, 20, 256, 256, 3, device=dev)
+    r = bench_model(dev, lambda: Unet3d(dim=256, out_channels=3, dim_mults=[1, 2, 4], channels=3, in_time=20, out_time=20),
+                    x, y, 1e-4, steps, "U-Net fsi-shaped C3 mesh [1,20,256,256,3], dim 256 -> 256/512/1024 channels", forward=False)
+    r["note"] = "BASELINE configs[2] asks B=128 over 8 GPUs = 16 per GPU; fp32 activations allow 2 per 288 GB GPU"
+    return r
 
 
 def bench_galerkin(dev, steps=3):
-    """Galerkin Transformer at the reference's configs/cylinder/galerkin_transformer.yaml (n = 20*64*128 tokens, hidden
-    256, freq_dim 128, modes (4,16,20), train_batch_size 16): train step through the drop-in protocol (HIP
-    forward/backward, dropout masks drawn, torch.optim.Adam) and eval forward.  Dense FLOPs per token forward:
-    2*(768*256 + 2*256*256 + 128*256) Linear + 2*2*256*64 head products = 0.79 MFLOP, x3 for a step; the spectral
-    regressor and the head products are HBM-bound."""
-    import yaml
+    """Galerkin Transformer at the reference's configs/cylinder/galerkin_transformer.yaml (n = 20*64*128 tokens, hidden 256,
+    freq_dim 128, modes (4,16,20), train_batch_size 16)."""
     from realpdebench_amd.model.galerkin_transformer import GalerkinTransformer3d
-    with open(os.path.join(ROOT, "realpdebench_amd", "configs", "cylinder", "galerkin_transformer.yaml")) as fh:
-        cfg = yaml.safe_load(fh)
+    cfg = _yaml("cylinder", "galerkin_transformer.yaml")
     T, H, W, Cin = cfg["shape_in"]
     B = int(cfg["train_batch_size"])
     cfg.update(node_feats=Cin, n_targets=cfg["shape_out"][-1])
-    torch.manual_seed(0)
-    m = GalerkinTransformer3d(**cfg).to(dev)
     x = torch.randn(B, T, H, W, Cin, device=dev)
     y = torch.randn(B, *cfg["shape_out"], device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"])
-
-    def step():
-        opt.zero_grad()
-        m.train_loss(x, y).mean().backward()
-        opt.step()
-
-    m.train()
-    step()
-    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    t_train = (time.perf_counter() - t0) / steps
-    m.eval()
-    with torch.no_grad():
-        m(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            m(x)
-        torch.cuda.synchronize()
-    t_fwd = (time.perf_counter() - t0) / steps
-    tokens = B * T * H * W
-    flops_step = 3 * 0.79e6 * tokens
-    del m, opt
-    torch.cuda.empty_cache()
-    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
-            "forward_fields_per_s": B * cfg["shape_out"][0] / t_fwd, "ms_per_forward": 1e3 * t_fwd,
-            "mfma_f32": {"achieved": flops_step / t_train / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": flops_step / t_train / 1e12 / MFMA_F32_PEAK_TF},
-            "config": "configs/cylinder/galerkin_transformer.yaml: [16,20,64,128,3], n_hidden 256, 4 heads, freq_dim 128, "
-                      "modes (4,16,20), dropout 0.05 / attention 0.5"}
+    return bench_model(dev, lambda: GalerkinTransformer3d(**cfg), x, y, cfg["lr"], steps,
+                       "configs/cylinder/galerkin_transformer.yaml: [16,20,64,128,3], n_hidden 256, 4 heads, freq_dim 128, "
+                       "modes (4,16,20), dropout 0.05 / attention 0.5")
 
 
 def bench_transolver(dev, B=4, steps=3):
     """Transolver (configs/cylinder/trainsolver.yaml: 20x64x128x3 tokens -> mesh 128x64x20, hidden 256, 8 heads, 16
-    slices, 1 layer) -- train step through the drop-in protocol (HIP forward/backward + torch.optim.Adam) and eval
-    forward.  Reported next to the FNO headline; MFMA roofline (the two 3x3x3 convolutions are 83 % of the FLOPs)."""
+    slices, 1 layer, dropout 0.1)."""
     from realpdebench_amd.model.transolver import Transolver
-    torch.manual_seed(0)
-    m = Transolver(space_dim=3, n_layers=1, n_hidden=256, n_head=8, fun_dim=0, out_dim=3, slice_num=16, mlp_ratio=4,
-                   H=128, W=64, D=20, dropout=0.1).to(dev)
     x = torch.randn(B, 20, 64, 128, 3, device=dev)
     y = torch.randn(B, 20, 64, 128, 3, device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=7e-4)
+    return bench_model(dev, lambda: Transolver(space_dim=3, n_layers=1, n_hidden=256, n_head=8, fun_dim=0, out_dim=3,
+                                               slice_num=16, mlp_ratio=4, H=128, W=64, D=20, dropout=0.1), x, y, 7e-4, steps,
+                       "Transolver cylinder: tokens 20x64x128 -> mesh (128,64,20), n_hidden 256, 8 heads, 16 slices, "
+                       "1 layer, mlp_ratio 4, dropout 0.1, fp32", exact_line=True)
 
-    def step():
-        opt.zero_grad()
-        m.train_loss(x, y).mean().backward()
-        opt.step()
 
-    m.train()
-    step()
-    step()                                  # two warm-up steps: the first one pays allocator growth and code loading
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    t_train = (time.perf_counter() - t0) / steps
-    m.eval()
-    with torch.no_grad():
-        m(x)
+def bench_rollout_bf16(dev):
+    """BASELINE.json configs[4]: FNO3d on the 64^3 combustion volume, bf16 activation storage, 20 autoregressive steps."""
+    try:
+        from realpdebench_amd.model.fno import FNO3d
+        if not hasattr(FNO3d, "set_storage"):
+            return {"status": "not built"}
+    except Exception as e:                                      # pragma: no cover
+        return {"status": f"unavailable: {e}"}
+    from realpdebench_amd.rollout import autoregressive_rollout
+    shape, modes, L, B, n_ar = (64, 64, 64, 16), (4, 16, 16), 4, 8, 20
+    torch.manual_seed(0)
+    m = FNO3d(*modes, L, 64, shape, shape).to(dev).eval()
+    x = torch.randn(B, *shape, device=dev)
+    res = {}
+    outs = {}
+    for storage in ("f32", "bf16"):
+        m.set_storage(storage)
+        autoregressive_rollout(m, x, 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            m(x)
+        outs[storage] = autoregressive_rollout(m, x, n_ar)
         torch.cuda.synchronize()
-    t_fwd = (time.perf_counter() - t0) / steps
-    tokens = B * 20 * 64 * 128
-    flops_step = 3 * 8.56e6 * tokens              # SURVEY.md section 8(d): 8.56 MFLOP/token forward, x3 for a step
-    del m, opt
+        rt = time.perf_counter() - t0
+        bpe = 2 if storage == "bf16" else 4
+        fwd_bytes = (0.445 * bpe / 2 * B + 0.537) * 1e9       # SURVEY.md section 8(d), C5: 2 B/element activations, fp32 weights
+        res[storage] = {"value": B * shape[0] * n_ar / rt, "unit": "fields/s", "ms_per_forward": 1e3 * rt / n_ar,
+                        "roofline": {"bound": "hbm", "algorithmic_bytes_per_forward": fwd_bytes,
+                                     "achieved": fwd_bytes / (1e6 * rt / n_ar), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": fwd_bytes / (1e6 * rt / n_ar) / HBM_PEAK_GBS}}
+    d = (outs["bf16"].float() - outs["f32"]).double()
+    T = shape[0]
+    res["rel_l2_vs_f32_step1"] = float(d[:, :T].norm() / outs["f32"][:, :T].double().norm())
+    res["rel_l2_vs_f32_step20"] = float(d[:, -T:].norm() / outs["f32"][:, -T:].double().norm())
+    res["config"] = f"FNO3d combustion volume [B={B},64,64,64,16] -> padded 70^3, modes (4,16,16), width 64, 4 layers, {n_ar} AR steps"
+    m.set_storage("f32")
+    del m
     torch.cuda.empty_cache()
-    return {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
-            "forward_fields_per_s": B * 20 / t_fwd, "ms_per_forward": 1e3 * t_fwd,
-            "mfma": _conv_model_roofline(flops_step / t_train / 1e12),
-            "config": "Transolver cylinder: tokens 20x64x128 -> mesh (128,64,20), n_hidden 256, 8 heads, 16 slices, "
-                      "1 layer, mlp_ratio 4, dropout 0.1, fp32"}
+    return res
+
+
+def family(label):
+    return label.split("[")[0]
+
+
+def by_family(summary):
+    """HIP-event summary per label -> per kernel family (label up to '['): launches, total time, total algorithmic bytes /
+    flops, and the variants it is made of."""
+    fam = {}
+    for label, v in summary.items():
+        f = fam.setdefault(family(label), {"calls": 0, "total_ms": 0.0, "bytes": 0.0, "flops": 0.0, "variants": {}})
+        f["calls"] += v["calls"]
+        f["total_ms"] += v["total_ms"]
+        f["bytes"] += v["bytes"] * v["calls"]
+        f["flops"] += v["flops"] * v["calls"]
+        f["variants"][label] = {"launches": v["calls"], "avg_launch_ms": v["avg_ms"],
+                                "algorithmic_bytes_per_launch": v["bytes"],
+                                "achieved_GBps": v["bytes"] / v["avg_ms"] / 1e6 if v["avg_ms"] else None,
+                                "frac_of_hbm_peak": v["bytes"] / v["avg_ms"] / 1e6 / HBM_PEAK_GBS if v["avg_ms"] else None}
+    return fam
 
 
 def main():
     a = parse()
     if a.cpu_baseline_worker:
         return cpu_baseline_worker()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}", file=sys.stderr)
+    share = os.environ.get("RPB_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     force_dp = os.environ.get("RPB_FORCE_DP") == "1"       # exercise the RCCL code path on a single rank
+    backend = None
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = "gloo" if share else "nccl"              # "nccl" IS RCCL on ROCm; gloo only for the shared-GPU plumbing test
+        if share:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=dev)
 
     from realpdebench_amd import _lib
     from realpdebench_amd.model.fno import FNO3d
-    from realpdebench_amd.trainer import Trainer
     from realpdebench_amd.rollout import autoregressive_rollout
+    from realpdebench_amd.synthetic import bench_batch
+    from realpdebench_amd.trainer import Trainer
 
     shape, modes, width, L = (20, 128, 128, 2), (4, 12, 16), 64, 4
     torch.manual_seed(0)
@@ -289,9 +388,7 @@ def main():
         DataParallel(model)
     trainer = Trainer(model, lr=1e-4, num_update=4000, scheduler="cosine")
     B = a.batch
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    x = torch.randn(B, *shape, device=dev, generator=g)
-    y = torch.randn(B, *shape, device=dev, generator=g)
+    x, y = (t.to(dev) for t in bench_batch(B, rank=rank, shape=shape))     # seeded N(0,1), identical on every host
 
     def barrier():
         torch.cuda.synchronize()
@@ -299,29 +396,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up with every launch timed: find the dominant kernel
+    # ---- warm-up with every launch timed: find the dominant kernel FAMILY (all template variants of one kernel)
     _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
-    for _ in range(max(a.warmup, 1)):
-        trainer.step(x, y)
+    first_loss = None
+    for i in range(max(a.warmup, 1)):
+        l_ = trainer.step(x, y)
+        if i == 0:
+            first_loss = float(l_)
     torch.cuda.synchronize()
     warm = _lib.profile_summary()
-    dominant = max(warm, key=lambda k: warm[k]["total_ms"])
+    fam_warm = by_family(warm)
+    dominant = max(fam_warm, key=lambda k: fam_warm[k]["total_ms"])
+    dom_labels = set(fam_warm[dominant]["variants"])
     if a.profile_all and rank == 0:
         tot = sum(v["total_ms"] for v in warm.values())
         for k, v in sorted(warm.items(), key=lambda kv: -kv[1]["total_ms"]):
             print(f"{k:48s} calls/step {v['calls'] / max(a.warmup, 1):5.1f}  avg {v['avg_ms']:8.3f} ms  "
                   f"{100 * v['total_ms'] / tot:5.1f}%  {v['bytes'] / v['avg_ms'] / 1e6:8.1f} GB/s  "
                   f"{v['flops'] / v['avg_ms'] / 1e9:7.2f} TF/s", file=sys.stderr)
+        for k, v in sorted(fam_warm.items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"family {k:40s} {100 * v['total_ms'] / tot:5.1f}%  {v['total_ms'] / max(a.warmup, 1):7.2f} ms/step  "
+                  f"{v['bytes'] / v['total_ms'] / 1e6:8.1f} GB/s", file=sys.stderr)
 
-    # ---- timed region: exactly K steps, only the dominant kernel carries HIP events
-    _lib.PROFILE, _lib.PROFILE_ONLY = {}, {dominant}
+    # ---- parity guard on the timed workload itself: the first-step loss of this exact batch / these exact weights must be
+    #      the one the IMPORTED reference computed for them (tests/golden/make_golden_headline.py)
+    loss_check = None
+    if world == 1 and B == 32 and rank == 0:
+        import numpy as np
+        gz = np.load(os.path.join(ROOT, "tests", "golden", "fno3d_headline.npz"))
+        ref = float(gz["b32/loss"])
+        rel = abs(first_loss - ref) / abs(ref)
+        loss_check = {"first_step_loss": first_loss, "reference_loss": ref, "rel_err": rel, "tol": 1e-5,
+                      "source": "tests/golden/fno3d_headline.npz (imported reference, B=32, same seeds)"}
+        if not rel < 1e-5:
+            raise SystemExit(f"bench.py: first-step loss {first_loss!r} differs from the reference's {ref!r} (rel {rel:.2e}) "
+                             "-- the timed path is not computing the reference's step; refusing to report a number")
+
+    # ---- timed region: exactly K steps, only the dominant family's launches carry HIP events
+    _lib.PROFILE, _lib.PROFILE_ONLY = {}, dom_labels
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = trainer.step(x, y)
     barrier()
     dt = time.perf_counter() - t0
-    dom = _lib.profile_summary()[dominant]
+    dom = by_family(_lib.profile_summary())[dominant]
     _lib.PROFILE = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -346,20 +465,23 @@ def main():
             t = torch.tensor([rt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rt = float(t)
+        fwd_bytes = (1.165 * B + 0.403) * 1e9            # algorithmic bytes of one eval forward
         rollout = {"value": B * world * shape[0] * a.rollout_steps / rt, "unit": "fields/s",
-                   "n_autoregressive": a.rollout_steps, "ms_per_forward": 1e3 * rt / a.rollout_steps}
+                   "n_autoregressive": a.rollout_steps, "ms_per_forward": 1e3 * rt / a.rollout_steps,
+                   "roofline": {"bound": "hbm", "algorithmic_bytes_per_forward": fwd_bytes,
+                                "achieved": fwd_bytes / (1e6 * rt / a.rollout_steps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": fwd_bytes / (1e6 * rt / a.rollout_steps) / HBM_PEAK_GBS}}
 
-    # ---- secondary: Transolver (north_star's second model) at the reference's cylinder config, rank 0 / N=1 only
-    transolver = None
-    if not a.no_transolver and world == 1:
-        transolver = bench_transolver(dev)
-
-    galerkin = None
-    if not a.no_galerkin and world == 1:
-        galerkin = bench_galerkin(dev)
-    unet = None
-    if not a.no_unet and world == 1:
-        unet = bench_unet(dev)
+    extra = {}
+    if world == 1:
+        model = None
+        torch.cuda.empty_cache()
+        for name, fn, flag in (("rollout_bf16", bench_rollout_bf16, a.no_bf16), ("transolver", bench_transolver, a.no_transolver),
+                               ("galerkin_transformer", bench_galerkin, a.no_galerkin), ("unet", bench_unet, a.no_unet),
+                               ("unet_c3", bench_unet_c3, a.no_unet)):
+            if not flag:
+                extra[name] = fn(dev)
+    rccl_ranks = dist.get_world_size() if (world > 1 or force_dp) else 1
     if world > 1 or force_dp:
         torch.cuda.synchronize()
         _flush_c_stdio()                                    # every rank empties its C stdio buffer (RCCL banner) ...
@@ -367,14 +489,16 @@ def main():
         dist.destroy_process_group()
 
     if rank == 0:
-        ach_gbs = dom["bytes"] / dom["avg_ms"] / 1e6
-        ach_tf = dom["flops"] / dom["avg_ms"] / 1e9
+        ach_gbs = dom["bytes"] / dom["total_ms"] / 1e6
+        ach_tf = dom["flops"] / dom["total_ms"] / 1e9
+        per_launch = dom["bytes"] / dom["calls"]
         step_bytes = (6.238 * B + 4.03) * 1e9          # algorithmic bytes of one train step
-        traffic = None                                  # HBM bytes per launch of the dominant kernel, from the committed
+        traffic = traffic_src = None                    # HBM bytes per launch of the dominant family, from the committed
         try:                                            # PMC request-size passes (bench.py cannot run rocprofv3 itself)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
             if B == 32:
                 traffic = tj["bytes_per_launch"].get(dominant)
+                traffic_src = tj.get("source")
         except Exception:
             pass
         line = {
@@ -385,23 +509,28 @@ def main():
             "config": {"workload": "FNO3d train step (fwd+MSE+bwd+Adam+cosine), cylinder-shaped [B,20,128,128,2] "
                                    "-> padded 26x134x134, modes (4,12,16), width 64, 4 layers (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.txt" if traffic else None,
-                         "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["calls"],
-                         "algorithmic_bytes_per_launch": dom["bytes"],
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "collective": (f"{'RCCL' if backend == 'nccl' else backend} all-reduce, {rccl_ranks} rank(s)"
+                                      if backend else None)},
+            "roofline": {"bound": "hbm", "kernel": dominant + " (all template variants, aggregated)",
+                         "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": dom["total_ms"] / dom["calls"], "launches_timed": dom["calls"],
+                         "launches_per_step": dom["calls"] / a.steps,
+                         "family_ms_per_step": dom["total_ms"] / a.steps,
+                         "family_share_of_step": dom["total_ms"] / a.steps / ms_per_step,
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "variants": dom["variants"],
                          "mfma_f32": {"achieved": ach_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                       "frac": ach_tf / MFMA_F32_PEAK_TF},
                          "whole_step": {"algorithmic_bytes": step_bytes,
                                         "achieved": step_bytes / (ms_per_step * 1e6), "unit": "GB/s",
                                         "frac": step_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS}},
             "rollout": rollout,
-            "transolver": transolver,
-            "galerkin_transformer": galerkin,
-            "unet": unet,
             "loss": float(loss),
+            "loss_check": loss_check,
         }
+        line.update(extra)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -154,10 +154,11 @@ def adam_update(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_steps(sd, batches, modes, n_layers, shape_in, shape_out, lr0, t_max, start_iter=1):
+def train_steps(sd, batches, modes, n_layers, shape_in, shape_out, lr0, t_max, start_iter=1, stamps=None):
     """Reference hot loop, train.py:321-334: zero_grad, fwd, mean loss, bwd, Adam, cosine step.
 
-    ``sd`` is updated in place.  Returns the list of losses.
+    ``sd`` is updated in place.  Returns the list of losses.  ``stamps``: optional list that receives ``time.time()``
+    after every completed step (bench.py's CPU baseline times steady-state steps with it).
     """
     state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items() if is_param(k)}
     losses = []
@@ -168,6 +169,9 @@ def train_steps(sd, batches, modes, n_layers, shape_in, shape_out, lr0, t_max, s
             adam_update(sd[k], g, state[k][0], state[k][1], it - start_iter + 1, lr)
         sd.update(new_buf)
         losses.append(float(loss))
+        if stamps is not None:
+            import time
+            stamps.append(time.time())
     return losses
 
 
