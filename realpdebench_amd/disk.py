@@ -30,11 +30,19 @@ import threading
 import numpy as np
 import torch
 
-SCENARIOS = {   # data/fluid_hf_dataset.py:341-349, 409-417, 477-485, 545-553
-    "cylinder": dict(file_name_pattern=r"(\d+)\.h5", condition_on_para=False),
-    "fsi": dict(file_name_pattern=r"(\d+)_([\d\.]+)_", condition_on_para=False),
-    "controlled_cylinder": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=True),
-    "foil": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=False),
+# Per-scenario constants AND constructor defaults of the reference's dataset subclasses (data/fluid_hf_dataset.py:341-349 + 350-375
+# cylinder, 409-417 + 418-443 fsi, 477-485 + 486-511 controlled_cylinder, 545-553 + 554-579 foil).  train.py / eval.py pass none of
+# in_step / out_step / n_sim_frame / sub_s_* (train.py:131-154), so these defaults ARE the benchmark's windows: controlled_cylinder is
+# 10 -> 10 frames, fsi has 2173 frames per simulation and sub-samples its real data by 2, foil sub-samples its real data by 2.
+_FLUID_DEFAULTS = dict(mask_prob=0.5, in_step=20, out_step=20, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2)
+SCENARIOS = {
+    "cylinder": dict(file_name_pattern=r"(\d+)\.h5", condition_on_para=False, defaults=dict(_FLUID_DEFAULTS)),
+    "fsi": dict(file_name_pattern=r"(\d+)_([\d\.]+)_", condition_on_para=False,
+                defaults=dict(_FLUID_DEFAULTS, n_sim_frame=2173, sub_s_real=2)),
+    "controlled_cylinder": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=True,
+                                defaults=dict(_FLUID_DEFAULTS, in_step=10, out_step=10)),
+    "foil": dict(file_name_pattern=r"(\d+)_(\d+\.?\d*)\.h5", condition_on_para=False,
+                 defaults=dict(_FLUID_DEFAULTS, sub_s_real=2)),
 }
 
 
@@ -101,12 +109,19 @@ class FluidWindows:
     contiguous full-resolution slabs; ``__getitem__`` reproduces the reference's CPU tensors exactly (a plain Dataset)."""
     SPEC = None                                                           # subclasses outside SCENARIOS bring their own
 
-    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.5, in_step=20, out_step=20,
-                 N_autoregressive=1, n_sim_frame=3990, sub_s_real=1, sub_s_numerical=2, noise_scale=0.0, noise_type="gaussian",
-                 **_ignored):
+    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=None, in_step=None, out_step=None,
+                 N_autoregressive=1, n_sim_frame=None, sub_s_real=None, sub_s_numerical=None, noise_scale=0.0,
+                 noise_type="gaussian", **_ignored):
         spec = self.SPEC or SCENARIOS.get(dataset_name)
         if spec is None:
             raise ValueError(f"dataset_name={dataset_name!r}: fluid scenarios are {sorted(SCENARIOS)}")
+        dflt = spec.get("defaults", _FLUID_DEFAULTS)          # ``None`` = the reference subclass's own constructor default
+        mask_prob = dflt["mask_prob"] if mask_prob is None else mask_prob
+        in_step = dflt["in_step"] if in_step is None else in_step
+        out_step = dflt["out_step"] if out_step is None else out_step
+        n_sim_frame = dflt["n_sim_frame"] if n_sim_frame is None else n_sim_frame
+        sub_s_real = dflt["sub_s_real"] if sub_s_real is None else sub_s_real
+        sub_s_numerical = dflt["sub_s_numerical"] if sub_s_numerical is None else sub_s_numerical
         self.dataset_name, self.dataset_type, self.mode, self.test_mode = dataset_name, dataset_type, mode, test_mode
         self.file_name_pattern, self.condition_on_para = spec["file_name_pattern"], spec["condition_on_para"]
         self.in_step = int(in_step)
@@ -202,11 +217,12 @@ class CombustionWindows(FluidWindows):
     """``CombustionHFDataset`` (data/combustion_hf_dataset.py): one planar cell ``observed`` [T, H, W] + one channels-last cell
     ``numerical`` [T, H, W, 15] (numerical data only; zeros for real data and with probability ``mask_prob``), 16 channels."""
     NUMERICAL_CHANNEL = 15                                                # combustion_hf_dataset.py:43
-    SPEC = dict(file_name_pattern=r"(.*)", condition_on_para=False)
+    SPEC = dict(file_name_pattern=r"(.*)", condition_on_para=False,       # defaults: combustion_hf_dataset.py:66-79
+                defaults=dict(mask_prob=0.8, in_step=20, out_step=20, n_sim_frame=2001, sub_s_real=2, sub_s_numerical=2))
 
-    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=0.8, in_step=20, out_step=20,
-                 N_autoregressive=1, n_sim_frame=2001, sub_s_real=2, sub_s_numerical=2, noise_scale=0.0, noise_type="gaussian",
-                 **_ignored):
+    def __init__(self, dataset_name, dataset_root, dataset_type, mode, test_mode="all", mask_prob=None, in_step=None, out_step=None,
+                 N_autoregressive=1, n_sim_frame=None, sub_s_real=None, sub_s_numerical=None, noise_scale=0.0,
+                 noise_type="gaussian", **_ignored):
         if dataset_name != "combustion":
             raise ValueError(f"dataset_name={dataset_name!r}: CombustionWindows reads the combustion scenario")
         super().__init__(dataset_name, dataset_root, dataset_type, mode, test_mode=test_mode, mask_prob=mask_prob, in_step=in_step,
@@ -516,9 +532,13 @@ class DiskBatchLoader:
             raise item
         slot, nb = item
         f = dict(device=self.device, dtype=torch.float32)
-        inp = torch.empty(nb, self.in_step, self.H, self.W, self.c_in, **f)
-        tgt = torch.empty(nb, self.horizon - self.in_step, self.H, self.W, self.c_out, **f)
         with torch.cuda.stream(self.stream):
+            # the batch is ALLOCATED on the side stream: the caching allocator then treats the side stream as its home, and the
+            # record_stream(compute stream) below really defers the block's reuse until the step that reads it has run (allocated on
+            # the compute stream, record_stream would be a no-op and a sync-free trainer several steps ahead of the GPU could
+            # have batch k+2 written over batch k while step k's lift_bwd still reads it)
+            inp = torch.empty(nb, self.in_step, self.H, self.W, self.c_in, **f)
+            tgt = torch.empty(nb, self.horizon - self.in_step, self.H, self.W, self.c_out, **f)
             slot["dev"].copy_(slot["host"], non_blocking=True)
             slot["dflags"].copy_(slot["flags"], non_blocking=True)
             if slot["devl"] is not None:
@@ -635,9 +655,9 @@ class SurrogateBatchLoader:
         if isinstance(slot, BaseException):
             raise slot
         f = dict(device=self.device, dtype=torch.float32)
-        inp = torch.empty(self.B, self.T, self.H, self.W, self.c_in, **f)
-        tgt = torch.empty(self.B, self.T, self.H, self.W, 1, **f)
         with torch.cuda.stream(self.stream):
+            inp = torch.empty(self.B, self.T, self.H, self.W, self.c_in, **f)      # side-stream allocation: see DiskBatchLoader
+            tgt = torch.empty(self.B, self.T, self.H, self.W, 1, **f)
             for d, h in (("dnum", "num"), ("dreal", "real"), ("dpara", "para")):
                 slot[d].copy_(slot[h], non_blocking=True)
             self.ops.pair_pack(slot["dnum"], slot["dreal"], slot["dpara"], inp, tgt, self.B, self.T * self.H * self.W, self.Cl,

@@ -172,3 +172,51 @@ def test_device_poisson_noise(tmp_path):
     k = (x - lam) / scale                                          # Poisson(lam) counts
     assert torch.equal(k, k.round()) and float(k.min()) >= 0
     assert abs(float(k.mean()) - lam) < 0.1 and abs(float(k.var()) - lam) < 0.3
+
+
+def test_scenario_defaults_are_the_reference_subclasses():
+    """The entrypoints pass none of in_step / out_step / n_sim_frame / sub_s_* (like realpdebench/train.py:131-154), so the
+    defaults of the sample-list classes must be those of the reference's per-scenario dataset classes
+    (tests/golden/scenario_defaults.json, read from the imported classes by make_golden_defaults.py)."""
+    from realpdebench_amd.disk import SCENARIOS, CombustionWindows
+    with open(os.path.join(HERE, "golden", "scenario_defaults.json")) as fh:
+        ref = json.load(fh)
+    assert set(ref) == set(SCENARIOS) | {"combustion"}
+    for scen, want in ref.items():
+        have = (CombustionWindows.SPEC if scen == "combustion" else SCENARIOS[scen])["defaults"]
+        assert have == want, scen
+
+
+def test_default_constructed_controlled_cylinder_windows_are_10_to_10():
+    """ControlledCylinderHFDataset defaults to in_step = out_step = 10 (fluid_hf_dataset.py:498-499): the default-constructed
+    window list must take them from the scenario, not from the cylinder class."""
+    w = open_windows("controlled_cylinder", dataset_root=ROOT, dataset_type="numerical", mode="train")
+    assert (w.in_step, w.out_step, w.horizon, w.sub_s, w.n_sim_frame) == (10, 10, 20, 2, 3990)
+    w = open_windows("cylinder", dataset_root=ROOT, dataset_type="real", mode="val")
+    assert (w.in_step, w.out_step, w.sub_s) == (20, 20, 1)
+    w = open_windows("combustion", dataset_root=ROOT, dataset_type="real", mode="test")
+    assert (w.in_step, w.sub_s, w.n_sim_frame, w.mask_prob) == (20, 2, 2001, 0.8)
+
+
+@pytest.mark.gpu
+def test_batches_survive_a_consumer_that_never_synchronises(gold):
+    """A sync-free trainer runs many steps ahead of the GPU: batch k must still be intact when a kernel enqueued long after
+    ``next(loader)`` returned finally reads it, although the loader has meanwhile produced batches k+1, k+2, ... on its side
+    stream (the batch tensors are allocated on the side stream so record_stream defers their reuse)."""
+    from realpdebench_amd.disk import DiskBatchLoader
+    w = _windows(gold, "cyl_num_train")
+    random.seed(1234)
+    want = [a.cpu() for a, _ in DiskBatchLoader(w, 1, "cuda", stats=None, shuffle=False, drop_last=False, epochs=3)]
+    random.seed(1234)
+    loader = DiskBatchLoader(w, 1, "cuda", stats=None, shuffle=False, drop_last=False, epochs=3)
+    big = torch.randn(4096, 4096, device="cuda")
+    late = []
+    for inp, _ in loader:                                          # no host synchronisation anywhere in this loop
+        for _ in range(6):
+            big = torch.tanh(big @ big * 1e-4)                     # ~ms of queued work before the batch is finally read
+        late.append(inp.clone())
+        del inp
+    torch.cuda.synchronize()
+    assert len(late) == len(want) and len(want) >= 6
+    for a, b in zip(late, want):
+        assert torch.equal(a.cpu(), b)
