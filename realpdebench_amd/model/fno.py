@@ -30,6 +30,7 @@ class _Workspace:
     def __init__(self, model, B, training, device):
         d = ops.Dims(B, *model.shape_in[:3], model.dim_in, model.width, model.padding)
         self.d, self.training = d, training
+        self.generation = 0          # bumped by every training-mode forward: a backward whose graph saw an older value must not run
         C, L, plan = model.width, model.n_layers, model.plan
         f = dict(device=device, dtype=torch.float32)
         # Lazy activations: a_{l+1} = act(BN(s_l)) is never materialised (its consumers transform s_l on load), so the
@@ -76,12 +77,17 @@ class _FNO3dFunction(torch.autograd.Function):
     def forward(ctx, x, flat, model):
         ws = model._workspace(x.shape[0], True, x.device)
         out = model._forward_impl(x, ws, training=True)
-        ctx.model, ctx.ws, ctx.x = model, ws, x
+        ctx.model, ctx.ws, ctx.x, ctx.generation = model, ws, x, ws.generation
         return model._shape_output(out.clone(), x.shape[0])
 
     @staticmethod
     def backward(ctx, gout):
         model, ws = ctx.model, ctx.ws
+        if ws.generation != ctx.generation:
+            raise RuntimeError("FNO3d backward: the activations of this graph were overwritten by a later training-mode forward "
+                               "with the same batch size (they live in a per-batch-size workspace, not in the autograd graph). "
+                               "Call backward() before the next training-mode forward; gradient accumulation over micro-batches "
+                               "is forward -> backward -> forward -> backward")
         g = model._unshape_grad(gout.contiguous(), ctx.x.shape[0])
         gflat = torch.zeros_like(model.flat)
         if model.dp is not None:            # caller took a local .mean(): average over ranks like DDP would
@@ -299,6 +305,8 @@ class FNO3d(Model):
         d, C, L = ws.d, self.width, self.n_layers
         grids, plan = self._consts(x.device)
         P = self.pview
+        if training:
+            ws.generation += 1
         self._lift_fwd(x, ws)
         world = self.dp.world_size if (self.dp is not None and training) else 1
         a_in, xf = ws.A0, None                   # layer input tensor and its lazy transform

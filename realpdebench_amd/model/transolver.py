@@ -2,9 +2,9 @@
 ``realpdebench.model.TRANSOLVER_libs.Transolver_Structured_Mesh_3D.Model`` (``Transolver_Structured_Mesh_3D.py:80-214``),
 built by ``load_model`` exactly like ``realpdebench/model/load_model.py:145-152``.
 
-State: **forward / rollout path** (eval mode) in HIP; the backward pass is the next row and
-``train_loss`` under autograd raises instead of silently falling back to PyTorch.  Parameter names, shapes and dtypes
-equal the reference's ``state_dict`` so its checkpoints load.
+Forward, rollout and the whole backward pass (``train_loss(...).mean().backward()`` through one autograd Function) run in
+the HIP kernels of ``csrc/``; there is no PyTorch fallback.  Parameter names, shapes and dtypes equal the reference's
+``state_dict`` so its checkpoints load.
 
 Pipeline per block (Transolver_Structured_Mesh_3D.py:71-77, Physics_Attention.py:148-176), tokens channels-last:
 LayerNorm -> [both 3x3x3 convolutions as ONE implicit GEMM, N = 2C] -> slice softmax + slice-token sums ->

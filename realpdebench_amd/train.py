@@ -82,7 +82,12 @@ def main(argv=None):
         logging.info(f"args: {args}")
 
     train_dataset, val_dataset, stats = make_datasets(args)
+    if args.train_batch_size % world != 0 or args.train_batch_size < world:
+        raise ValueError(f"train_batch_size={args.train_batch_size} must be a positive multiple of the {world} data-parallel ranks")
     per_rank_bs = args.train_batch_size // world
+    if len(train_dataset) < args.train_batch_size:
+        raise ValueError(f"the training set has {len(train_dataset)} samples, fewer than one global batch of "
+                         f"{args.train_batch_size}: with drop_last the loader would never yield a batch")
     sampler = None
     if world > 1:
         from torch.utils.data.distributed import DistributedSampler
@@ -91,7 +96,7 @@ def main(argv=None):
     on_disk = isinstance(train_dataset, FluidWindows)
     train_loader = None if on_disk else cycle(DataLoader(train_dataset, batch_size=per_rank_bs, shuffle=sampler is None,
                                                          sampler=sampler, pin_memory=True, num_workers=args.num_workers,
-                                                         drop_last=True))
+                                                         drop_last=True), sampler=sampler)   # new permutation every epoch
     val_loader = DataLoader(val_dataset, batch_size=args.test_batch_size, shuffle=False, num_workers=args.num_workers)
     if args.normalizer == "gaussian":
         if stats is None:

@@ -41,10 +41,22 @@ def setup_logging(exp_path, is_train=True):
     logging.info(f"Logging initialized at {log_filename}")
 
 
-def cycle(iterable):
+def cycle(iterable, sampler=None):
+    """utils/utils.py ``cycle``: restart the loader forever.  ``sampler``: a DistributedSampler whose ``set_epoch`` is called at
+    every restart so that each epoch draws a new permutation (without it every epoch reuses the first one); an epoch that yields
+    nothing raises instead of spinning."""
+    epoch = 0
     while True:
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        n = 0
         for x in iterable:
+            n += 1
             yield x
+        if n == 0:
+            raise RuntimeError("cycle(): the loader produced no batch in a whole epoch (dataset smaller than one batch with "
+                               "drop_last?)")
+        epoch += 1
 
 
 def add_hf_compat_flags(parser):
