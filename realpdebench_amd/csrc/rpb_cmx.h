@@ -1,0 +1,24 @@
+// Interface between rpb_cell.hip (dispatch) and rpb_cmx.hip (cell_mix on the bf16 matrix pipe, C = 64).
+#pragma once
+#include "rpb_common.h"
+
+struct CmxArgs {
+    const float* x;       // [ncell][64]
+    const float* Wm;      // transpose_w == 0: [CO][KC] (out = x W^T) ; == 1: [KC][CO] (out = x W)
+    const float* bias;    // [64] or null
+    const float* z2;      // [G][K2][64]
+    const float* GW;      // [K2][Wp]  (transposed stage matrix)
+    float* out;           // [ncell][64]
+    float* stats_part;    // [gridDim.x*8][2][64] or null
+    long ncell;
+    int K2, Wp;
+    int transpose_w;
+    XForm xf;             // lazy BatchNorm(+GELU) applied to x on load
+    const float* bnb_s;   // STATS == 2: pre-BN tensor of the layer whose output gradient this launch produces
+    XForm bnb;            //             and that layer's BatchNorm; STATS == 0 with bnb.mean: OUTPUT transform (eval)
+    int write_gz;         // STATS == 2: store gz = out * act'(z) instead of out (the consumer then skips act')
+};
+
+bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather);
+long rpb_cmx_stat_rows(long ncell, int Wp, int stats);   // stats: 0 / 1 / 2 as in the kernel template
+int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);

@@ -1,0 +1,374 @@
+// cell_mix on the bf16 matrix pipe ("cmx"): the C = 64 instance of rpb_cell_mix (last inverse-DFT stage + 1x1x1 Conv3d + bias +
+// add, with the BatchNorm forward / backward sums in the epilogue -- fno.py:63,115-117 and their autograd) with both
+// contractions on v_mfma_f32_16x16x32_bf16 from operands split into three bf16 planes (x = hi + mid + lo exactly, truncation
+// splits: 8 + 8 + 8 significand bits; a product is accumulated in fp32 from hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi,
+// each bf16 x bf16 product exact in fp32, the three dropped terms <= 2^-24 |a b| -- the same fp32-grade arithmetic as
+// csrc/rpb_conv3x.hip, Rel-L2 vs fp64 ~2e-7).
+//
+// Why: the fp32 kernel (rpb_cell.hip) keeps the fp32 matrix pipe 66-76 % busy at a clock the chip throttles to ~1.7 GHz and still
+// needs 6144 pipe cycles per 32 cells -- above the 5600 cycles the same 32 cells cost at 6.3 TB/s of HBM.  Six bf16 MFMAs replace
+// eight fp32 MFMAs of twice the issue time (0.375x the pipe time), which leaves HBM as the only bound.
+//
+// No activation goes through LDS:
+//  * a wave walks whole (b,t,h) lines; a wave tile = 32 consecutive cells of the line = two 16-row MFMA tiles.  Lane (m = lane & 15, kg = lane >> 4) loads 4 x 16 B of cell m:
+//    bytes [64 i + 16 kg, +16) of the cell's 256 B channel row for i = 0..3, so every load instruction reads 16 x 64 contiguous
+//    bytes and the four together whole 128 B lines; the 8 values of loads (2 ks, 2 ks + 1) ARE the lane's A operand of K-step ks
+//    (the contraction index is permuted consistently on the weight side: k = (ks, kg, e) <-> channel 16 (2 ks + e / 4) + 4 kg + e % 4);
+//  * the MFMA column index n of output tile t stands for channel 4 n + t, so a lane's accumulators are 4 consecutive channels of
+//    4 cells: the store is 16 B per lane, 4 whole 256 B cell rows per instruction (the fp32 kernel: 32 dword stores per tile);
+//  * the z2 row of a line (spectral branch, [K2][C] fp32) is loaded in B-operand layout with 16 B loads and split in registers
+//    once per line (a tile-granular version fetched every row ~3x from HBM: 10.3 GB of traffic for 8.56 GB algorithmic);
+//    GW and the conv weights are split once per workgroup into LDS in operand order.
+#include "rpb_cmx.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+// (a, b) fp32 -> one dword of two truncated bf16 (a low half, b high half)
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+// 8 fp32 -> three bf16x8 planes (exact: hi + mid + lo == v)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = pack_hi(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        um[q] = pack_hi(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        ul[q] = pack_hi(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// waves per workgroup (= per CU): the z2 planes of a line take 12 KB of LDS per wave: 8 waves + operands = 147 KB
+#ifndef CMX_WAVES_A
+#define CMX_WAVES_A 8
+#endif
+#ifndef CMX_WAVES_B
+#define CMX_WAVES_B 8
+#endif
+#define CMX_WAVES_OF(STATS) ((STATS) == 2 ? CMX_WAVES_B : CMX_WAVES_A)
+
+// STATS: 0 none (bnb.mean != null: output transform) | 1 sum / sum of squares of the output | 2 BatchNorm-backward sums
+template <int STATS>
+__global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a) {
+    constexpr int CMX_WAVES = CMX_WAVES_OF(STATS);
+    extern __shared__ u32x4 lds4[];
+    const int Wp = a.Wp, K2 = a.K2;
+    u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
+    u32x4* GWs = Bw + 24 * 64;               // [plane 3][w Wp][kg 4]           last-stage DFT matrix, A-operand rows
+    u32x4* Zs = GWs + 3 * Wp * 4;            // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
+    float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kg = lane >> 4;         // A role: cell row m, k group kg;  B / D role: column n = m, row group mg = kg
+    const bool has_xf = a.xf.mean != nullptr;
+
+    // ---- per-workgroup operand preparation
+    for (int idx = tid; idx < 2 * 4 * 64; idx += blockDim.x) {
+        const int l = idx & 63, t = (idx >> 6) & 3, ks = idx >> 8;
+        const int n = l & 15, kgb = l >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
+            const int co = 4 * n + t;
+            v[e] = a.transpose_w ? a.Wm[ci * 64 + co] : a.Wm[co * 64 + ci];
+        }
+        bf16x8 h, md, lo;
+        split8(v, h, md, lo);
+        Bw[((ks * 3 + 0) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        Bw[((ks * 3 + 1) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, md);
+        Bw[((ks * 3 + 2) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+    }
+    for (int idx = tid; idx < Wp * 4; idx += blockDim.x) {
+        const int w = idx >> 2, kgw = idx & 3;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * kgw + e;
+            v[e] = k < K2 ? a.GW[k * Wp + w] : 0.f;
+        }
+        bf16x8 h, md, lo;
+        split8(v, h, md, lo);
+        GWs[(0 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, h);
+        GWs[(1 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, md);
+        GWs[(2 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, lo);
+    }
+    if (has_xf && tid < 64) {
+        xfp[tid] = a.xf.mean[tid];
+        xfp[64 + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
+        xfp[128 + tid] = a.xf.beta[tid];
+    }
+    __syncthreads();
+
+    // ---- per-lane output-channel constants (channels 4 n .. 4 n + 3)
+    const bool oxf = STATS == 0 && a.bnb.mean != nullptr;
+    float bv[4];
+    XParam bp[4];
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        bv[t] = a.bias ? a.bias[4 * m + t] : 0.f;
+        if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, 4 * m + t);
+        ssum[t] = ssq[t] = 0.f;
+    }
+    const bool xgelu = a.xf.gelu != 0;
+    const bool bgelu = a.bnb.gelu != 0;
+
+    // ---- work item = one (b,t,h) line of Wp cells, walked in TQ = ceil(Wp / 32) wave tiles by ONE wave: the line's z2 row is
+    //      fetched from HBM exactly once chip-wide and split once; tiles never straddle lines (the last tile of a line is partial:
+    //      its out-of-range loads return 0 and its stores are dropped by the line's buffer descriptor)
+    const long G = a.ncell / Wp;
+    const int TQ = (Wp + 31) >> 5;
+    const long nslots = (long)gridDim.x * CMX_WAVES;
+    const long slot = (long)blockIdx.x * CMX_WAVES + wave;
+    const unsigned line_bytes = (unsigned)Wp * 256u;
+    const int xoff = m * 256 + kg * 16;                  // byte offset of the lane's first 16 B inside a 16-cell block
+    const int ooff = (4 * kg) * 256 + m * 16;            // output: cell 4 mg + r, channels 4 n ..
+
+    u32x4 xa[2][4];
+    // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
+    auto issue_x = [&](long g, int q, int j, int ks) {
+        const rsrc_t rx = make_rsrc(a.x + g * Wp * 64, line_bytes);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) xa[j][2 * ks + hf] = ld16(rx, q * 8192 + xoff + j * 4096 + (2 * ks + hf) * 64);
+    };
+    u32x4 zr[8];
+    auto issue_z = [&](long g) {        // z2 row in B-operand layout: lane (n, kg) holds k = 8 kg + e, channels 4 n .. 4 n + 3
+        const rsrc_t rz = make_rsrc(a.z2 + g * K2 * 64, (unsigned)K2 * 256u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * 256 + m * 16);
+    };
+
+    if (slot < G) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            issue_x(slot, 0, j, 0);
+            issue_x(slot, 0, j, 1);
+        }
+        issue_z(slot);
+    }
+    u32x4* Zw = Zs + wave * 12 * 64 + lane;
+    for (long g = slot; g < G; g += nslots) {
+        const rsrc_t ro = make_rsrc(a.out + g * Wp * 64, line_bytes);
+        const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.x, line_bytes);
+        for (int q = 0; q < TQ; ++q) {
+            const bool last = q + 1 == TQ;
+            const long gn = last ? g + nslots : g;                           // next wave tile: (gn, qn)
+            const int qn = last ? 0 : q + 1;
+            const bool more = gn < G;
+            const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
+            asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS operand reads inside the loop: hoisted, they cost 150 VGPRs
+
+            f32x4v acc[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[j][t] = f32x4v{bv[t], bv[t], bv[t], bv[t]};     // the bias rides in the accumulator
+            u32x4 spre[2][4];
+            // ---- channel mixing: K = 64 = 2 steps of 32.  Per step: x registers -> A planes (lazy BN+GELU of the producer
+            //      applied here), then the freed registers take the next wave tile's loads, in flight during everything below
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 Ah[2], Am[2], Al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && half_tile) continue;
+                    float v[8];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int i = 2 * ks + hf;
+                        const f32x4v xv = __builtin_bit_cast(f32x4v, xa[j][i]);
+                        if (has_xf) {
+                            const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfp + 16 * i + 4 * kg);
+                            const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + 64 + 16 * i + 4 * kg);
+                            const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 128 + 16 * i + 4 * kg);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float z = fmaf(xv[c] - mu[c], sc[c], be[c]);
+                                v[4 * hf + c] = xgelu ? gelu_f(z) : z;
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[4 * hf + c] = xv[c];
+                        }
+                    }
+                    split8(v, Ah[j], Am[j], Al[j]);
+                }
+                if (more) {
+                    issue_x(gn, qn, 0, ks);
+                    issue_x(gn, qn, 1, ks);
+                }
+                if (ks == 0) {
+                    if (q == 0) {                  // new line: its z2 row (requested one tile ago) -> three bf16 planes per channel,
+#pragma unroll                                     // parked in the wave's own LDS slice (48 registers otherwise)
+                        for (int t = 0; t < 4; ++t) {
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(f32x4v, zr[e])[t];
+                            bf16x8 zh, zm, zl;
+                            split8(v, zh, zm, zl);
+                            Zw[(0 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zh);
+                            Zw[(1 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zm);
+                            Zw[(2 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zl);
+                        }
+                    }
+                    if (last && more) issue_z(gn);                           // next line's row: in flight for a whole tile
+                    if (STATS == 2) {              // pre-BN values at the output positions (needed by the epilogue)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) spre[j][r] = ld16(rs, q * 8192 + ooff + j * 4096 + r * 256);
+                    }
+                }
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    bf16x8 Bh[2], Bm[2], Bl[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int t = 2 * tp + u;
+                        Bh[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 0) * 4 + t) * 64 + lane]);
+                        Bm[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 1) * 4 + t) * 64 + lane]);
+                        Bl[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 2) * 4 + t) * 64 + lane]);
+                    }
+#define CMX_PROD(AP, BP)                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], BP[u], acc[j][2 * tp + u]);
+                    CMX_PROD(Ah, Bl) CMX_PROD(Al, Bh) CMX_PROD(Am, Bm) CMX_PROD(Ah, Bm) CMX_PROD(Am, Bh) CMX_PROD(Ah, Bh)
+#undef CMX_PROD
+                }
+            }
+            // ---- last inverse-DFT stage: A = GW row of the cell's w (LDS; rows past the line end are clamped: their results are
+            //      never stored), B = the line's z2 planes (the wave's LDS slice)
+            {
+                bf16x8 ah[2], am[2], al[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int wl = 32 * q + 16 * j + m;
+                    wl = wl < Wp ? wl : Wp - 1;
+                    ah[j] = __builtin_bit_cast(bf16x8, GWs[(0 * Wp + wl) * 4 + kg]);
+                    am[j] = __builtin_bit_cast(bf16x8, GWs[(1 * Wp + wl) * 4 + kg]);
+                    al[j] = __builtin_bit_cast(bf16x8, GWs[(2 * Wp + wl) * 4 + kg]);
+                }
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    bf16x8 Zh[2], Zm[2], Zl[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        Zh[u] = __builtin_bit_cast(bf16x8, Zw[(0 * 4 + 2 * tp + u) * 64]);
+                        Zm[u] = __builtin_bit_cast(bf16x8, Zw[(1 * 4 + 2 * tp + u) * 64]);
+                        Zl[u] = __builtin_bit_cast(bf16x8, Zw[(2 * 4 + 2 * tp + u) * 64]);
+                    }
+#define CMX_SPEC(AP, ZP)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)                                 \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], ZP[u], acc[j][2 * tp + u]);
+                    CMX_SPEC(ah, Zl) CMX_SPEC(al, Zh) CMX_SPEC(am, Zm) CMX_SPEC(ah, Zm) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+#undef CMX_SPEC
+                }
+            }
+            // ---- epilogue: cell 32 q + 16 j + 4 mg + r of the line, channels 4 n + t: one 16 B store per (j, r).  Only the last
+            //      tile of a line has cells past the line end (their stores are dropped by the descriptor; the sums skip them)
+            auto epilogue = [&](auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1 && half_tile) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = !MASKED || (32 * q + 16 * j + 4 * kg + r < Wp);
+                        f32x4v o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float v = acc[j][t][r];
+                            if (STATS == 0 && oxf) v = xf_apply(v, bp[t], bgelu);
+                            if (STATS == 1) {
+                                const float vm = valid ? v : 0.f;
+                                ssum[t] += vm;
+                                ssq[t] = fmaf(vm, vm, ssq[t]);
+                            } else if (STATS == 2) {
+                                const float sh = (__builtin_bit_cast(f32x4v, spre[j][r])[t] - bp[t].mu) * bp[t].is;
+                                float gz = bgelu ? v * gelu_grad_f(sh * bp[t].ga + bp[t].be) : v;
+                                if (a.write_gz) v = gz;
+                                gz = valid ? gz : 0.f;
+                                ssum[t] += gz;
+                                ssq[t] = fmaf(gz, sh, ssq[t]);
+                            }
+                            o[t] = v;
+                        }
+                        st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
+                    }
+                }
+            };
+            if (last) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
+        }
+    }
+    if (STATS != 0) {
+        float* part = a.stats_part + ((long)blockIdx.x * CMX_WAVES + wave) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float s1 = ssum[t], s2 = ssq[t];
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (kg == 0) {
+                part[4 * m + t] = s1;
+                part[64 + 4 * m + t] = s2;
+            }
+        }
+    }
+}
+
+static size_t cmx_lds(int Wp, int waves) { return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4; }
+
+// the bf16-pipe kernel covers the C = 64 spectral instances; everything else stays on rpb_cell.hip
+bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather) {
+    static const bool off = getenv("RPB_CELL_MIX_F32") && atoi(getenv("RPB_CELL_MIX_F32")) == 1;   // exact-fp32 MFMA kernel
+    return !off && spec && !gather && KC == 64 && CO == 64 && K2 > 0 && K2 <= 32 && Wp >= 32 && ncell % Wp == 0 &&
+           cmx_lds(Wp, CMX_WAVES_A) <= 160 * 1024;
+}
+
+long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
+    const int waves = CMX_WAVES_OF(stats);
+    const long G = ncell / Wp;
+    long grid = rpb_num_cus();
+    const long need = (G + waves - 1) / waves;
+    if (grid > need) grid = need;
+    return grid * waves;
+}
+
+int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
+    const int waves = CMX_WAVES_OF(stats);
+    const int grid = (int)(rpb_cmx_stat_rows(a.ncell, a.Wp, stats) / waves);
+    const size_t lds = cmx_lds(a.Wp, waves);
+#define RPB_CMX(ST_)                                                                                                  \
+    if (stats == ST_) {                                                                                               \
+        (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((cmx_kernel<ST_>), dim3(grid), dim3(waves * 64), lds, st, a);                          \
+        RPB_CHECK_LAUNCH("cell_mix(bf16x3)");                                                                         \
+    }
+    RPB_CMX(0) RPB_CMX(1) RPB_CMX(2)
+#undef RPB_CMX
+    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: bad stats mode %d", stats);
+}

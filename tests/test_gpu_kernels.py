@@ -391,3 +391,58 @@ def test_fused_bn_bwd_row(ops, C, gelu, lazy_x):
     tot = part.double().sum(0).cpu()
     assert rel_l2(tot[:C * C].view(C, C), gs_ref.t() @ x_ref) < 5e-6
     assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
+
+
+@pytest.mark.parametrize("Wp,rows,K2", [(134, 7, 32), (70, 11, 32), (38, 5, 24), (33, 3, 7), (134, 1, 32)])
+def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2):
+    """The C = 64 spectral cell_mix runs on the bf16 matrix pipe from operands split into three bf16 planes
+    (csrc/rpb_cmx.hip): fp32-grade against fp64 in every mode -- plain / transposed weight, lazy input transform,
+    BatchNorm forward sums, BatchNorm-backward sums (with and without GELU) and the eval output transform -- on row
+    lengths that make tiles straddle (b,t,h) lines and on cell counts that are not a multiple of the 32-cell tile."""
+    torch.manual_seed(Wp * 7 + K2)
+    C = 64
+    ncell = rows * Wp
+    assert ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True) % 8 == 0          # the bf16-pipe kernel: 8 waves per workgroup
+    f8 = dict(dtype=torch.float64)
+    s = torch.randn(ncell, C, **f8) * 1.5 + 0.3
+    Wc, bias = torch.randn(C, C, **f8) / 8, torch.randn(C, **f8)
+    z2, GW = torch.randn(rows, K2, C, **f8), torch.randn(Wp, K2, **f8)
+    mean, invstd = torch.randn(C, **f8) * 0.2, torch.rand(C, **f8) + 0.5
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    spec = torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C)
+    for gelu in (True, False):
+        a = _xf_ref(s, mean, invstd, gamma, beta, gelu)
+        xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), gelu)
+        ref = spec + a @ Wc.t() + bias
+        out = torch.full((ncell, C), float("nan"), device="cuda")
+        nrows = ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True)
+        part = torch.zeros(nrows, 2, C, device="cuda")
+        ops.cell_mix(dev(s), dev(Wc), dev(bias), dev(z2), dev(GW.t()), out, part, ncell, C, C, K2, Wp, xf=xf)
+        assert rel_l2(out.cpu(), ref) < 2e-6
+        tot = part.double().sum(0).cpu()
+        assert rel_l2(tot[0], ref.sum(0)) < 1e-5 and rel_l2(tot[1], (ref ** 2).sum(0)) < 1e-5
+        # eval: output transform act(BN(out)) with another layer's statistics
+        om, oi = torch.randn(C, **f8) * 0.1, torch.rand(C, **f8) + 0.5
+        og, ob = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.2
+        ops.cell_mix(dev(s), dev(Wc), dev(bias), dev(z2), dev(GW.t()), out, None, ncell, C, C, K2, Wp, xf=xf,
+                     oxf=(dev(om), dev(oi), dev(og), dev(ob), gelu))
+        assert rel_l2(out.cpu(), _xf_ref(ref, om, oi, og, ob, gelu)) < 3e-6
+        # backward flavour: transposed weight, no bias, BatchNorm-backward sums of the layer that produced the input
+        g = torch.randn(ncell, C, **f8)
+        ref2 = spec + g @ Wc
+        sh = (s - mean) * invstd
+        if gelu:
+            zz = (sh * gamma + beta).clone().requires_grad_(True)
+            torch.nn.functional.gelu(zz).backward(ref2)
+            gz = zz.grad
+        else:
+            gz = ref2
+        nb = ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True, True)
+        part2 = torch.zeros(nb, 2, C, device="cuda")
+        ops.cell_mix(dev(g), dev(Wc), None, dev(z2), dev(GW.t()), out, part2, ncell, C, C, K2, Wp, transpose_w=True,
+                     bnb=(dev(s),) + xf)
+        assert rel_l2(out.cpu(), ref2) < 2e-6
+        tot = part2.double().sum(0).cpu()
+        assert rel_l2(tot[0], gz.sum(0)) < 2e-5 and rel_l2(tot[1], (gz * sh).sum(0)) < 2e-5
+    ops.cell_mix(dev(g), dev(Wc), None, dev(z2), dev(GW.t()), out, None, ncell, C, C, K2, Wp, transpose_w=True)
+    assert rel_l2(out.cpu(), spec + g @ Wc) < 2e-6

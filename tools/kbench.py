@@ -47,6 +47,18 @@ if "cell_mix" in which:
            lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, part, d.ncell, C, C, K2, d.Wp), nb, fl)
     timeit("cell_mix bwd (spec)",
            lambda: ops.cell_mix(x, Wc, None, z2, plan.FW, y, None, d.ncell, C, C, K2, d.Wp, transpose_w=True), nb, fl)
+    mean, invstd, gamma, beta = torch.zeros(C, **f), torch.ones(C, **f), torch.ones(C, **f), torch.zeros(C, **f)
+    xfg = (mean, invstd, gamma, beta, True)
+    timeit("cell_mix fwd (lazy gelu in, spec+stats)",
+           lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, part, d.ncell, C, C, K2, d.Wp, xf=xfg), nb, fl)
+    rows2 = ops.cell_mix_stat_rows(d.ncell, C, C, K2, d.Wp, True, True)
+    part2 = torch.empty(rows2 * 2 * C, **f)
+    s_prev = torch.randn(d.ncell, C, **f)
+    timeit("cell_mix bwd (spec + BN-bwd sums, gelu)",
+           lambda: ops.cell_mix(x, Wc, None, z2, plan.FW, y, part2, d.ncell, C, C, K2, d.Wp, transpose_w=True,
+                                bnb=(s_prev,) + xfg), nb + 4 * d.ncell * C, fl)
+    timeit("cell_mix eval (out = gelu(bn(.)))",
+           lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, None, d.ncell, C, C, K2, d.Wp, oxf=xfg), nb, fl)
     gu = torch.randn(d.ncrop, 128, **f)
     w1 = torch.randn(128, C, **f)
     timeit("cell_mix gather (fc1 dgrad)",
