@@ -68,6 +68,9 @@ int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, i
  *     the output is the gradient w.r.t. act(BN(bnb_s)) and the partials are instead (sum gz, sum gz*shat), the
  *     first pass of that layer's BatchNorm backward (bnb_* = its mean, invstd, gamma, beta, gelu flag). */
 long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int bn_bwd_stats);
+/*     1 when the kernel this shape dispatches to honours bnb_gelu == 2: "GELU, and store gz = out * gelu'(z) instead of out", so
+ *     that the BatchNorm-backward apply that consumes the tensor (rpb_bn_bwd_row with gelu = 0) does not evaluate gelu' again. */
+int rpb_cell_mix_writes_gz(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int gather);
 /*     bnb_s == NULL with the four bnb vectors given (and no stats_part): OUTPUT transform, the tile is stored as
  *     act(BN(out)) -- eval mode, where the running statistics are known before the launch (fno.py:117-119). */
 int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out,

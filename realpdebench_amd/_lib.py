@@ -24,6 +24,7 @@ SIGNATURES = {
     "rpb_mode_contract_dgrad": (_I, "ppp" + "iii" + "p"),
     "rpb_mode_contract_wgrad": (_I, "ppp" + "iiii" + "p"),
     "rpb_cell_mix_stat_rows": (_L, "liiiiii"),
+    "rpb_cell_mix_writes_gz": (_I, "liiiiii"),
     "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "ppppi" + "pppppi" + "p"),
     "rpb_cell_wgrad_slots": (_L, "lii"),
     "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "ppppi" + "p"),

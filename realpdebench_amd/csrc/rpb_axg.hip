@@ -1,0 +1,330 @@
+// Truncated-DFT stage on the bf16 matrix pipe ("axg"): the same contraction as rpb_axis_gemm.hip,
+//
+//   out[g][o][n] = sum_k M[o][k] * in[g][k][n]        n contiguous, k / o strided, g = batch
+//
+// (every stage of rfftn / irfftn of fno.py:48,63 and their adjoints) with both operands split into three bf16 planes and the
+// products on v_mfma_f32_16x16x32_bf16 -- the fp32-grade arithmetic of rpb_cmx.hip / rpb_conv3x.hip (hi*lo + lo*hi + mid*mid +
+// hi*mid + mid*hi + hi*hi, fp32 accumulate; Rel-L2 vs fp64 ~2e-7).
+//
+// Why: as fp32 MFMA the H stages are matrix-pipe-bound (832 x 32 x 2 x 134 MFMAs of 64 cycles = 0.30 ms of pipe time for a
+// 1.08 GB problem whose HBM time is 0.18 ms; O = 48 pads to 64 rows).  The contraction index k is the SLOW memory index here, but
+// an MFMA operand only needs "8 consecutive k per lane": lane (c = lane & 15, kg = lane >> 4) issues 8 loads of 16 B, one per
+// k = 32 s + 8 kg + e, each fetching columns n0 + 4 c .. 4 c + 3 -- every load instruction reads 4 rows x 256 contiguous bytes,
+// and the 4 columns are the lane's B operands of 4 MFMA column tiles (column j of tile t <-> n = n0 + 4 j + t), so the output
+// store is 16 B per lane / 256 B per row as well.  The matrix is split once per workgroup into LDS in A-operand order
+// (16-row tiles: O = 48 is exact).
+#include "rpb_axg.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = pack_hi(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        um[q] = pack_hi(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        ul[q] = pack_hi(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+}  // namespace
+
+#define AXG_WAVES 8
+
+// MT = 16-row output tiles per pass (the accumulators of a pass: MT x 4 column tiles x 4 registers)
+template <int MT, bool XF>
+__global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
+    extern __shared__ u32x4 Ml[];            // [ks][plane 3][mt][lane 64]   M in A-operand order
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int KS = (a.k_valid + 31) >> 5;                    // K-steps that hold non-zero input
+    const int mtiles = (a.O + 15) >> 4;
+    for (int idx = tid; idx < KS * mtiles * 64; idx += blockDim.x) {
+        const int l = idx & 63, mt = (idx >> 6) % mtiles, ks = (idx >> 6) / mtiles;
+        const int o = 16 * mt + (l & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * ks + 8 * (l >> 4) + e;
+            v[e] = (o < a.O && k < a.k_valid) ? a.Mt[(long)k * a.O + o] : 0.f;
+        }
+        bf16x8 h, md, lo;
+        split8(v, h, md, lo);
+        Ml[((ks * 3 + 0) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        Ml[((ks * 3 + 1) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, md);
+        Ml[((ks * 3 + 2) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+    }
+    __syncthreads();
+
+    XParam xp[4];
+    if (XF) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xp[t] = xf_load(a.xf, 4 * c16 + t);       // N == channels == 64 * strips, strip 0 .. N/64
+    }
+    const bool xgelu = a.xf.gelu != 0;
+    const int strips = a.N >> 6;
+    const long items = (long)a.G * strips;
+    const long nslots = (long)gridDim.x * AXG_WAVES;
+    const int passes = (mtiles + MT - 1) / MT;
+    const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * 4);
+    const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * 4);
+    const int ioff = (8 * kg) * (int)a.in_k * 4 + c16 * 16;                  // row 8 kg, columns 4 c .. 4 c + 3
+    const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;                 // row 4 mg, columns 4 c ..
+
+    for (long it = (long)blockIdx.x * AXG_WAVES + wave; it < items; it += nslots) {
+        const long g = it / strips;
+        const int n0 = (int)(it - g * strips) << 6;
+        const rsrc_t ri = make_rsrc(a.in + g * a.in_g + n0, in_bytes);
+        const rsrc_t ro = make_rsrc(a.out + g * a.out_g + n0, out_bytes);
+        if (XF && strips > 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xp[t] = xf_load(a.xf, n0 + 4 * c16 + t);
+        }
+        for (int p = 0; p < passes; ++p) {
+            asm volatile("" ::: "memory");
+            f32x4v acc[MT][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            u32x4 zr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zr[e] = ld16(ri, ioff + e * (int)a.in_k * 4);
+            for (int ks = 0; ks < KS; ++ks) {
+                // ---- this step's 8 x 4 values -> B planes of the 4 column tiles (lazy BN+GELU of the producer applied here)
+                bf16x8 Bh[4], Bm[4], Bl[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = __builtin_bit_cast(f32x4v, zr[e])[t];
+                        if (XF) {
+                            // rows past k_valid must stay zero: the transform of a masked load is not
+                            x = (32 * ks + 8 * kg + e < a.k_valid) ? xf_apply(x, xp[t], xgelu) : 0.f;
+                        }
+                        v[e] = x;
+                    }
+                    split8(v, Bh[t], Bm[t], Bl[t]);
+                }
+                // ---- next step's loads go out now and are in flight during the MFMAs below
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zr[e] = ld16(ri, ioff + (32 * (ks + 1) + e) * (int)a.in_k * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int mt = p * MT + i;
+                    if (mt >= mtiles) break;                                   // uniform
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 0) * mtiles + mt) * 64 + lane]);
+                    const bf16x8 am = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 1) * mtiles + mt) * 64 + lane]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 2) * mtiles + mt) * 64 + lane]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bl[t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(al, Bh[t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bm[t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bm[t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bh[t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bh[t], acc[i][t]);
+                }
+            }
+            // ---- out[g][16 mt + 4 mg + r][n0 + 4 c + t]: 16 B per lane, 256 B per row; rows >= O fall outside the descriptor
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mt = p * MT + i;
+                if (mt >= mtiles) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4v o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = acc[i][t][r];
+                    st16(o, ro, ooff + (16 * mt + r) * (int)a.out_o * 4);
+                }
+            }
+        }
+    }
+}
+
+// Short contractions (K <= 64, e.g. the inverse H stage K = 48 -> O = 268): the B planes of the whole K range stay in registers
+// and the 16-row output tiles are walked in passes of MT against them -- the input is loaded and split once per item instead of
+// once per pass.
+template <int MT>
+__global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a) {
+    extern __shared__ u32x4 Ml[];            // [ks][plane 3][mt][lane 64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    const int KS = (a.k_valid + 31) >> 5;                    // 1 or 2
+    const int mtiles = (a.O + 15) >> 4;
+    for (int idx = tid; idx < KS * mtiles * 64; idx += blockDim.x) {
+        const int l = idx & 63, mt = (idx >> 6) % mtiles, ks = (idx >> 6) / mtiles;
+        const int o = 16 * mt + (l & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * ks + 8 * (l >> 4) + e;
+            v[e] = (o < a.O && k < a.k_valid) ? a.Mt[(long)k * a.O + o] : 0.f;
+        }
+        bf16x8 h, md, lo;
+        split8(v, h, md, lo);
+        Ml[((ks * 3 + 0) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        Ml[((ks * 3 + 1) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, md);
+        Ml[((ks * 3 + 2) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+    }
+    __syncthreads();
+    const int strips = a.N >> 6;
+    const long items = (long)a.G * strips;
+    const long nslots = (long)gridDim.x * AXG_WAVES;
+    const int passes = (mtiles + MT - 1) / MT;
+    const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * 4);
+    const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * 4);
+    const int ioff = (8 * kg) * (int)a.in_k * 4 + c16 * 16;
+    const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;
+
+    u32x4 zr[2][8];
+    auto issue = [&](long it) {
+        const long g = it / strips;
+        const int n0 = (int)(it - g * strips) << 6;
+        const rsrc_t ri = make_rsrc(a.in + g * a.in_g + n0, in_bytes);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zr[ks][e] = ld16(ri, ioff + (32 * ks + e) * (int)a.in_k * 4);   // ks >= KS: out of range -> 0
+    };
+    long it = (long)blockIdx.x * AXG_WAVES + wave;
+    if (it < items) issue(it);
+    for (; it < items; it += nslots) {
+        const long g = it / strips;
+        const int n0 = (int)(it - g * strips) << 6;
+        const rsrc_t ro = make_rsrc(a.out + g * a.out_g + n0, out_bytes);
+        bf16x8 Bh[2][4], Bm[2][4], Bl[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(f32x4v, zr[ks][e])[t];
+                split8(v, Bh[ks][t], Bm[ks][t], Bl[ks][t]);
+            }
+        if (it + nslots < items) issue(it + nslots);            // the next item's input is in flight during all passes below
+        for (int p = 0; p < passes; ++p) {
+            asm volatile("" ::: "memory");
+            f32x4v acc[MT][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks >= KS) break;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int mt = p * MT + i;
+                    if (mt >= mtiles) break;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 0) * mtiles + mt) * 64 + lane]);
+                    const bf16x8 am = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 1) * mtiles + mt) * 64 + lane]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 2) * mtiles + mt) * 64 + lane]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bl[ks][t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(al, Bh[ks][t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bm[ks][t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bm[ks][t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bh[ks][t], acc[i][t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bh[ks][t], acc[i][t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mt = p * MT + i;
+                if (mt >= mtiles) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4v o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = acc[i][t][r];
+                    st16(o, ro, ooff + (16 * mt + r) * (int)a.out_o * 4);
+                }
+            }
+        }
+    }
+}
+
+static size_t axg_lds(int k_valid, int O) { return (size_t)((k_valid + 31) / 32) * 3 * ((O + 15) / 16) * 64 * 16; }
+
+// N in 64-column strips, 16 B-aligned strides, 32-bit row offsets, the split matrix fits LDS; RPB_AXIS_GEMM_F32=1 forces the exact-fp32 kernel
+bool rpb_axg_supported(int G, int K, int O, int N, long in_g, long in_k, long out_g, long out_o, int k_valid, int accumulate,
+                       bool has_xf) {
+    static const bool off = getenv("RPB_AXIS_GEMM_F32") && atoi(getenv("RPB_AXIS_GEMM_F32")) == 1;
+    if (off || accumulate || N % 64 != 0 || k_valid < 1) return false;
+    if ((in_g | in_k | out_g | out_o) & 3) return false;
+    if (has_xf && N > 128) return false;
+    if ((long)(k_valid + 32) * in_k * 4 + 256 >= (1L << 31) || (long)(O + 16) * out_o * 4 + 256 >= (1L << 31)) return false;
+    return axg_lds(k_valid, O) <= 160 * 1024;
+}
+
+int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
+    const int mtiles = (a.O + 15) / 16;
+    const long items = (long)a.G * (a.N / 64);
+    long grid = rpb_num_cus();
+    const long need = (items + AXG_WAVES - 1) / AXG_WAVES;
+    if (grid > need) grid = need;
+    const size_t lds = axg_lds(a.k_valid, a.O);
+    const bool xf = a.xf.mean != nullptr;
+#define RPB_AXG(MT_, XF_)                                                                                                  \
+    {                                                                                                                      \
+        (void)hipFuncSetAttribute((const void*)axg_kernel<MT_, XF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((axg_kernel<MT_, XF_>), dim3((unsigned)grid), dim3(AXG_WAVES * 64), lds, st, a);                \
+        RPB_CHECK_LAUNCH("axis_gemm(bf16x3)");                                                                             \
+    }
+    if (!xf && a.k_valid <= 64 && mtiles > 4) {        // short K, many output rows: B planes resident across the passes
+        (void)hipFuncSetAttribute((const void*)axg_resident_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((axg_resident_kernel<2>), dim3((unsigned)grid), dim3(AXG_WAVES * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("axis_gemm(bf16x3, resident)");
+    }
+    if (mtiles <= 1) {
+        if (xf) RPB_AXG(1, true) else RPB_AXG(1, false)
+    } else if (mtiles == 2) {
+        if (xf) RPB_AXG(2, true) else RPB_AXG(2, false)
+    } else if (mtiles == 3) {
+        if (xf) RPB_AXG(3, true) else RPB_AXG(3, false)
+    } else {
+        if (xf) RPB_AXG(4, true) else RPB_AXG(4, false)
+    }
+#undef RPB_AXG
+}

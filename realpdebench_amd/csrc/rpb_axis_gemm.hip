@@ -13,6 +13,7 @@
 // B operand (the data) is loaded straight from HBM in MFMA layout; A operand (the matrix) sits in LDS
 // as Mlds[k][o] (o contiguous -> conflict-free ds_read_b32).  Persistent grid, one item per wave.
 #include "rpb_common.h"
+#include "rpb_axg.h"
 
 template <int NV>
 struct VecN;
@@ -250,6 +251,10 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     RPB_REQUIRE(N % 32 == 0, "axis_gemm: N=%d must be a multiple of 32", N);
     RPB_REQUIRE(k_valid >= 0 && k_valid <= K, "axis_gemm: k_valid=%d out of range", k_valid);
     hipStream_t st = (hipStream_t)stream;
+    if (rpb_axg_supported(G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf_mean != nullptr)) {
+        AxgArgs a{in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, xf};      // bf16 matrix pipe, split operands
+        return rpb_axg_launch(a, st);
+    }
     const int ot_total = (O + 31) / 32;
     int OT = ot_total >= 3 ? 3 : ot_total;
     int NV = (N % 128 == 0) ? 4 : (N % 64 == 0) ? 2 : 1;

@@ -385,6 +385,10 @@ extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int W
     return grid * waves;
 }
 
+extern "C" int rpb_cell_mix_writes_gz(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int gather) {
+    return rpb_cmx_supported(ncell, KC, CO, K2, Wp, has_spec != 0, gather != 0) ? 1 : 0;
+}
+
 extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW,
                             float* out, float* stats_part, long ncell, int KC, int CO, int K2, int Wp, int transpose_w,
                             int gather, int T, int H, int W, int Tp, int Hp, int Wp_pad, const float* xf_mean,
@@ -406,10 +410,11 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = transpose_w;
         c.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
         c.bnb_s = bnb_s;
-        c.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu};
-        c.write_gz = 0;
+        c.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu != 0};
+        c.write_gz = bnb_s != nullptr && bnb_gelu == 2;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
+    RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
     const int waves = cell_mix_waves(KC, CO, K2, Wp, spec, bnb_s != nullptr);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);
     CellMixArgs a;

@@ -366,9 +366,13 @@ class FNO3d(Model):
         ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, ws.bn_part, d.ncell, HID, C, 0, 1, transpose_w=True,
                      gather=True, crop6=d.crop6, bnb=(ws.S[L - 1],) + self._layer_xf(ws, L - 1, True))
         ops.reduce_partials(ws.bn_part, ws.bnb_rows_gather, 2 * C, out_f32=ws.bn_sums)
+        # the C = 64 bf16-pipe cell_mix stores gz = g * gelu'(z) when asked (it evaluates gelu' for the BatchNorm-backward sums
+        # anyway), so the BatchNorm-backward apply of the layer below skips gelu'
+        gz_ok = ws.fused_bwd and ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True)
+        g_is_gz = False                                  # the last layer has no GELU
         # ---- Fourier layers, last to first
         for l in range(L - 1, -1, -1):
-            gelu = l < L - 1
+            gelu = l < L - 1 and not g_is_gz
             gam, bet = P(f"bns.{l}.weight"), P(f"bns.{l}.bias")
             # ws.bn_sums = (sum gz, sum gz*shat) of layer l, left by the kernel that produced g
             GP(f"bns.{l}.bias").copy_(ws.bn_sums[:C])          # local sums are this rank's d beta / d gamma
@@ -399,8 +403,10 @@ class FNO3d(Model):
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
             self._spectral_inverse_stages(gxh, ws, (plan.FT, plan.FH))
             if l > 0:      # g_x of layer l = gradient w.r.t. act(BN(s_{l-1})): also leave layer l-1's BN-backward sums
+                g_is_gz = gz_ok and l - 1 < L - 1
                 ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, ws.bn_part, d.ncell, C, C,
-                             2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True))
+                             2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True),
+                             write_gz=g_is_gz)
                 ops.reduce_partials(ws.bn_part, ws.bnb_rows_conv, 2 * C, out_f32=ws.bn_sums)
             else:
                 ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW,

@@ -36,12 +36,13 @@ def _p(t, dtype=F32):
     return t.data_ptr()
 
 
-def _xf(xf):
-    """Lazy-activation argument group: ``None`` or ``(mean, invstd, gamma, beta, gelu)`` -> 5 C arguments."""
+def _xf(xf, gelu_code=None):
+    """Lazy-activation argument group: ``None`` or ``(mean, invstd, gamma, beta, gelu)`` -> 5 C arguments.
+    ``gelu_code``: the integer passed instead of 1 when the GELU flag is set (cell_mix: 2 = "and store gz")."""
     if xf is None:
         return (None, None, None, None, 0)
     mean, invstd, gamma, beta, gelu = xf
-    return (_p(mean), _p(invstd), _p(gamma), _p(beta), int(bool(gelu)))
+    return (_p(mean), _p(invstd), _p(gamma), _p(beta), (gelu_code or 1) if gelu else 0)
 
 
 class Dims:
@@ -108,11 +109,16 @@ def cell_mix_stat_rows(ncell, KC, CO, K2, Wp, has_spec, bn_bwd_stats=False):
     return _lib.query("rpb_cell_mix_stat_rows", ncell, KC, CO, K2, Wp, int(has_spec), int(bn_bwd_stats))
 
 
+def cell_mix_writes_gz(ncell, KC, CO, K2, Wp, has_spec, gather=False):
+    return bool(_lib.query("rpb_cell_mix_writes_gz", ncell, KC, CO, K2, Wp, int(has_spec), int(gather)))
+
+
 def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transpose_w=False, gather=False,
-             crop6=(0, 0, 0, 1, 1, 1), xf=None, bnb=None, oxf=None):
+             crop6=(0, 0, 0, 1, 1, 1), xf=None, bnb=None, oxf=None, write_gz=False):
     """``bnb`` = (s, mean, invstd, gamma, beta, gelu) of the layer whose output gradient this launch produces: the
     stats partials then hold that layer's BatchNorm-backward sums (sum gz, sum gz*shat).
-    ``oxf`` = (mean, invstd, gamma, beta, gelu): store act(BN(out)) instead of out (eval mode, no statistics)."""
+    ``oxf`` = (mean, invstd, gamma, beta, gelu): store act(BN(out)) instead of out (eval mode, no statistics).
+    ``write_gz`` (with ``bnb`` and its GELU): store gz = out * gelu'(z); the consumer's BatchNorm backward then runs with gelu off."""
     tag = None
     if oxf is not None:
         assert bnb is None and stats_part is None
@@ -122,7 +128,7 @@ def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transp
     rows_in = (crop6[0] * crop6[1] * crop6[2] * (ncell // (crop6[3] * crop6[4] * crop6[5]))) if gather else ncell
     _lib.call("rpb_cell_mix", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, KC, CO, K2, Wp,
               int(transpose_w), int(gather), *crop6, *_xf(xf),
-              *((None,) + _xf(None) if bnb is None else (_p(bnb[0]),) + _xf(bnb[1:])), _stream(),
+              *((None,) + _xf(None) if bnb is None else (_p(bnb[0]),) + _xf(bnb[1:], 2 if write_gz else None)), _stream(),
               label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={tag or int(stats) + int(bnb is not None)}]",
               nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)

@@ -444,5 +444,13 @@ def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2):
         assert rel_l2(out.cpu(), ref2) < 2e-6
         tot = part2.double().sum(0).cpu()
         assert rel_l2(tot[0], gz.sum(0)) < 2e-5 and rel_l2(tot[1], (gz * sh).sum(0)) < 2e-5
+        if gelu:            # "store gz": the tensor handed to the BatchNorm-backward apply already carries gelu'(z)
+            assert ops.cell_mix_writes_gz(ncell, C, C, K2, Wp, True)
+            part2.zero_()
+            ops.cell_mix(dev(g), dev(Wc), None, dev(z2), dev(GW.t()), out, part2, ncell, C, C, K2, Wp, transpose_w=True,
+                         bnb=(dev(s),) + xf, write_gz=True)
+            assert rel_l2(out.cpu(), gz) < 3e-6
+            tot = part2.double().sum(0).cpu()
+            assert rel_l2(tot[0], gz.sum(0)) < 2e-5 and rel_l2(tot[1], (gz * sh).sum(0)) < 2e-5
     ops.cell_mix(dev(g), dev(Wc), None, dev(z2), dev(GW.t()), out, None, ncell, C, C, K2, Wp, transpose_w=True)
     assert rel_l2(out.cpu(), spec + g @ Wc) < 2e-6
