@@ -308,10 +308,11 @@ def bench_rollout_bf16(dev):
         fwd_bytes = (0.445 * bpe / 2 * B + 0.537) * 1e9       # 2 B/element activations, fp32 weights
         res[storage] = {"value": B * shape[0] * n_ar / rt, "unit": "fields/s", "ms_per_forward": 1e3 * rt / n_ar,
                         "roofline": {"bound": "hbm", "algorithmic_bytes_per_forward": fwd_bytes,
-                                     "achieved": fwd_bytes / (1e6 * rt / n_ar), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": fwd_bytes / (1e6 * rt / n_ar) / HBM_PEAK_GBS}}
+                                     "achieved": fwd_bytes / (1e9 * rt / n_ar), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": fwd_bytes / (1e9 * rt / n_ar) / HBM_PEAK_GBS}}
     d = (outs["bf16"].float() - outs["f32"]).double()
     T = shape[0]
+    res["tolerance"] = "stated by this repo (the reference has no bf16 path): Rel-L2 vs the fp32 path < 2e-3 after 1 step, < 1e-2 after 20"
     res["rel_l2_vs_f32_step1"] = float(d[:, :T].norm() / outs["f32"][:, :T].double().norm())
     res["rel_l2_vs_f32_step20"] = float(d[:, -T:].norm() / outs["f32"][:, -T:].double().norm())
     res["config"] = f"FNO3d combustion volume [B={B},64,64,64,16] -> padded 70^3, modes (4,16,16), width 64, 4 layers, {n_ar} AR steps"
@@ -469,8 +470,8 @@ def main():
         rollout = {"value": B * world * shape[0] * a.rollout_steps / rt, "unit": "fields/s",
                    "n_autoregressive": a.rollout_steps, "ms_per_forward": 1e3 * rt / a.rollout_steps,
                    "roofline": {"bound": "hbm", "algorithmic_bytes_per_forward": fwd_bytes,
-                                "achieved": fwd_bytes / (1e6 * rt / a.rollout_steps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": fwd_bytes / (1e6 * rt / a.rollout_steps) / HBM_PEAK_GBS}}
+                                "achieved": fwd_bytes / (1e9 * rt / a.rollout_steps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": fwd_bytes / (1e9 * rt / a.rollout_steps) / HBM_PEAK_GBS}}
 
     extra = {}
     if world == 1:

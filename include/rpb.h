@@ -322,6 +322,21 @@ int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, 
 int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n, void* stream);
 int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream);
 
+/* ---- bf16 ACTIVATION STORAGE for the eval / rollout forward (BASELINE.json configs[4]: FNO3d on the combustion volume, "bf16").
+ *      The reference has no reduced-precision path; this variant keeps weights, spectra, accumulation and BatchNorm in fp32 and
+ *      stores only the [cells][C] activations between kernels as bf16 (round to nearest even): lift -> W stage -> ... ->
+ *      cell_mix -> projection read / write 2 bytes per element (SURVEY.md section 8d byte model 0.445 GB*B + 0.537 GB per step).
+ *      Replaces the same reference lines as their fp32 twins (fno.py:106-129). */
+int rpb_lift_pad_fwd_bf16(const float* x, const float* gt, const float* gh, const float* gw, const float* w0, const float* b0,
+                          void* out_bf16, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp, void* stream);
+int rpb_axis_gemm_bf16in(const void* in_bf16, float* out, const float* Mt, int G, int K, int O, int N, long in_g, long in_k,
+                         long out_g, long out_o, int k_valid, void* stream);
+int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out_bf16,
+                      long ncell, int C, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
+                      const float* oxf_beta, int oxf_gelu, void* stream);
+int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                      long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

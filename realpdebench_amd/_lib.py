@@ -17,6 +17,10 @@ SIGNATURES = {
     "rpb_last_error": (ctypes.c_char_p, ""),
     "rpb_abi_version": (_I, ""),
     "rpb_lift_pad_fwd": (_I, "ppppppp" + "iiiiiiiii" + "p"),
+    "rpb_lift_pad_fwd_bf16": (_I, "ppppppp" + "iiiiiiiii" + "p"),
+    "rpb_axis_gemm_bf16in": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),
+    "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
+    "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
     "rpb_lift_bwd_rows": (_I, ""),
     "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "ppppi" + "p"),

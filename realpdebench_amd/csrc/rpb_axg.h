@@ -10,6 +10,7 @@ struct AxgArgs {
     long in_g, in_k, out_g, out_o;
     int k_valid;
     XForm xf;            // lazy BatchNorm(+GELU) on the input, channel = n (N <= 128)
+    int in_bf16;         // `in` holds bf16 (strides in bf16 elements); plain stage, O <= 64
 };
 
 bool rpb_axg_supported(int G, int K, int O, int N, long in_g, long in_k, long out_g, long out_o, int k_valid, int accumulate,

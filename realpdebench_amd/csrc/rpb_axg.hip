@@ -54,8 +54,11 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #define AXG_WAVES 8
 
 // MT = 16-row output tiles per pass (the accumulators of a pass: MT x 4 column tiles x 4 registers)
-template <int MT, bool XF>
+// BFIN: the input is STORED as bf16 (in_g / in_k in bf16 elements; BASELINE.json configs[4]): the B operand is one exact bf16
+//       plane, so a (row tile, column tile) costs 3 products instead of 6; a lane's 8 loads are 8 B each (4 columns).
+template <int MT, bool XF, bool BFIN = false>
 __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
+    static_assert(!(BFIN && XF), "bf16 storage holds materialised activations: no lazy transform");
     extern __shared__ u32x4 Ml[];            // [ks][plane 3][mt][lane 64]   M in A-operand order
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,15 +93,17 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const long items = (long)a.G * strips;
     const long nslots = (long)gridDim.x * AXG_WAVES;
     const int passes = (mtiles + MT - 1) / MT;
-    const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * 4);
+    constexpr int EB = BFIN ? 2 : 4;                                         // bytes per input element
+    const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * EB);
     const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * 4);
-    const int ioff = (8 * kg) * (int)a.in_k * 4 + c16 * 16;                  // row 8 kg, columns 4 c .. 4 c + 3
+    const int ioff = (8 * kg) * (int)a.in_k * EB + c16 * 4 * EB;             // row 8 kg, columns 4 c .. 4 c + 3
     const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;                 // row 4 mg, columns 4 c ..
+    const int istep = (int)a.in_k * EB;                                      // bytes between consecutive k rows
 
     for (long it = (long)blockIdx.x * AXG_WAVES + wave; it < items; it += nslots) {
         const long g = it / strips;
         const int n0 = (int)(it - g * strips) << 6;
-        const rsrc_t ri = make_rsrc(a.in + g * a.in_g + n0, in_bytes);
+        const rsrc_t ri = make_rsrc(reinterpret_cast<const char*>(a.in) + (g * a.in_g + n0) * EB, in_bytes);
         const rsrc_t ro = make_rsrc(a.out + g * a.out_g + n0, out_bytes);
         if (XF && strips > 1) {
 #pragma unroll
@@ -112,13 +117,36 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[i][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
             u32x4 zr[8];
+            auto issue = [&](int ks) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) zr[e] = ld16(ri, ioff + e * (int)a.in_k * 4);
+                for (int e = 0; e < 8; ++e) {
+                    if (BFIN) {
+                        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                        const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(ri, ioff + (32 * ks + e) * istep, 0, 0);
+                        zr[e][0] = w[0];
+                        zr[e][1] = w[1];
+                    } else {
+                        zr[e] = ld16(ri, ioff + (32 * ks + e) * istep);
+                    }
+                }
+            };
+            issue(0);
             for (int ks = 0; ks < KS; ++ks) {
                 // ---- this step's 8 x 4 values -> B planes of the 4 column tiles (lazy BN+GELU of the producer applied here)
                 bf16x8 Bh[4], Bm[4], Bl[4];
+                if (BFIN) {                 // word 0 = columns (0, 1), word 1 = columns (2, 3): gather each column's 8 rows
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        u32x4 u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            u[q] = __builtin_amdgcn_perm(zr[2 * q + 1][t >> 1], zr[2 * q][t >> 1], (t & 1) ? 0x07060302u : 0x05040100u);
+                        Bh[t] = __builtin_bit_cast(bf16x8, u);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (BFIN) break;
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -132,10 +160,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                     split8(v, Bh[t], Bm[t], Bl[t]);
                 }
                 // ---- next step's loads go out now and are in flight during the MFMAs below
-                if (ks + 1 < KS) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) zr[e] = ld16(ri, ioff + (32 * (ks + 1) + e) * (int)a.in_k * 4);
-                }
+                if (ks + 1 < KS) issue(ks + 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int mt = p * MT + i;
@@ -143,6 +168,15 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 0) * mtiles + mt) * 64 + lane]);
                     const bf16x8 am = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 1) * mtiles + mt) * 64 + lane]);
                     const bf16x8 al = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 2) * mtiles + mt) * 64 + lane]);
+                    if (BFIN) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(al, Bh[t], acc[i][t]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bh[t], acc[i][t]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bh[t], acc[i][t]);
+                        continue;
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(ah, Bl[t], acc[i][t]);
 #pragma unroll
@@ -306,6 +340,12 @@ int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
     if (grid > need) grid = need;
     const size_t lds = axg_lds(a.k_valid, a.O);
     const bool xf = a.xf.mean != nullptr;
+    if (a.in_bf16) {
+        if (xf || mtiles > 4) RPB_FAIL(RPB_ERR_UNSUPPORTED, "axg: bf16 input supports plain stages with O <= 64 (the forward W stage)");
+        (void)hipFuncSetAttribute((const void*)axg_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((axg_kernel<4, false, true>), dim3((unsigned)grid), dim3(AXG_WAVES * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("axis_gemm(bf16x3, bf16 input)");
+    }
 #define RPB_AXG(MT_, XF_)                                                                                                  \
     {                                                                                                                      \
         (void)hipFuncSetAttribute((const void*)axg_kernel<MT_, XF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -252,7 +252,7 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     RPB_REQUIRE(k_valid >= 0 && k_valid <= K, "axis_gemm: k_valid=%d out of range", k_valid);
     hipStream_t st = (hipStream_t)stream;
     if (rpb_axg_supported(G, K, O, N, in_g, in_k, out_g, out_o, k_valid, accumulate, xf_mean != nullptr)) {
-        AxgArgs a{in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, xf};      // bf16 matrix pipe, split operands
+        AxgArgs a{in, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, xf, 0};      // bf16 matrix pipe, split operands
         return rpb_axg_launch(a, st);
     }
     const int ot_total = (O + 31) / 32;
@@ -269,4 +269,15 @@ extern "C" int rpb_axis_gemm(const float* in, float* out, const float* M, int G,
     RPB_AX(1, 1) RPB_AX(1, 2) RPB_AX(1, 4) RPB_AX(2, 1) RPB_AX(2, 2) RPB_AX(2, 4) RPB_AX(3, 1) RPB_AX(3, 2)
 #undef RPB_AX
     RPB_FAIL(RPB_ERR_UNSUPPORTED, "axis_gemm: no instantiation OT=%d NV=%d", OT, NV);
+}
+
+// forward W stage reading bf16 activations (BASELINE.json configs[4] storage): same contraction, `in` holds bf16 and in_g / in_k
+// count bf16 elements; the output (truncated spectrum rows) stays fp32
+extern "C" int rpb_axis_gemm_bf16in(const void* in_bf16, float* out, const float* M, int G, int K, int O, int N, long in_g,
+                                    long in_k, long out_g, long out_o, int k_valid, void* stream) {
+    RPB_REQUIRE(in_bf16 && out && M, "axis_gemm_bf16in: null pointer");
+    RPB_REQUIRE(G > 0 && K > 0 && O > 0 && O <= 64 && N > 0 && k_valid >= 1 && k_valid <= K, "axis_gemm_bf16in: bad sizes G=%d K=%d O=%d N=%d", G, K, O, N);
+    RPB_REQUIRE(rpb_axg_supported(G, K, O, N, in_g, in_k, out_g, out_o, k_valid, 0, false), "axis_gemm_bf16in: unsupported layout (N=%d must be a multiple of 64, strides 16 B aligned)", N);
+    AxgArgs a{(const float*)in_bf16, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, XForm{nullptr, nullptr, nullptr, nullptr, 0}, 1};
+    return rpb_axg_launch(a, (hipStream_t)stream);
 }

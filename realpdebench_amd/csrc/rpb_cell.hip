@@ -412,6 +412,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.bnb_s = bnb_s;
         c.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu != 0};
         c.write_gz = bnb_s != nullptr && bnb_gelu == 2;
+        c.bf16_io = 0;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
@@ -445,6 +446,26 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
 #undef RPB_CM3
 #undef RPB_CM
     RPB_FAIL(RPB_ERR_UNSUPPORTED, "cell_mix: unsupported configuration KC=%d CO=%d K2=%d stats=%d", KC, CO, K2, (int)stats);
+}
+
+// eval / rollout with bf16 activation storage (BASELINE.json configs[4]): x and out are bf16 [ncell][64]; the statistics are the
+// running ones, so BatchNorm(+GELU) is applied to the tile before it is rounded and stored (oxf_* = that layer's vectors)
+extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GW,
+                                 void* out_bf16, long ncell, int C, int K2, int Wp, const float* oxf_mean,
+                                 const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu,
+                                 void* stream) {
+    RPB_REQUIRE(x_bf16 && Wm && z2 && GW && out_bf16, "cell_mix_bf16: null pointer");
+    RPB_REQUIRE(rpb_cmx_supported(ncell, C, C, K2, Wp, true, false), "cell_mix_bf16: needs C = 64, K2 <= 32, Wp >= 32 (C=%d K2=%d Wp=%d)", C, K2, Wp);
+    if (oxf_mean) RPB_REQUIRE(oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_bf16: the output transform needs all four vectors");
+    CmxArgs c;
+    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.write_gz = 0;
+    c.bf16_io = 1;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad

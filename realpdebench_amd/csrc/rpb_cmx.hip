@@ -68,8 +68,12 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #define CMX_WAVES_OF(STATS) ((STATS) == 2 ? CMX_WAVES_B : CMX_WAVES_A)
 
 // STATS: 0 none (bnb.mean != null: output transform) | 1 sum / sum of squares of the output | 2 BatchNorm-backward sums
-template <int STATS>
+// BF: activations are STORED as bf16 (x and out: [ncell][64] bf16, 128 B per cell; BASELINE.json configs[4]).  The x operand is
+//     then exactly one bf16 plane (no split: 3 products per weight column instead of 6) and a lane's 16 B load is its whole
+//     A operand of a K-step (k = (ks, kg, e) <-> channel 32 ks + 8 kg + e); arithmetic and accumulation stay fp32-grade.
+template <int STATS, bool BF = false>
 __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
     constexpr int CMX_WAVES = CMX_WAVES_OF(STATS);
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ci = 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
+            const int ci = BF ? 32 * ks + 8 * kgb + e : 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
             const int co = 4 * n + t;
             v[e] = a.transpose_w ? a.Wm[ci * 64 + co] : a.Wm[co * 64 + ci];
         }
@@ -142,16 +146,21 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     const int TQ = (Wp + 31) >> 5;
     const long nslots = (long)gridDim.x * CMX_WAVES;
     const long slot = (long)blockIdx.x * CMX_WAVES + wave;
-    const unsigned line_bytes = (unsigned)Wp * 256u;
+    const unsigned line_bytes = (unsigned)Wp * (BF ? 128u : 256u);
+    const long line_floats = (long)Wp * (BF ? 32 : 64);          // bf16 storage: two channels per float slot
     const int xoff = m * 256 + kg * 16;                  // byte offset of the lane's first 16 B inside a 16-cell block
     const int ooff = (4 * kg) * 256 + m * 16;            // output: cell 4 mg + r, channels 4 n ..
 
     u32x4 xa[2][4];
     // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
     auto issue_x = [&](long g, int q, int j, int ks) {
-        const rsrc_t rx = make_rsrc(a.x + g * Wp * 64, line_bytes);
+        const rsrc_t rx = make_rsrc(a.x + g * line_floats, line_bytes);
+        if (BF) {
+            xa[j][ks] = ld16(rx, q * 4096 + j * 2048 + m * 128 + ks * 64 + kg * 16);
+        } else {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) xa[j][2 * ks + hf] = ld16(rx, q * 8192 + xoff + j * 4096 + (2 * ks + hf) * 64);
+            for (int hf = 0; hf < 2; ++hf) xa[j][2 * ks + hf] = ld16(rx, q * 8192 + xoff + j * 4096 + (2 * ks + hf) * 64);
+        }
     };
     u32x4 zr[8];
     auto issue_z = [&](long g) {        // z2 row in B-operand layout: lane (n, kg) holds k = 8 kg + e, channels 4 n .. 4 n + 3
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     }
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
     for (long g = slot; g < G; g += nslots) {
-        const rsrc_t ro = make_rsrc(a.out + g * Wp * 64, line_bytes);
+        const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
         const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.x, line_bytes);
         for (int q = 0; q < TQ; ++q) {
             const bool last = q + 1 == TQ;
@@ -194,6 +203,10 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (j == 1 && half_tile) continue;
+                    if (BF) {                       // the 16 B load IS the operand
+                        Ah[j] = __builtin_bit_cast(bf16x8, xa[j][ks]);
+                        continue;
+                    }
                     float v[8];
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
@@ -254,7 +267,11 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
 #define CMX_PROD(AP, BP)                                                     \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)  \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], BP[u], acc[j][2 * tp + u]);
-                    CMX_PROD(Ah, Bl) CMX_PROD(Al, Bh) CMX_PROD(Am, Bm) CMX_PROD(Ah, Bm) CMX_PROD(Am, Bh) CMX_PROD(Ah, Bh)
+                    if (BF) {
+                        CMX_PROD(Ah, Bl) CMX_PROD(Ah, Bm) CMX_PROD(Ah, Bh)
+                    } else {
+                        CMX_PROD(Ah, Bl) CMX_PROD(Al, Bh) CMX_PROD(Am, Bm) CMX_PROD(Ah, Bm) CMX_PROD(Am, Bh) CMX_PROD(Ah, Bh)
+                    }
 #undef CMX_PROD
                 }
             }
@@ -315,7 +332,17 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
                             }
                             o[t] = v;
                         }
-                        st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
+                        if (BF) {               // round to nearest even, 4 channels = 8 B per lane, 128 B per cell row
+                            typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                            typedef float f32x2v __attribute__((ext_vector_type(2)));
+                            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                            u32x2v pk;
+                            pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[0], o[1]}, bf16x2v));
+                            pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[2], o[3]}, bf16x2v));
+                            __builtin_amdgcn_raw_buffer_store_b64(pk, ro, q * 4096 + j * 2048 + (4 * kg + r) * 128 + m * 8, 0, 0);
+                        } else {
+                            st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
+                        }
                     }
                 }
             };
@@ -367,6 +394,12 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((cmx_kernel<ST_>), dim3(grid), dim3(waves * 64), lds, st, a);                          \
         RPB_CHECK_LAUNCH("cell_mix(bf16x3)");                                                                         \
+    }
+    if (a.bf16_io) {
+        if (stats != 0) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: bf16 activation storage is an eval / rollout path (no statistics)");
+        (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cmx_kernel<0, true>), dim3(grid), dim3(waves * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("cell_mix(bf16x3, bf16 storage)");
     }
     RPB_CMX(0) RPB_CMX(1) RPB_CMX(2)
 #undef RPB_CMX

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
                                                               const float* __restrict__ gh, const float* __restrict__ gw,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
                                                               float* __restrict__ out, long nrows_pad, int Cin, int C,
-                                                              CropMap cm) {
+                                                              CropMap cm, int out_bf16) {
     extern __shared__ float wl[];   // [F][C] transposed fc0.weight, bias [C], then the feature row [W][Cin]
     const int F = FT > 0 ? FT : Cin + 3;
     float* xrow = wl + (F + 1) * C;
@@ -46,8 +46,15 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
         const int t = (int)(r2 % cm.Tp);
         const long b = r2 / cm.Tp;
         float* op = out + row * cm.Wp * C + o;
+        // bf16 activation storage (BASELINE.json configs[4]): the same cell rows at 2 bytes per channel, rounded to nearest even
+        __bf16* ob = reinterpret_cast<__bf16*>(out) + row * cm.Wp * C + o;
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        typedef float f32x4w __attribute__((ext_vector_type(4)));
         if (h >= cm.H || t >= cm.T) {                                   // uniform: whole row is padding
-            for (int w = sub; w < cm.Wp; w += nsub) *reinterpret_cast<f32x4*>(op + (long)w * C) = z4;
+            for (int w = sub; w < cm.Wp; w += nsub) {
+                if (out_bf16) *reinterpret_cast<uint2*>(ob + (long)w * C) = uint2{0u, 0u};
+                else *reinterpret_cast<f32x4*>(op + (long)w * C) = z4;
+            }
             continue;
         }
         __syncthreads();                                               // previous row's readers are done (and wl is filled)
@@ -68,7 +75,12 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
                 for (int j = 0; j < (FT > 0 ? FT - 3 : LIFT_FMAX - 3); ++j)
                     if (FT > 0 || j < Ci) v += *reinterpret_cast<const f32x4*>(wl + j * C + o) * xrow[w * Ci + j];
             }
-            *reinterpret_cast<f32x4*>(op + (long)w * C) = v;
+            if (out_bf16) {
+                const bf16x4v b = __builtin_convertvector(f32x4w{v[0], v[1], v[2], v[3]}, bf16x4v);
+                *reinterpret_cast<bf16x4v*>(ob + (long)w * C) = b;
+            } else {
+                *reinterpret_cast<f32x4*>(op + (long)w * C) = v;
+            }
         }
     }
 }
@@ -76,14 +88,14 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
 template <int FT>
 static void lift_pad_launch(int grid, size_t lds, hipStream_t st, const float* x, const float* gt, const float* gh,
                             const float* gw, const float* w0, const float* b0, float* out, long nrows, int Cin, int C,
-                            CropMap cm) {
+                            CropMap cm, int out_bf16) {
     hipLaunchKernelGGL(lift_pad_kernel<FT>, dim3(grid), dim3(PW_THREADS), lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C,
-                       cm);
+                       cm, out_bf16);
 }
 
-extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
-                                const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
-                                int Wp, void* stream) {
+static int lift_pad_impl(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
+                         const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
+                         int Wp, int out_bf16, void* stream) {
     RPB_REQUIRE(x && gt && gh && gw && w0 && b0 && out, "lift_pad: null pointer");
     RPB_REQUIRE(C % 4 == 0 && PW_THREADS % (C / 4) == 0 && Cin >= 0 && Cin + 3 <= LIFT_FMAX, "lift_pad: C=%d Cin=%d unsupported", C, Cin);
     const long nrows = (long)B * Tp * Hp;
@@ -94,13 +106,25 @@ extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh
     const CropMap cm{T, H, W, Tp, Hp, Wp};
     hipStream_t st = (hipStream_t)stream;
     switch (F) {
-        case 5: lift_pad_launch<5>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
-        case 6: lift_pad_launch<6>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
-        case 8: lift_pad_launch<8>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
-        case 19: lift_pad_launch<19>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
-        default: lift_pad_launch<0>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm); break;
+        case 5: lift_pad_launch<5>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm, out_bf16); break;
+        case 6: lift_pad_launch<6>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm, out_bf16); break;
+        case 8: lift_pad_launch<8>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm, out_bf16); break;
+        case 19: lift_pad_launch<19>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm, out_bf16); break;
+        default: lift_pad_launch<0>((int)grid, lds, st, x, gt, gh, gw, w0, b0, out, nrows, Cin, C, cm, out_bf16); break;
     }
     RPB_CHECK_LAUNCH("lift_pad");
+}
+
+extern "C" int rpb_lift_pad_fwd(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
+                                const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
+                                int Wp, void* stream) {
+    return lift_pad_impl(x, gt, gh, gw, w0, b0, out, B, T, H, W, Cin, C, Tp, Hp, Wp, 0, stream);
+}
+
+extern "C" int rpb_lift_pad_fwd_bf16(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
+                                     const float* b0, void* out_bf16, int B, int T, int H, int W, int Cin, int C, int Tp,
+                                     int Hp, int Wp, void* stream) {
+    return lift_pad_impl(x, gt, gh, gw, w0, b0, (float*)out_bf16, B, T, H, W, Cin, C, Tp, Hp, Wp, 1, stream);
 }
 
 // d fc0.weight[o][j] = sum_cells g[cell][o] * feat[cell][j],  d fc0.bias[o] = sum_cells g[cell][o]

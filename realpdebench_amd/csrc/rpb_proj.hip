@@ -30,6 +30,7 @@ struct ProjArgs {
     CropMap cm;
     XForm xf;            // lazy BatchNorm of the last Fourier layer (no GELU there, fno.py:118)
     int act;             // 0: exact GELU (fno.py:124); 1: SiLU (Galerkin SpectralRegressor, model.py:631-632)
+    int a_bf16;          // forward only: `a` holds bf16 (BASELINE.json configs[4] activation storage)
 };
 
 // v = gelu(u), d = gelu'(u) with ONE erf evaluation
@@ -101,12 +102,21 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
         for (int k = 0; k < 4; ++k) xp4[k] = xf_load(p.xf, 4 * (lane % (C / 4)) + k);
     }
     f32x4 xr[NX];
+    // 4 consecutive channels of a cell: 16 B of fp32, or 8 B of bf16 widened (exact) to fp32
+    auto load4 = [&](long elem) -> f32x4 {
+        if (!BWD && p.a_bf16) {
+            const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p.a) + elem);
+            return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                         __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+        }
+        return *reinterpret_cast<const f32x4*>(p.a + elem);
+    };
     auto issue_x = [&](long tile) {
         const long q0 = tile * 32;
         if (ROWFAST && q0 + 32 <= p.ncrop) {
-            const float* base = p.a + crop_to_pad(p.cm, q0) * C;            // uniform: 32 consecutive padded cells
+            const long base = crop_to_pad(p.cm, q0) * C;                     // uniform: 32 consecutive padded cells
 #pragma unroll
-            for (int j = 0; j < NX; ++j) xr[j] = *reinterpret_cast<const f32x4*>(base + lane * 4 + j * 256);
+            for (int j = 0; j < NX; ++j) xr[j] = load4(base + lane * 4 + j * 256);
         } else {
             if (lane < 32) {
                 const long q = q0 + lane;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(512) void proj_kernel(ProjArgs p) {
                 const int row = idx / (C / 4), c4 = idx - row * (C / 4);
                 const int sr = srow[row];
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (sr >= 0) v = *reinterpret_cast<const f32x4*>(p.a + (long)sr * C + 4 * c4);
+                if (sr >= 0) v = load4((long)sr * C + 4 * c4);
                 xr[j] = v;
             }
             __builtin_amdgcn_wave_barrier();
@@ -358,6 +368,19 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
     p.act = act;
     p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    return proj_launch(false, p, (hipStream_t)stream);
+}
+
+extern "C" int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, int act,
+                                 void* stream) {
+    RPB_REQUIRE(out && a_bf16, "proj_fwd_bf16: null pointer");
+    ProjArgs p{};
+    p.act = act;
+    p.a_bf16 = 1;
+    p.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    p.a = (const float*)a_bf16; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
     return proj_launch(false, p, (hipStream_t)stream);
 }

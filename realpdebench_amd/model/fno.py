@@ -30,13 +30,15 @@ class _Workspace:
     def __init__(self, model, B, training, device):
         d = ops.Dims(B, *model.shape_in[:3], model.dim_in, model.width, model.padding)
         self.d, self.training = d, training
+        self.bf16 = (not training) and model.storage == "bf16"       # eval / rollout only: activations stored as bf16
         self.generation = 0          # bumped by every training-mode forward: a backward whose graph saw an older value must not run
         C, L, plan = model.width, model.n_layers, model.plan
         f = dict(device=device, dtype=torch.float32)
         # Lazy activations: a_{l+1} = act(BN(s_l)) is never materialised (its consumers transform s_l on load), so the
         # step keeps the lifted input A0 and the pre-BatchNorm tensors S[l] only.  Eval ping-pongs two S buffers.
-        self.A0 = torch.empty(d.ncell, C, **f)
-        self.S = [torch.empty(d.ncell, C, **f) for _ in range(L if training else 2)]
+        fa = dict(device=device, dtype=torch.bfloat16) if self.bf16 else f
+        self.A0 = torch.empty(d.ncell, C, **fa)
+        self.S = [torch.empty(d.ncell, C, **fa) for _ in range(L if training else 2)]
         G1, N1 = B * d.Tp * d.Hp, 2 * plan.KW * C
         self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
         self.Y2 = torch.empty(B * d.Tp * 2 * plan.KH * plan.KW * C, **f)     # after H stage
@@ -148,6 +150,7 @@ class FNO3d(Model):
         self._ws = {}
         self._dev_cache = None
         self.dp = None            # set by realpdebench_amd.dp.DataParallel (RCCL)
+        self.storage = "f32"      # activation storage of the eval / rollout forward, see set_storage
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self):
@@ -253,6 +256,19 @@ class FNO3d(Model):
                 out[n] = g(n)
         return out
 
+    def set_storage(self, storage):
+        """Activation storage of the eval / rollout forward: ``"f32"`` (the parity path) or ``"bf16"`` (BASELINE.json configs[4]:
+        the [cells][C] tensors between kernels are stored as bf16, round to nearest even; weights, spectra, accumulation and
+        BatchNorm stay fp32).  Training always stores fp32.  bf16 needs width 64 and 2 * modes3 <= 32 (the bf16-pipe kernels)."""
+        if storage not in ("f32", "bf16"):
+            raise ValueError(f"storage must be 'f32' or 'bf16', got {storage!r}")
+        if storage == "bf16" and (self.width != 64 or 2 * self.modes3 > 32 or type(self)._lift_fwd is not FNO3d._lift_fwd):
+            raise NotImplementedError("bf16 activation storage is built for FNO3d at width 64 with modes3 <= 16")
+        if storage != self.storage:
+            self.storage = storage
+            self._ws = {k: v for k, v in self._ws.items() if k[1]}       # drop the eval workspaces (dtype changed)
+        return self
+
     # ------------------------------------------------------------------ device-side constants
     def _consts(self, device):
         if self._dev_cache is None or self._dev_cache[0] != device:
@@ -264,7 +280,7 @@ class FNO3d(Model):
         return self._dev_cache[1], self._dev_cache[2]
 
     def _workspace(self, B, training, device):
-        key = (B, training, str(device))
+        key = (B, training, str(device), self.storage if not training else "f32")
         if key not in self._ws:
             self._consts(device)
             self._ws[key] = _Workspace(self, B, training, device)
@@ -278,7 +294,10 @@ class FNO3d(Model):
         m3, KH, KT = p.KW, p.KH, p.KT
         MW, MH, MT = mats
         N2, N3 = m3 * C, KH * m3 * C
-        if MW is not None:                      # None: ws.Y1 was already produced (fused backward row kernel)
+        if MW is not None and x.dtype == torch.bfloat16:     # eval with bf16 activation storage
+            ops.axis_gemm_bf16in(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
+                                 k_valid=d.W if first_layer else None)
+        elif MW is not None:                    # None: ws.Y1 was already produced (fused backward row kernel)
             ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
                           k_valid=d.W if first_layer else None, xf=xf)
         ops.axis_gemm(ws.Y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
@@ -331,11 +350,19 @@ class FNO3d(Model):
                 # cell_mix's epilogue and the next W stage / cell_mix / projection read plain activations (one erf per
                 # element instead of two)
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
-                ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, None, d.ncell, C, C,
-                             2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
+                if ws.bf16:
+                    ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d.ncell, C,
+                                      2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
+                else:
+                    ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, None, d.ncell, C, C,
+                                 2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 a_in, xf = s, None
-        ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
-                     xf=xf, act=self.proj_act)
+        if not training and ws.bf16:
+            ops.proj_fwd_bf16(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
+                              act=self.proj_act)
+        else:
+            ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
+                         xf=xf, act=self.proj_act)
         return ws.out
 
     def _backward_impl(self, x, gout, ws, gflat):
@@ -424,7 +451,10 @@ class FNO3d(Model):
     def _lift_fwd(self, x, ws):
         """fno.py:106-111: ws.A0 = pad(fc0(cat(x, grid))), channels-last."""
         grids, _ = self._consts(x.device)
-        ops.lift_pad_fwd(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)
+        if ws.A0.dtype == torch.bfloat16:
+            ops.lift_pad_fwd_bf16(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)
+        else:
+            ops.lift_pad_fwd(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)
 
     def _lift_bwd(self, g, x, ws, gflat):
         """g = dLoss/d(ws.A0) -> d fc0.weight, d fc0.bias."""

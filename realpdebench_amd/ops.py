@@ -65,6 +65,13 @@ def lift_pad_fwd(x, grids, w0, b0, out, d):
               label="lift_pad", nbytes=4 * (d.ncrop * d.Cin + d.ncell * d.C), flops=2 * d.ncrop * d.C * (d.Cin + 3))
 
 
+def lift_pad_fwd_bf16(x, grids, w0, b0, out, d):
+    assert out.dtype == torch.bfloat16
+    _lib.call("rpb_lift_pad_fwd_bf16", _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(w0), _p(b0), _p(out, torch.bfloat16),
+              d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream(),
+              label="lift_pad_bf16", nbytes=4 * d.ncrop * d.Cin + 2 * d.ncell * d.C, flops=2 * d.ncrop * d.C * (d.Cin + 3))
+
+
 def lift_bwd(g, x, grids, part, d):
     _lib.call("rpb_lift_bwd", _p(g), _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(part),
               d.B, d.T, d.H, d.W, d.Cin, d.C, d.Tp, d.Hp, d.Wp, _stream(),
@@ -78,6 +85,22 @@ def axis_gemm(inp, out, Mt, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None, 
     kv = K if k_valid is None else k_valid
     _lib.call("rpb_axis_gemm", _p(inp), _p(out), _p(M), G, K, O, N, in_g, in_k, out_g, out_o, kv, int(accumulate),
               *_xf(xf), _stream(), label=f"axis_gemm[{tag}K{K}xO{O}]", nbytes=4 * G * N * (kv + O), flops=2 * G * N * kv * O)
+
+
+def axis_gemm_bf16in(inp, out, Mt, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None):
+    """The forward W stage reading bf16-stored activations (strides in bf16 elements); spectra stay fp32."""
+    assert tuple(Mt.shape) == (K, O) and inp.dtype == torch.bfloat16
+    kv = K if k_valid is None else k_valid
+    _lib.call("rpb_axis_gemm_bf16in", _p(inp, torch.bfloat16), _p(out), _p(Mt), G, K, O, N, in_g, in_k, out_g, out_o, kv, _stream(),
+              label=f"axis_gemm_bf16in[K{K}xO{O}]", nbytes=G * N * (2 * kv + 4 * O), flops=2 * G * N * kv * O)
+
+
+def cell_mix_bf16(x, Wm, bias, z2, GW, out, ncell, C, K2, Wp, oxf=None):
+    """Eval cell_mix on bf16-stored activations: x, out bf16 ``[ncell][C]``; ``oxf`` = (mean, invstd, gamma, beta, gelu)."""
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    _lib.call("rpb_cell_mix_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, torch.bfloat16), ncell, C, K2, Wp,
+              *_xf(oxf), _stream(), label="cell_mix_bf16", nbytes=4 * ncell * C + 4 * (ncell // Wp) * K2 * C,
+              flops=2 * ncell * C * (K2 + C))
 
 
 def mode_contract_fwd(X, W, Y, B, M, C):
@@ -200,6 +223,12 @@ def proj_fwd(a, w1, b1, w2, b2, out, d, DO, xf=None, act=0):
     _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, *_xf(xf),
               int(act), _stream(),
               label="proj_fwd", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
+
+
+def proj_fwd_bf16(a, w1, b1, w2, b2, out, d, DO, act=0):
+    assert a.dtype == torch.bfloat16
+    _lib.call("rpb_proj_fwd_bf16", _p(a, torch.bfloat16), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6,
+              int(act), _stream(), label="proj_fwd_bf16", nbytes=d.ncrop * (2 * d.C + 4 * DO), flops=2 * d.ncrop * 128 * (d.C + DO))
 
 
 def proj_bwd(a, w1, b1, w2, b2, gout, gu, part, d, DO, xf=None, act=0):

@@ -454,3 +454,66 @@ def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2):
             assert rel_l2(tot[0], gz.sum(0)) < 2e-5 and rel_l2(tot[1], (gz * sh).sum(0)) < 2e-5
     ops.cell_mix(dev(g), dev(Wc), None, dev(z2), dev(GW.t()), out, None, ncell, C, C, K2, Wp, transpose_w=True)
     assert rel_l2(out.cpu(), spec + g @ Wc) < 2e-6
+
+
+def _bf16_ulps(a, b):
+    """|a - b| in units of the bf16 spacing at |b| (both bf16 tensors)."""
+    a, b = a.float(), b.float()
+    ulp = torch.clamp(b.abs(), min=1e-30).log2().floor().exp2() * 2.0 ** -7
+    return (a - b).abs() / ulp
+
+
+@pytest.mark.parametrize("Wp,rows,K2", [(70, 9, 32), (134, 3, 24)])
+def test_bf16_storage_kernels(ops, Wp, rows, K2):
+    """BASELINE.json configs[4] activation storage: lift / W stage / cell_mix / projection with bf16 activations are the fp32-grade
+    computation on the (exactly representable) bf16 inputs, rounded once to nearest even on store: against fp64 on the same
+    bf16 inputs the stored bf16 values differ by at most one unit in the last place, and fp32 outputs hold 2e-6."""
+    torch.manual_seed(Wp + K2)
+    C = 64
+    ncell = rows * Wp
+    f8 = dict(dtype=torch.float64)
+    xb = (torch.randn(ncell, C) * 1.3).to(torch.bfloat16)
+    x8 = xb.double()
+    # ---- W stage, bf16 in
+    M = torch.randn(32, Wp, **f8)
+    out = torch.full((rows, 32, C), float("nan"), device="cuda")
+    ops.axis_gemm_bf16in(xb.cuda(), out, dev(M.t()), rows, Wp, 32, C, Wp * C, C, 32 * C, C)
+    assert rel_l2(out.cpu(), torch.einsum("ok,gkn->gon", M, x8.view(rows, Wp, C))) < TOL
+    ops.axis_gemm_bf16in(xb.cuda(), out, dev(M.t()), rows, Wp, 32, C, Wp * C, C, 32 * C, C, k_valid=Wp - 6)
+    xx = x8.view(rows, Wp, C).clone()
+    xx[:, Wp - 6:] = 0
+    assert rel_l2(out.cpu(), torch.einsum("ok,gkn->gon", M, xx)) < TOL
+    # ---- cell_mix, bf16 in / out, eval output transform
+    Wc, bias = torch.randn(C, C, **f8) / 8, torch.randn(C, **f8)
+    z2, GW = torch.randn(rows, K2, C, **f8), torch.randn(Wp, K2, **f8)
+    om, oi = torch.randn(C, **f8) * 0.1, torch.rand(C, **f8) + 0.5
+    og, ob = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.2
+    for gelu in (True, False):
+        ref = _xf_ref(torch.einsum("wk,gkc->gwc", GW, z2).reshape(ncell, C) + x8 @ Wc.t() + bias, om, oi, og, ob, gelu)
+        o = torch.zeros(ncell, C, device="cuda", dtype=torch.bfloat16)
+        ops.cell_mix_bf16(xb.cuda(), dev(Wc), dev(bias), dev(z2), dev(GW.t()), o, ncell, C, K2, Wp,
+                          oxf=(dev(om), dev(oi), dev(og), dev(ob), gelu))
+        # one bf16 unit in the last place, plus the fp32-level error of the O(1) sums for results that cancel to ~0
+        refb = ref.to(torch.bfloat16)
+        excess = (o.cpu().float() - refb.float()).abs() - 1e-5
+        u = excess / (torch.clamp(refb.float().abs(), min=1e-30).log2().floor().exp2() * 2.0 ** -7)
+        assert float(u.max()) <= 1.0 and float(((o.cpu() != refb) & (excess > 0)).float().mean()) < 0.02   # boundary cases only
+        assert rel_l2(o.cpu().double(), ref) < 4e-3
+    # ---- lift, bf16 out == round(fp32 lift)
+    B, T, H, W, pad, Cin = 2, 3, 5, 34, 2, 3
+    d = ops.Dims(B, T, H, W, Cin, C, pad)
+    xin = torch.randn(B, T, H, W, Cin, device="cuda")
+    grids = [torch.linspace(0, 1, n, device="cuda") for n in (T, H, W)]
+    w0, b0 = torch.randn(C, Cin + 3, device="cuda"), torch.randn(C, device="cuda")
+    a32 = torch.empty(d.ncell, C, device="cuda")
+    a16 = torch.empty(d.ncell, C, device="cuda", dtype=torch.bfloat16)
+    ops.lift_pad_fwd(xin, grids, w0, b0, a32, d)
+    ops.lift_pad_fwd_bf16(xin, grids, w0, b0, a16, d)
+    assert torch.equal(a16, a32.to(torch.bfloat16))
+    # ---- projection, bf16 in == fp32 projection of the widened input
+    w1, b1 = torch.randn(128, C, device="cuda") / 8, torch.randn(128, device="cuda")
+    w2, b2 = torch.randn(2, 128, device="cuda") / 11, torch.randn(2, device="cuda")
+    o32, o16 = torch.empty(d.ncrop, 2, device="cuda"), torch.empty(d.ncrop, 2, device="cuda")
+    ops.proj_fwd(a16.float(), w1, b1, w2, b2, o32, d, 2)
+    ops.proj_fwd_bf16(a16, w1, b1, w2, b2, o16, d, 2)
+    assert torch.equal(o16, o32)
