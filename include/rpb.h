@@ -337,6 +337,20 @@ int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, co
 int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
                       long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, int act, void* stream);
 
+/* ---- data-parallel gradient exchange: RCCL all-reduce over xGMI on a side HIP stream (the reference is
+ *      single-process, realpdebench/train.py:63).  rank 0 creates 128 opaque bytes with rpb_dp_unique_id and the launcher hands them to
+ *      every rank; _init builds the communicator on the CURRENT device plus a side stream; _enqueue sums `buf` in place across ranks
+ *      (dtype 0 = fp32, 1 = fp64) once everything queued on producer_stream so far has run, and returns immediately; _wait makes
+ *      consumer_stream wait for every bucket enqueued so far; _inline runs the reduction on the given stream (SyncBN statistics).
+ *      rpb_dp_available() == 0 when no librccl.so can be loaded (everything else in this header still works). */
+int rpb_dp_available(void);
+int rpb_dp_unique_id(void* id128);
+int rpb_dp_allreduce_init(const void* id128, int rank, int world, void** handle);
+int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream);
+int rpb_dp_allreduce_wait(void* handle, void* consumer_stream);
+int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream);
+int rpb_dp_allreduce_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,13 @@ SIGNATURES = {
     "rpb_axis_gemm_bf16in": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),
     "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
     "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
+    "rpb_dp_available": (_I, ""),
+    "rpb_dp_unique_id": (_I, "p"),
+    "rpb_dp_allreduce_init": (_I, "piip"),
+    "rpb_dp_allreduce_enqueue": (_I, "pplip"),
+    "rpb_dp_allreduce_wait": (_I, "pp"),
+    "rpb_dp_allreduce_inline": (_I, "pplip"),
+    "rpb_dp_allreduce_destroy": (_I, "p"),
     "rpb_lift_bwd_rows": (_I, ""),
     "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "ppppi" + "p"),

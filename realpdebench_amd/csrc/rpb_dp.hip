@@ -1,0 +1,158 @@
+// Data-parallel gradient exchange behind the C ABI: RCCL all-reduce over xGMI on a SIDE HIP stream, ordered against the
+// compute stream with events -- SURVEY.md section 8(b)/(e).  The reference has no distributed path at all (single process,
+// realpdebench/train.py:63); this is the collective a maintainer binds next to the kernels:
+//
+//   rank 0: rpb_dp_unique_id(id)            -> 128 opaque bytes, handed to every rank by whatever launcher is in use
+//   all   : rpb_dp_allreduce_init(id, rank, world, &h)       (communicator on the CURRENT device, side stream, events)
+//   per bucket, from inside the backward pass:
+//           rpb_dp_allreduce_enqueue(h, buf, count, dtype, producer_stream)
+//              the side stream waits for everything enqueued on producer_stream so far, then sums `buf` in place across
+//              ranks; the call returns immediately and the producer stream keeps running backward kernels meanwhile
+//   before the optimizer:
+//           rpb_dp_allreduce_wait(h, consumer_stream)        (consumer_stream waits for every bucket enqueued so far)
+//   small synchronous reductions (SyncBN statistics): rpb_dp_allreduce_inline(h, buf, count, dtype, stream)
+//
+// RCCL is resolved at run time (dlopen of the librccl already loaded into the process -- PyTorch-ROCm brings one -- else the
+// system one), so librpb_hip.so itself loads on hosts without RCCL and two RCCL copies never coexist in one process.
+#include "rpb_common.h"
+#include <dlfcn.h>
+
+namespace {
+typedef struct {
+    char internal[128];
+} nccl_uid_t;
+typedef void* nccl_comm_t;
+typedef int (*fn_get_uid)(nccl_uid_t*);
+typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_uid_t, int);
+typedef int (*fn_destroy)(nccl_comm_t);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+
+struct Rccl {
+    void* lib = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allreduce allreduce = nullptr;
+    fn_errstr errstr = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)                      // the copy already mapped into the process, if any
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) {
+            r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
+            r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
+            r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
+            r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
+            r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
+        }
+    }
+    return (r.lib && r.get_uid && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
+}
+
+struct DpHandle {
+    nccl_comm_t comm;
+    hipStream_t side;
+    hipEvent_t ready, done;
+    int rank, world;
+    long enqueued;
+};
+
+const int kNcclSum = 0, kNcclF32 = 7, kNcclF64 = 8;
+}  // namespace
+
+#define RPB_NCCL(call, what)                                                                                  \
+    do {                                                                                                      \
+        int rc_ = (call);                                                                                     \
+        if (rc_ != 0) RPB_FAIL(RPB_ERR_LAUNCH, "%s: RCCL error %d (%s)", what, rc_, R->errstr ? R->errstr(rc_) : "?"); \
+    } while (0)
+#define RPB_HIP(call, what)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) RPB_FAIL(RPB_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_));     \
+    } while (0)
+
+extern "C" int rpb_dp_available(void) { return rccl() != nullptr; }
+
+extern "C" int rpb_dp_unique_id(void* id128) {
+    RPB_REQUIRE(id128, "dp_unique_id: null pointer");
+    Rccl* R = rccl();
+    if (!R) RPB_FAIL(RPB_ERR_UNSUPPORTED, "dp: librccl.so could not be loaded");
+    nccl_uid_t id;
+    RPB_NCCL(R->get_uid(&id), "ncclGetUniqueId");
+    memcpy(id128, &id, sizeof(id));
+    return RPB_OK;
+}
+
+extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, void** handle) {
+    RPB_REQUIRE(id128 && handle && world >= 1 && rank >= 0 && rank < world, "dp_allreduce_init: bad arguments (rank %d of %d)", rank, world);
+    Rccl* R = rccl();
+    if (!R) RPB_FAIL(RPB_ERR_UNSUPPORTED, "dp: librccl.so could not be loaded");
+    DpHandle* h = new DpHandle();
+    h->rank = rank;
+    h->world = world;
+    h->enqueued = 0;
+    nccl_uid_t id;
+    memcpy(&id, id128, sizeof(id));
+    int rc = R->init_rank(&h->comm, world, id, rank);
+    if (rc != 0) {
+        delete h;
+        RPB_FAIL(RPB_ERR_LAUNCH, "ncclCommInitRank: RCCL error %d (%s)", rc, R->errstr ? R->errstr(rc) : "?");
+    }
+    RPB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), "dp side stream");
+    RPB_HIP(hipEventCreateWithFlags(&h->ready, hipEventDisableTiming), "dp event");
+    RPB_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming), "dp event");
+    *handle = h;
+    return RPB_OK;
+}
+
+static int dp_dtype(int dtype) { return dtype == 0 ? kNcclF32 : (dtype == 1 ? kNcclF64 : -1); }
+
+extern "C" int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream) {
+    RPB_REQUIRE(handle && buf && count > 0 && dp_dtype(dtype) >= 0, "dp_allreduce_enqueue: bad arguments");
+    Rccl* R = rccl();
+    DpHandle* h = (DpHandle*)handle;
+    RPB_HIP(hipEventRecord(h->ready, (hipStream_t)producer_stream), "dp record");
+    RPB_HIP(hipStreamWaitEvent(h->side, h->ready, 0), "dp wait");
+    RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, h->side), "ncclAllReduce");
+    h->enqueued++;
+    return RPB_OK;
+}
+
+extern "C" int rpb_dp_allreduce_wait(void* handle, void* consumer_stream) {
+    RPB_REQUIRE(handle, "dp_allreduce_wait: null handle");
+    DpHandle* h = (DpHandle*)handle;
+    RPB_HIP(hipEventRecord(h->done, h->side), "dp record");
+    RPB_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, h->done, 0), "dp wait");
+    return RPB_OK;
+}
+
+extern "C" int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream) {
+    RPB_REQUIRE(handle && buf && count > 0 && dp_dtype(dtype) >= 0, "dp_allreduce_inline: bad arguments");
+    Rccl* R = rccl();
+    DpHandle* h = (DpHandle*)handle;
+    RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, (hipStream_t)stream), "ncclAllReduce");
+    return RPB_OK;
+}
+
+extern "C" int rpb_dp_allreduce_destroy(void* handle) {
+    if (!handle) return RPB_OK;
+    Rccl* R = rccl();
+    DpHandle* h = (DpHandle*)handle;
+    (void)hipStreamSynchronize(h->side);
+    if (R) (void)R->destroy(h->comm);
+    (void)hipEventDestroy(h->ready);
+    (void)hipEventDestroy(h->done);
+    (void)hipStreamDestroy(h->side);
+    delete h;
+    return RPB_OK;
+}

@@ -14,7 +14,69 @@ The reference has no distributed path at all (single process, realpdebench/train
 
 Everything here works on CPU tensors with the gloo backend too (tests/test_dp_gloo.py).
 """
+import ctypes
+import os
+
+import torch
 import torch.distributed as dist
+
+
+class RcclComm:
+    """The C-ABI collective (include/rpb.h ``rpb_dp_*``: RCCL all-reduce on a side HIP stream) for CUDA tensors.
+
+    ``torch.distributed`` is only the launcher's rendezvous here: it carries the 128-byte RCCL unique id from rank 0 to the
+    others; the gradient traffic itself goes librpb_hip.so -> librccl.so -> xGMI."""
+
+    def __init__(self, process_group=None):
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        self.rank, self.world_size = dist.get_rank(process_group), dist.get_world_size(process_group)
+        buf = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            _lib.call("rpb_dp_unique_id", ctypes.addressof(buf))
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=0, group=process_group)
+        idbuf = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        _lib.call("rpb_dp_allreduce_init", ctypes.addressof(idbuf), self.rank, self.world_size, ctypes.addressof(h))
+        self.handle = h.value
+        self._lib_obj = lib
+
+    @staticmethod
+    def _dtype(t):
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.float64:
+            return 1
+        raise TypeError(f"rpb_dp all-reduce: fp32 / fp64 only, got {t.dtype}")
+
+    def enqueue(self, t):
+        """Sum ``t`` (contiguous CUDA tensor / slice) in place across ranks on the side stream, after the work queued so far."""
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.call("rpb_dp_allreduce_enqueue", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
+                       torch.cuda.current_stream().cuda_stream)
+
+    def wait(self):
+        self._lib.call("rpb_dp_allreduce_wait", self.handle, torch.cuda.current_stream().cuda_stream)
+
+    def inline(self, t):
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.call("rpb_dp_allreduce_inline", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
+                       torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if self.handle:
+            self._lib.call("rpb_dp_allreduce_destroy", self.handle)
+            self.handle = None
+
+
+def use_rccl_abi(t=None):
+    """The C-ABI RCCL path serves CUDA tensors under the nccl backend; gloo groups (CPU tests, ranks sharing one GPU) and
+    RPB_DP_TORCH=1 keep ``torch.distributed`` collectives."""
+    if os.environ.get("RPB_DP_TORCH") == "1" or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return False
+    return t is None or t.is_cuda
 
 
 def layer_buckets(seg, n_layers, total):
@@ -37,13 +99,17 @@ class StatsSync:
     Transformer: its spectral regressor is an FNO block with a training-mode BatchNorm3d, galerkin_transformer_libs/
     model.py:572,622): global-batch statistics forward and backward, no gradient buckets."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, comm=None):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        self.comm = comm
 
     def all_reduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.comm is not None and t.is_cuda:
+            self.comm.inline(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def bucket_ready(self, grad):
         pass
@@ -60,6 +126,7 @@ class DataParallel:
         self.buckets = layer_buckets(model._seg, model.n_layers, model.flat.numel())
         self._works = []
         self._next = 0
+        self.comm = RcclComm(process_group) if use_rccl_abi(model.flat) else None      # C-ABI RCCL on a side stream
         model.dp = self
         self.sync_parameters()
 
@@ -71,7 +138,10 @@ class DataParallel:
 
     # ---- small synchronous reductions (SyncBN statistics)
     def all_reduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.comm is not None and t.is_cuda:
+            self.comm.inline(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- bucketed, overlapped gradient reduction
     def begin_step(self, grad):
@@ -81,11 +151,16 @@ class DataParallel:
         """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete."""
         s, e = self.buckets[self._next]
         self._next += 1
-        self._works.append(dist.all_reduce(grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.comm is not None and grad.is_cuda:
+            self.comm.enqueue(grad[s:e])               # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
+        else:
+            self._works.append(dist.all_reduce(grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish_step(self, grad):
         while self._next < len(self.buckets):          # anything the backward pass did not announce
             self.bucket_ready(grad)
+        if self.comm is not None and grad.is_cuda:
+            self.comm.wait()                           # the compute stream (Adam next) waits for every bucket
         for w in self._works:
             w.wait()
         self._works = []

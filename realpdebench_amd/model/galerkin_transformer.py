@@ -364,6 +364,9 @@ class GalerkinTransformer3d(_ModelBase):
         gflat = torch.zeros_like(reg.flat)
         reg._backward_impl(sv["X2"], reg._unshape_grad(g_out, B), ws, gflat)
         grads[reg.flat] = gflat
+        early = getattr(self, "_dp_early", None)
+        if early is not None:              # data parallel: the 99 % of the gradient bytes that are final already start their RCCL
+            early(reg.flat, gflat)         # all-reduce on the side stream and overlap the encoder's backward below
         g = ws.gx                                                     # dLoss/dX2
         # ---- FeedForward
         g2 = self._through_dropout(g, self._site(mk, "d2"), M * C)

@@ -72,65 +72,167 @@ class Trainer:
         return ck
 
 
-class ProtocolTrainer:
-    """The reference's loop body verbatim in structure (train.py:323-334) for models without a flat arena
-    (Transolver, Galerkin Transformer): ``zero_grad``; ``train_loss(...).mean().backward()`` runs the HIP forward/backward through the model's
-    autograd Function; Adam + LR schedule are ``torch.optim`` (4 M parameters: off the critical path).  Under data
-    parallelism the gradients are averaged with one RCCL all-reduce per parameter after backward."""
+class ArenaTrainer:
+    """Training step for the models whose parameters are ordinary ``nn.Parameter`` tensors (Transolver, Galerkin Transformer,
+    U-Net) -- the reference's loop body (train.py:323-334) with the optimizer and the gradient exchange on the arena design
+    of the FNO trainer:
 
-    def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0, dp_group=None):
-        self.model = model
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr)
-        if scheduler == "step":
-            self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=step_size, gamma=0.5)
-        elif scheduler == "cosine":
-            self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=num_update)
-        else:
+    * every parameter is re-homed into ONE flat fp32 arena (``p.data`` becomes a view; ``state_dict`` / checkpoints are
+      unchanged), gradients and the two Adam moments are arenas of the same layout, so Adam is ONE ``rpb_adam_step`` launch
+      (torch.optim.Adam semantics: defaults, complex weights as 2 x fp32, parameters without a gradient are left alone
+      because a zero gradient moves nothing) and the LR schedule is the closed form of CosineAnnealingLR / StepLR;
+    * ``train_loss(...).mean().backward()`` runs the model's HIP forward / backward through its autograd Function;
+    * data parallel: gradients are summed over ranks in a few large contiguous buckets by RCCL on a side HIP stream
+      (``rpb_dp_allreduce_*``).  A model may announce a finished gradient from INSIDE its backward pass through
+      ``model._dp_early(param, grad)`` -- the Galerkin Transformer does so for its 670 MB spectral regressor, whose
+      all-reduce then overlaps the rest of the backward; the remaining buckets go out right after backward and Adam waits.
+      The sum is turned into the mean inside the Adam kernel (``gscale = 1 / world``).
+    """
+
+    BUCKET_ELEMS = 16 * 1024 * 1024          # 64 MB buckets: large enough for xGMI ring bandwidth, several in flight
+
+    def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, betas=(0.9, 0.999), eps=1e-8,
+                 clip_grad_norm=0.0, dp_group=None):
+        if scheduler not in ("cosine", "step"):
             raise ValueError(f"Scheduler {scheduler} not supported")
-        self.clip = float(clip_grad_norm or 0.0)
+        self.model = model
+        self.lr0, self.num_update, self.scheduler, self.step_size = float(lr), int(num_update), scheduler, int(step_size)
+        self.betas, self.eps, self.clip = betas, eps, float(clip_grad_norm or 0.0)
         self.iteration = 0
-        self.world = 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if any(p.dtype != torch.float32 for p in self.params):
+            raise TypeError("ArenaTrainer: fp32 parameters only")
+        dev = self.params[0].device
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 63) // 64 * 64                     # 256 B-aligned segments
+        self.offsets, self.total = offs, off
+        self.flat = torch.zeros(off, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat[o:o + p.numel()].view(p.shape)   # the parameter now LIVES in the arena
+        self.grad = torch.zeros_like(self.flat)
+        self.gviews = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)]
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        # ---- data parallel
+        self.world, self.comm, self.group = 1, None, dp_group
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(dp_group)
-            for p in list(model.parameters()) + list(model.buffers()):   # one init for everyone, like the single-process reference
-                torch.distributed.broadcast(p.data, src=0, group=dp_group)
+        if self.world > 1:
+            from .dp import RcclComm, StatsSync, use_rccl_abi
+            torch.distributed.broadcast(self.flat, src=0, group=dp_group)      # one init for everyone, like the reference
+            for b in model.buffers():
+                torch.distributed.broadcast(b.data, src=0, group=dp_group)
+            if use_rccl_abi(self.flat):
+                self.comm = RcclComm(dp_group)
             core = getattr(model, "regressor", None)
-            if core is not None and hasattr(core, "dp") and self.world > 1:
-                from .dp import StatsSync
-                core.dp = StatsSync(dp_group)                    # BatchNorm3d over the global batch (SyncBN)
-        self.group = dp_group
+            if core is not None and hasattr(core, "dp"):
+                core.dp = StatsSync(dp_group, comm=self.comm)       # BatchNorm3d over the global batch (SyncBN)
+        self._early = {}            # param -> its gradient tensor, all-reduce already in flight
+        self._works = []
 
     def current_lr(self):
-        return self.opt.param_groups[0]["lr"]
+        k = self.iteration
+        if self.scheduler == "cosine":
+            return self.lr0 * (1.0 + math.cos(math.pi * k / self.num_update)) / 2.0
+        return self.lr0 * (0.5 ** (k // self.step_size))
+
+    # ---- gradient exchange
+    def _reduce(self, t):
+        if self.comm is not None:
+            self.comm.enqueue(t)
+        else:
+            self._works.append(torch.distributed.all_reduce(t, group=self.group, async_op=True))
+
+    def _dp_early(self, param, grad):
+        """Called by a model from inside its backward pass: ``grad`` (the final gradient of ``param``) starts its all-reduce now."""
+        if self.world > 1 and grad.is_contiguous():
+            self._reduce(grad.view(-1))
+            self._early[param] = grad
 
     def step(self, input, target):
-        self.model.train()
-        self.opt.zero_grad()
-        loss = self.model.train_loss(input, target).mean()
+        model = self.model
+        model.train()
+        for p in self.params:
+            p.grad = None
+        self._early, self._works = {}, []
+        model._dp_early = self._dp_early if self.world > 1 else None
+        loss = model.train_loss(input, target).mean()
         loss.backward()
+        model._dp_early = None
+        # ---- gradients -> arena (storage plumbing; parameters the loss does not reach keep a zero gradient)
+        late_dst, late_src, early = [], [], []
+        for p, gv in zip(self.params, self.gviews):
+            if p.grad is None:
+                gv.zero_()
+            elif p in self._early:
+                early.append((gv, p.grad))
+            else:
+                late_dst.append(gv)
+                late_src.append(p.grad)
+        if late_dst:
+            torch._foreach_copy_(late_dst, late_src)
         if self.world > 1:
-            works = [torch.distributed.all_reduce(p.grad, group=self.group, async_op=True)
-                     for p in self.model.parameters() if p.grad is not None]
-            for w in works:
+            # everything not announced early: contiguous runs of the arena, cut into large buckets
+            runs, start = [], None
+            for p, o in zip(self.params, self.offsets):
+                if p in self._early:
+                    if start is not None:
+                        runs.append((start, o))
+                        start = None
+                elif start is None:
+                    start = o
+            if start is not None:
+                runs.append((start, self.total))
+            for s0, e0 in runs:
+                for b0 in range(s0, e0, self.BUCKET_ELEMS):
+                    self._reduce(self.grad[b0:min(e0, b0 + self.BUCKET_ELEMS)])
+            if self.comm is not None:
+                self.comm.wait()
+            for w in self._works:
                 w.wait()
-            for p in self.model.parameters():
-                if p.grad is not None:
-                    p.grad.div_(self.world)
-        if self.clip > 0:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
-        self.opt.step()
-        self.sched.step()
+            for gv, g in early:            # reduced in place where the backward pass left them; now into the arena
+                gv.copy_(g)
+        elif early:
+            for gv, g in early:
+                gv.copy_(g)
+        for p in self.params:
+            p.grad = None
+        gscale = 1.0 / self.world
+        if self.clip > 0:                                            # train.py:330-331 (unused by the shipped YAMLs: one sync)
+            norm = float(torch.linalg.vector_norm(self.grad)) * gscale
+            gscale *= min(1.0, self.clip / (norm + 1e-6))
+        lr = self.current_lr()
         self.iteration += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.total, lr, self.betas[0], self.betas[1],
+                      self.eps, self.iteration, gscale)
+        # the kernel wrote the arena through raw pointers: tell autograd's version counters, which the models' caches of
+        # re-laid-out / split weights are keyed on (an in-place torch op would have done this)
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
         return loss.detach().reshape(1)
+
+    def mean_grads(self):
+        """{parameter: gradient of the last step averaged over ranks} -- views of the gradient arena (tests, diagnostics)."""
+        return {p: gv / self.world for p, gv in zip(self.params, self.gviews)}
+
+    def checkpoint(self, extra=None):
+        ck = {"model_state_dict": self.model.state_dict(), "iteration": self.iteration}
+        if extra:
+            ck.update(extra)
+        return ck
 
 
 def make_trainer(model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0):
-    """Fused arena trainer for FNO3d, protocol trainer for everything else."""
+    """Fused trainer for FNO3d (one flat arena built into the model), ArenaTrainer for the nn.Parameter models."""
     if hasattr(model, "flat"):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and model.dp is None:
             from .dp import DataParallel
             DataParallel(model)
         return Trainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
                        clip_grad_norm=clip_grad_norm)
-    return ProtocolTrainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
-                           clip_grad_norm=clip_grad_norm)
+    return ArenaTrainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
+                        clip_grad_norm=clip_grad_norm)

@@ -1,0 +1,95 @@
+"""The C-ABI collective (include/rpb.h rpb_dp_*: RCCL all-reduce on a side HIP stream) called through ctypes, as a maintainer's
+binding would: a one-rank communicator on the 1-GPU box (plumbing, stream / event ordering, both dtypes) and -- when the node
+has two GPUs -- a two-rank sum over xGMI with one process per GPU."""
+import ctypes
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from realpdebench_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def _comm(id_bytes, rank, world):
+    L = _lib()
+    buf = (ctypes.c_char * 128).from_buffer_copy(id_bytes)
+    h = ctypes.c_void_p()
+    L.call("rpb_dp_allreduce_init", ctypes.addressof(buf), rank, world, ctypes.addressof(h))
+    return h.value
+
+
+def _unique_id():
+    L = _lib()
+    buf = (ctypes.c_char * 128)()
+    L.call("rpb_dp_unique_id", ctypes.addressof(buf))
+    return bytes(buf)
+
+
+def test_single_rank_communicator_orders_against_the_compute_stream():
+    L = _lib()
+    assert L.load().rpb_dp_available() == 1
+    torch.cuda.set_device(0)
+    h = _comm(_unique_id(), 0, 1)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        a = torch.randn(4096, 4096, device="cuda")
+        for _ in range(4):
+            a = torch.tanh(a @ a * 1e-3)                       # milliseconds of queued work the side stream must wait for
+        want = a.clone()
+        g = a.view(-1)
+        L.call("rpb_dp_allreduce_enqueue", h, g.data_ptr(), g.numel(), 0, st)          # sum over one rank = identity
+        L.call("rpb_dp_allreduce_enqueue", h, g[:1000].data_ptr(), 1000, 0, st)        # a second bucket behind it
+        L.call("rpb_dp_allreduce_wait", h, st)
+        b = a * 2.0                                            # consumer on the compute stream
+        d = torch.arange(7, device="cuda", dtype=torch.float64)
+        L.call("rpb_dp_allreduce_inline", h, d.data_ptr(), d.numel(), 1, st)           # fp64, on the compute stream itself
+        torch.cuda.synchronize()
+        assert torch.equal(a, want) and torch.equal(b, want * 2.0)
+        assert torch.equal(d.cpu(), torch.arange(7, dtype=torch.float64))
+        with pytest.raises(L.RpbError):
+            L.call("rpb_dp_allreduce_enqueue", h, g.data_ptr(), g.numel(), 5, st)      # unknown dtype code
+    finally:
+        L.call("rpb_dp_allreduce_destroy", h)
+
+
+def _two_rank_worker(rank, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=2)              # rendezvous only: carries the RCCL id
+    try:
+        box = [_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        L = _lib()
+        h = _comm(box[0], rank, 2)
+        st = torch.cuda.current_stream().cuda_stream
+        g = torch.full((1 << 20,), float(rank + 1), device="cuda") * torch.arange(1 << 20, device="cuda").remainder(7).float()
+        L.call("rpb_dp_allreduce_enqueue", h, g.data_ptr(), g.numel(), 0, st)
+        L.call("rpb_dp_allreduce_wait", h, st)
+        torch.cuda.synchronize()
+        out[rank] = g.cpu()
+        L.call("rpb_dp_allreduce_destroy", h)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two-rank RCCL needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_sum_over_xgmi():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_two_rank_worker, args=(port, out), nprocs=2, join=True)
+        res = {k: v for k, v in out.items()}
+    want = 3.0 * torch.arange(1 << 20).remainder(7).float()
+    assert torch.equal(res[0], want) and torch.equal(res[1], want)
