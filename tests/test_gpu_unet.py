@@ -95,6 +95,46 @@ def test_temporal_attention_kernel(ops):
     assert rel_l2(db, bias.grad) < 2e-5
 
 
+def test_temporal_attention_rotary_known_answers(ops):
+    """The rotary embedding inside rpb_tattn_fwd against the published algorithm stated with complex arithmetic (pair j =
+    x[2j] + i x[2j+1], times exp(i p theta^(-2j/32))) and against hand-computed attention weights -- independent of
+    oracle/unet_oracle.py, whose restatement the kernel otherwise shares (parity unpinned by the reference: third-party source)."""
+    import math
+    from realpdebench_amd.model.unet import _rotary_tables
+    torch.manual_seed(5)
+    B, T, HW, d = 1, 3, 2, 32
+    freqs = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    rc, rs = _rotary_tables(freqs.cuda(), T)
+    # (1) hand numbers: head 0, q = e_0 at every position, k = e_1 (same PAIR, other component), v = one-hot per position:
+    #     score[t][s] = 32^-1/2 * Re[(1 e^{it}) conj(i e^{is})] = 32^-1/2 * sin(t - s); a half-split pairing would give 0
+    qkv = torch.zeros(B, T, HW, 384)
+    qkv[..., 0] = 1.0                       # q, head 0, feature 0
+    qkv[..., 128 + 1] = 1.0                 # k, head 0, feature 1
+    for t in range(T):
+        qkv[:, t, :, 256 + t] = 1.0         # v, head 0: position t -> feature t
+    out = torch.empty(B * T * HW, 128, device="cuda")
+    ops.tattn_fwd(qkv.cuda().view(-1, 384), rc, rs, torch.zeros(4, T, T, device="cuda"), out, B, T, HW)
+    got = out.view(B, T, HW, 128)[0, :, 0, :T].cpu().double()          # softmax weights P[t][s] of head 0
+    S = torch.tensor([[math.sin(t - s) for s in range(T)] for t in range(T)], dtype=torch.float64) / math.sqrt(32)
+    assert torch.allclose(got, S.softmax(-1), atol=2e-6)
+    assert abs(float(got[0, 1]) - math.exp(-0.8414709848078965 / math.sqrt(32)) /
+               (1 + math.exp(-0.8414709848078965 / math.sqrt(32)) + math.exp(-0.9092974268256817 / math.sqrt(32)))) < 2e-6
+    # (2) random data against the complex-multiplication form
+    def rot(t):
+        z = torch.view_as_complex(t.double().reshape(*t.shape[:-1], d // 2, 2).contiguous())
+        ang = torch.arange(t.shape[-2], dtype=torch.float64)[:, None] * freqs.double()[None, :]
+        return torch.view_as_real(z * torch.polar(torch.ones_like(ang), ang)).reshape(t.shape)
+    B, T, HW = 2, 6, 5
+    rc, rs = _rotary_tables(freqs.cuda(), T)
+    qkv = torch.randn(B, T, HW, 384, dtype=torch.float64)
+    bias = torch.randn(4, T, T, dtype=torch.float64)
+    q, k, v = (t.reshape(B, HW, T, 4, 32).transpose(-2, -3) for t in qkv.permute(0, 2, 1, 3).chunk(3, dim=-1))
+    o = ((rot(q * 32 ** -0.5) @ rot(k).transpose(-1, -2) + bias).softmax(-1) @ v).transpose(-2, -3).reshape(B, HW, T, 128)
+    out = torch.empty(B * T * HW, 128, device="cuda")
+    ops.tattn_fwd(dev(qkv).view(-1, 384), rc, rs, dev(bias), out, B, T, HW)
+    assert rel_l2(out.cpu(), o.permute(0, 2, 1, 3).reshape(-1, 128)) < 1e-5
+
+
 @pytest.mark.parametrize("Fr,n", [(3, 70), (2, 512), (1, 1100)])
 def test_bottleneck_attention_kernels(ops, Fr, n):
     """Flash-style MFMA attention over the h*w tokens of a frame (unet.py:455-457): ragged n, n = one full block of four
@@ -224,3 +264,42 @@ def test_c3_channel_widths_vs_oracle():
     m.eval()
     with torch.no_grad():
         assert rel_l2(m(x.cuda()).cpu(), pred_ref) < 2e-5
+
+
+def test_c3_full_fsi_mesh_one_sample():
+    """BASELINE.json configs[2] / SURVEY.md C3 at its REAL mesh: one 20 x 256 x 256 fsi-shaped sample, dim = H = 256
+    (load_model.py:52) -> 256 / 512 / 1024 channels, 64 x 64 = 4096 bottleneck tokens per frame.  The CPU oracle needs many
+    minutes for this size, so the full mesh is checked through properties: shapes, finiteness, every parameter receives a
+    finite gradient, the step is deterministic, and the loss responds to the target exactly as (pred - target)^2 must.
+    (Parity at these channel widths is checked against the oracle on a reduced mesh above.)  Peak memory ~115 GiB at B = 1."""
+    from realpdebench_amd.model.unet import Unet3d
+    torch.manual_seed(0)
+    m = Unet3d(dim=256, out_channels=3, dim_mults=[1, 2, 4], channels=3, in_time=20, out_time=20).cuda().train()
+    x = torch.randn(1, 20, 256, 256, 3, device="cuda")
+    y = torch.randn(1, 20, 256, 256, 3, device="cuda")
+    torch.cuda.reset_peak_memory_stats()
+    elem = m.train_loss(x, y)
+    assert elem.shape == y.shape
+    loss = elem.mean()
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    g1 = {}
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+            g1[n] = p.grad.clone()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert 60 < peak < 200, peak
+    with torch.no_grad():
+        m.eval()
+        pred = m(x)
+        assert pred.shape == y.shape and bool(torch.isfinite(pred).all())
+        # train_loss is elementwise (pred - target)^2 of the SAME prediction (train and eval forward agree: no dropout, no BN)
+        assert rel_l2(elem.detach(), (pred - y) ** 2) < 1e-4
+    m.train()
+    for p in m.parameters():
+        p.grad = None
+    m.train_loss(x, y).mean().backward()
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.grad, g1[n]), n                # run-to-run deterministic (no atomics in the backward)

@@ -150,3 +150,44 @@ def test_headline_fixture_streams_are_reproducible_here():
     assert np.allclose(checksum(xb), z["b32/x_checksum"], rtol=1e-12, atol=1e-9)
     assert 0.5 < float(z["b32/loss"]) < 2.0 and 0.5 < float(z["b2/loss"]) < 2.0
     assert sum(k.startswith("b2/gnorm/") for k in z.files) == 38          # every FNO3d parameter tensor
+
+
+def _rotary_complex(t, theta=10000.0):
+    """Independent statement of the published rotary algorithm (lucidrains rotary-embedding-torch, RotaryEmbedding(dim),
+    rotate_queries_or_keys): consecutive feature PAIRS (x[2j], x[2j+1]) are the complex numbers x[2j] + i x[2j+1]; position p
+    multiplies pair j by exp(i p theta^(-2j/dim)).  Used only as a checker, written with complex arithmetic on purpose."""
+    n, d = t.shape[-2], t.shape[-1]
+    z = torch.view_as_complex(t.double().reshape(*t.shape[:-1], d // 2, 2).contiguous())
+    freq = theta ** (-torch.arange(0, d, 2, dtype=torch.float64) / d)
+    ang = torch.arange(n, dtype=torch.float64)[:, None] * freq[None, :]
+    return torch.view_as_real(z * torch.polar(torch.ones_like(ang), ang)).reshape(t.shape)
+
+
+def test_unet_rotary_known_answers():
+    """The U-Net's temporal attention depends on the un-vendored rotary_embedding_torch: no reference
+    vector can pin it, so the restatement in oracle/unet_oracle.py is pinned to hand-computed numbers of the published
+    algorithm -- a half-split (GPT-NeoX style) pairing, a transposed sin sign or a wrong frequency ladder all fail here."""
+    from oracle import unet_oracle as UO
+    d = 32
+    freqs = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    assert abs(float(freqs[0]) - 1.0) < 1e-7 and abs(float(freqs[8]) - 0.01) < 1e-9        # theta^(-2j/32): j = 8 -> 10000^-0.5
+    # position 0 is the identity
+    x1 = torch.randn(3, 1, d)
+    assert torch.equal(UO.rotary(x1, freqs), x1)
+    # unit vectors: e_0 and e_1 form pair 0 (frequency 1 rad / position), e_16 and e_17 pair 8 (0.01 rad / position)
+    t = torch.zeros(4, 3, d)                      # 4 probes x positions 0..2
+    t[0, :, 0] = 1.0
+    t[1, :, 1] = 1.0
+    t[2, :, 16] = 1.0
+    t[3, :, 17] = 1.0
+    r = UO.rotary(t, freqs)
+    c1, s1, c2, s2 = 0.5403023058681398, 0.8414709848078965, -0.4161468365471424, 0.9092974268256817   # cos/sin of 1, 2 rad
+    assert torch.allclose(r[0, 1, :2], torch.tensor([c1, s1]), atol=1e-6)                  # (1,0) at position 1
+    assert torch.allclose(r[0, 2, :2], torch.tensor([c2, s2]), atol=1e-6)                  # (1,0) at position 2
+    assert torch.allclose(r[1, 1, :2], torch.tensor([-s1, c1]), atol=1e-6)                 # (0,1) at position 1
+    assert torch.allclose(r[2, 2, 16:18], torch.tensor([0.9998000066665778, 0.019998666693333084]), atol=1e-6)   # 0.02 rad
+    assert torch.allclose(r[3, 1, 16:18], torch.tensor([-0.009999833334166664, 0.9999500004166653]), atol=1e-6)  # 0.01 rad
+    assert float(r[0, :, 2:].abs().max()) == 0.0 and float(r[2, :, :16].abs().max()) == 0.0          # nothing leaks across pairs
+    # and the complex-multiplication statement of the same algorithm on random data
+    x = torch.randn(2, 4, 7, d)
+    assert rel_l2(UO.rotary(x, freqs), _rotary_complex(x)) < 1e-6
