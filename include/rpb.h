@@ -322,6 +322,11 @@ int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, 
 int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n, void* stream);
 int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream);
 
+/* ---- eval_metrics (realpdebench/utils/metrics.py:71-100): |F|^2 of the truncated spectrum corner accumulated by radial bin
+ *      floor(sqrt(i^2+j^2+k^2)) < R.  Y [R][R][R][2][NB] (re, im planes; columns = (channel, sample)), out [R][NB].  The three
+ *      truncated DFT stages in front of it are rpb_axis_gemm launches (realpdebench_amd/metrics.py). */
+int rpb_spectrum_bin(const float* Y, float* out, int R, int NB, void* stream);
+
 /* ---- bf16 ACTIVATION STORAGE for the eval / rollout forward (BASELINE.json configs[4]: FNO3d on the combustion volume, "bf16").
  *      The reference has no reduced-precision path; this variant keeps weights, spectra, accumulation and BatchNorm in fp32 and
  *      stores only the [cells][C] activations between kernels as bf16 (round to nearest even): lift -> W stage -> ... ->

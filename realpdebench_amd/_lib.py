@@ -21,6 +21,7 @@ SIGNATURES = {
     "rpb_axis_gemm_bf16in": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),
     "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
     "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
+    "rpb_spectrum_bin": (_I, "ppiip"),
     "rpb_dp_available": (_I, ""),
     "rpb_dp_unique_id": (_I, "p"),
     "rpb_dp_allreduce_init": (_I, "piip"),

@@ -6,8 +6,9 @@ The reference takes a full ``fftn`` of prediction and target and then walks ``(t
 loop, twice (20 480 iterations each at 20x64x128), on whatever device the tensors live.  Only bins with
 ``floor(sqrt(i^2+j^2+k^2)) < R = min(t,h,w)//2`` are ever accumulated, i.e. the corner ``i,j,k < R`` of the spectrum, so
 here the corner is computed directly as a truncated DFT -- three small dense GEMMs with precomputed twiddle matrices
-(the same idea as the FNO spectral layer, csrc/rpb_axis_gemm.hip) -- and binned with one more GEMM against a 0/1
-``[R, R^3]`` matrix.  The transform is linear, so the error spectrum is the spectrum of ``pred - target``.  Everything
+(the same idea as the FNO spectral layer) and binned radially.  On the GPU the three stages ARE the FNO kernels
+(``rpb_axis_gemm`` over a batch-innermost layout) followed by ``rpb_spectrum_bin`` (csrc/rpb_metrics.hip); on CPU tensors the
+same algorithm runs as three einsums and a 0/1 ``[R, R^3]`` binning matrix.  The transform is linear, so the error spectrum is the spectrum of ``pred - target``.  Everything
 stays on the tensors' device; no Python loop over bins, no host round trip.
 """
 import math
@@ -48,6 +49,56 @@ def _binned_power(x, plan):
     return torch.einsum("rq,bqc->brc", binm, p)
 
 
+def _hip_plan(t, h, w, device):
+    """Real stage matrices of the truncated forward DFT (e^{-i theta}) for the planar (re, im) layout of the HIP path, built in
+    fp64: T stage [2R (kt, ri)][t] on real input; H / W stages [(k, ri')][(ri, n)] = complex multiply by cos - i sin."""
+    key = ("hip", t, h, w, str(device))
+    if key not in _PLAN_CACHE:
+        R = min(t // 2, h // 2, w // 2)
+
+        def cs(n):
+            ang = 2.0 * math.pi * torch.arange(R, dtype=torch.float64)[:, None] * torch.arange(n, dtype=torch.float64) / n
+            return torch.cos(ang), torch.sin(ang)
+
+        ct, st = cs(t)
+        MT = torch.stack([ct, -st], dim=1).reshape(2 * R, t)                       # rows (kt, ri)
+
+        def cplx(n):
+            c, s = cs(n)
+            M = torch.zeros(R, 2, 2, n, dtype=torch.float64)                        # [k][ri'][ri][n]
+            M[:, 0, 0], M[:, 0, 1] = c, s                                           # re' =  re cos + im sin
+            M[:, 1, 0], M[:, 1, 1] = -s, c                                          # im' = -re sin + im cos
+            return M.reshape(2 * R, 2 * n)
+
+        to = lambda M: M.t().contiguous().float().to(device)                        # axis_gemm takes M^T [K][O]
+        _PLAN_CACHE[key] = (R, to(MT), to(cplx(h)), to(cplx(w)))
+    return _PLAN_CACHE[key]
+
+
+def _binned_power_hip(x):
+    """x [b,t,h,w,c] fp32 on the GPU -> [b,R,c], through the C ABI: batch-innermost transpose (storage plumbing), three
+    truncated DFT stages on ``rpb_axis_gemm`` (the FNO spectral-layer kernels) and ``rpb_spectrum_bin``."""
+    from . import ops
+    b, t, h, w, c = x.shape
+    R, MTt, MHt, MWt = _hip_plan(t, h, w, x.device)
+    ncol = c * b
+    NB = (ncol + 63) // 64 * 64
+    xt = torch.zeros(t, h, w, NB, device=x.device, dtype=torch.float32)
+    xt[..., :ncol] = x.permute(1, 2, 3, 4, 0).reshape(t, h, w, ncol)
+    f = dict(device=x.device, dtype=torch.float32)
+    n1 = h * w * NB
+    y1 = torch.empty(2 * R, n1, **f)                                                # [kt][ri][h][w][NB]
+    ops.axis_gemm(xt, y1, MTt, 1, t, 2 * R, n1, t * n1, n1, 2 * R * n1, n1, tag="metricsT")
+    n2 = w * NB
+    y2 = torch.empty(R, 2 * R, n2, **f)                                             # [kt][kh][ri][w][NB]
+    ops.axis_gemm(y1, y2, MHt, R, 2 * h, 2 * R, n2, 2 * h * n2, n2, 2 * R * n2, n2, tag="metricsH")
+    y3 = torch.empty(R * R, 2 * R, NB, **f)                                         # [kt][kh][kw][ri][NB]
+    ops.axis_gemm(y2, y3, MWt, R * R, 2 * w, 2 * R, NB, 2 * w * NB, NB, 2 * R * NB, NB, tag="metricsW")
+    out = torch.empty(R, NB, **f)
+    ops.spectrum_bin(y3, out, R, NB)
+    return out[:, :ncol].reshape(R, c, b).permute(2, 0, 1)
+
+
 def kinetic_energy(x):
     """metrics.py:15-22."""
     u = ((x[..., 0] - x[..., 0].mean(dim=1, keepdim=True)) ** 2).mean(1)
@@ -77,8 +128,12 @@ def eval_metrics(pred, target, c, batch_size=None):
         rel_l2 = torch.mean(torch.norm(d.reshape(nb, -1), dim=1) / torch.norm(q.reshape(nb, -1), dim=1))
         r2 = 1 - torch.sum(d ** 2) / torch.sum((q - q.mean(0, keepdim=True)) ** 2)
         ke = (kinetic_energy(p) - kinetic_energy(q)).abs().mean() if c >= 2 else torch.zeros((), device=p.device)
-        err_f = torch.sqrt(_binned_power(d, plan).mean(0)) / nvox              # [R, c]
-        norm_f = torch.sqrt(_binned_power(q, plan).mean(0)) / nvox
+        if d.is_cuda:       # HIP kernels through the C ABI; the einsum form below is the host-side restatement (CPU tensors)
+            err_f = torch.sqrt(_binned_power_hip(d).mean(0)) / nvox            # [R, c]
+            norm_f = torch.sqrt(_binned_power_hip(q).mean(0)) / nvox
+        else:
+            err_f = torch.sqrt(_binned_power(d, plan).mean(0)) / nvox
+            norm_f = torch.sqrt(_binned_power(q, plan).mean(0)) / nvox
         rel = err_f / norm_f
         sp, sq = p.sum(dim=(2, 3, 4)), q.sum(dim=(2, 3, 4))
         freq = torch.mean(torch.abs(torch.fft.fft(sp - sq, dim=1)))

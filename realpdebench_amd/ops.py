@@ -597,3 +597,7 @@ def col_reduce(x, ldx, part, F, n, C, mode):
 def dropout_mul(g, out, n, seed, keep):
     """out = g * inverted-dropout mask regenerated from (seed, element index): backward of the in-kernel dropout."""
     _lib.call("rpb_dropout_mul", _p(g), _p(out), n, int(seed), float(keep), _stream(), label="dropout_mul", nbytes=8 * n)
+
+
+def spectrum_bin(Y, out, R, NB):
+    _lib.call("rpb_spectrum_bin", _p(Y), _p(out), R, NB, _stream(), label="spectrum_bin", nbytes=8 * R * R * R * NB)

@@ -208,3 +208,31 @@ def _check_evaluate_against_a_plain_restatement(root, cfg_path, ckpt, res):
         assert abs(res[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, res[k], v)
     res2, p2, t2 = ev.evaluate(model, loader, GaussianNormalizer(*stats, device="cuda"), 1, args.test_batch_size)
     assert torch.allclose(p2[..., :2], pred, rtol=1e-5, atol=1e-5) and abs(res2["rmse"] - res["rmse"]) < 1e-7
+
+
+def test_eval_metrics_hip_path_matches_reference():
+    """Row f3 on the device: eval_metrics through rpb_axis_gemm (three truncated DFT stages) + rpb_spectrum_bin equals the
+    reference's fftn + Python-triple-loop values (tests/golden/metrics_small.npz, generated from the imported reference)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    from realpdebench_amd import _lib
+    from realpdebench_amd.metrics import eval_metrics
+    z = np.load(os.path.join(GOLDEN_DIR, "metrics_small.npz"))
+    _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
+    try:
+        for name in ("a", "b", "c"):
+            pred, tgt = torch.from_numpy(z[f"{name}/pred"]).cuda(), torch.from_numpy(z[f"{name}/target"]).cuda()
+            bs = int(z[f"{name}/bs"]) or None
+            vals = eval_metrics(pred, tgt, int(z[f"{name}/c"]), batch_size=bs)
+            ref = z[f"{name}/vals"]
+            for i, (v, r) in enumerate(zip(vals, ref)):
+                if not np.isfinite(r):
+                    assert float(v) == r, (name, i, float(v), r)
+                    continue
+                assert abs(float(v) - r) <= 2e-5 * max(abs(r), 1e-3), (name, i, float(v), r)
+        torch.cuda.synchronize()
+        labels = set(_lib.profile_summary())
+    finally:
+        _lib.PROFILE = None
+    assert "spectrum_bin" in labels and any(k.startswith("axis_gemm[metricsW") for k in labels)      # the HIP path ran
