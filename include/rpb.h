@@ -322,6 +322,28 @@ int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, 
 int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n, void* stream);
 int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream);
 
+/* ---- backward of the projection head without the gu round trips (fno.py:121-125 autograd; C = 64, DO <= 4, W >= 16):
+ *      gh = (fc2^T gout) * act'(fc1 a + b1) is recomputed on the bf16 matrix pipe by each consumer instead of being written once
+ *      ([ncrop][128] fp32) and read twice.  `s` is the PADDED pre-BatchNorm tensor of the last Fourier layer, a = xf(s) on the
+ *      cropped cells (xf_* = that layer's mean, invstd, gamma, beta, gelu flag); act 0 = exact GELU, 1 = SiLU.
+ *      rpb_proj_dgrad: g [ncell][64] = gradient w.r.t. the layer output in the padded layout (zeros in the margin) and
+ *        (gu != NULL: gh is READ from gu [ncrop][128] as written by rpb_proj_bwd instead of recomputed -- the faster choice, see
+ *        csrc/rpb_pjx.hip -- and gout may be NULL)
+ *        stats_part [rpb_proj_dgrad_slots][2][64] = partial (sum g, sum g * shat), shat = (s - mean) * invstd.
+ *      rpb_proj_wgrad: part [rpb_proj_wgrad_slots][rpb_proj_wgrad_row(DO)], row `slot` = partial sums for the HB = 128 / roles hidden
+ *        units [HB * (slot % roles), + HB): [HB*64] d fc1.weight | [DO*HB] d fc2.weight | [HB] d fc1.bias | [DO] d fc2.bias. */
+int rpb_proj_bwd_fused_supported(int C, int DO, int W, int Wp);
+long rpb_proj_dgrad_slots(int B, int Tp, int Hp);
+int rpb_proj_dgrad(const float* s, const float* w1, const float* b1, const float* w2, const float* gout, const float* gu,
+                   float* g, float* stats_part, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean,
+                   const float* xf_invstd, const float* xf_gamma, const float* xf_beta, int xf_gelu, int act, void* stream);
+long rpb_proj_wgrad_slots(int B, int T, int H);
+int rpb_proj_wgrad_row(int DO);
+int rpb_proj_wgrad_roles(void);
+int rpb_proj_wgrad(const float* s, const float* w1, const float* b1, const float* w2, const float* gout, float* part, int B,
+                   int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd,
+                   const float* xf_gamma, const float* xf_beta, int xf_gelu, int act, void* stream);
+
 /* ---- eval_metrics (realpdebench/utils/metrics.py:71-100): |F|^2 of the truncated spectrum corner accumulated by radial bin
  *      floor(sqrt(i^2+j^2+k^2)) < R.  Y [R][R][R][2][NB] (re, im planes; columns = (channel, sample)), out [R][NB].  The three
  *      truncated DFT stages in front of it are rpb_axis_gemm launches (realpdebench_amd/metrics.py). */

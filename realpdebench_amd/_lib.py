@@ -22,6 +22,13 @@ SIGNATURES = {
     "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
     "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
     "rpb_spectrum_bin": (_I, "ppiip"),
+    "rpb_proj_bwd_fused_supported": (_I, "iiii"),
+    "rpb_proj_dgrad_slots": (_L, "iii"),
+    "rpb_proj_dgrad": (_I, "pppppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
+    "rpb_proj_wgrad_slots": (_L, "iii"),
+    "rpb_proj_wgrad_row": (_I, "i"),
+    "rpb_proj_wgrad_roles": (_I, ""),
+    "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
     "rpb_dp_available": (_I, ""),
     "rpb_dp_unique_id": (_I, "p"),
     "rpb_dp_allreduce_init": (_I, "piip"),

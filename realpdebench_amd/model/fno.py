@@ -8,6 +8,7 @@ mode-major ``[M][Ci][Co][2]`` (see ``dft.py``) and converted from / to the refer
 tensors only in ``state_dict`` / ``load_state_dict``.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -52,11 +53,25 @@ class _Workspace:
         self.out = torch.empty(d.ncrop, model.dim_out, **f)
         if training:
             self.G = [torch.empty(d.ncell, C, **f) for _ in range(2)]
-            self.gu = torch.empty(d.ncrop, HID, **f)
+            # projection-head backward: bf16-pipe kernels that recompute gh (no gu tensor) when the shape allows, else the
+            # round-1 chain through gu
+            # projection-head backward (csrc/rpb_pjx.hip): "gu" (default where supported) = round-1 proj_bwd + cell_wgrad with the
+            # fc1 dgrad on the bf16 pipe reading gu; "recompute" (RPB_PROJ_RECOMPUTE=1) = no gu tensor at all, both kernels rebuild
+            # gh -- measured slower (act' on 128 hidden units per cell twice); None = the round-1 chain
+            ok = (C == 64 and type(model)._lift_fwd is FNO3d._lift_fwd and ops.proj_bwd_fused_supported(C, model.dim_out, d.W, d.Wp))
+            self.proj_mode = None if not ok else ("recompute" if os.environ.get("RPB_PROJ_RECOMPUTE") == "1" else "gu")
+            self.proj_fused = self.proj_mode == "recompute"
+            self.gu = None if self.proj_fused else torch.empty(d.ncrop, HID, **f)
+            if ok:
+                self.pd_slots = ops.proj_dgrad_slots(d)
+            if self.proj_fused:
+                self.pw_slots, self.pw_row, self.pw_roles = ops.proj_wgrad_slots(d), ops.proj_wgrad_row(model.dim_out), ops.proj_wgrad_roles()
+                self.pw_part = torch.empty(self.pw_slots * self.pw_row, **f)
+                self.pw_sum = torch.empty(self.pw_roles * self.pw_row, **f)
             # BatchNorm-backward sums are produced by the kernels that write the gradient (cell_mix STATS=2)
             self.bnb_rows_gather = ops.cell_mix_stat_rows(d.ncell, HID, C, 0, 1, False, True)
             self.bnb_rows_conv = ops.cell_mix_stat_rows(d.ncell, C, C, 2 * plan.KW, d.Wp, True, True)
-            self.bn_part = torch.empty(max(self.bnb_rows_gather, self.bnb_rows_conv) * 2 * C, **f)
+            self.bn_part = torch.empty(max(self.bnb_rows_gather, self.bnb_rows_conv, getattr(self, "pd_slots", 0)) * 2 * C, **f)
             self.bn_sums = torch.empty(2 * C, **f)
             self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
             self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
@@ -374,25 +389,49 @@ class FNO3d(Model):
         world = self.dp.world_size if self.dp is not None else 1
         # ---- projection
         a_last, xf_last = ws.S[L - 1], self._layer_xf(ws, L - 1, True)
-        ops.proj_bwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
-                     ws.proj_part, d, DO, xf=xf_last, act=self.proj_act)
-        row = DO * HID + HID + DO
-        part = ws.proj_part.view(ws.proj_rows, row)
-        # partial row layout: [d fc2.weight | d fc1.bias | d fc2.bias]; the three segments are reduced separately
-        self._reduce_cols(part, 0, DO * HID, GP("fc2.weight"))
-        self._reduce_cols(part, DO * HID, HID, GP("fc1.bias"))
-        self._reduce_cols(part, DO * HID + HID, DO, GP("fc2.bias"))
-        ops.cell_wgrad(ws.gu, a_last, ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6, xf=xf_last)
-        partp = ws.wg_part[:ws.wg_rows_p * (HID * C + HID)].view(ws.wg_rows_p, HID * C + HID)
-        self._reduce_cols(partp, 0, HID * C, GP("fc1.weight"))
-        if self.dp is not None:
-            self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
         g, g2 = ws.G
-        # fc1 dgrad scattered into the padded layout; its epilogue also accumulates the BatchNorm-backward sums
-        # (sum gz, sum gz*shat) of the last Fourier layer, so no separate reduction pass reads g again
-        ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, ws.bn_part, d.ncell, HID, C, 0, 1, transpose_w=True,
-                     gather=True, crop6=d.crop6, bnb=(ws.S[L - 1],) + self._layer_xf(ws, L - 1, True))
-        ops.reduce_partials(ws.bn_part, ws.bnb_rows_gather, 2 * C, out_f32=ws.bn_sums)
+        if ws.proj_fused:
+            # bf16 matrix pipe, no gu tensor: each kernel recomputes gh = (fc2^T gout) * act'(fc1 a + b1) in the operand
+            # orientation it needs (csrc/rpb_pjx.hip).  wgrad first: its partials feed the first all-reduce bucket
+            w1, b1, w2 = P("fc1.weight"), P("fc1.bias"), P("fc2.weight")
+            ops.proj_wgrad(a_last, w1, b1, w2, gout, ws.pw_part, d, DO, xf_last, act=self.proj_act)
+            roles, row = ws.pw_roles, ws.pw_row
+            HB = HID // roles
+            # slot = k * roles + role: one reduction over k leaves [role][row]; the four blocks then move into the arena
+            ops.reduce_partials(ws.pw_part, ws.pw_slots // roles, roles * row, out_f32=ws.pw_sum)
+            tot = ws.pw_sum.view(roles, row)
+            GP("fc1.weight").view(roles, HB * C).copy_(tot[:, :HB * C])
+            GP("fc2.weight").view(DO, roles, HB).copy_(tot[:, HB * C:HB * C + DO * HB].view(roles, DO, HB).permute(1, 0, 2))
+            GP("fc1.bias").view(roles, HB).copy_(tot[:, HB * C + DO * HB:HB * C + DO * HB + HB])
+            GP("fc2.bias").copy_(tot[0, HB * C + DO * HB + HB:])
+            if self.dp is not None:
+                self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
+            ops.proj_dgrad(a_last, w1, b1, w2, gout, g, ws.bn_part, d, DO, xf_last, act=self.proj_act)
+            ops.reduce_partials(ws.bn_part, ws.pd_slots, 2 * C, out_f32=ws.bn_sums)
+        else:
+            ops.proj_bwd(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), gout, ws.gu,
+                         ws.proj_part, d, DO, xf=xf_last, act=self.proj_act)
+            row = DO * HID + HID + DO
+            part = ws.proj_part.view(ws.proj_rows, row)
+            # partial row layout: [d fc2.weight | d fc1.bias | d fc2.bias]; the three segments are reduced separately
+            self._reduce_cols(part, 0, DO * HID, GP("fc2.weight"))
+            self._reduce_cols(part, DO * HID, HID, GP("fc1.bias"))
+            self._reduce_cols(part, DO * HID + HID, DO, GP("fc2.bias"))
+            ops.cell_wgrad(ws.gu, a_last, ws.wg_part, d.ncrop, HID, C, crop=True, crop6=d.crop6, xf=xf_last)
+            partp = ws.wg_part[:ws.wg_rows_p * (HID * C + HID)].view(ws.wg_rows_p, HID * C + HID)
+            self._reduce_cols(partp, 0, HID * C, GP("fc1.weight"))
+            if self.dp is not None:
+                self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
+            # fc1 dgrad scattered into the padded layout; its epilogue also accumulates the BatchNorm-backward sums
+            # (sum gz, sum gz*shat) of the last Fourier layer, so no separate reduction pass reads g again
+            if ws.proj_mode == "gu":           # bf16 matrix pipe, 16 B stores, line-persistent waves (csrc/rpb_pjx.hip)
+                ops.proj_dgrad(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), None, g, ws.bn_part, d, DO, xf_last,
+                               act=self.proj_act, gu=ws.gu)
+                ops.reduce_partials(ws.bn_part, ws.pd_slots, 2 * C, out_f32=ws.bn_sums)
+            else:
+                ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, ws.bn_part, d.ncell, HID, C, 0, 1, transpose_w=True,
+                             gather=True, crop6=d.crop6, bnb=(ws.S[L - 1],) + self._layer_xf(ws, L - 1, True))
+                ops.reduce_partials(ws.bn_part, ws.bnb_rows_gather, 2 * C, out_f32=ws.bn_sums)
         # the C = 64 bf16-pipe cell_mix stores gz = g * gelu'(z) when asked (it evaluates gelu' for the BatchNorm-backward sums
         # anyway), so the BatchNorm-backward apply of the layer below skips gelu'
         gz_ok = ws.fused_bwd and ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True)

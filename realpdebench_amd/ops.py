@@ -601,3 +601,38 @@ def dropout_mul(g, out, n, seed, keep):
 
 def spectrum_bin(Y, out, R, NB):
     _lib.call("rpb_spectrum_bin", _p(Y), _p(out), R, NB, _stream(), label="spectrum_bin", nbytes=8 * R * R * R * NB)
+
+
+def proj_bwd_fused_supported(C, DO, W, Wp):
+    return bool(_lib.query("rpb_proj_bwd_fused_supported", C, DO, W, Wp))
+
+
+def proj_dgrad_slots(d):
+    return _lib.query("rpb_proj_dgrad_slots", d.B, d.Tp, d.Hp)
+
+
+def proj_dgrad(s, w1, b1, w2, gout, g, stats_part, d, DO, xf, act=0, gu=None):
+    """g [ncell][64] (padded layout) = fc1^T gh, gh = (fc2^T gout) * act'(fc1 a + b1) recomputed (a = xf(s) cropped) or read from
+    ``gu`` [ncrop][128]; stats_part = BN-backward sums."""
+    _lib.call("rpb_proj_dgrad", _p(s), _p(w1), _p(b1), _p(w2), _p(gout), _p(gu), _p(g), _p(stats_part), d.B, DO, *d.crop6,
+              *_xf(xf), int(act), _stream(), label="proj_dgrad[gu]" if gu is not None else "proj_dgrad[recompute]",
+              nbytes=4 * (d.ncrop * (d.C + (128 if gu is not None else DO)) + d.ncell * d.C),
+              flops=2 * d.ncrop * 128 * (d.C if gu is not None else 2 * d.C))
+
+
+def proj_wgrad_slots(d):
+    return _lib.query("rpb_proj_wgrad_slots", d.B, d.T, d.H)
+
+
+def proj_wgrad_row(DO):
+    return _lib.query("rpb_proj_wgrad_row", DO)
+
+
+def proj_wgrad_roles():
+    return _lib.query("rpb_proj_wgrad_roles")
+
+
+def proj_wgrad(s, w1, b1, w2, gout, part, d, DO, xf, act=0):
+    """Per-wave partial rows of d fc1.weight / d fc2.weight / d fc1.bias / d fc2.bias (layout: include/rpb.h)."""
+    _lib.call("rpb_proj_wgrad", _p(s), _p(w1), _p(b1), _p(w2), _p(gout), _p(part), d.B, DO, *d.crop6, *_xf(xf), int(act),
+              _stream(), label="proj_wgrad", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * 2 * d.C)

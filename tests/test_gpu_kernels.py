@@ -517,3 +517,64 @@ def test_bf16_storage_kernels(ops, Wp, rows, K2):
     ops.proj_fwd(a16.float(), w1, b1, w2, b2, o32, d, 2)
     ops.proj_fwd_bf16(a16, w1, b1, w2, b2, o16, d, 2)
     assert torch.equal(o16, o32)
+
+
+@pytest.mark.parametrize("B,T,H,W,pad,DO,gelu,act", [(2, 3, 5, 32, 2, 2, False, 0), (1, 2, 4, 48, 3, 1, False, 0),
+                                                      (1, 2, 3, 40, 6, 3, True, 1)])
+def test_projection_backward_without_gu(ops, B, T, H, W, pad, DO, gelu, act):
+    """rpb_proj_dgrad / rpb_proj_wgrad (bf16 matrix pipe, gh recomputed, never stored) against fp64 autograd of
+    fno.py:121-125 on the cropped cells: gradient w.r.t. the padded layer output (zeros in the margin), the BatchNorm-backward
+    sums, and the four parameter gradients; row lengths that are not a multiple of the 32-cell wave tile included."""
+    torch.manual_seed(B * 100 + W)
+    C = 64
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    assert ops.proj_bwd_fused_supported(C, DO, W, d.Wp)
+    f8 = dict(dtype=torch.float64)
+    s = (torch.randn(d.ncell, C, **f8) * 1.2 + 0.2).requires_grad_(True)
+    mean, invstd = torch.randn(C, **f8) * 0.2, torch.rand(C, **f8) + 0.5
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    w1 = (torch.randn(128, C, **f8) / 8).requires_grad_(True)
+    b1 = torch.randn(128, **f8).requires_grad_(True)
+    w2 = (torch.randn(DO, 128, **f8) / 11).requires_grad_(True)
+    b2 = torch.randn(DO, **f8).requires_grad_(True)
+    sh = (s - mean) * invstd
+    a_full = _xf_ref(s, mean, invstd, gamma, beta, gelu)
+    a = a_full.view(B, d.Tp, d.Hp, d.Wp, C)[:, :T, :H, :W].reshape(-1, C)
+    u = a @ w1.t() + b1
+    v = torch.nn.functional.silu(u) if act == 1 else torch.nn.functional.gelu(u)
+    out = v @ w2.t() + b2
+    gout = torch.randn_like(out)
+    a_full.retain_grad()
+    out.backward(gout)
+    g_ref = a_full.grad                                   # gradient w.r.t. act(BN(s)): zero in the pad margin
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), gelu)
+    S = dev(s.detach())
+    g = torch.full((d.ncell, C), float("nan"), device="cuda")
+    rows = ops.proj_dgrad_slots(d)
+    part = torch.zeros(rows, 2, C, device="cuda")
+    args = (S, dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), dev(gout))
+    ops.proj_dgrad(*args, g, part, d, DO, xf, act=act)
+    assert rel_l2(g.cpu(), g_ref) < 3e-6
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(tot[0], g_ref.sum(0)) < 2e-5 and rel_l2(tot[1], (g_ref * sh.detach()).sum(0)) < 2e-5
+    # the same dgrad reading gh from HBM (the default path: rpb_proj_bwd writes it, cell_wgrad reads it too)
+    u2 = (a.detach() @ w1.detach().t() + b1.detach()).requires_grad_(True)
+    v2 = torch.nn.functional.silu(u2) if act == 1 else torch.nn.functional.gelu(u2)
+    (v2 @ w2.detach().t()).backward(gout)
+    g.fill_(float("nan"))
+    part.zero_()
+    ops.proj_dgrad(S, dev(w1.detach()), dev(b1.detach()), dev(w2.detach()), None, g, part, d, DO, xf, act=act, gu=dev(u2.grad))
+    assert rel_l2(g.cpu(), g_ref) < 3e-6
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(tot[0], g_ref.sum(0)) < 2e-5 and rel_l2(tot[1], (g_ref * sh.detach()).sum(0)) < 2e-5
+    slots, row, roles = ops.proj_wgrad_slots(d), ops.proj_wgrad_row(DO), ops.proj_wgrad_roles()
+    HB = 128 // roles
+    wp = torch.full((slots, row), float("nan"), device="cuda")
+    ops.proj_wgrad(*args, wp, d, DO, xf, act=act)
+    tot = wp.double().view(slots // roles, roles, row).sum(0).cpu()           # [role][row]
+    dw1 = tot[:, :HB * 64].reshape(128, 64)
+    dw2 = tot[:, HB * 64:HB * 64 + DO * HB].reshape(roles, DO, HB).permute(1, 0, 2).reshape(DO, 128)
+    db1 = tot[:, HB * 64 + DO * HB:HB * 64 + DO * HB + HB].reshape(128)
+    db2 = tot[:, HB * 64 + DO * HB + HB:].sum(0)
+    assert rel_l2(dw1, w1.grad) < 5e-6 and rel_l2(dw2, w2.grad) < 5e-6
+    assert rel_l2(db1, b1.grad) < 5e-6 and rel_l2(db2, b2.grad) < 5e-6

@@ -138,6 +138,21 @@ if "proj" in which:
     timeit("proj_bwd", lambda: ops.proj_bwd(x, w1, b1, w2, b2, out, gu, part, d, 2), 4 * d.ncrop * (C + 2 + 128),
            2 * d.ncrop * 128 * (C + 4))
 
+if "proj" in which and ops.proj_bwd_fused_supported(C, 2, W, d.Wp):
+    mean, invstd, gamma, beta = torch.zeros(C, **f), torch.ones(C, **f), torch.ones(C, **f), torch.zeros(C, **f)
+    xfl = (mean, invstd, gamma, beta, False)
+    gout = torch.randn(d.ncrop, 2, **f)
+    g = torch.empty(d.ncell, C, **f)
+    sp = torch.empty(ops.proj_dgrad_slots(d) * 2 * C, **f)
+    timeit("proj_dgrad (bf16 pipe, no gu)", lambda: ops.proj_dgrad(x, w1, b1, w2, gout, g, sp, d, 2, xfl),
+           4 * (d.ncrop * (C + 2) + d.ncell * C), 2 * d.ncrop * 128 * 2 * C)
+    gu2 = torch.randn(d.ncrop, 128, **f)
+    timeit("proj_dgrad (bf16 pipe, reads gu)", lambda: ops.proj_dgrad(x, w1, b1, w2, None, g, sp, d, 2, xfl, gu=gu2),
+           4 * (d.ncrop * (C + 128) + d.ncell * C), 2 * d.ncrop * 128 * C)
+    wp = torch.empty(ops.proj_wgrad_slots(d) * ops.proj_wgrad_row(2), **f)
+    timeit("proj_wgrad (bf16 pipe, no gu)", lambda: ops.proj_wgrad(x, w1, b1, w2, gout, wp, d, 2, xfl),
+           4 * d.ncrop * (C + 2), 2 * d.ncrop * 128 * 2 * C)
+
 if "lift" in which:
     xin = torch.randn(B, T, H, W, Cin, **f)
     grids = [torch.linspace(0, 1, n, **f) for n in (T, H, W)]
