@@ -90,6 +90,9 @@ int rpb_cell_wgrad(const float* gs, const float* x, float* part, long ncell, int
 /*     out[j] (+)= scale * sum_r part[r*row_stride + j], j < L, accumulated in fp64 (deterministic, no atomics). */
 int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, float* out_f32, double* out_f64,
                         double scale, int accumulate, void* stream);
+/*     nbatch independent reductions in one launch: out[b][j] = sum_r part[b*batch_stride + r*row_stride + j] (fp64 accumulate). */
+int rpb_reduce_partials_batched(const float* part, int nbatch, long rows, long L, long row_stride, long batch_stride,
+                                float* outf, void* stream);
 int rpb_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, int C, void* stream);
 int rpb_bn_eval_prep(const float* running_var, float eps, float* invstd, int C, void* stream);
@@ -200,6 +203,12 @@ int rpb_colsum(const float* x, float* part, long M, int N, int ld, void* stream)
 /*     attention among the G slice tokens of every (sample, head) (Physics_Attention.py:164-171, eval mode). */
 int rpb_slice_attn(const float* tokS, const float* norm, const float* Wq, const float* Wk, const float* Wv, float* out,
                    int BH, int G, void* stream);
+/*     the same attention in TRAINING: nn.Dropout on the attention map as a given inverted-dropout mask amask [BH][G][G] (or NULL),
+ *     and -- with go = dLoss/d(out) -- its whole backward: gT [BH][G][32] (w.r.t. tokS), gN [BH][G] (w.r.t. norm) and
+ *     gW [BH][3][32][32] (per-(b,h) partials of d to_q / to_k / to_v weights).  out may be NULL in a backward-only call. */
+int rpb_slice_attn_train(const float* tokS, const float* norm, const float* Wq, const float* Wk, const float* Wv,
+                         const float* amask, const float* go, float* out, float* gT, float* gN, float* gW, int BH, int G,
+                         void* stream);
 /*     deslice: out[m][h*32+c] = sum_g w[m][h][g] tok2[b][h][g][c] (Physics_Attention.py:173-175). */
 int rpb_deslice_fwd(const float* w, const float* tok2, float* out, int B, int ntok, int heads, int G, void* stream);
 

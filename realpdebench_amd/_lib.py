@@ -48,6 +48,7 @@ SIGNATURES = {
     "rpb_cell_wgrad_slots": (_L, "lii"),
     "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "ppppi" + "p"),
     "rpb_reduce_partials": (_I, "p" + "lll" + "pp" + "d" + "i" + "p"),
+    "rpb_reduce_partials_batched": (_I, "p" + "i" + "llll" + "p" + "p"),
     "rpb_bn_finalize": (_I, "p" + "d" + "ff" + "pppp" + "i" + "p"),
     "rpb_bn_eval_prep": (_I, "p" + "f" + "p" + "i" + "p"),
     "rpb_bn_act_fwd": (_I, "pppppp" + "l" + "ii" + "p"),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "rpb_slice_blocks_per_sample": (_I, "i"),
     "rpb_slice_fwd": (_I, "ppppppp" + "iiiii" + "p" + "p"),
     "rpb_slice_attn": (_I, "pppppp" + "ii" + "p"),
+    "rpb_slice_attn_train": (_I, "ppppppppppp" + "ii" + "p"),
     "rpb_deslice_fwd": (_I, "ppp" + "iiii" + "p"),
     "rpb_headnorm_fwd": (_I, "pipppi" + "l" + "i" + "f" + "p"),
     "rpb_headnorm_bwd_rows": (_L, "l"),

@@ -235,9 +235,13 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
                                                                long row_stride, float* __restrict__ outf,
                                                                double* __restrict__ outd, double scale,
-                                                               int accumulate) {
+                                                               int accumulate, long batch_stride) {
     // block = 64 columns x 16 row groups; 4 independent fp64 chains per thread keep the loads pipelined
+    // blockIdx.y = batch: an independent reduction over `rows` rows starting batch_stride floats further, out + y * L
     __shared__ double red[16][64];
+    part += (long)blockIdx.y * batch_stride;
+    if (outf) outf += (long)blockIdx.y * L;
+    if (outd) outd += (long)blockIdx.y * L;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 64 + cl;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -267,8 +271,17 @@ extern "C" int rpb_reduce_partials(const float* part, long rows, long L, long ro
                                    double scale, int accumulate, void* stream) {
     RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0 && row_stride >= L, "reduce_partials: bad arguments");
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
-                       part, rows, L, row_stride, outf, outd, scale, accumulate);
+                       part, rows, L, row_stride, outf, outd, scale, accumulate, 0L);
     RPB_CHECK_LAUNCH("reduce_partials");
+}
+
+// nbatch independent reductions in one launch: out[b][j] = sum_r part[b*batch_stride + r*row_stride + j]
+extern "C" int rpb_reduce_partials_batched(const float* part, int nbatch, long rows, long L, long row_stride, long batch_stride,
+                                           float* outf, void* stream) {
+    RPB_REQUIRE(part && outf && nbatch > 0 && nbatch < 65536 && rows > 0 && L > 0 && row_stride >= L, "reduce_partials_batched: bad arguments");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)nbatch), dim3(1024), 0,
+                       (hipStream_t)stream, part, rows, L, row_stride, outf, (double*)nullptr, 1.0, 0, batch_stride);
+    RPB_CHECK_LAUNCH("reduce_partials_batched");
 }
 
 // ---------------------------------------------------------------------------------- K6 BatchNorm3d (+GELU)

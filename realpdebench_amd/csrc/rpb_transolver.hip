@@ -322,6 +322,149 @@ extern "C" int rpb_slice_attn(const float* tokS, const float* norm, const float*
     RPB_CHECK_LAUNCH("slice_attn");
 }
 
+// ---------------------------------------------------------------------------------- slice-token attention: training
+// Physics_Attention.py:164-171 with nn.Dropout on the attention map (a given inverted-dropout mask amask[b][h][G][G], or none)
+// and its full backward.  One block per (b, h); everything lives in LDS (G <= 32 tokens of 32 channels).
+//   t = tokS / (norm + 1e-5);  q, k, v = t Wq^T, t Wk^T, t Wv^T;  P = softmax(q k^T / sqrt(32));  A = P * amask;  o = A v
+__global__ __launch_bounds__(TS_THREADS) void slice_attn_train_kernel(const float* __restrict__ tokS, const float* __restrict__ norm,
+                                                                      const float* __restrict__ Wq, const float* __restrict__ Wk,
+                                                                      const float* __restrict__ Wv, const float* __restrict__ amask,
+                                                                      const float* __restrict__ go, float* __restrict__ out,
+                                                                      float* __restrict__ gT, float* __restrict__ gN,
+                                                                      float* __restrict__ gW, int G, float scale) {
+    // forward values, then (go != null) the gradients; gW [BH][3][32][32] per-block partials of d to_q / to_k / to_v weights
+    __shared__ float t[32][33], q[32][33], k[32][33], v[32][33], p[32][33], a[32][33];
+    __shared__ float g1[32][33], g2[32][33], g3[32][33], gs[32][33];
+    const int bh = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {
+        const int g = idx >> 5, c = idx & 31;
+        t[g][c] = tokS[((long)bh * G + g) * 32 + c] / (norm[(long)bh * G + g] + 1e-5f);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {
+        const int g = idx >> 5, c = idx & 31;
+        float sq = 0.f, sk = 0.f, sv = 0.f;
+        for (int j = 0; j < 32; ++j) {
+            const float tv = t[g][j];
+            sq += tv * Wq[c * 32 + j];
+            sk += tv * Wk[c * 32 + j];
+            sv += tv * Wv[c * 32 + j];
+        }
+        q[g][c] = sq; k[g][c] = sk; v[g][c] = sv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * G; idx += blockDim.x) {
+        const int i = idx / G, j = idx - i * G;
+        float sacc = 0.f;
+        for (int c = 0; c < 32; ++c) sacc += q[i][c] * k[j][c];
+        p[i][j] = sacc * scale;
+    }
+    __syncthreads();
+    if (tid < G) {
+        float mx = -3.0e38f;
+        for (int j = 0; j < G; ++j) mx = fmaxf(mx, p[tid][j]);
+        float den = 0.f;
+        for (int j = 0; j < G; ++j) {
+            p[tid][j] = expf(p[tid][j] - mx);
+            den += p[tid][j];
+        }
+        const float inv = 1.f / den;
+        for (int j = 0; j < G; ++j) {
+            p[tid][j] *= inv;
+            a[tid][j] = amask ? p[tid][j] * amask[((long)bh * G + tid) * G + j] : p[tid][j];
+        }
+    }
+    __syncthreads();
+    if (out) {
+        for (int idx = tid; idx < G * 32; idx += blockDim.x) {
+            const int g = idx >> 5, c = idx & 31;
+            float sacc = 0.f;
+            for (int j = 0; j < G; ++j) sacc += a[g][j] * v[j][c];
+            out[((long)bh * G + g) * 32 + c] = sacc;
+        }
+    }
+    if (!go) return;
+    // ---- backward.  g1 = go (then gq), g2 = gv (then gk), gs = dS
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) g1[idx >> 5][idx & 31] = go[(long)bh * G * 32 + idx];
+    __syncthreads();
+    for (int idx = tid; idx < G * G; idx += blockDim.x) {               // dA = go v^T, dP = dA * mask
+        const int i = idx / G, j = idx - i * G;
+        float sacc = 0.f;
+        for (int c = 0; c < 32; ++c) sacc += g1[i][c] * v[j][c];
+        gs[i][j] = amask ? sacc * amask[((long)bh * G + i) * G + j] : sacc;
+    }
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {              // gv = A^T go
+        const int g = idx >> 5, c = idx & 31;
+        float sacc = 0.f;
+        for (int i = 0; i < G; ++i) sacc += a[i][g] * g1[i][c];
+        g3[g][c] = sacc;
+    }
+    __syncthreads();
+    if (tid < G) {                                                       // dS = scale * P * (dP - sum_j dP P)
+        float dot = 0.f;
+        for (int j = 0; j < G; ++j) dot += gs[tid][j] * p[tid][j];
+        for (int j = 0; j < G; ++j) gs[tid][j] = scale * p[tid][j] * (gs[tid][j] - dot);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {              // gq = dS k,  gk = dS^T q
+        const int g = idx >> 5, c = idx & 31;
+        float sq = 0.f, sk = 0.f;
+        for (int j = 0; j < G; ++j) {
+            sq += gs[g][j] * k[j][c];
+            sk += gs[j][g] * q[j][c];
+        }
+        g1[g][c] = sq;                                                   // go is dead (consumed above, barrier passed)
+        g2[g][c] = sk;
+    }
+    __syncthreads();
+    // d W*[c][j] = sum_g g*[g][c] t[g][j]   (per-block partials)
+    for (int idx = tid; idx < 32 * 32; idx += blockDim.x) {
+        const int c = idx >> 5, j = idx & 31;
+        float sq = 0.f, sk = 0.f, sv = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float tv = t[g][j];
+            sq += g1[g][c] * tv;
+            sk += g2[g][c] * tv;
+            sv += g3[g][c] * tv;
+        }
+        float* w = gW + (long)bh * 3 * 1024;
+        w[idx] = sq;
+        w[1024 + idx] = sk;
+        w[2048 + idx] = sv;
+    }
+    // gt = gq Wq + gk Wk + gv Wv;  t = tokS / (norm + eps):  d tokS = gt / (norm + eps),  d norm = -sum_j gt t / (norm + eps)
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {
+        const int g = idx >> 5, j = idx & 31;
+        float sacc = 0.f;
+        for (int c = 0; c < 32; ++c) sacc += g1[g][c] * Wq[c * 32 + j] + g2[g][c] * Wk[c * 32 + j] + g3[g][c] * Wv[c * 32 + j];
+        a[g][j] = sacc;                                                  // A is dead: reuse as gt
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * 32; idx += blockDim.x) {
+        const int g = idx >> 5, j = idx & 31;
+        gT[((long)bh * G + g) * 32 + j] = a[g][j] / (norm[(long)bh * G + g] + 1e-5f);
+    }
+    if (tid < G) {
+        float sacc = 0.f;
+        for (int j = 0; j < 32; ++j) sacc += a[tid][j] * t[tid][j];
+        gN[(long)bh * G + tid] = -sacc / (norm[(long)bh * G + tid] + 1e-5f);
+    }
+}
+
+// out (optional) = the attended slice tokens under the attention-map dropout mask amask (optional).  With go: the backward --
+// gT [BH][G][32], gN [BH][G] and gW [BH][3][32][32] (per-(b,h) partials of d to_q / to_k / to_v, summed by the caller).
+extern "C" int rpb_slice_attn_train(const float* tokS, const float* norm, const float* Wq, const float* Wk, const float* Wv,
+                                    const float* amask, const float* go, float* out, float* gT, float* gN, float* gW, int BH,
+                                    int G, void* stream) {
+    RPB_REQUIRE(tokS && norm && Wq && Wk && Wv && BH > 0 && G >= 1 && G <= 32, "slice_attn_train: bad arguments");
+    RPB_REQUIRE(out || go, "slice_attn_train: nothing to compute");
+    if (go) RPB_REQUIRE(gT && gN && gW, "slice_attn_train: the backward needs gT, gN and gW");
+    hipLaunchKernelGGL(slice_attn_train_kernel, dim3(BH), dim3(TS_THREADS), 0, (hipStream_t)stream, tokS, norm, Wq, Wk, Wv,
+                       amask, go, out, gT, gN, gW, G, 1.0f / sqrtf(32.f));
+    RPB_CHECK_LAUNCH("slice_attn_train");
+}
+
 // ---------------------------------------------------------------------------------- deslice
 // out[m][h*32+c] = sum_g w[m][h][g] * tok2[b][h][g][c]     (Physics_Attention.py:173-175)
 __global__ __launch_bounds__(TS_THREADS) void deslice_kernel(const float* __restrict__ w, const float* __restrict__ tok2,

@@ -3,7 +3,8 @@
 built by ``load_model`` exactly like ``realpdebench/model/load_model.py:145-152``.
 
 Forward, rollout and the whole backward pass (``train_loss(...).mean().backward()`` through one autograd Function) run in
-the HIP kernels of ``csrc/``; there is no PyTorch fallback.  Parameter names, shapes and dtypes equal the reference's
+the HIP kernels of ``csrc/`` -- including the training-mode slice-token attention with its dropout mask and its backward
+(``rpb_slice_attn_train``); there is no PyTorch fallback and no torch autograd inside the backward.  Parameter names, shapes and dtypes equal the reference's
 ``state_dict`` so its checkpoints load.
 
 Pipeline per block (Transolver_Structured_Mesh_3D.py:71-77, Physics_Attention.py:148-176), tokens channels-last:
@@ -154,9 +155,9 @@ class Transolver(_ModelBase):
             ops.conv3(a, wcat, xf, M, 2 * C, C, (self.H, self.W, self.D), bias=bcat)
             ops.slice_fwd(xf, at.in_project_slice.weight.data, at.in_project_slice.bias.data,
                           at.temperature.data.reshape(-1).contiguous(), w, tok_part, norm_part, B, ntok, heads, G, 2 * C)
-            for b in range(B):            # per-sample finish of the block partials (deterministic fp64 sums)
-                ops.reduce_partials(tok_part[b * bps:(b + 1) * bps], bps, heads * G * 32, out_f32=tokS[b])
-                ops.reduce_partials(norm_part[b * bps:(b + 1) * bps], bps, heads * G, out_f32=norm[b])
+            # per-sample finish of the block partials (deterministic fp64 sums), all samples in one launch each
+            ops.reduce_partials_batched(tok_part, B, bps, heads * G * 32, tokS)
+            ops.reduce_partials_batched(norm_part, B, bps, heads * G, norm)
             amask = omask = None
             if keep and self.training and self.dropout_p > 0:
                 # nn.Dropout(p) on the slice attention map and after to_out (Physics_Attention.py:169,144): inverted-
@@ -168,10 +169,9 @@ class Transolver(_ModelBase):
                     amask = (torch.rand(B, heads, G, G, **f) < keep_p).float() / keep_p
                     # the token-sized mask after to_out never exists: (seed, keep) expanded by Philox in the GEMM epilogue
                     omask = (int(torch.randint(0, 2 ** 62, (1,))), keep_p)
-                # 16 x 16 attention with the mask: a few thousand numbers per sample (plumbing-scale torch glue)
-                tk = tokS.view(B, heads, G, 32) / (norm.view(B, heads, G) + 1e-5)[..., None]
-                q, k, v = tk @ at.to_q.weight.data.t(), tk @ at.to_k.weight.data.t(), tk @ at.to_v.weight.data.t()
-                tok2.copy_(((torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1) * amask) @ v).reshape(B, -1))
+                # slice-token attention with the dropout mask on the attention map (rpb_slice_attn_train)
+                ops.slice_attn_train(tokS, norm, at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data,
+                                     amask.contiguous(), B * heads, G, out=tok2)
             else:
                 ops.slice_attn(tokS, norm, at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data, tok2,
                                B * heads, G)
@@ -278,27 +278,22 @@ class Transolver(_ModelBase):
             tp = new(B * bps, heads * G * 32)
             ops.slice_fwd(gox, None, None, None, None, tp, None, B, ntok, heads, G, C, w_in=st["w"])
             gtok2 = new(B, heads * G * 32)
-            for b in range(B):
-                ops.reduce_partials(tp[b * bps:(b + 1) * bps], bps, heads * G * 32, out_f32=gtok2[b])
-            # ---- 16-token attention backward on [B, heads, G, 32] tensors (a few thousand numbers per sample):
-            #      torch autograd on these tiny tensors is plumbing-scale glue, not a compute path
-            with torch.enable_grad():
-                tS = st["tokS"].view(B, heads, G, 32).detach().requires_grad_(True)
-                nm = st["norm"].view(B, heads, G).detach().requires_grad_(True)
-                wq, wk, wv = (p.detach().requires_grad_(True) for p in (at.to_q.weight, at.to_k.weight, at.to_v.weight))
-                tok = tS / (nm + 1e-5)[..., None]
-                q, k, v = tok @ wq.t(), tok @ wk.t(), tok @ wv.t()
-                attn = torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, dim=-1)
-                if st["amask"] is not None:
-                    attn = attn * st["amask"]
-                o = attn @ v
-                gT, gN, gq, gk, gv = torch.autograd.grad(o, (tS, nm, wq, wk, wv), gtok2.view(B, heads, G, 32))
-            grads[at.to_q.weight], grads[at.to_k.weight], grads[at.to_v.weight] = gq, gk, gv
+            ops.reduce_partials_batched(tp, B, bps, heads * G * 32, gtok2)
+            # ---- slice-token attention backward (rpb_slice_attn_train with go): gradients w.r.t. the slice-token sums, their
+            #      masses and the shared to_q / to_k / to_v weights (per-(b,h) partials summed in fp64)
+            gT, gN, gWp = new(B, heads * G * 32), new(B, heads * G), new(B * heads, 3 * 1024)
+            am = st["amask"]
+            ops.slice_attn_train(st["tokS"], st["norm"], at.to_q.weight.data, at.to_k.weight.data, at.to_v.weight.data,
+                                 None if am is None else am.contiguous(), B * heads, G, go=gtok2, gT=gT, gN=gN, gW=gWp)
+            gW3 = new(3 * 1024)
+            ops.reduce_partials(gWp, B * heads, 3 * 1024, out_f32=gW3)
+            grads[at.to_q.weight], grads[at.to_k.weight], grads[at.to_v.weight] = (gW3[i * 1024:(i + 1) * 1024].view(32, 32).clone()
+                                                                                   for i in range(3))
             # ---- slice + deslice backward w.r.t. the dual-convolution output
             gxf = new(M, 2 * C)
             sp = new(B * bps, G * 32 + G + heads)
             temp = at.temperature.data.reshape(-1).contiguous()
-            ops.slice_bwd(st["xf"], st["w"], gox, st["tok2"], gT.contiguous().view(B, -1), gN.contiguous().view(B, -1),
+            ops.slice_bwd(st["xf"], st["w"], gox, st["tok2"], gT, gN,
                           at.in_project_slice.weight.data, temp, gxf, sp, B, ntok, heads, G)
             tot = new(G * 32 + G + heads)
             ops.reduce_partials(sp, B * bps, G * 32 + G + heads, out_f32=tot)

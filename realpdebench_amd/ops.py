@@ -173,6 +173,11 @@ def reduce_partials(part, rows, L, out_f32=None, out_f64=None, scale=1.0, accumu
               _p(out_f32), _p(out_f64, torch.float64), float(scale), int(accumulate), _stream())
 
 
+def reduce_partials_batched(part, nbatch, rows, L, out):
+    """out[b][j] = sum_r part[b][r][j]: ``nbatch`` independent fp64 reductions of contiguous [rows][L] blocks, one launch."""
+    _lib.call("rpb_reduce_partials_batched", _p(part), nbatch, rows, L, L, rows * L, _p(out), _stream())
+
+
 def bn_finalize(sums, count, eps, momentum, mean, invstd, rmean, rvar, C):
     _lib.call("rpb_bn_finalize", _p(sums, torch.float64), float(count), eps, momentum, _p(mean), _p(invstd), _p(rmean),
               _p(rvar), C, _stream())
@@ -366,6 +371,12 @@ def slice_fwd(xf, Ws, bs, temp, w_out, tok_part, norm_part, B, ntok, heads, G, l
 
 def slice_attn(tokS, norm, Wq, Wk, Wv, out, BH, G):
     _lib.call("rpb_slice_attn", _p(tokS), _p(norm), _p(Wq), _p(Wk), _p(Wv), _p(out), BH, G, _stream(), label="slice_attn")
+
+
+def slice_attn_train(tokS, norm, Wq, Wk, Wv, amask, BH, G, out=None, go=None, gT=None, gN=None, gW=None):
+    """Training-mode slice-token attention (attention-map dropout mask ``amask`` or None) and, with ``go``, its backward."""
+    _lib.call("rpb_slice_attn_train", _p(tokS), _p(norm), _p(Wq), _p(Wk), _p(Wv), _p(amask), _p(go), _p(out), _p(gT), _p(gN),
+              _p(gW), BH, G, _stream(), label="slice_attn_train")
 
 
 def deslice_fwd(w, tok2, out, B, ntok, heads, G):
