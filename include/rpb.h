@@ -197,6 +197,10 @@ int rpb_slice_bwd(const float* xf, const float* w, const float* gox, const float
                   void* stream);
 /*     out = a * b elementwise (dropout masks in the backward pass). */
 int rpb_mul(const float* a, const float* b, float* out, long n, void* stream);
+/*     out = a + b (gradient sum where the U-Net's tape forks) and strided row-block copies
+ *     dst[m][doff..doff+C) = src[m][soff..soff+C) (the skip-connection concat torch.cat(dim=1) of unet.py:463,479 and its split). */
+int rpb_add(const float* a, const float* b, float* out, long n, void* stream);
+int rpb_copy_cols(const float* src, float* dst, long M, int C, int lds, int ldd, int soff, int doff, void* stream);
 /*     column sums (bias / placeholder gradients): part[rpb_colsum_rows()][N]. */
 int rpb_colsum_rows(void);
 int rpb_colsum(const float* x, float* part, long M, int N, int ld, void* stream);

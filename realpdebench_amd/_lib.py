@@ -67,6 +67,8 @@ SIGNATURES = {
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
     "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiiii" + "lf" + "p"),
     "rpb_mul": (_I, "ppp" + "l" + "p"),
+    "rpb_add": (_I, "ppp" + "l" + "p"),
+    "rpb_copy_cols": (_I, "pp" + "l" + "iiiii" + "p"),
     "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
     "rpb_layernorm_bwd_rows": (_L, "l"),

@@ -631,3 +631,33 @@ extern "C" int rpb_mul(const float* a, const float* b, float* out, long n, void*
     hipLaunchKernelGGL(mul_kernel, dim3(pw_grid(n / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, a, b, out, n / 4);
     RPB_CHECK_LAUNCH("mul");
 }
+
+// out = a + b elementwise: the sum of two gradients where the U-Net's tape forks (residual / skip connections)
+__global__ __launch_bounds__(PW_THREADS) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+extern "C" int rpb_add(const float* a, const float* b, float* out, long n, void* stream) {
+    RPB_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "add: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3(pw_grid(n / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, a, b, out, n / 4);
+    RPB_CHECK_LAUNCH("add");
+}
+
+// dst[m][doff .. doff + C) = src[m][soff .. soff + C) for m < M (row strides ldd / lds floats): the skip-connection concat of
+// the U-Net (torch.cat((x, skip), dim=1), unet.py:463,479) and its backward split, as strided row copies (C % 4 == 0)
+__global__ __launch_bounds__(PW_THREADS) void copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, long M,
+                                                               int C4, int lds4, int ldd4, int soff4, int doff4) {
+    const long total = M * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C4;
+        const int c = (int)(i - m * C4);
+        reinterpret_cast<f32x4*>(dst)[m * ldd4 + doff4 + c] = reinterpret_cast<const f32x4*>(src)[m * lds4 + soff4 + c];
+    }
+}
+extern "C" int rpb_copy_cols(const float* src, float* dst, long M, int C, int lds, int ldd, int soff, int doff, void* stream) {
+    RPB_REQUIRE(src && dst && M > 0 && C > 0 && ((C | lds | ldd | soff | doff) & 3) == 0, "copy_cols: sizes must be multiples of 4");
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(pw_grid(M * (C / 4))), dim3(PW_THREADS), 0, (hipStream_t)stream, src, dst, M,
+                       C / 4, lds / 4, ldd / 4, soff / 4, doff / 4);
+    RPB_CHECK_LAUNCH("copy_cols");
+}

@@ -82,7 +82,7 @@ class _Tape:
 
     def acc(self, t, g):
         k = id(t)
-        self.g[k] = g if k not in self.g else self.g[k] + g
+        self.g[k] = g if k not in self.g else ops.add(self.g[k], g)
 
     def grad(self, t):
         return self.g.pop(id(t))
@@ -578,12 +578,18 @@ class Unet3d(_ModelBase):
         return tp.leaves[name]
 
     def _cat(self, tp, a, b, Ca, Cb):
-        y = torch.cat((a, b), dim=1)
+        M = a.shape[0]
+        y = _new(M, Ca + Cb, like=a)                         # torch.cat((x, skip), dim=1) of unet.py:463,479 as two row-block copies
+        ops.copy_cols(a, y, M, Ca, Ca, Ca + Cb, 0, 0)
+        ops.copy_cols(b, y, M, Cb, Cb, Ca + Cb, 0, Ca)
 
         def bwd():
             g = tp.grad(y)
-            tp.acc(a, g[:, :Ca].contiguous())
-            tp.acc(b, g[:, Ca:].contiguous())
+            ga, gb = _new(M, Ca, like=g), _new(M, Cb, like=g)
+            ops.copy_cols(g, ga, M, Ca, Ca + Cb, Ca, 0, 0)
+            ops.copy_cols(g, gb, M, Cb, Ca + Cb, Cb, Ca, 0)
+            tp.acc(a, ga)
+            tp.acc(b, gb)
 
         tp.add(bwd)
         return y

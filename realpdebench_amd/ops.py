@@ -647,3 +647,16 @@ def proj_wgrad(s, w1, b1, w2, gout, part, d, DO, xf, act=0):
     """Per-wave partial rows of d fc1.weight / d fc2.weight / d fc1.bias / d fc2.bias (layout: include/rpb.h)."""
     _lib.call("rpb_proj_wgrad", _p(s), _p(w1), _p(b1), _p(w2), _p(gout), _p(part), d.B, DO, *d.crop6, *_xf(xf), int(act),
               _stream(), label="proj_wgrad", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * 2 * d.C)
+
+
+def add(a, b):
+    """a + b as a new tensor (HIP kernel; shapes equal, numel % 4 == 0 else torch adds the handful of numbers)."""
+    if a.numel() % 4 or not a.is_cuda or a.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
+        return a + b
+    out = torch.empty_like(a)
+    _lib.call("rpb_add", _p(a), _p(b), _p(out), a.numel(), _stream(), label="add", nbytes=12 * a.numel())
+    return out
+
+
+def copy_cols(src, dst, M, C, lds, ldd, soff, doff):
+    _lib.call("rpb_copy_cols", _p(src), _p(dst), M, C, lds, ldd, soff, doff, _stream(), label="copy_cols", nbytes=8 * M * C)

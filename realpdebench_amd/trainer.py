@@ -18,9 +18,7 @@ from . import ops
 class Trainer:
     def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, betas=(0.9, 0.999), eps=1e-8,
                  clip_grad_norm=0.0):
-        if clip_grad_norm and clip_grad_norm > 0:
-            raise NotImplementedError("clip_grad_norm > 0 is not used by any FNO config of the reference "
-                                      "(configs/*/fno.yaml: clip_grad_norm: 0.) and is not implemented")
+        self.clip = float(clip_grad_norm or 0.0)       # train.py:330-331 (0 in every shipped FNO YAML)
         if scheduler not in ("cosine", "step"):
             raise ValueError(f"Scheduler {scheduler} not supported")          # train.py:296
         self.model = model
@@ -58,10 +56,17 @@ class Trainer:
         model._backward_impl(x, ws.gout, ws, self.grad)
         if dp is not None:
             dp.finish_step(self.grad)
+        gscale = 1.0
+        if self.clip > 0:
+            # torch.nn.utils.clip_grad_norm_ (train.py:330-331): total 2-norm over all parameters (complex weights count both
+            # parts: the arena holds them as 2 x fp32), coefficient min(1, max_norm / (norm + 1e-6)) folded into the Adam kernel's
+            # gradient scale; one host sync, only when clipping is on.  The arena's alignment gaps are zero.
+            norm = float(torch.linalg.vector_norm(self.grad))
+            gscale = min(1.0, self.clip / (norm + 1e-6))
         lr = self.current_lr()
         self.iteration += 1
         ops.adam_step(model.flat.data, self.grad, self.exp_avg, self.exp_avg_sq, model.flat.numel(), lr,
-                      self.betas[0], self.betas[1], self.eps, self.iteration)
+                      self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
         return ws.loss
 
     # ---- checkpoint in the reference's format (train.py:410-418)

