@@ -335,6 +335,18 @@ int rpb_linattn_prep_fwd(const float* qkv, const float* kmax, float* qe, int F, 
 int rpb_linattn_prep_bwd(const float* qe, const float* dqe, const float* dz, float* gqkv, int F, int n, void* stream);
 int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, int mode, void* stream);
 
+/* ---- layer-0 algebra (fno.py:106-111 feeding :113-116): A0 = pad(fc0 [x, grid]) is linear in the F + 1 = Cin + 4 feature fields
+ *      phi = (x_j, grid_t, grid_h, grid_w, 1), so the first spectral layer transforms the FIELDS (rpb_axis_gemm on a
+ *      [T][H][W][NB] tensor) and these kernels move between the field spectra Phi [2][M][NB] (columns b*Cin + j, then the four
+ *      shared fields at B*Cin..) and the 64-channel spectra: Xh[b][r][c] = sum_j W0ext[c][j] Phi[r][col(b, j)] (r = (re/im, mode),
+ *      M2 = 2 M rows) and the adjoint sum over (b, r) for d fc0 (part [rpb_feat_mix_wgrad_rows()][C][Cin + 4], last column = d bias).
+ *      rpb_small_atb: out (+)= A^T B for tiny matrices (the conv path of d fc0 = Wc0^T (sum_cells gs0 (x) phi)). */
+int rpb_feat_mix(const float* Phi, const float* w0, const float* b0, float* Xh, int B, int M2, int NB, int Cin, int C, void* stream);
+int rpb_feat_mix_wgrad_rows(void);
+int rpb_feat_mix_wgrad(const float* G, const float* Phi, float* part, int B, int M2, int NB, int Cin, int C, void* stream);
+int rpb_small_atb(const float* A, const float* Bm, float* out, int K, int M, int N, int lda, int ldb, int ldo, int accumulate,
+                  void* stream);
+
 /* ---- backward of the projection head without the gu round trips (fno.py:121-125 autograd; C = 64, DO <= 4, W >= 16):
  *      gh = (fc2^T gout) * act'(fc1 a + b1) is recomputed on the bf16 matrix pipe by each consumer instead of being written once
  *      ([ncrop][128] fp32) and read twice.  `s` is the PADDED pre-BatchNorm tensor of the last Fourier layer, a = xf(s) on the

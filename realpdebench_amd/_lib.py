@@ -22,6 +22,10 @@ SIGNATURES = {
     "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
     "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
     "rpb_spectrum_bin": (_I, "ppiip"),
+    "rpb_feat_mix": (_I, "pppp" + "iiiii" + "p"),
+    "rpb_feat_mix_wgrad_rows": (_I, ""),
+    "rpb_feat_mix_wgrad": (_I, "ppp" + "iiiii" + "p"),
+    "rpb_small_atb": (_I, "ppp" + "iiiiiii" + "p"),
     "rpb_proj_bwd_fused_supported": (_I, "iiii"),
     "rpb_proj_dgrad_slots": (_L, "iii"),
     "rpb_proj_dgrad": (_I, "pppppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),

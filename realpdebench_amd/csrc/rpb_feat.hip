@@ -1,0 +1,116 @@
+// Layer-0 algebra of FNO3d: the lifted input A0 = pad(fc0 [x, grid]) (fno.py:106-111) is LINEAR in F + 1 "feature fields"
+// phi = (x_0 .. x_{Cin-1}, grid_t, grid_h, grid_w, 1) (zero in the pad margin), A0 = W0ext phi with W0ext = [fc0.weight | fc0.bias].
+// The truncated DFT D of the first spectral layer is linear too, so
+//
+//   forward    X^0 = D(A0) = W0ext D(phi):     the three DFT stages run on the F + 1 fields (a [T][H][W][Cin*B + 4] tensor, ~2 % of
+//                                              the 64-channel A0) and rpb_feat_mix expands the result to 64 channels per mode;
+//   backward   d W0ext = sum_cells g_A0 (x) phi with g_A0 = Wc0^T gs0 + D^T g^x  splits into
+//                 conv path      Wc0^T (sum_cells gs0 (x) phi)          = rpb_small_atb(Wc0, rpb_lift_bwd(gs0))
+//                 spectral path  sum_modes g^x (x) D(phi)               = rpb_feat_mix_wgrad
+//              so layer 0's inverse DFT stages, its data-gradient cell_mix and the 3.8 GB gradient tensor they produce
+//              (whose only consumer was rpb_lift_bwd) disappear.
+//
+// Phi^ = D(phi) is laid out [2 (re, im)][M modes][NB columns]: columns b * Cin + j = field j of sample b, then the four
+// sample-independent fields (grid_t, grid_h, grid_w, 1) at columns B * Cin .. + 3 (NB = that, padded to a multiple of 64).
+#include "rpb_common.h"
+
+// Xh[b][ri][m][c] = sum_j W0[c][j] Phi[ri][m][b*Cin + j] + sum_j' W0[c][Cin + j'] Phi[ri][m][B*Cin + j']   (j' < 3)  + b0[c] Phi[..][B*Cin + 3]
+__global__ __launch_bounds__(256) void feat_mix_kernel(const float* __restrict__ Phi, const float* __restrict__ w0,
+                                                       const float* __restrict__ b0, float* __restrict__ Xh, int B, int M2,
+                                                       int NB, int Cin, int C) {
+    // one thread = 4 channels of one (b, row); rows = 2 * M
+    const int c4n = C >> 2;
+    const long total = (long)B * M2 * c4n;
+    const int F = Cin + 3;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long r = idx / c4n;
+        const int row = (int)(r % M2);
+        const int b = (int)(r / M2);
+        const float* ph = Phi + (long)row * NB;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < F + 1; ++j) {
+            const float v = j < Cin ? ph[b * Cin + j] : ph[B * Cin + (j - Cin)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * c4 + k;
+                acc[k] += v * (j < F ? w0[c * F + j] : b0[c]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(Xh + ((long)b * M2 + row) * C + 4 * c4) = acc;
+    }
+}
+
+extern "C" int rpb_feat_mix(const float* Phi, const float* w0, const float* b0, float* Xh, int B, int M2, int NB, int Cin, int C,
+                            void* stream) {
+    RPB_REQUIRE(Phi && w0 && b0 && Xh && B > 0 && M2 > 0 && C % 4 == 0 && NB >= B * Cin + 4, "feat_mix: bad arguments");
+    const long total = (long)B * M2 * (C / 4);
+    long grid = (total + 255) / 256;
+    const long cap = (long)rpb_num_cus() * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(feat_mix_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Phi, w0, b0, Xh, B, M2, NB, Cin, C);
+    RPB_CHECK_LAUNCH("feat_mix");
+}
+
+// part[block][c * (F + 1) + j] = sum over the block's (b, row) of G[b][row][c] * phi_j(b, row)     (j == F: the ones field -> d b0)
+// C = 64: a thread owns (channel c = tid & 63, feature group tid >> 6 of 4 threads); rows are walked block-cyclically.
+#define FM_FMAX 24
+__global__ __launch_bounds__(256) void feat_mix_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ Phi,
+                                                             float* __restrict__ part, int B, int M2, int NB, int Cin, int C) {
+    const int c = threadIdx.x % C;
+    const int grp = threadIdx.x / C, ngrp = blockDim.x / C;
+    const int F1 = Cin + 4;
+    float acc[FM_FMAX];
+#pragma unroll
+    for (int j = 0; j < FM_FMAX; ++j) acc[j] = 0.f;
+    const long rows = (long)B * M2;
+    for (long r = (long)blockIdx.x * ngrp + grp; r < rows; r += (long)gridDim.x * ngrp) {
+        const int row = (int)(r % M2);
+        const int b = (int)(r / M2);
+        const float g = G[r * C + c];
+        const float* ph = Phi + (long)row * NB;
+#pragma unroll
+        for (int j = 0; j < FM_FMAX; ++j) {
+            if (j < F1) acc[j] += g * (j < Cin ? ph[b * Cin + j] : ph[B * Cin + (j - Cin)]);
+        }
+    }
+    extern __shared__ float red[];          // [ngrp][C][F1]
+    for (int j = 0; j < F1; ++j) red[(grp * C + c) * F1 + j] = acc[j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * F1; idx += blockDim.x) {
+        float s = 0.f;
+        for (int g2 = 0; g2 < ngrp; ++g2) s += red[g2 * C * F1 + idx];
+        part[(long)blockIdx.x * C * F1 + idx] = s;
+    }
+}
+
+extern "C" int rpb_feat_mix_wgrad_rows(void) { return rpb_num_cus() * 2; }
+
+// part [rpb_feat_mix_wgrad_rows()][C][Cin + 4]: per-block partial sums of sum_(b,row) G[b][row][c] * phi_j; column Cin + 3 is d bias
+extern "C" int rpb_feat_mix_wgrad(const float* G, const float* Phi, float* part, int B, int M2, int NB, int Cin, int C,
+                                  void* stream) {
+    RPB_REQUIRE(G && Phi && part && B > 0 && M2 > 0 && C > 0 && 256 % C == 0 && Cin + 4 <= FM_FMAX && NB >= B * Cin + 4, "feat_mix_wgrad: bad arguments (C=%d Cin=%d)", C, Cin);
+    const int grid = rpb_feat_mix_wgrad_rows();
+    const size_t lds = (size_t)256 * (Cin + 4) * 4;
+    hipLaunchKernelGGL(feat_mix_wgrad_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, G, Phi, part, B, M2, NB, Cin, C);
+    RPB_CHECK_LAUNCH("feat_mix_wgrad");
+}
+
+// out[i][j] (+)= sum_k A[k][i] * Bm[k][j]   (A^T B for matrices of at most a few thousand elements: one workgroup)
+__global__ __launch_bounds__(256) void small_atb_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ out, int K, int M, int N, int lda, int ldb,
+                                                        int ldo, int accumulate) {
+    for (int idx = threadIdx.x; idx < M * N; idx += blockDim.x) {
+        const int i = idx / N, j = idx - i * N;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += (double)A[k * lda + i] * (double)Bm[k * ldb + j];
+        out[i * ldo + j] = accumulate ? out[i * ldo + j] + (float)s : (float)s;
+    }
+}
+
+extern "C" int rpb_small_atb(const float* A, const float* Bm, float* out, int K, int M, int N, int lda, int ldb, int ldo,
+                             int accumulate, void* stream) {
+    RPB_REQUIRE(A && Bm && out && K > 0 && M > 0 && N > 0 && (long)M * N <= 65536, "small_atb: bad arguments");
+    hipLaunchKernelGGL(small_atb_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, Bm, out, K, M, N, lda, ldb, ldo, accumulate);
+    RPB_CHECK_LAUNCH("small_atb");
+}

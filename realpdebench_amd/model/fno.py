@@ -51,6 +51,29 @@ class _Workspace:
         self.stat_part = torch.empty(self.stat_rows * 2 * C, **f) if training else None
         self.sums64 = torch.empty(2 * C, device=device, dtype=torch.float64)
         self.out = torch.empty(d.ncrop, model.dim_out, **f)
+        # layer-0 algebra (csrc/rpb_feat.hip): the first spectral layer transforms the Cin + 4 feature FIELDS instead of the 64
+        # lifted channels; in training its data gradient is never formed (only fc0's 64 x (Cin + 4) gradient is needed)
+        self.feat0 = (type(model)._lift_fwd is FNO3d._lift_fwd and C == 64 and os.environ.get("RPB_LAYER0_GENERIC") != "1")
+        if self.feat0:
+            T_, H_, W_, Cin = d.T, d.H, d.W, model.dim_in
+            self.NB = (B * Cin + 4 + 63) // 64 * 64
+            grids, _ = model._consts(device)
+            phi = torch.zeros(T_, H_, W_, self.NB, **f)
+            c0 = B * Cin
+            phi[..., c0] = grids[0].view(T_, 1, 1)
+            phi[..., c0 + 1] = grids[1].view(1, H_, 1)
+            phi[..., c0 + 2] = grids[2].view(1, 1, W_)
+            phi[..., c0 + 3] = 1.0
+            self.phi = phi
+            n1 = 2 * plan.KW * self.NB
+            self.fy1 = torch.empty(T_ * H_ * n1, **f)
+            self.fy2 = torch.empty(T_ * 2 * plan.KH * plan.KW * self.NB, **f)
+            self.PhiH = torch.empty(2 * plan.M * self.NB, **f)
+            if training:
+                self.fm_rows = ops.feat_mix_wgrad_rows()
+                self.fm_part = torch.empty(self.fm_rows * C * (Cin + 4), **f)
+                self.fm_sum = torch.empty(C * (Cin + 4), **f)
+                self.mgf = torch.empty(C * (Cin + 3) + C, **f)
         if training:
             self.G = [torch.empty(d.ncell, C, **f) for _ in range(2)]
             # projection-head backward: bf16-pipe kernels that recompute gh (no gu tensor) when the shape allows, else the
@@ -329,6 +352,20 @@ class FNO3d(Model):
         ops.axis_gemm(yh, ws.Y2, MT, d.B, 2 * KT, 2 * d.Tp, N3, 2 * KT * N3, N3, 2 * d.Tp * N3, N3)
         ops.axis_gemm(ws.Y2, ws.Y1, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
 
+    def _feature_spectrum(self, x, ws, plan):
+        """ws.PhiH [2][M][NB] = truncated DFT of the Cin + 4 feature fields (x_j per sample, grid_t, grid_h, grid_w, 1; zero in
+        the pad margin, which the stages skip through k_valid), batch-innermost so that the contiguous index is wide."""
+        d = ws.d
+        Cin, NB, m3, KH = self.dim_in, ws.NB, plan.KW, plan.KH
+        ws.phi[..., :d.B * Cin].copy_(x.permute(1, 2, 3, 0, 4).reshape(d.T, d.H, d.W, d.B * Cin))      # storage plumbing
+        n1, n2, n3 = NB, m3 * NB, KH * m3 * NB
+        ops.axis_gemm(ws.phi, ws.fy1, plan.FWt, d.T * d.H, d.Wp, 2 * m3, n1, d.W * n1, n1, 2 * m3 * n1, n1, k_valid=d.W,
+                      tag="featW")
+        ops.axis_gemm(ws.fy1, ws.fy2, plan.FHt, d.T, 2 * d.Hp, 2 * KH, n2, 2 * d.H * n2, n2, 2 * KH * n2, n2, k_valid=2 * d.H,
+                      tag="featH")
+        ops.axis_gemm(ws.fy2, ws.PhiH, plan.FTt, 1, 2 * d.Tp, 2 * plan.KT, n3, 2 * d.T * n3, n3, 2 * plan.KT * n3, n3,
+                      k_valid=2 * d.T, tag="featT")
+
     # ------------------------------------------------------------------ forward / backward pipelines
     def _layer_xf(self, ws, l, training):
         """Lazy-activation descriptor of layer ``l``'s output: (mean, invstd, gamma, beta, gelu)."""
@@ -347,7 +384,11 @@ class FNO3d(Model):
         for l in range(L):
             s = ws.S[l] if training else ws.S[l % 2]
             xh = ws.Xh[l] if training else ws.Xh[0]
-            self._spectral_forward_stages(a_in, ws, xh, (plan.FWt, plan.FHt, plan.FTt), first_layer=(l == 0), xf=xf)
+            if l == 0 and ws.feat0:
+                self._feature_spectrum(x, ws, plan)
+                ops.feat_mix(ws.PhiH, P("fc0.weight"), P("fc0.bias"), xh, d.B, 2 * plan.M, ws.NB, self.dim_in, C)
+            else:
+                self._spectral_forward_stages(a_in, ws, xh, (plan.FWt, plan.FHt, plan.FTt), first_layer=(l == 0), xf=xf)
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
             self._spectral_inverse_stages(ws.Yh, ws, (plan.GTt, plan.GHt))
             if training:
@@ -467,6 +508,23 @@ class FNO3d(Model):
                 self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward
             gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
+            if l == 0 and ws.feat0:
+                # d fc0 = sum_cells g_A0 (x) phi,  g_A0 = Wc0^T gs0 + D^T gX^: the spectral path contracts gX^ with the field
+                # spectra, the conv path is Wc0^T times the field moments of gs0 (rpb_lift_bwd applied to gs0 = g); the data
+                # gradient g_A0 itself (inverse stages + cell_mix + 3.8 GB) is never formed
+                Cin, F = self.dim_in, self.dim_in + 3
+                ops.feat_mix_wgrad(gxh, ws.PhiH, ws.fm_part, d.B, 2 * plan.M, ws.NB, Cin, C)
+                ops.reduce_partials(ws.fm_part, ws.fm_rows, C * (F + 1), out_f32=ws.fm_sum)
+                tot = ws.fm_sum.view(C, F + 1)
+                GP("fc0.weight").copy_(tot[:, :F])
+                GP("fc0.bias").copy_(tot[:, F])
+                ops.lift_bwd(g, x, grids, ws.lift_part, ws.d)
+                partl = ws.lift_part.view(ws.lift_rows, C * F + C)
+                self._reduce_cols(partl, 0, C * F + C, ws.mgf)
+                wc = P("convs.0.weight")
+                ops.small_atb(wc, ws.mgf[:C * F], GP("fc0.weight"), C, C, F, C, F, F, accumulate=True)
+                ops.small_atb(wc, ws.mgf[C * F:], GP("fc0.bias"), C, C, 1, C, 1, 1, accumulate=True)
+                break
             self._spectral_inverse_stages(gxh, ws, (plan.FT, plan.FH))
             if l > 0:      # g_x of layer l = gradient w.r.t. act(BN(s_{l-1})): also leave layer l-1's BN-backward sums
                 g_is_gz = gz_ok and l - 1 < L - 1
@@ -478,7 +536,8 @@ class FNO3d(Model):
                 ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW,
                              d.Wp, transpose_w=True)
             g, g2 = g2, g
-        self._lift_bwd(g, x, ws, gflat)
+        else:
+            self._lift_bwd(g, x, ws, gflat)
 
     # ------------------------------------------------------------------ lift stage (overridden by the Galerkin regressor)
     proj_act = 0           # activation between fc1 and fc2: 0 exact GELU (fno.py:124)

@@ -660,3 +660,21 @@ def add(a, b):
 
 def copy_cols(src, dst, M, C, lds, ldd, soff, doff):
     _lib.call("rpb_copy_cols", _p(src), _p(dst), M, C, lds, ldd, soff, doff, _stream(), label="copy_cols", nbytes=8 * M * C)
+
+
+def feat_mix(Phi, w0, b0, Xh, B, M2, NB, Cin, C):
+    _lib.call("rpb_feat_mix", _p(Phi), _p(w0), _p(b0), _p(Xh), B, M2, NB, Cin, C, _stream(), label="feat_mix",
+              nbytes=4 * B * M2 * C)
+
+
+def feat_mix_wgrad_rows():
+    return _lib.query("rpb_feat_mix_wgrad_rows")
+
+
+def feat_mix_wgrad(G, Phi, part, B, M2, NB, Cin, C):
+    _lib.call("rpb_feat_mix_wgrad", _p(G), _p(Phi), _p(part), B, M2, NB, Cin, C, _stream(), label="feat_mix_wgrad",
+              nbytes=4 * B * M2 * C)
+
+
+def small_atb(A, Bm, out, K, M, N, lda, ldb, ldo, accumulate=False):
+    _lib.call("rpb_small_atb", _p(A), _p(Bm), _p(out), K, M, N, lda, ldb, ldo, int(accumulate), _stream(), label="small_atb")
