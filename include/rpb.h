@@ -340,12 +340,24 @@ int rpb_col_reduce(const float* x, int ldx, float* part, int F, long n, int C, i
  *      [T][H][W][NB] tensor) and these kernels move between the field spectra Phi [2][M][NB] (columns b*Cin + j, then the four
  *      shared fields at B*Cin..) and the 64-channel spectra: Xh[b][r][c] = sum_j W0ext[c][j] Phi[r][col(b, j)] (r = (re/im, mode),
  *      M2 = 2 M rows) and the adjoint sum over (b, r) for d fc0 (part [rpb_feat_mix_wgrad_rows()][C][Cin + 4], last column = d bias).
- *      rpb_small_atb: out (+)= A^T B for tiny matrices (the conv path of d fc0 = Wc0^T (sum_cells gs0 (x) phi)). */
+ *      rpb_small_gemm: out[m][n] (+)= sum_k A[m*a_rs + k*a_cs] B[k*b_rs + n*b_cs] for tiny matrices (the composite weight
+ *      Wc0 W0ext and the conv paths of d fc0 / d convs.0.weight from the field moments sum_cells gs0 (x) phi). */
 int rpb_feat_mix(const float* Phi, const float* w0, const float* b0, float* Xh, int B, int M2, int NB, int Cin, int C, void* stream);
 int rpb_feat_mix_wgrad_rows(void);
 int rpb_feat_mix_wgrad(const float* G, const float* Phi, float* part, int B, int M2, int NB, int Cin, int C, void* stream);
-int rpb_small_atb(const float* A, const float* Bm, float* out, int K, int M, int N, int lda, int ldb, int ldo, int accumulate,
-                  void* stream);
+int rpb_small_gemm(const float* A, const float* Bm, float* out, int M, int N, int K, int a_rs, int a_cs, int b_rs, int b_cs,
+                   int ldo, int accumulate, void* stream);
+/*     Phi_c [ncell][FW] (FW = 8 or 32 >= Cin + 4): the feature fields per padded cell (x_j, grid_t, grid_h, grid_w, 1, 0..; zeros in
+ *     the pad margin).  Layer 0's channel mixing and conv weight gradient read it instead of the 64-channel lifted tensor:
+ *     rpb_cell_mix_feat / rpb_bn_bwd_row_feat. */
+int rpb_lift_feat(const float* x, const float* gt, const float* gh, const float* gw, float* out, int B, int T, int H, int W,
+                  int Cin, int Tp, int Hp, int Wp, int FW, void* stream);
+int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const float* bias, const float* z2, const float* GWt, float* out,
+                      float* stats_part, long ncell, int FW, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd,
+                      const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, void* stream);
+int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float* phi, float* gs, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, const float* sums, double count, int gelu, const float* GWt,
+                        float* Y1, float* part, int G, int Wp, int C, int K2, int FW, void* stream);
 
 /* ---- backward of the projection head without the gu round trips (fno.py:121-125 autograd; C = 64, DO <= 4, W >= 16):
  *      gh = (fc2^T gout) * act'(fc1 a + b1) is recomputed on the bf16 matrix pipe by each consumer instead of being written once

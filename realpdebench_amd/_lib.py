@@ -25,7 +25,10 @@ SIGNATURES = {
     "rpb_feat_mix": (_I, "pppp" + "iiiii" + "p"),
     "rpb_feat_mix_wgrad_rows": (_I, ""),
     "rpb_feat_mix_wgrad": (_I, "ppp" + "iiiii" + "p"),
-    "rpb_small_atb": (_I, "ppp" + "iiiiiii" + "p"),
+    "rpb_small_gemm": (_I, "ppp" + "iiiiiiiii" + "p"),
+    "rpb_lift_feat": (_I, "ppppp" + "iiiiiiiii" + "p"),
+    "rpb_cell_mix_feat": (_I, "ppppppp" + "l" + "iii" + "ppppi" + "p"),
+    "rpb_bn_bwd_row_feat": (_I, "ppppppppp" + "d" + "i" + "ppp" + "iiiii" + "p"),
     "rpb_proj_bwd_fused_supported": (_I, "iiii"),
     "rpb_proj_dgrad_slots": (_L, "iii"),
     "rpb_proj_dgrad": (_I, "pppppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),

@@ -66,9 +66,13 @@ struct BwdRowArgs {
     float* Y1;             // [G][K2][C]
     float* part;           // [nslots][C*C + C]
     int G, Wp, K2;
+    int feat_w;            // > 0 (layer 0): x is the feature tensor Phi_c [G*Wp][feat_w]; dW comes out as [C][feat_w] field moments
 };
 
-template <int C>
+// FEAT (layer 0 of FNO3d, csrc/rpb_feat.hip): the layer input A0 = W0ext Phi_c is never materialised; the weight-gradient operand
+// is the feature tensor itself (lane col < FW holds field col of the cell), so the partial holds sum_cells gs (x) phi in columns
+// 0 .. FW-1 of its C x C block, from which d convs.0.weight = (.) W0ext^T and the conv path of d fc0 follow by tiny GEMMs.
+template <int C, bool FEAT = false>
 __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
     constexpr int NT = C / 32;
     typedef typename RowVec<NT>::T vec;
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
     const long slot = (long)blockIdx.x * waves + wave;
     const long nslots = (long)gridDim.x * waves;
     const bool gelu = a.gelu != 0;
-    const bool has_xf = a.xf.mean != nullptr;
+    const bool has_xf = !FEAT && a.xf.mean != nullptr;
+    const int FW = a.feat_w;
 
     float mu[NT], is[NT], ga[NT], be[NT], m1[NT], m2[NT];
     XParam xp[NT];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
         const long off = g * (long)Wp * C;
         const rsrc_t rs = make_rsrc(a.s + off, row_bytes);
         const rsrc_t ry = make_rsrc(a.gy + off, row_bytes);
-        const rsrc_t rx = make_rsrc(a.x + off, row_bytes);
+        const rsrc_t rx = FEAT ? make_rsrc(a.x + g * (long)Wp * FW, (unsigned)Wp * FW * 4u) : make_rsrc(a.x + off, row_bytes);
         const rsrc_t ro = make_rsrc(a.gs + off, row_bytes);
         f32x16 accw[NT];
 #pragma unroll
@@ -134,7 +139,12 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
             for (int j = 0; j < 4; ++j) {
                 sv[j] = row_load<NT>(rs, vo + 2 * j * C * 4, 0);
                 yv[j] = row_load<NT>(ry, vo + 2 * j * C * 4, 0);
-                xv[j] = row_load<NT>(rx, vo + 2 * j * C * 4, 0);
+                if (FEAT) {        // field `col` of cell 8 c + 2 j + half (lanes past FW: an offset outside the descriptor -> 0)
+                    const int fo = col < FW ? ((c * 8 + 2 * j + half) * FW + col) * 4 : 0x7ffffff0;
+                    rset<NT>(xv[j], 0, buf_load_f32(rx, fo, 0));
+                } else {
+                    xv[j] = row_load<NT>(rx, vo + 2 * j * C * 4, 0);
+                }
             }
         };
         auto compute_chunk = [&](int c, const vec (&sv)[4], const vec (&yv)[4], const vec (&xv)[4]) {
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
                     const float v = ga[t] * is[t] * (gz - m1[t] - sh * m2[t]);
                     gsv[t] = valid ? v : 0.f;
                     rset<NT>(gout, t, gsv[t]);
-                    const float xv0 = rget<NT>(xv[j], t);
+                    const float xv0 = (FEAT && t > 0) ? 0.f : rget<NT>(xv[j], t);
                     xt[t] = has_xf ? xf_apply(xv0, xp[t], a.xf.gelu != 0) : xv0;
                 }
                 row_store<NT>(gout, ro, vo + 2 * j * C * 4, 0);          // pad steps fall outside the descriptor
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
                 for (int o = 0; o < NT; ++o) {
                     bsum[o] += gsv[o];
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) dW[o][i] = mfma32(gsv[o], xt[i], dW[o][i]);
+                    for (int i = 0; i < (FEAT ? 1 : NT); ++i) dW[o][i] = mfma32(gsv[o], xt[i], dW[o][i]);
                 }
             }
         };
@@ -192,9 +202,10 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
 #pragma unroll
     for (int o = 0; o < NT; ++o) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < (FEAT ? 1 : NT); ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[(long)(mfma_row(lane, r) * NT + o) * C + col * NT + i] = dW[o][i][r];
+            for (int r = 0; r < 16; ++r)
+                part[(long)(mfma_row(lane, r) * NT + o) * C + (FEAT ? col : col * NT + i)] = dW[o][i][r];
         const float b = bsum[o] + __shfl_xor(bsum[o], 32, 64);
         if (half == 0) part[(long)C * C + col * NT + o] = b;
     }
@@ -221,11 +232,31 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
     a.s = s; a.gy = gy; a.x = x; a.gs = gs; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
     a.sums = sums; a.inv_count = (float)(1.0 / count); a.gelu = gelu;
     a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
-    a.GWt = GWt; a.Y1 = Y1; a.part = part; a.G = G; a.Wp = Wp; a.K2 = K2;
+    a.GWt = GWt; a.Y1 = Y1; a.part = part; a.G = G; a.Wp = Wp; a.K2 = K2; a.feat_w = 0;
     const int grid = (int)(rpb_bn_bwd_row_slots(G) / 8);
     const size_t lds = (size_t)((Wp + 7) / 8 * 8) * 32 * 4;
     hipStream_t st = (hipStream_t)stream;
     if (C == 32) hipLaunchKernelGGL((bwd_row_kernel<32>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((bwd_row_kernel<64>), dim3(grid), dim3(512), lds, st, a);
     RPB_CHECK_LAUNCH("bn_bwd_row");
+}
+
+// layer 0 of FNO3d on the feature fields: as rpb_bn_bwd_row with x = Phi_c [G*Wp][FW] (rpb_lift_feat, FW = 8 or 32); the partial's
+// C x C block holds the field moments sum_cells gs (x) phi in its columns 0 .. FW-1 (the rest is not written), then [C] sum gs
+extern "C" int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float* phi, float* gs, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, const float* sums, double count,
+                                   int gelu, const float* GWt, float* Y1, float* part, int G, int Wp, int C, int K2, int FW,
+                                   void* stream) {
+    RPB_REQUIRE(s && gy && phi && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_feat: null pointer");
+    RPB_REQUIRE(C == 64 && (FW == 8 || FW == 32), "bn_bwd_row_feat: C=%d FW=%d unsupported", C, FW);
+    RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row_feat: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
+    BwdRowArgs a;
+    a.s = s; a.gy = gy; a.x = phi; a.gs = gs; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
+    a.sums = sums; a.inv_count = (float)(1.0 / count); a.gelu = gelu;
+    a.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    a.GWt = GWt; a.Y1 = Y1; a.part = part; a.G = G; a.Wp = Wp; a.K2 = K2; a.feat_w = FW;
+    const int grid = (int)(rpb_bn_bwd_row_slots(G) / 8);
+    const size_t lds = (size_t)((Wp + 7) / 8 * 8) * 32 * 4;
+    hipLaunchKernelGGL((bwd_row_kernel<64, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    RPB_CHECK_LAUNCH("bn_bwd_row_feat");
 }

@@ -413,6 +413,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.bnb = XForm{bnb_mean, bnb_invstd, bnb_gamma, bnb_beta, bnb_gelu != 0};
         c.write_gz = bnb_s != nullptr && bnb_gelu == 2;
         c.bf16_io = 0;
+        c.feat_w = 0;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
@@ -465,7 +466,30 @@ extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const floa
     c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
     c.write_gz = 0;
     c.bf16_io = 1;
+    c.feat_w = 0;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
+
+// layer 0 of FNO3d on the feature fields (csrc/rpb_feat.hip): out = GW z2 + Wcomp phi + bias with phi [ncell][FW] (rpb_lift_feat)
+// and Wcomp = convs.0.weight [fc0.weight | fc0.bias] [64][FW]; stats_part: BatchNorm forward sums (training) or NULL with the
+// oxf_* vectors (eval: store act(BN(out)))
+extern "C" int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const float* bias, const float* z2, const float* GW,
+                                 float* out, float* stats_part, long ncell, int FW, int K2, int Wp, const float* oxf_mean,
+                                 const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu,
+                                 void* stream) {
+    RPB_REQUIRE(phi && Wcomp && z2 && GW && out && (FW == 8 || FW == 32), "cell_mix_feat: bad arguments (FW=%d)", FW);
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false), "cell_mix_feat: needs K2 <= 32, Wp >= 32 (K2=%d Wp=%d)", K2, Wp);
+    if (oxf_mean) RPB_REQUIRE(!stats_part && oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_feat: output transform xor statistics");
+    CmxArgs c;
+    c.x = phi; c.Wm = Wcomp; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = stats_part;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.write_gz = 0;
+    c.bf16_io = 0;
+    c.feat_w = FW;
+    return rpb_cmx_launch(c, stats_part ? 1 : 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad

@@ -17,6 +17,7 @@ struct CmxArgs {
     const float* bnb_s;   // STATS == 2: pre-BN tensor of the layer whose output gradient this launch produces
     XForm bnb;            //             and that layer's BatchNorm; STATS == 0 with bnb.mean: OUTPUT transform (eval)
     int bf16_io;          // x and out are bf16 [ncell][64] (passed through the float pointers); eval path only
+    int feat_w;           // > 0: x is the feature tensor Phi_c [ncell][feat_w] and Wm the composite weight [64][feat_w] (layer 0, forward)
     int write_gz;         // STATS == 2: store gz = out * act'(z) instead of out (the consumer then skips act')
 };
 

@@ -71,9 +71,15 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // BF: activations are STORED as bf16 (x and out: [ncell][64] bf16, 128 B per cell; BASELINE.json configs[4]).  The x operand is
 //     then exactly one bf16 plane (no split: 3 products per weight column instead of 6) and a lane's 16 B load is its whole
 //     A operand of a K-step (k = (ks, kg, e) <-> channel 32 ks + 8 kg + e); arithmetic and accumulation stay fp32-grade.
-template <int STATS, bool BF = false>
+// FEAT: layer 0 -- x is the feature tensor Phi_c [ncell][FW] (FW = 8 or 32 floats per cell, rpb_lift_feat) and Wm the COMPOSITE
+//       weight Wc0 W0ext [64][FW]: A0 = W0ext Phi_c is never materialised, the channel mixing is one K-step (k = (kg, e) <->
+//       field 8 kg + e; lanes with 8 kg >= FW load nothing).
+template <int STATS, bool BF = false, bool FEAT = false>
 __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a) {
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
+    static_assert(!(BF && FEAT), "the feature tensor is fp32");
+    constexpr int KSN = FEAT ? 1 : 2;                    // K-steps of the channel mixing
+    const int FW = a.feat_w;
     constexpr int CMX_WAVES = CMX_WAVES_OF(STATS);
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
@@ -88,15 +94,16 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     const bool has_xf = a.xf.mean != nullptr;
 
     // ---- per-workgroup operand preparation
-    for (int idx = tid; idx < 2 * 4 * 64; idx += blockDim.x) {
+    for (int idx = tid; idx < KSN * 4 * 64; idx += blockDim.x) {
         const int l = idx & 63, t = (idx >> 6) & 3, ks = idx >> 8;
         const int n = l & 15, kgb = l >> 4;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ci = BF ? 32 * ks + 8 * kgb + e : 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
+            const int ci = (BF || FEAT) ? 32 * ks + 8 * kgb + e : 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
             const int co = 4 * n + t;
-            v[e] = a.transpose_w ? a.Wm[ci * 64 + co] : a.Wm[co * 64 + ci];
+            if (FEAT) v[e] = ci < FW ? a.Wm[co * FW + ci] : 0.f;
+            else v[e] = a.transpose_w ? a.Wm[ci * 64 + co] : a.Wm[co * 64 + ci];
         }
         bf16x8 h, md, lo;
         split8(v, h, md, lo);
@@ -148,14 +155,22 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     const long slot = (long)blockIdx.x * CMX_WAVES + wave;
     const unsigned line_bytes = (unsigned)Wp * (BF ? 128u : 256u);
     const long line_floats = (long)Wp * (BF ? 32 : 64);          // bf16 storage: two channels per float slot
+    const unsigned xline_bytes = FEAT ? (unsigned)Wp * FW * 4u : line_bytes;
+    const long xline_floats = FEAT ? (long)Wp * FW : line_floats;
     const int xoff = m * 256 + kg * 16;                  // byte offset of the lane's first 16 B inside a 16-cell block
     const int ooff = (4 * kg) * 256 + m * 16;            // output: cell 4 mg + r, channels 4 n ..
 
     u32x4 xa[2][4];
     // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
     auto issue_x = [&](long g, int q, int j, int ks) {
-        const rsrc_t rx = make_rsrc(a.x + g * line_floats, line_bytes);
-        if (BF) {
+        const rsrc_t rx = make_rsrc(a.x + g * xline_floats, xline_bytes);
+        if (FEAT) {                 // 32 B of fields 8 kg .. 8 kg + 7 (lane groups past FW: an offset outside the descriptor -> 0)
+            if (ks == 0) {
+                const int off = 8 * kg < FW ? (32 * q + 16 * j + m) * FW * 4 + kg * 32 : 0x7ffffff0;
+                xa[j][0] = ld16(rx, off);
+                xa[j][1] = ld16(rx, off + 16);
+            }
+        } else if (BF) {
             xa[j][ks] = ld16(rx, q * 4096 + j * 2048 + m * 128 + ks * 64 + kg * 16);
         } else {
 #pragma unroll
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
     for (long g = slot; g < G; g += nslots) {
         const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
-        const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.x, line_bytes);
+        const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
         for (int q = 0; q < TQ; ++q) {
             const bool last = q + 1 == TQ;
             const long gn = last ? g + nslots : g;                           // next wave tile: (gn, qn)
@@ -198,13 +213,22 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
             // ---- channel mixing: K = 64 = 2 steps of 32.  Per step: x registers -> A planes (lazy BN+GELU of the producer
             //      applied here), then the freed registers take the next wave tile's loads, in flight during everything below
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KSN; ++ks) {
                 bf16x8 Ah[2], Am[2], Al[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (j == 1 && half_tile) continue;
                     if (BF) {                       // the 16 B load IS the operand
                         Ah[j] = __builtin_bit_cast(bf16x8, xa[j][ks]);
+                        continue;
+                    }
+                    if (FEAT) {
+                        float v[8];
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[4 * hf + c] = __builtin_bit_cast(f32x4v, xa[j][hf])[c];
+                        split8(v, Ah[j], Am[j], Al[j]);
                         continue;
                     }
                     float v[8];
@@ -394,6 +418,17 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((cmx_kernel<ST_>), dim3(grid), dim3(waves * 64), lds, st, a);                          \
         RPB_CHECK_LAUNCH("cell_mix(bf16x3)");                                                                         \
+    }
+    if (a.feat_w) {
+        if (stats == 2 || a.bf16_io) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the feature-field input is a forward (layer 0) path");
+#define RPB_CMXF(ST_)                                                                                                          \
+    if (stats == ST_) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((cmx_kernel<ST_, false, true>), dim3(grid), dim3(waves * 64), lds, st, a);                          \
+        RPB_CHECK_LAUNCH("cell_mix(bf16x3, feature fields)");                                                                  \
+    }
+        RPB_CMXF(0) RPB_CMXF(1)
+#undef RPB_CMXF
     }
     if (a.bf16_io) {
         if (stats != 0) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: bf16 activation storage is an eval / rollout path (no statistics)");

@@ -96,21 +96,66 @@ extern "C" int rpb_feat_mix_wgrad(const float* G, const float* Phi, float* part,
     RPB_CHECK_LAUNCH("feat_mix_wgrad");
 }
 
-// out[i][j] (+)= sum_k A[k][i] * Bm[k][j]   (A^T B for matrices of at most a few thousand elements: one workgroup)
-__global__ __launch_bounds__(256) void small_atb_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                        float* __restrict__ out, int K, int M, int N, int lda, int ldb,
-                                                        int ldo, int accumulate) {
+// out[m][n] (+)= sum_k A[m*a_rs + k*a_cs] * Bm[k*b_rs + n*b_cs]   (strided operands: any transposition; matrices of at most a
+// few thousand elements, one workgroup, fp64 accumulation)
+__global__ __launch_bounds__(256) void small_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                         float* __restrict__ out, int M, int N, int K, int a_rs, int a_cs,
+                                                         int b_rs, int b_cs, int ldo, int accumulate) {
     for (int idx = threadIdx.x; idx < M * N; idx += blockDim.x) {
-        const int i = idx / N, j = idx - i * N;
+        const int m = idx / N, n = idx - m * N;
         double s = 0.0;
-        for (int k = 0; k < K; ++k) s += (double)A[k * lda + i] * (double)Bm[k * ldb + j];
-        out[i * ldo + j] = accumulate ? out[i * ldo + j] + (float)s : (float)s;
+        for (int k = 0; k < K; ++k) s += (double)A[m * a_rs + k * a_cs] * (double)Bm[k * b_rs + n * b_cs];
+        out[m * ldo + n] = accumulate ? out[m * ldo + n] + (float)s : (float)s;
     }
 }
 
-extern "C" int rpb_small_atb(const float* A, const float* Bm, float* out, int K, int M, int N, int lda, int ldb, int ldo,
-                             int accumulate, void* stream) {
-    RPB_REQUIRE(A && Bm && out && K > 0 && M > 0 && N > 0 && (long)M * N <= 65536, "small_atb: bad arguments");
-    hipLaunchKernelGGL(small_atb_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, Bm, out, K, M, N, lda, ldb, ldo, accumulate);
-    RPB_CHECK_LAUNCH("small_atb");
+extern "C" int rpb_small_gemm(const float* A, const float* Bm, float* out, int M, int N, int K, int a_rs, int a_cs, int b_rs,
+                              int b_cs, int ldo, int accumulate, void* stream) {
+    RPB_REQUIRE(A && Bm && out && K > 0 && M > 0 && N > 0 && (long)M * N <= 65536, "small_gemm: bad arguments");
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, Bm, out, M, N, K, a_rs, a_cs, b_rs,
+                       b_cs, ldo, accumulate);
+    RPB_CHECK_LAUNCH("small_gemm");
+}
+
+// Phi_c[cell][FW]: the feature fields per padded cell, channels-last -- (x_0 .. x_{Cin-1}, grid_t, grid_h, grid_w, 1, 0 ..) on the
+// cells of the data, all zeros in the pad margin.  It replaces the lifted tensor A0 = W0ext Phi_c (64 channels) as the input of
+// layer 0's channel mixing and of its weight gradient: 8 (or 32) floats per cell instead of 64.
+__global__ __launch_bounds__(256) void lift_feat_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                        const float* __restrict__ gh, const float* __restrict__ gw,
+                                                        float* __restrict__ out, long ncell, int Cin, int FW, CropMap cm) {
+    const int q4 = FW >> 2;
+    const long total = ncell * q4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long cell = idx / q4;
+        const int f0 = (int)(idx - cell * q4) * 4;
+        int w = (int)(cell % cm.Wp);
+        long r = cell / cm.Wp;
+        int h = (int)(r % cm.Hp);
+        r /= cm.Hp;
+        int t = (int)(r % cm.Tp);
+        const long b = r / cm.Tp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (w < cm.W && h < cm.H && t < cm.T) {
+            const float* xp = x + ((((b * cm.T + t) * cm.H + h) * (long)cm.W) + w) * Cin;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = f0 + k;
+                v[k] = f < Cin ? xp[f] : f == Cin ? gt[t] : f == Cin + 1 ? gh[h] : f == Cin + 2 ? gw[w] : f == Cin + 3 ? 1.f : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + cell * FW + f0) = v;
+    }
+}
+
+extern "C" int rpb_lift_feat(const float* x, const float* gt, const float* gh, const float* gw, float* out, int B, int T, int H,
+                             int W, int Cin, int Tp, int Hp, int Wp, int FW, void* stream) {
+    RPB_REQUIRE(x && gt && gh && gw && out && (FW == 8 || FW == 32) && Cin + 4 <= FW, "lift_feat: FW=%d must be 8 or 32 and hold Cin + 4 = %d fields", FW, Cin + 4);
+    const long ncell = (long)B * Tp * Hp * Wp;
+    const long total = ncell * (FW / 4);
+    long grid = (total + 255) / 256;
+    const long cap = (long)rpb_num_cus() * 16;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(lift_feat_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, gt, gh, gw, out, ncell, Cin,
+                       FW, CropMap{T, H, W, Tp, Hp, Wp});
+    RPB_CHECK_LAUNCH("lift_feat");
 }

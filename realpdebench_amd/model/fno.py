@@ -38,7 +38,16 @@ class _Workspace:
         # Lazy activations: a_{l+1} = act(BN(s_l)) is never materialised (its consumers transform s_l on load), so the
         # step keeps the lifted input A0 and the pre-BatchNorm tensors S[l] only.  Eval ping-pongs two S buffers.
         fa = dict(device=device, dtype=torch.bfloat16) if self.bf16 else f
-        self.A0 = torch.empty(d.ncell, C, **fa)
+        # layer 0 entirely on the feature fields (csrc/rpb_feat.hip): the 64-channel lifted tensor A0 is never materialised
+        self.FW = 8 if model.dim_in + 4 <= 8 else 32
+        self.featfull = (type(model)._lift_fwd is FNO3d._lift_fwd and C == 64 and not self.bf16 and model.dim_in + 4 <= 32
+                         and os.environ.get("RPB_LAYER0_GENERIC") != "1" and os.environ.get("RPB_LAYER0_A0") != "1"
+                         and ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True))
+        self.A0 = None if self.featfull else torch.empty(d.ncell, C, **fa)
+        if self.featfull:
+            self.phic = torch.empty(d.ncell, self.FW, **f)
+            self.w0ext = torch.zeros(C, self.FW, **f)
+            self.wcomp = torch.empty(C, self.FW, **f)
         self.S = [torch.empty(d.ncell, C, **fa) for _ in range(L if training else 2)]
         G1, N1 = B * d.Tp * d.Hp, 2 * plan.KW * C
         self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
@@ -74,6 +83,8 @@ class _Workspace:
                 self.fm_part = torch.empty(self.fm_rows * C * (Cin + 4), **f)
                 self.fm_sum = torch.empty(C * (Cin + 4), **f)
                 self.mgf = torch.empty(C * (Cin + 3) + C, **f)
+                self.mgf2 = torch.empty(C * C, **f)
+                self.dconv = torch.empty(C * (Cin + 4), **f)
         if training:
             self.G = [torch.empty(d.ncell, C, **f) for _ in range(2)]
             # projection-head backward: bf16-pipe kernels that recompute gh (no gu tensor) when the shape allows, else the
@@ -392,8 +403,12 @@ class FNO3d(Model):
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
             self._spectral_inverse_stages(ws.Yh, ws, (plan.GTt, plan.GHt))
             if training:
-                ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, ws.stat_part,
-                             d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
+                if l == 0 and ws.featfull:
+                    ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Y1, plan.GWt, s, ws.stat_part, d.ncell, ws.FW,
+                                      2 * plan.KW, d.Wp)
+                else:
+                    ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, ws.stat_part,
+                                 d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
                 ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
                 if world > 1:
                     self.dp.all_reduce_sum(ws.sums64)
@@ -406,7 +421,10 @@ class FNO3d(Model):
                 # cell_mix's epilogue and the next W stage / cell_mix / projection read plain activations (one erf per
                 # element instead of two)
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
-                if ws.bf16:
+                if l == 0 and ws.featfull:
+                    ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Y1, plan.GWt, s, None, d.ncell, ws.FW,
+                                      2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
+                elif ws.bf16:
                     ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d.ncell, C,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 else:
@@ -488,7 +506,13 @@ class FNO3d(Model):
                 self.dp.all_reduce_sum(ws.bn_sums)
             a_in = ws.A0 if l == 0 else ws.S[l - 1]          # layer input = lazily activated output of layer l-1
             xf_in = None if l == 0 else self._layer_xf(ws, l - 1, True)
-            if ws.fused_bwd:
+            feat_l0 = l == 0 and ws.featfull
+            if feat_l0:
+                # layer 0: the weight-gradient operand is the feature tensor; the partial's C x C block holds the field moments
+                ops.bn_bwd_row_feat(ws.S[l], g, ws.phic, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
+                                    float(d.ncell) * world, gelu, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp, d.Wp, C,
+                                    2 * plan.KW, ws.FW)
+            elif ws.fused_bwd:
                 # one pass: gs = BN/GELU backward (in place), Y1 = GW^T gs (adjoint W stage), conv wgrad partials
                 ops.bn_bwd_row(ws.S[l], g, a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
                                float(d.ncell) * world, gelu, xf_in, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
@@ -498,7 +522,12 @@ class FNO3d(Model):
                                  g, d.ncell, C, gelu)
                 ops.cell_wgrad(g, a_in, ws.wg_part, d.ncell, C, C, xf=xf_in)
             partc = ws.wg_part[:ws.wg_rows_c * (C * C + C)].view(ws.wg_rows_c, C * C + C)
-            self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
+            if feat_l0:
+                # Mgf[o][f] = sum_cells gs0[o] phi_f (columns f < FW of the block);  d convs.0.weight = Mgf W0ext^T
+                self._reduce_cols(partc, 0, C * C, ws.mgf2)
+                ops.small_gemm(ws.mgf2, ws.w0ext, GP("convs.0.weight"), C, C, ws.FW, C, 1, 1, ws.FW, C)
+            else:
+                self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
             self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GW, plan.GH, plan.GT),
@@ -518,12 +547,19 @@ class FNO3d(Model):
                 tot = ws.fm_sum.view(C, F + 1)
                 GP("fc0.weight").copy_(tot[:, :F])
                 GP("fc0.bias").copy_(tot[:, F])
+                wc = P("convs.0.weight")
+                if ws.featfull:            # field moments already left by the layer-0 row kernel: conv path = Wc0^T Mgf[:, :F+1]
+                    ops.small_gemm(wc, ws.mgf2, ws.dconv, C, F + 1, C, 1, C, C, 1, F + 1)
+                    dc = ws.dconv.view(C, F + 1)
+                    GP("fc0.weight").add_(dc[:, :F])
+                    GP("fc0.bias").add_(dc[:, F])
+                    break
                 ops.lift_bwd(g, x, grids, ws.lift_part, ws.d)
                 partl = ws.lift_part.view(ws.lift_rows, C * F + C)
                 self._reduce_cols(partl, 0, C * F + C, ws.mgf)
-                wc = P("convs.0.weight")
-                ops.small_atb(wc, ws.mgf[:C * F], GP("fc0.weight"), C, C, F, C, F, F, accumulate=True)
-                ops.small_atb(wc, ws.mgf[C * F:], GP("fc0.bias"), C, C, 1, C, 1, 1, accumulate=True)
+                # out[i][j] += sum_o Wc0[o][i] * Mgf[o][j]
+                ops.small_gemm(wc, ws.mgf[:C * F], GP("fc0.weight"), C, F, C, 1, C, F, 1, F, accumulate=True)
+                ops.small_gemm(wc, ws.mgf[C * F:], GP("fc0.bias"), C, 1, C, 1, C, 1, 1, 1, accumulate=True)
                 break
             self._spectral_inverse_stages(gxh, ws, (plan.FT, plan.FH))
             if l > 0:      # g_x of layer l = gradient w.r.t. act(BN(s_{l-1})): also leave layer l-1's BN-backward sums
@@ -549,7 +585,15 @@ class FNO3d(Model):
     def _lift_fwd(self, x, ws):
         """fno.py:106-111: ws.A0 = pad(fc0(cat(x, grid))), channels-last."""
         grids, _ = self._consts(x.device)
-        if ws.A0.dtype == torch.bfloat16:
+        if ws.featfull:
+            F = self.dim_in + 3
+            ops.lift_feat(x, grids, ws.phic, ws.d, ws.FW)
+            ws.w0ext[:, :F].copy_(self.pview("fc0.weight"))          # W0ext = [fc0.weight | fc0.bias | 0]: storage plumbing
+            ws.w0ext[:, F].copy_(self.pview("fc0.bias"))
+            # composite weight of layer 0's channel mixing: Wcomp = convs.0.weight W0ext  [64][FW]
+            ops.small_gemm(self.pview("convs.0.weight"), ws.w0ext, ws.wcomp, self.width, ws.FW, self.width, self.width, 1,
+                           ws.FW, 1, ws.FW)
+        elif ws.A0.dtype == torch.bfloat16:
             ops.lift_pad_fwd_bf16(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)
         else:
             ops.lift_pad_fwd(x, grids, self.pview("fc0.weight"), self.pview("fc0.bias"), ws.A0, ws.d)

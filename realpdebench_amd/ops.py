@@ -676,5 +676,26 @@ def feat_mix_wgrad(G, Phi, part, B, M2, NB, Cin, C):
               nbytes=4 * B * M2 * C)
 
 
-def small_atb(A, Bm, out, K, M, N, lda, ldb, ldo, accumulate=False):
-    _lib.call("rpb_small_atb", _p(A), _p(Bm), _p(out), K, M, N, lda, ldb, ldo, int(accumulate), _stream(), label="small_atb")
+def small_gemm(A, Bm, out, M, N, K, a_rs, a_cs, b_rs, b_cs, ldo, accumulate=False):
+    """out[m][n] (+)= sum_k A[m*a_rs + k*a_cs] * Bm[k*b_rs + n*b_cs] (tiny matrices, one workgroup)."""
+    _lib.call("rpb_small_gemm", _p(A), _p(Bm), _p(out), M, N, K, a_rs, a_cs, b_rs, b_cs, ldo, int(accumulate), _stream(),
+              label="small_gemm")
+
+
+def lift_feat(x, grids, out, d, FW):
+    _lib.call("rpb_lift_feat", _p(x), _p(grids[0]), _p(grids[1]), _p(grids[2]), _p(out), d.B, d.T, d.H, d.W, d.Cin, d.Tp, d.Hp,
+              d.Wp, FW, _stream(), label="lift_feat", nbytes=4 * (d.ncrop * d.Cin + d.ncell * FW))
+
+
+def cell_mix_feat(phi, Wcomp, bias, z2, GW, out, stats_part, ncell, FW, K2, Wp, oxf=None):
+    """Layer 0 on the feature tensor: out = GW z2 + Wcomp phi + bias (+ BatchNorm forward sums, or eval output transform)."""
+    _lib.call("rpb_cell_mix_feat", _p(phi), _p(Wcomp), _p(bias), _p(z2), _p(GW), _p(out), _p(stats_part), ncell, FW, K2, Wp,
+              *_xf(oxf), _stream(), label=f"cell_mix[feat{FW}->CO64,spec=1,stats={'oxf' if oxf is not None else int(stats_part is not None)}]",
+              nbytes=4 * (ncell * (FW + 64) + (ncell // Wp) * K2 * 64), flops=2 * ncell * 64 * (K2 + FW))
+
+
+def bn_bwd_row_feat(s, gy, phi, gs, mean, invstd, gamma, beta, sums, count, gelu, GWt, Y1, part, G, Wp, C, K2, FW):
+    _lib.call("rpb_bn_bwd_row_feat", _p(s), _p(gy), _p(phi), _p(gs), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
+              float(count), int(gelu), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, FW, _stream(),
+              label=f"bn_bwd_row[C{C},feat{FW}]", nbytes=4 * (3 * G * Wp * C + G * Wp * FW + G * K2 * C),
+              flops=2 * G * Wp * C * (FW + K2))
