@@ -290,7 +290,7 @@ def bench_rollout_bf16(dev):
     except Exception as e:                                      # pragma: no cover
         return {"status": f"unavailable: {e}"}
     from realpdebench_amd.rollout import autoregressive_rollout
-    shape, modes, L, B, n_ar = (64, 64, 64, 16), (4, 16, 16), 4, 8, 20
+    shape, modes, L, B, n_ar = (64, 64, 64, 16), (4, 16, 16), 4, 16, 20
     torch.manual_seed(0)
     m = FNO3d(*modes, L, 64, shape, shape).to(dev).eval()
     x = torch.randn(B, *shape, device=dev)

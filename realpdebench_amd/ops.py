@@ -153,7 +153,8 @@ def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transp
               int(transpose_w), int(gather), *crop6, *_xf(xf),
               *((None,) + _xf(None) if bnb is None else (_p(bnb[0]),) + _xf(bnb[1:], 2 if write_gz else None)), _stream(),
               label=f"cell_mix[KC{KC}->CO{CO},spec={int(spec)},stats={tag or int(stats) + int(bnb is not None)}]",
-              nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)),
+              nbytes=4 * (rows_in * KC + ncell * CO + (ncell // Wp * K2 * CO if spec else 0)
+                          + (ncell * CO if bnb is not None and oxf is None else 0)),     # BN-backward sums: the pre-BN tensor is read too
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
 
 

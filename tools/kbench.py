@@ -59,6 +59,11 @@ if "cell_mix" in which:
                                 bnb=(s_prev,) + xfg), nb + 4 * d.ncell * C, fl)
     timeit("cell_mix eval (out = gelu(bn(.)))",
            lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, None, d.ncell, C, C, K2, d.Wp, oxf=xfg), nb, fl)
+    phic = torch.randn(d.ncell, 8, **f)
+    wcomp = torch.randn(C, 8, **f)
+    timeit("cell_mix layer 0 (feature fields, spec+stats)",
+           lambda: ops.cell_mix_feat(phic, wcomp, bias, z2, plan.GWt, y, part, d.ncell, 8, K2, d.Wp),
+           4 * (d.ncell * (8 + C) + d.ncell // d.Wp * K2 * C), 2 * d.ncell * C * (K2 + 8))
     gu = torch.randn(d.ncrop, 128, **f)
     w1 = torch.randn(128, C, **f)
     timeit("cell_mix gather (fc1 dgrad)",
