@@ -144,20 +144,28 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                         Bh[t] = __builtin_bit_cast(bf16x8, u);
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (BFIN) break;
-                    float v[8];
+                if (!BFIN) {
+                    float v[4][8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float x = __builtin_bit_cast(f32x4v, zr[e])[t];
-                        if (XF) {
-                            // rows past k_valid must stay zero: the transform of a masked load is not
-                            x = (32 * ks + 8 * kg + e < a.k_valid) ? xf_apply(x, xp[t], xgelu) : 0.f;
+                        const f32x4v x4 = __builtin_bit_cast(f32x4v, zr[e]);
+                        // rows past k_valid must stay zero: the transform of a masked load is not
+                        const bool live = !XF || (32 * ks + 8 * kg + e < a.k_valid);
+#pragma unroll
+                        for (int t = 0; t < 4; t += 2) {                      // channel pairs: packed fp32 math
+                            f32x2 x = f32x2{x4[t], x4[t + 1]};
+                            if (XF) {
+                                x = pk_fma((x - f32x2{xp[t].mu, xp[t + 1].mu}) * f32x2{xp[t].is, xp[t + 1].is},
+                                           f32x2{xp[t].ga, xp[t + 1].ga}, f32x2{xp[t].be, xp[t + 1].be});
+                                if (xgelu) x = gelu2(x);
+                                x = live ? x : pk2(0.f);
+                            }
+                            v[t][e] = x[0];
+                            v[t + 1][e] = x[1];
                         }
-                        v[e] = x;
                     }
-                    split8(v, Bh[t], Bm[t], Bl[t]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) split8(v[t], Bh[t], Bm[t], Bl[t]);
                 }
                 // ---- next step's loads go out now and are in flight during the MFMAs below
                 if (ks + 1 < KS) issue(ks + 1);

@@ -155,6 +155,30 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
                 const bool valid = c * 8 + 2 * j + half < Wp;
                 float gsv[NT], xt[NT];
                 vec gout;
+                if constexpr (NT == 2) {           // the lane's two channels are a pair: packed fp32 math
+                    const f32x2 isv = f32x2{is[0], is[1]}, gav = f32x2{ga[0], ga[1]};
+                    const f32x2 sh = (sv[j] - f32x2{mu[0], mu[1]}) * isv;
+                    f32x2 gz = yv[j];
+                    if (gelu) gz = gz * gelu_grad2(pk_fma(sh, gav, f32x2{be[0], be[1]}));
+                    f32x2 v = (gav * isv) * ((gz - f32x2{m1[0], m1[1]}) - sh * f32x2{m2[0], m2[1]});
+                    v = valid ? v : pk2(0.f);
+                    gout = v;
+                    gsv[0] = v[0];
+                    gsv[1] = v[1];
+                    if (FEAT) {
+                        xt[0] = xv[j][0];
+                        xt[1] = 0.f;
+                    } else {
+                        f32x2 xx = xv[j];
+                        if (has_xf) {
+                            xx = pk_fma((xx - f32x2{xp[0].mu, xp[1].mu}) * f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].ga, xp[1].ga},
+                                        f32x2{xp[0].be, xp[1].be});
+                            if (a.xf.gelu != 0) xx = gelu2(xx);
+                        }
+                        xt[0] = xx[0];
+                        xt[1] = xx[1];
+                    }
+                } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const float sh = (rget<NT>(sv[j], t) - mu[t]) * is[t];
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
                     rset<NT>(gout, t, gsv[t]);
                     const float xv0 = (FEAT && t > 0) ? 0.f : rget<NT>(xv[j], t);
                     xt[t] = has_xf ? xf_apply(xv0, xp[t], a.xf.gelu != 0) : xv0;
+                }
                 }
                 row_store<NT>(gout, ro, vo + 2 * j * C * 4, 0);          // pad steps fall outside the descriptor
                 const float aw = mp[2 * j * 32];

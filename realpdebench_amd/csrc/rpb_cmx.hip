@@ -136,12 +136,12 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     const bool oxf = STATS == 0 && a.bnb.mean != nullptr;
     float bv[4];
     XParam bp[4];
-    float ssum[4], ssq[4];
+    f32x2 ssum[2], ssq[2];                           // channel pairs (4 n, 4 n + 1), (4 n + 2, 4 n + 3)
+    ssum[0] = ssum[1] = ssq[0] = ssq[1] = pk2(0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         bv[t] = a.bias ? a.bias[4 * m + t] : 0.f;
         if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, 4 * m + t);
-        ssum[t] = ssq[t] = 0.f;
     }
     const bool xgelu = a.xf.gelu != 0;
     const bool bgelu = a.bnb.gelu != 0;
@@ -241,9 +241,12 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
                             const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + 64 + 16 * i + 4 * kg);
                             const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 128 + 16 * i + 4 * kg);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const float z = fmaf(xv[c] - mu[c], sc[c], be[c]);
-                                v[4 * hf + c] = xgelu ? gelu_f(z) : z;
+                            for (int c = 0; c < 4; c += 2) {         // channel pairs: packed fp32 math
+                                f32x2 z = pk_fma(f32x2{xv[c], xv[c + 1]} - f32x2{mu[c], mu[c + 1]}, f32x2{sc[c], sc[c + 1]},
+                                                 f32x2{be[c], be[c + 1]});
+                                if (xgelu) z = gelu2(z);
+                                v[4 * hf + c] = z[0];
+                                v[4 * hf + c + 1] = z[1];
                             }
                         } else {
 #pragma unroll
@@ -339,22 +342,29 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
                         const bool valid = !MASKED || (32 * q + 16 * j + 4 * kg + r < Wp);
                         f32x4v o;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            float v = acc[j][t][r];
-                            if (STATS == 0 && oxf) v = xf_apply(v, bp[t], bgelu);
-                            if (STATS == 1) {
-                                const float vm = valid ? v : 0.f;
-                                ssum[t] += vm;
-                                ssq[t] = fmaf(vm, vm, ssq[t]);
-                            } else if (STATS == 2) {
-                                const float sh = (__builtin_bit_cast(f32x4v, spre[j][r])[t] - bp[t].mu) * bp[t].is;
-                                float gz = bgelu ? v * gelu_grad_f(sh * bp[t].ga + bp[t].be) : v;
-                                if (a.write_gz) v = gz;
-                                gz = valid ? gz : 0.f;
-                                ssum[t] += gz;
-                                ssq[t] = fmaf(gz, sh, ssq[t]);
+                        for (int t = 0; t < 4; t += 2) {             // channel pairs: packed fp32 math
+                            f32x2 v = f32x2{acc[j][t][r], acc[j][t + 1][r]};
+                            if (STATS == 0 && oxf) {
+                                v = pk_fma((v - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is},
+                                           f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
+                                if (bgelu) v = gelu2(v);
                             }
-                            o[t] = v;
+                            if (STATS == 1) {
+                                const f32x2 vm = valid ? v : pk2(0.f);
+                                ssum[t >> 1] += vm;
+                                ssq[t >> 1] = pk_fma(vm, vm, ssq[t >> 1]);
+                            } else if (STATS == 2) {
+                                const f32x4v sp = __builtin_bit_cast(f32x4v, spre[j][r]);
+                                const f32x2 sh = (f32x2{sp[t], sp[t + 1]} - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is};
+                                f32x2 gz = v;
+                                if (bgelu) gz = v * gelu_grad2(pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be}));
+                                if (a.write_gz) v = gz;
+                                gz = valid ? gz : pk2(0.f);
+                                ssum[t >> 1] += gz;
+                                ssq[t >> 1] = pk_fma(gz, sh, ssq[t >> 1]);
+                            }
+                            o[t] = v[0];
+                            o[t + 1] = v[1];
                         }
                         if (BF) {               // round to nearest even, 4 channels = 8 B per lane, 128 B per cell row
                             typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
         float* part = a.stats_part + ((long)blockIdx.x * CMX_WAVES + wave) * 128;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float s1 = ssum[t], s2 = ssq[t];
+            float s1 = ssum[t >> 1][t & 1], s2 = ssq[t >> 1][t & 1];
             s1 += __shfl_xor(s1, 16, 64);
             s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);

@@ -101,6 +101,48 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// The same functions on channel PAIRS: gfx950 issues v_pk_{fma,mul,add}_f32 (two fp32 lanes per VGPR pair) at the rate of the
+// scalar forms, so the polynomial, the affine transforms and the statistics cost half the VALU slots; only |x|, min, exp2 and
+// the sign transfer stay per element.  Element-wise the operations (and therefore the results) are those of the scalar forms.
+__device__ __forceinline__ f32x2 pk2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 fast_erf2(f32x2 x) {
+    const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), pk2(4.0f));
+    f32x2 p = pk2(1.160457393e-05f);
+    p = pk_fma(p, t, pk2(-1.529619341e-04f));
+    p = pk_fma(p, t, pk2(8.482242992e-04f));
+    p = pk_fma(p, t, pk2(-2.274763673e-03f));
+    p = pk_fma(p, t, pk2(8.477856228e-05f));
+    p = pk_fma(p, t, pk2(2.772449465e-02f));
+    p = pk_fma(p, t, pk2(-1.483079179e-01f));
+    p = pk_fma(p, t, pk2(-9.184428993e-01f));
+    p = pk_fma(p, t, pk2(-1.627907267e+00f));
+    const f32x2 q = p * t;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 r = pk2(1.0f) - e;
+    return f32x2{copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    return (pk2(0.5f) * x) * (pk2(1.0f) + fast_erf2(x * pk2(0.70710678118654752440f)));
+}
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+    const f32x2 cdf = pk2(0.5f) * (pk2(1.0f) + fast_erf2(x * pk2(0.70710678118654752440f)));
+    const f32x2 q = (pk2(-0.72134752044448170368f) * x) * x;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    return cdf + x * (pk2(0.39894228040143267794f) * e);
+}
+
+// four channels at once (two packed pairs)
+__device__ __forceinline__ f32x4 join4(f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; }
+__device__ __forceinline__ f32x4 gelu4(f32x4 x) { return join4(gelu2(x.lo), gelu2(x.hi)); }
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 x) { return join4(gelu_grad2(x.lo), gelu_grad2(x.hi)); }
+// shat = (x - mu) * is;  z = shat * ga + be
+__device__ __forceinline__ f32x4 bn4(f32x4 x, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, f32x4* shat = nullptr) {
+    const f32x2 s0 = (x.lo - mu.lo) * is.lo, s1 = (x.hi - mu.hi) * is.hi;
+    if (shat) *shat = join4(s0, s1);
+    return join4(pk_fma(s0, ga.lo, be.lo), pk_fma(s1, ga.hi, be.hi));
+}
+
 // Lazy activation: a layer output a = act(gamma * (s - mean) * invstd + beta) is never written to HBM; its consumers
 // read the pre-BatchNorm tensor s and apply this per-channel transform on load (fno.py:117-119 fused into :48,:115,:123).
 struct XForm {

@@ -224,13 +224,10 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_dgrad_kernel(PjxArgs p) {
                     const f32x4v is = *reinterpret_cast<const f32x4v*>(xfl + 64 + 16 * i + 4 * kg);
                     const f32x4v ga = *reinterpret_cast<const f32x4v*>(xfl + 128 + 16 * i + 4 * kg);
                     const f32x4v be = *reinterpret_cast<const f32x4v*>(xfl + 192 + 16 * i + 4 * kg);
+                    f32x4v z = bn4(xv, mu, is, ga, be, &shat[i]);            // channel pairs: packed fp32 math
+                    if (xgelu) z = gelu4(z);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float sh = (xv[c] - mu[c]) * is[c];
-                        shat[i][c] = sh;
-                        const float z = sh * ga[c] + be[c];
-                        v[4 * hf + c] = xgelu ? gelu_f(z) : z;
-                    }
+                    for (int c = 0; c < 4; ++c) v[4 * hf + c] = z[c];
                 }
                 bf16x8 Bh, Bm, Bl;
                 split8(v, Bh, Bm, Bl);
@@ -456,11 +453,10 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_wgrad_kernel(PjxArgs p) {
                         const f32x4v is = *reinterpret_cast<const f32x4v*>(xfl + 64 + 16 * i + 4 * kg);
                         const f32x4v ga = *reinterpret_cast<const f32x4v*>(xfl + 128 + 16 * i + 4 * kg);
                         const f32x4v be = *reinterpret_cast<const f32x4v*>(xfl + 192 + 16 * i + 4 * kg);
+                        f32x4v z = bn4(xv, mu, is, ga, be);
+                        if (xgelu) z = gelu4(z);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float z = (xv[c] - mu[c]) * is[c] * ga[c] + be[c];
-                            v[4 * hf + c] = xgelu ? gelu_f(z) : z;
-                        }
+                        for (int c = 0; c < 4; ++c) v[4 * hf + c] = z[c];
                     }
                     split8(v, Ah[j], Am[j], Al[j]);
                 }
@@ -519,14 +515,15 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_wgrad_kernel(PjxArgs p) {
                 const f32x4v bmu = *reinterpret_cast<const f32x4v*>(xfl + 4 * n16), bis = *reinterpret_cast<const f32x4v*>(xfl + 64 + 4 * n16);
                 const f32x4v bga = *reinterpret_cast<const f32x4v*>(xfl + 128 + 4 * n16), bbe = *reinterpret_cast<const f32x4v*>(xfl + 192 + 4 * n16);
 #pragma unroll
+                for (int e = 0; e < 8; ++e) {       // rows of cells >= W read as 0 but xf(0) != 0: their gh is 0, so the product vanishes anyway
+                    xr[e] = bn4(xr[e], bmu, bis, bga, bbe);
+                    if (xgelu) xr[e] = gelu4(xr[e]);
+                }
+#pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float z = (xr[e][u] - bmu[u]) * bis[u] * bga[u] + bbe[u];
-                        // rows of cells >= W read as 0 but xf(0) != 0: their gh is 0, so the product vanishes anyway
-                        v[e] = xgelu ? gelu_f(z) : z;
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = xr[e][u];
                     bf16x8 Xh, Xm, Xl;
                     split8(v, Xh, Xm, Xl);
 #pragma unroll
