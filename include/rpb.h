@@ -415,6 +415,44 @@ int rpb_dp_allreduce_wait(void* handle, void* consumer_stream);
 int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream);
 int rpb_dp_allreduce_destroy(void* handle);
 
+/* ---- DPOT: AFNO patch transformer (realpdebench/model/dpot.py + dpot_libs/models/dpot.py).  Tokens are
+ *      channels-last rows; the dense layers run on rpb_gemm_nt / rpb_gemm_tn, the 2-D DFT stages on rpb_axis_gemm.
+ *      rpb_dpot_patch_tokens: PatchEmbed's input gather -- P[((b*nx + px)*ny + py)*T + t][(c*ps + i)*ps + j] for the conv weight
+ *        [E][Cm + 3][ps][ps] (dpot.py:199-203): c < Cd data channel of u [B][T][H][W][Cd], Cd <= c < Cm the wrapper's ones padding
+ *        (model/dpot.py:213-221), then get_grid_3d's x / y / t coordinates (dpot.py:352-363,370-372).
+ *      rpb_rowtable_add / _grad: x[r][:] += table[(r / rows_per_entry) % nent][:] (x + pos_embed, dpot.py:375) and d table.
+ *      rpb_dpot_tagg_prep / _finish: TimeAggregator 'exp_mlp' (dpot.py:227-241): e[t][i] = cos(tt[t] gamma[i]); Wb [(t,i)][j] = e w and
+ *        its transpose Wf [j][(t,i)], the W operands of the data-gradient / forward token GEMMs (K = T*C resp. N = T*C);
+ *        finish: dWb -> d w, d gamma.
+ *      rpb_gn_tokens_fwd / _bwd: torch.nn.GroupNorm(G, C) (dpot.py:143,151) of x (+ x2) [B][P][C]; stat [B*G][2] = (mean, rstd);
+ *        bwd: gx (+ gadd), pg / pb [B][C] per-sample partials of d weight / d bias.
+ *      rpb_afno_wprep / _mlp / _wgrad: AFNO2D's block-diagonal complex MLP on the kept modes (dpot.py:72-94).  Spectral rows
+ *        [ntok][2 (re, im)][C = nb*bs]; wprep turns w [2][nb][bs][bs] into the real composite [nb][2 bs][2 bs] (transpose != 0: its
+ *        transpose); mlp mode 0: out = (gelu(X Wa + ba)) Wb + bb with the pre-activation saved to `mid` (optional),
+ *        mode 1: mid = (X Wa) * gelu'(aux), out = mid Wb (data gradient with the transposed composites);
+ *        wgrad: dw [2][nb][bs][bs] = complex-structured sum_tok A^T G (A through GELU when a_gelu), part [rpb_afno_wgrad_splits][nb][2bs][2bs].
+ *      rpb_dpot_unpatch(_bwd): out_layer rows O[(((b*nx + px)*ny + py)*ps + i)*ps + j][ldo], column t*Co + c, <-> [B][T][H][W][Cd]
+ *        (dpot.py:395-396 and the channel slice of model/dpot.py:227). */
+int rpb_dpot_patch_tokens(const float* u, const float* gx, const float* gy, const float* gt, float* P, int B, int T, int H, int W,
+                          int Cd, int Cm, int ps, void* stream);
+int rpb_rowtable_add(float* x, const float* table, long M, int C, int rows_per_entry, int nent, void* stream);
+int rpb_rowtable_grad(const float* g, float* dtable, int B, int C, int rows_per_entry, int nent, void* stream);
+int rpb_dpot_tagg_prep(const float* w, const float* gamma, const float* tt, float* Wf, float* Wb, float* e_out, int T, int C,
+                       void* stream);
+int rpb_dpot_tagg_finish(const float* dWb, const float* w, const float* gamma, const float* tt, float* dw, float* dgamma, int T,
+                         int C, void* stream);
+int rpb_gn_tokens_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float* y, float* stat, int B, int P,
+                      int C, int G, float eps, void* stream);
+int rpb_gn_tokens_bwd(const float* x, const float* x2, const float* gamma, const float* stat, const float* gy, const float* gadd,
+                      float* gx, float* pg, float* pb, int B, int P, int C, int G, void* stream);
+int rpb_afno_wprep(const float* w, float* Wc, int nb, int bs_in, int bs_out, int transpose, void* stream);
+int rpb_afno_mlp(const float* X, const float* Wa, const float* ba, const float* Wb, const float* bb, const float* aux, float* mid,
+                 float* out, long ntok, int nb, int bs, int mode, void* stream);
+int rpb_afno_wgrad_splits(long ntok);
+int rpb_afno_wgrad(const float* A, const float* G, float* part, float* dw, long ntok, int nb, int bs, int a_gelu, void* stream);
+int rpb_dpot_unpatch(const float* O, float* pred, int B, int T, int H, int W, int Cd, int Co, int ps, int ldo, void* stream);
+int rpb_dpot_unpatch_bwd(const float* gpred, float* gO, int B, int T, int H, int W, int Cd, int Co, int ps, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

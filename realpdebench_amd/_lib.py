@@ -36,6 +36,19 @@ SIGNATURES = {
     "rpb_proj_wgrad_row": (_I, "i"),
     "rpb_proj_wgrad_roles": (_I, ""),
     "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
+    "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),
+    "rpb_rowtable_add": (_I, "pp" + "l" + "iii" + "p"),
+    "rpb_rowtable_grad": (_I, "pp" + "iiii" + "p"),
+    "rpb_dpot_tagg_prep": (_I, "pppppp" + "ii" + "p"),
+    "rpb_dpot_tagg_finish": (_I, "pppppp" + "ii" + "p"),
+    "rpb_gn_tokens_fwd": (_I, "pppppp" + "iiii" + "f" + "p"),
+    "rpb_gn_tokens_bwd": (_I, "ppppppppp" + "iiii" + "p"),
+    "rpb_afno_wprep": (_I, "pp" + "iiii" + "p"),
+    "rpb_afno_mlp": (_I, "pppppppp" + "l" + "iii" + "p"),
+    "rpb_afno_wgrad_splits": (_I, "l"),
+    "rpb_afno_wgrad": (_I, "pppp" + "l" + "iii" + "p"),
+    "rpb_dpot_unpatch": (_I, "pp" + "iiiiiiii" + "p"),
+    "rpb_dpot_unpatch_bwd": (_I, "pp" + "iiiiiiii" + "p"),
     "rpb_dp_available": (_I, ""),
     "rpb_dp_unique_id": (_I, "p"),
     "rpb_dp_allreduce_init": (_I, "piip"),

@@ -1,0 +1,489 @@
+"""DPOT (AFNO patch transformer) on MI355X -- drop-in for ``realpdebench.model.dpot.DPOT`` with ``model_type='dpot'``
+(reference realpdebench/model/dpot.py:21-289 wrapping dpot_libs/models/dpot.py:22-404), built by ``load_model`` like
+``realpdebench/model/load_model.py:108-131`` for the configuration family of the reference's ``configs/*/dpot_{s,l}.yaml``:
+2-D ``DPOTNet``, ``normalize=False``, GELU, ``time_agg`` 'exp_mlp' or 'mlp', data resolution == ``img_size``.
+
+Pipeline (token rows channels-last; every product runs in a HIP kernel of ``csrc/``):
+  PatchEmbed (dpot.py:183-211): the wrapper's channel padding with ones, the (x, y, t) grid channels and the patch gather in ONE
+  kernel (rpb_dpot_patch_tokens, token order (b, px, py, t)) -> token GEMM + GELU -> token GEMM (+ bias), + pos_embed
+  (rpb_rowtable_add) -> TimeAggregator (dpot.py:227-241) as ONE token GEMM with K = T*E on weights pre-scaled by cos(t gamma)
+  (rpb_dpot_tagg_prep; the (b, px, py, t) order makes the (t, channel) contraction contiguous) ->
+  depth x Block (dpot.py:139-180): GroupNorm(8) (rpb_gn_tokens) -> AFNO2D (dpot.py:22-108): rfft2 / irfft2 as two small real DFT
+  GEMM stages each (rpb_axis_gemm; all kept modes), the block-diagonal complex MLP on the fp32 MFMA (rpb_afno_mlp), + skip ->
+  GroupNorm(8) -> 1x1-conv MLP as two token GEMMs (GELU / residual fused) ->
+  out_layer (dpot.py:306-312): ConvTranspose2d(stride = kernel) as a token GEMM to pixel-major rows, two per-pixel GEMMs ->
+  rpb_dpot_unpatch to ``[B, T_out, H, W, C_data]``.
+The training backward mirrors it with the same kernels (data gradients = token GEMMs on transposed weights, weight gradients =
+TN GEMMs, rpb_afno_mlp mode 1 / rpb_afno_wgrad, rpb_gn_tokens_bwd); there is no PyTorch fallback.  ``cls_head`` (dpot.py:296-302)
+exists for state_dict compatibility; its output is discarded by the wrapper (model/dpot.py:224) and never computed here.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .galerkin_transformer import _wgrad
+from .model import Model as _ModelBase
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+class _AFNO2D(nn.Module):
+    """Parameter container of dpot.py:22-48 (same shapes and initial distribution)."""
+
+    def __init__(self, width, num_blocks):
+        super().__init__()
+        bs = width // num_blocks
+        scale = 1.0 / (bs * bs)
+        self.w1 = nn.Parameter(scale * torch.rand(2, num_blocks, bs, bs))
+        self.b1 = nn.Parameter(scale * torch.rand(2, num_blocks, bs))
+        self.w2 = nn.Parameter(scale * torch.rand(2, num_blocks, bs, bs))
+        self.b2 = nn.Parameter(scale * torch.rand(2, num_blocks, bs))
+
+
+class _Block(nn.Module):
+    def __init__(self, width, n_blocks, mlp_ratio):
+        super().__init__()
+        hid = int(width * mlp_ratio)
+        self.norm1 = nn.GroupNorm(8, width)
+        self.filter = _AFNO2D(width, n_blocks)
+        self.norm2 = nn.GroupNorm(8, width)
+        self.mlp = nn.Sequential(nn.Conv2d(width, hid, 1), nn.GELU(), nn.Conv2d(hid, width, 1))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch, in_chans, embed_dim, out_dim):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_chans, embed_dim, patch, patch), nn.GELU(), nn.Conv2d(embed_dim, out_dim, 1))
+
+
+class _TimeAgg(nn.Module):
+    def __init__(self, n_t, C, kind):
+        super().__init__()
+        self.w = nn.Parameter(1 / (n_t * C ** 0.5) * torch.randn(n_t, C, C))
+        if kind == "exp_mlp":
+            self.gamma = nn.Parameter(2 ** torch.linspace(-10, 10, C).unsqueeze(0))
+
+
+class _DPOTNet(nn.Module):
+    """Parameter tree of dpot_libs/models/dpot.py:245-325 (names = the reference's state_dict keys)."""
+
+    def __init__(self, img_size, patch_size, in_channels, out_channels, in_timesteps, out_timesteps, n_blocks, embed_dim,
+                 out_layer_dim, depth, mlp_ratio, n_cls, time_agg):
+        super().__init__()
+        self.patch_embed = _PatchEmbed(patch_size, in_channels + 3, out_channels * patch_size + 3, embed_dim)
+        n = img_size // patch_size
+        self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, n, n))
+        self.blocks = nn.ModuleList([_Block(embed_dim, n_blocks, mlp_ratio) for _ in range(depth)])
+        self.cls_head = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.GELU(), nn.Linear(embed_dim, embed_dim), nn.GELU(),
+                                      nn.Linear(embed_dim, n_cls))
+        self.time_agg_layer = _TimeAgg(in_timesteps, embed_dim, time_agg)
+        self.out_layer = nn.Sequential(nn.ConvTranspose2d(embed_dim, out_layer_dim, patch_size, patch_size), nn.GELU(),
+                                       nn.Conv2d(out_layer_dim, out_layer_dim, 1), nn.GELU(),
+                                       nn.Conv2d(out_layer_dim, out_channels * out_timesteps, 1))
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+
+
+class DPOT(_ModelBase):
+    def __init__(self, shape_in, shape_out, img_size=128, in_channels=4, out_channels=4, in_timesteps=1, out_timesteps=1,
+                 patch_size=8, embed_dim=512, depth=12, n_blocks=8, modes=32, mlp_ratio=4, out_layer_dim=32, normalize=False,
+                 act="gelu", time_agg="exp_mlp", n_cls=1, model_type="dpot", checkpoint_path=None, **kwargs):
+        super().__init__()
+        self.shape_in, self.shape_out = tuple(int(v) for v in shape_in), tuple(int(v) for v in shape_out)
+        unsupported = []
+        if model_type != "dpot":
+            unsupported.append(f"model_type={model_type!r} (DPOTNet3D)")
+        if normalize:
+            unsupported.append("normalize=True")
+        if act != "gelu":
+            unsupported.append(f"act={act!r}")
+        if time_agg not in ("exp_mlp", "mlp"):
+            unsupported.append(f"time_agg={time_agg!r}")
+        if kwargs.get("mixing_type", "afno") != "afno":
+            unsupported.append("mixing_type != 'afno'")
+        if embed_dim % n_blocks or (embed_dim // n_blocks) % 16 or embed_dim % 32 or embed_dim % 8:
+            unsupported.append(f"embed_dim={embed_dim} / n_blocks={n_blocks} (block size must be a multiple of 16)")
+        if ((in_channels + 3) * patch_size * patch_size) % 32 or out_layer_dim % 32 or int(embed_dim * mlp_ratio) % 32:
+            unsupported.append("patch / out_layer / mlp widths must give GEMM depths that are multiples of 32")
+        if img_size % patch_size:
+            unsupported.append("img_size % patch_size != 0")
+        if tuple(self.shape_in[1:3]) != (img_size, img_size):
+            unsupported.append(f"data resolution {self.shape_in[1:3]} != img_size {img_size} (the FFT resize of "
+                               "dpot_libs/utils/utilities.py:277 is not built)")
+        if unsupported:
+            raise NotImplementedError("MI355X DPOT covers the configuration family of the reference's configs/*/dpot_*.yaml "
+                                      "at the model's native resolution; unsupported: " + "; ".join(unsupported))
+        self.data_in_channels, self.data_out_channels = self.shape_in[-1], self.shape_out[-1]
+        self.data_in_timesteps, self.data_out_timesteps = self.shape_in[0], self.shape_out[0]
+        assert self.data_in_timesteps == in_timesteps, \
+            f"Data input timesteps ({self.data_in_timesteps}) must be equal to in_timesteps ({in_timesteps})"       # model/dpot.py:82
+        assert self.data_out_timesteps >= out_timesteps
+        if self.data_in_channels > in_channels or (self.data_in_channels < in_channels and in_channels != 4):
+            raise ValueError("data channels are padded with ones up to the model's 4 input channels (model/dpot.py:213-221)")
+        if self.data_out_channels > out_channels:
+            raise ValueError("out_channels must cover the data's output channels (model/dpot.py:110-112)")
+        self.img_size, self.patch_size = int(img_size), int(patch_size)
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.in_timesteps, self.out_timesteps = int(in_timesteps), int(out_timesteps)
+        self.embed_dim, self.depth, self.n_blocks, self.modes = int(embed_dim), int(depth), int(n_blocks), int(modes)
+        self.hidden = int(embed_dim * mlp_ratio)
+        self.out_layer_dim, self.time_agg, self.model_type = int(out_layer_dim), time_agg, model_type
+        self.checkpoint_path = checkpoint_path
+        self.dpot_model = _DPOTNet(img_size, patch_size, in_channels, out_channels, in_timesteps, out_timesteps, n_blocks, embed_dim,
+                                   out_layer_dim, depth, mlp_ratio, n_cls, time_agg)
+        self._plan = None
+        if checkpoint_path is not None:
+            self.load_checkpoint(checkpoint_path)
+
+    # ------------------------------------------------------------------ checkpoints (model/dpot.py:291-400)
+    def load_checkpoint(self, checkpoint_path, device="cpu"):
+        ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        sd = ck.get("model", ck.get("model_state_dict", ck)) if isinstance(ck, dict) else ck
+        own = self.dpot_model.state_dict()
+        ok = {}
+        for k, v in sd.items():
+            for pre in ("dpot_model.", "module."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            if k in own and tuple(v.shape) == tuple(own[k].shape):
+                ok[k] = v
+        self.dpot_model.load_state_dict(ok, strict=False)
+        return None
+
+    # ------------------------------------------------------------------ constants
+    def _consts(self, device):
+        if self._plan is not None and self._plan["device"] == device:
+            return self._plan
+        n = self.img_size // self.patch_size
+        mk = min(self.modes, n)                    # dpot.py:69-72: x[:, :kept, :kept] (slices clip at the spectrum's extent)
+        mky = min(self.modes, n // 2 + 1)
+        x = np.arange(n)
+        sq = 1.0 / math.sqrt(n)
+        th = 2 * np.pi * np.outer(x, np.arange(mk)) / n                          # [x][kx]
+        F1 = np.zeros((n, 2 * mk))
+        F1[:, 0::2], F1[:, 1::2] = np.cos(th) * sq, -np.sin(th) * sq
+        thy = 2 * np.pi * np.outer(x, np.arange(mky)) / n                        # [y][ky]
+        F2 = np.zeros((2 * n, 2 * mky))                                          # k = (ri, y) -> o = (ky, ri')
+        F2[:n, 0::2], F2[n:, 0::2] = np.cos(thy) * sq, np.sin(thy) * sq
+        F2[:n, 1::2], F2[n:, 1::2] = -np.sin(thy) * sq, np.cos(thy) * sq
+        cw = np.full(mky, 2.0)
+        cw[0] = 1.0
+        if n % 2 == 0 and mky == n // 2 + 1:
+            cw[-1] = 1.0
+        I1 = np.zeros((2 * mky, 2 * n))                                          # k = (ky, ri) -> o = (ri', y)
+        c, s = (np.cos(thy) * sq * cw).T, (np.sin(thy) * sq * cw).T              # [ky][y]
+        I1[0::2, :n], I1[1::2, :n] = c, -s
+        I1[0::2, n:], I1[1::2, n:] = s, c
+        I2 = np.zeros((2 * mk, n))                                               # k = (kx, ri) -> o = x
+        I2[0::2, :], I2[1::2, :] = (np.cos(th) * sq).T, (-np.sin(th) * sq).T
+        f = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
+        T = self.in_timesteps
+        lin = lambda m: torch.tensor(np.linspace(0, 1, m), dtype=torch.float32)                 # dpot.py:352-363
+        self._plan = dict(device=device, n=n, mk=mk, mky=mky, F1=f(F1), F2=f(F2), I1=f(I1), I2=f(I2), F1t=f(F1.T), F2t=f(F2.T),
+                          I1t=f(I1.T), I2t=f(I2.T), gx=lin(self.img_size).to(device), gy=lin(self.img_size).to(device),
+                          gt=lin(T).to(device), tt=torch.linspace(0, 1, T).to(device))           # dpot.py:238
+        return self._plan
+
+    # ------------------------------------------------------------------ spectral stages
+    def _rfft2(self, Y, A1, S, B, pl, E, fwd=True):
+        """fwd: tokens Y [B][n][n][E] -> S [(b,kx,ky)][2][E];  not fwd: the adjoint (S -> Y)."""
+        n, mk, mky = pl["n"], pl["mk"], pl["mky"]
+        if fwd:
+            ops.axis_gemm(Y, A1, pl["F1"], B, n, 2 * mk, n * E, n * n * E, n * E, 2 * mk * n * E, n * E, tag="dpotF1")
+            ops.axis_gemm(A1, S, pl["F2"], B * mk, 2 * n, 2 * mky, E, 2 * n * E, E, 2 * mky * E, E, tag="dpotF2")
+        else:
+            ops.axis_gemm(S, A1, pl["F2t"], B * mk, 2 * mky, 2 * n, E, 2 * mky * E, E, 2 * n * E, E, tag="dpotF2t")
+            ops.axis_gemm(A1, Y, pl["F1t"], B, 2 * mk, n, n * E, 2 * mk * n * E, n * E, n * n * E, n * E, tag="dpotF1t")
+
+    def _irfft2(self, Z, A1, Y, B, pl, E, fwd=True):
+        n, mk, mky = pl["n"], pl["mk"], pl["mky"]
+        if fwd:
+            ops.axis_gemm(Z, A1, pl["I1"], B * mk, 2 * mky, 2 * n, E, 2 * mky * E, E, 2 * n * E, E, tag="dpotI1")
+            ops.axis_gemm(A1, Y, pl["I2"], B, 2 * mk, n, n * E, 2 * mk * n * E, n * E, n * n * E, n * E, tag="dpotI2")
+        else:
+            ops.axis_gemm(Y, A1, pl["I2t"], B, n, 2 * mk, n * E, n * n * E, n * E, 2 * mk * n * E, n * E, tag="dpotI2t")
+            ops.axis_gemm(A1, Z, pl["I1t"], B * mk, 2 * n, 2 * mky, E, 2 * n * E, E, 2 * mky * E, E, tag="dpotI1t")
+
+    # ------------------------------------------------------------------ forward (one window)
+    @torch.no_grad()
+    def _forward_hip(self, x, save=None):
+        net = self.dpot_model
+        B, T, H, W, Cd = x.shape
+        E, ps, Cm, Co, To = self.embed_dim, self.patch_size, self.in_channels, self.out_channels, self.out_timesteps
+        pl = self._consts(x.device)
+        n, mk, mky = pl["n"], pl["mk"], pl["mky"]
+        f = dict(device=x.device, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f)
+        nb, bs = self.n_blocks, E // self.n_blocks
+        Mt, M1 = B * n * n, B * n * n * T
+        training = save is not None
+        # ---- PatchEmbed
+        Kp = (Cm + 3) * ps * ps
+        E1 = Co * ps + 3
+        E1p = _rup(E1, 32)
+        P = new(M1, Kp)
+        ops.dpot_patch_tokens(x, pl["gx"], pl["gy"], pl["gt"], P, B, T, H, W, Cd, Cm, ps)
+        pe0, pe2 = net.patch_embed.proj[0], net.patch_embed.proj[2]
+        H1 = torch.zeros(M1, E1p, **f)
+        H1pre = torch.zeros(M1, E1p, **f) if training else None
+        ops.gemm_nt(P, pe0.weight.data.view(E1, Kp), H1, M1, E1, Kp, bias=pe0.bias.data, act=1, ldo=E1p, pre_out=H1pre)
+        W2p = torch.zeros(E, E1p, **f)
+        W2p[:, :E1] = pe2.weight.data.view(E, E1)
+        Etok = new(M1, E)
+        ops.gemm_nt(H1, W2p, Etok, M1, E, E1p, bias=pe2.bias.data)
+        pos = net.pos_embed.data[0].permute(1, 2, 0).reshape(n * n, E).contiguous()
+        ops.rowtable_add(Etok, pos, M1, E, T, n * n)
+        # ---- TimeAggregator: one GEMM over K = (t, channel)
+        ta = net.time_agg_layer
+        gamma = ta.gamma.data.view(E) if self.time_agg == "exp_mlp" else torch.zeros(E, **f)
+        Wf, Wb, ecos = new(E, T * E), new(T * E, E), new(T, E)
+        ops.dpot_tagg_prep(ta.w.data, gamma, pl["tt"], Wf, Wb, ecos, T, E)
+        X = new(Mt, E)
+        ops.gemm_nt(Etok, Wf, X, Mt, E, T * E)
+        del Wf
+        # ---- blocks
+        ntok = B * mk * mky
+        tapes = []
+        A1 = new(B * 2 * mk * n * E)
+        for blk in net.blocks:
+            fl = blk.filter
+            Y1, st1 = new(Mt, E), new(B * 8, 2)
+            ops.gn_tokens_fwd(X, None, blk.norm1.weight.data, blk.norm1.bias.data, Y1, st1, B, n * n, E, 8, blk.norm1.eps)
+            S = new(ntok, 2 * E)
+            self._rfft2(Y1, A1, S, B, pl, E)
+            W1c, W2c = new(nb, 2 * bs, 2 * bs), new(nb, 2 * bs, 2 * bs)
+            ops.afno_wprep(fl.w1.data, W1c, nb, bs, False)
+            ops.afno_wprep(fl.w2.data, W2c, nb, bs, False)
+            Hs = new(ntok, 2 * E) if training else None
+            O2 = new(ntok, 2 * E)
+            ops.afno_mlp(S, W1c, fl.b1.data, W2c, fl.b2.data, None, Hs, O2, ntok, nb, bs, 0)
+            Fo = new(Mt, E)
+            self._irfft2(O2, A1, Fo, B, pl, E)
+            Y2, st2 = new(Mt, E), new(B * 8, 2)
+            ops.gn_tokens_fwd(Fo, Y1, blk.norm2.weight.data, blk.norm2.bias.data, Y2, st2, B, n * n, E, 8, blk.norm2.eps)
+            m0, m2 = blk.mlp[0], blk.mlp[2]
+            hid = self.hidden
+            Hh = new(Mt, hid)
+            Hpre = new(Mt, hid) if training else None
+            ops.gemm_nt(Y2, m0.weight.data.view(hid, E), Hh, Mt, hid, E, bias=m0.bias.data, act=1, pre_out=Hpre)
+            Xn = new(Mt, E)
+            ops.gemm_nt(Hh, m2.weight.data.view(E, hid), Xn, Mt, E, hid, bias=m2.bias.data, residual=X)
+            if training:
+                tapes.append(dict(X=X, Y1=Y1, st1=st1, S=S, Hs=Hs, Fo=Fo, st2=st2, Y2=Y2, Hh=Hh, Hpre=Hpre))
+            X = Xn
+        # ---- out_layer
+        ol0, ol2, ol4 = net.out_layer[0], net.out_layer[2], net.out_layer[4]
+        OD = self.out_layer_dim
+        NU = ps * ps * OD
+        Wt = ol0.weight.data.permute(2, 3, 1, 0).reshape(NU, E).contiguous()           # [(i, j, oc)][c]
+        bt = ol0.bias.data.repeat(ps * ps)
+        U = new(Mt, NU)
+        Upre = new(Mt, NU) if training else None
+        ops.gemm_nt(X, Wt, U, Mt, NU, E, bias=bt, act=1, pre_out=Upre)
+        Mp = Mt * ps * ps
+        V = new(Mp, OD)
+        Vpre = new(Mp, OD) if training else None
+        ops.gemm_nt(U, ol2.weight.data.view(OD, OD), V, Mp, OD, OD, bias=ol2.bias.data, act=1, pre_out=Vpre)
+        NO = To * Co
+        NOp = _rup(NO, 32)
+        W3p, b3p = torch.zeros(NOp, OD, **f), torch.zeros(NOp, **f)
+        W3p[:NO] = ol4.weight.data.view(NO, OD)
+        b3p[:NO] = ol4.bias.data
+        O = new(Mp, NOp)
+        ops.gemm_nt(V, W3p, O, Mp, NOp, OD, bias=b3p)
+        Cdo = self.data_out_channels
+        pred = new(B, To, H, W, Cdo)
+        ops.dpot_unpatch(O, pred, B, To, H, W, Cdo, Co, ps, NOp)
+        if training:
+            save.update(B=B, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
+                        U=U, Upre=Upre, V=V, Vpre=Vpre, W3p=W3p)
+        return pred
+
+    # ------------------------------------------------------------------ backward
+    @torch.no_grad()
+    def _backward_hip(self, sv, g_pred):
+        net = self.dpot_model
+        B = sv["B"]
+        E, ps, Cm, Co, To, T = self.embed_dim, self.patch_size, self.in_channels, self.out_channels, self.out_timesteps, self.in_timesteps
+        H = W = self.img_size
+        pl = self._consts(g_pred.device)
+        n, mk, mky = pl["n"], pl["mk"], pl["mky"]
+        f = dict(device=g_pred.device, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, **f)
+        Tr = lambda w: w.t().contiguous()
+        nb, bs, hid, OD = self.n_blocks, E // self.n_blocks, self.hidden, self.out_layer_dim
+        Mt, M1, Mp = B * n * n, B * n * n * T, B * n * n * ps * ps
+        NO, NOp, NU = To * Co, _rup(To * Co, 32), ps * ps * OD
+        Cdo = self.data_out_channels
+        grads = {}
+        ol0, ol2, ol4 = net.out_layer[0], net.out_layer[2], net.out_layer[4]
+        # ---- out_layer
+        gO = new(Mp, NOp)
+        ops.dpot_unpatch_bwd(g_pred, gO, B, To, H, W, Cdo, Co, ps, NOp)
+        dW3, db3 = _wgrad(gO, sv["V"], Mp, NOp, OD)
+        grads[ol4.weight], grads[ol4.bias] = dW3[:NO].reshape(ol4.weight.shape).contiguous(), db3[:NO].contiguous()
+        gV = new(Mp, OD)
+        ops.gemm_nt(gO, Tr(sv["W3p"]), gV, Mp, OD, NOp, act=2, aux=sv["Vpre"])
+        del gO
+        dW2, db2 = _wgrad(gV, sv["U"], Mp, OD, OD)
+        grads[ol2.weight], grads[ol2.bias] = dW2.reshape(ol2.weight.shape), db2
+        gU = new(Mt, NU)
+        ops.gemm_nt(gV, Tr(ol2.weight.data.view(OD, OD)), gU, Mp, OD, OD, act=2, aux=sv["Upre"])
+        del gV
+        dWt, dbt = _wgrad(gU, sv["Xlast"], Mt, NU, E)
+        grads[ol0.weight] = dWt.view(ps, ps, OD, E).permute(3, 2, 0, 1).contiguous()
+        grads[ol0.bias] = dbt.view(ps * ps, OD).sum(0)
+        g = new(Mt, E)
+        ops.gemm_nt(gU, Tr(sv["Wt"]), g, Mt, E, NU)
+        del gU
+        # ---- blocks, last to first
+        ntok = B * mk * mky
+        A1 = new(B * 2 * mk * n * E)
+        splits = ops.afno_wgrad_splits(ntok)
+        wpart = new(splits * nb * 4 * bs * bs)
+        for blk, tp in zip(reversed(list(net.blocks)), reversed(sv["tapes"])):
+            fl, m0, m2 = blk.filter, blk.mlp[0], blk.mlp[2]
+            dWm2, dbm2 = _wgrad(g, tp["Hh"], Mt, E, hid)
+            grads[m2.weight], grads[m2.bias] = dWm2.reshape(m2.weight.shape), dbm2
+            gH = new(Mt, hid)
+            ops.gemm_nt(g, Tr(m2.weight.data.view(E, hid)), gH, Mt, hid, E, act=2, aux=tp["Hpre"])
+            dWm0, dbm0 = _wgrad(gH, tp["Y2"], Mt, hid, E)
+            grads[m0.weight], grads[m0.bias] = dWm0.reshape(m0.weight.shape), dbm0
+            gY2 = new(Mt, E)
+            ops.gemm_nt(gH, Tr(m0.weight.data.view(hid, E)), gY2, Mt, E, hid)
+            del gH
+            pg, pb = new(B, E), new(B, E)
+            gz = new(Mt, E)
+            ops.gn_tokens_bwd(tp["Fo"], tp["Y1"], blk.norm2.weight.data, tp["st2"], gY2, None, gz, pg, pb, B, n * n, E, 8)
+            grads[blk.norm2.weight], grads[blk.norm2.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
+            # AFNO: z = irfft2(mlp_c(rfft2(y1))) + y1
+            gO2 = new(ntok, 2 * E)
+            self._irfft2(gO2, A1, gz, B, pl, E, fwd=False)
+            W2t, W1t = new(nb, 2 * bs, 2 * bs), new(nb, 2 * bs, 2 * bs)
+            ops.afno_wprep(fl.w2.data, W2t, nb, bs, True)
+            ops.afno_wprep(fl.w1.data, W1t, nb, bs, True)
+            gHs, gS = new(ntok, 2 * E), new(ntok, 2 * E)
+            ops.afno_mlp(gO2, W2t, None, W1t, None, tp["Hs"], gHs, gS, ntok, nb, bs, 1)
+            dw2, dw1 = torch.empty_like(fl.w2), torch.empty_like(fl.w1)
+            ops.afno_wgrad(tp["Hs"], gO2, wpart, dw2, ntok, nb, bs, True)
+            ops.afno_wgrad(tp["S"], gHs, wpart, dw1, ntok, nb, bs, False)
+            grads[fl.w2], grads[fl.w1] = dw2, dw1
+            grads[fl.b2] = self._colsum(gO2, ntok, 2 * E).view(fl.b2.shape)
+            grads[fl.b1] = self._colsum(gHs, ntok, 2 * E).view(fl.b1.shape)
+            gY1 = new(Mt, E)
+            self._rfft2(gY1, A1, gS, B, pl, E, fwd=False)
+            gY1 = ops.add(gY1, gz)
+            gX = new(Mt, E)
+            ops.gn_tokens_bwd(tp["X"], None, blk.norm1.weight.data, tp["st1"], gY1, g, gX, pg, pb, B, n * n, E, 8)
+            grads[blk.norm1.weight], grads[blk.norm1.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
+            g = gX
+        # ---- TimeAggregator
+        ta = net.time_agg_layer
+        Etok = sv["Etok"]
+        dWb, _ = _wgrad(Etok, g, Mt, T * E, E, ldg=T * E, lda=E)                     # [(t,i)][j] = sum_m E[m][(t,i)] g[m][j]
+        dw, dgamma = torch.empty_like(ta.w), new(E)
+        ops.dpot_tagg_finish(dWb, ta.w.data, sv["gamma"], pl["tt"], dw, dgamma, T, E)
+        del dWb
+        grads[ta.w] = dw
+        if self.time_agg == "exp_mlp":
+            grads[ta.gamma] = dgamma.view(1, E)
+        gE = new(M1, E)
+        ops.gemm_nt(g, sv["Wb"], gE, Mt, T * E, E)
+        # ---- pos_embed, PatchEmbed
+        dpos = new(n * n, E)
+        ops.rowtable_grad(gE, dpos, B, E, T, n * n)
+        grads[net.pos_embed] = dpos.view(n, n, E).permute(2, 0, 1).unsqueeze(0).contiguous()
+        pe0, pe2 = net.patch_embed.proj[0], net.patch_embed.proj[2]
+        E1 = Co * ps + 3
+        E1p = _rup(E1, 32)
+        Kp = (Cm + 3) * ps * ps
+        dW2p, dbp2 = _wgrad(gE, sv["H1"], M1, E, E1p)
+        grads[pe2.weight], grads[pe2.bias] = dW2p[:, :E1].reshape(pe2.weight.shape).contiguous(), dbp2
+        gH1 = torch.zeros(M1, E1p, **f)
+        ops.gemm_nt(gE, Tr(sv["W2p"]), gH1, M1, E1, E, act=2, aux=sv["H1pre"], ldo=E1p)
+        del gE
+        dW1, db1 = _wgrad(gH1, sv["P"], M1, E1, Kp, ldg=E1p, lda=Kp)
+        grads[pe0.weight], grads[pe0.bias] = dW1.reshape(pe0.weight.shape), db1
+        return grads
+
+    @staticmethod
+    def _sum_rows(part, rows, L):
+        out = torch.empty(L, device=part.device, dtype=torch.float32)
+        ops.reduce_partials(part, rows, L, out_f32=out)
+        return out
+
+    @staticmethod
+    def _colsum(x, M, N):
+        """Column sums of x [M][N] (bias gradients) in column chunks the reduction kernel takes (a power of two <= 1024)."""
+        rows = ops.colsum_rows()
+        chunk = 1024
+        while N % chunk:
+            chunk //= 2
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        part = torch.empty(rows, chunk, device=x.device, dtype=torch.float32)
+        for c0 in range(0, N, chunk):
+            ops.colsum(ops.Sub(x, c0), part, M, chunk, ld=N)
+            ops.reduce_partials(part, rows, chunk, out_f32=ops.Sub(out, c0))
+        return out
+
+    # ------------------------------------------------------------------ Model protocol
+    def _window(self, x):
+        """model/dpot.py:180-237 at native resolution: one DPOTNet call on ``in_timesteps`` frames."""
+        if not x.is_cuda:
+            raise RuntimeError("realpdebench_amd.DPOT runs on MI355X only: there is no CPU fallback")
+        x = x.contiguous().float()
+        params = [p for p in self.parameters()]
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in params):
+            return _DPOTFunction.apply(x, self, *params)
+        return self._forward_hip(x, save=None)
+
+    def forward(self, x):
+        B, T_in, H, W, C = x.shape
+        T_out = self.data_out_timesteps
+        if tuple(x.shape[2:]) != tuple(self.shape_in[1:]) or T_in < self.in_timesteps:
+            raise ValueError(f"expected input [B,>={self.in_timesteps},{','.join(map(str, self.shape_in[1:]))}], got {tuple(x.shape)}")
+        if self.out_timesteps == T_out:
+            return self._window(x[:, -self.in_timesteps:] if T_in != self.in_timesteps else x)
+        cur, outs = x, []                                                     # model/dpot.py:151-178: sliding windows
+        for t in range(0, T_out, self.out_timesteps):
+            win = cur[:, -self.in_timesteps:]
+            if t + self.out_timesteps > T_out:
+                rem = T_out - t
+                if rem < self.out_timesteps // 2:
+                    break
+                outs.append(self._window(win)[:, :rem])
+            else:
+                pred = self._window(win)
+                cur = torch.cat([cur, pred], dim=1)
+                outs.append(pred)
+        return torch.cat(outs, dim=1)
+
+    def train_loss(self, input, target):
+        """model/dpot.py:239-289 for out_timesteps == T_out (every reference YAML): mean squared error of one window."""
+        if self.out_timesteps != target.shape[1]:
+            raise NotImplementedError("sliding-window training (out_timesteps < target length, model/dpot.py:256-289) back-propagates "
+                                      "through the fed-back predictions and is not built; every reference YAML trains one window")
+        pred = self._window(input)
+        return ((pred - target) ** 2).mean()
+
+
+class _DPOTFunction(torch.autograd.Function):
+    """Autograd glue: one forward / backward call into the HIP pipelines above."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        sv = {}
+        out = model._forward_hip(x, save=sv)
+        ctx.model, ctx.sv, ctx.params = model, sv, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        grads = ctx.model._backward_hip(ctx.sv, g_out.contiguous().float())
+        ctx.sv = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -41,7 +41,13 @@ def load_model(train_dataset, device="cpu", **kwargs):
         from .unet import Unet3d
         model = Unet3d(dim=input_shape[1], out_channels=output_shape[-1], dim_mults=kwargs["dim_mults"],   # load_model.py:47-58
                        channels=input_shape[-1], in_time=input_shape[0], out_time=output_shape[0]).to(device)
+    elif model_name == "dpot":
+        from .dpot import DPOT
+        keys = ("img_size", "in_channels", "out_channels", "in_timesteps", "out_timesteps", "patch_size", "embed_dim", "depth",
+                "n_blocks", "modes", "mlp_ratio", "out_layer_dim", "normalize", "act", "time_agg", "n_cls", "model_type",
+                "checkpoint_path")                            # load_model.py:108-131
+        model = DPOT(shape_in=input_shape, shape_out=output_shape, **{k: kwargs[k] for k in keys}).to(device)
     else:
         raise ValueError(f"Model {model_name} not supported by the MI355X backend "
-                         "(supported: fno, transolver, galerkin_transformer, unet)")
+                         "(supported: fno, transolver, galerkin_transformer, unet, dpot)")
     return model

@@ -700,3 +700,66 @@ def bn_bwd_row_feat(s, gy, phi, gs, mean, invstd, gamma, beta, sums, count, gelu
               float(count), int(gelu), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, FW, _stream(),
               label=f"bn_bwd_row[C{C},feat{FW}]", nbytes=4 * (3 * G * Wp * C + G * Wp * FW + G * K2 * C),
               flops=2 * G * Wp * C * (FW + K2))
+
+
+# ---------------------------------------------------------------------------------------------- DPOT (csrc/rpb_dpot.hip)
+def dpot_patch_tokens(u, gx, gy, gt, P, B, T, H, W, Cd, Cm, ps):
+    _lib.call("rpb_dpot_patch_tokens", _p(u), _p(gx), _p(gy), _p(gt), _p(P), B, T, H, W, Cd, Cm, ps, _stream(),
+              label="dpot_patch_tokens", nbytes=4 * (u.numel() + P.numel()))
+
+
+def rowtable_add(x, table, M, C, rows_per_entry, nent):
+    _lib.call("rpb_rowtable_add", _p(x), _p(table), M, C, rows_per_entry, nent, _stream(), label="rowtable_add", nbytes=8 * M * C)
+
+
+def rowtable_grad(g, dtable, B, C, rows_per_entry, nent):
+    _lib.call("rpb_rowtable_grad", _p(g), _p(dtable), B, C, rows_per_entry, nent, _stream(), label="rowtable_grad",
+              nbytes=4 * B * nent * rows_per_entry * C)
+
+
+def dpot_tagg_prep(w, gamma, tt, Wf, Wb, e_out, T, C):
+    _lib.call("rpb_dpot_tagg_prep", _p(w), _p(gamma), _p(tt), _p(Wf), _p(Wb), _p(e_out), T, C, _stream(), label="dpot_tagg_prep",
+              nbytes=12 * T * C * C)
+
+
+def dpot_tagg_finish(dWb, w, gamma, tt, dw, dgamma, T, C):
+    _lib.call("rpb_dpot_tagg_finish", _p(dWb), _p(w), _p(gamma), _p(tt), _p(dw), _p(dgamma), T, C, _stream(),
+              label="dpot_tagg_finish", nbytes=12 * T * C * C)
+
+
+def gn_tokens_fwd(x, x2, gamma, beta, y, stat, B, P, C, G, eps=1e-5):
+    _lib.call("rpb_gn_tokens_fwd", _p(x), _p(x2), _p(gamma), _p(beta), _p(y), _p(stat), B, P, C, G, float(eps), _stream(),
+              label="gn_tokens_fwd", nbytes=4 * B * P * C * (2 if x2 is None else 3))
+
+
+def gn_tokens_bwd(x, x2, gamma, stat, gy, gadd, gx, pg, pb, B, P, C, G):
+    _lib.call("rpb_gn_tokens_bwd", _p(x), _p(x2), _p(gamma), _p(stat), _p(gy), _p(gadd), _p(gx), _p(pg), _p(pb), B, P, C, G, _stream(),
+              label="gn_tokens_bwd", nbytes=4 * B * P * C * 4)
+
+
+def afno_wprep(w, Wc, nb, bs, transpose):
+    _lib.call("rpb_afno_wprep", _p(w), _p(Wc), nb, bs, bs, int(transpose), _stream(), label="afno_wprep", nbytes=24 * nb * bs * bs)
+
+
+def afno_mlp(X, Wa, ba, Wb, bb, aux, mid, out, ntok, nb, bs, mode):
+    _lib.call("rpb_afno_mlp", _p(X), _p(Wa), _p(ba), _p(Wb), _p(bb), _p(aux), _p(mid), _p(out), ntok, nb, bs, int(mode), _stream(),
+              label=f"afno_mlp[mode={int(mode)}]", nbytes=4 * ntok * 2 * nb * bs * 3, flops=2 * 2 * ntok * nb * (2 * bs) ** 2)
+
+
+def afno_wgrad_splits(ntok):
+    return _lib.query("rpb_afno_wgrad_splits", ntok)
+
+
+def afno_wgrad(A, G, part, dw, ntok, nb, bs, a_gelu):
+    _lib.call("rpb_afno_wgrad", _p(A), _p(G), _p(part), _p(dw), ntok, nb, bs, int(a_gelu), _stream(), label="afno_wgrad",
+              nbytes=4 * ntok * 4 * nb * bs, flops=2 * ntok * nb * (2 * bs) ** 2)
+
+
+def dpot_unpatch(O, pred, B, T, H, W, Cd, Co, ps, ldo):
+    _lib.call("rpb_dpot_unpatch", _p(O), _p(pred), B, T, H, W, Cd, Co, ps, ldo, _stream(), label="dpot_unpatch",
+              nbytes=8 * pred.numel())
+
+
+def dpot_unpatch_bwd(gpred, gO, B, T, H, W, Cd, Co, ps, ldo):
+    _lib.call("rpb_dpot_unpatch_bwd", _p(gpred), _p(gO), B, T, H, W, Cd, Co, ps, ldo, _stream(), label="dpot_unpatch_bwd",
+              nbytes=4 * (gpred.numel() + gO.numel()))

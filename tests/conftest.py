@@ -80,3 +80,20 @@ def galerkin_golden():
     g["modes"] = tuple(int(v) for v in z["cfg/modes"])
     g["shape_out"] = tuple(int(v) for v in z["cfg/shape_out"])
     return g
+
+
+def dpot_golden():
+    """tests/golden/dpot_small.npz (make_golden_dpot.py: imported reference DPOT, forward + loss + every gradient)."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpot_small.npz"))
+    g = dict(sd={}, grad={}, cfg={})
+    for k in z.files:
+        if k.startswith("sd/"):
+            g["sd"][k[3:]] = torch.from_numpy(z[k])
+        elif k.startswith("grad/"):
+            g["grad"][k[5:]] = torch.from_numpy(z[k])
+        elif k.startswith("cfg/"):
+            g["cfg"][k[4:]] = int(z[k])
+    g["x"], g["y"], g["pred"], g["loss"] = torch.from_numpy(z["x"]), torch.from_numpy(z["y"]), torch.from_numpy(z["pred"]), float(z["loss"])
+    g["cfg"].update(time_agg="exp_mlp", data_out_channels=g["y"].shape[-1])
+    return g

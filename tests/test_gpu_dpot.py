@@ -1,0 +1,125 @@
+"""DPOT (AFNO patch transformer) on the HIP path vs vectors taken from the imported reference
+(tests/golden/dpot_small.npz) and vs the pinned CPU oracle at the production widths of configs/cylinder/dpot_s.yaml."""
+import pytest
+import torch
+
+from conftest import dpot_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(g, **over):
+    from realpdebench_amd.model.dpot import DPOT
+    cfg = {k: v for k, v in g["cfg"].items() if k not in ("data_out_channels",)}
+    cfg.update(over)
+    T, S, Cd = g["x"].shape[1], g["x"].shape[2], g["x"].shape[-1]
+    m = DPOT(shape_in=(T, S, S, Cd), shape_out=(g["y"].shape[1], S, S, g["y"].shape[-1]), normalize=False, act="gelu", **cfg).cuda()
+    missing, unexpected = m.load_state_dict(g["sd"], strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+def test_state_dict_names_match_reference():
+    g = dpot_golden()
+    m = _model(g)
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(g["sd"][k].shape), k
+
+
+def test_eval_forward_matches_reference():
+    g = dpot_golden()
+    m = _model(g).eval()
+    with torch.no_grad():
+        out = m(g["x"].cuda())
+    assert out.shape == g["pred"].shape
+    assert rel_l2(out.cpu(), g["pred"]) < 1e-5
+
+
+def test_train_loss_and_every_gradient_match_reference():
+    g = dpot_golden()
+    m = _model(g).train()
+    loss = m.train_loss(g["x"].cuda(), g["y"].cuda())
+    loss.backward()
+    assert abs(float(loss) - g["loss"]) < 1e-5 * abs(g["loss"])
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(g["grad"])
+    for k, ref in g["grad"].items():
+        assert rel_l2(got[k].cpu(), ref) < 1e-4, k
+
+
+def _oracle_case(B, T, S, Cd, cfg, seed):
+    """Random weights of the HIP model's own initialisation (perturbed so every bias / affine matters) vs the CPU oracle."""
+    from oracle import dpot_oracle as DO
+    from realpdebench_amd.model.dpot import DPOT
+    torch.manual_seed(seed)
+    m = DPOT(shape_in=(T, S, S, Cd), shape_out=(cfg["out_timesteps"], S, S, Cd), normalize=False, act="gelu", **cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "norm" in n or n.endswith("bias") or "pos_embed" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            if n.endswith((".b1", ".b2", ".w1", ".w2")):
+                p.copy_(torch.randn_like(p) / p.shape[-1] ** 0.5)
+    x, y = torch.randn(B, T, S, S, Cd), torch.randn(B, cfg["out_timesteps"], S, S, Cd)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    ocfg = dict(cfg, data_out_channels=Cd)
+    loss_ref = ((DO.dpot_forward(sd, x, ocfg) - y) ** 2).mean()
+    loss_ref.backward()
+    m = m.cuda().train()
+    loss = m.train_loss(x.cuda(), y.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    for n, p in m.named_parameters():
+        ref = sd[n].grad
+        if ref is None:
+            assert p.grad is None, n
+            continue
+        assert rel_l2(p.grad.cpu(), ref) < 2e-4, n
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+        ref = DO.dpot_forward({k: v.detach() for k, v in sd.items()}, x, ocfg)
+    assert rel_l2(out.cpu(), ref) < 1e-5
+
+
+def test_dpot_s_widths_vs_oracle():
+    """embed 1024 in 8 blocks of 128, GroupNorm groups of 128 channels, 16 x 16 latent grid (img 128 / patch 8), all 16 x 9 modes
+    kept (modes 32 clips), out_layer_dim 32 -- configs/cylinder/dpot_s.yaml at depth 1, 4 frames, B = 1."""
+    cfg = dict(img_size=128, in_channels=4, out_channels=4, in_timesteps=4, out_timesteps=4, patch_size=8, embed_dim=1024, depth=1,
+               n_blocks=8, modes=32, mlp_ratio=1, out_layer_dim=32, n_cls=12, time_agg="exp_mlp")
+    _oracle_case(1, 4, 128, 2, cfg, seed=5)
+
+
+def test_dpot_l_block_shapes_and_truncated_modes_vs_oracle():
+    """dpot_l's block geometry (16 blocks of 96 channels, GroupNorm groups of 192, mlp_ratio 4) on a small image, with fewer kept
+    modes than the latent grid has (modes 3 < 8: the [:kept, :kept] corner of dpot.py:72-94) and the plain 'mlp' aggregator."""
+    cfg = dict(img_size=64, in_channels=4, out_channels=4, in_timesteps=2, out_timesteps=2, patch_size=8, embed_dim=1536, depth=1,
+               n_blocks=16, modes=3, mlp_ratio=4, out_layer_dim=64, n_cls=12, time_agg="mlp")
+    _oracle_case(2, 2, 64, 3, cfg, seed=6)
+
+
+def test_sliding_window_eval_forward():
+    """out_timesteps < T_out: the wrapper's autoregressive windows (model/dpot.py:151-178)."""
+    from oracle import dpot_oracle as DO
+    from realpdebench_amd.model.dpot import DPOT
+    torch.manual_seed(9)
+    cfg = dict(img_size=32, in_channels=4, out_channels=4, in_timesteps=4, out_timesteps=2, patch_size=8, embed_dim=128, depth=1,
+               n_blocks=8, modes=32, mlp_ratio=1, out_layer_dim=32, n_cls=12, time_agg="exp_mlp")
+    m = DPOT(shape_in=(4, 32, 32, 2), shape_out=(5, 32, 32, 2), normalize=False, act="gelu", **cfg)
+    x = torch.randn(2, 4, 32, 32, 2)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    ocfg = dict(cfg, data_out_channels=2)
+    cur, outs = x, []
+    for t in range(0, 5, 2):                      # windows at t = 0, 2; the last one (1 remaining step) is kept: 1 >= 2 // 2
+        win = cur[:, -4:]
+        p = DO.dpot_forward(sd, win, ocfg)
+        if t + 2 > 5:
+            outs.append(p[:, :5 - t])
+        else:
+            cur = torch.cat([cur, p], 1)
+            outs.append(p)
+    ref = torch.cat(outs, 1)
+    with torch.no_grad():
+        out = m.cuda().eval()(x.cuda())
+    assert out.shape == ref.shape == (2, 5, 32, 32, 2)
+    assert rel_l2(out.cpu(), ref) < 1e-5

@@ -191,3 +191,22 @@ def test_unet_rotary_known_answers():
     # and the complex-multiplication statement of the same algorithm on random data
     x = torch.randn(2, 4, 7, d)
     assert rel_l2(UO.rotary(x, freqs), _rotary_complex(x)) < 1e-6
+
+
+def test_dpot_oracle_matches_reference():
+    """Eval forward, training loss and every parameter gradient of oracle/dpot_oracle.py against vectors taken from the imported
+    reference DPOT (tests/golden/make_golden_dpot.py)."""
+    from conftest import dpot_golden
+    from oracle import dpot_oracle as DO
+    g = dpot_golden()
+    with torch.no_grad():
+        out = DO.dpot_forward(g["sd"], g["x"], g["cfg"])
+    assert out.shape == g["pred"].shape
+    assert rel_l2(out, g["pred"]) < TOL
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g["sd"].items()}
+    loss = ((DO.dpot_forward(sd, g["x"], g["cfg"]) - g["y"]) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) - g["loss"]) < 1e-6 * abs(g["loss"])
+    assert {k for k, v in sd.items() if v.grad is not None} == set(g["grad"])
+    for k, ref in g["grad"].items():
+        assert rel_l2(sd[k].grad, ref) < 2e-5, k
