@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
     ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
     ap.add_argument("--no-galerkin", action="store_true", help="skip the secondary Galerkin Transformer measurement")
+    ap.add_argument("--no-dpot", action="store_true", help="skip the secondary DPOT-S measurement")
     ap.add_argument("--no-unet", action="store_true", help="skip the secondary U-Net measurements (cylinder YAML and C3 mesh)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage FNO rollout (BASELINE.json configs[4])")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -170,14 +171,14 @@ def pipe_rooflines(summary, steps):
     return out
 
 
-def bench_model(dev, make_model, x, y, lr, steps, config, exact_line=False, forward=True):
+def bench_model(dev, make_model, x, y, lr, steps, config, exact_line=False, forward=True, clip=0.0):
     """Train step (the reference's loop body through realpdebench_amd.trainer.make_trainer) and eval forward of one of the
     secondary models; one extra step runs with HIP events around every launch for the measured per-pipe rooflines."""
     from realpdebench_amd import _lib, ops
     from realpdebench_amd.trainer import make_trainer
     torch.manual_seed(0)
     m = make_model().to(dev)
-    tr = make_trainer(m, lr=lr, num_update=4000)
+    tr = make_trainer(m, lr=lr, num_update=4000, clip_grad_norm=clip)
     B = x.shape[0]
 
     def timed(n):
@@ -194,6 +195,10 @@ def bench_model(dev, make_model, x, y, lr, steps, config, exact_line=False, forw
     timed(1)
     prof = _lib.profile_summary()
     _lib.PROFILE = None
+    if os.environ.get("RPB_BENCH_TABLE"):            # per-kernel HIP-event table of the profiled step (stderr)
+        for label, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"{label:44s} calls {v['calls']:4d}  total {v['total_ms']:8.3f} ms  {v['bytes'] * v['calls'] / v['total_ms'] / 1e6:8.1f} GB/s"
+                  f"  {v['flops'] * v['calls'] / v['total_ms'] / 1e9:7.2f} TF/s", file=sys.stderr)
     res = {"train_samples_per_s": B / t_train, "ms_per_step": 1e3 * t_train, "batch": B,
            "trainer": type(tr).__name__, "roofline": pipe_rooflines(prof, 1),
            "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30, "config": config}
@@ -252,6 +257,19 @@ def bench_unet_c3(dev, steps=1):
                     x, y, 1e-4, steps, "U-Net fsi-shaped C3 mesh [1,20,256,256,3], dim 256 -> 256/512/1024 channels", forward=False)
     r["note"] = "BASELINE configs[2] asks B=128 over 8 GPUs = 16 per GPU; fp32 activations allow 2 per 288 GB GPU"
     return r
+
+
+def bench_dpot(dev, steps=3):
+    """DPOT-S at the reference's configs/cylinder/dpot_s.yaml ([16,20,128,128,2] -> 16 x 16 patches, embed 1024, depth 6)."""
+    from realpdebench_amd.model.load_model import load_model
+    cfg = _yaml("cylinder", "dpot_s.yaml")
+    B = int(cfg["train_batch_size"])
+    x = torch.randn(B, *cfg["shape_in"], device=dev)
+    y = torch.randn(B, *cfg["shape_out"], device=dev)
+    ds = [(x[0], y[0])]
+    return bench_model(dev, lambda: load_model(ds, device="cpu", **cfg), x, y, cfg["lr"], steps,
+                       "configs/cylinder/dpot_s.yaml: [16,20,128,128,2], patch 8, embed 1024 in 8 blocks, depth 6, 20 -> 20 frames, "
+                       "random initial weights", clip=float(cfg["clip_grad_norm"]))
 
 
 def bench_galerkin(dev, steps=3):
@@ -478,7 +496,8 @@ def main():
         model = None
         torch.cuda.empty_cache()
         for name, fn, flag in (("rollout_bf16", bench_rollout_bf16, a.no_bf16), ("transolver", bench_transolver, a.no_transolver),
-                               ("galerkin_transformer", bench_galerkin, a.no_galerkin), ("unet", bench_unet, a.no_unet),
+                               ("galerkin_transformer", bench_galerkin, a.no_galerkin), ("dpot_s", bench_dpot, a.no_dpot),
+                               ("unet", bench_unet, a.no_unet),
                                ("unet_c3", bench_unet_c3, a.no_unet)):
             if not flag:
                 extra[name] = fn(dev)

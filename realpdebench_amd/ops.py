@@ -271,6 +271,8 @@ def mul(a, b, out, n):
 
 
 GEMM_SPLIT = os.environ.get("RPB_GEMM_EXACT", "0") != "1"
+GEMM_SPLIT_WIDE_N = 8192               # ... unless the output is wide enough to fill the chip from few rows (DPOT's TimeAggregator data
+                                       # gradient, M = 4096, N = 20480: 167 vs 124 TF/s; its N = 1024 GEMMs: 83-108 vs 93-118, stay fp32)
 GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
 
 
@@ -279,7 +281,8 @@ GEMM_SPLIT_MIN_N = 256                # the K-split tiles of N = 64 / 128 lose t
 
 
 def gemm_split_ok(M, N, K, lda, ldo, conv):
-    return (GEMM_SPLIT and not conv and M >= GEMM_SPLIT_MIN_ROWS and K % 64 == 0 and K >= GEMM_SPLIT_MIN_K
+    big = M >= GEMM_SPLIT_MIN_ROWS or (M >= 2048 and N >= GEMM_SPLIT_WIDE_N)
+    return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= GEMM_SPLIT_MIN_K
             and (N in (64, 128) or N % 256 == 0) and N >= GEMM_SPLIT_MIN_N and lda % 4 == 0 and ldo % 4 == 0)
 
 

@@ -49,8 +49,7 @@ def test_lr_schedules_match_torch():
             ts.step()
     with pytest.raises(ValueError):
         Trainer(m, lr=1e-2, num_update=10, scheduler="linear")
-    with pytest.raises(NotImplementedError):
-        Trainer(m, lr=1e-2, num_update=10, clip_grad_norm=1.0)
+    assert Trainer(m, lr=1e-2, num_update=10, clip_grad_norm=1.0).clip == 1.0      # train.py:330-331 (tests/test_gpu_fno.py runs it)
 
 
 def test_galerkin_state_dict_contract_cpu():
@@ -101,3 +100,25 @@ def test_eval_metrics_matches_reference():
                 assert float(v) == r, (name, i, float(v), r)
                 continue
             assert abs(float(v) - r) <= 2e-5 * max(abs(r), 1e-3), (name, i, float(v), r)
+
+
+def test_dpot_registry_state_dict_and_loud_limits():
+    """load_model('dpot') with the reference's keyword surface (load_model.py:108-131): the state_dict carries the reference's key set
+    (fixture taken from the imported reference), unsupported members of the family are refused by name, and there is no CPU path."""
+    import yaml
+    from conftest import dpot_golden
+    from realpdebench_amd.model.load_model import load_model
+    g = dpot_golden()
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "realpdebench_amd", "configs", "cylinder", "dpot_s.yaml")))
+    cfg.update({k: v for k, v in g["cfg"].items() if k not in ("data_out_channels",)})
+    m = load_model([(g["x"][0], g["y"][0])], device="cpu", **cfg)
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    m.load_state_dict(g["sd"], strict=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(g["x"])
+    with pytest.raises(NotImplementedError, match="normalize=True"):
+        load_model([(g["x"][0], g["y"][0])], device="cpu", **dict(cfg, normalize=True))
+    with pytest.raises(NotImplementedError, match="data resolution"):
+        load_model([(torch.zeros(4, 64, 64, 2), torch.zeros(4, 64, 64, 2))], device="cpu", **cfg)
+    with pytest.raises(NotImplementedError, match="DPOTNet3D"):
+        load_model([(g["x"][0], g["y"][0])], device="cpu", **dict(cfg, model_type="dpot3d"))
