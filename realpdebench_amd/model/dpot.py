@@ -153,6 +153,11 @@ class DPOT(_ModelBase):
             if k in own and tuple(v.shape) == tuple(own[k].shape):
                 ok[k] = v
         self.dpot_model.load_state_dict(ok, strict=False)
+        self.dpot_model.to(device)
+        keys = ("train_losses", "val_losses", "iteration", "best_iteration", "best_val_loss")
+        if isinstance(ck, dict) and all(k in ck for k in keys):            # model/dpot.py:390-399: this trainer's own checkpoints
+            return {"all_train_losses": ck["train_losses"], "all_val_losses": ck["val_losses"], "iteration": ck["iteration"],
+                    "best_iteration": ck["best_iteration"], "best_val_loss": ck["best_val_loss"]}
         return None
 
     # ------------------------------------------------------------------ constants

@@ -236,3 +236,24 @@ def test_eval_metrics_hip_path_matches_reference():
     finally:
         _lib.PROFILE = None
     assert "spectrum_bin" in labels and any(k.startswith("axis_gemm[metricsW") for k in labels)      # the HIP path ran
+
+
+def test_dpot_train_then_eval(tmp_path):
+    """Same entrypoints with model_name: dpot (the shipped configs/cylinder/dpot_s.yaml key surface at a reduced size; clip_grad_norm 1
+    as in the reference YAML; N_autoregressive 2 feeds the 4 predicted frames back as the next window)."""
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd import train as tr
+    with open(os.path.join(os.path.dirname(tr.__file__), "configs", "cylinder", "dpot_s.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg.update(exp_name="d", results_path=str(tmp_path), shape_in=[4, 32, 32, 2], shape_out=[4, 32, 32, 2], n_train=8, n_val=4,
+               img_size=32, embed_dim=128, depth=2, in_timesteps=4, out_timesteps=4, num_update=100, train_batch_size=4,
+               test_batch_size=4, lr=1e-3, N_autoregressive=2)
+    path = tmp_path / "dp.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = tr.main(["--config", str(path), "--max_updates", "6"])
+    ckpts = sorted(glob.glob(os.path.join(exp, "model_*.pth")))
+    ck = torch.load(ckpts[-1], map_location="cpu")
+    assert ck["iteration"] == 6 and "dpot_model.blocks.0.filter.w1" in ck["model_state_dict"]
+    assert all(l == l and l < 1e3 for l in ck["train_losses"])
+    assert ck["train_losses"][-1] < 1.5 * ck["train_losses"][0]
+    ev.main(["--config", str(path), "--checkpoint_path", ckpts[-1]])
