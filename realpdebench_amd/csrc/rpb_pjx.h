@@ -1,0 +1,10 @@
+// Projection head (fc1 -> act -> fc2, fno.py:121-125) on the bf16 matrix pipe: internal entry points of csrc/rpb_pjx.hip that
+// rpb_proj_fwd / rpb_proj_bwd (csrc/rpb_proj.hip) dispatch to when the shape is covered (C = 64, fc2 out features <= 4, fp32 input).
+#pragma once
+#include "rpb_common.h"
+
+bool rpb_pjx_head_supported(int C, int DO, bool bwd);
+long rpb_pjx_head_slots(int B, int T, int H, bool bwd);
+int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
+                        float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
+                        const XForm& xf, int act, hipStream_t st);

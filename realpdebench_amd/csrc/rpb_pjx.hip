@@ -355,6 +355,242 @@ extern "C" int rpb_proj_dgrad(const float* s, const float* w1, const float* b1, 
     RPB_CHECK_LAUNCH("proj_dgrad");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------ head forward / gu
+// The projection head itself on the bf16 matrix pipe (replaces the fp32-MFMA kernels of rpb_proj.hip for C = 64):
+//   BWD = false:  out[cell][j] = b2[j] + sum_hid w2[j][hid] act(u[hid]),  u = fc1 a + b1           (fno.py:123-125)
+//   BWD = true :  gu[cell][hid] = (sum_j gout[cell][j] w2[j][hid]) act'(u[hid])  + partial sums of d fc2.weight, d fc1.bias, d fc2.bias
+// u^T = W1 a^T is computed as in the data-gradient kernel above (hidden units = MFMA rows, the lane's cell = MFMA column), so a lane
+// holds the 32 hidden units {16 mt + 4 mg + r} of ONE cell: the fc2 contraction is 32 FMAs per output + two cross-group adds, the
+// gu rows are 16 B stores, and the parameter-gradient sums are per-lane accumulators reduced over the 16 cell lanes once at the end.
+struct PjhArgs {
+    const float* s;
+    const float* w1;
+    const float* b1;
+    const float* w2;
+    const float* b2;
+    const float* gout;    // BWD: [ncrop][DO]
+    float* out;           // FWD: [ncrop][DO]
+    float* gu;            // BWD: [ncrop][128]
+    float* part;          // BWD: [slots][DO*128 + 128 + DO]
+    int B, DO, act;
+    CropMap cm;
+    XForm xf;
+};
+
+template <bool BWD, int DOT>
+__global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
+    extern __shared__ u32x4 lds4[];
+    u32x4* W1A = lds4;                                              // [ks 2][plane 3][mt 8][lane]
+    float* xfl = reinterpret_cast<float*>(W1A + 2 * 3 * 8 * 64);    // [4][64]
+    float* b1l = xfl + 256;                                         // [128]
+    float* w2l = b1l + PJ_HID;                                      // [DOT][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kg = lane >> 4;
+    const int DO = p.DO;
+    for (int idx = tid; idx < 2 * 8 * 64; idx += blockDim.x) {
+        const int l = idx & 63, mt = (idx >> 6) & 7, ks = idx >> 9;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p.w1[(16 * mt + (l & 15)) * 64 + chan_of(ks, l >> 4, e)];
+        bf16x8 h, m, lo;
+        split8(v, h, m, lo);
+        W1A[((ks * 3 + 0) * 8 + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        W1A[((ks * 3 + 1) * 8 + mt) * 64 + l] = __builtin_bit_cast(u32x4, m);
+        W1A[((ks * 3 + 2) * 8 + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+    }
+    for (int idx = tid; idx < PJ_HID; idx += blockDim.x) b1l[idx] = p.b1[idx];
+    for (int idx = tid; idx < DOT * PJ_HID; idx += blockDim.x) w2l[idx] = idx < DO * PJ_HID ? p.w2[idx] : 0.f;
+    const bool has_xf = p.xf.mean != nullptr;
+    if (tid < 64) {
+        xfl[tid] = has_xf ? p.xf.mean[tid] : 0.f;
+        xfl[64 + tid] = has_xf ? p.xf.invstd[tid] : 1.f;
+        xfl[128 + tid] = has_xf ? p.xf.gamma[tid] : 1.f;
+        xfl[192 + tid] = has_xf ? p.xf.beta[tid] : 0.f;
+    }
+    __syncthreads();
+
+    const CropMap cm = p.cm;
+    const long GL = (long)p.B * cm.T * cm.H;                        // cropped lines
+    const long nslots = (long)gridDim.x * PJ_WAVES;
+    const long slot = (long)blockIdx.x * PJ_WAVES + wave;
+    const int TQ = (cm.W + 15) >> 4;
+    const bool xgelu = has_xf && p.xf.gelu != 0, silu = p.act == 1;
+    float b2v[DOT];
+#pragma unroll
+    for (int j = 0; j < DOT; ++j) b2v[j] = (!BWD && j < DO) ? p.b2[j] : 0.f;
+    f32x4v db1[BWD ? 8 : 1], dw2[BWD ? DOT : 1][BWD ? 8 : 1];
+    float db2[DOT];
+#pragma unroll
+    for (int j = 0; j < DOT; ++j) db2[j] = 0.f;
+    if (BWD) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            db1[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < DOT; ++j) dw2[j][mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    auto line_of = [&](long gl) {                                   // cropped line -> padded line
+        const int h = (int)(gl % cm.H);
+        const long r2 = gl / cm.H;
+        return ((r2 / cm.T) * cm.Tp + r2 % cm.T) * cm.Hp + h;
+    };
+    u32x4 xa[4];
+    auto issue = [&](long gl, int q) {
+        const rsrc_t rx = make_rsrc(p.s + line_of(gl) * cm.Wp * 64, (unsigned)cm.W * 256u);      // cells >= W read as 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[i] = ld16(rx, (16 * q + n16) * 256 + i * 64 + kg * 16);
+    };
+    if (slot < GL) issue(slot, 0);
+    for (long gl = slot; gl < GL; gl += nslots) {
+        const rsrc_t rgo = make_rsrc((BWD ? p.gout : p.out) + gl * cm.W * DO, (unsigned)(cm.W * DO) * 4u);
+        const rsrc_t rgu = make_rsrc(BWD ? p.gu + gl * cm.W * PJ_HID : p.s, BWD ? (unsigned)(cm.W * PJ_HID) * 4u : 0u);
+        for (int q = 0; q < TQ; ++q) {
+            asm volatile("" ::: "memory");
+            const bool last = q + 1 == TQ;
+            const long gn = last ? gl + nslots : gl;
+            f32x4v acc[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt] = *reinterpret_cast<const f32x4v*>(b1l + 16 * mt + 4 * kg);
+            float go[DOT];
+#pragma unroll
+            for (int j = 0; j < DOT; ++j) go[j] = (BWD && j < DO) ? buf_load_f32(rgo, ((16 * q + n16) * DO + j) * 4, 0) : 0.f;
+            bf16x8 Bh[2], Bm[2], Bl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int i = 2 * ks + hf;
+                    const f32x4v xv = __builtin_bit_cast(f32x4v, xa[i]);
+                    const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfl + 16 * i + 4 * kg);
+                    const f32x4v is = *reinterpret_cast<const f32x4v*>(xfl + 64 + 16 * i + 4 * kg);
+                    const f32x4v ga = *reinterpret_cast<const f32x4v*>(xfl + 128 + 16 * i + 4 * kg);
+                    const f32x4v be = *reinterpret_cast<const f32x4v*>(xfl + 192 + 16 * i + 4 * kg);
+                    f32x4v z = bn4(xv, mu, is, ga, be);
+                    if (xgelu) z = gelu4(z);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[4 * hf + c] = z[c];
+                }
+                split8(v, Bh[ks], Bm[ks], Bl[ks]);
+            }
+            if (gn < GL) issue(gn, last ? 0 : q + 1);               // the next tile's loads fly during the products below
+            // MG row tiles advance together: MG independent accumulation chains per product keep the matrix pipe issuing back to back
+            constexpr int MG = BWD ? 2 : 4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m0 = 0; m0 < 8; m0 += MG) {
+                    bf16x8 ah[MG], am[MG], al[MG];
+#pragma unroll
+                    for (int u = 0; u < MG; ++u) {
+                        ah[u] = __builtin_bit_cast(bf16x8, W1A[((ks * 3 + 0) * 8 + m0 + u) * 64 + lane]);
+                        am[u] = __builtin_bit_cast(bf16x8, W1A[((ks * 3 + 1) * 8 + m0 + u) * 64 + lane]);
+                        al[u] = __builtin_bit_cast(bf16x8, W1A[((ks * 3 + 2) * 8 + m0 + u) * 64 + lane]);
+                    }
+#define PJ_ROW(AP, BP) _Pragma("unroll") for (int u = 0; u < MG; ++u) acc[m0 + u] = mfma16(AP[u], BP[ks], acc[m0 + u]);
+                    PJ_ROW(ah, Bl) PJ_ROW(al, Bh) PJ_ROW(am, Bm) PJ_ROW(ah, Bm) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
+#undef PJ_ROW
+                }
+            if (!BWD) {
+                float po[DOT];
+#pragma unroll
+                for (int j = 0; j < DOT; ++j) po[j] = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    f32x4v vv;
+                    if (silu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v1, d;
+                            act_pair(acc[mt][r], true, v1, d);
+                            vv[r] = v1;
+                        }
+                    } else {
+                        vv = gelu4(acc[mt]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < DOT; ++j) {
+                        const f32x4v w = *reinterpret_cast<const f32x4v*>(w2l + j * PJ_HID + 16 * mt + 4 * kg);
+                        const f32x4v pr = w * vv;
+                        po[j] += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < DOT; ++j) {
+                    float t = po[j];
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    if (kg == 0 && j < DO) buf_store_f32(t + b2v[j], rgo, ((16 * q + n16) * DO + j) * 4, 0);   // cells >= W: dropped
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    f32x4v gp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < DOT; ++j) gp += *reinterpret_cast<const f32x4v*>(w2l + j * PJ_HID + 16 * mt + 4 * kg) * go[j];
+                    f32x4v vv, dd;
+                    if (silu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v1, d1;
+                            act_pair(acc[mt][r], true, v1, d1);
+                            vv[r] = v1;
+                            dd[r] = d1;
+                        }
+                    } else {                                        // v = u Phi(u), d = Phi(u) + u phi(u): one erf, packed pairs
+                        const f32x4v u = acc[mt];
+                        const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
+                        const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
+                        const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
+                        f32x4v ex;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(q2[r]);
+                        vv = u * cdf;
+                        dd = cdf + u * (ex * 0.39894228040143267794f);
+                    }
+                    const f32x4v guv = gp * dd;                     // cells >= W carry gout == 0 -> 0, and their store is dropped
+                    st16(guv, rgu, (16 * q + n16) * 512 + (16 * mt + 4 * kg) * 4);
+                    db1[mt] += guv;
+#pragma unroll
+                    for (int j = 0; j < DOT; ++j) dw2[j][mt] += vv * go[j];
+                }
+#pragma unroll
+                for (int j = 0; j < DOT; ++j) db2[j] += kg == 0 ? go[j] : 0.f;
+            }
+        }
+    }
+    if (BWD) {      // sums over the 16 cell lanes of each lane group; lane n16 == 0 of group mg writes hidden 16 mt + 4 mg + r
+        float* part = p.part + slot * ((long)DO * PJ_HID + PJ_HID + DO);
+        auto red16 = [&](float v) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+            return v;
+        };
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float b = red16(db1[mt][r]);
+                if (n16 == 0) part[DO * PJ_HID + 16 * mt + 4 * kg + r] = b;
+#pragma unroll
+                for (int j = 0; j < DOT; ++j) {
+                    const float w = red16(dw2[j][mt][r]);
+                    if (n16 == 0 && j < DO) part[j * PJ_HID + 16 * mt + 4 * kg + r] = w;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < DOT; ++j) {
+            float b = red16(db2[j]);                                 // only group 0 counted the cells
+            if (lane == 0 && j < DO) part[DO * PJ_HID + PJ_HID + j] = b;
+        }
+    }
+}
+
+static size_t pjx_head_lds(int dot) { return (size_t)(2 * 3 * 8 * 64) * 16 + (256 + PJ_HID + (size_t)dot * PJ_HID) * 4; }
+
 // ------------------------------------------------------------------------------------------------------------ wgrad
 // A wave owns PJ_NT 16-wide hidden tiles = PJ_HB hidden units (role = slot % PJ_ROLES); part row of a slot:
 //   [PJ_HB * 64]  d fc1.weight[PJ_HB role + hl][ch]
@@ -607,4 +843,43 @@ extern "C" int rpb_proj_wgrad(const float* s, const float* w1, const float* b1, 
         hipLaunchKernelGGL(pjx_wgrad_kernel<4>, dim3(grid), dim3(PJ_WAVES * 64), lds, (hipStream_t)stream, p);
     }
     RPB_CHECK_LAUNCH("proj_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------------------------ head entry points
+// (called by rpb_proj_fwd / rpb_proj_bwd in rpb_proj.hip when the shape is covered; same arguments, same partial-row layout)
+// (the gu producer keeps 32 (1 + DO) gradient accumulators per lane: two fc2 outputs fit the register file, four spill)
+bool rpb_pjx_head_supported(int C, int DO, bool bwd) { return !pjx_off() && C == 64 && DO >= 1 && DO <= (bwd ? 2 : PJ_DOMAX); }
+
+long rpb_pjx_head_slots(int B, int T, int H, bool bwd) {
+    const long GL = (long)B * T * H;
+    long grid = (bwd ? 1L : 2L) * rpb_num_cus();          // forward: 122 registers, 60 KB of LDS -> two workgroups per CU
+    const long need = (GL + PJ_WAVES - 1) / PJ_WAVES;
+    if (grid > need) grid = need;
+    return grid * PJ_WAVES;
+}
+
+int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
+                        float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
+                        const XForm& xf, int act, hipStream_t st) {
+    PjhArgs p{};
+    p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.out = out; p.gu = gu; p.part = part;
+    p.B = (int)(ncrop / ((long)T * H * W)); p.DO = DO; p.act = act;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    p.xf = xf;
+    long slots = rpb_pjx_head_slots(p.B, T, H, bwd);
+    if (bwd && slots > part_rows) slots = part_rows / PJ_WAVES * PJ_WAVES;       // never more partial rows than the caller allocated
+    RPB_REQUIRE(slots >= PJ_WAVES, "proj (bf16 pipe): no partial rows");
+    const int grid = (int)(slots / PJ_WAVES);
+    if (bwd && part_rows > slots)                                                 // rows this launch does not write
+        (void)hipMemsetAsync(part + slots * ((long)DO * PJ_HID + PJ_HID + DO), 0, (size_t)(part_rows - slots) * ((long)DO * PJ_HID + PJ_HID + DO) * 4, st);
+    const int dot = DO <= 2 ? 2 : 4;
+    const size_t lds = pjx_head_lds(dot);
+#define RPB_PJH(BWD_, D_)                                                                                                    \
+    if (bwd == BWD_ && dot == D_) {                                                                                          \
+        (void)hipFuncSetAttribute((const void*)pjx_head_kernel<BWD_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pjx_head_kernel<BWD_, D_>), dim3(grid), dim3(PJ_WAVES * 64), lds, st, p);                        \
+    }
+    RPB_PJH(false, 2) RPB_PJH(false, 4) RPB_PJH(true, 2)
+#undef RPB_PJH
+    RPB_CHECK_LAUNCH("proj (bf16 pipe)");
 }

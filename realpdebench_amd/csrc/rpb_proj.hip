@@ -11,6 +11,7 @@
 // B=32), produces gu = (fc2^T g) * gelu'(u) for the downstream dgrad / wgrad kernels and accumulates
 // d fc2.weight, d fc2.bias, d fc1.bias in registers.
 #include "rpb_common.h"
+#include "rpb_pjx.h"
 
 #define HID 128
 #define NTH (HID / 32)
@@ -369,6 +370,11 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
     p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    if (rpb_pjx_head_supported(C, DO, false)) {      // bf16 matrix pipe, fp32-grade split operands (csrc/rpb_pjx.hip)
+        RPB_REQUIRE(a && w1 && b1 && w2 && b2, "proj: null pointer");
+        return rpb_pjx_head_launch(false, a, w1, b1, w2, b2, nullptr, out, nullptr, nullptr, 0, DO, T, H, W, Tp, Hp, Wp, ncrop, p.xf, act,
+                                   (hipStream_t)stream);
+    }
     return proj_launch(false, p, (hipStream_t)stream);
 }
 
@@ -396,5 +402,10 @@ extern "C" int rpb_proj_bwd(const float* a, const float* w1, const float* b1, co
     p.a = a; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.gu = gu; p.part = part;
     p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    if (rpb_pjx_head_supported(C, DO, true)) {
+        RPB_REQUIRE(a && w1 && b1 && w2 && b2, "proj: null pointer");
+        return rpb_pjx_head_launch(true, a, w1, b1, w2, b2, gout, nullptr, gu, part, rpb_proj_slots(ncrop, C, DO), DO, T, H, W, Tp, Hp, Wp,
+                                   ncrop, p.xf, act, (hipStream_t)stream);
+    }
     return proj_launch(true, p, (hipStream_t)stream);
 }

@@ -131,10 +131,12 @@ def test_cell_wgrad_crop(ops):
     assert rel_l2(part.double().sum(0).cpu()[:CO * CI].view(CO, CI), ref) < TOL
 
 
-@pytest.mark.parametrize("C,DO", [(64, 2), (32, 3), (128, 5), (64, 16)])
-def test_proj_fwd_bwd(ops, C, DO):
+@pytest.mark.parametrize("C,DO,W", [(64, 2, 7), (64, 2, 40), (64, 1, 16), (64, 4, 21), (32, 3, 7), (128, 5, 7), (64, 16, 7)])
+def test_proj_fwd_bwd(ops, C, DO, W):
+    """C = 64 with DO <= 4 (forward) / <= 2 (backward) runs on the bf16 matrix pipe (csrc/rpb_pjx.hip: line-walking waves, partial
+    last tile), everything else on the fp32 MFMA kernels."""
     torch.manual_seed(C + DO)
-    B, T, H, W, pad = 2, 3, 6, 7, 2
+    B, T, H, pad = 2, 3, 6, 2
     d = ops.Dims(B, T, H, W, 2, C, pad)
     a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64)
     w1 = (torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)).requires_grad_(True)
@@ -514,9 +516,9 @@ def test_bf16_storage_kernels(ops, Wp, rows, K2):
     w1, b1 = torch.randn(128, C, device="cuda") / 8, torch.randn(128, device="cuda")
     w2, b2 = torch.randn(2, 128, device="cuda") / 11, torch.randn(2, device="cuda")
     o32, o16 = torch.empty(d.ncrop, 2, device="cuda"), torch.empty(d.ncrop, 2, device="cuda")
-    ops.proj_fwd(a16.float(), w1, b1, w2, b2, o32, d, 2)
-    ops.proj_fwd_bf16(a16, w1, b1, w2, b2, o16, d, 2)
-    assert torch.equal(o16, o32)
+    ops.proj_fwd(a16.float(), w1, b1, w2, b2, o32, d, 2)           # fp32 input: bf16 matrix pipe, split operands
+    ops.proj_fwd_bf16(a16, w1, b1, w2, b2, o16, d, 2)              # bf16 input: fp32 MFMA on the widened values
+    assert rel_l2(o16, o32) < 1e-6
 
 
 @pytest.mark.parametrize("B,T,H,W,pad,DO,gelu,act", [(2, 3, 5, 32, 2, 2, False, 0), (1, 2, 4, 48, 3, 1, False, 0),
