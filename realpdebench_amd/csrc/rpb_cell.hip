@@ -414,6 +414,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.write_gz = bnb_s != nullptr && bnb_gelu == 2;
         c.bf16_io = 0;
         c.feat_w = 0;
+        c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
@@ -467,6 +468,7 @@ extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const floa
     c.write_gz = 0;
     c.bf16_io = 1;
     c.feat_w = 0;
+    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 
@@ -489,7 +491,35 @@ extern "C" int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const flo
     c.write_gz = 0;
     c.bf16_io = 0;
     c.feat_w = FW;
+    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
     return rpb_cmx_launch(c, stats_part ? 1 : 0, (hipStream_t)stream);
+}
+
+// Eval cell_mix (output transform = this layer's BatchNorm (+GELU)) with the NEXT layer's forward W stage fused in (csrc/rpb_cmx.hip):
+// out [ncell][64] as rpb_cell_mix / rpb_cell_mix_feat (feat_w > 0: x is the feature tensor, Wm the composite weight), and
+// y1 [ncell / Wp][K2f][64] = sum_w FWt[w][k] out[line, w][c] -- what rpb_axis_gemm(out, y1, FWt, ...) would compute from a second read.
+extern "C" int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+                                     long ncell, int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd,
+                                     const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1,
+                                     void* stream) {
+    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1, "cell_mix_eval_dft: null pointer");
+    RPB_REQUIRE(feat_w == 0 || feat_w == 8 || feat_w == 32, "cell_mix_eval_dft: feat_w=%d", feat_w);
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f),
+                "cell_mix_eval_dft: unsupported sizes (K2=%d Wp=%d K2f=%d)", K2, Wp, K2f);
+    CmxArgs c;
+    c.x = x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.write_gz = 0;
+    c.bf16_io = 0;
+    c.feat_w = feat_w;
+    c.FWt = FWt; c.y1out = y1; c.K2f = K2f;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
+extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f) {
+    return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad

@@ -19,8 +19,12 @@ struct CmxArgs {
     int bf16_io;          // x and out are bf16 [ncell][64] (passed through the float pointers); eval path only
     int feat_w;           // > 0: x is the feature tensor Phi_c [ncell][feat_w] and Wm the composite weight [64][feat_w] (layer 0, forward)
     int write_gz;         // STATS == 2: store gz = out * act'(z) instead of out (the consumer then skips act')
+    const float* FWt;     // eval (STATS == 0 with the output transform): forward W-stage matrix [Wp][K2f] of the NEXT layer's spectral branch ...
+    float* y1out;         // ... and its result [G][K2f][64] = that stage applied to the activated line this launch writes (fused: the
+    int K2f;              //     activations are not read again for it); null = off
 };
 
+bool rpb_cmx_dft_supported(int Wp, int K2f);
 bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather);
 long rpb_cmx_stat_rows(long ncell, int Wp, int stats);   // stats: 0 / 1 / 2 as in the kernel template
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);

@@ -74,19 +74,27 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // FEAT: layer 0 -- x is the feature tensor Phi_c [ncell][FW] (FW = 8 or 32 floats per cell, rpb_lift_feat) and Wm the COMPOSITE
 //       weight Wc0 W0ext [64][FW]: A0 = W0ext Phi_c is never materialised, the channel mixing is one K-step (k = (kg, e) <->
 //       field 8 kg + e; lanes with 8 kg >= FW load nothing).
-template <int STATS, bool BF = false, bool FEAT = false>
-__global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a) {
+// DFT:  eval only -- the activated line this wave writes is also the input of the next layer's forward W stage (fno.py:48): the
+//       tile's outputs sit in the accumulators in exactly that stage's B-operand form (lane group kg holds cells {4 kg + r, 16 + 4 kg + r}
+//       of channels 4 n + t), so Y1[line] = FW a accumulates on the matrix pipe from the split outputs and the stage never reads the
+//       activations from HBM (one of the three activation passes per layer of the rollout).  The stage matrix per wave tile lives in
+//       LDS in A-operand order; that costs two waves per workgroup (6 instead of 8).
+#define CMX_WAVES_DFT 6
+template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false>
+__global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!DFT || (STATS == 0 && !BF), "fused forward W stage: fp32 eval path");
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
     static_assert(!(BF && FEAT), "the feature tensor is fp32");
     constexpr int KSN = FEAT ? 1 : 2;                    // K-steps of the channel mixing
     const int FW = a.feat_w;
-    constexpr int CMX_WAVES = CMX_WAVES_OF(STATS);
+    constexpr int CMX_WAVES = DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS);
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
     u32x4* GWs = Bw + 24 * 64;               // [plane 3][w Wp][kg 4]           last-stage DFT matrix, A-operand rows
     u32x4* Zs = GWs + 3 * Wp * 4;            // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
     float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
+    u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * 64);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,6 +132,24 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
         GWs[(0 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, h);
         GWs[(1 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, md);
         GWs[(2 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, lo);
+    }
+    if (DFT) {
+        const int TQ0 = (Wp + 31) >> 5;
+        for (int idx = tid; idx < TQ0 * 2 * 64; idx += blockDim.x) {
+            const int l = idx & 63, mt2 = (idx >> 6) & 1, q = idx >> 7;
+            const int k = 16 * mt2 + (l & 15);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int w = 32 * q + 16 * (e >> 2) + 4 * (l >> 4) + (e & 3);
+                v[e] = (k < a.K2f && w < Wp) ? a.FWt[w * a.K2f + k] : 0.f;        // cells past the line end contribute nothing
+            }
+            bf16x8 h, md, lo;
+            split8(v, h, md, lo);
+            FWs[((q * 3 + 0) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, h);
+            FWs[((q * 3 + 1) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, md);
+            FWs[((q * 3 + 2) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+        }
     }
     if (has_xf && tid < 64) {
         xfp[tid] = a.xf.mean[tid];
@@ -193,6 +219,7 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
         issue_z(slot);
     }
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
+    f32x4v Yacc[DFT ? 2 : 1][DFT ? 4 : 1];
     for (long g = slot; g < G; g += nslots) {
         const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
         const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
@@ -365,6 +392,10 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
                             }
                             o[t] = v[0];
                             o[t + 1] = v[1];
+                            if (DFT) {                               // keep the stored value: operand of the fused W stage below
+                                acc[j][t][r] = v[0];
+                                acc[j][t + 1][r] = v[1];
+                            }
                         }
                         if (BF) {               // round to nearest even, 4 channels = 8 B per lane, 128 B per cell row
                             typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -382,6 +413,49 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
             };
             if (last) epilogue(std::true_type{});
             else epilogue(std::false_type{});
+            if (DFT) {
+                if (q == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) Yacc[i][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+                bf16x8 fh[2], fm[2], fl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fh[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 0) * 2 + i) * 64 + lane]);
+                    fm[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 1) * 2 + i) * 64 + lane]);
+                    fl[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 2) * 2 + i) * 64 + lane]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[0][t][r];
+                        v[4 + r] = half_tile ? 0.f : acc[1][t][r];            // the second MFMA tile was not computed
+                    }
+                    bf16x8 yh, ym, yl;
+                    split8(v, yh, ym, yl);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Yacc[i][t] = mfma16(fh[i], yl, Yacc[i][t]);
+                        Yacc[i][t] = mfma16(fl[i], yh, Yacc[i][t]);
+                        Yacc[i][t] = mfma16(fm[i], ym, Yacc[i][t]);
+                        Yacc[i][t] = mfma16(fh[i], ym, Yacc[i][t]);
+                        Yacc[i][t] = mfma16(fm[i], yh, Yacc[i][t]);
+                        Yacc[i][t] = mfma16(fh[i], yh, Yacc[i][t]);
+                    }
+                }
+                if (last) {                     // Y1[g][k = 16 i + 4 mg + r][channels 4 n ..]: 16 B per lane and row
+                    const rsrc_t ry = make_rsrc(a.y1out + g * a.K2f * 64, (unsigned)a.K2f * 256u);   // rows >= K2f: dropped
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            st16(f32x4v{Yacc[i][0][r], Yacc[i][1][r], Yacc[i][2][r], Yacc[i][3][r]}, ry, (16 * i + 4 * kg + r) * 256 + m * 16);
+                }
+            }
         }
     }
     if (STATS != 0) {
@@ -401,7 +475,10 @@ __global__ __launch_bounds__(CMX_WAVES_OF(STATS) * 64) void cmx_kernel(CmxArgs a
     }
 }
 
-static size_t cmx_lds(int Wp, int waves) { return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4; }
+static size_t cmx_lds(int Wp, int waves, bool dft = false) {
+    return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0);
+}
+bool rpb_cmx_dft_supported(int Wp, int K2f) { return K2f > 0 && K2f <= 32 && cmx_lds(Wp, CMX_WAVES_DFT, true) <= 160 * 1024; }
 
 // the bf16-pipe kernel covers the C = 64 spectral instances; everything else stays on rpb_cell.hip
 bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather) {
@@ -420,6 +497,23 @@ long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
 }
 
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
+    if (a.y1out) {                  // eval with the next layer's forward W stage fused in
+        if (stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !rpb_cmx_dft_supported(a.Wp, a.K2f))
+            RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the fp32 eval path (output transform) and K2f <= 32");
+        const int waves = CMX_WAVES_DFT;
+        const long G = a.ncell / a.Wp;
+        long grid = rpb_num_cus();
+        if (grid > (G + waves - 1) / waves) grid = (G + waves - 1) / waves;
+        const size_t lds = cmx_lds(a.Wp, waves, true);
+        if (a.feat_w) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, false, true, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, false, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        }
+        RPB_CHECK_LAUNCH("cell_mix(bf16x3, + next W stage)");
+    }
     const int waves = CMX_WAVES_OF(stats);
     const int grid = (int)(rpb_cmx_stat_rows(a.ncell, a.Wp, stats) / waves);
     const size_t lds = cmx_lds(a.Wp, waves);

@@ -52,6 +52,10 @@ class _Workspace:
         G1, N1 = B * d.Tp * d.Hp, 2 * plan.KW * C
         self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
         self.Y2 = torch.empty(B * d.Tp * 2 * plan.KH * plan.KW * C, **f)     # after H stage
+        # eval: cell_mix also applies the next layer's forward W stage (csrc/rpb_cmx.hip, DFT variant) into its own buffer
+        self.fuse_w = (not training and not self.bf16 and C == 64 and os.environ.get("RPB_EVAL_FUSE_W", "1") != "0"
+                       and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
+        self.Y1f = torch.empty(G1 * N1, **f) if self.fuse_w else None
         self.Xh = [torch.empty(B * 2 * plan.M * C, **f) for _ in range(L if training else 1)]
         self.Yh = torch.empty(B * 2 * plan.M * C, **f)
         self.mean = torch.empty(L, C, **f)
@@ -336,20 +340,22 @@ class FNO3d(Model):
         return self._ws[key]
 
     # ------------------------------------------------------------------ spectral stages
-    def _spectral_forward_stages(self, x, ws, xh, mats, first_layer, xf=None):
+    def _spectral_forward_stages(self, x, ws, xh, mats, first_layer, xf=None, y1=None):
         """x [cells][C] -> truncated spectrum xh [B][2][M][C] with stage matrices ``mats`` = (W, H, T).
-        ``xf``: lazy BatchNorm(+GELU) of the producing layer, applied while the W stage loads ``x``."""
+        ``xf``: lazy BatchNorm(+GELU) of the producing layer, applied while the W stage loads ``x``.
+        ``y1``: the W stage's result when a fused producer already wrote it (then ``mats[0]`` is None)."""
         d, p, C = ws.d, self.plan, self.width
         m3, KH, KT = p.KW, p.KH, p.KT
         MW, MH, MT = mats
         N2, N3 = m3 * C, KH * m3 * C
+        y1 = ws.Y1 if y1 is None else y1
         if MW is not None and x.dtype == torch.bfloat16:     # eval with bf16 activation storage
             ops.axis_gemm_bf16in(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
                                  k_valid=d.W if first_layer else None)
-        elif MW is not None:                    # None: ws.Y1 was already produced (fused backward row kernel)
+        elif MW is not None:                    # None: y1 was already produced (fused backward row kernel / eval cell_mix)
             ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
                           k_valid=d.W if first_layer else None, xf=xf)
-        ops.axis_gemm(ws.Y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
+        ops.axis_gemm(y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
                       k_valid=2 * d.H if first_layer else None)
         ops.axis_gemm(ws.Y2, xh, MT, d.B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3,
                       k_valid=2 * d.T if first_layer else None)
@@ -392,12 +398,15 @@ class FNO3d(Model):
         self._lift_fwd(x, ws)
         world = self.dp.world_size if (self.dp is not None and training) else 1
         a_in, xf = ws.A0, None                   # layer input tensor and its lazy transform
+        y1_ready = False                         # eval: the previous cell_mix already applied this layer's forward W stage
         for l in range(L):
             s = ws.S[l] if training else ws.S[l % 2]
             xh = ws.Xh[l] if training else ws.Xh[0]
             if l == 0 and ws.feat0:
                 self._feature_spectrum(x, ws, plan)
                 ops.feat_mix(ws.PhiH, P("fc0.weight"), P("fc0.bias"), xh, d.B, 2 * plan.M, ws.NB, self.dim_in, C)
+            elif y1_ready:
+                self._spectral_forward_stages(a_in, ws, xh, (None, plan.FHt, plan.FTt), first_layer=False, y1=ws.Y1f)
             else:
                 self._spectral_forward_stages(a_in, ws, xh, (plan.FWt, plan.FHt, plan.FTt), first_layer=(l == 0), xf=xf)
             ops.mode_contract_fwd(xh, P(f"spec.{l}"), ws.Yh, d.B, plan.M, C)
@@ -421,7 +430,15 @@ class FNO3d(Model):
                 # cell_mix's epilogue and the next W stage / cell_mix / projection read plain activations (one erf per
                 # element instead of two)
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
-                if l == 0 and ws.featfull:
+                y1_ready = False
+                if ws.fuse_w and l < L - 1 and (l > 0 or ws.featfull):
+                    # ... and the NEXT layer's forward W stage rides in the same launch: the activated line is never read for it
+                    feat = l == 0
+                    ops.cell_mix_eval_dft(ws.phic if feat else a_in, ws.wcomp if feat else P(f"convs.{l}.weight"), P(f"convs.{l}.bias"),
+                                          ws.Y1, plan.GWt, s, d.ncell, 2 * plan.KW, d.Wp, self._layer_xf(ws, l, False), plan.FWt,
+                                          2 * plan.KW, ws.Y1f, feat_w=ws.FW if feat else 0)
+                    y1_ready = True
+                elif l == 0 and ws.featfull:
                     ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Y1, plan.GWt, s, None, d.ncell, ws.FW,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 elif ws.bf16:

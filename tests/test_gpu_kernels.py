@@ -580,3 +580,29 @@ def test_projection_backward_without_gu(ops, B, T, H, W, pad, DO, gelu, act):
     db2 = tot[:, HB * 64 + DO * HB + HB:].sum(0)
     assert rel_l2(dw1, w1.grad) < 5e-6 and rel_l2(dw2, w2.grad) < 5e-6
     assert rel_l2(db1, b1.grad) < 5e-6 and rel_l2(db2, b2.grad) < 5e-6
+
+
+@pytest.mark.parametrize("feat_w,Wp,K2f", [(0, 70, 32), (0, 134, 32), (8, 134, 32), (0, 45, 24), (32, 40, 16)])
+def test_eval_cell_mix_with_fused_forward_w_stage(ops, feat_w, Wp, K2f):
+    """rpb_cell_mix_eval_dft == rpb_cell_mix (oxf) followed by rpb_axis_gemm along w of what it wrote (the rollout's fused stage):
+    same `out` bit for bit, y1 to fp32-grade accuracy vs fp64; lines with a partial last tile and a half tile."""
+    torch.manual_seed(Wp + K2f)
+    G, C, K2 = 6, 64, 32
+    ncell = G * Wp
+    KC = feat_w or C
+    x = torch.randn(ncell, KC, device="cuda")
+    Wm = torch.randn(C, KC, device="cuda") / KC ** 0.5
+    bias, z2, GW = torch.randn(C, device="cuda"), torch.randn(G * K2 * C, device="cuda"), torch.randn(K2, Wp, device="cuda") / 5
+    oxf = (torch.randn(C, device="cuda"), torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda"), torch.randn(C, device="cuda"), True)
+    FWt = torch.randn(Wp, K2f, device="cuda") / Wp ** 0.5
+    assert ops.cell_mix_eval_dft_supported(ncell, K2, Wp, K2f)
+    out, y1 = torch.empty(ncell, C, device="cuda"), torch.full((G, K2f, C), float("nan"), device="cuda")
+    ops.cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1, feat_w=feat_w)
+    ref = torch.empty(ncell, C, device="cuda")
+    if feat_w:
+        ops.cell_mix_feat(x, Wm, bias, z2, GW, ref, None, ncell, feat_w, K2, Wp, oxf=oxf)
+    else:
+        ops.cell_mix(x, Wm, bias, z2, GW, ref, None, ncell, C, C, K2, Wp, oxf=oxf)
+    assert torch.equal(out, ref)
+    y_ref = torch.einsum("wk,gwc->gkc", FWt.double().cpu(), ref.double().cpu().view(G, Wp, C))
+    assert rel_l2(y1.cpu(), y_ref) < 5e-6
