@@ -7,4 +7,4 @@ bool rpb_pjx_head_supported(int C, int DO, bool bwd);
 long rpb_pjx_head_slots(int B, int T, int H, bool bwd);
 int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
                         float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
-                        const XForm& xf, int act, hipStream_t st);
+                        const XForm& xf, int act, hipStream_t st, bool a_bf16 = false);

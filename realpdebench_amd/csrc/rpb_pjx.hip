@@ -378,13 +378,21 @@ struct PjhArgs {
     XForm xf;
 };
 
-template <bool BWD, int DOT>
+// DOT = 16 (forward only: the combustion configurations have 16 output features): fc2 runs on the matrix pipe as well -- the
+//   activated hidden units in the accumulators are the B operand of out^T = W2 v^T (rows {4 mg + r, 16 + 4 mg + r} of a 32-row
+//   K-step, the same accumulator-as-operand trick as the data gradient), W2 sits in LDS in A-operand order.
+// BFIN: the input is STORED as bf16 [ncell][64] (BASELINE.json configs[4]): one 16 B load is the exact B operand of a K-step
+//   (channel 32 ks + 8 kg + e), three products instead of six, no lazy transform.
+template <bool BWD, int DOT, bool BFIN = false>
 __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
+    static_assert(!(BWD && (BFIN || DOT > 4)), "gu producer: fp32 input, <= 4 outputs");
+    constexpr bool FC2M = DOT > 4;
     extern __shared__ u32x4 lds4[];
     u32x4* W1A = lds4;                                              // [ks 2][plane 3][mt 8][lane]
     float* xfl = reinterpret_cast<float*>(W1A + 2 * 3 * 8 * 64);    // [4][64]
     float* b1l = xfl + 256;                                         // [128]
-    float* w2l = b1l + PJ_HID;                                      // [DOT][128]
+    float* w2l = b1l + PJ_HID;                                      // [DOT][128]            (FC2M: unused)
+    u32x4* W2A = reinterpret_cast<u32x4*>(w2l + (FC2M ? 0 : DOT * PJ_HID));   // FC2M: [s 4][plane 3][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
         const int l = idx & 63, mt = (idx >> 6) & 7, ks = idx >> 9;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = p.w1[(16 * mt + (l & 15)) * 64 + chan_of(ks, l >> 4, e)];
+        for (int e = 0; e < 8; ++e) v[e] = p.w1[(16 * mt + (l & 15)) * 64 + (BFIN ? 32 * ks + 8 * (l >> 4) + e : chan_of(ks, l >> 4, e))];
         bf16x8 h, m, lo;
         split8(v, h, m, lo);
         W1A[((ks * 3 + 0) * 8 + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
@@ -401,8 +409,23 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
         W1A[((ks * 3 + 2) * 8 + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
     for (int idx = tid; idx < PJ_HID; idx += blockDim.x) b1l[idx] = p.b1[idx];
-    for (int idx = tid; idx < DOT * PJ_HID; idx += blockDim.x) w2l[idx] = idx < DO * PJ_HID ? p.w2[idx] : 0.f;
-    const bool has_xf = p.xf.mean != nullptr;
+    if (FC2M) {
+        for (int idx = tid; idx < 4 * 64; idx += blockDim.x) {
+            const int l = idx & 63, s = idx >> 6;
+            const int j = l & 15;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = j < DO ? p.w2[j * PJ_HID + 32 * s + 16 * (e >> 2) + 4 * (l >> 4) + (e & 3)] : 0.f;
+            bf16x8 h, m, lo;
+            split8(v, h, m, lo);
+            W2A[(s * 3 + 0) * 64 + l] = __builtin_bit_cast(u32x4, h);
+            W2A[(s * 3 + 1) * 64 + l] = __builtin_bit_cast(u32x4, m);
+            W2A[(s * 3 + 2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+        }
+    } else {
+        for (int idx = tid; idx < DOT * PJ_HID; idx += blockDim.x) w2l[idx] = idx < DO * PJ_HID ? p.w2[idx] : 0.f;
+    }
+    const bool has_xf = !BFIN && p.xf.mean != nullptr;
     if (tid < 64) {
         xfl[tid] = has_xf ? p.xf.mean[tid] : 0.f;
         xfl[64 + tid] = has_xf ? p.xf.invstd[tid] : 1.f;
@@ -437,11 +460,17 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
         const long r2 = gl / cm.H;
         return ((r2 / cm.T) * cm.Tp + r2 % cm.T) * cm.Hp + h;
     };
-    u32x4 xa[4];
+    u32x4 xa[BFIN ? 2 : 4];
     auto issue = [&](long gl, int q) {
-        const rsrc_t rx = make_rsrc(p.s + line_of(gl) * cm.Wp * 64, (unsigned)cm.W * 256u);      // cells >= W read as 0
+        if (BFIN) {                                                  // 128 B per cell: loads ks = 0, 1 are the two K-steps
+            const rsrc_t rx = make_rsrc(p.s + line_of(gl) * cm.Wp * 32, (unsigned)cm.W * 128u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xa[i] = ld16(rx, (16 * q + n16) * 256 + i * 64 + kg * 16);
+            for (int i = 0; i < 2; ++i) xa[i] = ld16(rx, (16 * q + n16) * 128 + i * 64 + kg * 16);
+        } else {
+            const rsrc_t rx = make_rsrc(p.s + line_of(gl) * cm.Wp * 64, (unsigned)cm.W * 256u);      // cells >= W read as 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = ld16(rx, (16 * q + n16) * 256 + i * 64 + kg * 16);
+        }
     };
     if (slot < GL) issue(slot, 0);
     for (long gl = slot; gl < GL; gl += nslots) {
@@ -460,10 +489,14 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
             bf16x8 Bh[2], Bm[2], Bl[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (BFIN) {
+                    Bh[ks] = __builtin_bit_cast(bf16x8, xa[ks]);
+                    continue;
+                }
                 float v[8];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const int i = 2 * ks + hf;
+                    const int i = BFIN ? 0 : 2 * ks + hf;
                     const f32x4v xv = __builtin_bit_cast(f32x4v, xa[i]);
                     const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfl + 16 * i + 4 * kg);
                     const f32x4v is = *reinterpret_cast<const f32x4v*>(xfl + 64 + 16 * i + 4 * kg);
@@ -491,10 +524,56 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
                         al[u] = __builtin_bit_cast(bf16x8, W1A[((ks * 3 + 2) * 8 + m0 + u) * 64 + lane]);
                     }
 #define PJ_ROW(AP, BP) _Pragma("unroll") for (int u = 0; u < MG; ++u) acc[m0 + u] = mfma16(AP[u], BP[ks], acc[m0 + u]);
-                    PJ_ROW(ah, Bl) PJ_ROW(al, Bh) PJ_ROW(am, Bm) PJ_ROW(ah, Bm) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
+                    if (BFIN) {
+                        PJ_ROW(al, Bh) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
+                    } else {
+                        PJ_ROW(ah, Bl) PJ_ROW(al, Bh) PJ_ROW(am, Bm) PJ_ROW(ah, Bm) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
+                    }
 #undef PJ_ROW
                 }
-            if (!BWD) {
+            if (!BWD && FC2M) {
+                // out^T [j][cell] = W2 v^T + b2: K-step s takes hidden rows {32 s + 4 mg + r, 32 s + 16 + 4 mg + r} = acc[2 s], acc[2 s + 1]
+                f32x4v o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = 4 * kg + r < DO ? p.b2[4 * kg + r] : 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    f32x4v v0, v1;
+                    if (silu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a0, a1, d;
+                            act_pair(acc[2 * s4][r], true, a0, d);
+                            act_pair(acc[2 * s4 + 1][r], true, a1, d);
+                            v0[r] = a0;
+                            v1[r] = a1;
+                        }
+                    } else {
+                        v0 = gelu4(acc[2 * s4]);
+                        v1 = gelu4(acc[2 * s4 + 1]);
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = v0[r];
+                        v[4 + r] = v1[r];
+                    }
+                    bf16x8 Vh, Vm, Vl;
+                    split8(v, Vh, Vm, Vl);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, W2A[(s4 * 3 + 0) * 64 + lane]);
+                    const bf16x8 am = __builtin_bit_cast(bf16x8, W2A[(s4 * 3 + 1) * 64 + lane]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, W2A[(s4 * 3 + 2) * 64 + lane]);
+                    PJ_MAC6(o, ah, am, al, Vh, Vm, Vl)
+                }
+                // lane (cell n16, group mg) holds outputs j = 4 mg + r of its cell
+                if ((DO & 3) == 0) {
+                    if (4 * kg < DO) st16(o, rgo, ((16 * q + n16) * DO + 4 * kg) * 4);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * kg + r < DO) buf_store_f32(o[r], rgo, ((16 * q + n16) * DO + 4 * kg + r) * 4, 0);
+                }
+            } else if (!BWD) {
                 float po[DOT];
 #pragma unroll
                 for (int j = 0; j < DOT; ++j) po[j] = 0.f;
@@ -589,7 +668,9 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
     }
 }
 
-static size_t pjx_head_lds(int dot) { return (size_t)(2 * 3 * 8 * 64) * 16 + (256 + PJ_HID + (size_t)dot * PJ_HID) * 4; }
+static size_t pjx_head_lds(int dot) {
+    return (size_t)(2 * 3 * 8 * 64) * 16 + (256 + PJ_HID) * 4 + (dot > 4 ? (size_t)(4 * 3 * 64) * 16 : (size_t)dot * PJ_HID * 4);
+}
 
 // ------------------------------------------------------------------------------------------------------------ wgrad
 // A wave owns PJ_NT 16-wide hidden tiles = PJ_HB hidden units (role = slot % PJ_ROLES); part row of a slot:
@@ -848,7 +929,7 @@ extern "C" int rpb_proj_wgrad(const float* s, const float* w1, const float* b1, 
 // ------------------------------------------------------------------------------------------------------------ head entry points
 // (called by rpb_proj_fwd / rpb_proj_bwd in rpb_proj.hip when the shape is covered; same arguments, same partial-row layout)
 // (the gu producer keeps 32 (1 + DO) gradient accumulators per lane: two fc2 outputs fit the register file, four spill)
-bool rpb_pjx_head_supported(int C, int DO, bool bwd) { return !pjx_off() && C == 64 && DO >= 1 && DO <= (bwd ? 2 : PJ_DOMAX); }
+bool rpb_pjx_head_supported(int C, int DO, bool bwd) { return !pjx_off() && C == 64 && DO >= 1 && DO <= (bwd ? 2 : 16); }
 
 long rpb_pjx_head_slots(int B, int T, int H, bool bwd) {
     const long GL = (long)B * T * H;
@@ -860,7 +941,7 @@ long rpb_pjx_head_slots(int B, int T, int H, bool bwd) {
 
 int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
                         float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
-                        const XForm& xf, int act, hipStream_t st) {
+                        const XForm& xf, int act, hipStream_t st, bool a_bf16) {
     PjhArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.out = out; p.gu = gu; p.part = part;
     p.B = (int)(ncrop / ((long)T * H * W)); p.DO = DO; p.act = act;
@@ -872,14 +953,23 @@ int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* 
     const int grid = (int)(slots / PJ_WAVES);
     if (bwd && part_rows > slots)                                                 // rows this launch does not write
         (void)hipMemsetAsync(part + slots * ((long)DO * PJ_HID + PJ_HID + DO), 0, (size_t)(part_rows - slots) * ((long)DO * PJ_HID + PJ_HID + DO) * 4, st);
-    const int dot = DO <= 2 ? 2 : 4;
+    const int dot = DO <= 2 ? 2 : (DO <= 4 ? 4 : 16);
     const size_t lds = pjx_head_lds(dot);
+    if (a_bf16 && bwd) RPB_FAIL(RPB_ERR_UNSUPPORTED, "proj (bf16 pipe): bf16 activation storage is a forward path");
 #define RPB_PJH(BWD_, D_)                                                                                                    \
     if (bwd == BWD_ && dot == D_) {                                                                                          \
         (void)hipFuncSetAttribute((const void*)pjx_head_kernel<BWD_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((pjx_head_kernel<BWD_, D_>), dim3(grid), dim3(PJ_WAVES * 64), lds, st, p);                        \
     }
-    RPB_PJH(false, 2) RPB_PJH(false, 4) RPB_PJH(true, 2)
+#define RPB_PJHB(D_)                                                                                                        \
+    if (a_bf16 && dot == D_) {                                                                                               \
+        (void)hipFuncSetAttribute((const void*)pjx_head_kernel<false, D_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pjx_head_kernel<false, D_, true>), dim3(grid), dim3(PJ_WAVES * 64), lds, st, p);                 \
+        RPB_CHECK_LAUNCH("proj (bf16 pipe, bf16 storage)");                                                                  \
+    }
+    RPB_PJHB(2) RPB_PJHB(4) RPB_PJHB(16)
+#undef RPB_PJHB
+    RPB_PJH(false, 2) RPB_PJH(false, 4) RPB_PJH(false, 16) RPB_PJH(true, 2)
 #undef RPB_PJH
     RPB_CHECK_LAUNCH("proj (bf16 pipe)");
 }

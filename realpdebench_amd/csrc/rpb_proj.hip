@@ -388,6 +388,11 @@ extern "C" int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const floa
     p.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
     p.a = (const float*)a_bf16; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.ncrop = ncrop; p.C = C; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    if (rpb_pjx_head_supported(C, DO, false)) {
+        RPB_REQUIRE(w1 && b1 && w2 && b2, "proj: null pointer");
+        return rpb_pjx_head_launch(false, (const float*)a_bf16, w1, b1, w2, b2, nullptr, out, nullptr, nullptr, 0, DO, T, H, W, Tp, Hp, Wp,
+                                   ncrop, p.xf, act, (hipStream_t)stream, true);
+    }
     return proj_launch(false, p, (hipStream_t)stream);
 }
 

@@ -131,10 +131,11 @@ def test_cell_wgrad_crop(ops):
     assert rel_l2(part.double().sum(0).cpu()[:CO * CI].view(CO, CI), ref) < TOL
 
 
-@pytest.mark.parametrize("C,DO,W", [(64, 2, 7), (64, 2, 40), (64, 1, 16), (64, 4, 21), (32, 3, 7), (128, 5, 7), (64, 16, 7)])
+@pytest.mark.parametrize("C,DO,W", [(64, 2, 7), (64, 2, 40), (64, 1, 16), (64, 4, 21), (32, 3, 7), (128, 5, 7), (64, 16, 7), (64, 16, 70),
+                                    (64, 12, 40), (64, 5, 21)])
 def test_proj_fwd_bwd(ops, C, DO, W):
-    """C = 64 with DO <= 4 (forward) / <= 2 (backward) runs on the bf16 matrix pipe (csrc/rpb_pjx.hip: line-walking waves, partial
-    last tile), everything else on the fp32 MFMA kernels."""
+    """C = 64 with DO <= 16 (forward; fc2 on the matrix pipe too above 4 outputs) / <= 2 (backward) runs on the bf16 matrix pipe
+    (csrc/rpb_pjx.hip: line-walking waves, partial last tile), everything else on the fp32 MFMA kernels."""
     torch.manual_seed(C + DO)
     B, T, H, pad = 2, 3, 6, 2
     d = ops.Dims(B, T, H, W, 2, C, pad)

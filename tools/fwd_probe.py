@@ -10,8 +10,14 @@ from realpdebench_amd import _lib  # noqa: E402
 from realpdebench_amd.model.fno import FNO3d  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-m = FNO3d(4, 12, 16, 4, 64, (20, 128, 128, 2), (20, 128, 128, 2)).cuda().eval()
-x = torch.randn(B, 20, 128, 128, 2, device="cuda")
+if len(sys.argv) > 2 and sys.argv[2].startswith("comb"):       # BASELINE.json configs[4]: combustion volume, optional bf16 storage
+    m = FNO3d(4, 16, 16, 4, 64, (64, 64, 64, 16), (64, 64, 64, 16)).cuda().eval()
+    x = torch.randn(B, 64, 64, 64, 16, device="cuda")
+    if sys.argv[2].endswith("bf16"):
+        m.set_storage("bf16")
+else:
+    m = FNO3d(4, 12, 16, 4, 64, (20, 128, 128, 2), (20, 128, 128, 2)).cuda().eval()
+    x = torch.randn(B, 20, 128, 128, 2, device="cuda")
 with torch.no_grad():
     for _ in range(2):
         m(x)
