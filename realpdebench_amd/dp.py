@@ -76,7 +76,14 @@ def use_rccl_abi(t=None):
     RPB_DP_TORCH=1 keep ``torch.distributed`` collectives."""
     if os.environ.get("RPB_DP_TORCH") == "1" or not dist.is_initialized() or dist.get_backend() != "nccl":
         return False
-    return t is None or t.is_cuda
+    if t is not None and not t.is_cuda:
+        return False
+    from . import _lib
+    if not _lib.query("rpb_dp_available"):        # no loadable librccl.so (the same answer on every rank of a node): ProcessGroupNCCL
+        import logging                             # still works, only the side-stream scheduling is torch's instead of ours
+        logging.warning("rpb_dp: librccl.so could not be resolved by librpb_hip.so; gradients go through torch.distributed")
+        return False
+    return True
 
 
 def layer_buckets(seg, n_layers, total):
