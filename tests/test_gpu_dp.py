@@ -207,8 +207,10 @@ def test_arena_trainer_two_ranks_equal_single_rank(kind):
     x, y = torch.randn(4, *shape, generator=g), torch.randn(4, *shape, generator=g)
     losses = [float(tr.step(x.cuda(), y.cuda())) for _ in range(2)]
     assert torch.equal(res[0]["flat"], res[1]["flat"])
-    for i in range(2):
-        assert abs(0.5 * (res[0]["loss"][i] + res[1]["loss"][i]) - losses[i]) < 2e-5 * abs(losses[i])
+    # first step: same weights on both sides -> tight; second step: after an Adam update that moved the (exactly-)zero-gradient
+    # elements by +-lr with a sharding-dependent sign (see below), so the two losses agree to ~1e-5..1e-4 only
+    for i, tol in enumerate((2e-5, 2e-4)):
+        assert abs(0.5 * (res[0]["loss"][i] + res[1]["loss"][i]) - losses[i]) < tol * abs(losses[i])
     assert rel_l2(res[0]["grad"], tr.grad.cpu()) < 5e-4                       # second-step gradient, averaged over ranks
     # weights: Adam turns round-off on exactly-zero gradients (biases in front of GroupNorm / LayerNorm) into +-lr steps whose
     # sign depends on the summation order -> robust comparison (see the FNO test above)
