@@ -174,7 +174,10 @@ class ArenaTrainer:
             if p.grad is None:
                 gv.zero_()
             elif p in self._early:
-                early.append((gv, p.grad))
+                # the tensor the model handed to _dp_early is the one being reduced in place; p.grad may be a COPY autograd made
+                # when it accumulated the gradient (it cannot steal a tensor we hold a reference to), taken while the all-reduce
+                # was still in flight on another stream
+                early.append((gv, self._early[p]))
             else:
                 late_dst.append(gv)
                 late_src.append(p.grad)
