@@ -12,6 +12,7 @@
 // coalesced rows, and keeps the [B][2][C] coefficient tile of that mode in LDS (broadcast reads).
 // At B=32 this kernel is a pure weight stream: 100.7 MB per layer against ~50 MB of coefficients.
 #include "rpb_common.h"
+#include <stdlib.h>
 
 #define MC_THREADS 256
 #define MC_BT 8   // batch entries accumulated per thread per pass
@@ -183,6 +184,112 @@ __global__ __launch_bounds__(MC_THREADS) void mode_wgrad_kernel(const float* __r
     }
 }
 
+
+// ---- C = 64 on the fp32 matrix pipe: per mode the complex contraction is a real GEMM with the composite [[wr, wi], [-wi, wr]]
+// (forward: [B x 128] x [128 x 128]; dgrad: the conjugate transpose; wgrad: [128 x 2B]^T products with K = batch).  One workgroup per
+// mode, 4 waves x 64 MFMAs of 32x32x2; the mode's coefficient tile(s) and its weight tile are staged in LDS planar and padded, so the
+// operand reads of every variant (batch-major, channel-major, weight rows or weight columns) are conflict-free.  The VALU kernels
+// above ran at ~20 TF/s (16 LDS reads per 32 FMAs); they remain the path for other widths.
+//   MODE 0 fwd, 1 dgrad, 2 wgrad.  Batches larger than 32 are walked in passes of 32 rows.
+#define MM_LD 65
+template <int MODE>
+__global__ __launch_bounds__(256) void mode_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ GY,
+                                                         float* __restrict__ OUT, int B, int M, int accumulate) {
+    constexpr int C = 64;
+    __shared__ float Xs[2 * 32 * MM_LD];          // [ri][b][c]      fwd: X, dgrad: gY, wgrad: X
+    __shared__ float Ws[2 * 64 * MM_LD];          // fwd / dgrad: [ri][i][o] weights;  wgrad: [ri][b][o] = gY (first 2*32 rows)
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const long plane = (long)M * C;
+    const float* src = MODE == 1 ? GY : X;
+    if (MODE != 2) {
+        const float* Wm = Wt + (long)m * C * C * 2;
+        for (int idx = tid; idx < C * C / 2; idx += 256) {       // two complex numbers per 16 B load
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wm + (long)idx * 4);
+            const int i = (2 * idx) / C, o = 2 * idx - i * C;
+            Ws[(0 * 64 + i) * MM_LD + o] = w[0];
+            Ws[(1 * 64 + i) * MM_LD + o] = w[1];
+            Ws[(0 * 64 + i) * MM_LD + o + 1] = w[2];
+            Ws[(1 * 64 + i) * MM_LD + o + 1] = w[3];
+        }
+    }
+    f32x16 accA = zero16(), accB = zero16();                     // wgrad: (re, im) of the wave's 32 x 32 tile, summed over the passes
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        if (b0) __syncthreads();
+        for (int idx = tid; idx < 2 * 32 * (C / 4); idx += 256) {
+            const int c4 = idx % (C / 4), r = idx / (C / 4);     // r = bl * 2 + ri
+            const int bl = r >> 1, ri = r & 1, b = b0 + bl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                v = *reinterpret_cast<const f32x4*>(src + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+                if (MODE == 2) g = *reinterpret_cast<const f32x4*>(GY + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Xs[(ri * 32 + bl) * MM_LD + 4 * c4 + t] = v[t];
+                if (MODE == 2) Ws[(ri * 32 + bl) * MM_LD + 4 * c4 + t] = g[t];
+            }
+        }
+        __syncthreads();
+        if (MODE != 2) {
+            // out[b][(ro, n)] for the wave's (ro = wave >> 1, 32 columns n0 ..): K = (ri, k) over both input planes
+            const int ro = wave >> 1, n0 = (wave & 1) * 32;
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                // fwd:   Yr = Xr wr - Xi wi, Yi = Xr wi + Xi wr          -> weight plane (ri ^ ro), sign - for (ri, ro) = (1, 0)
+                // dgrad: gXr = gYr wr + gYi wi, gXi = -gYr wi + gYi wr   -> weight plane (ri ^ ro), sign - for (ri, ro) = (0, 1)
+                const int wp = ri ^ ro;
+                const bool neg = MODE == 0 ? (ri == 1 && ro == 0) : (ri == 0 && ro == 1);
+                const float* xa = Xs + (ri * 32 + col) * MM_LD + half;
+                // fwd: B[k][n] = W[i = k][o = n0 + col];  dgrad: B[k][n] = W[i = n0 + col][o = k]
+                const float* wb = MODE == 0 ? Ws + (wp * 64 + half) * MM_LD + n0 + col : Ws + (wp * 64 + n0 + col) * MM_LD + half;
+                constexpr int kstep = MODE == 0 ? 2 * MM_LD : 2;
+#pragma unroll 8
+                for (int s = 0; s < 32; ++s) {
+                    const float a = xa[2 * s];
+                    acc = mfma32(neg ? -a : a, wb[s * kstep], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = b0 + mfma_row(lane, r);
+                if (b < B) OUT[(long)(b * 2 + ro) * plane + (long)m * C + n0 + col] = acc[r];
+            }
+        } else {
+            // gW[i][o]: re = sum_b Xr gYr + Xi gYi, im = sum_b Xr gYi - Xi gYr;  wave = (i tile, o tile), K = the pass's 32 batch rows
+            const int i0 = (wave >> 1) * 32, o0 = (wave & 1) * 32;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int bl = 2 * s + half;
+                const float xr = Xs[(0 * 32 + bl) * MM_LD + i0 + col], xi = Xs[(1 * 32 + bl) * MM_LD + i0 + col];
+                const float gr = Ws[(0 * 32 + bl) * MM_LD + o0 + col], gi = Ws[(1 * 32 + bl) * MM_LD + o0 + col];
+                accA = mfma32(xr, gr, accA);
+                accA = mfma32(xi, gi, accA);
+                accB = mfma32(xr, gi, accB);
+                accB = mfma32(-xi, gr, accB);
+            }
+        }
+    }
+    if (MODE == 2) {
+        const int i0 = (wave >> 1) * 32, o0 = (wave & 1) * 32;
+        float* Gm = OUT + (long)m * C * C * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x2* dst = reinterpret_cast<f32x2*>(Gm + ((long)(i0 + mfma_row(lane, r)) * C + o0 + col) * 2);
+            f32x2 v = {accA[r], accB[r]};
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+static bool mode_mfma_on(int C) {
+    static const bool off = getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1;
+    return !off && C == 64;
+}
+
 static int mc_check(const void* a, const void* b, const void* c, int B, int M, int C) {
     RPB_REQUIRE(a && b && c, "mode_contract: null pointer");
     RPB_REQUIRE(B > 0 && M > 0, "mode_contract: bad sizes B=%d M=%d", B, M);
@@ -192,6 +299,10 @@ static int mc_check(const void* a, const void* b, const void* c, int B, int M, i
 
 extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream) {
     if (int e = mc_check(X, W, Y, B, M, C)) return e;
+    if (mode_mfma_on(C)) {
+        hipLaunchKernelGGL((mode_mfma_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
+        RPB_CHECK_LAUNCH("mode_contract_fwd");
+    }
     const size_t lds = (size_t)B * 2 * C * 4;
     RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_fwd: B*C too large for LDS");
     (void)hipFuncSetAttribute((const void*)mode_contract_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -203,6 +314,10 @@ extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, i
 
 extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* GX, int B, int M, int C, void* stream) {
     if (int e = mc_check(GY, W, GX, B, M, C)) return e;
+    if (mode_mfma_on(C)) {
+        hipLaunchKernelGGL((mode_mfma_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        RPB_CHECK_LAUNCH("mode_contract_dgrad");
+    }
     if (C % MD_ROWS == 0) {
         const size_t lds = ((size_t)B * 2 * C + (size_t)MD_ROWS * (C + 1) * 2) * 4;
         RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_dgrad: tiles too large for LDS (B=%d C=%d)", B, C);
@@ -222,6 +337,10 @@ extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* G
 extern "C" int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, int M, int C, int accumulate,
                                        void* stream) {
     if (int e = mc_check(X, GY, GW, B, M, C)) return e;
+    if (mode_mfma_on(C)) {
+        hipLaunchKernelGGL((mode_mfma_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        RPB_CHECK_LAUNCH("mode_contract_wgrad");
+    }
     const size_t lds = (size_t)B * 4 * C * 4;
     RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_wgrad: B*C too large for LDS");
     (void)hipFuncSetAttribute((const void*)mode_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
