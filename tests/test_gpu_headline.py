@@ -127,3 +127,44 @@ def test_headline_b32_first_step_loss_is_the_references(gold):
     loss = float(tr.step(x.cuda(), y.cuda()))
     ref = float(gold["b32/loss"])
     assert abs(loss - ref) < OUT_TOL * abs(ref)
+
+
+
+def test_full_size_properties_b32():
+    """BASELINE configs[1] at its FULL size (B = 32), where no CPU checker finishes in seconds: size-independent properties.
+    * eval mode uses running statistics, so samples do not interact: the B = 32 forward equals the forwards of its 8-sample blocks;
+    * determinism: two launches of the same forward are bit-equal;
+    * the MSE is exactly quadratic in fc2.weight: central differences along a random direction give the same slope and the same
+      (positive) curvature at two step sizes -- a wrong head kernel (bias, crop, output order) breaks this at any size;
+    * a 3-step rollout is three chained forwards (eval.py:314-319)."""
+    from realpdebench_amd.rollout import autoregressive_rollout
+    m = _model(headline_state_dict()).eval()
+    x, y = (torch.as_tensor(v).cuda() for v in bench_batch(32))
+    with torch.no_grad():
+        full = m(x).clone()
+        assert torch.equal(full, m(x))
+        for i in range(0, 32, 8):
+            assert rel_l2(m(x[i:i + 8]), full[i:i + 8]) < 1e-6
+        w = m.pview("fc2.weight")
+        base, d = w.clone(), torch.randn_like(w)
+
+        def loss_at(t):
+            w.copy_(base + t * d)
+            v = float(((m(x) - y).double() ** 2).mean())
+            w.copy_(base)
+            return v
+
+        l0 = loss_at(0.0)
+        fits = []
+        for h in (1e-2, 3e-2):
+            lp, lm = loss_at(h), loss_at(-h)
+            fits.append(((lp - lm) / (2 * h), (lp + lm - 2 * l0) / (2 * h * h)))
+        (g1, c1), (g2, c2) = fits
+        assert c1 > 0 and abs(c2 - c1) < 5e-3 * c1
+        assert abs(g2 - g1) < 1e-3 * max(abs(g1), 1e-2 * c1)
+        r3 = autoregressive_rollout(m, x, 3)
+        cur, outs = x, []
+        for _ in range(3):
+            cur = m(cur).clone()
+            outs.append(cur)
+        assert torch.equal(r3, torch.cat(outs, 1))
