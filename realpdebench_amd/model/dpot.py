@@ -1,7 +1,9 @@
 """DPOT (AFNO patch transformer) on MI355X -- drop-in for ``realpdebench.model.dpot.DPOT`` with ``model_type='dpot'``
 (reference realpdebench/model/dpot.py:21-289 wrapping dpot_libs/models/dpot.py:22-404), built by ``load_model`` like
 ``realpdebench/model/load_model.py:108-131`` for the configuration family of the reference's ``configs/*/dpot_{s,l}.yaml``:
-2-D ``DPOTNet``, ``normalize=False``, GELU, ``time_agg`` 'exp_mlp' or 'mlp', data resolution == ``img_size``.
+2-D ``DPOTNet``, ``normalize=False``, GELU, ``time_agg`` 'exp_mlp' or 'mlp'; data at another resolution than ``img_size`` (the
+reference's own samples are 64 x 128 / 64 x 64) goes through the wrapper's FFT ``resize`` (dpot_libs/utils/utilities.py:277) as
+dense operators: one token GEMM over (w, channel) rows and two rpb_axis_gemm stages along h, in front of and behind the network.
 
 Pipeline (token rows channels-last; every product runs in a HIP kernel of ``csrc/``):
   PatchEmbed (dpot.py:183-211): the wrapper's channel padding with ones, the (x, y, t) grid channels and the patch gather in ONE
@@ -112,9 +114,11 @@ class DPOT(_ModelBase):
             unsupported.append("patch / out_layer / mlp widths must give GEMM depths that are multiples of 32")
         if img_size % patch_size:
             unsupported.append("img_size % patch_size != 0")
-        if tuple(self.shape_in[1:3]) != (img_size, img_size):
-            unsupported.append(f"data resolution {self.shape_in[1:3]} != img_size {img_size} (the FFT resize of "
-                               "dpot_libs/utils/utilities.py:277 is not built)")
+        self.needs_resize = tuple(self.shape_in[1:3]) != (img_size, img_size)
+        if self.needs_resize and ((self.shape_in[2] * self.shape_in[-1]) % 32 or (img_size * self.shape_in[-1]) % 32
+                                  or (self.shape_out[2] * self.shape_out[-1]) % 32 or (img_size * self.shape_out[-1]) % 32):
+            unsupported.append(f"data resolution {self.shape_in[1:3]} != img_size {img_size} with width x channels not a multiple "
+                               "of 32 (the spectral resize runs as token GEMMs over (w, channel) rows)")
         if unsupported:
             raise NotImplementedError("MI355X DPOT covers the configuration family of the reference's configs/*/dpot_*.yaml "
                                       "at the model's native resolution; unsupported: " + "; ".join(unsupported))
@@ -194,6 +198,65 @@ class DPOT(_ModelBase):
                           gt=lin(T).to(device), tt=torch.linspace(0, 1, T).to(device))           # dpot.py:238
         return self._plan
 
+    # ------------------------------------------------------------------ spectral resize (dpot_libs/utils/utilities.py:277-305)
+    @staticmethod
+    def _resize_ops(n_in, n_out, C, device):
+        """``resize`` = irfft2 . (copy the low-frequency corners) . rfft2, scaled by the size ratio -- a linear map of each (h, w) plane.
+        With Cx = IFFT_x S_x FFT_x = A + iB (complex, [Ho x Hi]) and the real matrices Ry = c2r_y S_y rfft_y, Qy = c2r_y S_y (i rfft_y)
+        ([Wo x Wi]) it is  T(X) = A X Ry^T + B X Qy^T  (B != 0 when an even size keeps only one of the two +-Nyquist rows).
+        Returned: KY [(2, w', c)][(w, c)] = [Ry; Qy] (x) I_C for the (w, channel)-row token GEMM, AXt / BXt [h][h'] as rpb_axis_gemm
+        stage matrices, and their transposes for the adjoint.  Built in fp64 from numpy's FFT applied to the identity."""
+        (hi, wi), (ho, wo) = n_in, n_out
+        top1, bot1 = min((hi + 1) // 2, (ho + 1) // 2), min(hi // 2, ho // 2)
+        top2 = min(wi // 2 + 1, wo // 2 + 1)
+        Fx = np.fft.fft(np.eye(hi), axis=0)                                   # [kx][h]
+        Sel = np.zeros((ho, hi), dtype=complex)                                # f_z rows <- f rows
+        Sel[:top1] = Fx[:top1]
+        if bot1 > 0:
+            Sel[ho - bot1:] = Fx[hi - bot1:]
+        Cx = np.fft.ifft(Sel, axis=0) * (ho / hi)                              # [h'][h]; ifft carries 1/Ho
+        Fy = np.fft.rfft(np.eye(wi), axis=0)                                   # [ky][w]
+        Zy = np.zeros((wo // 2 + 1, wi), dtype=complex)
+        Zy[:top2] = Fy[:top2]
+        Ry = np.fft.irfft(Zy, n=wo, axis=0) * (wo / wi)                        # [w'][w]
+        Qy = np.fft.irfft(1j * Zy, n=wo, axis=0) * (wo / wi)
+        eye = np.eye(C)
+        KY = np.concatenate([np.kron(Ry, eye), np.kron(Qy, eye)], 0)           # [(term, w', c)][(w, c)]
+        f = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
+        A, Bm = Cx.real, Cx.imag
+        return dict(KY=f(KY), KYt=f(KY.T), AXt=f(A.T), BXt=f(Bm.T), AX=f(A), BX=f(Bm), n_in=n_in, n_out=n_out, C=C)
+
+    def _resize_plan(self, device):
+        if getattr(self, "_rs", None) is not None and self._rs["device"] == device:
+            return self._rs
+        S = self.img_size
+        (Hi, Wi, Ci), (Ho, Wo, Co) = self.shape_in[1:], self.shape_out[1:]
+        self._rs = dict(device=device, inp=self._resize_ops((Hi, Wi), (S, S), Ci, device),
+                        out=self._resize_ops((S, S), (Ho, Wo), Co, device))
+        return self._rs
+
+    @staticmethod
+    def _resize_apply(x, op, adjoint=False):
+        """x [G, h, w, C] (G = B*T) -> [G, h', w', C]; ``adjoint``: the transposed map (gradient w.r.t. the resize input)."""
+        (hi, wi), (ho, wo), C = op["n_in"], op["n_out"], op["C"]
+        G = x.shape[0]
+        f = dict(device=x.device, dtype=torch.float32)
+        if not adjoint:
+            tmp = torch.empty(G * hi, 2 * wo * C, **f)
+            ops.gemm_nt(x, op["KY"], tmp, G * hi, 2 * wo * C, wi * C)
+            out = torch.empty(G, ho, wo, C, **f)
+            N = wo * C
+            ops.axis_gemm(tmp, out, op["AXt"], G, hi, ho, N, hi * 2 * N, 2 * N, ho * N, N, tag="resizeA")
+            ops.axis_gemm(ops.Sub(tmp, N), out, op["BXt"], G, hi, ho, N, hi * 2 * N, 2 * N, ho * N, N, accumulate=True, tag="resizeB")
+            return out
+        N = wo * C
+        tmp = torch.empty(G * hi, 2 * N, **f)
+        ops.axis_gemm(x, tmp, op["AX"], G, ho, hi, N, ho * N, N, hi * 2 * N, 2 * N, tag="resizeAt")
+        ops.axis_gemm(x, ops.Sub(tmp, N), op["BX"], G, ho, hi, N, ho * N, N, hi * 2 * N, 2 * N, tag="resizeBt")
+        out = torch.empty(G, hi, wi, C, **f)
+        ops.gemm_nt(tmp, op["KYt"], out, G * hi, wi * C, 2 * N)
+        return out
+
     # ------------------------------------------------------------------ spectral stages
     def _rfft2(self, Y, A1, S, B, pl, E, fwd=True):
         """fwd: tokens Y [B][n][n][E] -> S [(b,kx,ky)][2][E];  not fwd: the adjoint (S -> Y)."""
@@ -218,6 +281,10 @@ class DPOT(_ModelBase):
     @torch.no_grad()
     def _forward_hip(self, x, save=None):
         net = self.dpot_model
+        if self.needs_resize:                                  # model/dpot.py:204-208: data resolution -> the model's
+            rs = self._resize_plan(x.device)
+            Bx, Tx = x.shape[:2]
+            x = self._resize_apply(x.reshape(Bx * Tx, *x.shape[2:]), rs["inp"]).view(Bx, Tx, self.img_size, self.img_size, x.shape[-1])
         B, T, H, W, Cd = x.shape
         E, ps, Cm, Co, To = self.embed_dim, self.patch_size, self.in_channels, self.out_channels, self.out_timesteps
         pl = self._consts(x.device)
@@ -304,6 +371,9 @@ class DPOT(_ModelBase):
         Cdo = self.data_out_channels
         pred = new(B, To, H, W, Cdo)
         ops.dpot_unpatch(O, pred, B, To, H, W, Cdo, Co, ps, NOp)
+        if self.needs_resize:                                  # model/dpot.py:229-231: back to the data resolution
+            Ho, Wo = self.shape_out[1:3]
+            pred = self._resize_apply(pred.view(B * To, H, W, Cdo), rs["out"]).view(B, To, Ho, Wo, Cdo)
         if training:
             save.update(B=B, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
                         U=U, Upre=Upre, V=V, Vpre=Vpre, W3p=W3p)
@@ -327,6 +397,9 @@ class DPOT(_ModelBase):
         Cdo = self.data_out_channels
         grads = {}
         ol0, ol2, ol4 = net.out_layer[0], net.out_layer[2], net.out_layer[4]
+        if self.needs_resize:
+            rs = self._resize_plan(g_pred.device)
+            g_pred = self._resize_apply(g_pred.reshape(B * To, *g_pred.shape[2:]), rs["out"], adjoint=True).view(B, To, H, W, Cdo)
         # ---- out_layer
         gO = new(Mp, NOp)
         ops.dpot_unpatch_bwd(g_pred, gO, B, To, H, W, Cdo, Co, ps, NOp)

@@ -82,10 +82,11 @@ def galerkin_golden():
     return g
 
 
-def dpot_golden():
-    """tests/golden/dpot_small.npz (make_golden_dpot.py: imported reference DPOT, forward + loss + every gradient)."""
+def dpot_golden(name="dpot_small"):
+    """tests/golden/dpot_small.npz / dpot_resize_small.npz (make_golden_dpot.py: imported reference DPOT, forward + loss + every
+    gradient; the second one at a data resolution that differs from img_size)."""
     import numpy as np
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpot_small.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     g = dict(sd={}, grad={}, cfg={})
     for k in z.files:
         if k.startswith("sd/"):

@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _model(g, **over):
+    """The HIP model for a fixture (shapes from its tensors, keyword surface of load_model.py:108-131)."""
     from realpdebench_amd.model.dpot import DPOT
     cfg = {k: v for k, v in g["cfg"].items() if k not in ("data_out_channels",)}
     cfg.update(over)
-    T, S, Cd = g["x"].shape[1], g["x"].shape[2], g["x"].shape[-1]
-    m = DPOT(shape_in=(T, S, S, Cd), shape_out=(g["y"].shape[1], S, S, g["y"].shape[-1]), normalize=False, act="gelu", **cfg).cuda()
+    m = DPOT(shape_in=tuple(g["x"].shape[1:]), shape_out=tuple(g["y"].shape[1:]), normalize=False, act="gelu", **cfg).cuda()
     missing, unexpected = m.load_state_dict(g["sd"], strict=True)
     assert not missing and not unexpected
     return m
@@ -49,18 +49,20 @@ def test_train_loss_and_every_gradient_match_reference():
 
 
 def _oracle_case(B, T, S, Cd, cfg, seed):
-    """Random weights of the HIP model's own initialisation (perturbed so every bias / affine matters) vs the CPU oracle."""
+    """Random weights of the HIP model's own initialisation (perturbed so every bias / affine matters) vs the CPU oracle.
+    ``S``: the data resolution, an int (square) or (H, W)."""
     from oracle import dpot_oracle as DO
     from realpdebench_amd.model.dpot import DPOT
     torch.manual_seed(seed)
-    m = DPOT(shape_in=(T, S, S, Cd), shape_out=(cfg["out_timesteps"], S, S, Cd), normalize=False, act="gelu", **cfg)
+    HW = (S, S) if isinstance(S, int) else tuple(S)
+    m = DPOT(shape_in=(T, *HW, Cd), shape_out=(cfg["out_timesteps"], *HW, Cd), normalize=False, act="gelu", **cfg)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if "norm" in n or n.endswith("bias") or "pos_embed" in n:
                 p.add_(0.1 * torch.randn_like(p))
             if n.endswith((".b1", ".b2", ".w1", ".w2")):
                 p.copy_(torch.randn_like(p) / p.shape[-1] ** 0.5)
-    x, y = torch.randn(B, T, S, S, Cd), torch.randn(B, cfg["out_timesteps"], S, S, Cd)
+    x, y = torch.randn(B, T, *HW, Cd), torch.randn(B, cfg["out_timesteps"], *HW, Cd)
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
     ocfg = dict(cfg, data_out_channels=Cd)
     loss_ref = ((DO.dpot_forward(sd, x, ocfg) - y) ** 2).mean()
@@ -123,3 +125,33 @@ def test_sliding_window_eval_forward():
         out = m.cuda().eval()(x.cuda())
     assert out.shape == ref.shape == (2, 5, 32, 32, 2)
     assert rel_l2(out.cpu(), ref) < 1e-5
+
+
+def test_non_native_resolution_matches_reference():
+    """Data at 16 x 32 with img_size 32: the wrapper's FFT resize in front of and behind the network (model/dpot.py:204-231) as token
+    GEMMs + rpb_axis_gemm stages -- eval forward, training loss and every gradient (through the adjoint of the output resize)
+    against the imported reference."""
+    g = dpot_golden("dpot_resize_small")
+    m = _model(g)
+    assert m.needs_resize
+    m.eval()
+    with torch.no_grad():
+        out = m(g["x"].cuda())
+    assert out.shape == g["pred"].shape
+    assert rel_l2(out.cpu(), g["pred"]) < 1e-5
+    m.train()
+    loss = m.train_loss(g["x"].cuda(), g["y"].cuda())
+    loss.backward()
+    assert abs(float(loss) - g["loss"]) < 1e-5 * abs(g["loss"])
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(g["grad"])
+    for k, ref in g["grad"].items():
+        assert rel_l2(got[k].cpu(), ref) < 1e-4, k
+
+
+def test_reference_native_cylinder_shape_vs_oracle():
+    """The reference's own cylinder samples are [20, 64, 128, 3] (three channels padded to four, 64 x 128 resized to 128 x 128 and
+    back): dpot_s widths at depth 1, B = 1, 4 frames."""
+    cfg = dict(img_size=128, in_channels=4, out_channels=4, in_timesteps=4, out_timesteps=4, patch_size=8, embed_dim=1024, depth=1,
+               n_blocks=8, modes=32, mlp_ratio=1, out_layer_dim=32, n_cls=12, time_agg="exp_mlp")
+    _oracle_case(1, 4, (64, 128), 3, cfg, seed=8)

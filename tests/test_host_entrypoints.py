@@ -118,7 +118,8 @@ def test_dpot_registry_state_dict_and_loud_limits():
         m(g["x"])
     with pytest.raises(NotImplementedError, match="normalize=True"):
         load_model([(g["x"][0], g["y"][0])], device="cpu", **dict(cfg, normalize=True))
-    with pytest.raises(NotImplementedError, match="data resolution"):
-        load_model([(torch.zeros(4, 64, 64, 2), torch.zeros(4, 64, 64, 2))], device="cpu", **cfg)
+    assert load_model([(torch.zeros(4, 64, 64, 2), torch.zeros(4, 64, 64, 2))], device="cpu", **cfg).needs_resize     # FFT resize path
+    with pytest.raises(NotImplementedError, match="data resolution"):                    # 20 x 2 = 40 columns: not a GEMM depth
+        load_model([(torch.zeros(4, 20, 20, 2), torch.zeros(4, 20, 20, 2))], device="cpu", **cfg)
     with pytest.raises(NotImplementedError, match="DPOTNet3D"):
         load_model([(g["x"][0], g["y"][0])], device="cpu", **dict(cfg, model_type="dpot3d"))

@@ -1,4 +1,5 @@
 """Pins the CPU oracle (oracle/fno3d_oracle.py) to golden vectors produced by the reference itself."""
+import pytest
 import torch
 
 from conftest import rel_l2
@@ -193,12 +194,13 @@ def test_unet_rotary_known_answers():
     assert rel_l2(UO.rotary(x, freqs), _rotary_complex(x)) < 1e-6
 
 
-def test_dpot_oracle_matches_reference():
+@pytest.mark.parametrize("name", ["dpot_small", "dpot_resize_small"])
+def test_dpot_oracle_matches_reference(name):
     """Eval forward, training loss and every parameter gradient of oracle/dpot_oracle.py against vectors taken from the imported
-    reference DPOT (tests/golden/make_golden_dpot.py)."""
+    reference DPOT (tests/golden/make_golden_dpot.py); the second fixture goes through the wrapper's FFT resize (16 x 32 -> 32 x 32)."""
     from conftest import dpot_golden
     from oracle import dpot_oracle as DO
-    g = dpot_golden()
+    g = dpot_golden(name)
     with torch.no_grad():
         out = DO.dpot_forward(g["sd"], g["x"], g["cfg"])
     assert out.shape == g["pred"].shape
@@ -210,3 +212,26 @@ def test_dpot_oracle_matches_reference():
     assert {k for k, v in sd.items() if v.grad is not None} == set(g["grad"])
     for k, ref in g["grad"].items():
         assert rel_l2(sd[k].grad, ref) < 2e-5, k
+
+
+@pytest.mark.parametrize("n_in,n_out", [((16, 32), (32, 32)), ((32, 32), (16, 32)), ((12, 10), (7, 16)), ((9, 9), (14, 5))])
+def test_dpot_resize_operators_equal_the_fft_formula(n_in, n_out):
+    """Host logic of realpdebench_amd.model.dpot: the dense operators of the spectral resize (T(X) = A X Ry^T + B X Qy^T, built from
+    numpy FFTs of the identity) reproduce dpot_libs/utils/utilities.py:277-305 as restated (and pinned) in the oracle -- even / odd
+    sizes, up- and down-sampling, and the adjoint is the transpose."""
+    from oracle import dpot_oracle as DO
+    from realpdebench_amd.model.dpot import DPOT
+    C = 3
+    op = DPOT._resize_ops(n_in, n_out, C, "cpu")
+    torch.manual_seed(1)
+    x = torch.randn(2, n_in[0], n_in[1], 4, C)                                  # B, X, Y, T, C
+    ref = DO.resize(x, n_out)
+    (hi, wi), (ho, wo) = n_in, n_out
+    X = x.permute(0, 3, 1, 2, 4).reshape(8, hi, wi * C).double()                # rows (w, c)
+    KY = op["KY"].double()
+    tmp = X @ KY.t()                                                            # [.., h, (term, w', c)]
+    N = wo * C
+    out = torch.einsum("oh,ghn->gon", op["AX"].double(), tmp[..., :N]) + torch.einsum("oh,ghn->gon", op["BX"].double(), tmp[..., N:])
+    got = out.view(2, 4, ho, wo, C).permute(0, 2, 3, 1, 4)
+    assert rel_l2(got.float(), ref) < 5e-6
+    assert torch.equal(op["KYt"], op["KY"].t()) and torch.equal(op["AXt"], op["AX"].t()) and torch.equal(op["BXt"], op["BX"].t())
