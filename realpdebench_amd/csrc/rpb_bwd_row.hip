@@ -14,6 +14,7 @@
 // double-buffered in registers 4 MFMA steps (8 cells) ahead through SRSRC descriptors (per-row bounds: the pad
 // steps of the last chunk read zeros and their stores are dropped by the hardware).
 #include "rpb_common.h"
+#include <stdlib.h>
 
 template <int N>
 struct RowVec;
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
 }
 
 extern "C" long rpb_bn_bwd_row_slots(int G) {
-    long slots = (long)rpb_num_cus() * 8;
+    static const int per_cu = getenv("RPB_BWD_ROW_WG_PER_CU") ? atoi(getenv("RPB_BWD_ROW_WG_PER_CU")) : 1;
+    long slots = (long)rpb_num_cus() * 8 * (per_cu > 0 ? per_cu : 1);
     const long need = ((long)G + 7) / 8 * 8;
     return slots < need ? slots : need;
 }
