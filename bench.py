@@ -247,15 +247,35 @@ def bench_unet(dev, steps=2):
 
 
 def bench_unet_c3(dev, steps=1):
-    """BASELINE.json configs[2] mesh: U-Net on the fsi-shaped 20 x 256 x 256 sample, dim = H = 256 (load_model.py:52) ->
-    256/512/1024 channels.  One sample is what fp32 allows: B=1 peaks at ~115 GiB, so the configuration's B=16 per GPU is out
-    of reach of a 288 GB device in fp32 (for the reference as well); reported as measured, with its memory footprint."""
+    """BASELINE.json configs[2]: U-Net on the fsi-shaped 20 x 256 x 256 sample, dim = H = 256 (load_model.py:52) -> 256/512/1024
+    channels, at the configuration's 16 samples per GPU (B = 128 over 8 GPUs).  One fp32 sample peaks at ~116 GiB of activations, so
+    the step runs as 16 micro-batches of one sample with accumulated gradients and ONE optimizer update (ArenaTrainer(micro_batch=1):
+    the same step, exactly -- the model has no batch statistics).  First the one-sample step with its per-pipe rooflines, then one
+    timed 16-sample step."""
     from realpdebench_amd.model.unet import Unet3d
+    from realpdebench_amd.trainer import make_trainer
+    make = lambda: Unet3d(dim=256, out_channels=3, dim_mults=[1, 2, 4], channels=3, in_time=20, out_time=20)
     x = torch.randn(1, 20, 256, 256, 3, device=dev)
     y = torch.randn(1, 20, 256, 256, 3, device=dev)
-    r = bench_model(dev, lambda: Unet3d(dim=256, out_channels=3, dim_mults=[1, 2, 4], channels=3, in_time=20, out_time=20),
-                    x, y, 1e-4, steps, "U-Net fsi-shaped C3 mesh [1,20,256,256,3], dim 256 -> 256/512/1024 channels", forward=False)
-    r["note"] = "BASELINE configs[2] asks B=128 over 8 GPUs = 16 per GPU; fp32 activations allow 2 per 288 GB GPU"
+    r = bench_model(dev, make, x, y, 1e-4, steps, "U-Net fsi-shaped C3 mesh [1,20,256,256,3], dim 256 -> 256/512/1024 channels", forward=False)
+    torch.manual_seed(0)
+    m = make().to(dev)
+    tr = make_trainer(m, lr=1e-4, num_update=4000, micro_batch=1)
+    tr.step(x, y)                                    # warm-up at one sample (allocator, code loading)
+    B = 16
+    xb, yb = torch.randn(B, 20, 256, 256, 3, device=dev), torch.randn(B, 20, 256, 256, 3, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.step(xb, yb)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    r["per_gpu_batch_16"] = {"batch": B, "micro_batch": 1, "ms_per_step": 1e3 * dt, "train_samples_per_s": B / dt,
+                             "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    r["note"] = ("BASELINE configs[2] asks B=128 over 8 GPUs = 16 per GPU: run as 16 accumulated one-sample passes per optimizer step "
+                 "(fp32 activations of one sample take ~116 GiB)")
+    del m, tr
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     return r
 
 

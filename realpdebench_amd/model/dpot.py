@@ -92,6 +92,7 @@ class _DPOTNet(nn.Module):
 
 
 class DPOT(_ModelBase):
+    batch_independent = True      # no batch statistics (GroupNorm / LayerNorm): a step may run in micro-batches (trainer.ArenaTrainer)
     def __init__(self, shape_in, shape_out, img_size=128, in_channels=4, out_channels=4, in_timesteps=1, out_timesteps=1,
                  patch_size=8, embed_dim=512, depth=12, n_blocks=8, modes=32, mlp_ratio=4, out_layer_dim=32, normalize=False,
                  act="gelu", time_agg="exp_mlp", n_cls=1, model_type="dpot", checkpoint_path=None, **kwargs):

@@ -74,6 +74,7 @@ class _Block(nn.Module):
 
 
 class Transolver(_ModelBase):
+    batch_independent = True      # no batch statistics (GroupNorm / LayerNorm): a step may run in micro-batches (trainer.ArenaTrainer)
     def __init__(self, space_dim=1, n_layers=5, n_hidden=256, dropout=0.0, n_head=8, Time_Input=False, act="gelu",
                  mlp_ratio=1, fun_dim=1, out_dim=1, slice_num=32, ref=8, unified_pos=False, H=32, W=32, D=32):
         super().__init__()

@@ -113,6 +113,7 @@ def _rel_pos_bias(weight, n, num_buckets=32, max_distance=32):
 
 
 class Unet3d(_ModelBase):
+    batch_independent = True      # no batch statistics (GroupNorm / LayerNorm): a step may run in micro-batches (trainer.ArenaTrainer)
     def __init__(self, dim, cond_dim=None, out_channels=None, dim_mults=(1, 2, 4, 8), channels=6, attn_heads=4,
                  attn_dim_head=32, use_bert_text_cond=False, init_dim=None, init_kernel_size=7,
                  use_sparse_linear_attn=True, block_type="resnet", resnet_groups=8, out_channel=-1, in_time=10,

@@ -112,7 +112,8 @@ def main(argv=None):
         model.load_checkpoint(args.checkpoint_path, device)
         logging.info(f"Checkpoint {args.checkpoint_path} loaded.")
     trainer = make_trainer(model, lr=args.lr, num_update=args.num_update, scheduler=args.scheduler,
-                           step_size=args.step_size, clip_grad_norm=args.clip_grad_norm)   # wraps DP when world > 1
+                           step_size=args.step_size, clip_grad_norm=args.clip_grad_norm,   # wraps DP when world > 1
+                           micro_batch=getattr(args, "micro_batch_size", None))           # optional YAML key (not in the reference)
 
     n_iter = args.num_update if args.max_updates is None else min(args.num_update, args.max_updates)
     every = max(1, int(args.num_update / 50))                       # train.py:344

@@ -97,9 +97,17 @@ class ArenaTrainer:
     BUCKET_ELEMS = 16 * 1024 * 1024          # 64 MB buckets: large enough for xGMI ring bandwidth, several in flight
 
     def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, betas=(0.9, 0.999), eps=1e-8,
-                 clip_grad_norm=0.0, dp_group=None):
+                 clip_grad_norm=0.0, dp_group=None, micro_batch=None):
         if scheduler not in ("cosine", "step"):
             raise ValueError(f"Scheduler {scheduler} not supported")
+        # micro_batch: a step over B samples runs as ceil(B / micro_batch) forward / backward passes whose gradients accumulate
+        # before ONE all-reduce and ONE Adam update -- the same step, exactly, for models whose samples do not interact
+        # (GroupNorm / LayerNorm: U-Net, Transolver, DPOT).  This is how BASELINE.json configs[2] (U-Net on the 256^2 fsi mesh at
+        # 16 samples per GPU) fits: fp32 activations of ONE such sample take 116 GiB.
+        self.micro_batch = int(micro_batch) if micro_batch else None
+        if self.micro_batch and not getattr(model, "batch_independent", False):
+            raise ValueError("micro_batch needs a model without batch statistics (BatchNorm couples the samples of a step): "
+                             f"{type(model).__name__} does not declare batch_independent")
         self.model = model
         self.lr0, self.num_update, self.scheduler, self.step_size = float(lr), int(num_update), scheduler, int(step_size)
         self.betas, self.eps, self.clip = betas, eps, float(clip_grad_norm or 0.0)
@@ -164,10 +172,20 @@ class ArenaTrainer:
         for p in self.params:
             p.grad = None
         self._early, self._works = {}, []
-        model._dp_early = self._dp_early if self.world > 1 else None
-        loss = model.train_loss(input, target).mean()
-        loss.backward()
-        model._dp_early = None
+        B = input.shape[0]
+        if self.micro_batch and B > self.micro_batch:
+            model._dp_early = None                       # gradients are final only after the last micro-batch
+            loss = None
+            for i in range(0, B, self.micro_batch):
+                xi, yi = input[i:i + self.micro_batch], target[i:i + self.micro_batch]
+                li = model.train_loss(xi, yi).mean() * (xi.shape[0] / B)      # mean over the step = weighted mean of the parts
+                li.backward()                            # autograd accumulates into p.grad
+                loss = li.detach() if loss is None else loss + li.detach()
+        else:
+            model._dp_early = self._dp_early if self.world > 1 else None
+            loss = model.train_loss(input, target).mean()
+            loss.backward()
+            model._dp_early = None
         # ---- gradients -> arena (storage plumbing; parameters the loss does not reach keep a zero gradient)
         late_dst, late_src, early = [], [], []
         for p, gv in zip(self.params, self.gviews):
@@ -234,13 +252,15 @@ class ArenaTrainer:
         return ck
 
 
-def make_trainer(model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0):
+def make_trainer(model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0, micro_batch=None):
     """Fused trainer for FNO3d (one flat arena built into the model), ArenaTrainer for the nn.Parameter models."""
     if hasattr(model, "flat"):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and model.dp is None:
             from .dp import DataParallel
             DataParallel(model)
+        if micro_batch:
+            raise ValueError("micro_batch: FNO3d's BatchNorm3d couples the samples of a step")
         return Trainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
                        clip_grad_norm=clip_grad_norm)
     return ArenaTrainer(model, lr=lr, num_update=num_update, scheduler=scheduler, step_size=step_size,
-                        clip_grad_norm=clip_grad_norm)
+                        clip_grad_norm=clip_grad_norm, micro_batch=micro_batch)

@@ -227,3 +227,25 @@ def test_arena_trainer_two_ranks_equal_single_rank(kind):
     for (n, p), q in zip(model.named_parameters(), twin.parameters()):
         dw = (p.data - q.data).abs()        # same gradients bit for bit (same kernels, same batch): only the Adam arithmetic differs
         assert float(dw.max()) <= 0.05 * 1e-3, n
+
+
+@pytest.mark.parametrize("kind", ["transolver", "unet"])
+def test_micro_batched_step_equals_the_full_step(kind):
+    """ArenaTrainer(micro_batch=...): a 4-sample step run as two 2-sample forward / backward passes with accumulated gradients is
+    the same step (these models have no batch statistics) -- the way BASELINE.json configs[2]'s 16 samples per GPU fit (one fp32
+    fsi-mesh sample of the U-Net takes 116 GiB).  BatchNorm models are refused."""
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.trainer import ArenaTrainer, make_trainer
+    ma, shape = _small_model(kind)
+    mb, _ = _small_model(kind)
+    ma, mb = ma.cuda(), mb.cuda()
+    ta = make_trainer(ma, lr=1e-3, num_update=10)
+    tb = make_trainer(mb, lr=1e-3, num_update=10, micro_batch=2)
+    assert isinstance(tb, ArenaTrainer) and tb.micro_batch == 2
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.randn(4, *shape, generator=g).cuda(), torch.randn(4, *shape, generator=g).cuda()
+    la, lb = float(ta.step(x, y)), float(tb.step(x, y))
+    assert abs(la - lb) < 1e-6 * abs(la)
+    assert rel_l2(tb.grad, ta.grad) < 1e-5
+    with pytest.raises(ValueError, match="BatchNorm"):
+        make_trainer(FNO3d(2, 2, 3, 1, 32, (4, 8, 8, 2), (4, 8, 8, 2)).cuda(), lr=1e-3, num_update=10, micro_batch=2)
