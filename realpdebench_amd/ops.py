@@ -286,6 +286,9 @@ def mul(a, b, out, n):
 GEMM_SPLIT = os.environ.get("RPB_GEMM_EXACT", "0") != "1"
 GEMM_SPLIT_WIDE_N = 8192               # ... unless the output is wide enough to fill the chip from few rows (DPOT's TimeAggregator data
                                        # gradient, M = 4096, N = 20480: 167 vs 124 TF/s; its N = 1024 GEMMs: 83-108 vs 93-118, stay fp32)
+# K <= 256, N <= 256 with an epilogue that reads or writes a second [M][N] tensor: the exact-fp32 kernel is faster (2.6 M rows, GELU +
+# residual: 3.43 vs 4.12 ms; plain: 3.14 vs 2.49 -- DESIGN.md section 9)
+GEMM_F32_SHORT_HEAVY = os.environ.get("RPB_GEMM_F32_SHORT_HEAVY", "1") != "0"
 GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
 
 
@@ -313,7 +316,8 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     taps = {0: 1, 1: 27, 2: 16, 3: 4}[mode]
     lda = (K // taps) if lda is None else lda
     ldo = N if ldo is None else ldo
-    if gemm_split_ok(M, N, K, lda, ldo, conv):
+    heavy_epilogue = residual is not None or aux is not None or mask is not None or pre_out is not None
+    if gemm_split_ok(M, N, K, lda, ldo, conv) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue):
         wsrc = W.t if isinstance(W, Sub) else W
         wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
         _lib.call("rpb_gemm3x_wprep", _p(W), _p(wz, torch.int16), N, K, _stream(), label="gemm3x_wprep", nbytes=10 * N * K)
