@@ -418,11 +418,12 @@ int rpb_dp_allreduce_destroy(void* handle);
 /* ---- rollout: eval cell_mix (output = act(BatchNorm(.)) of THIS layer, as rpb_cell_mix with oxf_* / rpb_cell_mix_feat) with the NEXT
  *      layer's forward W stage fused in: y1 [ncell / Wp][K2f][64] = sum_w FWt[w][k] out[line, w][c], i.e. what
  *      rpb_axis_gemm(out, y1, FWt, ...) of fno.py:48 would compute from a second read of the activations (one of the three activation
- *      passes per layer of the evaluation forward).  feat_w > 0: x is the feature tensor [ncell][feat_w], Wm the composite weight. */
+ *      passes per layer of the evaluation forward).  feat_w > 0: x is the feature tensor [ncell][feat_w], Wm the composite weight.
+ *      scratch: 3 * Wp * 64 bytes the launch fills with GWt's bf16 planes in operand order (read back through L1 by the kernel). */
 int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f);
 int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out, long ncell,
                           int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
-                          const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* stream);
+                          const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* scratch, void* stream);
 
 /* ---- DPOT: AFNO patch transformer (realpdebench/model/dpot.py + dpot_libs/models/dpot.py).  Tokens are
  *      channels-last rows; the dense layers run on rpb_gemm_nt / rpb_gemm_tn, the 2-D DFT stages on rpb_axis_gemm.

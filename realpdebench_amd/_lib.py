@@ -37,7 +37,7 @@ SIGNATURES = {
     "rpb_proj_wgrad_roles": (_I, ""),
     "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
-    "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "p"),
+    "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),
     "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),
     "rpb_rowtable_add": (_I, "pp" + "l" + "iii" + "p"),
     "rpb_rowtable_grad": (_I, "pp" + "iiii" + "p"),

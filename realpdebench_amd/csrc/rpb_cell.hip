@@ -414,7 +414,7 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.write_gz = bnb_s != nullptr && bnb_gelu == 2;
         c.bf16_io = 0;
         c.feat_w = 0;
-        c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
+        c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0; c.gw_planes = nullptr;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
@@ -468,7 +468,7 @@ extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const floa
     c.write_gz = 0;
     c.bf16_io = 1;
     c.feat_w = 0;
-    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
+    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0; c.gw_planes = nullptr;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 
@@ -491,7 +491,7 @@ extern "C" int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const flo
     c.write_gz = 0;
     c.bf16_io = 0;
     c.feat_w = FW;
-    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0;
+    c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0; c.gw_planes = nullptr;
     return rpb_cmx_launch(c, stats_part ? 1 : 0, (hipStream_t)stream);
 }
 
@@ -501,8 +501,8 @@ extern "C" int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const flo
 extern "C" int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
                                      long ncell, int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd,
                                      const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1,
-                                     void* stream) {
-    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1, "cell_mix_eval_dft: null pointer");
+                                     void* scratch, void* stream) {
+    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1 && scratch, "cell_mix_eval_dft: null pointer");
     RPB_REQUIRE(feat_w == 0 || feat_w == 8 || feat_w == 32, "cell_mix_eval_dft: feat_w=%d", feat_w);
     RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f),
                 "cell_mix_eval_dft: unsupported sizes (K2=%d Wp=%d K2f=%d)", K2, Wp, K2f);
@@ -515,7 +515,7 @@ extern "C" int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const floa
     c.write_gz = 0;
     c.bf16_io = 0;
     c.feat_w = feat_w;
-    c.FWt = FWt; c.y1out = y1; c.K2f = K2f;
+    c.FWt = FWt; c.y1out = y1; c.K2f = K2f; c.gw_planes = scratch;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f) {

@@ -22,6 +22,7 @@ struct CmxArgs {
     const float* FWt;     // eval (STATS == 0 with the output transform): forward W-stage matrix [Wp][K2f] of the NEXT layer's spectral branch ...
     float* y1out;         // ... and its result [G][K2f][64] = that stage applied to the activated line this launch writes (fused: the
     int K2f;              //     activations are not read again for it); null = off
+    void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
 };
 
 bool rpb_cmx_dft_supported(int Wp, int K2f);

@@ -78,8 +78,8 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       tile's outputs sit in the accumulators in exactly that stage's B-operand form (lane group kg holds cells {4 kg + r, 16 + 4 kg + r}
 //       of channels 4 n + t), so Y1[line] = FW a accumulates on the matrix pipe from the split outputs and the stage never reads the
 //       activations from HBM (one of the three activation passes per layer of the rollout).  The stage matrix per wave tile lives in
-//       LDS in A-operand order; that costs two waves per workgroup (6 instead of 8).
-#define CMX_WAVES_DFT 6
+//       LDS in A-operand order; the inverse-stage matrix GW moves to a prepared global buffer to keep 8 waves per workgroup.
+#define CMX_WAVES_DFT 8
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false>
 __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) void cmx_kernel(CmxArgs a) {
     static_assert(!DFT || (STATS == 0 && !BF), "fused forward W stage: fp32 eval path");
@@ -91,8 +91,10 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
-    u32x4* GWs = Bw + 24 * 64;               // [plane 3][w Wp][kg 4]           last-stage DFT matrix, A-operand rows
-    u32x4* Zs = GWs + 3 * Wp * 4;            // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
+    // [plane 3][w Wp][kg 4]  last-stage DFT matrix, A-operand rows.  DFT variant: read from a prepared global buffer (26 KB, L1-resident)
+    // instead, which is what lets 8 waves fit next to the forward-stage matrix
+    u32x4* GWs = DFT ? const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.gw_planes)) : Bw + 24 * 64;
+    u32x4* Zs = Bw + 24 * 64 + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
     float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
     u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * 64);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
     const int tid = threadIdx.x;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
         Bw[((ks * 3 + 1) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, md);
         Bw[((ks * 3 + 2) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
-    for (int idx = tid; idx < Wp * 4; idx += blockDim.x) {
+    for (int idx = tid; idx < (DFT ? 0 : Wp * 4); idx += blockDim.x) {
         const int w = idx >> 2, kgw = idx & 3;
         float v[8];
 #pragma unroll
@@ -476,7 +478,25 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
 }
 
 static size_t cmx_lds(int Wp, int waves, bool dft = false) {
-    return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0);
+    return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0);
+}
+
+// GW [K2][Wp] -> three bf16 planes in A-operand row order [plane][w][kg] (the DFT variant's inverse-stage operand, read through L1)
+__global__ void cmx_gw_prep_kernel(const float* __restrict__ GW, u32x4* __restrict__ out, int K2, int Wp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Wp * 4) return;
+    const int w = idx >> 2, kgw = idx & 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kgw + e;
+        v[e] = k < K2 ? GW[k * Wp + w] : 0.f;
+    }
+    bf16x8 h, md, lo;
+    split8(v, h, md, lo);
+    out[(0 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, h);
+    out[(1 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, md);
+    out[(2 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, lo);
 }
 bool rpb_cmx_dft_supported(int Wp, int K2f) { return K2f > 0 && K2f <= 32 && cmx_lds(Wp, CMX_WAVES_DFT, true) <= 160 * 1024; }
 
@@ -498,8 +518,9 @@ long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
 
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
-        if (stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !rpb_cmx_dft_supported(a.Wp, a.K2f))
-            RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the fp32 eval path (output transform) and K2f <= 32");
+        if (stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
+            RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the fp32 eval path (output transform), a scratch buffer and K2f <= 32");
+        hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp);
         const int waves = CMX_WAVES_DFT;
         const long G = a.ncell / a.Wp;
         long grid = rpb_num_cus();

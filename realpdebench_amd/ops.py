@@ -103,6 +103,9 @@ def cell_mix_bf16(x, Wm, bias, z2, GW, out, ncell, C, K2, Wp, oxf=None):
               flops=2 * ncell * C * (K2 + C))
 
 
+_DFT_SCRATCH = {}
+
+
 def cell_mix_eval_dft_supported(ncell, K2, Wp, K2f):
     return bool(_lib.query("rpb_cell_mix_eval_dft_supported", ncell, K2, Wp, K2f))
 
@@ -111,8 +114,11 @@ def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1
     """Eval cell_mix (C = 64, output transform ``oxf``) + the next layer's forward W stage: ``y1 [ncell/Wp][K2f][64]``."""
     assert tuple(FWt.shape) == (Wp, K2f)
     KC = feat_w or 64
+    key = (str(out.device), Wp)
+    if key not in _DFT_SCRATCH:
+        _DFT_SCRATCH[key] = torch.empty(3 * Wp * 16, device=out.device, dtype=torch.float32)     # GW planes, rewritten by every launch
     _lib.call("rpb_cell_mix_eval_dft", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), ncell, K2, Wp, int(feat_w), *_xf(oxf),
-              _p(FWt), K2f, _p(y1), _stream(), label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W]",
+              _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W]",
               nbytes=4 * ncell * (KC + 64) + 4 * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + KC + K2f))
 
 
