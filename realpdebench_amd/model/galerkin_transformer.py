@@ -140,11 +140,9 @@ def _wgrad(G, A, M, N, K, ldg=None, lda=None):
     splits = ops.gemm_tn_splits(M, N, K)
     part = torch.empty(splits, N * K + N, device=base.device, dtype=torch.float32)
     ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
-    dW = torch.empty(N, K, device=base.device, dtype=torch.float32)
-    db = torch.empty(N, device=base.device, dtype=torch.float32)
-    ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
-    ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
-    return dW, db
+    tot = torch.empty(N * K + N, device=base.device, dtype=torch.float32)       # one reduction launch for [dW | db]
+    ops.reduce_partials(part, splits, N * K + N, out_f32=tot)
+    return tot[:N * K].view(N, K), tot[N * K:]
 
 
 _REG_RENAME = (("regressor.fc0.", "regressor.fc."), ("regressor.spectral_convs.", "regressor.spectral_conv."),
