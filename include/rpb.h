@@ -433,7 +433,7 @@ int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, co
  *      rpb_rowtable_add / _grad: x[r][:] += table[(r / rows_per_entry) % nent][:] (x + pos_embed, dpot.py:375) and d table.
  *      rpb_dpot_tagg_prep / _finish: TimeAggregator 'exp_mlp' (dpot.py:227-241): e[t][i] = cos(tt[t] gamma[i]); Wb [(t,i)][j] = e w and
  *        its transpose Wf [j][(t,i)], the W operands of the data-gradient / forward token GEMMs (K = T*C resp. N = T*C);
- *        finish: dWb -> d w, d gamma.
+ *        finish: dWb (+ dWsum [C][C] added to every frame's block, optional) -> d w, d gamma.
  *      rpb_gn_tokens_fwd / _bwd: torch.nn.GroupNorm(G, C) (dpot.py:143,151) of x (+ x2) [B][P][C]; stat [B*G][2] = (mean, rstd);
  *        bwd: gx (+ gadd), pg / pb [B][C] per-sample partials of d weight / d bias.
  *      rpb_afno_wprep / _mlp / _wgrad: AFNO2D's block-diagonal complex MLP on the kept modes (dpot.py:72-94).  Spectral rows
@@ -449,8 +449,8 @@ int rpb_rowtable_add(float* x, const float* table, long M, int C, int rows_per_e
 int rpb_rowtable_grad(const float* g, float* dtable, int B, int C, int rows_per_entry, int nent, void* stream);
 int rpb_dpot_tagg_prep(const float* w, const float* gamma, const float* tt, float* Wf, float* Wb, float* e_out, int T, int C,
                        void* stream);
-int rpb_dpot_tagg_finish(const float* dWb, const float* w, const float* gamma, const float* tt, float* dw, float* dgamma, int T,
-                         int C, void* stream);
+int rpb_dpot_tagg_finish(const float* dWb, const float* dWsum, const float* w, const float* gamma, const float* tt, float* dw,
+                         float* dgamma, int T, int C, void* stream);
 int rpb_gn_tokens_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float* y, float* stat, int B, int P,
                       int C, int G, float eps, void* stream);
 int rpb_gn_tokens_bwd(const float* x, const float* x2, const float* gamma, const float* stat, const float* gy, const float* gadd,

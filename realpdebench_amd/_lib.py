@@ -42,7 +42,7 @@ SIGNATURES = {
     "rpb_rowtable_add": (_I, "pp" + "l" + "iii" + "p"),
     "rpb_rowtable_grad": (_I, "pp" + "iiii" + "p"),
     "rpb_dpot_tagg_prep": (_I, "pppppp" + "ii" + "p"),
-    "rpb_dpot_tagg_finish": (_I, "pppppp" + "ii" + "p"),
+    "rpb_dpot_tagg_finish": (_I, "ppppppp" + "ii" + "p"),
     "rpb_gn_tokens_fwd": (_I, "pppppp" + "iiii" + "f" + "p"),
     "rpb_gn_tokens_bwd": (_I, "ppppppppp" + "iiii" + "p"),
     "rpb_afno_wprep": (_I, "pp" + "iiii" + "p"),

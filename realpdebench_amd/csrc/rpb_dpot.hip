@@ -92,9 +92,10 @@ __global__ void tagg_prep_kernel(const float* __restrict__ w, const float* __res
         Wf[(long)j * T * C + (long)t * C + i] = tile[lx][r];
     }
 }
-// dWb [(t,i)][j] -> dw[t][i][j] = e[t][i] dWb;  dgamma[i] = sum_t -sin(tt[t] gamma[i]) tt[t] sum_j dWb[(t,i)][j] w[t][i][j]
-__global__ void tagg_finish_kernel(const float* __restrict__ dWb, const float* __restrict__ w, const float* __restrict__ gamma,
-                                   const float* __restrict__ tt, float* __restrict__ dw, float* __restrict__ dgamma, int T, int C) {
+// dWb [(t,i)][j] (+ dWsum [i][j] for every t) -> dw[t][i][j] = e[t][i] dWb;  dgamma[i] = sum_t -sin(tt[t] gamma[i]) tt[t] sum_j dWb[(t,i)][j] w[t][i][j]
+__global__ void tagg_finish_kernel(const float* __restrict__ dWb, const float* __restrict__ dWsum, const float* __restrict__ w,
+                                   const float* __restrict__ gamma, const float* __restrict__ tt, float* __restrict__ dw,
+                                   float* __restrict__ dgamma, int T, int C) {
     const int i = blockIdx.x;
     const float ga = gamma[i];
     double acc = 0.0;
@@ -104,7 +105,7 @@ __global__ void tagg_finish_kernel(const float* __restrict__ dWb, const float* _
         const long base = ((long)t * C + i) * C;
         double s = 0.0;
         for (int j = threadIdx.x; j < C; j += blockDim.x) {
-            const float d = dWb[base + j];
+            const float d = dWb[base + j] + (dWsum ? dWsum[(long)i * C + j] : 0.f);   // + the gradient through sum_t Wb_t (composite path)
             dw[base + j] = e * d;
             s += (double)d * (double)w[base + j];
         }
@@ -454,10 +455,10 @@ extern "C" int rpb_dpot_tagg_prep(const float* w, const float* gamma, const floa
     hipLaunchKernelGGL(tagg_prep_kernel, dim3(C / 32, C / 32, T), dim3(256), 0, (hipStream_t)stream, w, gamma, tt, Wf, Wb, e_out, T, C);
     RPB_CHECK_LAUNCH("dpot_tagg_prep");
 }
-extern "C" int rpb_dpot_tagg_finish(const float* dWb, const float* w, const float* gamma, const float* tt, float* dw, float* dgamma,
-                                    int T, int C, void* stream) {
+extern "C" int rpb_dpot_tagg_finish(const float* dWb, const float* dWsum, const float* w, const float* gamma, const float* tt, float* dw,
+                                    float* dgamma, int T, int C, void* stream) {
     RPB_REQUIRE(dWb && w && gamma && tt && dw && dgamma && T > 0 && C > 0, "dpot_tagg_finish: bad arguments");
-    hipLaunchKernelGGL(tagg_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dWb, w, gamma, tt, dw, dgamma, T, C);
+    hipLaunchKernelGGL(tagg_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dWb, dWsum, w, gamma, tt, dw, dgamma, T, C);
     RPB_CHECK_LAUNCH("dpot_tagg_finish");
 }
 

@@ -20,6 +20,7 @@ TN GEMMs, rpb_afno_mlp mode 1 / rpb_afno_wgrad, rpb_gn_tokens_bwd); there is no 
 exists for state_dict compatibility; its output is discarded by the wrapper (model/dpot.py:224) and never computed here.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -307,17 +308,36 @@ class DPOT(_ModelBase):
         ops.gemm_nt(P, pe0.weight.data.view(E1, Kp), H1, M1, E1, Kp, bias=pe0.bias.data, act=1, ldo=E1p, pre_out=H1pre)
         W2p = torch.zeros(E, E1p, **f)
         W2p[:, :E1] = pe2.weight.data.view(E, E1)
-        Etok = new(M1, E)
-        ops.gemm_nt(H1, W2p, Etok, M1, E, E1p, bias=pe2.bias.data)
         pos = net.pos_embed.data[0].permute(1, 2, 0).reshape(n * n, E).contiguous()
-        ops.rowtable_add(Etok, pos, M1, E, T, n * n)
-        # ---- TimeAggregator: one GEMM over K = (t, channel)
         ta = net.time_agg_layer
         gamma = ta.gamma.data.view(E) if self.time_agg == "exp_mlp" else torch.zeros(E, **f)
         Wf, Wb, ecos = new(E, T * E), new(T * E, E), new(T, E)
         ops.dpot_tagg_prep(ta.w.data, gamma, pl["tt"], Wf, Wb, ecos, T, E)
         X = new(Mt, E)
-        ops.gemm_nt(Etok, Wf, X, Mt, E, T * E)
+        comp = os.environ.get("RPB_DPOT_COMPOSITE", "1") != "0"
+        Etok = WcT = WsumT = posb = None
+        if comp:
+            # PatchEmbed's second conv, + pos_embed and the TimeAggregator are one linear map of the 35-wide hidden layer: contract the
+            # weights first -- WcT[j][(t, k)] = sum_i (cos(t gamma_i) w[t][i][j]) W2[i][k] (20 small GEMMs), the constant part
+            # (b2 + pos[xy]) sum_t Wb_t -- and the aggregation is ONE token GEMM with K = T * 64 instead of T * E (29x fewer FLOPs on the
+            # largest product of the model; the [B n^2 T][E] token tensor is never materialised).  The layer-0 algebra of the FNO path again.
+            W2pT = W2p.t().contiguous()
+            WcT = new(E, T * E1p)
+            for t in range(T):
+                ops.gemm_nt(ops.Sub(Wf, t * E), W2pT, ops.Sub(WcT, t * E1p), E, E1p, E, lda=T * E, ldo=T * E1p)
+            ops.gemm_nt(H1, WcT, X, Mt, E, T * E1p)
+            WsumT = new(E, E)                                                  # [j][i] = sum_t Wb[(t, i)][j]
+            ops.reduce_partials_batched(Wf, E, T, E, WsumT)
+            posb = pos + pe2.bias.data                                         # [n^2][E]: parameter-sized
+            PosT = new(n * n, E)
+            ops.gemm_nt(posb, WsumT, PosT, n * n, E, E)
+            ops.rowtable_add(X, PosT, Mt, E, 1, n * n)
+        else:
+            Etok = new(M1, E)
+            ops.gemm_nt(H1, W2p, Etok, M1, E, E1p, bias=pe2.bias.data)
+            ops.rowtable_add(Etok, pos, M1, E, T, n * n)
+            # ---- TimeAggregator: one GEMM over K = (t, channel)
+            ops.gemm_nt(Etok, Wf, X, Mt, E, T * E)
         del Wf
         # ---- blocks
         ntok = B * mk * mky
@@ -377,6 +397,7 @@ class DPOT(_ModelBase):
             pred = self._resize_apply(pred.view(B * To, H, W, Cdo), rs["out"]).view(B, To, Ho, Wo, Cdo)
         if training:
             save.update(B=B, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
+                        comp=comp, WcT=WcT, WsumT=WsumT, posb=posb,
                         U=U, Upre=Upre, V=V, Vpre=Vpre, W3p=W3p)
         return pred
 
@@ -463,29 +484,55 @@ class DPOT(_ModelBase):
             g = gX
         # ---- TimeAggregator
         ta = net.time_agg_layer
-        Etok = sv["Etok"]
-        dWb, _ = _wgrad(Etok, g, Mt, T * E, E, ldg=T * E, lda=E)                     # [(t,i)][j] = sum_m E[m][(t,i)] g[m][j]
-        dw, dgamma = torch.empty_like(ta.w), new(E)
-        ops.dpot_tagg_finish(dWb, ta.w.data, sv["gamma"], pl["tt"], dw, dgamma, T, E)
-        del dWb
-        grads[ta.w] = dw
-        if self.time_agg == "exp_mlp":
-            grads[ta.gamma] = dgamma.view(1, E)
-        gE = new(M1, E)
-        ops.gemm_nt(g, sv["Wb"], gE, Mt, T * E, E)
-        # ---- pos_embed, PatchEmbed
-        dpos = new(n * n, E)
-        ops.rowtable_grad(gE, dpos, B, E, T, n * n)
-        grads[net.pos_embed] = dpos.view(n, n, E).permute(2, 0, 1).unsqueeze(0).contiguous()
         pe0, pe2 = net.patch_embed.proj[0], net.patch_embed.proj[2]
         E1 = Co * ps + 3
         E1p = _rup(E1, 32)
         Kp = (Cm + 3) * ps * ps
-        dW2p, dbp2 = _wgrad(gE, sv["H1"], M1, E, E1p)
-        grads[pe2.weight], grads[pe2.bias] = dW2p[:, :E1].reshape(pe2.weight.shape).contiguous(), dbp2
-        gH1 = torch.zeros(M1, E1p, **f)
-        ops.gemm_nt(gE, Tr(sv["W2p"]), gH1, M1, E1, E, act=2, aux=sv["H1pre"], ldo=E1p)
-        del gE
+        dw, dgamma = torch.empty_like(ta.w), new(E)
+        if sv["comp"]:
+            # adjoint of the contracted map X0 = Hb WcT^T + (b2 + pos) Wsum  (Hb = the hidden layer as [B n^2][T * 64] rows)
+            Hb, W2p, Wb, WcT = sv["H1"], sv["W2p"], sv["Wb"], sv["WcT"]
+            KT = T * E1p
+            GP = new(n * n, E)
+            ops.rowtable_grad(g, GP, B, E, 1, n * n)                            # sum over the samples
+            Wsum = Tr(sv["WsumT"])                                              # [i][j]
+            dposb = new(n * n, E)
+            ops.gemm_nt(GP, Wsum, dposb, n * n, E, E)
+            grads[net.pos_embed] = dposb.view(n, n, E).permute(2, 0, 1).unsqueeze(0).contiguous()
+            grads[pe2.bias] = self._colsum(dposb, n * n, E)
+            dWsum, _ = _wgrad(sv["posb"], GP, n * n, E, E)                      # [i][j]
+            dWcT, _ = _wgrad(g, Hb, Mt, E, KT, ldg=E, lda=KT)                   # [j][(t, k)]
+            dWc, _ = _wgrad(Hb, g, Mt, KT, E, ldg=KT, lda=E)                    # [(t, k)][j]
+            gH1 = new(M1, E1p)
+            ops.gemm_nt(g, Tr(WcT), gH1, Mt, KT, E, act=2, aux=sv["H1pre"])      # d hidden pre-activation, rows [B n^2][T * 64]
+            dWf = new(E, T * E)                                                 # [j][(t, i)] = sum_k dWcT[j][(t, k)] W2[i][k]
+            dW2p = new(E, E1p)
+            for t in range(T):
+                ops.gemm_nt(ops.Sub(dWcT, t * E1p), W2p, ops.Sub(dWf, t * E), E, E, E1p, lda=KT, ldo=T * E)
+                ops.gemm_nt(ops.Sub(Wb, t * E * E), ops.Sub(dWc, t * E1p * E), dW2p, E, E1p, E, residual=dW2p if t else None)
+            dWb = dWf.view(E, T, E).permute(1, 2, 0).contiguous()               # parameter-sized re-layout to [(t, i)][j]
+            ops.dpot_tagg_finish(dWb, ta.w.data, sv["gamma"], pl["tt"], dw, dgamma, T, E, dWsum=dWsum)
+            del dWb, dWf
+            grads[pe2.weight] = dW2p[:, :E1].reshape(pe2.weight.shape).contiguous()
+        else:
+            Etok = sv["Etok"]
+            dWb, _ = _wgrad(Etok, g, Mt, T * E, E, ldg=T * E, lda=E)                 # [(t,i)][j] = sum_m E[m][(t,i)] g[m][j]
+            ops.dpot_tagg_finish(dWb, ta.w.data, sv["gamma"], pl["tt"], dw, dgamma, T, E)
+            del dWb
+            gE = new(M1, E)
+            ops.gemm_nt(g, sv["Wb"], gE, Mt, T * E, E)
+            # ---- pos_embed, PatchEmbed
+            dpos = new(n * n, E)
+            ops.rowtable_grad(gE, dpos, B, E, T, n * n)
+            grads[net.pos_embed] = dpos.view(n, n, E).permute(2, 0, 1).unsqueeze(0).contiguous()
+            dW2p, dbp2 = _wgrad(gE, sv["H1"], M1, E, E1p)
+            grads[pe2.weight], grads[pe2.bias] = dW2p[:, :E1].reshape(pe2.weight.shape).contiguous(), dbp2
+            gH1 = torch.zeros(M1, E1p, **f)
+            ops.gemm_nt(gE, Tr(sv["W2p"]), gH1, M1, E1, E, act=2, aux=sv["H1pre"], ldo=E1p)
+            del gE
+        grads[ta.w] = dw
+        if self.time_agg == "exp_mlp":
+            grads[ta.gamma] = dgamma.view(1, E)
         dW1, db1 = _wgrad(gH1, sv["P"], M1, E1, Kp, ldg=E1p, lda=Kp)
         grads[pe0.weight], grads[pe0.bias] = dW1.reshape(pe0.weight.shape), db1
         return grads

@@ -748,8 +748,8 @@ def dpot_tagg_prep(w, gamma, tt, Wf, Wb, e_out, T, C):
               nbytes=12 * T * C * C)
 
 
-def dpot_tagg_finish(dWb, w, gamma, tt, dw, dgamma, T, C):
-    _lib.call("rpb_dpot_tagg_finish", _p(dWb), _p(w), _p(gamma), _p(tt), _p(dw), _p(dgamma), T, C, _stream(),
+def dpot_tagg_finish(dWb, w, gamma, tt, dw, dgamma, T, C, dWsum=None):
+    _lib.call("rpb_dpot_tagg_finish", _p(dWb), _p(dWsum), _p(w), _p(gamma), _p(tt), _p(dw), _p(dgamma), T, C, _stream(),
               label="dpot_tagg_finish", nbytes=12 * T * C * C)
 
 
