@@ -322,9 +322,8 @@ class DPOT(_ModelBase):
             # (b2 + pos[xy]) sum_t Wb_t -- and the aggregation is ONE token GEMM with K = T * 64 instead of T * E (29x fewer FLOPs on the
             # largest product of the model; the [B n^2 T][E] token tensor is never materialised).  The layer-0 algebra of the FNO path again.
             W2pT = W2p.t().contiguous()
-            WcT = new(E, T * E1p)
-            for t in range(T):
-                ops.gemm_nt(ops.Sub(Wf, t * E), W2pT, ops.Sub(WcT, t * E1p), E, E1p, E, lda=T * E, ldo=T * E1p)
+            WcT = new(E, T * E1p)                                              # rows (j, t) of Wf x W2^T: one GEMM, M = E * T
+            ops.gemm_nt(Wf, W2pT, WcT, E * T, E1p, E)
             ops.gemm_nt(H1, WcT, X, Mt, E, T * E1p)
             WsumT = new(E, E)                                                  # [j][i] = sum_t Wb[(t, i)][j]
             ops.reduce_partials_batched(Wf, E, T, E, WsumT)
@@ -338,7 +337,8 @@ class DPOT(_ModelBase):
             ops.rowtable_add(Etok, pos, M1, E, T, n * n)
             # ---- TimeAggregator: one GEMM over K = (t, channel)
             ops.gemm_nt(Etok, Wf, X, Mt, E, T * E)
-        del Wf
+        if not (comp and training):
+            del Wf
         # ---- blocks
         ntok = B * mk * mky
         tapes = []
@@ -397,7 +397,7 @@ class DPOT(_ModelBase):
             pred = self._resize_apply(pred.view(B * To, H, W, Cdo), rs["out"]).view(B, To, Ho, Wo, Cdo)
         if training:
             save.update(B=B, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
-                        comp=comp, WcT=WcT, WsumT=WsumT, posb=posb,
+                        comp=comp, WcT=WcT, WsumT=WsumT, posb=posb, Wf=Wf if comp else None,
                         U=U, Upre=Upre, V=V, Vpre=Vpre, W3p=W3p)
         return pred
 
@@ -491,7 +491,7 @@ class DPOT(_ModelBase):
         dw, dgamma = torch.empty_like(ta.w), new(E)
         if sv["comp"]:
             # adjoint of the contracted map X0 = Hb WcT^T + (b2 + pos) Wsum  (Hb = the hidden layer as [B n^2][T * 64] rows)
-            Hb, W2p, Wb, WcT = sv["H1"], sv["W2p"], sv["Wb"], sv["WcT"]
+            Hb, W2p, WcT = sv["H1"], sv["W2p"], sv["WcT"]
             KT = T * E1p
             GP = new(n * n, E)
             ops.rowtable_grad(g, GP, B, E, 1, n * n)                            # sum over the samples
@@ -502,14 +502,11 @@ class DPOT(_ModelBase):
             grads[pe2.bias] = self._colsum(dposb, n * n, E)
             dWsum, _ = _wgrad(sv["posb"], GP, n * n, E, E)                      # [i][j]
             dWcT, _ = _wgrad(g, Hb, Mt, E, KT, ldg=E, lda=KT)                   # [j][(t, k)]
-            dWc, _ = _wgrad(Hb, g, Mt, KT, E, ldg=KT, lda=E)                    # [(t, k)][j]
             gH1 = new(M1, E1p)
             ops.gemm_nt(g, Tr(WcT), gH1, Mt, KT, E, act=2, aux=sv["H1pre"])      # d hidden pre-activation, rows [B n^2][T * 64]
-            dWf = new(E, T * E)                                                 # [j][(t, i)] = sum_k dWcT[j][(t, k)] W2[i][k]
-            dW2p = new(E, E1p)
-            for t in range(T):
-                ops.gemm_nt(ops.Sub(dWcT, t * E1p), W2p, ops.Sub(dWf, t * E), E, E, E1p, lda=KT, ldo=T * E)
-                ops.gemm_nt(ops.Sub(Wb, t * E * E), ops.Sub(dWc, t * E1p * E), dW2p, E, E1p, E, residual=dW2p if t else None)
+            dWf = new(E, T * E)                                                 # [j][(t, i)] = sum_k dWcT[j][(t, k)] W2[i][k]: rows (j, t)
+            ops.gemm_nt(dWcT, W2p, dWf, E * T, E, E1p)
+            dW2p, _ = _wgrad(sv["Wf"], dWcT, E * T, E, E1p, ldg=E, lda=E1p)     # [i][k] = sum_(j,t) Wf[(j,t)][i] dWcT[(j,t)][k]
             dWb = dWf.view(E, T, E).permute(1, 2, 0).contiguous()               # parameter-sized re-layout to [(t, i)][j]
             ops.dpot_tagg_finish(dWb, ta.w.data, sv["gamma"], pl["tt"], dw, dgamma, T, E, dWsum=dWsum)
             del dWb, dWf
