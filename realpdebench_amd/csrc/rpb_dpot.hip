@@ -300,7 +300,16 @@ __global__ __launch_bounds__(1024) void afno_mlp_kernel(AfnoArgs a) {
     f32x16 acc = zero16();
     {
         const float* Wp = a.Wa + (long)k * K * K + n0 + col;
-        for (int s = 0; s < K; s += 2) acc = mfma32(Xs[col * LD + s + half], Wp[(long)(s + half) * K], acc);
+        for (int s = 0; s < K; s += 16) {              // K is a multiple of 32: eight steps' operands are requested before the first MFMA
+            float xa[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xa[u] = Xs[col * LD + s + 2 * u + half];
+                wb[u] = Wp[(long)(s + 2 * u + half) * K];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma32(xa[u], wb[u], acc);
+        }
     }
     const float bav = (a.mode == 0 && a.ba) ? a.ba[(long)ro * a.C + k * bs + oo] : 0.f;
 #pragma unroll
@@ -323,7 +332,16 @@ __global__ __launch_bounds__(1024) void afno_mlp_kernel(AfnoArgs a) {
     acc = zero16();
     {
         const float* Wp = a.Wb + (long)k * K * K + n0 + col;
-        for (int s = 0; s < K; s += 2) acc = mfma32(Hs[col * LD + s + half], Wp[(long)(s + half) * K], acc);
+        for (int s = 0; s < K; s += 16) {
+            float xa[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xa[u] = Hs[col * LD + s + 2 * u + half];
+                wb[u] = Wp[(long)(s + 2 * u + half) * K];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = mfma32(xa[u], wb[u], acc);
+        }
     }
     const float bbv = (a.mode == 0 && a.bb) ? a.bb[(long)ro * a.C + k * bs + oo] : 0.f;
 #pragma unroll
@@ -347,15 +365,20 @@ __global__ __launch_bounds__(64) void afno_wgrad_kernel(const float* __restrict_
     const long t0 = sp * per, t1 = (t0 + per < ntok) ? t0 + per : ntok;
     const long rowld = 2L * C;
     f32x16 acc = zero16();
-    for (long t = t0; t < t1; t += 2) {
-        const long tok = t + half;
-        float av = 0.f, gv = 0.f;
-        if (tok < t1) {
-            av = A[tok * rowld + offa];
-            if (a_gelu) av = gelu_f(av);
-            gv = G[tok * rowld + offb];
+    for (long t = t0; t < t1; t += 16) {               // eight MFMA steps (16 tokens) per trip: all loads first
+        float av[8], gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long tok = t + 2 * u + half;
+            av[u] = 0.f;
+            gv[u] = 0.f;
+            if (tok < t1) {
+                av[u] = A[tok * rowld + offa];
+                gv[u] = G[tok * rowld + offb];
+            }
         }
-        acc = mfma32(av, gv, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma32(a_gelu ? gelu_f(av[u]) : av[u], gv[u], acc);      // gelu(0) == 0 for the masked tail
     }
     float* p = part + (((long)sp * nb + k) * K) * K;
 #pragma unroll
@@ -497,7 +520,7 @@ extern "C" int rpb_afno_wprep(const float* w, float* Wc, int nb, int bs_in, int 
 extern "C" int rpb_afno_mlp(const float* X, const float* Wa, const float* ba, const float* Wb, const float* bb, const float* aux,
                             float* mid, float* out, long ntok, int nb, int bs, int mode, void* stream) {
     RPB_REQUIRE(X && Wa && Wb && out && ntok > 0 && nb > 0, "afno_mlp: bad arguments");
-    RPB_REQUIRE(bs % 16 == 0 && 2 * bs <= 512, "afno_mlp: block size %d unsupported (multiple of 16, <= 256)", bs);
+    RPB_REQUIRE(bs % 16 == 0 && 2 * bs <= 512, "afno_mlp: block size %d unsupported (multiple of 16, <= 256)", bs);      // 2 bs % 32 == 0: the K loops step by 16
     RPB_REQUIRE(mode == 0 || (mode == 1 && aux && mid), "afno_mlp: backward needs the saved pre-activation and a gradient buffer");
     AfnoArgs a{X, Wa, ba, Wb, bb, aux, mid, out, ntok, nb, bs, nb * bs, mode};
     const int waves = 2 * bs / 32;
