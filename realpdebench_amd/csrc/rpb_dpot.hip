@@ -146,6 +146,7 @@ __global__ void gn_tokens_fwd_kernel(const float* __restrict__ x, const float* _
     const long base = (long)b * P * C + g * cg + c;
     double sum = 0.0;
     if (act)
+#pragma unroll 4
         for (int p = s; p < P; p += S) {
             float v = x[base + (long)p * C];
             if (x2) v += x2[base + (long)p * C];
@@ -155,6 +156,7 @@ __global__ void gn_tokens_fwd_kernel(const float* __restrict__ x, const float* _
     const double mean = block_sum(sum, red) / n;
     double sq = 0.0;
     if (act)
+#pragma unroll 4
         for (int p = s; p < P; p += S) {
             float v = x[base + (long)p * C];
             if (x2) v += x2[base + (long)p * C];
@@ -169,6 +171,7 @@ __global__ void gn_tokens_fwd_kernel(const float* __restrict__ x, const float* _
     }
     if (act) {
         const float ga = gamma[g * cg + c], be = beta[g * cg + c];
+#pragma unroll 4
         for (int p = s; p < P; p += S) {
             float v = x[base + (long)p * C];
             if (x2) v += x2[base + (long)p * C];
@@ -194,6 +197,7 @@ __global__ void gn_tokens_bwd_kernel(const float* __restrict__ x, const float* _
     double s1 = 0.0, s2 = 0.0;
     float dg = 0.f, db = 0.f;
     if (act)
+#pragma unroll 4
         for (int p = s; p < P; p += S) {
             float v = x[base + (long)p * C];
             if (x2) v += x2[base + (long)p * C];
@@ -223,6 +227,7 @@ __global__ void gn_tokens_bwd_kernel(const float* __restrict__ x, const float* _
         pb[(long)b * C + g * cg + c] = bb;
     }
     if (act)
+#pragma unroll 4
         for (int p = s; p < P; p += S) {
             float v = x[base + (long)p * C];
             if (x2) v += x2[base + (long)p * C];
