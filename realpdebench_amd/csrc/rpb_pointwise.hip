@@ -232,46 +232,58 @@ extern "C" int rpb_lift_bwd(const float* g, const float* x, const float* gt, con
 
 // ---------------------------------------------------------------------------------- reducers
 // out[j] (+)= scale * sum_r part[r*row_stride + j], j < L   (fp64 accumulation)
+// CL columns x RG = 1024 / CL row groups per block.  Wide reductions (many columns) use 64 x 16: 256 B rows per wave; TALL ones (the
+// BatchNorm / weight-gradient partials: thousands of rows, a few hundred columns) use 16 x 64 -- a thread's serial chain of dependent
+// fp64 adds is a quarter as long and four times as many blocks share the work (2048 rows x 128 columns: ~20 us -> ~6 us, and most
+// reductions of a train step are of that shape).
+template <int CL>
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, long rows, long L,
                                                                long row_stride, float* __restrict__ outf,
                                                                double* __restrict__ outd, double scale,
                                                                int accumulate, long batch_stride) {
-    // block = 64 columns x 16 row groups; 4 independent fp64 chains per thread keep the loads pipelined
+    constexpr int RG = 1024 / CL;
+    // 4 independent fp64 chains per thread keep the loads pipelined
     // blockIdx.y = batch: an independent reduction over `rows` rows starting batch_stride floats further, out + y * L
-    __shared__ double red[16][64];
+    __shared__ double red[RG][CL];
     part += (long)blockIdx.y * batch_stride;
     if (outf) outf += (long)blockIdx.y * L;
     if (outd) outd += (long)blockIdx.y * L;
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const long j = (long)blockIdx.x * 64 + cl;
+    const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
+    const long j = (long)blockIdx.x * CL + cl;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (j < L) {
         long r = rg;
-        for (; r + 48 < rows; r += 64) {
+        for (; r + 3 * RG < rows; r += 4 * RG) {
             s0 += (double)part[r * row_stride + j];
-            s1 += (double)part[(r + 16) * row_stride + j];
-            s2 += (double)part[(r + 32) * row_stride + j];
-            s3 += (double)part[(r + 48) * row_stride + j];
+            s1 += (double)part[(r + RG) * row_stride + j];
+            s2 += (double)part[(r + 2 * RG) * row_stride + j];
+            s3 += (double)part[(r + 3 * RG) * row_stride + j];
         }
-        for (; r < rows; r += 16) s0 += (double)part[r * row_stride + j];
+        for (; r < rows; r += RG) s0 += (double)part[r * row_stride + j];
     }
     red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && j < L) {
         double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][cl];
+#pragma unroll 8
+        for (int k = 0; k < RG; ++k) v += red[k][cl];
         v *= scale;
         if (outd) outd[j] = accumulate ? outd[j] + v : v;
         if (outf) outf[j] = accumulate ? (float)((double)outf[j] + v) : (float)v;
     }
 }
 
+static bool reduce_tall(long rows, long L) { return rows >= 256 && L <= 16384; }
+
 extern "C" int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, float* outf, double* outd,
                                    double scale, int accumulate, void* stream) {
     RPB_REQUIRE(part && (outf || outd) && rows > 0 && L > 0 && row_stride >= L, "reduce_partials: bad arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
-                       part, rows, L, row_stride, outf, outd, scale, accumulate, 0L);
+    if (reduce_tall(rows, L))
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((unsigned)((L + 15) / 16)), dim3(1024), 0, (hipStream_t)stream,
+                           part, rows, L, row_stride, outf, outd, scale, accumulate, 0L);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((unsigned)((L + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                           part, rows, L, row_stride, outf, outd, scale, accumulate, 0L);
     RPB_CHECK_LAUNCH("reduce_partials");
 }
 
@@ -279,7 +291,7 @@ extern "C" int rpb_reduce_partials(const float* part, long rows, long L, long ro
 extern "C" int rpb_reduce_partials_batched(const float* part, int nbatch, long rows, long L, long row_stride, long batch_stride,
                                            float* outf, void* stream) {
     RPB_REQUIRE(part && outf && nbatch > 0 && nbatch < 65536 && rows > 0 && L > 0 && row_stride >= L, "reduce_partials_batched: bad arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)nbatch), dim3(1024), 0,
+    hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((unsigned)((L + 63) / 64), (unsigned)nbatch), dim3(1024), 0,
                        (hipStream_t)stream, part, rows, L, row_stride, outf, (double*)nullptr, 1.0, 0, batch_stride);
     RPB_CHECK_LAUNCH("reduce_partials_batched");
 }

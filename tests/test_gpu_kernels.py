@@ -607,3 +607,19 @@ def test_eval_cell_mix_with_fused_forward_w_stage(ops, feat_w, Wp, K2f):
     assert torch.equal(out, ref)
     y_ref = torch.einsum("wk,gwc->gkc", FWt.double().cpu(), ref.double().cpu().view(G, Wp, C))
     assert rel_l2(y1.cpu(), y_ref) < 5e-6
+
+
+@pytest.mark.parametrize("rows,L,stride", [(2048, 128, 128), (300, 4160, 4200), (255, 64, 64), (4096, 3, 8), (5, 100000, 100000)])
+def test_reduce_partials_shapes(ops, rows, L, stride):
+    """rpb_reduce_partials in both block shapes (tall: >= 256 rows of <= 16 K columns; wide otherwise): fp64 sums, scale, accumulate."""
+    torch.manual_seed(rows + L)
+    part = torch.randn(rows, stride, dtype=torch.float64)
+    ref = part[:, :L].sum(0)
+    o32 = torch.empty(L, device="cuda")
+    o64 = torch.empty(L, device="cuda", dtype=torch.float64)
+    p32 = dev(part)
+    ops.reduce_partials(p32, rows, L, out_f32=o32, out_f64=o64, row_stride=stride)
+    ref32 = p32.double().cpu()[:, :L].sum(0)
+    assert rel_l2(o64.cpu(), ref32) < 1e-14 and rel_l2(o32.cpu(), ref32) < 2e-7
+    ops.reduce_partials(p32, rows, L, out_f32=o32, row_stride=stride, scale=0.5, accumulate=True)
+    assert rel_l2(o32.cpu(), 1.5 * ref32) < 3e-7
