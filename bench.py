@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-dpot", action="store_true", help="skip the secondary DPOT-S measurement")
     ap.add_argument("--no-unet", action="store_true", help="skip the secondary U-Net measurements (cylinder YAML and C3 mesh)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage FNO rollout (BASELINE.json configs[4])")
+    ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from profiles/traffic_per_launch.json instead of measuring it "
+                    "now (default at N=1: two rocprofv3 --pmc request-size passes over tools/kbench.py cell_mix, --kernel-trace only, ~40 s)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -125,6 +127,45 @@ def cpu_baseline(timeout=480):
         return json.loads(lines[-1])
     return {"value": None, "unit": "samples/s", "cores": usable_cores(), "kind": "port",
             "sample": f"CPU oracle sample (configs[0], B=4) did not finish one part within {timeout} s"}
+
+
+def live_pmc_traffic(family):
+    """HBM bytes per launch of the cell_mix family from rocprofv3 request-size counters, collected as MI355X_MICROARCH.md prescribes:
+    separate --pmc passes with --kernel-trace only (read: 32 / 64 / 128 B requests, write: 64 B requests; FETCH_SIZE under-reports
+    128 B requests on gfx950), over tools/kbench.py at the bench's sizes (B = 32).  Family average over one step's launch mix
+    (3 x fwd + BN sums, 1 x layer 0, 3 x bwd + BN-backward sums).  Returns (bytes, source) or (None, None)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if family != "cell_mix" or not shutil.which("rocprofv3"):
+        return None, None
+    passes = {"rd": "TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B", "wr": "TCC_EA0_WRREQ_64B"}
+    size = {"TCC_EA0_RDREQ_32B": 32, "TCC_EA0_RDREQ_64B": 64, "TCC_EA0_RDREQ_128B": 128, "TCC_EA0_WRREQ_64B": 64}
+    per_kernel = {}
+    try:
+        for tag, counters in passes.items():
+            d = tempfile.mkdtemp(prefix=f"rpb_pmc_{tag}_", dir="/tmp")
+            subprocess.run(["rocprofv3", "--pmc", *counters.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                            sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "cell_mix"], cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=180, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            acc = {}
+            for r in csv.DictReader(open(files[0])):
+                if "cmx_kernel" in r["Kernel_Name"] and r["Counter_Name"] in size:
+                    k = (r["Kernel_Name"], r["Dispatch_Id"])
+                    acc[k] = acc.get(k, 0.0) + size[r["Counter_Name"]] * float(r["Counter_Value"])
+            for (kn, _), v in acc.items():
+                per_kernel.setdefault(kn, {}).setdefault(tag, []).append(v)
+            shutil.rmtree(d, ignore_errors=True)
+        tot = {kn: sum(sum(v) / len(v) for v in t.values()) for kn, t in per_kernel.items() if len(t) == 2}
+        pick = lambda sub: next(v for k, v in tot.items() if sub in k)
+        fam = (3 * pick("<1, false, false, false>") + pick("<1, false, true, false>") + 3 * pick("<2, false, false, false>")) / 7
+        return fam, "live: rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ_64B passes over tools/kbench.py cell_mix (this run)"
+    except Exception as e:                              # no counters on this box / profiler refused: fall back to the committed passes
+        print(f"[bench] --pmc failed ({type(e).__name__}: {e}); using profiles/traffic_per_launch.json", file=sys.stderr)
+        return None, None
 
 
 def _flush_c_stdio():
@@ -533,14 +574,17 @@ def main():
         ach_tf = dom["flops"] / dom["total_ms"] / 1e9
         per_launch = dom["bytes"] / dom["calls"]
         step_bytes = (6.238 * B + 4.03) * 1e9          # algorithmic bytes of one train step
-        traffic = traffic_src = None                    # HBM bytes per launch of the dominant family, from the committed
-        try:                                            # PMC request-size passes (bench.py cannot run rocprofv3 itself)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
-            if B == 32:
-                traffic = tj["bytes_per_launch"].get(dominant)
-                traffic_src = tj.get("source")
-        except Exception:
-            pass
+        traffic = traffic_src = None                    # HBM bytes per launch of the dominant family: measured now with --pmc
+        if not a.no_pmc and B == 32 and world == 1 and not force_dp:      # (two rocprofv3 counter passes over the kernel micro-benchmark) ...
+            traffic, traffic_src = live_pmc_traffic(dominant)
+        if traffic is None:                             # ... else from the committed passes of the same kernels
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
+                if B == 32:
+                    traffic = tj["bytes_per_launch"].get(dominant)
+                    traffic_src = tj.get("source")
+            except Exception:
+                pass
         line = {
             "metric": "train-step samples/sec (+ autoregressive rollout fields/sec in 'rollout'), FNO cylinder 128^2",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 ROOT=$(pwd)
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
-FNO="--no-bf16 --no-transolver --no-galerkin --no-unet --no-dpot --no-cpu-baseline"
+FNO="--no-pmc --no-bf16 --no-transolver --no-galerkin --no-unet --no-dpot --no-cpu-baseline"
 python bench.py $FNO --profile-all > /dev/null 2> gpurun_out/${TAG}_hip_event_kernel_table.txt
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$TAG && rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $ROOT/bench.py $FNO > /tmp/prof_$TAG.log 2>&1)
 DB=$(find /tmp/prof_$TAG -name "*_results.db" | head -1)
