@@ -129,12 +129,36 @@ def cpu_baseline(timeout=480):
             "sample": f"CPU oracle sample (configs[0], B=4) did not finish one part within {timeout} s"}
 
 
+PMC_REQUEST_BYTES = {"TCC_EA0_RDREQ_32B": 32, "TCC_EA0_RDREQ_64B": 64, "TCC_EA0_RDREQ_128B": 128, "TCC_EA0_WRREQ_64B": 64}
+
+
+def pmc_bytes_per_dispatch(csv_path, kernel_substring):
+    """{kernel name: mean over its dispatches of sum_counters request_size * count} from a rocprofv3 *_counter_collection.csv."""
+    import csv
+    acc = {}
+    for r in csv.DictReader(open(csv_path)):
+        if kernel_substring in r["Kernel_Name"] and r["Counter_Name"] in PMC_REQUEST_BYTES:
+            k = (r["Kernel_Name"], r["Dispatch_Id"])
+            acc[k] = acc.get(k, 0.0) + PMC_REQUEST_BYTES[r["Counter_Name"]] * float(r["Counter_Value"])
+    per = {}
+    for (kn, _), v in acc.items():
+        per.setdefault(kn, []).append(v)
+    return {kn: sum(v) / len(v) for kn, v in per.items()}
+
+
+def cell_mix_family_bytes(per_kernel):
+    """per_kernel: {kernel name: {"rd": bytes, "wr": bytes}} -> bytes per launch averaged over one train step's mix of the family:
+    3 x forward + BatchNorm sums, 1 x layer 0 on the feature fields, 3 x backward + BatchNorm-backward sums."""
+    tot = {kn: t["rd"] + t["wr"] for kn, t in per_kernel.items() if "rd" in t and "wr" in t}
+    pick = lambda sub: next(v for k, v in tot.items() if sub in k)
+    return (3 * pick("<1, false, false, false>") + pick("<1, false, true, false>") + 3 * pick("<2, false, false, false>")) / 7
+
+
 def live_pmc_traffic(family):
     """HBM bytes per launch of the cell_mix family from rocprofv3 request-size counters, collected as MI355X_MICROARCH.md prescribes:
     separate --pmc passes with --kernel-trace only (read: 32 / 64 / 128 B requests, write: 64 B requests; FETCH_SIZE under-reports
     128 B requests on gfx950), over tools/kbench.py at the bench's sizes (B = 32).  Family average over one step's launch mix
     (3 x fwd + BN sums, 1 x layer 0, 3 x bwd + BN-backward sums).  Returns (bytes, source) or (None, None)."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -142,7 +166,6 @@ def live_pmc_traffic(family):
     if family != "cell_mix" or not shutil.which("rocprofv3"):
         return None, None
     passes = {"rd": "TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B", "wr": "TCC_EA0_WRREQ_64B"}
-    size = {"TCC_EA0_RDREQ_32B": 32, "TCC_EA0_RDREQ_64B": 64, "TCC_EA0_RDREQ_128B": 128, "TCC_EA0_WRREQ_64B": 64}
     per_kernel = {}
     try:
         for tag, counters in passes.items():
@@ -151,18 +174,11 @@ def live_pmc_traffic(family):
                             sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "cell_mix"], cwd="/tmp",
                            env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=180, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            acc = {}
-            for r in csv.DictReader(open(files[0])):
-                if "cmx_kernel" in r["Kernel_Name"] and r["Counter_Name"] in size:
-                    k = (r["Kernel_Name"], r["Dispatch_Id"])
-                    acc[k] = acc.get(k, 0.0) + size[r["Counter_Name"]] * float(r["Counter_Value"])
-            for (kn, _), v in acc.items():
-                per_kernel.setdefault(kn, {}).setdefault(tag, []).append(v)
+            for kn, v in pmc_bytes_per_dispatch(files[0], "cmx_kernel").items():
+                per_kernel.setdefault(kn, {})[tag] = v
             shutil.rmtree(d, ignore_errors=True)
-        tot = {kn: sum(sum(v) / len(v) for v in t.values()) for kn, t in per_kernel.items() if len(t) == 2}
-        pick = lambda sub: next(v for k, v in tot.items() if sub in k)
-        fam = (3 * pick("<1, false, false, false>") + pick("<1, false, true, false>") + 3 * pick("<2, false, false, false>")) / 7
-        return fam, "live: rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ_64B passes over tools/kbench.py cell_mix (this run)"
+        return cell_mix_family_bytes(per_kernel), ("live: rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B} / TCC_EA0_WRREQ_64B passes over "
+                                                   "tools/kbench.py cell_mix (this run)")
     except Exception as e:                              # no counters on this box / profiler refused: fall back to the committed passes
         print(f"[bench] --pmc failed ({type(e).__name__}: {e}); using profiles/traffic_per_launch.json", file=sys.stderr)
         return None, None

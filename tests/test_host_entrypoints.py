@@ -123,3 +123,33 @@ def test_dpot_registry_state_dict_and_loud_limits():
         load_model([(torch.zeros(4, 20, 20, 2), torch.zeros(4, 20, 20, 2))], device="cpu", **cfg)
     with pytest.raises(NotImplementedError, match="DPOTNet3D"):
         load_model([(g["x"][0], g["y"][0])], device="cpu", **dict(cfg, model_type="dpot3d"))
+
+
+def test_bench_pmc_csv_to_family_traffic(tmp_path):
+    """bench.py's reading of rocprofv3 counter CSVs (roofline.traffic): bytes = request size x request count summed per dispatch, mean
+    over a kernel's dispatches, read + write passes combined, family average over one step's launch mix (3 x <1>, 1 x <1,feat>, 3 x <2>)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    names = {"f": "void cmx_kernel<1, false, false, false>(CmxArgs)", "l0": "void cmx_kernel<1, false, true, false>(CmxArgs)",
+             "b": "void cmx_kernel<2, false, false, false>(CmxArgs)", "x": "void other_kernel(Args)"}
+    def write(path, rows):
+        with open(path, "w") as fh:
+            fh.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+            for r in rows:
+                fh.write(",".join(str(v) if "," not in str(v) else f'"{v}"' for v in r) + "\n")
+    rd, wr = tmp_path / "rd.csv", tmp_path / "wr.csv"
+    write(rd, [(1, names["f"], "TCC_EA0_RDREQ_128B", 10), (1, names["f"], "TCC_EA0_RDREQ_64B", 2), (1, names["f"], "TCC_EA0_RDREQ", 12),
+               (2, names["f"], "TCC_EA0_RDREQ_128B", 14), (3, names["l0"], "TCC_EA0_RDREQ_32B", 8), (4, names["b"], "TCC_EA0_RDREQ_128B", 20),
+               (5, names["x"], "TCC_EA0_RDREQ_128B", 999)])
+    write(wr, [(1, names["f"], "TCC_EA0_WRREQ_64B", 4), (2, names["f"], "TCC_EA0_WRREQ_64B", 4), (3, names["l0"], "TCC_EA0_WRREQ_64B", 4),
+               (4, names["b"], "TCC_EA0_WRREQ_64B", 6), (4, names["b"], "TCC_EA0_WRREQ", 6)])
+    per = {}
+    for tag, path in (("rd", rd), ("wr", wr)):
+        for kn, v in bench.pmc_bytes_per_dispatch(str(path), "cmx_kernel").items():
+            per.setdefault(kn, {})[tag] = v
+    assert names["x"] not in per
+    f_bytes = ((10 * 128 + 2 * 64) + 14 * 128) / 2 + 4 * 64          # mean over the two dispatches + writes
+    assert per[names["f"]] == {"rd": ((10 * 128 + 2 * 64) + 14 * 128) / 2, "wr": 256.0}
+    fam = bench.cell_mix_family_bytes(per)
+    assert fam == pytest.approx((3 * f_bytes + (8 * 32 + 4 * 64) + 3 * (20 * 128 + 6 * 64)) / 7)
