@@ -172,7 +172,7 @@ def live_pmc_traffic(family):
             d = tempfile.mkdtemp(prefix=f"rpb_pmc_{tag}_", dir="/tmp")
             subprocess.run(["rocprofv3", "--pmc", *counters.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                             sys.executable, os.path.join(ROOT, "tools", "kbench.py"), "cell_mix"], cwd="/tmp",
-                           env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=180, check=True)
+                           env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=90, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             for kn, v in pmc_bytes_per_dispatch(files[0], "cmx_kernel").items():
                 per_kernel.setdefault(kn, {})[tag] = v
