@@ -36,6 +36,11 @@ def _rup(v, m):
     return (v + m - 1) // m * m
 
 
+def _out_cols(n):
+    """Padded width of the last per-pixel layer: 32 / 64 / 128 (the streaming weight-gradient kernel's widths) when it fits."""
+    return next((c for c in (32, 64, 128) if n <= c), _rup(n, 32))
+
+
 class _AFNO2D(nn.Module):
     """Parameter container of dpot.py:22-48 (same shapes and initial distribution)."""
 
@@ -383,7 +388,7 @@ class DPOT(_ModelBase):
         Vpre = new(Mp, OD) if training else None
         ops.gemm_nt(U, ol2.weight.data.view(OD, OD), V, Mp, OD, OD, bias=ol2.bias.data, act=1, pre_out=Vpre)
         NO = To * Co
-        NOp = _rup(NO, 32)
+        NOp = _out_cols(NO)
         W3p, b3p = torch.zeros(NOp, OD, **f), torch.zeros(NOp, **f)
         W3p[:NO] = ol4.weight.data.view(NO, OD)
         b3p[:NO] = ol4.bias.data
@@ -415,7 +420,7 @@ class DPOT(_ModelBase):
         Tr = lambda w: w.t().contiguous()
         nb, bs, hid, OD = self.n_blocks, E // self.n_blocks, self.hidden, self.out_layer_dim
         Mt, M1, Mp = B * n * n, B * n * n * T, B * n * n * ps * ps
-        NO, NOp, NU = To * Co, _rup(To * Co, 32), ps * ps * OD
+        NO, NOp, NU = To * Co, _out_cols(To * Co), ps * ps * OD
         Cdo = self.data_out_channels
         grads = {}
         ol0, ol2, ol4 = net.out_layer[0], net.out_layer[2], net.out_layer[4]
@@ -425,12 +430,12 @@ class DPOT(_ModelBase):
         # ---- out_layer
         gO = new(Mp, NOp)
         ops.dpot_unpatch_bwd(g_pred, gO, B, To, H, W, Cdo, Co, ps, NOp)
-        dW3, db3 = _wgrad(gO, sv["V"], Mp, NOp, OD)
+        dW3, db3 = self._wgrad_rows(gO, sv["V"], Mp, NOp, OD)
         grads[ol4.weight], grads[ol4.bias] = dW3[:NO].reshape(ol4.weight.shape).contiguous(), db3[:NO].contiguous()
         gV = new(Mp, OD)
         ops.gemm_nt(gO, Tr(sv["W3p"]), gV, Mp, OD, NOp, act=2, aux=sv["Vpre"])
         del gO
-        dW2, db2 = _wgrad(gV, sv["U"], Mp, OD, OD)
+        dW2, db2 = self._wgrad_rows(gV, sv["U"], Mp, OD)
         grads[ol2.weight], grads[ol2.bias] = dW2.reshape(ol2.weight.shape), db2
         gU = new(Mt, NU)
         ops.gemm_nt(gV, Tr(ol2.weight.data.view(OD, OD)), gU, Mp, OD, OD, act=2, aux=sv["Upre"])
@@ -533,6 +538,20 @@ class DPOT(_ModelBase):
         dW1, db1 = _wgrad(gH1, sv["P"], M1, E1, Kp, ldg=E1p, lda=Kp)
         grads[pe0.weight], grads[pe0.bias] = dW1.reshape(pe0.weight.shape), db1
         return grads
+
+    @staticmethod
+    def _wgrad_rows(G, A, M, CO, CI=None):
+        """(dW [CO][CI], db [CO]) = (G^T A, colsum G) for the per-pixel layers over M >> C rows: the streaming weight-gradient kernel of
+        the FNO path (both operands read once in MFMA layout) instead of the split-token TN GEMM, which is launch-bound at these widths."""
+        CI = CO if CI is None else CI
+        if (CO, CI) not in ((32, 32), (64, 64), (128, 128), (128, 32), (128, 64), (64, 32)):      # instances of csrc/rpb_cell.hip
+            return _wgrad(G, A, M, CO, CI)
+        slots = ops.cell_wgrad_slots(M, CO, CI)
+        part = torch.empty(slots, CO * CI + CO, device=G.device, dtype=torch.float32)
+        ops.cell_wgrad(G, A, part, M, CO, CI)
+        tot = torch.empty(CO * CI + CO, device=G.device, dtype=torch.float32)
+        ops.reduce_partials(part, slots, CO * CI + CO, out_f32=tot)
+        return tot[:CO * CI].view(CO, CI), tot[CO * CI:]
 
     @staticmethod
     def _sum_rows(part, rows, L):
