@@ -207,9 +207,10 @@ def test_arena_trainer_two_ranks_equal_single_rank(kind):
     x, y = torch.randn(4, *shape, generator=g), torch.randn(4, *shape, generator=g)
     losses = [float(tr.step(x.cuda(), y.cuda())) for _ in range(2)]
     assert torch.equal(res[0]["flat"], res[1]["flat"])
-    # first step: same weights on both sides -> tight; second step: after an Adam update that moved the (exactly-)zero-gradient
-    # elements by +-lr with a sharding-dependent sign (see below), so the two losses agree to ~1e-5..1e-4 only
-    for i, tol in enumerate((2e-5, 2e-4)):
+    # first step: same weights on both sides, but a 2-sample and a 4-sample batch take different tilings of the fp32-grade (split-bf16)
+    # convolution / GEMM kernels: the losses agree to the arithmetic's ~1e-5 (observed 1.9e-5 .. 2.4e-5 on the U-Net), not bit for bit;
+    # second step: after an Adam update that moved the (exactly-)zero-gradient elements by +-lr with a sharding-dependent sign (below)
+    for i, tol in enumerate((1e-4, 2e-4)):
         assert abs(0.5 * (res[0]["loss"][i] + res[1]["loss"][i]) - losses[i]) < tol * abs(losses[i])
     assert rel_l2(res[0]["grad"], tr.grad.cpu()) < 5e-4                       # second-step gradient, averaged over ranks
     # weights: Adam turns round-off on exactly-zero gradients (biases in front of GroupNorm / LayerNorm) into +-lr steps whose
