@@ -381,6 +381,23 @@ int rpb_proj_wgrad(const float* s, const float* w1, const float* b1, const float
                    int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd,
                    const float* xf_gamma, const float* xf_beta, int xf_gelu, int act, void* stream);
 
+/* ---- the whole backward of the projection head in ONE pass (round 3; fno.py:121-125 autograd + the BatchNorm-backward sums of the last
+ *      Fourier layer, fno.py:117; C = 64, DO <= 4, exact-GELU head after a BatchNorm without GELU):  csrc/rpb_pjf.hip.
+ *      rpb_head_bwd reads the PADDED pre-BatchNorm tensor s of the last layer (a = gamma * shat + beta, shat = (s - mean) * invstd on the
+ *      cropped cells) and gout [ncrop][DO]; writes g [ncell][64] = crop-scatter(gh fc1), gh = (fc2^T gout) * gelu'(fc1 a + b1) (zeros in
+ *      the pad margin) and per-wave partial rows part [rpb_head_bwd_slots][rpb_head_bwd_row(DO)] =
+ *      [128*64] M = gh^T shat | [DO*128] d fc2.weight | [128] d fc1.bias | [DO] d fc2.bias.  gh never reaches HBM.
+ *      rpb_head_bwd_finalize takes the row-reduced partials `tot` and writes d fc1.weight = gamma_c M + beta_c (d fc1.bias) [128][64],
+ *      d fc2.weight, d fc1.bias, d fc2.bias and bn_sums [2][64] = (sum_cells g, sum_cells g * shat) = (W1^T db1, sum_h W1 .* M). */
+int rpb_head_bwd_supported(int C, int DO, int W, int Wp, int xf_gelu, int act);
+long rpb_head_bwd_slots(int B, int T, int H);
+int rpb_head_bwd_row(int DO);
+int rpb_head_bwd(const float* s, const float* w1, const float* b1, const float* w2, const float* gout, float* g, float* part, int B,
+                 int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd,
+                 const float* xf_gamma, const float* xf_beta, void* stream);
+int rpb_head_bwd_finalize(const float* tot, const float* w1, const float* gamma, const float* beta, int DO, float* dw1, float* dw2,
+                          float* db1, float* db2, float* bn_sums, void* stream);
+
 /* ---- eval_metrics (realpdebench/utils/metrics.py:71-100): |F|^2 of the truncated spectrum corner accumulated by radial bin
  *      floor(sqrt(i^2+j^2+k^2)) < R.  Y [R][R][R][2][NB] (re, im planes; columns = (channel, sample)), out [R][NB].  The three
  *      truncated DFT stages in front of it are rpb_axis_gemm launches (realpdebench_amd/metrics.py). */

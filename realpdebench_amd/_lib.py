@@ -36,6 +36,11 @@ SIGNATURES = {
     "rpb_proj_wgrad_row": (_I, "i"),
     "rpb_proj_wgrad_roles": (_I, ""),
     "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
+    "rpb_head_bwd_supported": (_I, "iiiiii"),
+    "rpb_head_bwd_slots": (_L, "iii"),
+    "rpb_head_bwd_row": (_I, "i"),
+    "rpb_head_bwd": (_I, "ppppppp" + "ii" + "iiiiii" + "pppp" + "p"),
+    "rpb_head_bwd_finalize": (_I, "pppp" + "i" + "ppppp" + "p"),
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
     "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),
     "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),

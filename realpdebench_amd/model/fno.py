@@ -99,9 +99,18 @@ class _Workspace:
             ok = (C == 64 and type(model)._lift_fwd is FNO3d._lift_fwd and ops.proj_bwd_fused_supported(C, model.dim_out, d.W, d.Wp))
             self.proj_mode = None if not ok else ("recompute" if os.environ.get("RPB_PROJ_RECOMPUTE") == "1" else "gu")
             self.proj_fused = self.proj_mode == "recompute"
-            self.gu = None if self.proj_fused else torch.empty(d.ncrop, HID, **f)
+            # round 3: the whole head backward in one pass, gh never in HBM (csrc/rpb_pjf.hip); RPB_HEAD_BWD_FUSED=0 restores the chain
+            self.head_fused = (C == 64 and type(model)._lift_fwd is FNO3d._lift_fwd and
+                               ops.head_bwd_supported(C, model.dim_out, d.W, d.Wp, False, model.proj_act))
+            if self.head_fused:
+                self.proj_fused = False
+            self.gu = None if (self.proj_fused or self.head_fused) else torch.empty(d.ncrop, HID, **f)
             if ok:
                 self.pd_slots = ops.proj_dgrad_slots(d)
+            if self.head_fused:
+                self.hb_slots, self.hb_row = ops.head_bwd_slots(d), ops.head_bwd_row(model.dim_out)
+                self.hb_part = torch.empty(self.hb_slots * self.hb_row, **f)
+                self.hb_tot = torch.empty(self.hb_row, **f)
             if self.proj_fused:
                 self.pw_slots, self.pw_row, self.pw_roles = ops.proj_wgrad_slots(d), ops.proj_wgrad_row(model.dim_out), ops.proj_wgrad_roles()
                 self.pw_part = torch.empty(self.pw_slots * self.pw_row, **f)
@@ -466,7 +475,17 @@ class FNO3d(Model):
         # ---- projection
         a_last, xf_last = ws.S[L - 1], self._layer_xf(ws, L - 1, True)
         g, g2 = ws.G
-        if ws.proj_fused:
+        if ws.head_fused:
+            # one pass over (s, gout): g, and the partial rows of M = gh^T shat, d fc2, d fc1.bias, d fc2.bias; the finalize kernel
+            # derives d fc1.weight and the BatchNorm-backward sums of the last layer from them (csrc/rpb_pjf.hip)
+            w1 = P("fc1.weight")
+            ops.head_bwd(a_last, w1, P("fc1.bias"), P("fc2.weight"), gout, g, ws.hb_part, d, DO, xf_last)
+            ops.reduce_partials(ws.hb_part, ws.hb_slots, ws.hb_row, out_f32=ws.hb_tot)
+            ops.head_bwd_finalize(ws.hb_tot, w1, xf_last[2], xf_last[3], DO, GP("fc1.weight"), GP("fc2.weight"), GP("fc1.bias"),
+                                  GP("fc2.bias"), ws.bn_sums)
+            if self.dp is not None:
+                self.dp.bucket_ready(gflat)                      # fc1 / fc2 gradients are final: start their all-reduce
+        elif ws.proj_fused:
             # bf16 matrix pipe, no gu tensor: each kernel recomputes gh = (fc2^T gout) * act'(fc1 a + b1) in the operand
             # orientation it needs (csrc/rpb_pjx.hip).  wgrad first: its partials feed the first all-reduce bucket
             w1, b1, w2 = P("fc1.weight"), P("fc1.bias"), P("fc2.weight")

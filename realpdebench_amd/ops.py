@@ -676,6 +676,34 @@ def proj_wgrad(s, w1, b1, w2, gout, part, d, DO, xf, act=0):
               _stream(), label="proj_wgrad", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * 2 * d.C)
 
 
+def head_bwd_supported(C, DO, W, Wp, xf_gelu, act):
+    return bool(_lib.query("rpb_head_bwd_supported", C, DO, W, Wp, int(bool(xf_gelu)), int(act)))
+
+
+def head_bwd_slots(d):
+    return _lib.query("rpb_head_bwd_slots", d.B, d.T, d.H)
+
+
+def head_bwd_row(DO):
+    return _lib.query("rpb_head_bwd_row", DO)
+
+
+def head_bwd(s, w1, b1, w2, gout, g, part, d, DO, xf):
+    """The projection head's backward in one pass (csrc/rpb_pjf.hip): g [ncell][64] + per-wave partial rows
+    [M = gh^T shat | d fc2.weight | d fc1.bias | d fc2.bias]; gh never reaches HBM."""
+    mean, invstd, gamma, beta, gelu = xf
+    if gelu:
+        raise _lib.RpbError("head_bwd: the layer in front of the head must not end in GELU")
+    _lib.call("rpb_head_bwd", _p(s), _p(w1), _p(b1), _p(w2), _p(gout), _p(g), _p(part), d.B, DO, *d.crop6, _p(mean), _p(invstd),
+              _p(gamma), _p(beta), _stream(), label="head_bwd", nbytes=4 * (d.ncrop * (d.C + DO) + d.ncell * d.C),
+              flops=2 * d.ncrop * 128 * 3 * d.C)
+
+
+def head_bwd_finalize(tot, w1, gamma, beta, DO, dw1, dw2, db1, db2, bn_sums):
+    _lib.call("rpb_head_bwd_finalize", _p(tot), _p(w1), _p(gamma), _p(beta), DO, _p(dw1), _p(dw2), _p(db1), _p(db2), _p(bn_sums),
+              _stream(), label="head_bwd_finalize")
+
+
 def add(a, b):
     """a + b as a new tensor (HIP kernel; shapes equal, numel % 4 == 0 else torch adds the handful of numbers)."""
     if a.numel() % 4 or not a.is_cuda or a.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):

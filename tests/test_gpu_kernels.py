@@ -583,6 +583,52 @@ def test_projection_backward_without_gu(ops, B, T, H, W, pad, DO, gelu, act):
     assert rel_l2(db1, b1.grad) < 5e-6 and rel_l2(db2, b2.grad) < 5e-6
 
 
+@pytest.mark.parametrize("B,T,H,W,pad,DO", [(2, 3, 5, 32, 2, 2), (1, 2, 4, 48, 3, 1), (1, 2, 3, 40, 6, 3), (2, 2, 3, 128, 6, 2),
+                                             (1, 3, 2, 7, 6, 4), (5, 4, 7, 64, 6, 2)])
+def test_head_backward_one_pass(ops, B, T, H, W, pad, DO):
+    """rpb_head_bwd + rpb_head_bwd_finalize (csrc/rpb_pjf.hip: gh never in HBM, cells as MFMA rows, one LDS transposition for the data
+    gradient, BatchNorm-backward sums derived from M = gh^T shat) against fp64 autograd of fno.py:121-125 on the cropped cells:
+    gradient w.r.t. the padded layer output (zeros in the margin), the four parameter gradients and the BatchNorm-backward sums;
+    row lengths that are not a multiple of the 32-cell tile, more lines than waves, and fewer."""
+    torch.manual_seed(B * 100 + W + DO)
+    C = 64
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    assert ops.head_bwd_supported(C, DO, W, d.Wp, False, 0)
+    f8 = dict(dtype=torch.float64)
+    s = (torch.randn(d.ncell, C, **f8) * 1.2 + 0.2).requires_grad_(True)
+    mean, invstd = torch.randn(C, **f8) * 0.2, torch.rand(C, **f8) + 0.5
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    gamma[3], beta[5] = 0.0, 0.0                                    # the algebra behind d fc1 / the sums must not divide by gamma
+    w1 = (torch.randn(128, C, **f8) / 8).requires_grad_(True)
+    b1 = torch.randn(128, **f8).requires_grad_(True)
+    w2 = (torch.randn(DO, 128, **f8) / 11).requires_grad_(True)
+    b2 = torch.randn(DO, **f8).requires_grad_(True)
+    sh = (s - mean) * invstd
+    a_full = _xf_ref(s, mean, invstd, gamma, beta, False)
+    a = a_full.view(B, d.Tp, d.Hp, d.Wp, C)[:, :T, :H, :W].reshape(-1, C)
+    out = torch.nn.functional.gelu(a @ w1.t() + b1) @ w2.t() + b2
+    gout = torch.randn_like(out)
+    a_full.retain_grad()
+    out.backward(gout)
+    g_ref = a_full.grad                                   # gradient w.r.t. BN(s): zero in the pad margin
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), False)
+    g = torch.full((d.ncell, C), float("nan"), device="cuda")
+    slots, row = ops.head_bwd_slots(d), ops.head_bwd_row(DO)
+    part = torch.full((slots, row), float("nan"), device="cuda")
+    W1 = dev(w1.detach())
+    ops.head_bwd(dev(s.detach()), W1, dev(b1.detach()), dev(w2.detach()), dev(gout), g, part, d, DO, xf)
+    assert rel_l2(g.cpu(), g_ref) < 3e-6
+    assert torch.equal(g.view(B, d.Tp, d.Hp, d.Wp, C)[:, :, :, W:], torch.zeros(B, d.Tp, d.Hp, pad, C, device="cuda"))
+    tot = torch.empty(row, device="cuda")
+    ops.reduce_partials(part, slots, row, out_f32=tot)
+    dw1, dw2 = torch.empty(128, C, device="cuda"), torch.empty(DO, 128, device="cuda")
+    db1, db2, sums = torch.empty(128, device="cuda"), torch.empty(DO, device="cuda"), torch.empty(2, C, device="cuda")
+    ops.head_bwd_finalize(tot, W1, xf[2], xf[3], DO, dw1, dw2, db1, db2, sums)
+    assert rel_l2(dw1.cpu(), w1.grad) < 5e-6 and rel_l2(dw2.cpu(), w2.grad) < 5e-6
+    assert rel_l2(db1.cpu(), b1.grad) < 5e-6 and rel_l2(db2.cpu(), b2.grad) < 5e-6
+    assert rel_l2(sums[0].cpu(), g_ref.sum(0)) < 2e-5 and rel_l2(sums[1].cpu(), (g_ref * sh.detach()).sum(0)) < 2e-5
+
+
 @pytest.mark.parametrize("feat_w,Wp,K2f", [(0, 70, 32), (0, 134, 32), (8, 134, 32), (0, 45, 24), (32, 40, 16)])
 def test_eval_cell_mix_with_fused_forward_w_stage(ops, feat_w, Wp, K2f):
     """rpb_cell_mix_eval_dft == rpb_cell_mix (oxf) followed by rpb_axis_gemm along w of what it wrote (the rollout's fused stage):

@@ -158,6 +158,15 @@ if "proj" in which and ops.proj_bwd_fused_supported(C, 2, W, d.Wp):
     timeit("proj_wgrad (bf16 pipe, no gu)", lambda: ops.proj_wgrad(x, w1, b1, w2, gout, wp, d, 2, xfl),
            4 * d.ncrop * (C + 2), 2 * d.ncrop * 128 * 2 * C)
 
+if "proj" in which and ops.head_bwd_supported(C, 2, W, d.Wp, False, 0):
+    mean, invstd, gamma, beta = torch.zeros(C, **f), torch.ones(C, **f), torch.ones(C, **f), torch.zeros(C, **f)
+    xfl = (mean, invstd, gamma, beta, False)
+    gout = torch.randn(d.ncrop, 2, **f)
+    g = torch.empty(d.ncell, C, **f)
+    hp = torch.empty(ops.head_bwd_slots(d) * ops.head_bwd_row(2), **f)
+    timeit("head_bwd (one pass, gh never in HBM)", lambda: ops.head_bwd(x, w1, b1, w2, gout, g, hp, d, 2, xfl),
+           4 * (d.ncrop * (C + 2) + d.ncell * C), 2 * d.ncrop * 128 * 3 * C)
+
 if "lift" in which:
     xin = torch.randn(B, T, H, W, Cin, **f)
     grids = [torch.linspace(0, 1, n, **f) for n in (T, H, W)]
