@@ -34,7 +34,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU (weak scaling) / in total (--scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the headline): --batch trajectories on EVERY GPU; strong: --batch trajectories in total, "
+                         "--batch / N per GPU (SURVEY.md section 8d/e asks for both)")
+    ap.add_argument("--no-fno-native", action="store_true", help="skip the FNO3d line at the reference-native cylinder shape [32,20,64,128,3]")
     ap.add_argument("--rollout-steps", type=int, default=10, help="N_autoregressive of configs/cylinder/fno.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
@@ -46,8 +50,13 @@ def parse():
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage FNO rollout (BASELINE.json configs[4])")
     ap.add_argument("--no-pmc", action="store_true", help="take roofline.traffic from profiles/traffic_per_launch.json instead of measuring it "
                     "now (default at N=1: two rocprofv3 --pmc request-size passes over tools/kbench.py cell_mix, --kernel-trace only, ~40 s)")
+    ap.add_argument("--only-headline", action="store_true", help="the FNO train step only: no rollout, secondary models, PMC passes or CPU baseline")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.only_headline:
+        a.no_cpu_baseline = a.no_rollout = a.no_transolver = a.no_galerkin = a.no_dpot = a.no_unet = a.no_bf16 = a.no_pmc = True
+        a.no_fno_native = True
+    return a
 
 
 def self_launch(a):
@@ -376,6 +385,26 @@ def bench_transolver(dev, B=4, steps=3):
                        "1 layer, mlp_ratio 4, dropout 0.1, fp32", exact_line=True)
 
 
+def bench_transolver_c4(dev, B=8, steps=3):
+    """BASELINE.json configs[3]: Transolver at the foil-shaped 64 x 64 sample [B,20,64,64,3] -> mesh (64,64,20) (the H / W / D of the
+    reference's 64 x 64 trainsolver YAMLs), hidden 256, 8 heads, 16 slices, 1 layer, dropout 0.1; 81 920 tokens per sample."""
+    from realpdebench_amd.model.transolver import Transolver
+    x = torch.randn(B, 20, 64, 64, 3, device=dev)
+    y = torch.randn(B, 20, 64, 64, 3, device=dev)
+    r = bench_model(dev, lambda: Transolver(space_dim=3, n_layers=1, n_hidden=256, n_head=8, fun_dim=0, out_dim=3,
+                                            slice_num=16, mlp_ratio=4, H=64, W=64, D=20, dropout=0.1), x, y, 7e-4, steps,
+                    "Transolver C4 (foil-shaped): tokens 20x64x64 -> mesh (64,64,20), n_hidden 256, 8 heads, 16 slices, 1 layer, "
+                    "mlp_ratio 4, dropout 0.1, fp32 storage")
+    r["ms_per_sample"] = r["ms_per_step"] / B
+    # SURVEY.md section 8(d): 25.7 MFLOP per token and step, 81 920 tokens per sample, against the fp32 matrix pipe (the north star's
+    # roofline for this model) and against the split-bf16 pipe the convolutions and token GEMMs actually run on
+    fl = 25.7e6 * 81920 * B
+    r["flop_model"] = {"flops_per_step": fl, "achieved_TFLOPs": fl / r["ms_per_step"] / 1e9,
+                       "frac_of_f32_mfma_peak": fl / r["ms_per_step"] / 1e9 / MFMA_F32_PEAK_TF,
+                       "frac_of_split_bf16_peak": fl / r["ms_per_step"] / 1e9 / SPLIT_BF16_PEAK_TF}
+    return r
+
+
 def bench_rollout_bf16(dev):
     """BASELINE.json configs[4]: FNO3d on the 64^3 combustion volume, bf16 activation storage, 20 autoregressive steps."""
     try:
@@ -414,6 +443,87 @@ def bench_rollout_bf16(dev):
     m.set_storage("f32")
     del m
     torch.cuda.empty_cache()
+    return res
+
+
+def fno_step_bytes(B, T, H, W, Cin, Cout_r, width, L, modes, pad=6):
+    """algorithmic bytes of one FNO3d train step and of one eval forward."""
+    Tp, Hp, Wp = T + pad, H + pad, W + pad
+    n_in, n_out = B * T * H * W * Cin, B * T * H * W * Cout_r
+    n_u, n_p = B * width * T * H * W, B * width * Tp * Hp * Wp
+    M = 4 * modes[0] * modes[1] * modes[2]
+    wspec = width * width * M * 8
+    p_real = L * (2 * width * width * M + width * width + 3 * width) + width * (Cin + 3) + width + 128 * width + 128 + Cout_r * 128 + Cout_r
+    step = 4 * ((12 * L + 2) * n_p + 3 * n_u + n_in + 3 * n_out) + 3 * L * wspec + 28 * p_real
+    fwd = 4 * (n_in + n_out + (2 * L + 1) * n_p + n_u) + L * wspec
+    return float(step), float(fwd)
+
+
+def copy_ceiling(dev, n=14939392 * 64):
+    """The streaming ceiling of THIS chip for the read / write mixes of the FNO kernels, measured now with the library's plain
+    streaming kernel (csrc/rpb_probe.hip) on buffers of one activation tensor's size (3.82 GB): GB/s for 1, 2 and 3 tensors read + one
+    written.  A kernel that moves its algorithmic bytes exactly once cannot beat this rate, whatever the 8 TB/s datasheet says."""
+    from realpdebench_amd import ops
+    bufs = [torch.zeros(n, device=dev) for _ in range(4)]
+    res = {}
+    for nr in (1, 2, 3):
+        best = 0.0
+        for threads in (256, 512):
+            ops.stream_probe(bufs[0], bufs[1], bufs[2], bufs[3], nr, threads)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.stream_probe(bufs[0], bufs[1], bufs[2], bufs[3], nr, threads)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 5 * 4.0 * n * (nr + 1) / (e0.elapsed_time(e1) * 1e6))
+        res[f"r{nr}w1"] = best
+    del bufs
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_fno_native(dev, steps=5):
+    """FNO3d at the reference-native cylinder sample shape (realpdebench/configs/cylinder/fno.yaml with the released data:
+    [32,20,64,128,3] -> padded 26 x 70 x 134), same modes / width / depth: fused Trainer.step and the 10-step rollout."""
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.rollout import autoregressive_rollout
+    from realpdebench_amd.trainer import Trainer
+    shape, modes, width, L, B = (20, 64, 128, 3), (4, 12, 16), 64, 4, 32
+    torch.manual_seed(0)
+    m = FNO3d(*modes, L, width, shape, shape).to(dev)
+    tr = Trainer(m, lr=1e-4, num_update=4000)
+    x, y = torch.randn(B, *shape, device=dev), torch.randn(B, *shape, device=dev)
+    for _ in range(2):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(x, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    step_b, fwd_b = fno_step_bytes(B, *shape, shape[-1], width, L, modes)
+    res = {"train_samples_per_s": B / dt, "ms_per_step": 1e3 * dt, "batch": B,
+           "roofline": {"bound": "hbm", "algorithmic_bytes": step_b, "achieved": step_b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": step_b / dt / 1e9 / HBM_PEAK_GBS},
+           "config": "FNO3d [32,20,64,128,3] -> padded 26x70x134, modes (4,12,16), width 64, 4 layers (the reference's cylinder sample shape)"}
+    del tr
+    m._ws = {}
+    torch.cuda.empty_cache()
+    n_ar = 10
+    autoregressive_rollout(m, x, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    autoregressive_rollout(m, x, n_ar)
+    torch.cuda.synchronize()
+    rt = (time.perf_counter() - t0) / n_ar
+    res["rollout"] = {"value": B * shape[0] / rt, "unit": "fields/s", "ms_per_forward": 1e3 * rt, "n_autoregressive": n_ar,
+                      "roofline": {"bound": "hbm", "algorithmic_bytes_per_forward": fwd_b, "achieved": fwd_b / rt / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fwd_b / rt / 1e9 / HBM_PEAK_GBS}}
+    del m
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     return res
 
 
@@ -483,8 +593,18 @@ def main():
         from realpdebench_amd.dp import DataParallel
         DataParallel(model)
     trainer = Trainer(model, lr=1e-4, num_update=4000, scheduler="cosine")
-    B = a.batch
-    x, y = (t.to(dev) for t in bench_batch(B, rank=rank, shape=shape))     # seeded N(0,1), identical on every host
+    if a.scaling == "strong":
+        if a.batch % world:
+            raise SystemExit(f"bench.py --scaling strong: --batch {a.batch} is not divisible by {world} ranks")
+        B = a.batch // world                             # fixed GLOBAL batch: every rank takes its share
+    else:
+        B = a.batch
+    if a.scaling == "strong" and world > 1:
+        # the SAME global batch as the single-rank run of --batch (seeds of rank 0), cut into per-rank slices: with SyncBN and the
+        # 1/N_global loss scale the N-rank step IS the 1-rank step on that batch (tests/test_gpu_dp.py checks the bench line for it)
+        x, y = (t[rank * B:(rank + 1) * B].contiguous().to(dev) for t in bench_batch(a.batch, rank=0, shape=shape))
+    else:
+        x, y = (t.to(dev) for t in bench_batch(B, rank=rank, shape=shape))     # seeded N(0,1), identical on every host
 
     def barrier():
         torch.cuda.synchronize()
@@ -500,6 +620,11 @@ def main():
         if i == 0:
             first_loss = float(l_)
     torch.cuda.synchronize()
+    first_loss_global = first_loss
+    if world > 1:                                        # mean over ranks of the local means = the global batch's loss
+        t = torch.tensor([first_loss], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        first_loss_global = float(t) / world
     warm = _lib.profile_summary()
     fam_warm = by_family(warm)
     dominant = max(fam_warm, key=lambda k: fam_warm[k]["total_ms"])
@@ -545,6 +670,37 @@ def main():
     ms_per_step = 1e3 * dt / a.steps
     value = B * world * a.steps / dt
 
+    # ---- N > 1: one more step with the collective instrumented (per-bucket schedule on the side stream, how long Adam waited for the
+    #      last bucket, cost of the inline SyncBN reductions) -- outside the timed region
+    dp_info = None
+    if (world > 1 or force_dp) and model.dp is not None:
+        comm = getattr(model.dp, "comm", None)
+        dp_info = {"ranks_in_process_group": dist.get_world_size(), "backend": backend,
+                   "transport": "C-ABI rpb_dp_* (RCCL, side HIP stream, two communicators)" if comm is not None else f"torch.distributed {backend}",
+                   "buckets_MB": [4e-6 * (e - s_) for s_, e in model.dp.buckets]}
+        if comm is not None:
+            comm.set_timing(True)
+            trainer.step(x, y)
+            torch.cuda.synchronize()
+            try:
+                tms = comm.step_times()
+                dp_info.update(exposed_comm_ms=tms["exposed_ms"], first_announce_to_last_done_ms=tms["first_announce_to_last_done_ms"],
+                               bucket_schedule=tms["buckets"], syncbn_inline_reductions=len(tms["inline_ms"]),
+                               syncbn_inline_ms_total=sum(tms["inline_ms"]), syncbn_inline_ms_max=max(tms["inline_ms"] or [0.0]))
+            except Exception as e:                          # instrumentation must never cost the bench line
+                dp_info["timing_error"] = repr(e)
+            comm.set_timing(False)
+
+    # ---- the chip's streaming ceiling for the kernels' read / write mixes, measured now (rank 0)
+    ceiling = None
+    if rank == 0 and B * world >= 1:
+        try:
+            free_b = torch.cuda.mem_get_info()[0]
+            if free_b > 20e9:
+                ceiling = copy_ceiling(dev)
+        except Exception as e:
+            print(f"[bench] copy-ceiling probe failed: {e!r}", file=sys.stderr)
+
     # ---- rollout metric (eval.py:311-321), replicas: no collective
     rollout = None
     if not a.no_rollout:
@@ -572,7 +728,8 @@ def main():
     if world == 1:
         model = None
         torch.cuda.empty_cache()
-        for name, fn, flag in (("rollout_bf16", bench_rollout_bf16, a.no_bf16), ("transolver", bench_transolver, a.no_transolver),
+        for name, fn, flag in (("fno_native", bench_fno_native, a.no_fno_native), ("rollout_bf16", bench_rollout_bf16, a.no_bf16),
+                               ("transolver", bench_transolver, a.no_transolver), ("transolver_c4", bench_transolver_c4, a.no_transolver),
                                ("galerkin_transformer", bench_galerkin, a.no_galerkin), ("dpot_s", bench_dpot, a.no_dpot),
                                ("unet", bench_unet, a.no_unet),
                                ("unet_c3", bench_unet_c3, a.no_unet)):
@@ -583,6 +740,8 @@ def main():
         torch.cuda.synchronize()
         _flush_c_stdio()                                    # every rank empties its C stdio buffer (RCCL banner) ...
         dist.barrier()                                      # ... before rank 0 goes on to print the JSON line
+        if model is not None and getattr(model, "dp", None) is not None:
+            model.dp.close()                                # RCCL communicators go before the process group does
         dist.destroy_process_group()
 
     if rank == 0:
@@ -604,17 +763,20 @@ def main():
         line = {
             "metric": "train-step samples/sec (+ autoregressive rollout fields/sec in 'rollout'), FNO cylinder 128^2",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "dtype": "f32 storage / split-bf16x3 MFMA contractions (six bf16 products per fp32 product, fp32 accumulate), fp32-grade",
+            "data": "synthetic",
             "config": {"workload": "FNO3d train step (fwd+MSE+bwd+Adam+cosine), cylinder-shaped [B,20,128,128,2] "
                                    "-> padded 26x134x134, modes (4,12,16), width 64, 4 layers (BASELINE.json configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world,
+                       "batch_per_gpu": B, "global_batch": B * world, "scaling": a.scaling,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "collective": (f"{'RCCL' if backend == 'nccl' else backend} all-reduce, {rccl_ranks} rank(s)"
                                       if backend else None)},
             "roofline": {"bound": "hbm", "kernel": dominant + " (all template variants, aggregated)",
                          "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "PMC request-size bytes per launch of the same kernels at the same sizes, collected over the "
+                                         "kernel micro-benchmark tools/kbench.py (not inside the timed step)",
                          "avg_launch_ms": dom["total_ms"] / dom["calls"], "launches_timed": dom["calls"],
                          "launches_per_step": dom["calls"] / a.steps,
                          "family_ms_per_step": dom["total_ms"] / a.steps,
@@ -628,8 +790,30 @@ def main():
                                         "frac": step_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS}},
             "rollout": rollout,
             "loss": float(loss),
+            "first_step_loss": first_loss_global,
             "loss_check": loss_check,
         }
+        if ceiling:
+            # which mix each cell_mix variant streams: forward = 1 read + 1 write (+ the small z2 rows), backward with the BatchNorm
+            # sums = 2 reads + 1 write; the family figure weights them by time
+            best = max(ceiling.values())
+            fam_floor = sum(v["algorithmic_bytes_per_launch"] * v["launches"] / a.steps /
+                            ceiling["r2w1" if "stats=2" in k else "r1w1"] / 1e6 for k, v in dom["variants"].items())
+            kern_floor = sum(v["bytes"] * v["calls"] / max(a.warmup, 1) for v in warm.values()) / best / 1e6
+            line["roofline"].update(
+                copy_ceiling={"GBps": ceiling, "frac_of_peak": {k: v / HBM_PEAK_GBS for k, v in ceiling.items()},
+                              "how": "csrc/rpb_probe.hip: plain streaming kernel, 3.82 GB tensors, 16 B per lane, best of 256 / 512 threads; "
+                                     "measured in this run after the timed region"},
+                frac_of_copy_ceiling=fam_floor / (dom["total_ms"] / a.steps),
+                floor_ms={"dominant_family_at_copy_ceiling": fam_floor,
+                          "whole_step_kernels_at_copy_ceiling": kern_floor,
+                          "whole_step_survey_byte_model_at_copy_ceiling": step_bytes / best / 1e6,
+                          "note": "a step that moved every algorithmic byte exactly once at the rate a plain copy reaches on this chip; "
+                                  "kernels = sum over this step's launches of their own algorithmic bytes (layer-0 algebra and the fused "
+                                  "head move fewer bytes than SURVEY's model)"})
+            line["roofline"]["whole_step"]["frac_of_copy_ceiling"] = step_bytes / (ms_per_step * 1e6) / best
+        if dp_info:
+            line["dp"] = dp_info
         line.update(extra)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -398,6 +398,10 @@ int rpb_head_bwd(const float* s, const float* w1, const float* b1, const float* 
 int rpb_head_bwd_finalize(const float* tot, const float* w1, const float* gamma, const float* beta, int DO, float* dw1, float* dw2,
                           float* db1, float* db2, float* bn_sums, void* stream);
 
+/* ---- measurement aid (bench.py roofline.copy_ceiling; not on the model path): out = a (* b (+ c)) over n floats, `nread` tensors read
+ *      once + one written once with 16 B per lane -- the streaming ceiling of the chip for the read / write mix of the FNO kernels. */
+int rpb_stream_probe(const float* a, const float* b, const float* c, float* out, long n, int nread, int threads, void* stream);
+
 /* ---- eval_metrics (realpdebench/utils/metrics.py:71-100): |F|^2 of the truncated spectrum corner accumulated by radial bin
  *      floor(sqrt(i^2+j^2+k^2)) < R.  Y [R][R][R][2][NB] (re, im planes; columns = (channel, sample)), out [R][NB].  The three
  *      truncated DFT stages in front of it are rpb_axis_gemm launches (realpdebench_amd/metrics.py). */
@@ -431,6 +435,12 @@ int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int dtype, voi
 int rpb_dp_allreduce_wait(void* handle, void* consumer_stream);
 int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream);
 int rpb_dp_allreduce_destroy(void* handle);
+/*      Instrumentation (the N > 1 bench line): rpb_dp_set_timing(h, 1) brackets every bucket / inline reduction with timing events and
+ *      restarts the records; after a device synchronisation rpb_dp_step_times fills out[] = { nb, ni, exposed ms (how long after the
+ *      consumer stream reached rpb_dp_allreduce_wait the last bucket finished), ms from the first announcement to the last bucket's end,
+ *      nb x (start ms since the first announcement, duration ms, bytes), ni x inline duration ms } and returns the count. */
+int rpb_dp_set_timing(void* handle, int on);
+int rpb_dp_step_times(void* handle, float* out, int max_out);
 
 /* ---- rollout: eval cell_mix (output = act(BatchNorm(.)) of THIS layer, as rpb_cell_mix with oxf_* / rpb_cell_mix_feat) with the NEXT
  *      layer's forward W stage fused in: y1 [ncell / Wp][K2f][64] = sum_w FWt[w][k] out[line, w][c], i.e. what

@@ -36,6 +36,7 @@ SIGNATURES = {
     "rpb_proj_wgrad_row": (_I, "i"),
     "rpb_proj_wgrad_roles": (_I, ""),
     "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
+    "rpb_stream_probe": (_I, "pppp" + "l" + "ii" + "p"),
     "rpb_head_bwd_supported": (_I, "iiiiii"),
     "rpb_head_bwd_slots": (_L, "iii"),
     "rpb_head_bwd_row": (_I, "i"),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "rpb_dp_allreduce_wait": (_I, "pp"),
     "rpb_dp_allreduce_inline": (_I, "pplip"),
     "rpb_dp_allreduce_destroy": (_I, "p"),
+    "rpb_dp_set_timing": (_I, "pi"),
+    "rpb_dp_step_times": (_I, "ppi"),
     "rpb_lift_bwd_rows": (_I, ""),
     "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "ppppi" + "p"),

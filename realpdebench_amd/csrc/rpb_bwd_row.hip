@@ -14,6 +14,9 @@
 // double-buffered in registers 4 MFMA steps (8 cells) ahead through SRSRC descriptors (per-row bounds: the pad
 // steps of the last chunk read zeros and their stores are dropped by the hardware).
 #include "rpb_common.h"
+#ifndef RPB_STREAM_AUX
+#define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (experiment switch) */
+#endif
 #include <stdlib.h>
 
 template <int N>
@@ -31,13 +34,13 @@ struct RowVec<2> {
 
 template <int NT>
 __device__ __forceinline__ typename RowVec<NT>::T row_load(rsrc_t r, int voff, int soff) {
-    if constexpr (NT == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-    else return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    if constexpr (NT == 1) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, RPB_STREAM_AUX));
+    else return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, RPB_STREAM_AUX));
 }
 template <int NT>
 __device__ __forceinline__ void row_store(typename RowVec<NT>::T v, rsrc_t r, int voff, int soff) {
-    if constexpr (NT == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(typename RowVec<2>::U, v), r, voff, soff, 0);
+    if constexpr (NT == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, RPB_STREAM_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(typename RowVec<2>::U, v), r, voff, soff, RPB_STREAM_AUX);
 }
 template <int NT>
 __device__ __forceinline__ float rget(const typename RowVec<NT>::T& v, int i) {

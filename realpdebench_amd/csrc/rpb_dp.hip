@@ -59,12 +59,20 @@ Rccl* rccl() {
     return (r.lib && r.get_uid && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
 }
 
+#define DP_MAX_TIMED 32
 struct DpHandle {
     nccl_comm_t comm;
     hipStream_t side;
     hipEvent_t ready, done;
     int rank, world;
     long enqueued;
+    // optional instrumentation (rpb_dp_set_timing): per-bucket start / end events on the side stream, the moment the consumer
+    // stream reaches its wait, and start / end of every inline reduction since the last rpb_dp_allreduce_wait
+    int timing, events_made;
+    int nb, ni;
+    hipEvent_t b0[DP_MAX_TIMED], b1[DP_MAX_TIMED], i0[DP_MAX_TIMED], i1[DP_MAX_TIMED], cwait, first;
+    long bbytes[DP_MAX_TIMED];
+    int have_wait;
 };
 
 const int kNcclSum = 0, kNcclF32 = 7, kNcclF64 = 8;
@@ -101,6 +109,8 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
     h->rank = rank;
     h->world = world;
     h->enqueued = 0;
+    h->timing = h->events_made = 0;
+    h->nb = h->ni = h->have_wait = 0;
     nccl_uid_t id;
     memcpy(&id, id128, sizeof(id));
     int rc = R->init_rank(&h->comm, world, id, rank);
@@ -121,9 +131,23 @@ extern "C" int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int
     RPB_REQUIRE(handle && buf && count > 0 && dp_dtype(dtype) >= 0, "dp_allreduce_enqueue: bad arguments");
     Rccl* R = rccl();
     DpHandle* h = (DpHandle*)handle;
+    if (h->timing && h->have_wait) {                     // first bucket of a new step: forget the previous step's records
+        h->nb = h->ni = 0;
+        h->have_wait = 0;
+    }
     RPB_HIP(hipEventRecord(h->ready, (hipStream_t)producer_stream), "dp record");
     RPB_HIP(hipStreamWaitEvent(h->side, h->ready, 0), "dp wait");
+    const bool timed = h->timing && h->nb < DP_MAX_TIMED;
+    if (timed) {
+        if (h->nb == 0) RPB_HIP(hipEventRecord(h->first, (hipStream_t)producer_stream), "dp record");
+        RPB_HIP(hipEventRecord(h->b0[h->nb], h->side), "dp record");
+    }
     RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, h->side), "ncclAllReduce");
+    if (timed) {
+        RPB_HIP(hipEventRecord(h->b1[h->nb], h->side), "dp record");
+        h->bbytes[h->nb] = count * (dtype == 0 ? 4 : 8);
+        h->nb++;
+    }
     h->enqueued++;
     return RPB_OK;
 }
@@ -131,6 +155,10 @@ extern "C" int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int
 extern "C" int rpb_dp_allreduce_wait(void* handle, void* consumer_stream) {
     RPB_REQUIRE(handle, "dp_allreduce_wait: null handle");
     DpHandle* h = (DpHandle*)handle;
+    if (h->timing) {
+        RPB_HIP(hipEventRecord(h->cwait, (hipStream_t)consumer_stream), "dp record");
+        h->have_wait = 1;
+    }
     RPB_HIP(hipEventRecord(h->done, h->side), "dp record");
     RPB_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, h->done, 0), "dp wait");
     return RPB_OK;
@@ -140,8 +168,61 @@ extern "C" int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int 
     RPB_REQUIRE(handle && buf && count > 0 && dp_dtype(dtype) >= 0, "dp_allreduce_inline: bad arguments");
     Rccl* R = rccl();
     DpHandle* h = (DpHandle*)handle;
+    const bool timed = h->timing && h->ni < DP_MAX_TIMED;
+    if (timed) RPB_HIP(hipEventRecord(h->i0[h->ni], (hipStream_t)stream), "dp record");
     RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, (hipStream_t)stream), "ncclAllReduce");
+    if (timed) {
+        RPB_HIP(hipEventRecord(h->i1[h->ni], (hipStream_t)stream), "dp record");
+        h->ni++;
+    }
     return RPB_OK;
+}
+
+// Instrumentation for the N > 1 bench line.  on = 1: every bucket / inline reduction from now on is bracketed by timing events.
+extern "C" int rpb_dp_set_timing(void* handle, int on) {
+    RPB_REQUIRE(handle, "dp_set_timing: null handle");
+    DpHandle* h = (DpHandle*)handle;
+    if (on && !h->events_made) {
+        for (int i = 0; i < DP_MAX_TIMED; ++i) {
+            RPB_HIP(hipEventCreate(&h->b0[i]), "dp event");
+            RPB_HIP(hipEventCreate(&h->b1[i]), "dp event");
+            RPB_HIP(hipEventCreate(&h->i0[i]), "dp event");
+            RPB_HIP(hipEventCreate(&h->i1[i]), "dp event");
+        }
+        RPB_HIP(hipEventCreate(&h->cwait), "dp event");
+        RPB_HIP(hipEventCreate(&h->first), "dp event");
+        h->events_made = 1;
+    }
+    h->timing = on ? 1 : 0;
+    h->nb = h->ni = h->have_wait = 0;                    // (re)start the records
+    return RPB_OK;
+}
+
+// Times of the step that ended with the last rpb_dp_allreduce_wait (call after synchronising the device).  out[0] = number of
+// buckets nb, out[1] = number of inline reductions ni, out[2] = exposed milliseconds (how long after the consumer stream reached its
+// wait the last bucket finished; 0 when the reduction was fully hidden), out[3] = milliseconds from the first bucket's
+// announcement to the end of the last bucket, then nb triples (start since the first announcement, duration, bytes) and ni inline
+// durations.  Returns the number of floats written, or a negative status.
+extern "C" int rpb_dp_step_times(void* handle, float* out, int max_out) {
+    RPB_REQUIRE(handle && out && max_out >= 4, "dp_step_times: bad arguments");
+    DpHandle* h = (DpHandle*)handle;
+    const int nb = h->nb, ni = h->ni;
+    RPB_REQUIRE(4 + 3 * nb + ni <= max_out, "dp_step_times: need %d floats", 4 + 3 * nb + ni);
+    out[0] = (float)nb;
+    out[1] = (float)ni;
+    out[2] = out[3] = 0.f;
+    float ms = 0.f;
+    if (nb > 0 && h->have_wait) {
+        if (hipEventElapsedTime(&ms, h->cwait, h->b1[nb - 1]) == hipSuccess) out[2] = ms > 0.f ? ms : 0.f;
+        if (hipEventElapsedTime(&ms, h->first, h->b1[nb - 1]) == hipSuccess) out[3] = ms;
+    }
+    for (int i = 0; i < nb; ++i) {
+        out[4 + 3 * i] = hipEventElapsedTime(&ms, h->first, h->b0[i]) == hipSuccess ? ms : -1.f;
+        out[5 + 3 * i] = hipEventElapsedTime(&ms, h->b0[i], h->b1[i]) == hipSuccess ? ms : -1.f;
+        out[6 + 3 * i] = (float)h->bbytes[i];
+    }
+    for (int i = 0; i < ni; ++i) out[4 + 3 * nb + i] = hipEventElapsedTime(&ms, h->i0[i], h->i1[i]) == hipSuccess ? ms : -1.f;
+    return 4 + 3 * nb + ni;
 }
 
 extern "C" int rpb_dp_allreduce_destroy(void* handle) {
@@ -152,6 +233,16 @@ extern "C" int rpb_dp_allreduce_destroy(void* handle) {
     if (R) (void)R->destroy(h->comm);
     (void)hipEventDestroy(h->ready);
     (void)hipEventDestroy(h->done);
+    if (h->events_made) {
+        for (int i = 0; i < DP_MAX_TIMED; ++i) {
+            (void)hipEventDestroy(h->b0[i]);
+            (void)hipEventDestroy(h->b1[i]);
+            (void)hipEventDestroy(h->i0[i]);
+            (void)hipEventDestroy(h->i1[i]);
+        }
+        (void)hipEventDestroy(h->cwait);
+        (void)hipEventDestroy(h->first);
+    }
     (void)hipStreamDestroy(h->side);
     delete h;
     return RPB_OK;

@@ -14,24 +14,51 @@ The reference has no distributed path at all (single process, realpdebench/train
 
 Everything here works on CPU tensors with the gloo backend too (tests/test_dp_gloo.py).
 """
+import atexit
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
+
+_LIVE_COMMS = weakref.WeakSet()
+
+
+def _close_all():
+    for c in list(_LIVE_COMMS):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 class RcclComm:
     """The C-ABI collective (include/rpb.h ``rpb_dp_*``: RCCL all-reduce on a side HIP stream) for CUDA tensors.
 
-    ``torch.distributed`` is only the launcher's rendezvous here: it carries the 128-byte RCCL unique id from rank 0 to the
-    others; the gradient traffic itself goes librpb_hip.so -> librccl.so -> xGMI."""
+    ``torch.distributed`` is only the launcher's rendezvous here: it carries the 128-byte RCCL unique ids from rank 0 to the
+    others; the gradient traffic itself goes librpb_hip.so -> librccl.so -> xGMI.
+
+    TWO communicators: ``handle`` carries the gradient buckets on the side stream, ``small`` the few-hundred-byte SyncBN
+    statistics on the compute stream.  RCCL serialises the operations of ONE communicator, so with a single one every
+    statistics reduction of the backward pass queued behind the ~100 MB bucket still in flight and the overlap was lost
+    (round-2 advisor finding); operations on the two communicators are issued in the same order on every rank (same program),
+    which is what RCCL requires of concurrent communicators."""
 
     def __init__(self, process_group=None):
         from . import _lib
         self._lib = _lib
-        lib = _lib.load()
+        _lib.load()
         self.rank, self.world_size = dist.get_rank(process_group), dist.get_world_size(process_group)
+        self.handle = self._init_comm(process_group)
+        self.small = self._init_comm(process_group) if os.environ.get("RPB_DP_ONE_COMM") != "1" else self.handle
+        _LIVE_COMMS.add(self)
+
+    def _init_comm(self, process_group):
+        _lib = self._lib
         buf = (ctypes.c_char * 128)()
         if self.rank == 0:
             _lib.call("rpb_dp_unique_id", ctypes.addressof(buf))
@@ -40,8 +67,7 @@ class RcclComm:
         idbuf = (ctypes.c_char * 128).from_buffer_copy(box[0])
         h = ctypes.c_void_p()
         _lib.call("rpb_dp_allreduce_init", ctypes.addressof(idbuf), self.rank, self.world_size, ctypes.addressof(h))
-        self.handle = h.value
-        self._lib_obj = lib
+        return h.value
 
     @staticmethod
     def _dtype(t):
@@ -62,19 +88,45 @@ class RcclComm:
 
     def inline(self, t):
         assert t.is_cuda and t.is_contiguous()
-        self._lib.call("rpb_dp_allreduce_inline", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
+        self._lib.call("rpb_dp_allreduce_inline", self.small, t.data_ptr(), t.numel(), self._dtype(t),
                        torch.cuda.current_stream().cuda_stream)
 
     def close(self):
+        """Destroy the communicators (trainer teardown / interpreter exit; idempotent)."""
         if self.handle:
+            if self.small and self.small != self.handle:
+                self._lib.call("rpb_dp_allreduce_destroy", self.small)
             self._lib.call("rpb_dp_allreduce_destroy", self.handle)
-            self.handle = None
+            self.handle = self.small = None
+        _LIVE_COMMS.discard(self)
+
+    # ---- instrumentation (bench.py N > 1 line)
+    def set_timing(self, on=True):
+        for h in {self.handle, self.small}:
+            self._lib.call("rpb_dp_set_timing", h, int(on))
+
+    def step_times(self):
+        """After ``torch.cuda.synchronize()``: the last step's bucket schedule and the inline (SyncBN) reduction costs."""
+        def read(h):
+            out = (ctypes.c_float * 256)()
+            n = self._lib.load().rpb_dp_step_times(h, ctypes.addressof(out), 256)
+            if n < 0:
+                raise self._lib.RpbError("rpb_dp_step_times failed")
+            return list(out[:n])
+        b = read(self.handle)
+        nb = int(b[0])
+        res = {"buckets": [{"start_ms": b[4 + 3 * i], "ms": b[5 + 3 * i], "MB": b[6 + 3 * i] / 1e6} for i in range(nb)],
+               "exposed_ms": b[2], "first_announce_to_last_done_ms": b[3]}
+        s = read(self.small)
+        ni, off = int(s[1]), 4 + 3 * int(s[0])
+        res["inline_ms"] = s[off:off + ni]
+        return res
 
 
-def use_rccl_abi(t=None):
-    """The C-ABI RCCL path serves CUDA tensors under the nccl backend; gloo groups (CPU tests, ranks sharing one GPU) and
-    RPB_DP_TORCH=1 keep ``torch.distributed`` collectives."""
-    if os.environ.get("RPB_DP_TORCH") == "1" or not dist.is_initialized() or dist.get_backend() != "nccl":
+def use_rccl_abi(t=None, process_group=None):
+    """The C-ABI RCCL path serves CUDA tensors under the nccl backend of ``process_group`` (default group when None); gloo groups
+    (CPU tests, ranks sharing one GPU) and RPB_DP_TORCH=1 keep ``torch.distributed`` collectives."""
+    if os.environ.get("RPB_DP_TORCH") == "1" or not dist.is_initialized() or dist.get_backend(process_group) != "nccl":
         return False
     if t is not None and not t.is_cuda:
         return False
@@ -133,7 +185,7 @@ class DataParallel:
         self.buckets = layer_buckets(model._seg, model.n_layers, model.flat.numel())
         self._works = []
         self._next = 0
-        self.comm = RcclComm(process_group) if use_rccl_abi(model.flat) else None      # C-ABI RCCL on a side stream
+        self.comm = RcclComm(process_group) if use_rccl_abi(model.flat, process_group) else None      # C-ABI RCCL on a side stream
         model.dp = self
         self.sync_parameters()
 
@@ -171,6 +223,14 @@ class DataParallel:
         for w in self._works:
             w.wait()
         self._works = []
+
+    def close(self):
+        """Trainer teardown: destroy the RCCL communicators (also done at interpreter exit)."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+        if getattr(self.model, "dp", None) is self:
+            self.model.dp = None
 
     # ---- sharding of a global batch / dataset index (replaces shuffle=True of train.py:269 under DP)
     def shard(self, n_items):

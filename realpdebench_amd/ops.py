@@ -676,6 +676,12 @@ def proj_wgrad(s, w1, b1, w2, gout, part, d, DO, xf, act=0):
               _stream(), label="proj_wgrad", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * 2 * d.C)
 
 
+def stream_probe(a, b, c, out, nread, threads=256):
+    """Measurement aid (bench.py): out = a (* b (+ c)), ``nread`` tensors read + one written, 16 B per lane."""
+    _lib.call("rpb_stream_probe", _p(a), _p(b), _p(c), _p(out), a.numel(), nread, threads, _stream(), label=f"stream_probe[R{nread}W1]",
+              nbytes=4 * a.numel() * (nread + 1))
+
+
 def head_bwd_supported(C, DO, W, Wp, xf_gelu, act):
     return bool(_lib.query("rpb_head_bwd_supported", C, DO, W, Wp, int(bool(xf_gelu)), int(act)))
 

@@ -69,6 +69,11 @@ class Trainer:
                       self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
         return ws.loss
 
+    def close(self):
+        """Teardown: destroy the RCCL communicators of the data-parallel wrapper (also done at interpreter exit)."""
+        if self.model.dp is not None and hasattr(self.model.dp, "close"):
+            self.model.dp.close()
+
     # ---- checkpoint in the reference's format (train.py:410-418)
     def checkpoint(self, extra=None):
         ck = {"model_state_dict": self.model.state_dict(), "iteration": self.iteration}
@@ -139,13 +144,20 @@ class ArenaTrainer:
             torch.distributed.broadcast(self.flat, src=0, group=dp_group)      # one init for everyone, like the reference
             for b in model.buffers():
                 torch.distributed.broadcast(b.data, src=0, group=dp_group)
-            if use_rccl_abi(self.flat):
+            if use_rccl_abi(self.flat, dp_group):
                 self.comm = RcclComm(dp_group)
             core = getattr(model, "regressor", None)
             if core is not None and hasattr(core, "dp"):
                 core.dp = StatsSync(dp_group, comm=self.comm)       # BatchNorm3d over the global batch (SyncBN)
         self._early = {}            # param -> its gradient tensor, all-reduce already in flight
         self._works = []
+        self._had_grad = [False] * len(self.params)
+
+    def close(self):
+        """Teardown: destroy the RCCL communicators (also done at interpreter exit)."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def current_lr(self):
         k = self.iteration
@@ -188,8 +200,16 @@ class ArenaTrainer:
             model._dp_early = None
         # ---- gradients -> arena (storage plumbing; parameters the loss does not reach keep a zero gradient)
         late_dst, late_src, early = [], [], []
-        for p, gv in zip(self.params, self.gviews):
+        for i, (p, gv) in enumerate(zip(self.params, self.gviews)):
             if p.grad is None:
+                # torch.optim.Adam SKIPS a parameter without a gradient (no moment decay, no update, its own step count); the
+                # one-launch arena update treats it as a zero gradient, which is the same thing only while the parameter has
+                # never had one (moments stay 0: e.g. DPOT's cls_head, the Galerkin layer's unused `fc`).  A parameter that
+                # loses its gradient mid-run would drift on stale momentum here -- refuse instead of diverging silently.
+                if self._had_grad[i]:
+                    raise RuntimeError(f"ArenaTrainer: parameter #{i} {tuple(p.shape)} received gradients in earlier steps but none "
+                                       "in this one; the fused Adam launch cannot skip it the way torch.optim.Adam would "
+                                       "(conditionally used parameters are not supported)")
                 gv.zero_()
             elif p in self._early:
                 # the tensor the model handed to _dp_early is the one being reduced in place; p.grad may be a COPY autograd made
@@ -199,6 +219,8 @@ class ArenaTrainer:
             else:
                 late_dst.append(gv)
                 late_src.append(p.grad)
+            if p.grad is not None:
+                self._had_grad[i] = True
         if late_dst:
             torch._foreach_copy_(late_dst, late_src)
         if self.world > 1:

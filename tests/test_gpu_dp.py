@@ -67,6 +67,7 @@ def test_two_rank_step_equals_single_rank_on_concatenated_batch():
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = {k: v for k, v in out.items()}
     model = _model().cuda()
+    w0 = model.flat.data.cpu().clone()
     tr = Trainer(model, lr=1e-3, num_update=10)
     x, y = _data()
     ref_losses = [float(tr.step(x.cuda(), y.cuda())) for _ in range(2)]
@@ -77,14 +78,15 @@ def test_two_rank_step_equals_single_rank_on_concatenated_batch():
         if name.startswith("convs.") and name.endswith(".bias"):
             continue        # true gradient is 0 (BatchNorm cancels it): both runs hold rounding noise that Adam amplifies
         assert rel_l2(res[0]["grad"][off:off + n], tr.grad.cpu()[off:off + n]) < 2e-4, name   # 2nd-step gradient
-        # Adam normalises every element's step to ~lr, so gradient elements that are zero in exact arithmetic (the imaginary
-        # part of the k_w = 0 spectral weights: irfftn ignores it; conv biases under BatchNorm) turn round-off into full-size
-        # steps whose SIGN depends on the summation order, i.e. on how the batch is sharded: two steps can differ by up to
-        # 4 lr on such elements.  The gradients above are the real check; the weights are checked robustly.
-        wa, wb = res[0]["flat"][off:off + n], model.flat.data.cpu()[off:off + n]
-        dw = (wa - wb).abs()
-        assert float(dw.max()) <= 4 * 1e-3 * 1.01, name
-        assert float((dw > 0.1 * 1e-3).float().mean()) < 0.15, name
+        # Weights: Adam normalises every element's step to ~lr, so elements whose gradient is zero in exact arithmetic (conv biases
+        # under BatchNorm, spectral-weight components the inverse real transform ignores) turn round-off into full-size steps whose
+        # SIGN depends on the summation order, i.e. on how the batch is sharded.  Those elements are masked by what defines them --
+        # a gradient at the round-off level of its tensor -- and every element with a resolved gradient must have moved the same way.
+        g_ref = tr.grad.cpu()[off:off + n]
+        mask = g_ref.abs() > 0.05 * g_ref.pow(2).mean().sqrt()
+        assert float(mask.float().mean()) > 0.25, name       # (spectral gradients are heavy-tailed: a few low modes carry the norm)
+        da, db = res[0]["flat"][off:off + n] - w0[off:off + n], model.flat.data.cpu()[off:off + n] - w0[off:off + n]
+        assert rel_l2(da[mask], db[mask]) < 2e-2, name
     assert rel_l2(res[0]["rm"], model.bn_running_mean.cpu()) < 5e-3     # moves with the (noise-driven) conv bias
     assert rel_l2(res[0]["rv"], model.bn_running_var.cpu()) < 1e-4
     # each rank reports its local-shard loss; their mean is the global loss
@@ -250,3 +252,30 @@ def test_micro_batched_step_equals_the_full_step(kind):
     assert rel_l2(tb.grad, ta.grad) < 1e-5
     with pytest.raises(ValueError, match="BatchNorm"):
         make_trainer(FNO3d(2, 2, 3, 1, 32, (4, 8, 8, 2), (4, 8, 8, 2)).cuda(), lr=1e-3, num_update=10, micro_batch=2)
+
+
+# ------------------------------------------------------------------------------------------ bench.py --gpus 2 (plumbing of the driver's N > 1 run)
+def test_bench_two_ranks_self_launch_equals_single_rank():
+    """``python bench.py --gpus 2 --scaling strong`` on this 1-GPU box (RPB_BENCH_SHARE_GPU=1: the two ranks share cuda:0 and reduce
+    through gloo -- RCCL refuses two ranks on one device): the launcher path, rank / world bookkeeping, per-rank batch slices, bucketed
+    all-reduce + SyncBN inside the fused step and the JSON line.  The 2-rank first-step loss on the global batch of 4 must be the
+    1-rank loss on the same 4 samples."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(gpus, extra_env):
+        env = dict(os.environ, **extra_env)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--scaling", "strong", "--batch", "4",
+                            "--steps", "2", "--warmup", "1", "--only-headline"], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+
+    two = run(2, {"RPB_BENCH_SHARE_GPU": "1"})
+    one = run(1, {})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["scaling"] == "strong" and two["config"]["global_batch"] == 4 and two["config"]["batch_per_gpu"] == 2
+    assert two["dp"]["ranks_in_process_group"] == 2 and len(two["dp"]["buckets_MB"]) == 6
+    assert abs(two["first_step_loss"] - one["first_step_loss"]) < 1e-5 * abs(one["first_step_loss"])
+    assert two["value"] > 0 and two["roofline"]["frac"] > 0
