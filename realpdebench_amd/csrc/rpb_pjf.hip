@@ -35,6 +35,17 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define PF_WAVES 4
 #define PF_TS 132          // row stride (floats) of the wave's transposition tile: 4 * 132 = 16 (mod 32) -> conflict-free ds_write_b32
 #define PF_DOMAX 4
+// PF_PIPE=1 asks the scheduler (sched_group_barrier) to alternate each region's MFMAs with the neighbouring stage's VALU work.  Measured
+// at B = 32: 4.27-4.31 ms with the forced interleaving, 4.00 ms without (the compiler's own order), 4.04 ms for the phase-by-phase
+// version -- one wave per SIMD is bound by its issue slots (~4 cycles per instruction + 12 more per MFMA), not by missing overlap.
+#ifndef PF_PIPE
+#define PF_PIPE 0
+#endif
+#if PF_PIPE
+#define PF_SGB(m, n, id) __builtin_amdgcn_sched_group_barrier(m, n, id)
+#else
+#define PF_SGB(m, n, id)
+#endif
 
 namespace {
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
@@ -244,18 +255,13 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
             const int gn = last ? gln : (int)gl, pn = last ? pln : pl;                // next tile: cropped / padded line, tile index
             const int qn = last ? 0 : q + 1;
             const unsigned pf = prefetch(pn, qn);
-            // ================= u = a W1^T + b1: rows = the 32 cells (two row tiles j), columns = hidden 16 t + n16
+            // The tile body is written as scheduling REGIONS (sched_barrier(0) between them).  One wave per SIMD issues in order, so
+            // matrix and vector work only overlap when they alternate in the instruction stream: each region pairs the MFMAs of one
+            // stage with independent VALU work of the neighbouring stage and asks the scheduler for that interleaving
+            // (sched_group_barrier).  Measured before: 35 % matrix pipe busy, VALU and MFMA co-executing 3 % of the time.
             f32x4v acc[2][8];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float bv = b1l[16 * t + n16];
-                    acc[j][t] = f32x4v{bv, bv, bv, bv};
-                }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 Ah[2], Am[2], Al[2];
+            bf16x8 Ah[2][2], Am[2][2], Al[2][2];                     // [ks][j]: a in A-operand layout, split
+            auto split_A = [&](int ks) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v[8];
@@ -271,26 +277,26 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[4 * hf + c] = z[c];
                     }
-                    split8(v, Ah[j], Am[j], Al[j]);
+                    split8(v, Ah[ks][j], Am[ks][j], Al[ks][j]);
                 }
-                if (ks == 1) issue_xr(pl, q);                        // xa is dead: the B-layout view of THIS tile (L1 / L2 hits), used by the weight gradient
+            };
+            // products of K-step ks for the hidden-tile pair (t0, t0 + 1), both row tiles: 24 MFMAs on 4 independent accumulators
+            auto mac_pair = [&](int ks, int t0) {
+                bf16x8 bh[2], bm[2], bl[2];
 #pragma unroll
-                for (int t0 = 0; t0 < 8; t0 += 2) {
-                    bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        bh[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 0) * 8 + t0 + tt) * 64 + lane]);
-                        bm[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 1) * 8 + t0 + tt) * 64 + lane]);
-                        bl[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 2) * 8 + t0 + tt) * 64 + lane]);
-                    }
+                for (int tt = 0; tt < 2; ++tt) {
+                    bh[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 0) * 8 + t0 + tt) * 64 + lane]);
+                    bm[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 1) * 8 + t0 + tt) * 64 + lane]);
+                    bl[tt] = __builtin_bit_cast(bf16x8, W1B[((ks * 3 + 2) * 8 + t0 + tt) * 64 + lane]);
+                }
 #define PF_ACC(c) acc[(c) & 1][t0 + ((c) >> 1)]
-#define PF_AH(c) Ah[(c) & 1]
-#define PF_AM(c) Am[(c) & 1]
-#define PF_AL(c) Al[(c) & 1]
+#define PF_AH(c) Ah[ks][(c) & 1]
+#define PF_AM(c) Am[ks][(c) & 1]
+#define PF_AL(c) Al[ks][(c) & 1]
 #define PF_BH(c) bh[(c) >> 1]
 #define PF_BM(c) bm[(c) >> 1]
 #define PF_BL(c) bl[(c) >> 1]
-                    PF_MAC6(4, PF_ACC, PF_AH, PF_AM, PF_AL, PF_BH, PF_BM, PF_BL)
+                PF_MAC6(4, PF_ACC, PF_AH, PF_AM, PF_AL, PF_BH, PF_BM, PF_BL)
 #undef PF_ACC
 #undef PF_AH
 #undef PF_AM
@@ -298,44 +304,77 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
 #undef PF_BH
 #undef PF_BM
 #undef PF_BL
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ================= gh = (fc2^T gout) * gelu'(u) in place; d fc2, d b1, d b2: per-lane sums over the lane's 8 cells
+            };
+            // gh = (fc2^T gout) * gelu'(u) in place for hidden tile t of row tile j; d fc2, d b1: per-lane sums over the lane's cells
+            auto act = [&](int j, int t) {
+                const f32x4v u = acc[j][t];                          // rows = cells 16 j + 4 kg + r  <->  go[4 j + r]
+                const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
+                const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
+                const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
+                f32x4v ex;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+                for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(q2[r]);
+                const f32x4v vv = u * cdf;
+                const f32x4v dd = cdf + u * (ex * 0.39894228040143267794f);
+                f32x4v gp = z4;
+#pragma unroll
+                for (int jj = 0; jj < DOT; ++jj) {
+                    const f32x4v gv = {go[4 * j][jj], go[4 * j + 1][jj], go[4 * j + 2][jj], go[4 * j + 3][jj]};
+                    gp += gv * w2l[jj * PF_HID + 16 * t + n16];
+                    const f32x4v pr = gv * vv;
+                    dw2[jj][t] += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                }
+                const f32x4v gh = gp * dd;                           // cells >= W: gout == 0 -> gh == 0
+                acc[j][t] = gh;
+                db1[t] += (gh[0] + gh[1]) + (gh[2] + gh[3]);
+            };
+            // ---- region 1: split of the first K-step (needs this tile's A-layout loads); the B-layout view of THIS tile starts its way
+            issue_xr(pl, q);                                         // L1 / L2 hits: the lines were fetched by the xa loads
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const f32x4v u = acc[j][t];                      // rows = cells 16 j + 4 kg + r  <->  go[4 j + r]
-                    const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
-                    const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
-                    const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
-                    f32x4v ex;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(q2[r]);
-                    const f32x4v vv = u * cdf;
-                    const f32x4v dd = cdf + u * (ex * 0.39894228040143267794f);
-                    f32x4v gp = z4;
-#pragma unroll
-                    for (int jj = 0; jj < DOT; ++jj) {
-                        const f32x4v gv = {go[4 * j][jj], go[4 * j + 1][jj], go[4 * j + 2][jj], go[4 * j + 3][jj]};
-                        gp += gv * w2l[jj * PF_HID + 16 * t + n16];
-                        const f32x4v pr = gv * vv;
-                        dw2[jj][t] += (pr[0] + pr[1]) + (pr[2] + pr[3]);
-                    }
-                    const f32x4v gh = gp * dd;                       // cells >= W: gout == 0 -> gh == 0
-                    acc[j][t] = gh;
-                    db1[t] += (gh[0] + gh[1]) + (gh[2] + gh[3]);
-                    if (t & 1) __builtin_amdgcn_sched_barrier(0);        // keep the live ranges as written: two hidden tiles in flight
+                    const float bv = b1l[16 * t + n16];
+                    acc[j][t] = f32x4v{bv, bv, bv, bv};
                 }
+            split_A(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 2: u = a W1^T, first K-step (96 MFMAs)  ||  split of the second K-step
+#pragma unroll
+            for (int t0 = 0; t0 < 8; t0 += 2) mac_pair(0, t0);
+            split_A(1);
+#pragma unroll
+            for (int i = 0; i < 96; ++i) {
+                PF_SGB(0x008, 1, 0);
+                PF_SGB(0x002, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 3: second K-step of pair p (24 MFMAs)  ||  activation of pair p - 1 (whose accumulators are final)
+#pragma unroll
+            for (int pp = 0; pp < 5; ++pp) {
+                if (pp < 4) mac_pair(1, 2 * pp);
+                if (pp > 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        act(j, 2 * pp - 2);
+                        act(j, 2 * pp - 1);
+                    }
+                }
+                if (pp > 0 && pp < 4) {
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        PF_SGB(0x008, 1, 0);
+                        PF_SGB(0x002, 11, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int jj = 0; jj < DOT; ++jj)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) db2[jj] += go[e][jj];
             issue_go(gn, qn);
-            __builtin_amdgcn_sched_barrier(0);
-            // ================= M += gh^T shat: contraction over the 32 cells; lane group kg holds cells {4 kg + r, 16 + 4 kg + r}
+            // ---- region 4: M += gh^T shat: contraction over the 32 cells; lane group kg holds cells {4 kg + r, 16 + 4 kg + r}
             {
                 bf16x8 Xh[4], Xm[4], Xl[4];                          // shat in B-operand layout: column n16 of tile u = channel 4 n16 + u
                 const f32x4v bmu = *reinterpret_cast<const f32x4v*>(xfl + 4 * n16), bis = *reinterpret_cast<const f32x4v*>(xfl + 64 + 4 * n16);
@@ -349,20 +388,24 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                     for (int e = 0; e < 8; ++e) v[e] = sh[e][u];
                     split8(v, Xh[u], Xm[u], Xl[u]);
                 }
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                bf16x8 Gh[2], Gm[2], Gl[2];                          // gh^T of hidden tile t in A-operand layout, double-buffered
+                auto split_G = [&](int t) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[0][t][r];
                         v[4 + r] = acc[1][t][r];
                     }
-                    bf16x8 Gh, Gm, Gl;
-                    split8(v, Gh, Gm, Gl);
+                    split8(v, Gh[t & 1], Gm[t & 1], Gl[t & 1]);
+                };
+                split_G(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
 #define PF_ACC(c) acc3[t][c]
-#define PF_G1(c) Gh
-#define PF_G2(c) Gm
-#define PF_G3(c) Gl
+#define PF_G1(c) Gh[t & 1]
+#define PF_G2(c) Gm[t & 1]
+#define PF_G3(c) Gl[t & 1]
 #define PF_X1(c) Xh[c]
 #define PF_X2(c) Xm[c]
 #define PF_X3(c) Xl[c]
@@ -374,12 +417,20 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
 #undef PF_X1
 #undef PF_X2
 #undef PF_X3
+                    if (t < 7) {                                     // the next hidden tile's split rides between this tile's MFMAs
+                        split_G(t + 1);
+#pragma unroll
+                        for (int i = 0; i < 22; ++i) {
+                            PF_SGB(0x008, 1, 0);
+                            PF_SGB(0x002, 2, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(pf));
             issue_xa(pn, qn);                                        // the next tile's A-layout loads (prefetched into L2 a tile ago)
-            // ================= g = gh W1, one 16-cell row tile at a time through the wave's transposition tile
+            // ---- region 5: g = gh W1, one 16-cell row tile at a time through the wave's transposition tile
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -392,8 +443,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                 f32x4v acc2[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc2[u] = z4;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                bf16x8 Ah2[2], Am2[2], Al2[2];
+                auto split_T = [&](int s) {
                     const f32x4v t0 = *reinterpret_cast<const f32x4v*>(Tw + n16 * PF_TS + 32 * s + 8 * kg);
                     const f32x4v t1 = *reinterpret_cast<const f32x4v*>(Tw + n16 * PF_TS + 32 * s + 8 * kg + 4);
                     float v[8];
@@ -402,8 +453,12 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                         v[c] = t0[c];
                         v[4 + c] = t1[c];
                     }
-                    bf16x8 Ah, Am, Al;
-                    split8(v, Ah, Am, Al);
+                    split8(v, Ah2[s & 1], Am2[s & 1], Al2[s & 1]);
+                };
+                split_T(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
                     bf16x8 bh[4], bm[4], bl[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -412,9 +467,9 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                         bl[u] = __builtin_bit_cast(bf16x8, W1D[((s * 3 + 2) * 4 + u) * 64 + lane]);
                     }
 #define PF_ACC(c) acc2[c]
-#define PF_A1(c) Ah
-#define PF_A2(c) Am
-#define PF_A3(c) Al
+#define PF_A1(c) Ah2[s & 1]
+#define PF_A2(c) Am2[s & 1]
+#define PF_A3(c) Al2[s & 1]
 #define PF_B1(c) bh[c]
 #define PF_B2(c) bm[c]
 #define PF_B3(c) bl[c]
@@ -426,6 +481,15 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
 #undef PF_B1
 #undef PF_B2
 #undef PF_B3
+                    if (s < 3) {
+                        split_T(s + 1);
+#pragma unroll
+                        for (int i = 0; i < 22; ++i) {
+                            PF_SGB(0x008, 1, 0);
+                            PF_SGB(0x002, 2, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();                     // the tile is rewritten by the next row tile
