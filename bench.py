@@ -484,6 +484,24 @@ def copy_ceiling(dev, n=14939392 * 64):
     return res
 
 
+def mfma_ceiling(dev):
+    """Sustained bf16 MFMA rate of THIS chip (csrc/rpb_probe.hip: 4 independent 32x32x16 chains per wave, one wave per SIMD, register
+    operands) with random operands -- the power-limited rate real data sees -- and with zeros (the datasheet-like rate).  TFLOP/s."""
+    from realpdebench_amd import ops
+    res = {}
+    out = torch.empty(256 * 2 * 512, device=dev)
+    for name, seed in (("random_operands", torch.randn(4096, device=dev)), ("zero_operands", torch.zeros(4096, device=dev))):
+        ops.mfma_probe(seed, out, 2000)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fl = ops.mfma_probe(seed, out, 40000)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = fl / (e0.elapsed_time(e1) * 1e9)
+    return res
+
+
 def bench_fno_native(dev, steps=5):
     """FNO3d at the reference-native cylinder sample shape (realpdebench/configs/cylinder/fno.yaml with the released data:
     [32,20,64,128,3] -> padded 26 x 70 x 134), same modes / width / depth: fused Trainer.step and the 10-step rollout."""
@@ -692,12 +710,13 @@ def main():
             comm.set_timing(False)
 
     # ---- the chip's streaming ceiling for the kernels' read / write mixes, measured now (rank 0)
-    ceiling = None
+    ceiling = mfma_peak = None
     if rank == 0 and B * world >= 1:
         try:
             free_b = torch.cuda.mem_get_info()[0]
             if free_b > 20e9:
                 ceiling = copy_ceiling(dev)
+            mfma_peak = mfma_ceiling(dev)
         except Exception as e:
             print(f"[bench] copy-ceiling probe failed: {e!r}", file=sys.stderr)
 
@@ -812,6 +831,17 @@ def main():
                                   "kernels = sum over this step's launches of their own algorithmic bytes (layer-0 algebra and the fused "
                                   "head move fewer bytes than SURVEY's model)"})
             line["roofline"]["whole_step"]["frac_of_copy_ceiling"] = step_bytes / (ms_per_step * 1e6) / best
+        if mfma_peak:
+            for v in extra.values():                        # the secondary models' split-bf16 pipe fraction against the measured ceiling
+                sp = (v.get("roofline") or {}).get("split_bf16_mfma") if isinstance(v, dict) else None
+                if sp:
+                    sp["frac_of_sustained_rate"] = sp["achieved"] / (mfma_peak["random_operands"] / 6.0)
+            line["mfma_bf16_sustained"] = {"TFLOPs": mfma_peak, "datasheet_peak": MFMA_BF16_PEAK_TF,
+                                           "frac_of_datasheet": {k: v / MFMA_BF16_PEAK_TF for k, v in mfma_peak.items()},
+                                           "split_bf16_fp32_equivalent_TFLOPs": mfma_peak["random_operands"] / 6.0,
+                                           "how": "csrc/rpb_probe.hip: 4 independent v_mfma_f32_32x32x16_bf16 chains per wave, one wave per SIMD, "
+                                                  "register operands; measured in this run.  The secondary models' split-bf16 kernels move real "
+                                                  "(random-like) data: their ceiling is the random-operand rate, not the datasheet's"}
         if dp_info:
             line["dp"] = dp_info
         line.update(extra)

@@ -401,6 +401,10 @@ int rpb_head_bwd_finalize(const float* tot, const float* w1, const float* gamma,
 /* ---- measurement aid (bench.py roofline.copy_ceiling; not on the model path): out = a (* b (+ c)) over n floats, `nread` tensors read
  *      once + one written once with 16 B per lane -- the streaming ceiling of the chip for the read / write mix of the FNO kernels. */
 int rpb_stream_probe(const float* a, const float* b, const float* c, float* out, long n, int nread, int threads, void* stream);
+/*      rpb_mfma_probe: the matrix pipe's sustained bf16 rate (v_mfma_f32_32x32x16_bf16, register operands built from seed4096[4096]:
+ *      random values -> the power-limited rate real data sees, zeros -> the datasheet-like rate); out = scratch of
+ *      256 * waves_per_simd * CUs floats; *flops = operations executed by the launch. */
+int rpb_mfma_probe(const float* seed4096, float* out, int iters, int waves_per_simd, double* flops, void* stream);
 
 /* ---- eval_metrics (realpdebench/utils/metrics.py:71-100): |F|^2 of the truncated spectrum corner accumulated by radial bin
  *      floor(sqrt(i^2+j^2+k^2)) < R.  Y [R][R][R][2][NB] (re, im planes; columns = (channel, sample)), out [R][NB].  The three

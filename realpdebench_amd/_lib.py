@@ -37,6 +37,7 @@ SIGNATURES = {
     "rpb_proj_wgrad_roles": (_I, ""),
     "rpb_proj_wgrad": (_I, "pppppp" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),
     "rpb_stream_probe": (_I, "pppp" + "l" + "ii" + "p"),
+    "rpb_mfma_probe": (_I, "pp" + "ii" + "p" + "p"),
     "rpb_head_bwd_supported": (_I, "iiiiii"),
     "rpb_head_bwd_slots": (_L, "iii"),
     "rpb_head_bwd_row": (_I, "i"),

@@ -682,6 +682,14 @@ def stream_probe(a, b, c, out, nread, threads=256):
               nbytes=4 * a.numel() * (nread + 1))
 
 
+def mfma_probe(seed, out, iters, waves_per_simd=1):
+    """Measurement aid (bench.py): sustained bf16 MFMA rate on operands built from ``seed`` (4096 floats); returns the launch's flops."""
+    import ctypes
+    fl = ctypes.c_double(0.0)
+    _lib.call("rpb_mfma_probe", _p(seed), _p(out), int(iters), int(waves_per_simd), ctypes.addressof(fl), _stream())
+    return fl.value
+
+
 def head_bwd_supported(C, DO, W, Wp, xf_gelu, act):
     return bool(_lib.query("rpb_head_bwd_supported", C, DO, W, Wp, int(bool(xf_gelu)), int(act)))
 
