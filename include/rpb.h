@@ -476,6 +476,8 @@ int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, co
  *        (dpot.py:395-396 and the channel slice of model/dpot.py:227). */
 int rpb_dpot_patch_tokens(const float* u, const float* gx, const float* gy, const float* gt, float* P, int B, int T, int H, int W,
                           int Cd, int Cm, int ps, void* stream);
+/*      gradient of that gather w.r.t. the data frames (sliding-window training feeds predictions back in, model/dpot.py:256-309) */
+int rpb_dpot_patch_tokens_bwd(const float* gP, float* gu, int B, int T, int H, int W, int Cd, int Cm, int ps, void* stream);
 int rpb_rowtable_add(float* x, const float* table, long M, int C, int rows_per_entry, int nent, void* stream);
 int rpb_rowtable_grad(const float* g, float* dtable, int B, int C, int rows_per_entry, int nent, void* stream);
 int rpb_dpot_tagg_prep(const float* w, const float* gamma, const float* tt, float* Wf, float* Wb, float* e_out, int T, int C,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
     "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),
     "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),
+    "rpb_dpot_patch_tokens_bwd": (_I, "pp" + "iiiiiii" + "p"),
     "rpb_rowtable_add": (_I, "pp" + "l" + "iii" + "p"),
     "rpb_rowtable_grad": (_I, "pp" + "iiii" + "p"),
     "rpb_dpot_tagg_prep": (_I, "pppppp" + "ii" + "p"),

@@ -44,6 +44,25 @@ __global__ void patch_tokens_kernel(const float* __restrict__ u, const float* __
     }
 }
 
+// gradient of the gather above w.r.t. the data channels: patches do not overlap, so every input element has exactly one token entry
+__global__ void patch_tokens_bwd_kernel(const float* __restrict__ gP, float* __restrict__ gu, int B, int T, int H, int W, int Cd, int Cm,
+                                        int ps, long total) {
+    const int Kp = (Cm + 3) * ps * ps;
+    const int nx = H / ps, ny = W / ps;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cd);
+        long r = idx / Cd;
+        const int y = (int)(r % W);
+        r /= W;
+        const int x = (int)(r % H);
+        r /= H;
+        const int t = (int)(r % T);
+        const int b = (int)(r / T);
+        const long row = (((long)b * nx + x / ps) * ny + y / ps) * T + t;
+        gu[idx] = gP[row * Kp + (c * ps + x % ps) * ps + y % ps];
+    }
+}
+
 // x[r][c] += table[(r / rpe) % nent][c]
 __global__ void rowtable_add_kernel(float* __restrict__ x, const float* __restrict__ table, long M, int C, int rpe, int nent) {
     const long n4 = M * (C / 4);
@@ -461,6 +480,16 @@ extern "C" int rpb_dpot_patch_tokens(const float* u, const float* gx, const floa
     hipLaunchKernelGGL(patch_tokens_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, u, gx, gy, gt, P, B, T, H, W,
                        Cd, Cm, ps, total);
     RPB_CHECK_LAUNCH("dpot_patch_tokens");
+}
+
+// gu [B][T][H][W][Cd] = gradient w.r.t. the data frames from gP [B*nx*ny*T][(Cm+3)*ps*ps], the gradient of the token rows
+extern "C" int rpb_dpot_patch_tokens_bwd(const float* gP, float* gu, int B, int T, int H, int W, int Cd, int Cm, int ps, void* stream) {
+    RPB_REQUIRE(gP && gu, "dpot_patch_tokens_bwd: null pointer");
+    RPB_REQUIRE(B > 0 && T > 0 && ps > 0 && H % ps == 0 && W % ps == 0 && Cd > 0 && Cd <= Cm, "dpot_patch_tokens_bwd: bad sizes");
+    const long total = (long)B * T * H * W * Cd;
+    hipLaunchKernelGGL(patch_tokens_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, gP, gu, B, T, H, W, Cd, Cm,
+                       ps, total);
+    RPB_CHECK_LAUNCH("dpot_patch_tokens_bwd");
 }
 
 extern "C" int rpb_rowtable_add(float* x, const float* table, long M, int C, int rows_per_entry, int nent, void* stream) {

@@ -153,7 +153,13 @@ class DPOT(_ModelBase):
 
     # ------------------------------------------------------------------ checkpoints (model/dpot.py:291-400)
     def load_checkpoint(self, checkpoint_path, device="cpu"):
-        ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        try:                                               # model/dpot.py:320-324: safe load first; the released DPOT files carry an
+            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)       # argparse.Namespace and need the fallback
+        except Exception:
+            import logging
+            logging.warning("DPOT.load_checkpoint: %s needs weights_only=False (pickled non-tensor objects); only load files you trust",
+                            checkpoint_path)
+            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         sd = ck.get("model", ck.get("model_state_dict", ck)) if isinstance(ck, dict) else ck
         own = self.dpot_model.state_dict()
         ok = {}
@@ -401,14 +407,16 @@ class DPOT(_ModelBase):
             Ho, Wo = self.shape_out[1:3]
             pred = self._resize_apply(pred.view(B * To, H, W, Cdo), rs["out"]).view(B, To, Ho, Wo, Cdo)
         if training:
-            save.update(B=B, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
+            save.update(B=B, Cd=Cd, P=P, H1=H1, H1pre=H1pre, W2p=W2p, Etok=Etok, Wb=Wb, ecos=ecos, gamma=gamma, tapes=tapes, Xlast=X, Wt=Wt,
                         comp=comp, WcT=WcT, WsumT=WsumT, posb=posb, Wf=Wf if comp else None,
                         U=U, Upre=Upre, V=V, Vpre=Vpre, W3p=W3p)
         return pred
 
     # ------------------------------------------------------------------ backward
     @torch.no_grad()
-    def _backward_hip(self, sv, g_pred):
+    def _backward_hip(self, sv, g_pred, need_gx=False):
+        """{parameter: gradient}; with ``need_gx`` also ``grads['__x__']``, the gradient w.r.t. the window's input frames (sliding-window
+        training feeds predictions back in as inputs, model/dpot.py:256-309)."""
         net = self.dpot_model
         B = sv["B"]
         E, ps, Cm, Co, To, T = self.embed_dim, self.patch_size, self.in_channels, self.out_channels, self.out_timesteps, self.in_timesteps
@@ -537,6 +545,20 @@ class DPOT(_ModelBase):
             grads[ta.gamma] = dgamma.view(1, E)
         dW1, db1 = _wgrad(gH1, sv["P"], M1, E1, Kp, ldg=E1p, lda=Kp)
         grads[pe0.weight], grads[pe0.bias] = dW1.reshape(pe0.weight.shape), db1
+        if need_gx:
+            # gradient of the token rows, then the inverse of the patch gather (patches do not overlap) and of the input resize
+            W1p = torch.zeros(E1p, Kp, **f)
+            W1p[:E1] = pe0.weight.data.view(E1, Kp)
+            gP = new(M1, Kp)
+            ops.gemm_nt(gH1, Tr(W1p), gP, M1, Kp, E1p)
+            Cd = sv["Cd"]
+            gx = new(B, T, H, W, Cd)
+            ops.dpot_patch_tokens_bwd(gP, gx, B, T, H, W, Cd, Cm, ps)
+            if self.needs_resize:
+                rs = self._resize_plan(g_pred.device)
+                Hi, Wi = rs["inp"]["n_in"]
+                gx = self._resize_apply(gx.view(B * T, H, W, Cd), rs["inp"], adjoint=True).view(B, T, Hi, Wi, Cd)
+            grads["__x__"] = gx
         return grads
 
     @staticmethod
@@ -590,7 +612,7 @@ class DPOT(_ModelBase):
         if tuple(x.shape[2:]) != tuple(self.shape_in[1:]) or T_in < self.in_timesteps:
             raise ValueError(f"expected input [B,>={self.in_timesteps},{','.join(map(str, self.shape_in[1:]))}], got {tuple(x.shape)}")
         if self.out_timesteps == T_out:
-            return self._window(x[:, -self.in_timesteps:] if T_in != self.in_timesteps else x)
+            return self._window(self._exact_window(x))
         cur, outs = x, []                                                     # model/dpot.py:151-178: sliding windows
         for t in range(0, T_out, self.out_timesteps):
             win = cur[:, -self.in_timesteps:]
@@ -606,12 +628,45 @@ class DPOT(_ModelBase):
         return torch.cat(outs, dim=1)
 
     def train_loss(self, input, target):
-        """model/dpot.py:239-289 for out_timesteps == T_out (every reference YAML): mean squared error of one window."""
-        if self.out_timesteps != target.shape[1]:
-            raise NotImplementedError("sliding-window training (out_timesteps < target length, model/dpot.py:256-289) back-propagates "
-                                      "through the fed-back predictions and is not built; every reference YAML trains one window")
-        pred = self._window(input)
-        return ((pred - target) ** 2).mean()
+        """model/dpot.py:239-309.  out_timesteps == T_out (every reference YAML): the scalar mean squared error of one window.
+        out_timesteps < T_out: sliding windows -- each window's prediction is appended to the input of the next one, so the loss
+        back-propagates through the fed-back predictions (``_DPOTFunction`` returns the window's input gradient); a last partial window
+        with at least out_timesteps // 2 frames counts with weight remaining / out_timesteps.  The reference returns the ELEMENT-WISE
+        sum there (its callers take ``.mean()``), and a partial window's ``[B, remaining, ...]`` loss is added to the full windows'
+        ``[B, out_timesteps, ...]`` tensor by broadcasting, which only type-checks for remaining == 1 (or no partial window);
+        reproduced as is, including the error for other remainders."""
+        T_in, T_out, To = input.shape[1], target.shape[1], self.out_timesteps
+        if T_in < self.in_timesteps or To > T_out:
+            raise ValueError(f"DPOT.train_loss: input frames {T_in} < in_timesteps {self.in_timesteps} or out_timesteps {To} > target frames {T_out}")
+        if To == T_out:
+            pred = self._window(self._exact_window(input))
+            return ((pred - target) ** 2).mean()
+        total, nwin, cur = 0, 0, input
+        for t in range(0, T_out, To):
+            win = cur[:, -self.in_timesteps:]
+            if t + To > T_out:
+                rem = T_out - t
+                if rem < To // 2:
+                    break
+                pred = self._window(win)[:, :rem]
+                total = total + ((pred - target[:, t:t + rem]) ** 2) * (rem / To)        # broadcasts against [B, To, ...] like the reference
+                nwin += rem / To
+            else:
+                pred = self._window(win)
+                total = total + (pred - target[:, t:t + To]) ** 2
+                nwin += 1
+                cur = torch.cat([cur, pred], dim=1)
+        if nwin == 0:
+            raise ValueError(f"No valid training windows found. out_timesteps ({To}) may be too large for target length ({T_out})")
+        return total / nwin
+
+    def _exact_window(self, x):
+        """The single-window branches of the reference hand the WHOLE input to DPOTNet, whose TimeAggregator is sized for
+        in_timesteps frames (model/dpot.py:147-148, 253-256): more frames than that fail there with a shape error."""
+        if x.shape[1] != self.in_timesteps:
+            raise ValueError(f"DPOT: the single-window path takes exactly in_timesteps = {self.in_timesteps} input frames, got {x.shape[1]} "
+                             "(the reference's TimeAggregator fails on any other count)")
+        return x
 
 
 class _DPOTFunction(torch.autograd.Function):
@@ -626,6 +681,6 @@ class _DPOTFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        grads = ctx.model._backward_hip(ctx.sv, g_out.contiguous().float())
+        grads = ctx.model._backward_hip(ctx.sv, g_out.contiguous().float(), need_gx=ctx.needs_input_grad[0])
         ctx.sv = None
-        return (None, None) + tuple(grads.get(p) for p in ctx.params)
+        return (grads.get("__x__"), None) + tuple(grads.get(p) for p in ctx.params)

@@ -776,6 +776,11 @@ def dpot_patch_tokens(u, gx, gy, gt, P, B, T, H, W, Cd, Cm, ps):
               label="dpot_patch_tokens", nbytes=4 * (u.numel() + P.numel()))
 
 
+def dpot_patch_tokens_bwd(gP, gu, B, T, H, W, Cd, Cm, ps):
+    _lib.call("rpb_dpot_patch_tokens_bwd", _p(gP), _p(gu), B, T, H, W, Cd, Cm, ps, _stream(), label="dpot_patch_tokens_bwd",
+              nbytes=4 * (gu.numel() + gP.numel()))
+
+
 def rowtable_add(x, table, M, C, rows_per_entry, nent):
     _lib.call("rpb_rowtable_add", _p(x), _p(table), M, C, rows_per_entry, nent, _stream(), label="rowtable_add", nbytes=8 * M * C)
 

@@ -127,6 +127,46 @@ def test_sliding_window_eval_forward():
     assert rel_l2(out.cpu(), ref) < 1e-5
 
 
+def test_sliding_window_training_matches_reference():
+    """out_timesteps 2 < 5 target frames (tests/golden/dpot_sliding_small.npz, from the imported reference): the loss of
+    model/dpot.py:256-309 -- two full windows fed back into the input, one partial window of weight 1/2 added by broadcasting -- and
+    every parameter gradient, which includes the path through the fed-back predictions (the window's INPUT gradient)."""
+    g = dpot_golden("dpot_sliding_small")
+    m = _model(g).train()
+    loss = m.train_loss(g["x"].cuda(), g["y"].cuda())
+    assert loss.dim() == 5                                  # element-wise, like the reference's sliding branch; train.py:328 takes .mean()
+    loss = loss.mean()
+    loss.backward()
+    assert abs(float(loss) - g["loss"]) < 1e-5 * abs(g["loss"])
+    got = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert set(got) == set(g["grad"])
+    for k, ref in g["grad"].items():
+        assert rel_l2(got[k].cpu(), ref) < 1e-4, k
+    m.eval()
+    with torch.no_grad():
+        out = m(g["x"].cuda())
+    assert rel_l2(out.cpu(), g["pred"]) < 1e-5
+    # the window's input gradient on its own: autograd through the HIP window vs the CPU oracle's
+    from oracle import dpot_oracle as DO
+    x = g["x"][:, :4].clone().requires_grad_(True)
+    sd = {k: v for k, v in g["sd"].items()}
+    ref = DO.dpot_forward(sd, x, dict(g["cfg"]))
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    xc = g["x"][:, :4].cuda().requires_grad_(True)
+    m.train()
+    (m._window(xc) * w.cuda()).sum().backward()
+    assert rel_l2(xc.grad.cpu(), x.grad) < 1e-4
+
+
+def test_single_window_input_length_is_checked():
+    g = dpot_golden()
+    m = _model(g).eval()
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            m(torch.cat([g["x"], g["x"][:, :1]], 1).cuda())            # 5 frames into a 4-frame TimeAggregator
+
+
 def test_non_native_resolution_matches_reference():
     """Data at 16 x 32 with img_size 32: the wrapper's FFT resize in front of and behind the network (model/dpot.py:204-231) as token
     GEMMs + rpb_axis_gemm stages -- eval forward, training loss and every gradient (through the adjoint of the output resize)

@@ -214,6 +214,38 @@ def test_dpot_oracle_matches_reference(name):
         assert rel_l2(sd[k].grad, ref) < 2e-5, k
 
 
+def test_dpot_oracle_sliding_window_training_matches_reference():
+    """The oracle's single-window function composed the way model/dpot.py:256-309 slides it (predictions fed back, partial last window
+    of weight 1/2 added by broadcasting) against the imported reference's loss, gradients and eval forward (dpot_sliding_small.npz)."""
+    from conftest import dpot_golden
+    from oracle import dpot_oracle as DO
+    g = dpot_golden("dpot_sliding_small")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g["sd"].items()}
+    To, T_out, x, y = g["cfg"]["out_timesteps"], g["y"].shape[1], g["x"], g["y"]
+
+    def slide(sdd, train):
+        cur, outs, total, nwin = x, [], 0, 0
+        for t in range(0, T_out, To):
+            pred = DO.dpot_forward(sdd, cur[:, -g["cfg"]["in_timesteps"]:], g["cfg"])
+            if t + To > T_out:
+                rem = T_out - t
+                pred = pred[:, :rem]
+                total, nwin = total + ((pred - y[:, t:t + rem]) ** 2) * (rem / To), nwin + rem / To
+            else:
+                total, nwin = total + (pred - y[:, t:t + To]) ** 2, nwin + 1
+                cur = torch.cat([cur, pred], 1)
+            outs.append(pred)
+        return (total / nwin).mean() if train else torch.cat(outs, 1)
+
+    loss = slide(sd, True)
+    loss.backward()
+    assert abs(float(loss) - g["loss"]) < 2e-6 * abs(g["loss"])
+    for k, ref in g["grad"].items():
+        assert rel_l2(sd[k].grad, ref) < 2e-5, k
+    with torch.no_grad():
+        assert rel_l2(slide({k: v.detach() for k, v in sd.items()}, False), g["pred"]) < 2e-6
+
+
 @pytest.mark.parametrize("n_in,n_out", [((16, 32), (32, 32)), ((32, 32), (16, 32)), ((12, 10), (7, 16)), ((9, 9), (14, 5))])
 def test_dpot_resize_operators_equal_the_fft_formula(n_in, n_out):
     """Host logic of realpdebench_amd.model.dpot: the dense operators of the spectral resize (T(X) = A X Ry^T + B X Qy^T, built from
