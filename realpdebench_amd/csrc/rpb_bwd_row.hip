@@ -14,6 +14,7 @@
 // double-buffered in registers 4 MFMA steps (8 cells) ahead through SRSRC descriptors (per-row bounds: the pad
 // steps of the last chunk read zeros and their stores are dropped by the hardware).
 #include "rpb_common.h"
+#include "rpb_bwr.h"
 #ifndef RPB_STREAM_AUX
 #define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (experiment switch) */
 #endif
@@ -258,6 +259,13 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
     RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
     RPB_REQUIRE((long)Wp * C * 4 < (1L << 31), "bn_bwd_row: row too long");
     if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta, "bn_bwd_row: bad input-transform arguments");
+    if (rpb_bwr_supported(C, Wp, K2, 0)) {               // C = 64: bf16 matrix pipe, B-layout loads (csrc/rpb_bwr.hip)
+        BwrArgs b;
+        b.s = s; b.gy = gy; b.x = x; b.gs = gs; b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.sums = sums;
+        b.inv_count = (float)(1.0 / count); b.gelu = gelu; b.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
+        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = 0;
+        return rpb_bwr_launch(b, rpb_bn_bwd_row_slots(G), (hipStream_t)stream);
+    }
     BwdRowArgs a;
     a.s = s; a.gy = gy; a.x = x; a.gs = gs; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
     a.sums = sums; a.inv_count = (float)(1.0 / count); a.gelu = gelu;
@@ -280,6 +288,14 @@ extern "C" int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float*
     RPB_REQUIRE(s && gy && phi && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_feat: null pointer");
     RPB_REQUIRE(C == 64 && (FW == 8 || FW == 32), "bn_bwd_row_feat: C=%d FW=%d unsupported", C, FW);
     RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row_feat: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
+    // (measured at B = 32: the feature-field variant of the bf16-pipe kernel 2.72 ms, this fp32 kernel 2.47 ms -- scalar field loads; off unless asked for)
+    if (getenv("RPB_BWR_FEAT") && atoi(getenv("RPB_BWR_FEAT")) == 1 && rpb_bwr_supported(C, Wp, K2, FW)) {
+        BwrArgs b;
+        b.s = s; b.gy = gy; b.x = phi; b.gs = gs; b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.sums = sums;
+        b.inv_count = (float)(1.0 / count); b.gelu = gelu; b.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = FW;
+        return rpb_bwr_launch(b, rpb_bn_bwd_row_slots(G), (hipStream_t)stream);
+    }
     BwdRowArgs a;
     a.s = s; a.gy = gy; a.x = phi; a.gs = gs; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
     a.sums = sums; a.inv_count = (float)(1.0 / count); a.gelu = gelu;

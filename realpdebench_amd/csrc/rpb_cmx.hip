@@ -20,6 +20,9 @@
 //    once per line (a tile-granular version fetched every row ~3x from HBM: 10.3 GB of traffic for 8.56 GB algorithmic);
 //    GW and the conv weights are split once per workgroup into LDS in operand order.
 #include "rpb_cmx.h"
+#ifndef RPB_STREAM_AUX
+#define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (measured: no gain, tools/kbench.py A/B) */
+#endif
 #include <stdlib.h>
 #include <type_traits>
 

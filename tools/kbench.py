@@ -84,6 +84,17 @@ if "bwd_row" in which:
            lambda: ops.bn_bwd_row(x, gy, y, gy, mean, invstd, gamma, beta, sums, d.ncell, True, xf, plan.GW, Y1, part, G,
                                   d.Wp, C, K2), 4 * (4 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * (C + K2))
 
+    timeit("bn_bwd_row (gz in, lazy x)  [the step's variant]",
+           lambda: ops.bn_bwd_row(x, gy, y, gy, mean, invstd, gamma, beta, sums, d.ncell, False, xf, plan.GW, Y1, part, G,
+                                  d.Wp, C, K2), 4 * (4 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * (C + K2))
+    timeit("bn_bwd_row (gz in, plain x)",
+           lambda: ops.bn_bwd_row(x, gy, y, gy, mean, invstd, gamma, beta, sums, d.ncell, False, None, plan.GW, Y1, part, G,
+                                  d.Wp, C, K2), 4 * (4 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * (C + K2))
+    phic = torch.randn(d.ncell, 8, **f)
+    timeit("bn_bwd_row layer 0 (feature fields)",
+           lambda: ops.bn_bwd_row_feat(x, gy, phic, gy, mean, invstd, gamma, beta, sums, d.ncell, False, plan.GW, Y1, part, G,
+                                       d.Wp, C, K2, 8), 4 * (3 * d.ncell * C + d.ncell * 8 + G * K2 * C), 2 * d.ncell * C * (8 + K2))
+
 if "wgrad" in which:
     slots = ops.cell_wgrad_slots(d.ncell, C, C)
     part = torch.empty(slots * (C * C + C), **f)
