@@ -398,6 +398,23 @@ int rpb_head_bwd(const float* s, const float* w1, const float* b1, const float* 
 int rpb_head_bwd_finalize(const float* tot, const float* w1, const float* gamma, const float* beta, int DO, float* dw1, float* dw2,
                           float* db1, float* db2, float* bn_sums, void* stream);
 
+/* ---- U-Net: the [B x C]-sized algebra between the token kernels (csrc/rpb_unet_glue.hip; torch autograd glue in rounds 1-2).
+ *      rpb_gn_affine_fwd: sums [B][2][C] fp64 (per-channel sum x, sum x^2 over `count / (C/G)` positions; count = elements per group) ->
+ *        GroupNorm(G) statistics stat [B][G][2] = (mean, invstd) and the affine A, Bc [B][C] of y = A x + Bc, with the time-embedding
+ *        scale|shift ss [B][2C] (or NULL) folded in: A = invstd gamma (1 + scale), Bc = (beta - mean invstd gamma)(1 + scale) + shift
+ *        (unet.py:200-208, 223-229).  rpb_gn_affine_bwd: d [B][2][C] = (dL/dA, dL/dBc) -> per-sample parts dgam, dbet [B][C], dss
+ *        [B][2C], and P, Q [B][C] (the gradient through the statistics is P + Q x, applied by rpb_affine_silu_bwd_apply).
+ *      rpb_silu_fwd / _bwd: SiLU on the time embedding (unet.py:223).  rpb_relpos_bias_fwd / _bwd: bias [heads][n2] =
+ *        table[idx[p]][h] and its table gradient; idx [n2] = the reference's T5 bucket of every (i, j) (unet.py:78-116), host-computed. */
+int rpb_gn_affine_fwd(const double* sums, const float* gamma, const float* beta, const float* ss, double count, float eps, float* A,
+                      float* Bc, float* stat, int B, int C, int G, void* stream);
+int rpb_gn_affine_bwd(const float* d, const float* stat, const float* gamma, const float* beta, const float* ss, double count, float* dgam,
+                      float* dbet, float* dss, float* P, float* Q, int B, int C, int G, void* stream);
+int rpb_silu_fwd(const float* x, float* y, long n, void* stream);
+int rpb_silu_bwd(const float* x, const float* gy, float* gx, long n, void* stream);
+int rpb_relpos_bias_fwd(const float* table, const int* idx, float* bias, int n2, int heads, void* stream);
+int rpb_relpos_bias_bwd(const float* gbias, const int* idx, float* gtable, int n2, int heads, int nbuckets, void* stream);
+
 /* ---- measurement aid (bench.py roofline.copy_ceiling; not on the model path): out = a (* b (+ c)) over n floats, `nread` tensors read
  *      once + one written once with 16 B per lane -- the streaming ceiling of the chip for the read / write mix of the FNO kernels. */
 int rpb_stream_probe(const float* a, const float* b, const float* c, float* out, long n, int nread, int threads, void* stream);

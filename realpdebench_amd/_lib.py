@@ -137,6 +137,12 @@ SIGNATURES = {
     "rpb_affine_silu_fwd": (_I, "ppppp" + "ili" + "p"),
     "rpb_affine_silu_bwd_reduce": (_I, "ppppp" + "ili" + "p"),
     "rpb_affine_silu_bwd_apply": (_I, "ppppppp" + "ili" + "p"),
+    "rpb_gn_affine_fwd": (_I, "pppp" + "df" + "ppp" + "iii" + "p"),
+    "rpb_gn_affine_bwd": (_I, "ppppp" + "d" + "ppppp" + "iii" + "p"),
+    "rpb_silu_fwd": (_I, "pp" + "l" + "p"),
+    "rpb_silu_bwd": (_I, "ppp" + "l" + "p"),
+    "rpb_relpos_bias_fwd": (_I, "ppp" + "ii" + "p"),
+    "rpb_relpos_bias_bwd": (_I, "ppp" + "iii" + "p"),
     "rpb_im2col": (_I, "pp" + "iiiiiii" + "p"),
     "rpb_tattn_blocks": (_I, "l"),
     "rpb_tattn_fwd": (_I, "ppppp" + "iii" + "p"),

@@ -9,8 +9,10 @@ Activations are channels-last token tensors ``[B*T*H*W][C]`` at three resolution
 * 3x3x3 convolutions, the (1,4,4)/stride-2 down-sampling convolution, the transposed up-sampling convolution (four
   output-parity classes), every 1x1 convolution / ``nn.Linear``: implicit-GEMM modes of ``rpb_gemm_nt`` on fp32 MFMA;
   their weight gradients ``rpb_gemm_tn``; the 7x7x7 ``init_conv`` (C_in = 3) as ``rpb_im2col`` + plain GEMM;
-* GroupNorm(8) + time scale/shift + SiLU: ``rpb_chan_stats`` / ``rpb_affine_silu_*`` (per-(sample, channel) passes; the
-  ``B x C``-sized algebra between them -- group statistics, the time-embedding MLPs -- is host glue under torch autograd);
+* GroupNorm(8) + time scale/shift + SiLU: ``rpb_chan_stats`` / ``rpb_affine_silu_*`` (per-(sample, channel) passes) around
+  ``rpb_gn_affine_{fwd,bwd}`` (group statistics -> per-(sample, channel) affine and back, ``B x C`` numbers); the time-embedding MLPs
+  are small ``rpb_gemm_nt`` / ``rpb_gemm_tn`` calls + ``rpb_silu_*``, the relative-position bias ``rpb_relpos_bias_*`` -- no torch
+  autograd anywhere inside the model since round 3;
 * channel LayerNorm of ``PreNorm``: ``rpb_layernorm_{fwd,bwd}``;
 * temporal attention (rotary + T5 relative-position bias): ``rpb_tattn_{fwd,bwd}``; bottleneck softmax attention:
   ``rpb_sattn_{fwd,bwd}``; spatial linear attention: ``rpb_linattn_prep_*`` + ``rpb_head_scores`` / ``rpb_head_apply``.
@@ -97,9 +99,10 @@ def _rotary_tables(freqs, T):
     return ang.cos().contiguous(), ang.sin().contiguous()
 
 
-def _rel_pos_bias(weight, n, num_buckets=32, max_distance=32):
-    """unet.py:78-116 -> [heads, n, n] (differentiable w.r.t. ``weight``; n x n x heads numbers: host glue)."""
-    q = torch.arange(n, device=weight.device)
+def _rel_pos_index(n, device, num_buckets=32, max_distance=32):
+    """unet.py:78-116: the T5 bucket of every (i, j) pair, int32 [n * n] -- integer bookkeeping, computed with the reference's own
+    expression; ``rpb_relpos_bias_{fwd,bwd}`` gather / scatter the table through it."""
+    q = torch.arange(n, device=device)
     rel = q[None, :] - q[:, None]
     nb = num_buckets // 2
     m = -rel
@@ -109,7 +112,7 @@ def _rel_pos_bias(weight, n, num_buckets=32, max_distance=32):
     large = max_exact + (torch.log(m.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
     large = torch.min(large, torch.full_like(large, nb - 1))
     ret = ret + torch.where(m < max_exact, m, large)
-    return weight[ret].permute(2, 0, 1)
+    return ret.reshape(-1).to(torch.int32).contiguous()
 
 
 class Unet3d(_ModelBase):
@@ -386,27 +389,15 @@ class Unet3d(_ModelBase):
         return y
 
     def _gn_silu(self, tp, x, name, B, n, C, ss=None, res=None):
-        """GroupNorm(8) -> x*(scale+1)+shift -> SiLU (unet.py:200-208).  ``ss``: [B, 2C] scale|shift (autograd tensor) or None."""
+        """GroupNorm(8) -> x*(scale+1)+shift -> SiLU (unet.py:200-208).  ``ss``: [B, 2C] scale|shift or None."""
         nblk = ops.chan_blocks(B, n)
         part = _new(nblk, B * 2 * C, like=x)
         ops.chan_stats(x, part, B, n, C)
-        sums = _reduce(part, nblk, B * 2 * C, f64=True).view(B, 2, GROUPS, C // GROUPS).sum(-1)       # [B,2,8] fp64
+        sums = _reduce(part, nblk, B * 2 * C, f64=True)                      # [B][2][C] fp64: per-channel sum x, sum x^2
         cnt = float(n * (C // GROUPS))
-        with torch.enable_grad():
-            S = sums.float().requires_grad_(tp.record)
-            gam = self.p(name + ".weight").detach().requires_grad_(tp.record)
-            bet = self.p(name + ".bias").detach().requires_grad_(tp.record)
-            # statistics as differentiable functions of (sum x, sum x^2): the backward pass needs d/d(sums)
-            mean_g = S[:, 0] / cnt
-            invstd_g = (S[:, 1] / cnt - mean_g * mean_g + GN_EPS).rsqrt()
-            mean_c = mean_g.repeat_interleave(C // GROUPS, dim=1)
-            inv_c = invstd_g.repeat_interleave(C // GROUPS, dim=1)
-            A = inv_c * gam
-            Bc = bet - mean_c * A
-            if ss is not None:
-                A = A * (ss[:, :C] + 1)
-                Bc = Bc * (ss[:, :C] + 1) + ss[:, C:]
-        Ad, Bd = A.detach().contiguous(), Bc.detach().contiguous()
+        gam, bet = self.p(name + ".weight").detach(), self.p(name + ".bias").detach()
+        Ad, Bd, stat = _new(B, C, like=x), _new(B, C, like=x), _new(B, GROUPS, 2, like=x)
+        ops.gn_affine_fwd(sums, gam, bet, ss, cnt, GN_EPS, Ad, Bd, stat, B, C, GROUPS)   # statistics -> y = A x + Bc (scale|shift folded in)
         y = _new(B * n, C, like=x)
         ops.affine_silu_fwd(x, Ad, Bd, y, B, n, C, res=res)        # (+ res: the identity shortcut of ResnetBlock)
 
@@ -416,16 +407,14 @@ class Unet3d(_ModelBase):
                 tp.acc(res, gy)
             part2 = _new(nblk, B * 2 * C, like=x)
             ops.affine_silu_bwd_reduce(x, gy, Ad, Bd, part2, B, n, C)
-            d = _reduce(part2, nblk, B * 2 * C).view(B, 2, C)
-            leaves = [S, gam, bet]
-            gs = torch.autograd.grad([A, Bc], leaves + ([ss] if ss is not None else []), [d[:, 0], d[:, 1]],
-                                     allow_unused=True)
-            tp.pacc(name + ".weight", gs[1])
-            tp.pacc(name + ".bias", gs[2])
+            d = _reduce(part2, nblk, B * 2 * C)                               # [B][2][C] = (dL/dA, dL/dBc)
+            dgam, dbet, Pc, Qc = (_new(B, C, like=x) for _ in range(4))
+            dss = _new(B, 2 * C, like=x) if ss is not None else None
+            ops.gn_affine_bwd(d, stat, gam, bet, ss, cnt, dgam, dbet, dss, Pc, Qc, B, C, GROUPS)
+            tp.pacc(name + ".weight", _reduce(dgam, B, C))
+            tp.pacc(name + ".bias", _reduce(dbet, B, C))
             if ss is not None:
-                tp.acc(ss, gs[3])
-            Pc = gs[0][:, 0].repeat_interleave(C // GROUPS, dim=1).contiguous()           # d/d(sum x)   -> + P
-            Qc = (2.0 * gs[0][:, 1]).repeat_interleave(C // GROUPS, dim=1).contiguous()   # d/d(sum x^2) -> + Q * x
+                tp.acc(ss, dss)
             gx = _new(B * n, C, like=x)
             ops.affine_silu_bwd_apply(x, gy, Ad, Bd, Pc, Qc, gx, B, n, C)
             tp.acc(x, gx)
@@ -452,7 +441,7 @@ class Unet3d(_ModelBase):
         return y
 
     def _temporal_attn(self, tp, x, pre, B, mesh, C, bias):
-        """Residual(PreNorm(temporal Attention)) -- unet.py:388-390.  ``bias``: [4,T,T] autograd tensor."""
+        """Residual(PreNorm(temporal Attention)) -- unet.py:388-390.  ``bias``: [4,T,T] relative-position bias (shared by every temporal attention)."""
         T, H, W = mesh
         M = B * T * H * W
         y = self._chan_ln(tp, x, pre + "norm.gamma", M, C)
@@ -553,14 +542,18 @@ class Unet3d(_ModelBase):
         n = mesh[0] * mesh[1] * mesh[2]
         ss = None
         if temb is not None and (name + ".mlp.1.weight") in self._names:
-            Wl, bl = self._leaf(tp, name + ".mlp.1.weight"), self._leaf(tp, name + ".mlp.1.bias")
-            with torch.enable_grad():
-                ss = F.silu(temb) @ Wl.t() + bl                     # [B, 2*Co] scale | shift (unet.py:223-227), host glue
+            Wl, bl = self.p(name + ".mlp.1.weight").detach(), self.p(name + ".mlp.1.bias").detach()
+            TD = temb.shape[1]
+            ss = _new(B, 2 * Co, like=x)                                         # scale | shift = Linear(SiLU(t)) (unet.py:223-227); temb
+            ops.gemm_nt(temb, Wl, ss, B, 2 * Co, TD, bias=bl)                    # arrives as SiLU(time embedding), computed once
 
             def bwd_ss():
-                gw, gb, gt = torch.autograd.grad(ss, [Wl, bl, temb], tp.grad(ss), retain_graph=True)
-                tp.pacc(name + ".mlp.1.weight", gw)
-                tp.pacc(name + ".mlp.1.bias", gb)
+                g = tp.grad(ss)
+                dW, db = _wgrad(g, temb, B, 2 * Co, TD)
+                tp.pacc(name + ".mlp.1.weight", dW)
+                tp.pacc(name + ".mlp.1.bias", db)
+                gt = _new(B, TD, like=x)
+                ops.gemm_nt(g, Wl.t().contiguous(), gt, B, TD, 2 * Co)
                 tp.acc(temb, gt)
 
             tp.add(bwd_ss)
@@ -571,12 +564,6 @@ class Unet3d(_ModelBase):
             h = self._gn_silu(tp, h, name + ".block2.norm", B, n, Co)
             return self._linear(tp, x, name + ".res_conv.weight", name + ".res_conv.bias", B * n, Co, Ci, residual=h)
         return self._gn_silu(tp, h, name + ".block2.norm", B, n, Co, res=x)
-
-    def _leaf(self, tp, name):
-        """Small parameters that take part in the host-side autograd glue (time MLPs, relative-position bias)."""
-        if name not in tp.leaves:
-            tp.leaves[name] = self.p(name).detach().requires_grad_(tp.record)
-        return tp.leaves[name]
 
     def _cat(self, tp, a, b, Ca, Cb):
         M = a.shape[0]
@@ -603,13 +590,42 @@ class Unet3d(_ModelBase):
         if self.out_time > T:
             x = x.repeat(1, self.out_time // T, 1, 1, 1)        # unet.py:520 (input replication along time; no gradient)
             T = x.shape[1]
-        tp.leaves = {}
-        with torch.enable_grad():
-            bias = _rel_pos_bias(self._leaf(tp, "time_rel_pos_bias.relative_attention_bias.weight"), T)
-            emb = torch.cat((torch.zeros(B, dim // 2, device=x.device), torch.ones(B, dim // 2, device=x.device)), -1)
-            temb = F.gelu(emb @ self._leaf(tp, "time_mlp.1.weight").t() + self._leaf(tp, "time_mlp.1.bias")) \
-                @ self._leaf(tp, "time_mlp.3.weight").t() + self._leaf(tp, "time_mlp.3.bias")
-        tp.glue = [bias, temb]
+        f = dict(device=x.device, dtype=torch.float32)
+        # ---- relative-position bias of every temporal attention (unet.py:78-116): table gathered through the bucket index map
+        tname = "time_rel_pos_bias.relative_attention_bias.weight"
+        table = self.p(tname).detach().contiguous()
+        ridx = _rel_pos_index(T, x.device)
+        bias = torch.empty(HEADS, T, T, **f)
+        ops.relpos_bias_fwd(table, ridx, bias, T * T, HEADS)
+        # ---- time embedding (unet.py:419-424 with time = 0: sin 0 | cos 0): Linear -> GELU -> Linear, then the SiLU every ResnetBlock's
+        #      scale/shift projection starts with (unet.py:223), computed once
+        TD = 4 * dim
+        emb = torch.cat((torch.zeros(B, dim // 2, **f), torch.ones(B, dim // 2, **f)), -1)
+        W1, b1 = self.p("time_mlp.1.weight").detach(), self.p("time_mlp.1.bias").detach()
+        W3, b3 = self.p("time_mlp.3.weight").detach(), self.p("time_mlp.3.bias").detach()
+        h1, h1pre, tlin, temb = (torch.empty(B, TD, **f) for _ in range(4))
+        ops.gemm_nt(emb, W1, h1, B, TD, dim, bias=b1, act=1, pre_out=h1pre)
+        ops.gemm_nt(h1, W3, tlin, B, TD, TD, bias=b3)
+        ops.silu_fwd(tlin, temb)
+
+        def bwd_glue():                 # first on the tape = last in the reverse walk: every user has accumulated by then
+            if id(bias) in tp.g:
+                gt_ = torch.empty(32, HEADS, **f)
+                ops.relpos_bias_bwd(tp.grad(bias).contiguous(), ridx, gt_, T * T, HEADS, 32)
+                tp.pacc(tname, gt_)
+            if id(temb) in tp.g:
+                gl = torch.empty(B, TD, **f)
+                ops.silu_bwd(tlin, tp.grad(temb), gl)
+                dW3, db3 = _wgrad(gl, h1, B, TD, TD)
+                gh = torch.empty(B, TD, **f)
+                ops.gemm_nt(gl, W3.t().contiguous(), gh, B, TD, TD, act=2, aux=h1pre)
+                dW1, db1 = _wgrad(gh, emb, B, TD, dim)
+                tp.pacc("time_mlp.3.weight", dW3)
+                tp.pacc("time_mlp.3.bias", db3)
+                tp.pacc("time_mlp.1.weight", dW1)
+                tp.pacc("time_mlp.1.bias", db1)
+
+        tp.add(bwd_glue)
         mesh = (T, H, W)
         M = B * T * H * W
         # ---- init conv (7^3, C_in channels) as im2col + GEMM
@@ -674,25 +690,11 @@ class Unet3d(_ModelBase):
         tp.acc(tp.out, g_out.reshape(tp.out.shape).contiguous())
         for fn in reversed(tp.ops):
             fn()
-        # ---- host-side glue graphs: relative-position bias table and the time-embedding MLP
-        bias, temb = tp.glue
-        heads, grads = [], []
-        for t in (bias, temb):
-            if id(t) in tp.g:
-                heads.append(t)
-                grads.append(tp.g.pop(id(t)))
-        names = list(tp.leaves)
-        if heads:
-            gl = torch.autograd.grad(heads, [tp.leaves[n] for n in names], grads, allow_unused=True)
-            for n, g in zip(names, gl):
-                if g is not None:
-                    tp.pacc(n, g)
         # the closures on the tape reference the tape (cycles): release the saved activations now, not at the next GC run
         pg = tp.pg
         tp.ops.clear()
         tp.g.clear()
-        tp.leaves.clear()
-        tp.glue = tp.out = None
+        tp.out = None
         return pg
 
     # ------------------------------------------------------------------ Model protocol

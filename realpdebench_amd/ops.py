@@ -464,6 +464,32 @@ def chan_stats(x, part, B, n, C):
     _lib.call("rpb_chan_stats", _p(x), _p(part), B, n, C, _stream(), label="chan_stats", nbytes=4 * B * n * C)
 
 
+def gn_affine_fwd(sums64, gamma, beta, ss, count, eps, A, Bc, stat, B, C, G):
+    _lib.call("rpb_gn_affine_fwd", _p(sums64, torch.float64), _p(gamma), _p(beta), _p(ss), float(count), float(eps), _p(A), _p(Bc),
+              _p(stat), B, C, G, _stream())
+
+
+def gn_affine_bwd(d, stat, gamma, beta, ss, count, dgam, dbet, dss, P, Q, B, C, G):
+    _lib.call("rpb_gn_affine_bwd", _p(d), _p(stat), _p(gamma), _p(beta), _p(ss), float(count), _p(dgam), _p(dbet), _p(dss), _p(P), _p(Q),
+              B, C, G, _stream())
+
+
+def silu_fwd(x, y):
+    _lib.call("rpb_silu_fwd", _p(x), _p(y), x.numel(), _stream())
+
+
+def silu_bwd(x, gy, gx):
+    _lib.call("rpb_silu_bwd", _p(x), _p(gy), _p(gx), x.numel(), _stream())
+
+
+def relpos_bias_fwd(table, idx, bias, n2, heads):
+    _lib.call("rpb_relpos_bias_fwd", _p(table), _p(idx, torch.int32), _p(bias), n2, heads, _stream())
+
+
+def relpos_bias_bwd(gbias, idx, gtable, n2, heads, nbuckets):
+    _lib.call("rpb_relpos_bias_bwd", _p(gbias), _p(idx, torch.int32), _p(gtable), n2, heads, nbuckets, _stream())
+
+
 def affine_silu_fwd(x, A, Bc, y, B, n, C, res=None):
     _lib.call("rpb_affine_silu_fwd", _p(x), _p(A), _p(Bc), _p(res), _p(y), B, n, C, _stream(), label="affine_silu_fwd",
               nbytes=(8 + 4 * (res is not None)) * B * n * C)
