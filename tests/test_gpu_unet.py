@@ -303,3 +303,73 @@ def test_c3_full_fsi_mesh_one_sample():
     for n, p in m.named_parameters():
         if p.requires_grad:
             assert torch.equal(p.grad, g1[n]), n                # run-to-run deterministic (no atomics in the backward)
+
+
+def test_groupnorm_affine_kernels_vs_fp64_autograd():
+    """rpb_gn_affine_fwd / _bwd (csrc/rpb_unet_glue.hip) against fp64 autograd of the statistics algebra they replace (unet.py:200-208 with
+    the time-embedding scale|shift of :223-229): A, Bc, d gamma, d beta, d scale|shift and the (P, Q) pair = d/d(sum x), 2 d/d(sum x^2)."""
+    from realpdebench_amd import ops
+    torch.manual_seed(3)
+    B, C, G, n = 3, 64, 8, 50
+    cg = C // G
+    cnt = float(n * cg)
+    x = torch.randn(B, n, C, dtype=torch.float64) * 1.5 + 0.3
+    S = torch.stack([x.sum(1), (x * x).sum(1)], 1).requires_grad_(True)              # [B][2][C]
+    gamma = (torch.rand(C, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, dtype=torch.float64) * 0.3).requires_grad_(True)
+    for with_ss in (True, False):
+        ss = (torch.randn(B, 2 * C, dtype=torch.float64) * 0.4).requires_grad_(True) if with_ss else None
+        Sg = S.view(B, 2, G, cg).sum(-1)
+        mean = Sg[:, 0] / cnt
+        inv = (Sg[:, 1] / cnt - mean * mean + 1e-5).rsqrt()
+        A = inv.repeat_interleave(cg, 1) * gamma
+        Bc = beta - mean.repeat_interleave(cg, 1) * A
+        if with_ss:
+            A = A * (ss[:, :C] + 1)
+            Bc = Bc * (ss[:, :C] + 1) + ss[:, C:]
+        dA, dB = torch.randn(B, C, dtype=torch.float64), torch.randn(B, C, dtype=torch.float64)
+        leaves = [S, gamma, beta] + ([ss] if with_ss else [])
+        gr = torch.autograd.grad([A, Bc], leaves, [dA, dB])
+        f = dict(device="cuda", dtype=torch.float32)
+        Ad, Bd, stat = torch.empty(B, C, **f), torch.empty(B, C, **f), torch.empty(B, G, 2, **f)
+        ssd = ss.detach().float().cuda() if with_ss else None
+        ops.gn_affine_fwd(S.detach().cuda().contiguous(), gamma.detach().float().cuda(), beta.detach().float().cuda(), ssd, cnt, 1e-5,
+                          Ad, Bd, stat, B, C, G)
+        assert rel_l2(Ad.cpu(), A.detach()) < 2e-6 and rel_l2(Bd.cpu(), Bc.detach()) < 2e-6
+        d = torch.stack([dA, dB], 1).float().cuda().contiguous()
+        dgam, dbet, P, Q = (torch.empty(B, C, **f) for _ in range(4))
+        dss = torch.empty(B, 2 * C, **f) if with_ss else None
+        ops.gn_affine_bwd(d, stat, gamma.detach().float().cuda(), beta.detach().float().cuda(), ssd, cnt, dgam, dbet, dss, P, Q, B, C, G)
+        assert rel_l2(dgam.sum(0).cpu(), gr[1]) < 5e-6 and rel_l2(dbet.sum(0).cpu(), gr[2]) < 5e-6
+        if with_ss:
+            assert rel_l2(dss.cpu(), gr[3]) < 5e-6
+        # d/dS is constant over the channels of a group: P = dS0, Q = 2 dS1 (rpb_affine_silu_bwd_apply adds P + Q x)
+        dS = gr[0].view(B, 2, G, cg)
+        assert rel_l2(P.cpu(), dS[:, 0].reshape(B, C)) < 2e-5 and rel_l2(Q.cpu(), 2 * dS[:, 1].reshape(B, C)) < 2e-5
+
+
+def test_relpos_bias_and_silu_kernels():
+    from realpdebench_amd import ops
+    from realpdebench_amd.model.unet import _rel_pos_index
+    from oracle import unet_oracle as UO
+    torch.manual_seed(4)
+    T, heads = 20, 4
+    table = torch.randn(32, heads, dtype=torch.float64, requires_grad=True)
+    ref = UO.rel_pos_bias(table, T)                                                 # the oracle's restatement of unet.py:78-116
+    idx = _rel_pos_index(T, "cuda")
+    bias = torch.empty(heads, T, T, device="cuda")
+    ops.relpos_bias_fwd(table.detach().float().cuda(), idx, bias, T * T, heads)
+    assert torch.equal(bias.cpu().double(), ref.detach().float().double())
+    g = torch.randn(heads, T, T, dtype=torch.float64)
+    ref.backward(g)
+    gt = torch.empty(32, heads, device="cuda")
+    ops.relpos_bias_bwd(g.float().cuda().contiguous(), idx, gt, T * T, heads, 32)
+    assert rel_l2(gt.cpu(), table.grad) < 2e-6
+    x = torch.randn(7, 256, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.silu(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, yd, gxd = x.detach().float().cuda(), torch.empty(7, 256, device="cuda"), torch.empty(7, 256, device="cuda")
+    ops.silu_fwd(xd, yd)
+    ops.silu_bwd(xd, gy.float().cuda(), gxd)
+    assert rel_l2(yd.cpu(), y.detach()) < 2e-6 and rel_l2(gxd.cpu(), x.grad) < 2e-6
