@@ -5,7 +5,10 @@
  *   - every function is stream-ordered on the `hipStream_t` passed as `void* stream`, never synchronises,
  *     never allocates; scratch ("partial rows") is caller-allocated, sized by the `*_rows/_slots` queries;
  *   - returns 0 on success, <0 on error (RPB_ERR_*); `rpb_last_error()` returns a thread-local message;
- *   - fp32 everywhere (the reference is fp32; matrix work uses v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains).
+ *   - fp32 STORAGE everywhere unless an entry point says bf16 (the reference is fp32).  Arithmetic of the contractions: at the shapes
+ *     the reference's YAMLs use (C = 64, token GEMMs with K >= 256, 3x3x3 convolutions) v_mfma_f32_{16x16x32,32x32x16}_bf16 on operands split
+ *     into three bf16 planes, six products per fp32 product with fp32 accumulation (dropped terms <= 2^-24 |a b|: fp32-grade, Rel-L2 ~2e-7
+ *     against fp64); other shapes and the RPB_*_F32 / RPB_*_EXACT switches use v_mfma_f32_32x32x2_f32 = exact fp32 FMA chains.
  *
  * Tensor layouts (MI355X-first, not the reference's):
  *   activations   [B][Tp][Hp][Wp][C]       channels-last, one cell = C contiguous floats (256 B at C=64)
