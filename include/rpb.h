@@ -398,6 +398,12 @@ int rpb_head_bwd_row(int DO);
 int rpb_head_bwd(const float* s, const float* w1, const float* b1, const float* w2, const float* gout, float* g, float* part, int B,
                  int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean, const float* xf_invstd,
                  const float* xf_gamma, const float* xf_beta, void* stream);
+/*      rpb_head_fwd_bwd (fused trainer): the same pass with the head's FORWARD, the squared-error loss and dLoss/dout formed inside --
+ *      out = fc2 gelu(fc1 a + b1) + b2, loss_part [rpb_head_bwd_slots] = per-wave sums of (out - target)^2, gout = gscale (out - target);
+ *      replaces rpb_proj_fwd + rpb_mse + rpb_head_bwd of a training step (fno.py:121-125, utils/metrics.py:11-13, train.py:328-329). */
+int rpb_head_fwd_bwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* target, float gscale,
+                     float* g, float* part, float* loss_part, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp,
+                     const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta, void* stream);
 int rpb_head_bwd_finalize(const float* tot, const float* w1, const float* gamma, const float* beta, int DO, float* dw1, float* dw2,
                           float* db1, float* db2, float* bn_sums, void* stream);
 

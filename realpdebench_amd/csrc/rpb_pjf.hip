@@ -85,7 +85,10 @@ struct PjfArgs {
     const float* w1;      // fc1.weight [128][64]
     const float* b1;      // [128]
     const float* w2;      // fc2.weight [DO][128]
-    const float* gout;    // [ncrop][DO]
+    const float* gout;    // [ncrop][DO]  (LOSS: the TARGET y instead -- the kernel forms out = fc2 gelu(u) + b2 and gout = gscale (out - y) itself)
+    const float* b2;      // LOSS: fc2.bias [DO]
+    float gscale;         // LOSS: 2 / (number of output elements over all ranks)
+    float* loss_part;     // LOSS: [slots] partial sums of (out - y)^2
     float* g;             // [ncell][64] gradient w.r.t. the layer output, padded layout
     float* part;          // [slots][128*64 + DO*128 + 128 + DO]   (M = gh^T shat | d fc2 | d b1 | d b2)
     int B, DO;
@@ -103,7 +106,9 @@ struct PjfArgs {
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma16(AH(c_), BH(c_), ACC(c_));
 
 // DOT = register bound on the fc2 output features; EXACT: DO == DOT (vector loads of gout)
-template <int DOT, bool EXACT>
+// LOSS: the head's FORWARD rides along (fused trainer): gout is not an input but scale * (fc2 gelu(u) + b2 - y), the squared error is
+// summed per wave -- rpb_proj_fwd and rpb_mse disappear from the training step (u = fc1 a is recomputed here anyway)
+template <int DOT, bool EXACT, bool LOSS>
 __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
     extern __shared__ u32x4 lds4[];
     u32x4* W1B = lds4;                                   // [ks 2][plane 3][t 8][lane]    B of u = a W1^T    (columns = hidden 16 t + n16)
@@ -179,6 +184,9 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < DOT; ++j) db2[j] = 0.f;
+    float b2v[DOT], lacc = 0.f;
+#pragma unroll
+    for (int j = 0; j < DOT; ++j) b2v[j] = (LOSS && j < DO) ? p.b2[j] : 0.f;
     f32x4v acc3[8][4];                                   // M: [hidden tile t][channel tile u]; row 16 t + 4 mg + r, column = channel 4 n16 + u
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                 db1[t] += (gh[0] + gh[1]) + (gh[2] + gh[3]);
             };
             // ---- region 1: split of the first K-step (needs this tile's A-layout loads); the B-layout view of THIS tile starts its way
-            issue_xr(pl, q);                                         // L1 / L2 hits: the lines were fetched by the xa loads
+            if (!LOSS) issue_xr(pl, q);                              // L1 / L2 hits: the lines were fetched by the xa loads
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -349,25 +357,94 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
                 PF_SGB(0x002, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- region 3: second K-step of pair p (24 MFMAs)  ||  activation of pair p - 1 (whose accumulators are final)
+            if (LOSS) {
+                // ---- region 3 (fused forward): all second-K-step products, then one 16-cell row tile at a time:
+                //      v = gelu(u), out = fc2 v + b2 (per-lane partial over the lane's hidden units, summed over the 16 lanes of the
+                //      group with DPP), gout = gscale (out - y), then gh / d fc2 / d b1 as in the plain kernel
 #pragma unroll
-            for (int pp = 0; pp < 5; ++pp) {
-                if (pp < 4) mac_pair(1, 2 * pp);
-                if (pp > 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        act(j, 2 * pp - 2);
-                        act(j, 2 * pp - 1);
-                    }
-                }
-                if (pp > 0 && pp < 4) {
-#pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        PF_SGB(0x008, 1, 0);
-                        PF_SGB(0x002, 11, 0);
-                    }
-                }
+                for (int t0 = 0; t0 < 8; t0 += 2) mac_pair(1, t0);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 1) issue_xr(pl, q);                                      // (held back: registers) in flight during the second row tile
+                    f32x4v VV[8];
+                    float po[4][DOT];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int jj = 0; jj < DOT; ++jj) po[r][jj] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const f32x4v u = acc[j][t];
+                        const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
+                        const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
+                        const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
+                        f32x4v ex;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(q2[r]);
+                        VV[t] = u * cdf;
+                        acc[j][t] = cdf + u * (ex * 0.39894228040143267794f);          // gelu'(u), until gh replaces it below
+#pragma unroll
+                        for (int jj = 0; jj < DOT; ++jj) {
+                            const float w = w2l[jj * PF_HID + 16 * t + n16];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) po[r][jj] = fmaf(VV[t][r], w, po[r][jj]);
+                        }
+                        if (t & 1) __builtin_amdgcn_sched_barrier(0);                  // two hidden tiles in flight: bounds the temporaries
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = 32 * q + 16 * j + 4 * kg + r < cm.W;       // cells past the line end: no output element there
+#pragma unroll
+                        for (int jj = 0; jj < DOT; ++jj) {
+                            float v = po[r][jj];                                      // sum over the 16 lanes n16 of the lane group
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+                            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+                            const float diff = (v + b2v[jj]) - go[4 * j + r][jj];     // go holds the target y here
+                            lacc += (valid && n16 == 0 && jj < DO) ? diff * diff : 0.f;
+                            go[4 * j + r][jj] = (valid && jj < DO) ? p.gscale * diff : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        f32x4v gp = z4;
+#pragma unroll
+                        for (int jj = 0; jj < DOT; ++jj) {
+                            const f32x4v gv = {go[4 * j][jj], go[4 * j + 1][jj], go[4 * j + 2][jj], go[4 * j + 3][jj]};
+                            gp += gv * w2l[jj * PF_HID + 16 * t + n16];
+                            const f32x4v pr = gv * VV[t];
+                            dw2[jj][t] += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                        }
+                        const f32x4v gh = gp * acc[j][t];
+                        acc[j][t] = gh;
+                        db1[t] += (gh[0] + gh[1]) + (gh[2] + gh[3]);
+                        if (t & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // ---- region 3: second K-step of pair p (24 MFMAs)  ||  activation of pair p - 1 (whose accumulators are final)
+    #pragma unroll
+                for (int pp = 0; pp < 5; ++pp) {
+                    if (pp < 4) mac_pair(1, 2 * pp);
+                    if (pp > 0) {
+    #pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            act(j, 2 * pp - 2);
+                            act(j, 2 * pp - 1);
+                        }
+                    }
+                    if (pp > 0 && pp < 4) {
+    #pragma unroll
+                        for (int i = 0; i < 24; ++i) {
+                            PF_SGB(0x008, 1, 0);
+                            PF_SGB(0x002, 11, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < DOT; ++jj)
@@ -505,6 +582,10 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
         for (int off = TQ * 32 * 256 + lane * 16; off < (int)line_bytes; off += 1024) st16(z4, ro, off);
     }
 
+    if (LOSS) {
+        const float ls = wave_sum(lacc);
+        if (lane == 0) p.loss_part[slot] = ls;
+    }
     // ---- the wave's partial row
     float* part = p.part + slot * ((long)PF_HID * 64 + (long)DO * PF_HID + PF_HID + DO);
 #pragma unroll
@@ -569,6 +650,25 @@ extern "C" int rpb_head_bwd_row(int DO) { return PF_HID * 64 + DO * PF_HID + PF_
 // g [ncell][64] = crop-scatter(gh fc1) with gh = (fc2^T gout) * gelu'(fc1 a + b1), a = gamma * shat + beta, shat = (s - mean) * invstd on
 // the cropped cells;  part [rpb_head_bwd_slots][rpb_head_bwd_row(DO)] = per-wave partial sums (M = gh^T shat | d fc2.weight | d fc1.bias |
 // d fc2.bias): reduce over rows, then rpb_head_bwd_finalize
+static int pjf_launch(PjfArgs& p, bool loss, hipStream_t st) {
+    const int grid = (int)(rpb_head_bwd_slots(p.B, p.cm.T, p.cm.H) / PF_WAVES);
+    const size_t lds = pjf_lds();
+    const int DO = p.DO;
+#define RPB_PJF(D_, E_, L_)                                                                                                   \
+    if (loss == L_) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)pjf_kernel<D_, E_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((pjf_kernel<D_, E_, L_>), dim3(grid), dim3(PF_WAVES * 64), lds, st, p);                            \
+    }
+#define RPB_PJF2(D_, E_) RPB_PJF(D_, E_, false) RPB_PJF(D_, E_, true)
+    if (DO == 2) { RPB_PJF2(2, true) }
+    else if (DO == 1) { RPB_PJF2(2, false) }
+    else if (DO == 4) { RPB_PJF2(4, true) }
+    else { RPB_PJF2(4, false) }
+#undef RPB_PJF2
+#undef RPB_PJF
+    RPB_CHECK_LAUNCH("head_bwd");
+}
+
 extern "C" int rpb_head_bwd(const float* s, const float* w1, const float* b1, const float* w2, const float* gout, float* g,
                             float* part, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const float* xf_mean,
                             const float* xf_invstd, const float* xf_gamma, const float* xf_beta, void* stream) {
@@ -579,19 +679,26 @@ extern "C" int rpb_head_bwd(const float* s, const float* w1, const float* b1, co
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.gout = gout; p.g = g; p.part = part; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
     p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, 0};
-    const int grid = (int)(rpb_head_bwd_slots(B, T, H) / PF_WAVES);
-    const size_t lds = pjf_lds();
-#define RPB_PJF(D_, E_)                                                                                                  \
-    {                                                                                                                    \
-        (void)hipFuncSetAttribute((const void*)pjf_kernel<D_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((pjf_kernel<D_, E_>), dim3(grid), dim3(PF_WAVES * 64), lds, (hipStream_t)stream, p);           \
-    }
-    if (DO == 2) RPB_PJF(2, true)
-    else if (DO == 1) RPB_PJF(2, false)
-    else if (DO == 4) RPB_PJF(4, true)
-    else RPB_PJF(4, false)
-#undef RPB_PJF
-    RPB_CHECK_LAUNCH("head_bwd");
+    return pjf_launch(p, false, (hipStream_t)stream);
+}
+
+// The training step's head in ONE launch (fused trainer): forward out = fc2 gelu(fc1 a + b1) + b2 on the cropped cells, the squared-error
+// loss against `target` [ncrop][DO] (loss_part [rpb_head_bwd_slots] = per-wave sums of (out - target)^2), dLoss/dout = gscale (out - target)
+// and the whole backward of rpb_head_bwd from it.  Replaces rpb_proj_fwd + rpb_mse + rpb_head_bwd (fno.py:121-125, utils/metrics.py:11-13,
+// train.py:328-329): fc1 is recomputed by the backward anyway.
+extern "C" int rpb_head_fwd_bwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* target,
+                                float gscale, float* g, float* part, float* loss_part, int B, int DO, int T, int H, int W, int Tp, int Hp,
+                                int Wp, const float* xf_mean, const float* xf_invstd, const float* xf_gamma, const float* xf_beta,
+                                void* stream) {
+    RPB_REQUIRE(s && w1 && b1 && w2 && b2 && target && g && part && loss_part && xf_mean && xf_invstd && xf_gamma && xf_beta, "head_fwd_bwd: null pointer");
+    RPB_REQUIRE(rpb_head_bwd_supported(64, DO, W, Wp, 0, 0), "head_fwd_bwd: unsupported shape (DO=%d W=%d Wp=%d)", DO, W, Wp);
+    RPB_REQUIRE((long)Wp * 256 < (1L << 31), "head_fwd_bwd: line too long");
+    PjfArgs p{};
+    p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.gout = target; p.b2 = b2; p.gscale = gscale; p.loss_part = loss_part; p.g = g; p.part = part;
+    p.B = B; p.DO = DO;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    p.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, 0};
+    return pjf_launch(p, true, (hipStream_t)stream);
 }
 
 // tot [rpb_head_bwd_row(DO)] = the reduced partial row.  Writes d fc1.weight [128][64] = gamma_c M + beta_c db1, d fc2.weight [DO][128],

@@ -111,6 +111,9 @@ class _Workspace:
                 self.hb_slots, self.hb_row = ops.head_bwd_slots(d), ops.head_bwd_row(model.dim_out)
                 self.hb_part = torch.empty(self.hb_slots * self.hb_row, **f)
                 self.hb_tot = torch.empty(self.hb_row, **f)
+                self.hb_loss_part = torch.empty(self.hb_slots, **f)
+                # fused trainer: the head's forward + loss ride in the backward launch (RPB_HEAD_LOSS_FUSED=0: proj_fwd + mse + head_bwd)
+                self.head_loss_fused = os.environ.get("RPB_HEAD_LOSS_FUSED", "1") != "0"
             if self.proj_fused:
                 self.pw_slots, self.pw_row, self.pw_roles = ops.proj_wgrad_slots(d), ops.proj_wgrad_row(model.dim_out), ops.proj_wgrad_roles()
                 self.pw_part = torch.empty(self.pw_slots * self.pw_row, **f)
@@ -398,7 +401,9 @@ class FNO3d(Model):
         mean = ws.mean[l] if training else self.bn_running_mean[l]
         return (mean, ws.invstd[l], self.pview(f"bns.{l}.weight"), self.pview(f"bns.{l}.bias"), l < self.n_layers - 1)
 
-    def _forward_impl(self, x, ws, training):
+    def _forward_impl(self, x, ws, training, skip_head=False):
+        """``skip_head`` (fused trainer with the one-launch head): stop after the last Fourier layer; ``_backward_impl(target=...)`` runs the
+        head's forward inside its backward launch."""
         d, C, L = ws.d, self.width, self.n_layers
         grids, plan = self._consts(x.device)
         P = self.pview
@@ -457,6 +462,8 @@ class FNO3d(Model):
                     ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, None, d.ncell, C, C,
                                  2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 a_in, xf = s, None
+        if skip_head:
+            return None
         if not training and ws.bf16:
             ops.proj_fwd_bf16(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
                               act=self.proj_act)
@@ -465,8 +472,10 @@ class FNO3d(Model):
                          xf=xf, act=self.proj_act)
         return ws.out
 
-    def _backward_impl(self, x, gout, ws, gflat):
-        """gout [ncrop][DO] = dLoss/d(fc2 output); writes every parameter gradient into ``gflat``."""
+    def _backward_impl(self, x, gout, ws, gflat, target=None, gscale=None):
+        """gout [ncrop][DO] = dLoss/d(fc2 output); writes every parameter gradient into ``gflat``.  With ``target`` (and ``gout`` None; the
+        forward ran with ``skip_head``): the head's forward, the squared-error partial sums (``ws.hb_loss_part``) and
+        gout = gscale * (out - target) are formed inside the head's backward launch."""
         d, C, L, DO = ws.d, self.width, self.n_layers, self.dim_out
         grids, plan = self._consts(x.device)
         P = self.pview
@@ -479,7 +488,11 @@ class FNO3d(Model):
             # one pass over (s, gout): g, and the partial rows of M = gh^T shat, d fc2, d fc1.bias, d fc2.bias; the finalize kernel
             # derives d fc1.weight and the BatchNorm-backward sums of the last layer from them (csrc/rpb_pjf.hip)
             w1 = P("fc1.weight")
-            ops.head_bwd(a_last, w1, P("fc1.bias"), P("fc2.weight"), gout, g, ws.hb_part, d, DO, xf_last)
+            if target is not None:
+                ops.head_fwd_bwd(a_last, w1, P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), target, gscale, g, ws.hb_part, ws.hb_loss_part,
+                                 d, DO, xf_last)
+            else:
+                ops.head_bwd(a_last, w1, P("fc1.bias"), P("fc2.weight"), gout, g, ws.hb_part, d, DO, xf_last)
             ops.reduce_partials(ws.hb_part, ws.hb_slots, ws.hb_row, out_f32=ws.hb_tot)
             ops.head_bwd_finalize(ws.hb_tot, w1, xf_last[2], xf_last[3], DO, GP("fc1.weight"), GP("fc2.weight"), GP("fc1.bias"),
                                   GP("fc2.bias"), ws.bn_sums)

@@ -739,6 +739,16 @@ def head_bwd(s, w1, b1, w2, gout, g, part, d, DO, xf):
               flops=2 * d.ncrop * 128 * 3 * d.C)
 
 
+def head_fwd_bwd(s, w1, b1, w2, b2, target, gscale, g, part, loss_part, d, DO, xf):
+    """The training step's head in one launch: forward + squared-error loss + dLoss/dout + the whole backward (csrc/rpb_pjf.hip)."""
+    mean, invstd, gamma, beta, gelu = xf
+    if gelu:
+        raise _lib.RpbError("head_fwd_bwd: the layer in front of the head must not end in GELU")
+    _lib.call("rpb_head_fwd_bwd", _p(s), _p(w1), _p(b1), _p(w2), _p(b2), _p(target), float(gscale), _p(g), _p(part), _p(loss_part), d.B, DO,
+              *d.crop6, _p(mean), _p(invstd), _p(gamma), _p(beta), _stream(), label="head_fwd_bwd",
+              nbytes=4 * (d.ncrop * (d.C + DO) + d.ncell * d.C), flops=2 * d.ncrop * 128 * (3 * d.C + DO))
+
+
 def head_bwd_finalize(tot, w1, gamma, beta, DO, dw1, dw2, db1, db2, bn_sums):
     _lib.call("rpb_head_bwd_finalize", _p(tot), _p(w1), _p(gamma), _p(beta), DO, _p(dw1), _p(dw2), _p(db1), _p(db2), _p(bn_sums),
               _stream(), label="head_bwd_finalize")

@@ -46,14 +46,23 @@ class Trainer:
         ws = model._workspace(B, True, x.device)
         dp = model.dp
         world = dp.world_size if dp is not None else 1
-        out = model._forward_impl(x, ws, training=True)                       # [ncrop][DO]
         tgt = model._unshape_grad(target.contiguous().float(), B)
-        n = out.numel()
-        ops.mse(out, tgt, None, ws.gout, ws.mse_part, n, 2.0 / 2.0 / (n * world))   # gout = 2*(p-t)/N_global
-        ops.reduce_partials(ws.mse_part, ws.mse_part.numel(), 1, out_f32=ws.loss, scale=1.0 / n)
-        if dp is not None:
-            dp.begin_step(self.grad)
-        model._backward_impl(x, ws.gout, ws, self.grad)
+        n = tgt.numel()
+        if getattr(ws, "head_fused", False) and ws.head_loss_fused:
+            # one-launch head (csrc/rpb_pjf.hip): its forward, the squared error and dLoss/dout = 2 (pred - target) / N_global are formed
+            # inside the head's backward kernel -- no rpb_proj_fwd, no rpb_mse, no pred tensor in the training step
+            model._forward_impl(x, ws, training=True, skip_head=True)
+            if dp is not None:
+                dp.begin_step(self.grad)
+            model._backward_impl(x, None, ws, self.grad, target=tgt, gscale=2.0 / (n * world))
+            ops.reduce_partials(ws.hb_loss_part, ws.hb_slots, 1, out_f32=ws.loss, scale=1.0 / n)
+        else:
+            out = model._forward_impl(x, ws, training=True)                   # [ncrop][DO]
+            ops.mse(out, tgt, None, ws.gout, ws.mse_part, n, 2.0 / 2.0 / (n * world))   # gout = 2*(p-t)/N_global
+            ops.reduce_partials(ws.mse_part, ws.mse_part.numel(), 1, out_f32=ws.loss, scale=1.0 / n)
+            if dp is not None:
+                dp.begin_step(self.grad)
+            model._backward_impl(x, ws.gout, ws, self.grad)
         if dp is not None:
             dp.finish_step(self.grad)
         gscale = 1.0

@@ -627,6 +627,19 @@ def test_head_backward_one_pass(ops, B, T, H, W, pad, DO):
     assert rel_l2(dw1.cpu(), w1.grad) < 5e-6 and rel_l2(dw2.cpu(), w2.grad) < 5e-6
     assert rel_l2(db1.cpu(), b1.grad) < 5e-6 and rel_l2(db2.cpu(), b2.grad) < 5e-6
     assert rel_l2(sums[0].cpu(), g_ref.sum(0)) < 2e-5 and rel_l2(sums[1].cpu(), (g_ref * sh.detach()).sum(0)) < 2e-5
+    # ---- rpb_head_fwd_bwd: the same pass with the forward, the squared-error loss and dLoss/dout = gscale (out - y) formed inside
+    y = out.detach() - gout / 0.37                          # chosen so that 0.37 (out - y) == gout: every gradient above must come out again
+    g2 = torch.full((d.ncell, C), float("nan"), device="cuda")
+    part2 = torch.full((slots, row), float("nan"), device="cuda")
+    lpart = torch.full((slots,), float("nan"), device="cuda")
+    ops.head_fwd_bwd(dev(s.detach()), W1, dev(b1.detach()), dev(w2.detach()), dev(b2.detach()), dev(y), 0.37, g2, part2, lpart, d, DO, xf)
+    assert rel_l2(g2.cpu(), g_ref) < 2e-5                   # gout itself carries the forward's rounding now (out - y cancels ~3 digits)
+    assert abs(float(lpart.double().sum()) - float(((out.detach() - y) ** 2).sum())) < 2e-5 * float(((out.detach() - y) ** 2).sum())
+    tot2 = torch.empty(row, device="cuda")
+    ops.reduce_partials(part2, slots, row, out_f32=tot2)
+    ops.head_bwd_finalize(tot2, W1, xf[2], xf[3], DO, dw1, dw2, db1, db2, sums)
+    assert rel_l2(dw1.cpu(), w1.grad) < 2e-5 and rel_l2(dw2.cpu(), w2.grad) < 2e-5
+    assert rel_l2(db1.cpu(), b1.grad) < 2e-5 and rel_l2(db2.cpu(), b2.grad) < 2e-5
 
 
 @pytest.mark.parametrize("feat_w,Wp,K2f", [(0, 70, 32), (0, 134, 32), (8, 134, 32), (0, 45, 24), (32, 40, 16)])

@@ -178,6 +178,11 @@ if "proj" in which and ops.head_bwd_supported(C, 2, W, d.Wp, False, 0):
     timeit("head_bwd (one pass, gh never in HBM)", lambda: ops.head_bwd(x, w1, b1, w2, gout, g, hp, d, 2, xfl),
            4 * (d.ncrop * (C + 2) + d.ncell * C), 2 * d.ncrop * 128 * 3 * C)
 
+    lp = torch.empty(ops.head_bwd_slots(d), **f)
+    timeit("head_fwd_bwd (forward + loss + backward, one pass)",
+           lambda: ops.head_fwd_bwd(x, w1, b1, w2, b2, gout, 1e-7, g, hp, lp, d, 2, xfl),
+           4 * (d.ncrop * (C + 2) + d.ncell * C), 2 * d.ncrop * 128 * (3 * C + 2))
+
 if "lift" in which:
     xin = torch.randn(B, T, H, W, Cin, **f)
     grids = [torch.linspace(0, 1, n, **f) for n in (T, H, W)]
