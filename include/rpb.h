@@ -482,6 +482,13 @@ int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, co
                           int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
                           const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* scratch, void* stream);
 
+/* ---- rollout: eval cell_mix of the LAST Fourier layer (reference fno.py:117-121: BatchNorm without GELU, then the crop
+ *      x[..., :-6, :-6, :-6, :] feeds fc1): only the B * T * H lines of the crop are produced and of each line the 32-cell tiles up to
+ *      cell W - 1; pad cells of `out` are left untouched (rpb_proj_fwd reads the crop only).  bf16_io != 0: x / out bf16 [ncell][64]. */
+int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out, int B, int T,
+                           int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
+                           const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io, void* stream);
+
 /* ---- DPOT: AFNO patch transformer (realpdebench/model/dpot.py + dpot_libs/models/dpot.py).  Tokens are
  *      channels-last rows; the dense layers run on rpb_gemm_nt / rpb_gemm_tn, the 2-D DFT stages on rpb_axis_gemm.
  *      rpb_dpot_patch_tokens: PatchEmbed's input gather -- P[((b*nx + px)*ny + py)*T + t][(c*ps + i)*ps + j] for the conv weight

@@ -22,6 +22,8 @@ struct CmxArgs {
     const float* FWt;     // eval (STATS == 0 with the output transform): forward W-stage matrix [Wp][K2f] of the NEXT layer's spectral branch ...
     float* y1out;         // ... and its result [G][K2f][64] = that stage applied to the activated line this launch writes (fused: the
     int K2f;              //     activations are not read again for it); null = off
+    int crop_T, crop_H, crop_W, Tp, Hp;   // crop_T > 0 (eval, no statistics, no fused stage): only lines t < crop_T, h < crop_H of each [Tp][Hp] sample
+                                          // are produced, and of each line the tiles up to cell crop_W - 1 (the projection head reads nothing else)
     void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
 };
 

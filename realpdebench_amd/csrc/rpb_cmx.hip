@@ -180,8 +180,17 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     // ---- work item = one (b,t,h) line of Wp cells, walked in TQ = ceil(Wp / 32) wave tiles by ONE wave: the line's z2 row is
     //      fetched from HBM exactly once chip-wide and split once; tiles never straddle lines (the last tile of a line is partial:
     //      its out-of-range loads return 0 and its stores are dropped by the line's buffer descriptor)
-    const long G = a.ncell / Wp;
-    const int TQ = (Wp + 31) >> 5;
+    // crop_T > 0 (eval, last layer: only the un-padded cells are read by the projection head): the work list is the B * crop_T * crop_H
+    // lines of the crop and a line ends at the tile holding cell crop_W - 1
+    const bool crop = a.crop_T > 0;
+    const long G = crop ? (a.ncell / ((long)Wp * a.Hp * a.Tp)) * a.crop_T * a.crop_H : a.ncell / Wp;
+    const int TQ = ((crop ? a.crop_W : Wp) + 31) >> 5;
+    auto line_of = [&](long gi) -> long {
+        if (!crop) return gi;
+        const unsigned u = (unsigned)gi, th = (unsigned)(a.crop_T * a.crop_H);
+        const unsigned b = u / th, r = u - b * th, t = r / (unsigned)a.crop_H, h = r - t * (unsigned)a.crop_H;
+        return ((long)b * a.Tp + t) * a.Hp + h;
+    };
     const long nslots = (long)gridDim.x * CMX_WAVES;
     const long slot = (long)blockIdx.x * CMX_WAVES + wave;
     const unsigned line_bytes = (unsigned)Wp * (BF ? 128u : 256u);
@@ -216,23 +225,26 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     };
 
     if (slot < G) {
+        const long g0 = line_of(slot);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            issue_x(slot, 0, j, 0);
-            issue_x(slot, 0, j, 1);
+            issue_x(g0, 0, j, 0);
+            issue_x(g0, 0, j, 1);
         }
-        issue_z(slot);
+        issue_z(g0);
     }
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
     f32x4v Yacc[DFT ? 2 : 1][DFT ? 4 : 1];
-    for (long g = slot; g < G; g += nslots) {
+    for (long gi = slot; gi < G; gi += nslots) {
+        const long g = line_of(gi);
+        const long g_next = gi + nslots < G ? line_of(gi + nslots) : 0;
         const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
         const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
         for (int q = 0; q < TQ; ++q) {
             const bool last = q + 1 == TQ;
-            const long gn = last ? g + nslots : g;                           // next wave tile: (gn, qn)
+            const long gn = last ? g_next : g;                               // next wave tile: (gn, qn)
             const int qn = last ? 0 : q + 1;
-            const bool more = gn < G;
+            const bool more = !last || gi + nslots < G;
             const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
             asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS operand reads inside the loop: hoisted, they cost 150 VGPRs
 
@@ -521,7 +533,7 @@ long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
 
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
-        if (stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
+        if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
             RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the fp32 eval path (output transform), a scratch buffer and K2f <= 32");
         hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp);
         const int waves = CMX_WAVES_DFT;
@@ -538,6 +550,8 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
         }
         RPB_CHECK_LAUNCH("cell_mix(bf16x3, + next W stage)");
     }
+    if (a.crop_T > 0 && (stats != 0 || a.feat_w || a.crop_H <= 0 || a.crop_W <= 0 || a.ncell % ((long)a.Wp * a.Hp * a.Tp) != 0))
+        RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the crop-only mode is an eval path (no statistics, no fused stage, no feature input)");
     const int waves = CMX_WAVES_OF(stats);
     const int grid = (int)(rpb_cmx_stat_rows(a.ncell, a.Wp, stats) / waves);
     const size_t lds = cmx_lds(a.Wp, waves);

@@ -56,6 +56,10 @@ class _Workspace:
         self.fuse_w = (not training and not self.bf16 and C == 64 and os.environ.get("RPB_EVAL_FUSE_W", "1") != "0"
                        and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
         self.Y1f = torch.empty(G1 * N1, **f) if self.fuse_w else None
+        # eval: the last layer's cell_mix produces the crop only (the head reads nothing else): 0.70 of the cells at the headline shape
+        self.crop_last = (not training and C == 64 and model.n_layers > 1 and type(model)._lift_fwd is FNO3d._lift_fwd
+                          and os.environ.get("RPB_EVAL_CROP_LAST", "1") != "0"
+                          and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
         self.Xh = [torch.empty(B * 2 * plan.M * C, **f) for _ in range(L if training else 1)]
         self.Yh = torch.empty(B * 2 * plan.M * C, **f)
         self.mean = torch.empty(L, C, **f)
@@ -113,7 +117,8 @@ class _Workspace:
                 self.hb_tot = torch.empty(self.hb_row, **f)
                 self.hb_loss_part = torch.empty(self.hb_slots, **f)
                 # fused trainer: the head's forward + loss ride in the backward launch (RPB_HEAD_LOSS_FUSED=0: proj_fwd + mse + head_bwd)
-                self.head_loss_fused = os.environ.get("RPB_HEAD_LOSS_FUSED", "1") != "0"
+                # (fc2 widths 3-4: the fused variant keeps 32 more accumulators and spills -- measured slower at the cylinder's native C = 3)
+                self.head_loss_fused = os.environ.get("RPB_HEAD_LOSS_FUSED", "1") != "0" and model.dim_out <= 2
             if self.proj_fused:
                 self.pw_slots, self.pw_row, self.pw_roles = ops.proj_wgrad_slots(d), ops.proj_wgrad_row(model.dim_out), ops.proj_wgrad_roles()
                 self.pw_part = torch.empty(self.pw_slots * self.pw_row, **f)
@@ -455,6 +460,9 @@ class FNO3d(Model):
                 elif l == 0 and ws.featfull:
                     ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Y1, plan.GWt, s, None, d.ncell, ws.FW,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
+                elif ws.crop_last and l == L - 1:
+                    ops.cell_mix_eval_crop(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d, 2 * plan.KW,
+                                           self._layer_xf(ws, l, False))
                 elif ws.bf16:
                     ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d.ncell, C,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))

@@ -103,6 +103,17 @@ def cell_mix_bf16(x, Wm, bias, z2, GW, out, ncell, C, K2, Wp, oxf=None):
               flops=2 * ncell * C * (K2 + C))
 
 
+def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf):
+    """Eval cell_mix of the last Fourier layer over the crop only (``d`` = the padded / cropped sizes); x / out f32 or bf16 ``[ncell][64]``."""
+    bf = x.dtype == torch.bfloat16
+    assert out.dtype == x.dtype
+    nl, tq = d.B * d.T * d.H, (d.W + 31) // 32
+    ncell = nl * min(32 * tq, d.Wp)
+    _lib.call("rpb_cell_mix_eval_crop", _p(x, x.dtype), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, x.dtype), d.B, d.T, d.H, d.W, d.Tp, d.Hp,
+              d.Wp, K2, *_xf(oxf), int(bf), _stream(), label="cell_mix_bf16[crop]" if bf else "cell_mix[KC64->CO64,spec=1,stats=oxf,crop]",
+              nbytes=(4 if bf else 8) * ncell * 64 + 4 * nl * K2 * 64, flops=2 * ncell * 64 * (K2 + 64))
+
+
 _DFT_SCRATCH = {}
 
 

@@ -172,3 +172,38 @@ def test_fused_trainer_clips_like_clip_grad_norm_(gold):
     assert rel_l2((before - m2.flat.data)[sel].cpu(), upd[sel].cpu()) < 1e-4
     # and the unclipped trainer moved differently where eps matters, identically in direction
     assert abs(float(torch.linalg.vector_norm(tr.grad)) - gnorm) < 1e-5 * gnorm
+
+
+@pytest.mark.parametrize("W", [32, 40])
+def test_eval_last_layer_crop_only_equals_full_lines(W, monkeypatch):
+    """Eval forward at width 64 on lines long enough for the matrix-pipe cell_mix: the last layer produces only the crop
+    (rpb_cell_mix_eval_crop); the result is the oracle's and bit-equal to the path that computes whole padded lines, in both storages."""
+    from oracle import fno3d_oracle as O
+    from realpdebench_amd.model.fno import FNO3d
+    torch.manual_seed(11)
+    shape, modes, L, width, B = (3, 9, W, 2), (2, 4, 8), 3, 64, 2
+    sd = O.init_state_dict(modes, L, width, shape, shape, seed=5)
+    for l in range(L):
+        sd[f"bns.{l}.weight"] = torch.rand(width) + 0.5
+        sd[f"bns.{l}.bias"] = torch.randn(width) * 0.2
+        sd[f"bns.{l}.running_mean"] = torch.randn(width) * 0.1
+        sd[f"bns.{l}.running_var"] = torch.rand(width) + 0.5
+    x = torch.randn(B, *shape)
+    ref, _ = O.fno3d_forward(sd, x, modes, L, shape, shape, training=False)
+    m = FNO3d(*modes, L, width, shape, shape)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    outs = {}
+    for storage in ("f32", "bf16"):
+        for crop in ("1", "0"):
+            monkeypatch.setenv("RPB_EVAL_CROP_LAST", crop)
+            m._ws = {}
+            m.set_storage(storage)
+            with torch.no_grad():
+                outs[storage, crop] = m(x.cuda()).float().cpu().clone()
+            ws = next(iter(m._ws.values()))
+            assert ws.crop_last == (crop == "1")
+        assert torch.equal(outs[storage, "1"], outs[storage, "0"]), storage
+    m.set_storage("f32")
+    assert rel_l2(outs["f32", "1"], ref) < OUT_TOL
+    assert rel_l2(outs["bf16", "1"], ref) < 5e-3

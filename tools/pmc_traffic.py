@@ -25,6 +25,11 @@ alg = {
     "void cmx_kernel<1, false, true, false>(CmxArgs)": 4 * (ncell * (8 + 64) + G * 32 * 64),
     "void cmx_kernel<2, false, false, false>(CmxArgs)": 4 * (3 * ncell * 64 + G * 32 * 64),
     "void bwd_row_kernel<64, false>(BwdRowArgs)": 4 * (4 * ncell * 64 + G * 32 * 64),
+    "void bwr_kernel<false, true, true, false>(BwrArgs)": 4 * (4 * ncell * 64 + G * 32 * 64),
+    "void bwr_kernel<true, true, true, false>(BwrArgs)": 4 * (4 * ncell * 64 + G * 32 * 64),
+    "void bwr_kernel<false, false, false, false>(BwrArgs)": 4 * (4 * ncell * 64 + G * 32 * 64),
+    "void pjf_kernel<2, true, false>(PjfArgs)": 4 * (ncrop * 64 + ncrop * 2 + ncell * 64),
+    "void pjf_kernel<2, true, true>(PjfArgs)": 4 * (ncrop * 64 + 2 * ncrop * 2 + ncell * 64),
     "void pjx_head_kernel<false, 2, false>(PjhArgs)": 4 * (ncrop * 64 + ncrop * 2),
     "void pjx_head_kernel<true, 2, false>(PjhArgs)": 4 * (ncrop * 64 + ncrop * 2 + ncrop * 128),
     "void pjx_dgrad_kernel<true>(PjxArgs)": 4 * (ncrop * 64 + ncrop * 128 + ncell * 64),
@@ -50,7 +55,8 @@ if c1 and cf and c2:
     out += ["#", f"# cell_mix family of one train step (3 x <1>, 1 x <1,feat>, 3 x <2>): {fam / 1e9:.4f} GB per launch on average = roofline.traffic of bench.py"]
     json.dump({"source": f"{out_path} (rocprofv3 --pmc TCC_EA0_RDREQ_{{32B,64B,128B}} / TCC_EA0_WRREQ_64B passes over tools/kbench.py, B=32; family "
                          "average over the 7 launches of one train step)",
-               "bytes_per_launch": {"cell_mix": fam, "bn_bwd_row": tr.get("void bwd_row_kernel<64, false>(BwdRowArgs)")}},
+               "bytes_per_launch": {"cell_mix": fam, "bn_bwd_row": tr.get("void bwr_kernel<false, true, true, false>(BwrArgs)") or tr.get("void bwd_row_kernel<64, false>(BwdRowArgs)"),
+                                    "head_fwd_bwd": tr.get("void pjf_kernel<2, true, true>(PjfArgs)")}},
               open(os.path.join(os.path.dirname(out_path), "traffic_per_launch.json"), "w"), indent=1)
 open(out_path, "w").write("\n".join(out) + "\n")
 print("\n".join(out))
