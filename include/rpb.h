@@ -482,6 +482,12 @@ int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, co
                           int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
                           const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* scratch, void* stream);
 
+/* the same on bf16-stored activations (BASELINE.json configs[4]): x, out bf16 [ncell][64]; the fused stage is applied to the ROUNDED
+ * activations, i.e. y1 is what rpb_axis_gemm_bf16in(out, ...) would compute. */
+int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out_bf16,
+                               long ncell, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
+                               const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* scratch, void* stream);
+
 /* ---- rollout: eval cell_mix of the LAST Fourier layer (reference fno.py:117-121: BatchNorm without GELU, then the crop
  *      x[..., :-6, :-6, :-6, :] feeds fc1): only the B * T * H lines of the crop are produced and of each line the 32-cell tiles up to
  *      cell W - 1; pad cells of `out` are left untouched (rpb_proj_fwd reads the crop only).  bf16_io != 0: x / out bf16 [ncell][64]. */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "rpb_head_bwd": (_I, "ppppppp" + "ii" + "iiiiii" + "pppp" + "p"),
     "rpb_head_bwd_finalize": (_I, "pppp" + "i" + "ppppp" + "p"),
     "rpb_head_fwd_bwd": (_I, "pppppp" + "f" + "ppp" + "ii" + "iiiiii" + "pppp" + "p"),
+    "rpb_cell_mix_eval_dft_bf16": (_I, "pppppp" + "l" + "ii" + "ppppi" + "pip" + "pp"),
     "rpb_cell_mix_eval_crop": (_I, "pppppp" + "iiiiiiii" + "ppppi" + "ip"),
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
     "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),

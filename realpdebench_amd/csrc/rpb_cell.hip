@@ -540,6 +540,26 @@ extern "C" int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const floa
     c.crop_T = T; c.crop_H = H; c.crop_W = W; c.Tp = Tp; c.Hp = Hp;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
+// The same on bf16-stored activations (x, out bf16 [ncell][64]; y1 fp32): the stage sees the ROUNDED activations, i.e. exactly what
+// rpb_axis_gemm_bf16in would read back from `out`.
+extern "C" int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GW,
+                                          void* out_bf16, long ncell, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd,
+                                          const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f,
+                                          float* y1, void* scratch, void* stream) {
+    RPB_REQUIRE(x_bf16 && Wm && z2 && GW && out_bf16 && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1 && scratch,
+                "cell_mix_eval_dft_bf16: null pointer");
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f),
+                "cell_mix_eval_dft_bf16: unsupported sizes (K2=%d Wp=%d K2f=%d)", K2, Wp, K2f);
+    CmxArgs c{};
+    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.bf16_io = 1;
+    c.FWt = FWt; c.y1out = y1; c.K2f = K2f; c.gw_planes = scratch;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
 extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f) {
     return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f);
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #define CMX_WAVES_DFT 8
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false>
 __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) void cmx_kernel(CmxArgs a) {
-    static_assert(!DFT || (STATS == 0 && !BF), "fused forward W stage: fp32 eval path");
+    static_assert(!DFT || STATS == 0, "fused forward W stage: eval path");
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
     static_assert(!(BF && FEAT), "the feature tensor is fp32");
     constexpr int KSN = FEAT ? 1 : 2;                    // K-steps of the channel mixing
@@ -409,7 +409,7 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                             }
                             o[t] = v[0];
                             o[t + 1] = v[1];
-                            if (DFT) {                               // keep the stored value: operand of the fused W stage below
+                            if (DFT && !BF) {                        // keep the stored value: operand of the fused W stage below
                                 acc[j][t][r] = v[0];
                                 acc[j][t + 1][r] = v[1];
                             }
@@ -422,6 +422,11 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                             pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[0], o[1]}, bf16x2v));
                             pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[2], o[3]}, bf16x2v));
                             __builtin_amdgcn_raw_buffer_store_b64(pk, ro, q * 4096 + j * 2048 + (4 * kg + r) * 128 + m * 8, 0, 0);
+                            if (DFT) {          // the fused W stage sees what the next layer would read back: the ROUNDED values (one exact bf16 plane)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+                                    acc[j][t][r] = __builtin_bit_cast(float, (pk[t >> 1] >> (16 * (t & 1))) << 16);
+                            }
                         } else {
                             st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
                         }
@@ -451,6 +456,16 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[0][t][r];
                         v[4 + r] = half_tile ? 0.f : acc[1][t][r];            // the second MFMA tile was not computed
+                    }
+                    if (BF) {                   // exactly one plane: three products per stage-matrix plane, no split
+                        const bf16x8 yb = __builtin_bit_cast(bf16x8, u32x4{pack_hi(v[0], v[1]), pack_hi(v[2], v[3]), pack_hi(v[4], v[5]), pack_hi(v[6], v[7])});
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            Yacc[i][t] = mfma16(fl[i], yb, Yacc[i][t]);
+                            Yacc[i][t] = mfma16(fm[i], yb, Yacc[i][t]);
+                            Yacc[i][t] = mfma16(fh[i], yb, Yacc[i][t]);
+                        }
+                        continue;
                     }
                     bf16x8 yh, ym, yl;
                     split8(v, yh, ym, yl);
@@ -533,15 +548,18 @@ long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
 
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
-        if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || a.bf16_io || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
-            RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the fp32 eval path (output transform), a scratch buffer and K2f <= 32");
+        if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || (a.bf16_io && a.feat_w) || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
+            RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the eval path (output transform), a scratch buffer and K2f <= 32");
         hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp);
         const int waves = CMX_WAVES_DFT;
         const long G = a.ncell / a.Wp;
         long grid = rpb_num_cus();
         if (grid > (G + waves - 1) / waves) grid = (G + waves - 1) / waves;
         const size_t lds = cmx_lds(a.Wp, waves, true);
-        if (a.feat_w) {
+        if (a.bf16_io) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, true, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        } else if (a.feat_w) {
             (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((cmx_kernel<0, false, true, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
         } else {

@@ -18,10 +18,17 @@
 __global__ __launch_bounds__(256) void feat_mix_kernel(const float* __restrict__ Phi, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, float* __restrict__ Xh, int B, int M2,
                                                        int NB, int Cin, int C) {
-    // one thread = 4 channels of one (b, row); rows = 2 * M
+    // one thread = 4 channels of one (b, row); rows = 2 * M.  [W0 | b0] sits transposed in LDS ([F + 1][C]): per feature one 16 B LDS
+    // read and one (16-lane broadcast) global read, instead of five strided global reads
+    extern __shared__ float wt[];
     const int c4n = C >> 2;
     const long total = (long)B * M2 * c4n;
     const int F = Cin + 3;
+    for (int i = threadIdx.x; i < (F + 1) * C; i += blockDim.x) {
+        const int j = i / C, c = i - j * C;
+        wt[i] = j < F ? w0[c * F + j] : b0[c];
+    }
+    __syncthreads();
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % c4n);
         const long r = idx / c4n;
@@ -31,11 +38,9 @@ __global__ __launch_bounds__(256) void feat_mix_kernel(const float* __restrict__
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < F + 1; ++j) {
             const float v = j < Cin ? ph[b * Cin + j] : ph[B * Cin + (j - Cin)];
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wt + j * C + 4 * c4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = 4 * c4 + k;
-                acc[k] += v * (j < F ? w0[c * F + j] : b0[c]);
-            }
+            for (int k = 0; k < 4; ++k) acc[k] += v * w[k];
         }
         *reinterpret_cast<f32x4*>(Xh + ((long)b * M2 + row) * C + 4 * c4) = acc;
     }
@@ -48,7 +53,8 @@ extern "C" int rpb_feat_mix(const float* Phi, const float* w0, const float* b0, 
     long grid = (total + 255) / 256;
     const long cap = (long)rpb_num_cus() * 8;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(feat_mix_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, Phi, w0, b0, Xh, B, M2, NB, Cin, C);
+    hipLaunchKernelGGL(feat_mix_kernel, dim3((unsigned)grid), dim3(256), (size_t)(Cin + 4) * C * 4, (hipStream_t)stream, Phi, w0, b0,
+                       Xh, B, M2, NB, Cin, C);
     RPB_CHECK_LAUNCH("feat_mix");
 }
 

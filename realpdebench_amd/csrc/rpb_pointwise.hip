@@ -40,6 +40,17 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
     const int c4 = threadIdx.x % c4n, sub = threadIdx.x / c4n, nsub = blockDim.x / c4n;
     const int o = c4 * 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // wide inputs (C_in = 16: the combustion volume): the thread's 4 x C_in weights live in registers, the cell's inputs are read
+    // from LDS as 16 B vectors -- per cell 4 LDS reads instead of 32 (the kernel was LDS-bound at 1.4 TB/s)
+    constexpr bool WREG = FT > 8 && (FT - 3) % 4 == 0;
+    f32x4 wreg[WREG ? FT - 3 : 1];
+    if (WREG) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (WREG ? FT - 3 : 0); ++j) wreg[j] = *reinterpret_cast<const f32x4*>(wl + j * C + o);
+    }
+    float pre[8];
+    bool have = false;
     for (long row = blockIdx.x; row < nrows_pad; row += gridDim.x) {
         const int h = (int)(row % cm.Hp);
         const long r2 = row / cm.Hp;
@@ -57,10 +68,35 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
             }
             continue;
         }
-        __syncthreads();                                               // previous row's readers are done (and wl is filled)
         const float* xp = x + (((b * cm.T + t) * cm.H + h) * (long)cm.W) * Cin;
-        for (int idx = threadIdx.x; idx < cm.W * Cin; idx += blockDim.x) xrow[idx] = xp[idx];
+        const int rowlen = cm.W * Cin;
+        const bool pf = rowlen <= PW_THREADS * 8;                       // rows of <= 2048 inputs: the next row is prefetched into registers
+        if (pf && !have) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pre[i] = threadIdx.x + PW_THREADS * i < rowlen ? xp[threadIdx.x + PW_THREADS * i] : 0.f;
+        }
+        __syncthreads();                                               // previous row's readers are done (and wl is filled)
+        if (pf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (threadIdx.x + PW_THREADS * i < rowlen) xrow[threadIdx.x + PW_THREADS * i] = pre[i];
+        } else {
+            for (int idx = threadIdx.x; idx < rowlen; idx += blockDim.x) xrow[idx] = xp[idx];
+        }
         __syncthreads();
+        have = false;
+        if (pf && row + gridDim.x < nrows_pad) {                        // this block's next row, unless it is a pad row (those read nothing)
+            const long rn = row + gridDim.x;
+            const int hn = (int)(rn % cm.Hp);
+            const long r2n = rn / cm.Hp;
+            const int tn = (int)(r2n % cm.Tp);
+            if (hn < cm.H && tn < cm.T) {
+                const float* xn = x + ((((r2n / cm.Tp) * cm.T + tn) * cm.H + hn) * (long)cm.W) * Cin;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pre[i] = threadIdx.x + PW_THREADS * i < rowlen ? xn[threadIdx.x + PW_THREADS * i] : 0.f;
+                have = true;
+            }
+        }
         // row-constant part: bias + gt[t] * W[:, Cin] + gh[h] * W[:, Cin+1]
         const int Ci = F - 3;
         f32x4 base = *reinterpret_cast<const f32x4*>(wl + F * C + o);
@@ -71,9 +107,20 @@ __global__ __launch_bounds__(PW_THREADS) void lift_pad_kernel(const float* __res
             f32x4 v = z4;
             if (w < cm.W) {
                 v = base + wwv * gw[w];
+                if (WREG) {
 #pragma unroll
-                for (int j = 0; j < (FT > 0 ? FT - 3 : LIFT_FMAX - 3); ++j)
-                    if (FT > 0 || j < Ci) v += *reinterpret_cast<const f32x4*>(wl + j * C + o) * xrow[w * Ci + j];
+                    for (int j4 = 0; j4 < (WREG ? (FT - 3) / 4 : 0); ++j4) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + w * (FT - 3) + 4 * j4);
+                        v += wreg[4 * j4] * xv.x;
+                        v += wreg[4 * j4 + 1] * xv.y;
+                        v += wreg[4 * j4 + 2] * xv.z;
+                        v += wreg[4 * j4 + 3] * xv.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < (FT > 0 ? FT - 3 : LIFT_FMAX - 3); ++j)
+                        if (FT > 0 || j < Ci) v += *reinterpret_cast<const f32x4*>(wl + j * C + o) * xrow[w * Ci + j];
+                }
             }
             if (out_bf16) {
                 const bf16x4v b = __builtin_convertvector(f32x4w{v[0], v[1], v[2], v[3]}, bf16x4v);

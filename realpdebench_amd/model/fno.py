@@ -53,7 +53,7 @@ class _Workspace:
         self.Y1 = torch.empty(G1 * N1, **f)                                  # after W stage / before last stage
         self.Y2 = torch.empty(B * d.Tp * 2 * plan.KH * plan.KW * C, **f)     # after H stage
         # eval: cell_mix also applies the next layer's forward W stage (csrc/rpb_cmx.hip, DFT variant) into its own buffer
-        self.fuse_w = (not training and not self.bf16 and C == 64 and os.environ.get("RPB_EVAL_FUSE_W", "1") != "0"
+        self.fuse_w = (not training and C == 64 and os.environ.get("RPB_EVAL_FUSE_W", "1") != "0"
                        and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
         self.Y1f = torch.empty(G1 * N1, **f) if self.fuse_w else None
         # eval: the last layer's cell_mix produces the crop only (the head reads nothing else): 0.70 of the cells at the headline shape
@@ -450,9 +450,9 @@ class FNO3d(Model):
                 # element instead of two)
                 ops.bn_eval_prep(self.bn_running_var[l], BN_EPS, ws.invstd[l], C)
                 y1_ready = False
-                if ws.fuse_w and l < L - 1 and (l > 0 or ws.featfull):
+                if ws.fuse_w and l < L - 1 and (l > 0 or ws.featfull or ws.bf16):
                     # ... and the NEXT layer's forward W stage rides in the same launch: the activated line is never read for it
-                    feat = l == 0
+                    feat = l == 0 and ws.featfull
                     ops.cell_mix_eval_dft(ws.phic if feat else a_in, ws.wcomp if feat else P(f"convs.{l}.weight"), P(f"convs.{l}.bias"),
                                           ws.Y1, plan.GWt, s, d.ncell, 2 * plan.KW, d.Wp, self._layer_xf(ws, l, False), plan.FWt,
                                           2 * plan.KW, ws.Y1f, feat_w=ws.FW if feat else 0)

@@ -128,6 +128,12 @@ def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1
     key = (str(out.device), Wp)
     if key not in _DFT_SCRATCH:
         _DFT_SCRATCH[key] = torch.empty(3 * Wp * 16, device=out.device, dtype=torch.float32)     # GW planes, rewritten by every launch
+    if x.dtype == torch.bfloat16:
+        assert out.dtype == torch.bfloat16 and not feat_w
+        _lib.call("rpb_cell_mix_eval_dft_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, torch.bfloat16), ncell, K2, Wp,
+                  *_xf(oxf), _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label="cell_mix_bf16[+W]",
+                  nbytes=4 * ncell * 64 + 4 * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + 64 + K2f))
+        return
     _lib.call("rpb_cell_mix_eval_dft", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), ncell, K2, Wp, int(feat_w), *_xf(oxf),
               _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W]",
               nbytes=4 * ncell * (KC + 64) + 4 * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + KC + K2f))

@@ -204,6 +204,15 @@ def test_eval_last_layer_crop_only_equals_full_lines(W, monkeypatch):
             ws = next(iter(m._ws.values()))
             assert ws.crop_last == (crop == "1")
         assert torch.equal(outs[storage, "1"], outs[storage, "0"]), storage
+    # the next layer's forward W stage fused into cell_mix (both storages) against the separate stage
+    monkeypatch.setenv("RPB_EVAL_FUSE_W", "0")
+    for storage, tol in (("f32", 1e-6), ("bf16", 1e-3)):
+        m._ws = {}
+        m.set_storage(storage)
+        with torch.no_grad():
+            sep = m(x.cuda()).float().cpu()
+        assert not next(iter(m._ws.values())).fuse_w
+        assert rel_l2(outs[storage, "1"], sep) < tol, storage
     m.set_storage("f32")
     assert rel_l2(outs["f32", "1"], ref) < OUT_TOL
     assert rel_l2(outs["bf16", "1"], ref) < 5e-3
