@@ -15,13 +15,14 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 from ..dft import SpectralPlan, mode_major_to_ref_weights, ref_weights_to_mode_major
 from .model import Model
 
 HID = 128              # fc1 width, fno.py:103
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+_EVAL_GRAPH = os.environ.get("RPB_EVAL_GRAPH", "0") == "1"      # eval forward replayed from a hipGraph (FNO3d._forward_graphed)
 _ALIGN = 64            # floats: every parameter segment starts on a 256 B boundary
 
 
@@ -32,6 +33,8 @@ class _Workspace:
         d = ops.Dims(B, *model.shape_in[:3], model.dim_in, model.width, model.padding)
         self.d, self.training = d, training
         self.bf16 = (not training) and model.storage == "bf16"       # eval / rollout only: activations stored as bf16
+        self.graph = self.graph_out = self.graph_x = self.graph_key = None      # eval: hipGraph of one forward (FNO3d._forward_graphed)
+        self.graph_calls = 0
         self.generation = 0          # bumped by every training-mode forward: a backward whose graph saw an older value must not run
         C, L, plan = model.width, model.n_layers, model.plan
         f = dict(device=device, dtype=torch.float32)
@@ -702,8 +705,37 @@ class FNO3d(Model):
                                           "evaluation in torch.no_grad() as the reference does (train.py:345-361)")
             return _FNO3dFunction.apply(x, self.flat, self)
         ws = self._workspace(x.shape[0], self.training, x.device)
-        out = self._forward_impl(x, ws, training=self.training)
+        if not self.training and _EVAL_GRAPH and _lib.PROFILE is None and type(self)._forward_impl is FNO3d._forward_impl:
+            out = self._forward_graphed(x, ws)
+        else:
+            out = self._forward_impl(x, ws, training=self.training)
         return self._shape_output(out.clone(), x.shape[0])
+
+    def _forward_graphed(self, x, ws):
+        """Eval forward replayed from a hipGraph (the ~40 launches of one forward, 20-200 us each on the small spectral stages, leave
+        the host out of the loop: eval.py:314-319 calls this forward back to back).  The graph is captured on the third call with a
+        given workspace (the first two run eagerly: lazy allocations, function attributes) and reads the input through a fixed
+        staging buffer; it is dropped whenever a pointer it baked in (parameter arena, BatchNorm buffers) changes."""
+        key = (self.flat.data_ptr(), self.bn_running_mean.data_ptr(), self.bn_running_var.data_ptr(), torch.cuda.current_device())
+        if ws.graph is not None and ws.graph_key != key:
+            ws.graph = ws.graph_out = None
+            ws.graph_calls = 0
+        if ws.graph is None:
+            ws.graph_calls += 1
+            if ws.graph_calls < 3:
+                return self._forward_impl(x, ws, training=False)
+            if ws.graph_x is None:
+                ws.graph_x = torch.empty_like(x)
+            ws.graph_x.copy_(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                ws.graph_out = self._forward_impl(ws.graph_x, ws, training=False)
+            ws.graph, ws.graph_key = g, key
+        else:
+            ws.graph_x.copy_(x)
+        ws.graph.replay()
+        return ws.graph_out
 
     def train_loss(self, input, target):
         """fno.py:131-133: elementwise ``mse_loss(pred, target)`` (callers take ``.mean()``)."""

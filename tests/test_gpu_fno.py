@@ -216,3 +216,26 @@ def test_eval_last_layer_crop_only_equals_full_lines(W, monkeypatch):
     m.set_storage("f32")
     assert rel_l2(outs["f32", "1"], ref) < OUT_TOL
     assert rel_l2(outs["bf16", "1"], ref) < 5e-3
+
+
+def test_eval_forward_from_hipgraph_equals_eager(monkeypatch):
+    """RPB_EVAL_GRAPH=1: the eval forward is captured into a hipGraph on the third call with a workspace and replayed afterwards; every
+    replay (fresh inputs, parameters updated in place) is bit-equal to the eager launches.  (Off by default: replay is not faster)"""
+    import realpdebench_amd.model.fno as F
+    torch.manual_seed(3)
+    shape, modes, L, width, B = (3, 9, 40, 2), (2, 4, 8), 3, 64, 2
+    m = F.FNO3d(*modes, L, width, shape, shape).cuda().eval()
+    xs = [torch.randn(B, *shape, device="cuda") for _ in range(5)]
+    with torch.no_grad():
+        eager = [m(x).clone() for x in xs]
+        monkeypatch.setattr(F, "_EVAL_GRAPH", True)
+        m._ws = {}
+        got = [m(x).clone() for x in xs]
+        ws = next(iter(m._ws.values()))
+        assert ws.graph is not None
+        for a, b in zip(eager, got):
+            assert torch.equal(a, b)
+        m.flat.data.mul_(1.01)                           # in-place update: the graph reads the same arena
+        y_graph = m(xs[0]).clone()
+        monkeypatch.setattr(F, "_EVAL_GRAPH", False)
+        assert torch.equal(m(xs[0]), y_graph)
