@@ -104,6 +104,9 @@ SIGNATURES = {
     "rpb_mul": (_I, "ppp" + "l" + "p"),
     "rpb_add": (_I, "ppp" + "l" + "p"),
     "rpb_copy_cols": (_I, "pp" + "l" + "iiiii" + "p"),
+    "rpb_gemm3x_tn_supported": (_I, "liiii"),
+    "rpb_gemm3x_tn_splits": (_I, "lii"),
+    "rpb_gemm3x_tn": (_I, "ppp" + "l" + "iiii" + "p"),
     "rpb_gemm_tn_splits": (_I, "liii"),
     "rpb_gemm_tn": (_I, "ppp" + "l" + "iiii" + "iiii" + "p"),
     "rpb_layernorm_bwd_rows": (_L, "l"),

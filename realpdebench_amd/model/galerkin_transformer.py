@@ -137,7 +137,7 @@ class _RegressorCore(FNO3d):
 def _wgrad(G, A, M, N, K, ldg=None, lda=None):
     """(dW [N,K], db [N]) = (G^T A, colsum G): TN GEMM with split-token partials + fp64 reduction."""
     base = G.t if isinstance(G, ops.Sub) else G
-    splits = ops.gemm_tn_splits(M, N, K)
+    splits = ops.gemm_tn_splits(M, N, K, ldg=ldg, lda=lda)
     part = torch.empty(splits, N * K + N, device=base.device, dtype=torch.float32)
     ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
     tot = torch.empty(N * K + N, device=base.device, dtype=torch.float32)       # one reduction launch for [dW | db]

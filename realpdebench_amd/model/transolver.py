@@ -212,7 +212,7 @@ class Transolver(_ModelBase):
             part, taps_rev = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
             splits = part.shape[0]
         else:
-            splits = ops.gemm_tn_splits(M, N, K, False)
+            splits = ops.gemm_tn_splits(M, N, K, False, ldg=ldg, lda=lda)
             part = torch.empty(splits, N * K + N, device=G.device, dtype=torch.float32)
             ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
         dW = torch.empty(N, K, device=G.device, dtype=torch.float32)

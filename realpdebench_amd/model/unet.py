@@ -54,7 +54,7 @@ def _wgrad(G, A, M, N, K, conv=None, conv_mode=1, ldg=None, lda=None):
         part, taps_rev = ops.conv3_wgrad_parts(G, A, M, N, K // 27, conv, ldg=ldg, ldx=lda)
         splits = part.shape[0]
     else:
-        splits = ops.gemm_tn_splits(M, N, K, conv is not None, conv_mode)
+        splits = ops.gemm_tn_splits(M, N, K, conv is not None, conv_mode, ldg=ldg, lda=lda)
         part = _new(splits, N * K + N, like=G)
         ops.gemm_tn(G, A, part, M, N, K, conv=conv, conv_mode=conv_mode, ldg=ldg, lda=lda)
     dW, db = _new(N, K, like=G), _new(N, like=G)

@@ -355,12 +355,25 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
               flops=2 * M * N * K)
 
 
-def gemm_tn_splits(M, N, K, conv=False, conv_mode=1):
+def gemm_tn_split_bf16(M, N, K, ldg=None, lda=None):
+    """True when the plain weight-gradient GEMM runs on the bf16 matrix pipe from split operands (csrc/rpb_gemm3x_tn.hip)."""
+    return bool(_lib.query("rpb_gemm3x_tn_supported", M, N, K, N if ldg is None else ldg, K if lda is None else lda))
+
+
+def gemm_tn_splits(M, N, K, conv=False, conv_mode=1, ldg=None, lda=None):
+    if not conv and gemm_tn_split_bf16(M, N, K, ldg, lda):
+        return _lib.query("rpb_gemm3x_tn_splits", M, N, K)
     return _lib.query("rpb_gemm_tn_splits", M, N, K, int(conv_mode) if conv else 0)
 
 
 def gemm_tn(G, A, part, M, N, K, ldg=None, lda=None, conv=None, conv_mode=1):
     """part[splits][N*K + N]: partials of dW = G^T A(im2col) and db = colsum(G)."""
+    if conv is None and gemm_tn_split_bf16(M, N, K, ldg, lda):
+        if part.shape[0] != _lib.query("rpb_gemm3x_tn_splits", M, N, K):
+            raise _lib.RpbError("gemm_tn: size the partials with gemm_tn_splits(M, N, K, ldg=, lda=) of the same leading dimensions")
+        _lib.call("rpb_gemm3x_tn", _p(G), _p(A), _p(part), M, N, K, N if ldg is None else ldg, K if lda is None else lda, _stream(),
+                  label=f"gemm3x_tn[N{N},K{K}]", nbytes=4 * M * (N + K), flops=2 * M * N * K)
+        return
     hc, wc, dc = conv if conv else (0, 0, 0)
     mode = int(conv_mode) if conv else 0
     taps = {0: 1, 1: 27, 2: 16}[mode]

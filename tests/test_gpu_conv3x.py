@@ -136,3 +136,26 @@ def test_gemm3x_matches_fp64_and_the_fp32_kernel_epilogues(ops, monkeypatch, M, 
     ops.gemm_nt(A, W, out32, M, N, K, bias=bias, drop=(1234, 0.7), residual=res)
     assert torch.equal((out - res) == 0, (out32 - res) == 0) or rel_l2(out.cpu(), out32.cpu()) < 2e-6
     assert rel_l2(out.cpu(), out32.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,ldg,lda", [(65536, 256, 256, None, None), (70001, 512, 256, None, None), (65536 + 77, 256, 768, 800, 1024),
+                                           (131072, 768, 256, 768, 300)])
+def test_gemm3x_tn_weight_gradient_vs_fp64(ops, monkeypatch, M, N, K, ldg, lda):
+    """The split-bf16 weight-gradient GEMM (csrc/rpb_gemm3x_tn.hip) behind ops.gemm_tn: dW = G^T A and db = colsum G from row-major token
+    tensors (ragged M, leading dimensions larger than the widths, sub-block operands), fp32-grade against fp64; the exact-fp32 kernel
+    (RPB_GEMM_TN_F32=1 at library load, or unsupported shapes) agrees to the same tolerance."""
+    torch.manual_seed(M + N + K)
+    ldg_, lda_ = ldg or N, lda or K
+    Gf, Af = torch.randn(M, ldg_, device="cuda"), torch.randn(M, lda_, device="cuda")
+    assert ops.gemm_tn_split_bf16(M, N, K, ldg, lda)
+    splits = ops.gemm_tn_splits(M, N, K, ldg=ldg, lda=lda)
+    assert splits % 8 == 0
+    part = torch.full((splits, N * K + N), float("nan"), device="cuda")
+    g0, a0 = (ldg_ - N) // 2, lda_ - K                      # operand blocks that do not start at column 0
+    ops.gemm_tn(ops.Sub(Gf, g0) if g0 else Gf, ops.Sub(Af, a0) if a0 else Af, part, M, N, K, ldg=ldg, lda=lda)
+    tot = part.double().sum(0).cpu()
+    G64, A64 = Gf[:, g0:g0 + N].double().cpu(), Af[:, a0:a0 + K].double().cpu()
+    assert rel_l2(tot[:N * K].view(N, K), G64.t() @ A64) < 3e-6
+    assert rel_l2(tot[N * K:], G64.sum(0)) < 3e-6
+    # a shape the split kernel does not take (N % 256) goes to the fp32 kernel through the same entry point
+    assert not ops.gemm_tn_split_bf16(M, 128, K, ldg, lda)

@@ -35,3 +35,19 @@ for N, K in ((1024, 256), (256, 1024), (512, 256), (256, 256), (256, 512)):
     timeit(f"N={N} K={K} *gelu'(aux)", lambda: ops.gemm_nt(A, W, out, M, N, K, act=2, aux=aux), fl)
     timeit(f"N={N} K={K} bias+residual", lambda: ops.gemm_nt(A, W, out, M, N, K, bias=b, residual=res), fl)
     del A, W, out, pre, aux, res
+
+print("# weight gradients dW = G^T A (ops.gemm_tn): split-bf16 kernel, then RPB_GEMM_TN_F32-equivalent fp32 kernel through the C ABI")
+from realpdebench_amd import _lib  # noqa: E402
+for M2, N, K in ((M, 1024, 256), (M, 256, 1024), (M, 256, 512), (M, 256, 256), (4 * M, 768, 256), (4 * M, 256, 256)):
+    G, A = torch.randn(M2, N, **f), torch.randn(M2, K, **f)
+    sp = ops.gemm_tn_splits(M2, N, K)
+    part = torch.empty(sp, N * K + N, **f)
+    timeit(f"gemm_tn M={M2} N={N} K={K} split-bf16 sp={sp}", lambda: ops.gemm_tn(G, A, part, M2, N, K), 2 * M2 * N * K)
+    sp32 = _lib.query("rpb_gemm_tn_splits", M2, N, K, 0)
+    part32 = torch.empty(sp32, N * K + N, **f)
+    timeit(f"gemm_tn M={M2} N={N} K={K} fp32 MFMA sp={sp32}",
+           lambda: _lib.call("rpb_gemm_tn", G.data_ptr(), A.data_ptr(), part32.data_ptr(), M2, N, K, N, K, 0, 0, 0, 0,
+                             torch.cuda.current_stream().cuda_stream), 2 * M2 * N * K)
+    d = (part.double().sum(0) - part32.double().sum(0)).norm() / part32.double().sum(0).norm()
+    print(f"    rel. difference of the two results {float(d):.2e}")
+    del G, A, part, part32
