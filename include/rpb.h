@@ -175,7 +175,7 @@ int rpb_gemm_tn_splits(long M, int N, int K, int conv);
 int rpb_gemm_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, int conv, int Hc,
                 int Wc, int Dc, void* stream);
 /*     the same weight gradients (conv = 0) on the bf16 matrix pipe from three-plane splits of both operands (fp32-grade, six products,
- *     csrc/rpb_gemm3x_tn.hip): N, K multiples of 256, M >= 65536; part[rpb_gemm3x_tn_splits(M,N,K)][N*K + N] as above.  The token
+ *     csrc/rpb_gemm3x_tn.hip): N, K multiples of 256, M >= 4096; part[rpb_gemm3x_tn_splits(M,N,K)][N*K + N] as above.  The token
  *     tensors are read row-major as they are (the transposition to MFMA operand order happens in registers / LDS). */
 int rpb_gemm3x_tn_supported(long M, int N, int K, int ldg, int lda);
 int rpb_gemm3x_tn_splits(long M, int N, int K);

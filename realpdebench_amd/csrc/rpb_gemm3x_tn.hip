@@ -172,10 +172,15 @@ static long t3_plan(long M, int N, int K, int* splits_out) {
     return range;
 }
 
+static long t3_min_rows() {
+    static const long v = getenv("RPB_GEMM3X_TN_MIN_ROWS") ? atol(getenv("RPB_GEMM3X_TN_MIN_ROWS")) : 4096;
+    return v;
+}
+
 extern "C" int rpb_gemm3x_tn_supported(long M, int N, int K, int ldg, int lda) {
     static const bool off = getenv("RPB_GEMM_EXACT") && atoi(getenv("RPB_GEMM_EXACT")) == 1;
     static const bool off2 = getenv("RPB_GEMM_TN_F32") && atoi(getenv("RPB_GEMM_TN_F32")) == 1;
-    if (off || off2 || N <= 0 || K <= 0 || N % T3_TILE || K % T3_TILE || ldg < N || lda < K || M < 65536) return 0;
+    if (off || off2 || N <= 0 || K <= 0 || N % T3_TILE || K % T3_TILE || ldg < N || lda < K || M < t3_min_rows()) return 0;
     const int ntiles = (N / T3_TILE) * (K / T3_TILE);
     if (ntiles > rpb_num_cus() / 8) return 0;
     int splits;
@@ -192,7 +197,7 @@ extern "C" int rpb_gemm3x_tn_splits(long M, int N, int K) {
 
 extern "C" int rpb_gemm3x_tn(const float* G, const float* A, float* part, long M, int N, int K, int ldg, int lda, void* stream) {
     RPB_REQUIRE(G && A && part, "gemm3x_tn: null pointer");
-    RPB_REQUIRE(rpb_gemm3x_tn_supported(M, N, K, ldg, lda), "gemm3x_tn: M=%ld N=%d K=%d ldg=%d lda=%d unsupported (N, K multiples of 256, M >= 65536)",
+    RPB_REQUIRE(rpb_gemm3x_tn_supported(M, N, K, ldg, lda), "gemm3x_tn: M=%ld N=%d K=%d ldg=%d lda=%d unsupported (N, K multiples of 256, M >= 4096)",
                 M, N, K, ldg, lda);
     T3Args a{G, A, part, M, N, K, ldg, lda, 0, 0};
     a.range = t3_plan(M, N, K, &a.splits);

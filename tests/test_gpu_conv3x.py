@@ -138,7 +138,7 @@ def test_gemm3x_matches_fp64_and_the_fp32_kernel_epilogues(ops, monkeypatch, M, 
     assert rel_l2(out.cpu(), out32.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K,ldg,lda", [(65536, 256, 256, None, None), (70001, 512, 256, None, None), (65536 + 77, 256, 768, 800, 1024),
+@pytest.mark.parametrize("M,N,K,ldg,lda", [(4096, 1024, 1280, None, None), (4099, 256, 256, None, None), (65536, 256, 256, None, None), (70001, 512, 256, None, None), (65536 + 77, 256, 768, 800, 1024),
                                            (131072, 768, 256, 768, 300)])
 def test_gemm3x_tn_weight_gradient_vs_fp64(ops, monkeypatch, M, N, K, ldg, lda):
     """The split-bf16 weight-gradient GEMM (csrc/rpb_gemm3x_tn.hip) behind ops.gemm_tn: dW = G^T A and db = colsum G from row-major token
