@@ -10,6 +10,7 @@
 // residual), 16 B per lane through a wave-private LDS tile.  Replaces, for K % 64 == 0 and N in {64, 128, 256 k}, the nn.Linear
 // calls listed at rpb_gemm_nt in include/rpb.h.
 #include "rpb_common.h"
+#include "rpb_gemm3x2.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf16x8;
 typedef __bf16 g3_bf16x2 __attribute__((ext_vector_type(2)));
@@ -327,8 +328,12 @@ extern "C" int rpb_gemm3x(const float* A, const void* Wz, const float* bias, con
     RPB_REQUIRE(K % 64 == 0 && (N == 64 || N == 128 || N % 256 == 0) && lda % 4 == 0 && lda >= K && ldo % 4 == 0 && ldo >= N,
                 "gemm3x: N=%d K=%d lda=%d ldo=%d unsupported (K %% 64, N = 64, 128 or a multiple of 256, leading dimensions %% 4)", N, K, lda, ldo);
     RPB_REQUIRE(act >= 0 && act <= 4 && ((act != 2 && act != 4) || aux) && (!pre_out || act == 1), "gemm3x: bad activation arguments");
-    Gemm3xArgs a{A, (const uint16_t*)Wz, bias, addvec, residual, out, M, N, K, lda, ldo, act, aux, pre_out, mask,
-                 make_drop(drop_seed, drop_keep)};
+    const DropSpec dsp = make_drop(drop_seed, drop_keep);
+    if (rpb_gemm3x2_supported(M, N, K, mask != nullptr, dsp.thr != 0)) {   // N % 256 == 0, no dropout: 64-row tiles, two workgroups per CU
+        const G2Args g{A, (const uint16_t*)Wz, bias, addvec, residual, out, M, N, K, lda, ldo, act, aux, pre_out};
+        return rpb_gemm3x2_launch(g, (hipStream_t)stream);
+    }
+    Gemm3xArgs a{A, (const uint16_t*)Wz, bias, addvec, residual, out, M, N, K, lda, ldo, act, aux, pre_out, mask, dsp};
     const size_t lds = (size_t)2 * 24 * G3_BM * 16 + 24576 + 4 * 32 * 36 * 4;
     long gxl = (M + G3_BM - 1) / G3_BM;
     const long cus = rpb_num_cus() / (N > 256 ? N / 256 : 1);          // one workgroup per CU in total

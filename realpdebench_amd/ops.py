@@ -312,6 +312,7 @@ GEMM_SPLIT_WIDE_N = 8192               # ... unless the output is wide enough to
 # K <= 256, N <= 256 with an epilogue that reads or writes a second [M][N] tensor: the exact-fp32 kernel is faster (2.6 M rows, GELU +
 # residual: 3.43 vs 4.12 ms; plain: 3.14 vs 2.49 -- DESIGN.md section 9)
 GEMM_F32_SHORT_HEAVY = os.environ.get("RPB_GEMM_F32_SHORT_HEAVY", "1") != "0"
+GEMM3X_V2 = os.environ.get("RPB_GEMM3X_V2", "1") != "0"
 GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
 
 
@@ -340,7 +341,10 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     lda = (K // taps) if lda is None else lda
     ldo = N if ldo is None else ldo
     heavy_epilogue = residual is not None or aux is not None or mask is not None or pre_out is not None
-    if gemm_split_ok(M, N, K, lda, ldo, conv) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue):
+    # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no dropout) hides the epilogue; only the 128-row kernel
+    # loses to the fp32 one on short products with a heavy epilogue
+    v2 = GEMM3X_V2 and N % 256 == 0 and mask is None and not drop
+    if gemm_split_ok(M, N, K, lda, ldo, conv) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
         wsrc = W.t if isinstance(W, Sub) else W
         wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
         _lib.call("rpb_gemm3x_wprep", _p(W), _p(wz, torch.int16), N, K, _stream(), label="gemm3x_wprep", nbytes=10 * N * K)
