@@ -159,3 +159,31 @@ def test_gemm3x_tn_weight_gradient_vs_fp64(ops, monkeypatch, M, N, K, ldg, lda):
     assert rel_l2(tot[N * K:], G64.sum(0)) < 3e-6
     # a shape the split kernel does not take (N % 256) goes to the fp32 kernel through the same entry point
     assert not ops.gemm_tn_split_bf16(M, 128, K, ldg, lda)
+
+
+def test_gemm3x_tn_one_workgroup_per_cu_variant():
+    """RPB_GEMM3X_TN_TILE=256 (256 x 256 outputs per workgroup, one workgroup per CU; the default is 128 x 256, two per CU) is read when the
+    library loads: checked in a child process against fp64."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import torch
+from realpdebench_amd import ops
+torch.manual_seed(0)
+M, N, K = 70001, 512, 256
+G, A = torch.randn(M, N, device="cuda"), torch.randn(M, K, device="cuda")
+sp = ops.gemm_tn_splits(M, N, K)
+part = torch.full((sp, N * K + N), float("nan"), device="cuda")
+ops.gemm_tn(G, A, part, M, N, K)
+tot = part.double().sum(0).cpu()
+ref = G.double().cpu().t() @ A.double().cpu()
+e1 = float((tot[:N * K].view(N, K) - ref).norm() / ref.norm())
+e2 = float((tot[N * K:] - G.double().cpu().sum(0)).norm() / G.double().cpu().sum(0).norm())
+assert e1 < 3e-6 and e2 < 3e-6, (e1, e2)
+print("ok", sp)
+"""
+    env = dict(os.environ, RPB_GEMM3X_TN_TILE="256")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok 128" in r.stdout, r.stdout + r.stderr
