@@ -14,6 +14,7 @@ struct G2Args {
     int act;               // as rpb_gemm_nt: 0 none, 1 GELU (pre_out optional), 2 * gelu'(aux), 3 ReLU, 4 zero where aux <= 0
     const float* aux;
     float* pre_out;
+    DropSpec drop;         // thr != 0: in-kernel inverted dropout, same Philox counters as rpb_gemm_nt / rpb_dropout_mul (element index >> 2)
 };
 
 bool rpb_gemm3x2_supported(long M, int N, int K, bool has_mask, bool has_drop);

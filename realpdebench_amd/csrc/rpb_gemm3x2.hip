@@ -11,8 +11,10 @@
 //     per lane = two 128 B row segments per instruction through a per-tile buffer descriptor (rows past M are clipped by it);
 //   * the epilogue's reads do not depend on the product, so the first read stream of a tile (aux, else residual: 64 dwords per lane) is
 //     issued BEFORE the tile's matrix work and has arrived when the epilogue starts.
-// Not covered (rpb_gemm3x keeps them): in-kernel dropout / mask tensors (Philox yields 4 consecutive columns per counter: the row-major
-// 16 B epilogue of rpb_gemm3x fits it, this layout does not), N = 64 / 128.
+//   * in-kernel dropout: Philox yields the keep bits of 4 consecutive columns per counter, and in this layout those are 4 LANES (a quad).
+//     Lane j of a quad evaluates the counters of rows r = j (mod 4) of a block (4 instead of 16 per lane), packs their 4 x 4 keep bits,
+//     and one DPP quad broadcast per owner hands every lane the word that holds its (row, column) bit.
+// Not covered (rpb_gemm3x keeps them): mask tensors, N = 64 / 128.
 #include "rpb_gemm3x2.h"
 #include <stdlib.h>
 
@@ -48,7 +50,7 @@ __device__ __forceinline__ void g2_split8(f32x4 v0, f32x4 v1, g2_u32x4& h, g2_u3
 
 // ACT: G2Args::act; RES: a residual is added; the epilogue is straight-line code per instantiation (with run-time switches its 64
 // unrolled elements spill 70-90 registers)
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
     extern __shared__ g2_u32x4 lds4[];                                  // two stage buffers [3 planes][8 pieces of 8 k][64 rows] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
@@ -183,7 +185,22 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
             if (has_aux || RES) pre_issue(tm, pv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < 2; ++tn) {
+                unsigned keepw[4];                                      // [owner j]: bit 4 k + c = keep (row r = 4 k + j, column 4 * (col / 4) + c)
+                if (DROP) {
+                    unsigned mine = 0;
+                    const long e0 = tbase + (long)(tm * 32 + 4 * half + (lane & 3)) * a.ldo + tn * 32 + (col & ~3);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 m4 = dropout4(a.drop, (unsigned long long)(e0 + (long)(8 * k) * a.ldo) >> 2);
+                        mine |= ((m4[0] != 0.f ? 1u : 0u) | (m4[1] != 0.f ? 2u : 0u) | (m4[2] != 0.f ? 4u : 0u) | (m4[3] != 0.f ? 8u : 0u)) << (4 * k);
+                    }
+                    keepw[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, false);
+                    keepw[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, false);
+                    keepw[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, false);
+                    keepw[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, false);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int off = lane_off + (tm * 32 + 8 * (r >> 2) + (r & 3)) * ldo4 + tn * 128;
@@ -198,17 +215,20 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
                     } else if (ACT == 4) {
                         v = pv[tn][r] > 0.f ? v : 0.f;
                     }
+                    if (DROP) v = ((keepw[r & 3] >> (4 * (r >> 2) + (col & 3))) & 1u) ? v * a.drop.inv_keep : 0.f;
                     v += addv[tn];
                     if (RES) v += has_aux ? buf_load_f32(rr, off, 0) : pv[tn][r];
                     buf_store_f32(v, ro, off, 0);
                 }
+            }
         }
     }
 }
 
 bool rpb_gemm3x2_supported(long M, int N, int K, bool has_mask, bool has_drop) {
     static const int mode = getenv("RPB_GEMM3X_V2") ? atoi(getenv("RPB_GEMM3X_V2")) : 1;     // 0: off
-    return mode != 0 && !has_mask && !has_drop && N % 256 == 0 && K % 64 == 0 && M > 0;
+    (void)has_drop;
+    return mode != 0 && !has_mask && N % 256 == 0 && K % 64 == 0 && M > 0;
 }
 
 int rpb_gemm3x2_launch(const G2Args& a, hipStream_t st) {
@@ -217,13 +237,14 @@ int rpb_gemm3x2_launch(const G2Args& a, hipStream_t st) {
     const long cap = (long)rpb_num_cus() * 2 / (a.N / 256);             // two workgroups per CU in total
     if (gx > cap) gx = cap < 1 ? 1 : cap;
     const dim3 grid((unsigned)gx, a.N / 256);
-#define G2_LAUNCH(ACT_, RES_)                                                                                                  \
-    if (a.act == ACT_ && (a.residual != nullptr) == RES_) {                                                                    \
-        (void)hipFuncSetAttribute((const void*)gemm3x2_kernel<ACT_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((gemm3x2_kernel<ACT_, RES_>), grid, dim3(256), lds, st, a);                                         \
+#define G2_LAUNCH(ACT_, RES_, DROP_)                                                                                                   \
+    if (a.act == ACT_ && (a.residual != nullptr) == RES_ && (a.drop.thr != 0) == DROP_) {                                              \
+        (void)hipFuncSetAttribute((const void*)gemm3x2_kernel<ACT_, RES_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm3x2_kernel<ACT_, RES_, DROP_>), grid, dim3(256), lds, st, a);                                          \
     }
-    G2_LAUNCH(0, false) G2_LAUNCH(0, true) G2_LAUNCH(1, false) G2_LAUNCH(1, true) G2_LAUNCH(2, false) G2_LAUNCH(2, true)
-    G2_LAUNCH(3, false) G2_LAUNCH(3, true) G2_LAUNCH(4, false) G2_LAUNCH(4, true)
+#define G2_LAUNCH2(ACT_) G2_LAUNCH(ACT_, false, false) G2_LAUNCH(ACT_, true, false) G2_LAUNCH(ACT_, false, true) G2_LAUNCH(ACT_, true, true)
+    G2_LAUNCH2(0) G2_LAUNCH2(1) G2_LAUNCH2(2) G2_LAUNCH2(3) G2_LAUNCH2(4)
+#undef G2_LAUNCH2
 #undef G2_LAUNCH
     RPB_CHECK_LAUNCH("gemm3x (64-row tiles)");
 }

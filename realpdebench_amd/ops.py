@@ -341,9 +341,9 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     lda = (K // taps) if lda is None else lda
     ldo = N if ldo is None else ldo
     heavy_epilogue = residual is not None or aux is not None or mask is not None or pre_out is not None
-    # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no dropout) hides the epilogue; only the 128-row kernel
+    # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no mask tensor) hides the epilogue; only the 128-row kernel
     # loses to the fp32 one on short products with a heavy epilogue
-    v2 = GEMM3X_V2 and N % 256 == 0 and mask is None and not drop
+    v2 = GEMM3X_V2 and N % 256 == 0 and mask is None
     if gemm_split_ok(M, N, K, lda, ldo, conv) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
         wsrc = W.t if isinstance(W, Sub) else W
         wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
