@@ -313,6 +313,7 @@ GEMM_SPLIT_WIDE_N = 8192               # ... unless the output is wide enough to
 # residual: 3.43 vs 4.12 ms; plain: 3.14 vs 2.49 -- DESIGN.md section 9)
 GEMM_F32_SHORT_HEAVY = os.environ.get("RPB_GEMM_F32_SHORT_HEAVY", "1") != "0"
 GEMM3X_V2 = os.environ.get("RPB_GEMM3X_V2", "1") != "0"
+GEMM3X_V2_MIN_ROWS = 4096
 GEMM_SPLIT_MIN_ROWS = 65536           # below this the GEMM is launch-bound and the weight preparation does not pay
 
 
@@ -320,8 +321,9 @@ GEMM_SPLIT_MIN_K = int(os.environ.get("RPB_GEMM_SPLIT_MIN_K", 256))             
 GEMM_SPLIT_MIN_N = 256                # the K-split tiles of N = 64 / 128 lose to the fp32 kernel (64 vs 96 TF/s)
 
 
-def gemm_split_ok(M, N, K, lda, ldo, conv):
-    big = M >= GEMM_SPLIT_MIN_ROWS or (M >= 2048 and N >= GEMM_SPLIT_WIDE_N)
+def gemm_split_ok(M, N, K, lda, ldo, conv, v2=False):
+    # the 64-row-tile variant fills the chip from 4096 rows (DPOT's token GEMMs: 0.063 vs 0.090 ms at N = K = 1024, tools/nt_small.py)
+    big = M >= GEMM_SPLIT_MIN_ROWS or (M >= 2048 and N >= GEMM_SPLIT_WIDE_N) or (v2 and M >= GEMM3X_V2_MIN_ROWS)
     return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= GEMM_SPLIT_MIN_K
             and (N in (64, 128) or N % 256 == 0) and N >= GEMM_SPLIT_MIN_N and lda % 4 == 0 and ldo % 4 == 0)
 
@@ -344,7 +346,7 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no mask tensor) hides the epilogue; only the 128-row kernel
     # loses to the fp32 one on short products with a heavy epilogue
     v2 = GEMM3X_V2 and N % 256 == 0 and mask is None
-    if gemm_split_ok(M, N, K, lda, ldo, conv) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
+    if gemm_split_ok(M, N, K, lda, ldo, conv, v2) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
         wsrc = W.t if isinstance(W, Sub) else W
         wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
         _lib.call("rpb_gemm3x_wprep", _p(W), _p(wz, torch.int16), N, K, _stream(), label="gemm3x_wprep", nbytes=10 * N * K)
