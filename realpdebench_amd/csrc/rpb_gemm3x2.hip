@@ -5,8 +5,7 @@
 // the whole epilogue, and every epilogue read exposes a full memory latency (M = 655 k, N = 1024, K = 256: 2.5 ms plain, 3.9 ms with
 // a residual or gelu'(aux) read; tools/g3bench.py).  Here:
 //   * tiles are 64 rows x 256 columns, 4 waves x (64 x 64) = 64 accumulator registers per lane, so TWO workgroups fit a CU (2 waves per
-//     SIMD, 48 KB of LDS each): one workgroup's epilogue runs under the other's MFMAs -- across waves the vector and matrix pipes do
-//     overlap, inside one wave they do not;
+//     SIMD, 48 KB of LDS each): while one workgroup sits in its epilogue (memory waits, stores, activation code) the other issues MFMAs;
 //   * the epilogue works in ACCUMULATOR layout (lane = column, register = row): no LDS parking, no rolled loop; every access is a dword
 //     per lane = two 128 B row segments per instruction through a per-tile buffer descriptor (rows past M are clipped by it);
 //   * the epilogue's reads do not depend on the product, so the first read stream of a tile (aux, else residual: 64 dwords per lane) is

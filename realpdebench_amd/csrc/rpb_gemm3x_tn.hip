@@ -49,8 +49,8 @@ struct T3Args {
 };
 
 // TN = output rows (channels of G) per workgroup.  256: 4 waves x (128 x 128), 256 accumulator registers, one workgroup per CU.
-// 128: 4 waves x (64 x 128), 128 accumulator registers and 72 KB of LDS, so TWO workgroups share a CU and one's split / staging / barrier
-// time runs under the other's MFMAs (inside one wave vector and matrix instructions do not overlap, across waves they do).
+// 128: 4 waves x (64 x 128), 128 accumulator registers and 72 KB of LDS, so TWO workgroups share a CU and one's staging waits and
+// barriers fall into the other's MFMAs (3-5 % faster).
 template <int TN>
 __global__ __launch_bounds__(256, TN == 256 ? 1 : 2) void gemm3x_tn_kernel(T3Args a) {
     constexpr int NI = TN / 64;                                          // 32-row blocks of a wave's G range (wave grid 2 x 2)
