@@ -325,11 +325,12 @@ extern "C" int rpb_gemm3x(const float* A, const void* Wz, const float* bias, con
                           long M, int N, int K, int lda, int ldo, int act, const float* aux, float* pre_out, const float* mask,
                           long drop_seed, float drop_keep, void* stream) {
     RPB_REQUIRE(A && Wz && out && M > 0, "gemm3x: bad arguments");
-    RPB_REQUIRE(K % 64 == 0 && (N == 64 || N == 128 || N % 256 == 0) && lda % 4 == 0 && lda >= K && ldo % 4 == 0 && ldo >= N,
-                "gemm3x: N=%d K=%d lda=%d ldo=%d unsupported (K %% 64, N = 64, 128 or a multiple of 256, leading dimensions %% 4)", N, K, lda, ldo);
-    RPB_REQUIRE(act >= 0 && act <= 4 && ((act != 2 && act != 4) || aux) && (!pre_out || act == 1), "gemm3x: bad activation arguments");
     const DropSpec dsp = make_drop(drop_seed, drop_keep);
-    if (rpb_gemm3x2_supported(M, N, K, mask != nullptr, dsp.thr != 0)) {   // N % 256 == 0, no mask tensor: 64-row tiles, two workgroups per CU
+    const bool v2 = rpb_gemm3x2_supported(M, N, K, mask != nullptr, dsp.thr != 0);
+    RPB_REQUIRE(K % 64 == 0 && (N == 64 || N == 128 || N % 256 == 0 || (v2 && N % 128 == 0)) && lda % 4 == 0 && lda >= K && ldo % 4 == 0 && ldo >= N,
+                "gemm3x: N=%d K=%d lda=%d ldo=%d unsupported (K %% 64; N = 64, 128 or a multiple of 256 -- of 128 without mask / dropout; leading dimensions %% 4)", N, K, lda, ldo);
+    RPB_REQUIRE(act >= 0 && act <= 4 && ((act != 2 && act != 4) || aux) && (!pre_out || act == 1), "gemm3x: bad activation arguments");
+    if (v2) {   // N % 256 == 0, no mask tensor: 64-row tiles, two workgroups per CU
         const G2Args g{A, (const uint16_t*)Wz, bias, addvec, residual, out, M, N, K, lda, ldo, act, aux, pre_out, dsp};
         return rpb_gemm3x2_launch(g, (hipStream_t)stream);
     }

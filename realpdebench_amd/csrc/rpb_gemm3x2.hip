@@ -49,7 +49,8 @@ __device__ __forceinline__ void g2_split8(f32x4 v0, f32x4 v1, g2_u32x4& h, g2_u3
 
 // ACT: G2Args::act; RES: a residual is added; the epilogue is straight-line code per instantiation (with run-time switches its 64
 // unrolled elements spill 70-90 registers)
-template <int ACT, bool RES, bool DROP>
+// NB: 32-column blocks per wave -- 2: the workgroup covers 256 columns; 1: 128 columns (N = 128, 384, ..: short products, HBM-bound)
+template <int ACT, bool RES, bool DROP, int NB = 2>
 __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
     extern __shared__ g2_u32x4 lds4[];                                  // two stage buffers [3 planes][8 pieces of 8 k][64 rows] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
@@ -57,15 +58,15 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
     const long ntiles = (a.M + G2_BM - 1) / G2_BM;
     long tile = blockIdx.x;
     if (tile >= ntiles) return;
-    const int n0 = blockIdx.y * 256 + wave * 64;                        // the wave's 64 columns
+    const int n0 = blockIdx.y * (128 * NB) + wave * (32 * NB);          // the wave's 32 * NB columns
     const int NT = a.N >> 5, nc64 = a.K >> 6;
     const uint16_t* wbase = a.Wz + ((long)(n0 >> 5) * 64 + lane) * 8;
     const long wplane = (long)NT * 512, wchunk = 3 * wplane;
     const f32x4 zf = {0.f, 0.f, 0.f, 0.f};
 
-    float biasv[2], addv[2];
+    float biasv[NB], addv[NB];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < NB; ++tn) {
         biasv[tn] = a.bias ? a.bias[n0 + tn * 32 + col] : 0.f;
         addv[tn] = a.addvec ? a.addvec[n0 + tn * 32 + col] : 0.f;
     }
@@ -74,11 +75,11 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
     const int ldo4 = a.ldo * 4;
     const int lane_off = (4 * half * a.ldo + col) * 4;                  // byte offset of (row 4 * half, column col) inside a 32 x 32 block
 
-    auto bload = [&](const uint16_t* src, g2_u32x4 (&b)[2][3]) __attribute__((always_inline)) {
+    auto bload = [&](const uint16_t* src, g2_u32x4 (&b)[NB][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) b[tn][p] = *reinterpret_cast<const g2_u32x4*>(src + p * wplane + tn * 512);
+            for (int tn = 0; tn < NB; ++tn) b[tn][p] = *reinterpret_cast<const g2_u32x4*>(src + p * wplane + tn * 512);
     };
     // ---- A staging: 64 rows x 8 pieces of 8 columns per stage = 2 pieces (2 float4 loads each) per thread
     f32x4 sa0 = zf, sb0 = zf, sa1 = zf, sb1 = zf;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
         dst[(2 * 8 + sh) * G2_BM + 32 + row] = l;
     };
 
-    g2_u32x4 bc[2][3], bn[2][3];                                          // W operands of the current / next 16-k chunk (chunks wrap: tile after tile)
+    g2_u32x4 bc[NB][3], bn[NB][3];                                          // W operands of the current / next 16-k chunk (chunks wrap: tile after tile)
     bload(wbase, bc);
     stage_load(tile * G2_BM, 0);
     stage_store(lds4);
@@ -125,12 +126,14 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
         const bool next_tile = tile + gridDim.x < ntiles;
         long rows = a.M - m0;
         if (rows > G2_BM) rows = G2_BM;
-        const unsigned rec = (unsigned)(((rows - 1) * a.ldo + 64) * 4);  // the wave's 64 columns of the tile's valid rows
+        const unsigned rec = (unsigned)(((rows - 1) * a.ldo + 32 * NB) * 4);   // the wave's columns of the tile's valid rows
         const long tbase = m0 * a.ldo + n0;
 
-        f32x16 acc[2][2];
+        f32x16 acc[2][NB];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) acc[tm][0] = acc[tm][1] = zero16();
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < NB; ++tn) acc[tm][tn] = zero16();
         for (int c = 0; c < nc64; ++c) {
             const bool last = c + 1 == nc64;
             const bool more = !last || next_tile;                       // a next stage exists (of this tile or of the next one)
@@ -146,16 +149,16 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
                     for (int p = 0; p < 3; ++p) av[tm][p] = As[((p * 4 + s) * 2 + half) * G2_BM + tm * 32 + col];
                 __builtin_amdgcn_sched_barrier(0);                      // loads of chunk s + 1 stay here: hoisted over the unrolled chunks they spill
                 // (A plane, W plane): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi -- small terms first; four accumulators alternate
-#define G2_MF(PA, PB)                                                   \
-    acc[0][0] = g2_mfma(av[0][PA], bc[0][PB], acc[0][0]);               \
-    acc[0][1] = g2_mfma(av[0][PA], bc[1][PB], acc[0][1]);               \
-    acc[1][0] = g2_mfma(av[1][PA], bc[0][PB], acc[1][0]);               \
-    acc[1][1] = g2_mfma(av[1][PA], bc[1][PB], acc[1][1]);
+#define G2_MF(PA, PB)                                                               \
+    acc[0][0] = g2_mfma(av[0][PA], bc[0][PB], acc[0][0]);                           \
+    if (NB == 2) acc[0][NB - 1] = g2_mfma(av[0][PA], bc[NB - 1][PB], acc[0][NB - 1]); \
+    acc[1][0] = g2_mfma(av[1][PA], bc[0][PB], acc[1][0]);                           \
+    if (NB == 2) acc[1][NB - 1] = g2_mfma(av[1][PA], bc[NB - 1][PB], acc[1][NB - 1]);
                 G2_MF(2, 0) G2_MF(0, 2) G2_MF(1, 1) G2_MF(1, 0) G2_MF(0, 1) G2_MF(0, 0)
 #undef G2_MF
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < NB; ++tn)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bc[tn][p] = bn[tn][p];
             }
@@ -170,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
         const rsrc_t rr = make_rsrc((RES && has_aux) ? a.residual + tbase : a.out + tbase, (RES && has_aux) ? rec : 0u);
         // the epilogue's first read stream (aux, else residual), 32 rows at a time: 32 loads in flight per lane, their latency covered by
         // the CU's other workgroup (more live registers spill at two waves per SIMD: the matrix loop alone takes 251)
-        f32x16 pv[2];
+        f32x16 pv[NB];
         const rsrc_t rp = make_rsrc(pre_src ? pre_src + tbase : a.out + tbase, pre_src ? rec : 0u);
-        auto pre_issue = [&](int tm, f32x16 (&pf)[2]) __attribute__((always_inline)) {
+        auto pre_issue = [&](int tm, f32x16 (&pf)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < NB; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     pf[tn][r] = buf_load_f32(rp, lane_off + (tm * 32 + 8 * (r >> 2) + (r & 3)) * ldo4 + tn * 128, 0);
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
             if (has_aux || RES) pre_issue(tm, pv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
+            for (int tn = 0; tn < NB; ++tn) {
                 unsigned keepw[4];                                      // [owner j]: bit 4 k + c = keep (row r = 4 k + j, column 4 * (col / 4) + c)
                 if (DROP) {
                     unsigned mine = 0;
@@ -226,22 +229,25 @@ __global__ __launch_bounds__(256, 2) void gemm3x2_kernel(G2Args a) {
 
 bool rpb_gemm3x2_supported(long M, int N, int K, bool has_mask, bool has_drop) {
     static const int mode = getenv("RPB_GEMM3X_V2") ? atoi(getenv("RPB_GEMM3X_V2")) : 1;     // 0: off
-    (void)has_drop;
-    return mode != 0 && !has_mask && N % 256 == 0 && K % 64 == 0 && M > 0;
+    if (mode == 0 || has_mask || K % 64 != 0 || M <= 0) return false;
+    return N % 256 == 0 || (N % 128 == 0 && !has_drop);                  // 128-column workgroups are built without dropout
 }
 
 int rpb_gemm3x2_launch(const G2Args& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 24 * G2_BM * 16;
+    const int nb = a.N % 256 == 0 ? 2 : 1, gy = a.N / (128 * nb);
     long gx = (a.M + G2_BM - 1) / G2_BM;
-    const long cap = (long)rpb_num_cus() * 2 / (a.N / 256);             // two workgroups per CU in total
+    const long cap = (long)rpb_num_cus() * 2 / gy;                       // two workgroups per CU in total
     if (gx > cap) gx = cap < 1 ? 1 : cap;
-    const dim3 grid((unsigned)gx, a.N / 256);
-#define G2_LAUNCH(ACT_, RES_, DROP_)                                                                                                   \
-    if (a.act == ACT_ && (a.residual != nullptr) == RES_ && (a.drop.thr != 0) == DROP_) {                                              \
-        (void)hipFuncSetAttribute((const void*)gemm3x2_kernel<ACT_, RES_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((gemm3x2_kernel<ACT_, RES_, DROP_>), grid, dim3(256), lds, st, a);                                          \
+    const dim3 grid((unsigned)gx, gy);
+#define G2_LAUNCH(ACT_, RES_, DROP_, NB_)                                                                                                   \
+    if (a.act == ACT_ && (a.residual != nullptr) == RES_ && (a.drop.thr != 0) == DROP_ && nb == NB_) {                                      \
+        (void)hipFuncSetAttribute((const void*)gemm3x2_kernel<ACT_, RES_, DROP_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm3x2_kernel<ACT_, RES_, DROP_, NB_>), grid, dim3(256), lds, st, a);                                          \
     }
-#define G2_LAUNCH2(ACT_) G2_LAUNCH(ACT_, false, false) G2_LAUNCH(ACT_, true, false) G2_LAUNCH(ACT_, false, true) G2_LAUNCH(ACT_, true, true)
+#define G2_LAUNCH2(ACT_)                                                                                            \
+    G2_LAUNCH(ACT_, false, false, 2) G2_LAUNCH(ACT_, true, false, 2) G2_LAUNCH(ACT_, false, true, 2) G2_LAUNCH(ACT_, true, true, 2) \
+    G2_LAUNCH(ACT_, false, false, 1) G2_LAUNCH(ACT_, true, false, 1)
     G2_LAUNCH2(0) G2_LAUNCH2(1) G2_LAUNCH2(2) G2_LAUNCH2(3) G2_LAUNCH2(4)
 #undef G2_LAUNCH2
 #undef G2_LAUNCH

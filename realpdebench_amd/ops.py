@@ -324,8 +324,9 @@ GEMM_SPLIT_MIN_N = 256                # the K-split tiles of N = 64 / 128 lose t
 def gemm_split_ok(M, N, K, lda, ldo, conv, v2=False):
     # the 64-row-tile variant fills the chip from 4096 rows (DPOT's token GEMMs: 0.063 vs 0.090 ms at N = K = 1024, tools/nt_small.py)
     big = M >= GEMM_SPLIT_MIN_ROWS or (M >= 2048 and N >= GEMM_SPLIT_WIDE_N) or (v2 and M >= GEMM3X_V2_MIN_ROWS)
-    return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= GEMM_SPLIT_MIN_K
-            and (N in (64, 128) or N % 256 == 0) and N >= GEMM_SPLIT_MIN_N and lda % 4 == 0 and ldo % 4 == 0)
+    return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= (min(GEMM_SPLIT_MIN_K, 128) if v2 else GEMM_SPLIT_MIN_K)
+            and (N in (64, 128) or N % 256 == 0 or (v2 and N % 128 == 0)) and N >= (128 if v2 else GEMM_SPLIT_MIN_N)
+            and lda % 4 == 0 and ldo % 4 == 0)
 
 
 def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, lda=None, ldo=None, conv=None, aux=None,
@@ -345,7 +346,7 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     heavy_epilogue = residual is not None or aux is not None or mask is not None or pre_out is not None
     # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no mask tensor) hides the epilogue; only the 128-row kernel
     # loses to the fp32 one on short products with a heavy epilogue
-    v2 = GEMM3X_V2 and N % 256 == 0 and mask is None
+    v2 = GEMM3X_V2 and mask is None and (N % 256 == 0 or (N % 128 == 0 and not drop))
     if gemm_split_ok(M, N, K, lda, ldo, conv, v2) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
         wsrc = W.t if isinstance(W, Sub) else W
         wz = torch.empty(3 * N * K, dtype=torch.int16, device=wsrc.device)
