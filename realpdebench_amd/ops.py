@@ -324,7 +324,7 @@ GEMM_SPLIT_MIN_N = 256                # the K-split tiles of N = 64 / 128 lose t
 def gemm_split_ok(M, N, K, lda, ldo, conv, v2=False):
     # the 64-row-tile variant fills the chip from 4096 rows (DPOT's token GEMMs: 0.063 vs 0.090 ms at N = K = 1024, tools/nt_small.py)
     big = M >= GEMM_SPLIT_MIN_ROWS or (M >= 2048 and N >= GEMM_SPLIT_WIDE_N) or (v2 and M >= GEMM3X_V2_MIN_ROWS)
-    return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= (min(GEMM_SPLIT_MIN_K, 128) if v2 else GEMM_SPLIT_MIN_K)
+    return (GEMM_SPLIT and not conv and big and K % 64 == 0 and K >= (64 if v2 else GEMM_SPLIT_MIN_K)
             and (N in (64, 128) or N % 256 == 0 or (v2 and N % 128 == 0)) and N >= (128 if v2 else GEMM_SPLIT_MIN_N)
             and lda % 4 == 0 and ldo % 4 == 0)
 
