@@ -471,6 +471,7 @@ int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int dtype, voi
 int rpb_dp_allreduce_wait(void* handle, void* consumer_stream);
 int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream);
 int rpb_dp_allreduce_destroy(void* handle);
+int rpb_dp_allreduce_abort(void* handle);   /* process exit: ncclCommAbort, never blocks on a collective whose peer is gone */
 /*      Instrumentation (the N > 1 bench line): rpb_dp_set_timing(h, 1) brackets every bucket / inline reduction with timing events and
  *      restarts the records; after a device synchronisation rpb_dp_step_times fills out[] = { nb, ni, exposed ms (how long after the
  *      consumer stream reached rpb_dp_allreduce_wait the last bucket finished), ms from the first announcement to the last bucket's end,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rpb_dp_allreduce_wait": (_I, "pp"),
     "rpb_dp_allreduce_inline": (_I, "pplip"),
     "rpb_dp_allreduce_destroy": (_I, "p"),
+    "rpb_dp_allreduce_abort": (_I, "p"),
     "rpb_dp_set_timing": (_I, "pi"),
     "rpb_dp_step_times": (_I, "ppi"),
     "rpb_lift_bwd_rows": (_I, ""),

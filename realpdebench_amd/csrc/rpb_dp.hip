@@ -33,6 +33,7 @@ struct Rccl {
     fn_get_uid get_uid = nullptr;
     fn_init_rank init_rank = nullptr;
     fn_destroy destroy = nullptr;
+    fn_destroy abort = nullptr;
     fn_allreduce allreduce = nullptr;
     fn_errstr errstr = nullptr;
 };
@@ -52,6 +53,7 @@ Rccl* rccl() {
             r.get_uid = (fn_get_uid)dlsym(r.lib, "ncclGetUniqueId");
             r.init_rank = (fn_init_rank)dlsym(r.lib, "ncclCommInitRank");
             r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
+            r.abort = (fn_destroy)dlsym(r.lib, "ncclCommAbort");
             r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
             r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
         }
@@ -225,12 +227,22 @@ extern "C" int rpb_dp_step_times(void* handle, float* out, int max_out) {
     return 4 + 3 * nb + ni;
 }
 
-extern "C" int rpb_dp_allreduce_destroy(void* handle) {
+static int dp_teardown(void* handle, bool abort);
+extern "C" int rpb_dp_allreduce_destroy(void* handle) { return dp_teardown(handle, false); }
+// Process-exit teardown: ncclCommAbort instead of ncclCommDestroy and no wait for the side stream -- destroy blocks until outstanding
+// collectives finish, which never happens once a peer rank has died.
+extern "C" int rpb_dp_allreduce_abort(void* handle) { return dp_teardown(handle, true); }
+
+static int dp_teardown(void* handle, bool abort) {
     if (!handle) return RPB_OK;
     Rccl* R = rccl();
     DpHandle* h = (DpHandle*)handle;
-    (void)hipStreamSynchronize(h->side);
-    if (R) (void)R->destroy(h->comm);
+    if (abort && R && R->abort) {
+        (void)R->abort(h->comm);
+    } else {
+        (void)hipStreamSynchronize(h->side);
+        if (R) (void)R->destroy(h->comm);
+    }
     (void)hipEventDestroy(h->ready);
     (void)hipEventDestroy(h->done);
     if (h->events_made) {

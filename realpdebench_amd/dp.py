@@ -26,9 +26,12 @@ _LIVE_COMMS = weakref.WeakSet()
 
 
 def _close_all():
+    """Interpreter exit: abort (never a blocking destroy -- a peer may be gone), and only while the process group still exists:
+    after ``destroy_process_group`` the ranks no longer shut down together and the communicator is simply left to the OS."""
     for c in list(_LIVE_COMMS):
         try:
-            c.close()
+            if dist.is_available() and dist.is_initialized():
+                c.close(abort=True)
         except Exception:
             pass
 
@@ -42,11 +45,14 @@ class RcclComm:
     ``torch.distributed`` is only the launcher's rendezvous here: it carries the 128-byte RCCL unique ids from rank 0 to the
     others; the gradient traffic itself goes librpb_hip.so -> librccl.so -> xGMI.
 
-    TWO communicators: ``handle`` carries the gradient buckets on the side stream, ``small`` the few-hundred-byte SyncBN
-    statistics on the compute stream.  RCCL serialises the operations of ONE communicator, so with a single one every
-    statistics reduction of the backward pass queued behind the ~100 MB bucket still in flight and the overlap was lost
-    (round-2 advisor finding); operations on the two communicators are issued in the same order on every rank (same program),
-    which is what RCCL requires of concurrent communicators."""
+    ONE communicator by default: ``handle`` carries the gradient buckets on the side stream AND the few-hundred-byte SyncBN
+    statistics on the compute stream; RCCL orders the operations of one communicator, so a statistics reduction queues behind a
+    bucket that is still in flight.  The backward pass announces a layer's 100 MB bucket ~3 ms of kernels before the next
+    statistics reduction (model/fno.py: the bucket goes out after ``mode_contract_wgrad``, the reduction after the layer's
+    data-gradient ``cell_mix``), so at xGMI rates (100 MB over 8 ranks: < 1 ms) nothing is exposed.  ``RPB_DP_TWO_COMMS=1`` gives
+    the statistics their own communicator (``small``): concurrent communicators on two streams are only safe when every rank
+    schedules them in the same order, which stream scheduling does not guarantee (round-3 advisor finding) -- it stays opt-in
+    until an N > 1 run on hardware has exercised it (tests/test_gpu_rccl_abi.py holds the multi-GPU-gated test)."""
 
     def __init__(self, process_group=None):
         from . import _lib
@@ -54,7 +60,9 @@ class RcclComm:
         _lib.load()
         self.rank, self.world_size = dist.get_rank(process_group), dist.get_world_size(process_group)
         self.handle = self._init_comm(process_group)
-        self.small = self._init_comm(process_group) if os.environ.get("RPB_DP_ONE_COMM") != "1" else self.handle
+        two = os.environ.get("RPB_DP_TWO_COMMS") == "1" and os.environ.get("RPB_DP_ONE_COMM") != "1"
+        self.small = self._init_comm(process_group) if two else self.handle
+        self.closed = False
         _LIVE_COMMS.add(self)
 
     def _init_comm(self, process_group):
@@ -77,27 +85,37 @@ class RcclComm:
             return 1
         raise TypeError(f"rpb_dp all-reduce: fp32 / fp64 only, got {t.dtype}")
 
+    def _live(self):
+        if self.closed:
+            raise RuntimeError("rpb_dp: the RCCL communicator of this trainer was closed; build a new DataParallel / trainer")
+
     def enqueue(self, t):
         """Sum ``t`` (contiguous CUDA tensor / slice) in place across ranks on the side stream, after the work queued so far."""
+        self._live()
         assert t.is_cuda and t.is_contiguous()
         self._lib.call("rpb_dp_allreduce_enqueue", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
                        torch.cuda.current_stream().cuda_stream)
 
     def wait(self):
+        self._live()
         self._lib.call("rpb_dp_allreduce_wait", self.handle, torch.cuda.current_stream().cuda_stream)
 
     def inline(self, t):
+        self._live()
         assert t.is_cuda and t.is_contiguous()
         self._lib.call("rpb_dp_allreduce_inline", self.small, t.data_ptr(), t.numel(), self._dtype(t),
                        torch.cuda.current_stream().cuda_stream)
 
-    def close(self):
-        """Destroy the communicators (trainer teardown / interpreter exit; idempotent)."""
+    def close(self, abort=False):
+        """Destroy the communicators (trainer teardown; idempotent).  ``abort`` (interpreter exit): ``ncclCommAbort`` instead of
+        ``ncclCommDestroy`` -- destroy waits for outstanding collectives and would hang forever when a peer rank has died."""
         if self.handle:
+            fn = "rpb_dp_allreduce_abort" if abort else "rpb_dp_allreduce_destroy"
             if self.small and self.small != self.handle:
-                self._lib.call("rpb_dp_allreduce_destroy", self.small)
-            self._lib.call("rpb_dp_allreduce_destroy", self.handle)
+                self._lib.call(fn, self.small)
+            self._lib.call(fn, self.handle)
             self.handle = self.small = None
+        self.closed = True
         _LIVE_COMMS.discard(self)
 
     # ---- instrumentation (bench.py N > 1 line)
@@ -197,6 +215,7 @@ class DataParallel:
 
     # ---- small synchronous reductions (SyncBN statistics)
     def all_reduce_sum(self, t):
+        self._live()
         if self.comm is not None and t.is_cuda:
             self.comm.inline(t)
         else:
@@ -204,6 +223,7 @@ class DataParallel:
 
     # ---- bucketed, overlapped gradient reduction
     def begin_step(self, grad):
+        self._live()
         self._works, self._next = [], 0
 
     def bucket_ready(self, grad):
@@ -225,12 +245,16 @@ class DataParallel:
         self._works = []
 
     def close(self):
-        """Trainer teardown: destroy the RCCL communicators (also done at interpreter exit)."""
+        """Trainer teardown: destroy the RCCL communicators.  The wrapper stays attached to the model and is marked closed: a later
+        step raises instead of silently training unsynchronised (round-3 advisor finding)."""
         if self.comm is not None:
             self.comm.close()
-            self.comm = None
-        if getattr(self.model, "dp", None) is self:
-            self.model.dp = None
+        self.closed = True
+
+    def _live(self):
+        if getattr(self, "closed", False):
+            raise RuntimeError("DataParallel.close() was called: this model can no longer take synchronised steps "
+                               "(build a new DataParallel, or set model.dp = None for single-process training)")
 
     # ---- sharding of a global batch / dataset index (replaces shuffle=True of train.py:269 under DP)
     def shard(self, n_items):

@@ -336,16 +336,18 @@ def gemm_nt(A, W, out, M, N, K, bias=None, addvec=None, residual=None, act=0, ld
     ``cls`` of the matching transposed convolution (M = input tokens).
     act=1: GELU (``pre_out`` optionally receives the pre-activation); act=2: multiply by gelu'(``aux``); 3: ReLU; 4: ReLU'.
     ``mask``: inverted-dropout multiplier tensor, or ``drop=(seed, keep)``: the same dropout generated in the epilogue.
-    Large plain GEMMs (K % 64 == 0, N = 64 / 128 / 256 k) run on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip:
-    fp32-grade accuracy, ~2x the fp32 MFMA rate); RPB_GEMM_EXACT=1 keeps everything on the exact-fp32 kernel."""
+    Plain GEMMs with K % 64 == 0 run on the bf16 MFMA from split fp32 operands (csrc/rpb_gemm3x.hip, fp32-grade accuracy): the
+    64-row-tile organisation (csrc/rpb_gemm3x2.hip) from 4096 rows and K >= 64 for N % 256 == 0 without a mask tensor and for
+    N % 128 == 0 without dropout; the 128-row kernel for N = 64 / 128 / 256 k from K >= 256.  The weight's three bf16 planes are
+    prepared per call (rpb_gemm3x_wprep, N*K elements: 0.01 ms at 256 x 256); RPB_GEMM_EXACT=1 keeps everything on the exact-fp32 kernel."""
     hc, wc, dc = conv if conv else (0, 0, 0)
     mode = int(conv_mode) if conv else 0
     taps = {0: 1, 1: 27, 2: 16, 3: 4}[mode]
     lda = (K // taps) if lda is None else lda
     ldo = N if ldo is None else ldo
     heavy_epilogue = residual is not None or aux is not None or mask is not None or pre_out is not None
-    # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0, no mask tensor) hides the epilogue; only the 128-row kernel
-    # loses to the fp32 one on short products with a heavy epilogue
+    # rpb_gemm3x's 64-row-tile variant (csrc/rpb_gemm3x2.hip: N % 256 == 0 without a mask tensor, N % 128 == 0 without dropout) hides
+    # the epilogue; only the 128-row kernel loses to the fp32 one on short products with a heavy epilogue
     v2 = GEMM3X_V2 and mask is None and (N % 256 == 0 or (N % 128 == 0 and not drop))
     if gemm_split_ok(M, N, K, lda, ldo, conv, v2) and not (GEMM_F32_SHORT_HEAVY and K <= 256 and N <= 256 and heavy_epilogue and not v2):
         wsrc = W.t if isinstance(W, Sub) else W

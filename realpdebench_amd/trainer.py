@@ -276,11 +276,26 @@ class ArenaTrainer:
         """{parameter: gradient of the last step averaged over ranks} -- views of the gradient arena (tests, diagnostics)."""
         return {p: gv / self.world for p, gv in zip(self.params, self.gviews)}
 
-    def checkpoint(self, extra=None):
+    def checkpoint(self, extra=None, optimizer=False):
+        """The reference's checkpoint (train.py:410-418: model weights + bookkeeping, NO optimizer state -- a resumed run starts Adam
+        from zero moments there, and here).  ``optimizer=True`` adds the two moment arenas for callers that want an exact resume."""
         ck = {"model_state_dict": self.model.state_dict(), "iteration": self.iteration}
+        if optimizer:
+            ck["arena_adam_state"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
         if extra:
             ck.update(extra)
         return ck
+
+    def load_optimizer_state(self, state, iteration=None):
+        """Restore the moment arenas written by ``checkpoint(optimizer=True)``.  The "had a gradient before" flags that guard the
+        one-launch Adam update against conditionally used parameters are re-derived from the second moments (a parameter has
+        received a gradient iff its ``exp_avg_sq`` is non-zero), so the guard survives a resume (round-3 advisor finding)."""
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        if iteration is not None:
+            self.iteration = int(iteration)
+        flags = torch.stack([self.exp_avg_sq[o:o + p.numel()].any() for p, o in zip(self.params, self.offsets)])
+        self._had_grad = [bool(f) for f in flags.cpu()]
 
 
 def make_trainer(model, lr, num_update, scheduler="cosine", step_size=1000, clip_grad_norm=0.0, micro_batch=None):

@@ -93,3 +93,74 @@ def test_two_ranks_sum_over_xgmi():
         res = {k: v for k, v in out.items()}
     want = 3.0 * torch.arange(1 << 20).remainder(7).float()
     assert torch.equal(res[0], want) and torch.equal(res[1], want)
+
+
+def _rcclcomm_worker(rank, world, port, two_comms, out):
+    """dp.RcclComm as the trainers build it, under the nccl backend: buckets on the side stream, SyncBN-sized inline reductions on the
+    compute stream, the instrumentation of the N > 1 bench line, and teardown -- with one communicator (the default) or two."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if two_comms:
+        os.environ["RPB_DP_TWO_COMMS"] = "1"
+    else:
+        os.environ.pop("RPB_DP_TWO_COMMS", None)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from realpdebench_amd.dp import RcclComm
+        c = RcclComm()
+        assert (c.small != c.handle) == bool(two_comms)
+        c.set_timing(True)
+        g = torch.full((25 << 20,), float(rank + 1), device="cuda")              # a 100 MB bucket
+        s = torch.full((128,), float(rank + 1), device="cuda", dtype=torch.float64)
+        for _ in range(3):                                                       # bucket in flight while the statistics reduce
+            g.fill_(float(rank + 1))
+            s.fill_(float(rank + 1))
+            c.enqueue(g)
+            c.inline(s)
+            c.inline(s)
+            c.wait()
+        torch.cuda.synchronize()
+        tot = world * (world + 1) / 2
+        out[rank] = (float(g[0]), float(g[-1]), float(s[0]), tot)
+        t = c.step_times()
+        assert len(t["buckets"]) == 1 and len(t["inline_ms"]) == 2 and t["buckets"][0]["MB"] > 100
+        c.close()
+        with pytest.raises(RuntimeError):
+            c.inline(s)                                                          # closed communicators refuse, they do not detach
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("two_comms", [False, True])
+def test_rcclcomm_buckets_and_statistics_one_rank(two_comms):
+    """One rank through the whole dp.RcclComm path on the 1-GPU box (the two-rank variant below needs two GPUs)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rcclcomm_worker, args=(1, port, two_comms, out), nprocs=1, join=True)
+        res = dict(out)
+    assert res[0][:2] == (1.0, 1.0) and res[0][2] == 1.0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("two_comms", [False, True])
+def test_rcclcomm_buckets_and_statistics_two_ranks(two_comms):
+    """The multi-GPU gate of the advisor's round-3 finding: both communicator modes with a 100 MB bucket in flight while SyncBN-sized
+    reductions run on the compute stream, then step_times() and close()."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rcclcomm_worker, args=(2, port, two_comms, out), nprocs=2, join=True)
+        res = dict(out)
+    for r in (0, 1):
+        assert res[r][0] == 3.0 and res[r][1] == 3.0       # 1 + 2
+        assert res[r][2] == 6.0                            # two successive in-place sums: (1, 2) -> 3 on both ranks -> 6
