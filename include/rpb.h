@@ -82,6 +82,18 @@ int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float
                  const float* xf_gamma, const float* xf_beta, int xf_gelu, const float* bnb_s, const float* bnb_mean,
                  const float* bnb_invstd, const float* bnb_gamma, const float* bnb_beta, int bnb_gelu, void* stream);
 
+/*     The backward launch of a Fourier layer at C = 64 with the layer's Conv3d weight gradient riding along (csrc/rpb_cmw.hip;
+ *     autograd of fno.py:63,115-119): out = gs Wc + FW^T z2 (Wc = convs.l.weight [co][ci], FWt = the adjoint stage matrix [K2][Wp]),
+ *     stored as gz = out * act'(BN(s_prev)) when gelu == 2 (gelu == 1: act' only enters the sums, 0: identity activation);
+ *     stats_part[slot][2][64] = (sum gz, sum gz * shat) of the layer below;  wg_part[slot][64][64] = partial
+ *     d convs.l.weight[co][ci] = sum_cells gs[cell][co] * act(BN(s_prev))[cell][ci];  slot < rpb_cell_mix_wgrad_slots(ncell, Wp).
+ *     With it rpb_bn_bwd_row runs with x == NULL (no weight gradient there: the layer input is read by one kernel less). */
+long rpb_cell_mix_wgrad_slots(long ncell, int Wp);
+int rpb_cell_mix_wgrad_supported(long ncell, int K2, int Wp);
+int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float* z2, const float* FWt, float* out, float* stats_part,
+                       float* wg_part, long ncell, int K2, int Wp, const float* s_prev, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int gelu, void* stream);
+
 /*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
  *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */
 long rpb_cell_wgrad_slots(long ncell, int CO, int CI);
@@ -112,7 +124,8 @@ int rpb_bn_bwd_apply(const float* s, const float* gy, const float* mean, const f
  *     gy), adjoint W stage Y1[g][K2][C] = GWt gs, and the Conv3d weight/bias gradient partials -- one pass over
  *     s, gy, x instead of three kernels (autograd of fno.py:115-119 + first stage of the autograd of fno.py:63).
  *     part[rpb_bn_bwd_row_slots(G)][C*C + C]; G = B*Tp*Hp rows of Wp cells.  `M_wk` is the adjoint W-stage
- *     matrix transposed, i.e. [Wp][K2] row-major. */
+ *     matrix transposed, i.e. [Wp][K2] row-major.  x == NULL (C = 64, no xf_*): no weight gradient in this launch -- the
+ *     C*C block of the partial rows stays unwritten (rpb_cell_mix_wgrad forms it), only the [C] bias sums follow it. */
 long rpb_bn_bwd_row_slots(int G);
 int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, float* gs, const float* mean, const float* invstd,
                    const float* gamma, const float* beta, const float* sums, double count, int gelu,

@@ -79,6 +79,9 @@ SIGNATURES = {
     "rpb_mode_contract_dgrad": (_I, "ppp" + "iii" + "p"),
     "rpb_mode_contract_wgrad": (_I, "ppp" + "iiii" + "p"),
     "rpb_cell_mix_stat_rows": (_L, "liiiiii"),
+    "rpb_cell_mix_wgrad_slots": (_L, "li"),
+    "rpb_cell_mix_wgrad_supported": (_I, "lii"),
+    "rpb_cell_mix_wgrad": (_I, "ppppppp" + "lii" + "ppppp" + "i" + "p"),
     "rpb_cell_mix_writes_gz": (_I, "liiiiii"),
     "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "ppppi" + "pppppi" + "p"),
     "rpb_cell_wgrad_slots": (_L, "lii"),

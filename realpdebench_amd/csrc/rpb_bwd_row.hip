@@ -253,9 +253,12 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
                               double count, int gelu, const float* xf_mean, const float* xf_invstd,
                               const float* xf_gamma, const float* xf_beta, int xf_gelu, const float* GWt, float* Y1,
                               float* part, int G, int Wp, int C, int K2, void* stream) {
-    RPB_REQUIRE(s && gy && x && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part,
+    RPB_REQUIRE(s && gy && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part,
                 "bn_bwd_row: null pointer");
     RPB_REQUIRE(C == 32 || C == 64, "bn_bwd_row: C=%d not supported by the fused kernel (use the unfused kernels)", C);
+    // x == NULL: no weight gradient in this launch (rpb_cell_mix_wgrad of the same layer forms it): the C x C block of the partial
+    // rows is left unwritten, only [C] sum gs follows it
+    RPB_REQUIRE(x || (rpb_bwr_supported(C, Wp, K2, 0) && !xf_mean), "bn_bwd_row: x == NULL needs the C = 64 bf16-pipe kernel and no input transform");
     RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
     RPB_REQUIRE((long)Wp * C * 4 < (1L << 31), "bn_bwd_row: row too long");
     if (xf_mean) RPB_REQUIRE(xf_invstd && xf_gamma && xf_beta, "bn_bwd_row: bad input-transform arguments");

@@ -15,6 +15,7 @@
 // ds_read_b32); weights / DFT matrix sit in block-shared LDS with the MFMA column index contiguous.
 #include "rpb_common.h"
 #include "rpb_cmx.h"
+#include "rpb_bwr.h"
 
 // ---------------------------------------------------------------------------------- cell_mix
 struct CellMixArgs {
@@ -562,6 +563,32 @@ extern "C" int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, c
 }
 extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f) {
     return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f);
+}
+
+// Backward cell_mix of a Fourier layer with the layer's Conv3d weight gradient riding along (csrc/rpb_cmw.hip; C = 64):
+//   out  = gs Wc + FW^T z2, stored as gz = out * act'(BN(s_prev)) when gelu == 2        (as rpb_cell_mix with bnb_*)
+//   stats_part[slot][2][64] = partial (sum gz, sum gz * shat) of the layer below
+//   wg_part[slot][64][64]   = partial dWc[co][ci] = sum_cells gs[cell][co] * act(BN(s_prev))[cell][ci]
+// with slot < rpb_cell_mix_wgrad_slots(ncell, Wp).  Wc is convs.l.weight [co][ci]; FW the adjoint stage matrix [K2][Wp].
+extern "C" long rpb_cell_mix_wgrad_slots(long ncell, int Wp) { return Wp > 0 ? rpb_cmw_slots(ncell, Wp) : -1; }
+extern "C" int rpb_cell_mix_wgrad_supported(long ncell, int K2, int Wp) {
+    static const bool off = getenv("RPB_CELL_MIX_WGRAD") && atoi(getenv("RPB_CELL_MIX_WGRAD")) == 0;     // A/B switch: wgrad stays in bn_bwd_row
+    return !off && rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0;
+}
+extern "C" int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float* z2, const float* FW, float* out, float* stats_part,
+                                  float* wg_part, long ncell, int K2, int Wp, const float* s_prev, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int gelu, void* stream) {
+    RPB_REQUIRE(gs && Wc && z2 && FW && out && stats_part && wg_part && s_prev && mean && invstd && gamma && beta, "cell_mix_wgrad: null pointer");
+    RPB_REQUIRE(ncell > 0 && ncell < (1L << 31) && Wp > 0 && ncell % Wp == 0, "cell_mix_wgrad: bad sizes");
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false), "cell_mix_wgrad: needs C = 64, K2 <= 32, Wp >= 32 (K2=%d Wp=%d)", K2, Wp);
+    CmxArgs c{};
+    c.x = gs; c.Wm = Wc; c.bias = nullptr; c.z2 = z2; c.GW = FW; c.out = out; c.stats_part = stats_part; c.wg_part = wg_part;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 1;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = s_prev;
+    c.bnb = XForm{mean, invstd, gamma, beta, gelu != 0};
+    c.write_gz = gelu == 2;
+    return rpb_cmw_launch(c, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad

@@ -25,9 +25,15 @@ struct CmxArgs {
     int crop_T, crop_H, crop_W, Tp, Hp;   // crop_T > 0 (eval, no statistics, no fused stage): only lines t < crop_T, h < crop_H of each [Tp][Hp] sample
                                           // are produced, and of each line the tiles up to cell crop_W - 1 (the projection head reads nothing else)
     void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
+    float* wg_part;       // rpb_cmw.hip only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
 };
 
 bool rpb_cmx_dft_supported(int Wp, int K2f);
 bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather);
 long rpb_cmx_stat_rows(long ncell, int Wp, int stats);   // stats: 0 / 1 / 2 as in the kernel template
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);
+
+// csrc/rpb_cmw.hip: the STATS == 2 launch with the 1x1-conv weight gradient of the same layer riding along (x = gs of the layer,
+// bnb_s = the pre-BN tensor whose activation is the layer input): dWc[co][ci] = sum_cells x[cell][co] * act(BN(bnb_s))[cell][ci]
+long rpb_cmw_slots(long ncell, int Wp);            // partial rows of stats_part ([2][64]) and wg_part ([64][64])
+int rpb_cmw_launch(const CmxArgs& a, hipStream_t st);

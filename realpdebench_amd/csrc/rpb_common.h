@@ -132,6 +132,15 @@ __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
     return cdf + x * (pk2(0.39894228040143267794f) * e);
 }
 
+// gelu(x) and gelu'(x) from ONE erf (the backward cell_mix needs the layer input act(z) for the weight gradient next to act'(z))
+__device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& g, f32x2& gp) {
+    const f32x2 h = pk2(0.5f) * (pk2(1.0f) + fast_erf2(x * pk2(0.70710678118654752440f)));
+    const f32x2 q = (pk2(-0.72134752044448170368f) * x) * x;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    g = (pk2(0.5f) * x) * (pk2(1.0f) + fast_erf2(x * pk2(0.70710678118654752440f)));      // same expression as gelu2 (CSE'd erf)
+    gp = h + x * (pk2(0.39894228040143267794f) * e);
+}
+
 // four channels at once (two packed pairs)
 __device__ __forceinline__ f32x4 join4(f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; }
 __device__ __forceinline__ f32x4 gelu4(f32x4 x) { return join4(gelu2(x.lo), gelu2(x.hi)); }

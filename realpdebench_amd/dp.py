@@ -188,7 +188,10 @@ class StatsSync:
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def bucket_ready(self, grad):
+    def bucket_ready(self, grad, hold_small_of=None):
+        pass
+
+    def small_ready(self, grad, l):
         pass
 
 
@@ -203,6 +206,7 @@ class DataParallel:
         self.buckets = layer_buckets(model._seg, model.n_layers, model.flat.numel())
         self._works = []
         self._next = 0
+        self._held = {}
         self.comm = RcclComm(process_group) if use_rccl_abi(model.flat, process_group) else None      # C-ABI RCCL on a side stream
         model.dp = self
         self.sync_parameters()
@@ -224,20 +228,38 @@ class DataParallel:
     # ---- bucketed, overlapped gradient reduction
     def begin_step(self, grad):
         self._live()
-        self._works, self._next = [], 0
+        self._works, self._next, self._held = [], 0, {}
 
-    def bucket_ready(self, grad):
-        """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete."""
-        s, e = self.buckets[self._next]
-        self._next += 1
+    def _reduce(self, grad, s, e):
         if self.comm is not None and grad.is_cuda:
             self.comm.enqueue(grad[s:e])               # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
         else:
             self._works.append(dist.all_reduce(grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def bucket_ready(self, grad, hold_small_of=None):
+        """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete.  ``hold_small_of`` = l: the
+        bucket's tail from ``convs.l.weight`` on (the layer's Conv3d / BatchNorm gradients, 17 KB) is NOT final yet -- round 4 forms
+        d convs.l.weight in the layer's data-gradient cell_mix, ~3 ms of kernels after the 100 MB spectral gradient -- and goes out
+        with ``small_ready(grad, l)``; the spectral part starts its all-reduce now, as before."""
+        s, e = self.buckets[self._next]
+        self._next += 1
+        if hold_small_of is not None:
+            cut = self.model._seg[f"convs.{hold_small_of}.weight"][0]
+            if s < cut < e:
+                self._held[hold_small_of] = (cut, e)
+                e = cut
+        self._reduce(grad, s, e)
+
+    def small_ready(self, grad, l):
+        """The held tail of layer ``l``'s bucket is complete: its own (tiny) all-reduce."""
+        if l in self._held:
+            self._reduce(grad, *self._held.pop(l))
+
     def finish_step(self, grad):
         while self._next < len(self.buckets):          # anything the backward pass did not announce
             self.bucket_ready(grad)
+        for l in sorted(self._held, reverse=True):     # (same order on every rank)
+            self._reduce(grad, *self._held.pop(l))
         if self.comm is not None and grad.is_cuda:
             self.comm.wait()                           # the compute stream (Adam next) waits for every bucket
         for w in self._works:

@@ -138,6 +138,15 @@ class _Workspace:
                               else ops.cell_wgrad_slots(d.ncell, C, C))
             self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
             self.wg_part = torch.empty(max(self.wg_rows_c * (C * C + C), self.wg_rows_p * (HID * C + HID)), **f)
+            # round 4: d convs.l.weight of layers l >= 1 rides in the backward cell_mix of the same layer (csrc/rpb_cmw.hip), which
+            # streams gs_l and s_{l-1} anyway: the row kernel no longer reads the layer input (RPB_CELL_MIX_WGRAD=0: the round-3 split)
+            self.wg_in_cmx = (self.fused_bwd and C == 64 and ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True)
+                              and ops.cell_mix_wgrad_supported(d.ncell, 2 * plan.KW, d.Wp))
+            if self.wg_in_cmx:
+                self.cmw_slots = ops.cell_mix_wgrad_slots(d.ncell, d.Wp)
+                self.cmw_wpart = torch.empty(self.cmw_slots * C * C, **f)
+                if self.bn_part.numel() < self.cmw_slots * 2 * C:
+                    self.bn_part = torch.empty(self.cmw_slots * 2 * C, **f)
             model._alloc_lift_ws(self, f)
             self.tmp_b = torch.empty(HID, **f)
             self.gout = torch.empty(d.ncrop, model.dim_out, **f)
@@ -573,8 +582,10 @@ class FNO3d(Model):
                                     float(d.ncell) * world, gelu, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp, d.Wp, C,
                                     2 * plan.KW, ws.FW)
             elif ws.fused_bwd:
-                # one pass: gs = BN/GELU backward (in place), Y1 = GW^T gs (adjoint W stage), conv wgrad partials
-                ops.bn_bwd_row(ws.S[l], g, a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
+                # one pass: gs = BN/GELU backward (in place), Y1 = GW^T gs (adjoint W stage), conv wgrad partials -- or, when the
+                # backward cell_mix below forms the weight gradient, no read of the layer input at all
+                wg_later = ws.wg_in_cmx and l > 0
+                ops.bn_bwd_row(ws.S[l], g, None if wg_later else a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
                                float(d.ncell) * world, gelu, xf_in, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
                                d.Wp, C, 2 * plan.KW)
             else:
@@ -586,15 +597,15 @@ class FNO3d(Model):
                 # Mgf[o][f] = sum_cells gs0[o] phi_f (columns f < FW of the block);  d convs.0.weight = Mgf W0ext^T
                 self._reduce_cols(partc, 0, C * C, ws.mgf2)
                 ops.small_gemm(ws.mgf2, ws.w0ext, GP("convs.0.weight"), C, C, ws.FW, C, 1, 1, ws.FW, C)
-            else:
+            elif not (ws.fused_bwd and ws.wg_in_cmx and l > 0):
                 self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
             self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GW, plan.GH, plan.GT),
                                           first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
-            if self.dp is not None:
-                self.dp.bucket_ready(gflat)                  # layer l's 100 MB bucket overlaps the rest of backward
+            if self.dp is not None:                          # layer l's 100 MB bucket overlaps the rest of backward
+                self.dp.bucket_ready(gflat, hold_small_of=l if (ws.fused_bwd and ws.wg_in_cmx and l > 0) else None)
             gxh = ws.Xh[l]                                   # X^ of this layer is dead after wgrad: reuse for gX^
             ops.mode_contract_dgrad(ws.Yh, P(f"spec.{l}"), gxh, d.B, plan.M, C)
             if l == 0 and ws.feat0:
@@ -624,10 +635,19 @@ class FNO3d(Model):
             self._spectral_inverse_stages(gxh, ws, (plan.FT, plan.FH))
             if l > 0:      # g_x of layer l = gradient w.r.t. act(BN(s_{l-1})): also leave layer l-1's BN-backward sums
                 g_is_gz = gz_ok and l - 1 < L - 1
-                ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, ws.bn_part, d.ncell, C, C,
-                             2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True),
-                             write_gz=g_is_gz)
-                ops.reduce_partials(ws.bn_part, ws.bnb_rows_conv, 2 * C, out_f32=ws.bn_sums)
+                if ws.fused_bwd and ws.wg_in_cmx:
+                    # ... and d convs.l.weight = gs_l^T act(BN(s_{l-1})): both factors stream through this launch anyway
+                    ops.cell_mix_wgrad(g, P(f"convs.{l}.weight"), ws.Y1, plan.FW, g2, ws.bn_part, ws.cmw_wpart, d.ncell, 2 * plan.KW,
+                                       d.Wp, (ws.S[l - 1],) + self._layer_xf(ws, l - 1, True), write_gz=g_is_gz)
+                    ops.reduce_partials(ws.bn_part, ws.cmw_slots, 2 * C, out_f32=ws.bn_sums)
+                    ops.reduce_partials(ws.cmw_wpart, ws.cmw_slots, C * C, out_f32=GP(f"convs.{l}.weight").view(-1))
+                    if self.dp is not None:
+                        self.dp.small_ready(gflat, l)    # convs.l / bns.l (17 KB) are final only now: their own tiny all-reduce
+                else:
+                    ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, ws.bn_part, d.ncell, C, C,
+                                 2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True),
+                                 write_gz=g_is_gz)
+                    ops.reduce_partials(ws.bn_part, ws.bnb_rows_conv, 2 * C, out_f32=ws.bn_sums)
             else:
                 ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW,
                              d.Wp, transpose_w=True)

@@ -194,6 +194,25 @@ def cell_mix(x, Wm, bias, z2, GW, out, stats_part, ncell, KC, CO, K2, Wp, transp
               flops=2 * ncell * CO * ((K2 if spec else 0)) + 2 * rows_in * CO * KC)
 
 
+def cell_mix_wgrad_supported(ncell, K2, Wp):
+    return bool(_lib.query("rpb_cell_mix_wgrad_supported", ncell, K2, Wp))
+
+
+def cell_mix_wgrad_slots(ncell, Wp):
+    return _lib.query("rpb_cell_mix_wgrad_slots", ncell, Wp)
+
+
+def cell_mix_wgrad(gs, Wc, z2, FW, out, stats_part, wg_part, ncell, K2, Wp, bnb, write_gz=True):
+    """Backward cell_mix of a Fourier layer at C = 64 with d convs.l.weight riding along (csrc/rpb_cmw.hip): ``bnb`` = (s_prev, mean,
+    invstd, gamma, beta, gelu) of the layer below, whose activation is this layer's input.  ``stats_part`` / ``wg_part``:
+    ``cell_mix_wgrad_slots`` partial rows of [2][64] / [64][64]."""
+    C = 64
+    _lib.call("rpb_cell_mix_wgrad", _p(gs), _p(Wc), _p(z2), _p(FW), _p(out), _p(stats_part), _p(wg_part), ncell, K2, Wp, _p(bnb[0]),
+              _p(bnb[1]), _p(bnb[2]), _p(bnb[3]), _p(bnb[4]), (2 if write_gz else 1) if bnb[5] else 0, _stream(),
+              label="cell_mix[KC64->CO64,spec=1,stats=2,wgrad]", nbytes=4 * (3 * ncell * C + ncell // Wp * K2 * C),
+              flops=2 * ncell * C * (K2 + 2 * C))
+
+
 def cell_wgrad_slots(ncell, CO, CI):
     return _lib.query("rpb_cell_wgrad_slots", ncell, CO, CI)
 
@@ -249,11 +268,14 @@ def bn_bwd_row_slots(G):
 
 
 def bn_bwd_row(s, gy, x, gs, mean, invstd, gamma, beta, sums, count, gelu, xf, GWt, Y1, part, G, Wp, C, K2):
+    """``x`` None (C = 64): no weight gradient in this launch -- ``cell_mix_wgrad`` of the same layer forms it and the layer input is
+    not read here (3 instead of 4 tensor passes)."""
     ncell = G * Wp
+    nox = x is None
     _lib.call("rpb_bn_bwd_row", _p(s), _p(gy), _p(x), _p(gs), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
-              float(count), int(gelu), *_xf(xf), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, _stream(),
-              label=f"bn_bwd_row[C{C},gelu={int(gelu)}]", nbytes=4 * (4 * ncell * C + G * K2 * C),
-              flops=2 * ncell * C * (C + K2))
+              float(count), int(gelu), *_xf(None if nox else xf), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, _stream(),
+              label=f"bn_bwd_row[C{C},gelu={int(gelu)}{',nox' if nox else ''}]", nbytes=4 * ((3 if nox else 4) * ncell * C + G * K2 * C),
+              flops=2 * ncell * C * ((0 if nox else C) + K2))
 
 
 def proj_slots(ncrop, C, DO):

@@ -459,6 +459,60 @@ def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2):
     assert rel_l2(out.cpu(), spec + g @ Wc) < 2e-6
 
 
+@pytest.mark.parametrize("Wp,rows,K2", [(134, 9, 32), (70, 11, 32), (38, 5, 24), (33, 3, 7), (134, 1, 32)])
+@pytest.mark.parametrize("gelu,write_gz", [(True, True), (True, False), (False, False)])
+def test_cell_mix_with_the_conv_weight_gradient(ops, Wp, rows, K2, gelu, write_gz):
+    """rpb_cell_mix_wgrad (csrc/rpb_cmw.hip) == the STATS = 2 backward cell_mix + d convs.weight = gs^T act(BN(s_prev)), each stated in
+    fp64: rows that end inside a tile (Wp % 32 != 0), fewer lines than waves, weights that are far from symmetric (transpose-detecting)."""
+    torch.manual_seed(Wp * 11 + K2 + int(gelu))
+    C = 64
+    ncell = rows * Wp
+    assert ops.cell_mix_wgrad_supported(ncell, K2, Wp)
+    f8 = dict(dtype=torch.float64)
+    s = torch.randn(ncell, C, **f8) * 1.5 + 0.3
+    gs = torch.randn(ncell, C, **f8) * torch.linspace(0.2, 3.0, C, **f8)      # per-channel scales: a transposed dWc would not match
+    Wc = torch.randn(C, C, **f8) / 8
+    z2, FW = torch.randn(rows, K2, C, **f8), torch.randn(Wp, K2, **f8)
+    mean, invstd = torch.randn(C, **f8) * 0.2, torch.rand(C, **f8) + 0.5
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    sh = (s - mean) * invstd
+    act = _xf_ref(s, mean, invstd, gamma, beta, gelu)
+    gx = torch.einsum("wk,gkc->gwc", FW, z2).reshape(ncell, C) + gs @ Wc
+    if gelu:
+        zz = (sh * gamma + beta).clone().requires_grad_(True)
+        torch.nn.functional.gelu(zz).backward(gx)
+        gz = zz.grad
+    else:
+        gz = gx
+    slots = ops.cell_mix_wgrad_slots(ncell, Wp)
+    out = torch.full((ncell, C), float("nan"), device="cuda")
+    sp = torch.full((slots, 2, C), float("nan"), device="cuda")
+    wp = torch.full((slots, C, C), float("nan"), device="cuda")
+    ops.cell_mix_wgrad(dev(gs), dev(Wc), dev(z2), dev(FW.t()), out, sp, wp, ncell, K2, Wp,
+                       (dev(s), dev(mean), dev(invstd), dev(gamma), dev(beta), gelu), write_gz=write_gz)
+    assert rel_l2(out.cpu(), gz if write_gz else gx) < 3e-6
+    tot = sp.double().sum(0).cpu()
+    assert rel_l2(tot[0], gz.sum(0)) < 2e-5 and rel_l2(tot[1], (gz * sh).sum(0)) < 2e-5
+    dW = wp.double().sum(0).cpu()
+    assert rel_l2(dW, gs.t() @ act) < 3e-6
+    # ... and the row kernel without its weight-gradient operand: gs, Y1 and the bias sums as before, the C x C block untouched
+    G = rows
+    gy = torch.randn(ncell, C, **f8)
+    sums = torch.cat([gy.sum(0), (gy * sh).sum(0)])
+    gs_ref = gamma * invstd * (gy - sums[:C] / ncell - sh * sums[C:] / ncell)
+    GWt = torch.randn(K2, Wp, **f8)
+    g = dev(gy)
+    Y1 = torch.full((G, K2, C), float("nan"), device="cuda")
+    rs = ops.bn_bwd_row_slots(G)
+    part = torch.full((rs, C * C + C), 7.0, device="cuda")
+    ops.bn_bwd_row(dev(s), g, None, g, dev(mean), dev(invstd), dev(gamma), dev(beta), dev(sums), ncell, False, None,
+                   dev(GWt.t()), Y1, part, G, Wp, C, K2)
+    assert rel_l2(g.cpu(), gs_ref) < 5e-6
+    assert rel_l2(Y1.cpu(), torch.einsum("ok,gkc->goc", GWt, gs_ref.view(G, Wp, C))) < 5e-6
+    tot = part.double().sum(0).cpu()
+    assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
+
+
 def _bf16_ulps(a, b):
     """|a - b| in units of the bf16 spacing at |b| (both bf16 tensors)."""
     a, b = a.float(), b.float()

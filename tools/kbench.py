@@ -57,6 +57,12 @@ if "cell_mix" in which:
     timeit("cell_mix bwd (spec + BN-bwd sums, gelu)",
            lambda: ops.cell_mix(x, Wc, None, z2, plan.FW, y, part2, d.ncell, C, C, K2, d.Wp, transpose_w=True,
                                 bnb=(s_prev,) + xfg), nb + 4 * d.ncell * C, fl)
+    if ops.cell_mix_wgrad_supported(d.ncell, K2, d.Wp):
+        cs = ops.cell_mix_wgrad_slots(d.ncell, d.Wp)
+        sp3, wp3 = torch.empty(cs * 2 * C, **f), torch.empty(cs * C * C, **f)
+        timeit("cell_mix bwd + BN-bwd sums + conv wgrad (gelu, gz)  [round 4]",
+               lambda: ops.cell_mix_wgrad(x, Wc, z2, plan.FW, y, sp3, wp3, d.ncell, K2, d.Wp, (s_prev,) + xfg, write_gz=True),
+               nb + 4 * d.ncell * C, fl + 2 * d.ncell * C * C)
     timeit("cell_mix eval (out = gelu(bn(.)))",
            lambda: ops.cell_mix(x, Wc, bias, z2, plan.GWt, y, None, d.ncell, C, C, K2, d.Wp, oxf=xfg), nb, fl)
     phic = torch.randn(d.ncell, 8, **f)
@@ -90,6 +96,9 @@ if "bwd_row" in which:
     timeit("bn_bwd_row (gz in, plain x)",
            lambda: ops.bn_bwd_row(x, gy, y, gy, mean, invstd, gamma, beta, sums, d.ncell, False, None, plan.GW, Y1, part, G,
                                   d.Wp, C, K2), 4 * (4 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * (C + K2))
+    timeit("bn_bwd_row (gz in, NO weight gradient: x not read)  [round 4]",
+           lambda: ops.bn_bwd_row(x, gy, None, gy, mean, invstd, gamma, beta, sums, d.ncell, False, None, plan.GW, Y1, part, G,
+                                  d.Wp, C, K2), 4 * (3 * d.ncell * C + G * K2 * C), 2 * d.ncell * C * K2)
     phic = torch.randn(d.ncell, 8, **f)
     timeit("bn_bwd_row layer 0 (feature fields)",
            lambda: ops.bn_bwd_row_feat(x, gy, phic, gy, mean, invstd, gamma, beta, sums, d.ncell, False, plan.GW, Y1, part, G,
