@@ -572,8 +572,7 @@ extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K
 // with slot < rpb_cell_mix_wgrad_slots(ncell, Wp).  Wc is convs.l.weight [co][ci]; FW the adjoint stage matrix [K2][Wp].
 extern "C" long rpb_cell_mix_wgrad_slots(long ncell, int Wp) { return Wp > 0 ? rpb_cmw_slots(ncell, Wp) : -1; }
 extern "C" int rpb_cell_mix_wgrad_supported(long ncell, int K2, int Wp) {
-    static const bool off = getenv("RPB_CELL_MIX_WGRAD") && atoi(getenv("RPB_CELL_MIX_WGRAD")) == 0;     // A/B switch: wgrad stays in bn_bwd_row
-    return !off && rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0;
+    return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0;
 }
 extern "C" int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float* z2, const float* FW, float* out, float* stats_part,
                                   float* wg_part, long ncell, int K2, int Wp, const float* s_prev, const float* mean, const float* invstd,

@@ -69,6 +69,12 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #define CMX_WAVES_B 8
 #endif
 #define CMX_WAVES_OF(STATS) ((STATS) == 2 ? CMX_WAVES_B : CMX_WAVES_A)
+#ifndef CMX_PF2
+#define CMX_PF2 0    /* 1: x tiles requested TWO wave tiles ahead where registers allow.  Measured (round 4, tools/kbench.py, B = 32): no change --
+                        forward + stats 1.84-1.87 ms (1.80-1.86 one tile ahead), with the lazy GELU 2.18-2.24 (2.16-2.19), eval 1.83 (1.80-1.83):
+                        these launches are not short of bytes in flight; what separates them from the 5.16 TB/s of the plain backward
+                        variant (1.66 ms) is the ~70-400 extra vector instructions per tile (statistics, BatchNorm + GELU on load) */
+#endif
 
 // STATS: 0 none (bnb.mean != null: output transform) | 1 sum / sum of squares of the output | 2 BatchNorm-backward sums
 // BF: activations are STORED as bf16 (x and out: [ncell][64] bf16, 128 B per cell; BASELINE.json configs[4]).  The x operand is
@@ -200,9 +206,12 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     const int xoff = m * 256 + kg * 16;                  // byte offset of the lane's first 16 B inside a 16-cell block
     const int ooff = (4 * kg) * 256 + m * 16;            // output: cell 4 mg + r, channels 4 n ..
 
-    u32x4 xa[2][4];
+    // PF2 (compile-time experiment, off: see CMX_PF2): the x tiles requested TWO wave tiles ahead (two register images, the tile loop
+    // unrolled by two) -- 128 instead of 64 KB of loads in flight per CU.  Not for STATS == 2 / the fused W stage (no registers left).
+    constexpr bool PF2 = CMX_PF2 && !DFT && !BF && STATS != 2;
+    u32x4 xaA[2][4], xaB[2][4];
     // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
-    auto issue_x = [&](long g, int q, int j, int ks) {
+    auto issue_x = [&](u32x4 (&xa)[2][4], long g, int q, int j, int ks) {
         const rsrc_t rx = make_rsrc(a.x + g * xline_floats, xline_bytes);
         if (FEAT) {                 // 32 B of fields 8 kg .. 8 kg + 7 (lane groups past FW: an offset outside the descriptor -> 0)
             if (ks == 0) {
@@ -224,27 +233,20 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
         for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * 256 + m * 16);
     };
 
-    if (slot < G) {
-        const long g0 = line_of(slot);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            issue_x(g0, 0, j, 0);
-            issue_x(g0, 0, j, 1);
-        }
-        issue_z(g0);
-    }
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
     f32x4v Yacc[DFT ? 2 : 1][DFT ? 4 : 1];
-    for (long gi = slot; gi < G; gi += nslots) {
-        const long g = line_of(gi);
-        const long g_next = gi + nslots < G ? line_of(gi + nslots) : 0;
-        const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
-        const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
-        for (int q = 0; q < TQ; ++q) {
+    // one wave tile: (gi, q) = the tile computed from the register image `xa`; (ngi, nq) = the tile whose loads take the image's place
+    // (the next tile, or with PF2 the one after it; ngi >= G: none)
+    auto do_tile = [&](u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
+        {
+            const long g = line_of(gi);
+            const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
+            const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
             const bool last = q + 1 == TQ;
-            const long gn = last ? g_next : g;                               // next wave tile: (gn, qn)
-            const int qn = last ? 0 : q + 1;
-            const bool more = !last || gi + nslots < G;
+            const bool more = ngi < G;
+            const long gn = more ? line_of(ngi) : 0;                         // the tile to request: (gn, qn)
+            const int qn = nq;
+            const bool more_lines = gi + nslots < G;
             const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
             asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS operand reads inside the loop: hoisted, they cost 150 VGPRs
 
@@ -300,8 +302,8 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                     split8(v, Ah[j], Am[j], Al[j]);
                 }
                 if (more) {
-                    issue_x(gn, qn, 0, ks);
-                    issue_x(gn, qn, 1, ks);
+                    issue_x(xa, gn, qn, 0, ks);
+                    issue_x(xa, gn, qn, 1, ks);
                 }
                 if (ks == 0) {
                     if (q == 0) {                  // new line: its z2 row (requested one tile ago) -> three bf16 planes per channel,
@@ -317,7 +319,7 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                             Zw[(2 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zl);
                         }
                     }
-                    if (last && more) issue_z(gn);                           // next line's row: in flight for a whole tile
+                    if (last && more_lines) issue_z(line_of(gi + nslots));   // next line's row: in flight for a whole tile
                     if (STATS == 2) {              // pre-BN values at the output positions (needed by the epilogue)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
@@ -487,6 +489,54 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                         for (int r = 0; r < 4; ++r)
                             st16(f32x4v{Yacc[i][0][r], Yacc[i][1][r], Yacc[i][2][r], Yacc[i][3][r]}, ry, (16 * i + 4 * kg + r) * 256 + m * 16);
                 }
+            }
+        }
+    };
+    auto advance = [&](long& gi, int& q) {
+        if (++q == TQ) {
+            q = 0;
+            gi += nslots;
+        }
+    };
+    {
+        long g0 = slot, g1 = slot;
+        int q0 = 0, q1 = 0;
+        advance(g1, q1);
+        if (g0 < G) {
+            const long l0 = line_of(g0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                issue_x(xaA, l0, 0, j, 0);
+                issue_x(xaA, l0, 0, j, 1);
+            }
+            issue_z(l0);
+            if (PF2 && g1 < G) {
+                const long l1 = line_of(g1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    issue_x(xaB, l1, q1, j, 0);
+                    issue_x(xaB, l1, q1, j, 1);
+                }
+            }
+        }
+        if (PF2) {
+            while (g0 < G) {
+                long g2 = g1;
+                int q2 = q1;
+                advance(g2, q2);
+                do_tile(xaA, g0, q0, g2, q2);
+                if (g1 >= G) break;
+                long g3 = g2;
+                int q3 = q2;
+                advance(g3, q3);
+                do_tile(xaB, g1, q1, g3, q3);
+                g0 = g2; q0 = q2; g1 = g3; q1 = q3;
+            }
+        } else {
+            while (g0 < G) {
+                do_tile(xaA, g0, q0, g1, q1);
+                g0 = g1; q0 = q1;
+                advance(g1, q1);
             }
         }
     }

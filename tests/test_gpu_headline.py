@@ -168,3 +168,30 @@ def test_full_size_properties_b32():
             cur = m(cur).clone()
             outs.append(cur)
         assert torch.equal(r3, torch.cat(outs, 1))
+
+
+def test_conv_weight_gradient_in_the_backward_cell_mix_equals_the_row_kernel_path(monkeypatch):
+    """RPB_CELL_MIX_WGRAD=1 (csrc/rpb_cmw.hip: d convs.l.weight formed by the data-gradient cell_mix of layers >= 1, the row kernel
+    without its layer-input operand) against the default split, at the headline shape: same loss, every gradient within fp32 round-off
+    (the two paths sum the same products in a different order)."""
+    from realpdebench_amd.trainer import Trainer
+    sd = headline_state_dict(seed=29)
+    x, y = headline_batch(2, seed=97)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RPB_CELL_MIX_WGRAD", flag)
+        m = _model(sd)
+        tr = Trainer(m, lr=0.0, num_update=4000)
+        loss = float(tr.step(x.cuda(), y.cuda()))
+        ws = next(iter(m._ws.values()))
+        assert bool(ws.wg_in_cmx) == (flag == "1")
+        res[flag] = (loss, {k: v.cpu().clone() for k, v in m.grads_as_state_dict(tr.grad).items()})
+        del m, tr
+        torch.cuda.empty_cache()
+    assert abs(res["0"][0] - res["1"][0]) <= 1e-7 * abs(res["0"][0])
+    for k, g0 in res["0"][1].items():
+        g1 = res["1"][1][k]
+        if k.startswith("convs.") and k.endswith(".bias"):
+            assert float((g0 - g1).abs().max()) < 1e-5, k          # true gradient 0: noise on both sides
+        else:
+            assert rel_l2(g1, g0) < 5e-6, k
