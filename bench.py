@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--rollout-steps", type=int, default=10, help="N_autoregressive of configs/cylinder/fno.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--no-scaling-proxy", action="store_true", help="skip the one-rank strong-scaling proxy (step at B = 16 / 8 / 4 with the DP path on)")
     ap.add_argument("--profile-all", action="store_true", help="print per-kernel HIP-event table to stderr")
     ap.add_argument("--no-transolver", action="store_true", help="skip the secondary Transolver measurement")
     ap.add_argument("--no-galerkin", action="store_true", help="skip the secondary Galerkin Transformer measurement")
@@ -55,6 +56,7 @@ def parse():
     a = ap.parse_args()
     if a.only_headline:
         a.no_cpu_baseline = a.no_rollout = a.no_transolver = a.no_galerkin = a.no_dpot = a.no_unet = a.no_bf16 = a.no_pmc = True
+        a.no_scaling_proxy = True
         a.no_fno_native = True
     return a
 
@@ -569,6 +571,73 @@ def bench_fno_fsi(dev, steps=3):
                                    f"modes {modes}, width {cfg['width']}, {cfg['n_layers']} layers")
 
 
+def strong_scaling_proxy(dev, ms32, steps=5):
+    """What one GPU can say about the 8-GPU strong-scaling run (fixed global batch 32): the step at the per-rank batches 16 / 8 / 4 with
+    the WHOLE data-parallel path on (a one-rank RCCL process group: DataParallel, per-layer buckets through rpb_dp_* on the side
+    stream, SyncBN reductions inline) -- step(32) / step(32 / N) is the ceiling of the N-rank speed-up whatever the interconnect does
+    (batch-independent weight + Adam traffic, ~100 launches per step).  Kernel time of the B = 4 step next to its wall time says
+    whether the small step is launch-bound."""
+    import torch.distributed as dist
+    from realpdebench_amd import _lib
+    from realpdebench_amd.dp import DataParallel
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.trainer import Trainer
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    shape, modes, width, L = (20, 128, 128, 2), (4, 12, 16), 64, 4
+    res = {"how": "one-rank RCCL group, DataParallel + Trainer.step, 2 warm-up + %d timed steps per batch size" % steps,
+           "ms_per_step": {"32": ms32}, "note_32": "B = 32: the headline line itself (no DP wrapper; RPB_FORCE_DP=1 measured equal)"}
+    try:
+        torch.manual_seed(0)
+        model = FNO3d(*modes, L, width, shape, shape).to(dev)
+        DataParallel(model)
+        tr = Trainer(model, lr=1e-4, num_update=4000)
+        for B in (16, 8, 4):
+            x, y = torch.randn(B, *shape, device=dev), torch.randn(B, *shape, device=dev)
+            for _ in range(2):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            res["ms_per_step"][str(B)] = 1e3 * (time.perf_counter() - t0) / steps
+            if B == 4:
+                _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
+                tr.step(x, y)
+                torch.cuda.synchronize()
+                prof = _lib.profile_summary()
+                _lib.PROFILE = None
+                res["B4_kernel_ms"] = sum(v["total_ms"] for v in prof.values())
+                res["B4_launches"] = sum(v["calls"] for v in prof.values())
+                comm = getattr(model.dp, "comm", None)
+                if comm is not None:
+                    comm.set_timing(True)
+                    tr.step(x, y)
+                    torch.cuda.synchronize()
+                    tms = comm.step_times()
+                    res["B4_dp"] = {"exposed_comm_ms": tms["exposed_ms"], "buckets": len(tms["buckets"]),
+                                    "syncbn_inline_reductions": len(tms["inline_ms"]), "syncbn_inline_ms_total": sum(tms["inline_ms"]),
+                                    "syncbn_inline_ms_max": max(tms["inline_ms"] or [0.0])}
+                    comm.set_timing(False)
+            model._ws = {}
+            del x, y
+            torch.cuda.empty_cache()
+        m = res["ms_per_step"]
+        res["speedup_ceiling"] = {"2_ranks": ms32 / m["16"], "4_ranks": ms32 / m["8"], "8_ranks": ms32 / m["4"]}
+        res["byte_model_ceiling_8_ranks"] = (6.238 * 32 + 4.03) / (6.238 * 4 + 4.03)
+        tr.close()
+        del tr, model
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+        torch.cuda.empty_cache()
+    return res
+
+
 def family(label):
     return label.split("[")[0]
 
@@ -720,7 +789,8 @@ def main():
     if (world > 1 or force_dp) and model.dp is not None:
         comm = getattr(model.dp, "comm", None)
         dp_info = {"ranks_in_process_group": dist.get_world_size(), "backend": backend,
-                   "transport": "C-ABI rpb_dp_* (RCCL, side HIP stream, two communicators)" if comm is not None else f"torch.distributed {backend}",
+                   "transport": (f"C-ABI rpb_dp_* (RCCL, side HIP stream, {'two communicators' if comm.small != comm.handle else 'one communicator'})"
+                                 if comm is not None else f"torch.distributed {backend}"),
                    "buckets_MB": [4e-6 * (e - s_) for s_, e in model.dp.buckets]}
         if comm is not None:
             comm.set_timing(True)
@@ -770,9 +840,15 @@ def main():
                                 "frac": fwd_bytes / (1e9 * rt / a.rollout_steps) / HBM_PEAK_GBS}}
 
     extra = {}
+    proxy = None
     if world == 1:
         model = None
         torch.cuda.empty_cache()
+        if not a.no_scaling_proxy and not force_dp:
+            try:
+                proxy = strong_scaling_proxy(dev, ms_per_step)
+            except Exception as e:                          # must never cost the bench line
+                proxy = {"error": repr(e)}
         for name, fn, flag in (("fno_native", bench_fno_native, a.no_fno_native), ("fno_fsi", bench_fno_fsi, a.no_fno_native),
                                ("rollout_bf16", bench_rollout_bf16, a.no_bf16),
                                ("transolver", bench_transolver, a.no_transolver), ("transolver_b16", bench_transolver_b16, a.no_transolver),
@@ -879,6 +955,8 @@ def main():
                                                   "(random-like) data: their ceiling is the random-operand rate, not the datasheet's"}
         if dp_info:
             line["dp"] = dp_info
+        if proxy:
+            line["strong_scaling_proxy"] = proxy
         line.update(extra)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

@@ -350,7 +350,13 @@ __global__ __launch_bounds__(CMW_WAVES * 64, 1) void cmw_kernel(CmxArgs a) {
 
 static size_t cmw_lds(int Wp) { return (size_t)(24 * 64 + 3 * (Wp + 1) * 4 + CMW_WAVES * 12 * 64) * 16; }
 
+static bool cmw_one_wave() {
+    static const bool v = getenv("RPB_CMW_VARIANT") && atoi(getenv("RPB_CMW_VARIANT")) == 1;
+    return v;
+}
+
 long rpb_cmw_slots(long ncell, int Wp) {
+    if (!cmw_one_wave()) return rpb_cmx_wg_slots(ncell, Wp);
     const long G = ncell / Wp;
     long grid = rpb_num_cus();
     const long need = (G + CMW_WAVES - 1) / CMW_WAVES;
@@ -361,6 +367,7 @@ long rpb_cmw_slots(long ncell, int Wp) {
 int rpb_cmw_launch(const CmxArgs& a, hipStream_t st) {
     RPB_REQUIRE(a.x && a.Wm && a.z2 && a.GW && a.out && a.stats_part && a.wg_part && a.bnb_s && a.bnb.mean, "cell_mix_wgrad: null pointer");
     RPB_REQUIRE(!a.bias && !a.xf.mean && !a.bf16_io && !a.feat_w && !a.y1out && a.crop_T == 0, "cell_mix_wgrad: plain fp32 backward launch only");
+    if (!cmw_one_wave()) return rpb_cmx_wg_launch(a, st);
     const size_t lds = cmw_lds(a.Wp);
     RPB_REQUIRE(lds <= 160 * 1024, "cell_mix_wgrad: Wp=%d does not fit LDS", a.Wp);
     const int grid = (int)(rpb_cmw_slots(a.ncell, a.Wp) / CMW_WAVES);

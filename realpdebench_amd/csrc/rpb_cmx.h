@@ -35,5 +35,9 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);
 
 // csrc/rpb_cmw.hip: the STATS == 2 launch with the 1x1-conv weight gradient of the same layer riding along (x = gs of the layer,
 // bnb_s = the pre-BN tensor whose activation is the layer input): dWc[co][ci] = sum_cells x[cell][co] * act(BN(bnb_s))[cell][ci]
+// two organisations: wave pairs inside the two-waves-per-SIMD kernel (rpb_cmx.hip, the default) and one wave per SIMD (rpb_cmw.hip,
+// RPB_CMW_VARIANT=1); the partial-row count is the same function of the problem for both
+long rpb_cmx_wg_slots(long ncell, int Wp);
+int rpb_cmx_wg_launch(const CmxArgs& a, hipStream_t st);
 long rpb_cmw_slots(long ncell, int Wp);            // partial rows of stats_part ([2][64]) and wg_part ([64][64])
 int rpb_cmw_launch(const CmxArgs& a, hipStream_t st);

@@ -88,15 +88,28 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       of channels 4 n + t), so Y1[line] = FW a accumulates on the matrix pipe from the split outputs and the stage never reads the
 //       activations from HBM (one of the three activation passes per layer of the rollout).  The stage matrix per wave tile lives in
 //       LDS in A-operand order; the inverse-stage matrix GW moves to a prepared global buffer to keep 8 waves per workgroup.
+// WG:   STATS == 2 only -- the layer's Conv3d weight gradient dWc[co][ci] = sum_cells x[cell][co] act(BN(bnb_s))[cell][ci] rides along
+//       (x = gs of the layer, bnb_s = the pre-BN tensor whose activation is the layer input; autograd of fno.py:115).  The product
+//       contracts over CELLS, so it wants both factors as "8 cells of one channel per lane": act(z) has that form in the epilogue
+//       (accumulator layout), gs does not (it is this kernel's A operand, lane = cell).  A wave that did both would need 64 more
+//       accumulator registers than the 256 of a two-waves-per-SIMD kernel (the one-wave-per-SIMD version, csrc/rpb_cmw.hip, is
+//       bound by its own instruction stream: 3.4 ms against 2.4 ms for this launch without the product).  So the workgroup is
+//       FOUR PAIRS of waves: "mix" wave p (waves 0-3) is the STATS == 2 kernel and additionally leaves act(z) of its tile -- one erf
+//       serves act and act' -- in an 8 KB LDS mailbox; "wgrad" wave p + 4 fetches the same tile's gs in accumulator layout (L2 hits:
+//       the mix wave requested those lines a tile earlier), splits both factors and runs the 96 MFMAs into its own 64-register
+//       accumulator.  Hand-off per tile through two monotonic LDS counters per pair (produced / consumed); the two waves of a pair
+//       share a SIMD's issue slots, so the light wave runs in the stalls of the heavy one.
 #define CMX_WAVES_DFT 8
-template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false>
-__global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) void cmx_kernel(CmxArgs a) {
+#define CMX_WG_PAIRS 4
+template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false>
+__global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS))) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!WG || (STATS == 2 && !BF && !FEAT && !DFT), "weight-gradient pairs: the fp32 backward launch");
     static_assert(!DFT || STATS == 0, "fused forward W stage: eval path");
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
     static_assert(!(BF && FEAT), "the feature tensor is fp32");
     constexpr int KSN = FEAT ? 1 : 2;                    // K-steps of the channel mixing
     const int FW = a.feat_w;
-    constexpr int CMX_WAVES = DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS);
+    constexpr int CMX_WAVES = WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS));     // line-walking ("mix") waves
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
@@ -106,6 +119,8 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     u32x4* Zs = Bw + 24 * 64 + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
     float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
     u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * 64);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
+    u32x4* MBs = FWs;                                                  // WG: [pair][row (j, r) 8][lane 64]  act(z) of the pair's current tile (fp32)
+    int* flags = reinterpret_cast<int*>(MBs + CMX_WG_PAIRS * 8 * 64);  // WG: [pair][2]  tiles produced / tiles consumed
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,12 +177,111 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
             FWs[((q * 3 + 2) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
         }
     }
+    if (WG) {           // stale rows (the skipped half of a line's last tile) must be finite: they meet gs = 0
+        for (int idx = tid; idx < CMX_WG_PAIRS * 8 * 64; idx += blockDim.x) MBs[idx] = u32x4{0u, 0u, 0u, 0u};
+        if (tid < 2 * CMX_WG_PAIRS) flags[tid] = 0;
+    }
     if (has_xf && tid < 64) {
         xfp[tid] = a.xf.mean[tid];
         xfp[64 + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
         xfp[128 + tid] = a.xf.beta[tid];
     }
     __syncthreads();
+
+    if constexpr (WG) {
+        if (wave >= CMX_WG_PAIRS) {
+            // ================= "wgrad" wave of pair p = wave - 4: walks the same tiles as mix wave p
+            const int pair = wave - CMX_WG_PAIRS;
+            const int G = __builtin_amdgcn_readfirstlane((int)((unsigned)a.ncell / (unsigned)Wp));
+            const int TQ = (Wp + 31) >> 5;
+            const int nslots = (int)gridDim.x * CMX_WG_PAIRS;
+            const int slot = (int)blockIdx.x * CMX_WG_PAIRS + pair;
+            const unsigned line_bytes = (unsigned)Wp * 256u;
+            const int ooff = (4 * kg) * 256 + m * 16;        // accumulator layout: cell 4 mg + r of MFMA tile j, channels 4 n .. 4 n + 3
+            const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4v accW[4][4];                               // tile (uo, ui): row 4 mg + r <-> out channel 4 (4 mg + r) + uo, column n <-> in channel 4 n + ui
+#pragma unroll
+            for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+                for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = z4;
+            u32x4 gb[2][4];
+            auto issue_g = [&](int g_, int q, bool ok) {     // !ok: empty descriptor, zeros without traffic
+                const unsigned long long pa = (unsigned long long)(a.x + (long)g_ * Wp * 64);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+                const rsrc_t rx = make_rsrc(reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo),
+                                            __builtin_amdgcn_readfirstlane(ok ? line_bytes : 0u));
+                const int qo = __builtin_amdgcn_readfirstlane(q) * 8192;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gb[j][r] = ld16(rx, qo + ooff + j * 4096 + r * 256);
+            };
+            int* fl = flags + 2 * pair;
+            const u32x4* mb = MBs + pair * 8 * 64 + lane;
+            int g = slot, q = 0, k = 0;
+            if (g < G) issue_g(g, 0, true);
+            while (g < G) {
+                int gn = g, qn = q + 1;
+                if (qn == TQ) {
+                    qn = 0;
+                    gn = g + nslots;
+                }
+                // gs of this tile: K = (mg, e = 4 j + r) <-> cell 16 j + 4 mg + r; row n of tile uo <-> channel 4 n + uo
+                bf16x8 Gh[4], Gm[4], Gl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * j + r] = __builtin_bit_cast(f32x4v, gb[j][r])[u];
+                    split8(v, Gh[u], Gm[u], Gl[u]);
+                }
+                issue_g(gn, qn, gn < G);                     // next tile's gs: in flight while this wave waits for / multiplies act(z)
+                // (readfirstlane: a branch on a loaded value is divergent to the compiler, and everything downstream of a divergent
+                //  loop exit -- line indices, buffer descriptors -- would then be treated as per-lane values)
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < k + 1)
+                    __builtin_amdgcn_s_sleep(4);
+                u32x4 av[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[j][r] = mb[(4 * j + r) * 64];
+                bf16x8 Xh[4], Xm[4], Xl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * j + r] = __builtin_bit_cast(f32x4v, av[j][r])[u];
+                    split8(v, Xh[u], Xm[u], Xl[u]);
+                }
+                ++k;
+                if (lane == 0) __hip_atomic_store(fl + 1, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // mailbox read: free again
+#pragma unroll
+                for (int uo = 0; uo < 4; ++uo) {
+#define CMX_W(AP, BP) _Pragma("unroll") for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = mfma16(AP[uo], BP[ui], accW[uo][ui]);
+                    CMX_W(Gh, Xl) CMX_W(Gl, Xh) CMX_W(Gm, Xm) CMX_W(Gh, Xm) CMX_W(Gm, Xh) CMX_W(Gh, Xh)
+#undef CMX_W
+                }
+                g = gn;
+                q = qn;
+            }
+            float* wp = a.wg_part + (long)slot * (64 * 64);
+#pragma unroll
+            for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 4 * (4 * kg + r) + uo;
+                    *reinterpret_cast<f32x4v*>(wp + o * 64 + 4 * m) = f32x4v{accW[uo][0][r], accW[uo][1][r], accW[uo][2][r], accW[uo][3][r]};
+                }
+            return;
+        }
+    }
+    int wg_tiles = 0;                                // WG, mix wave: tiles handed to the pair's wgrad wave so far
+    u32x4* MBw = MBs + (WG ? wave : 0) * 8 * 64 + lane;
+    int* wg_fl = flags + 2 * (WG ? wave : 0);
 
     // ---- per-lane output-channel constants (channels 4 n .. 4 n + 3)
     const bool oxf = STATS == 0 && a.bnb.mean != nullptr;
@@ -237,14 +351,17 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     f32x4v Yacc[DFT ? 2 : 1][DFT ? 4 : 1];
     // one wave tile: (gi, q) = the tile computed from the register image `xa`; (ngi, nq) = the tile whose loads take the image's place
     // (the next tile, or with PF2 the one after it; ngi >= G: none)
+    // WG: pin the (wave-uniform) line indices to SGPRs -- with the second wave role in the kernel the compiler keeps them in VGPRs and
+    // wraps every buffer access in a waterfall loop
+    auto U = [&](long v) -> long { return WG ? (long)__builtin_amdgcn_readfirstlane((int)v) : v; };
     auto do_tile = [&](u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
         {
-            const long g = line_of(gi);
+            const long g = U(line_of(gi));
             const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
             const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
             const bool last = q + 1 == TQ;
             const bool more = ngi < G;
-            const long gn = more ? line_of(ngi) : 0;                         // the tile to request: (gn, qn)
+            const long gn = U(more ? line_of(ngi) : 0);                      // the tile to request: (gn, qn)
             const int qn = nq;
             const bool more_lines = gi + nslots < G;
             const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
@@ -319,7 +436,7 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                             Zw[(2 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zl);
                         }
                     }
-                    if (last && more_lines) issue_z(line_of(gi + nslots));   // next line's row: in flight for a whole tile
+                    if (last && more_lines) issue_z(U(line_of(gi + nslots)));   // next line's row: in flight for a whole tile
                     if (STATS == 2) {              // pre-BN values at the output positions (needed by the epilogue)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
@@ -380,13 +497,17 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
             //      tile of a line has cells past the line end (their stores are dropped by the descriptor; the sums skip them)
             auto epilogue = [&](auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
+                if (WG) {       // the pair's wgrad wave must have read the previous tile's act(z) out of the mailbox
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(wg_fl + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < wg_tiles)
+                        __builtin_amdgcn_s_sleep(1);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (j == 1 && half_tile) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool valid = !MASKED || (32 * q + 16 * j + 4 * kg + r < Wp);
-                        f32x4v o;
+                        f32x4v o, avr;
 #pragma unroll
                         for (int t = 0; t < 4; t += 2) {             // channel pairs: packed fp32 math
                             f32x2 v = f32x2{acc[j][t][r], acc[j][t + 1][r]};
@@ -403,7 +524,19 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                                 const f32x4v sp = __builtin_bit_cast(f32x4v, spre[j][r]);
                                 const f32x2 sh = (f32x2{sp[t], sp[t + 1]} - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is};
                                 f32x2 gz = v;
-                                if (bgelu) gz = v * gelu_grad2(pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be}));
+                                if (WG) {           // act(z) for the weight gradient: the same erf serves act and act'
+                                    const f32x2 zz = pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
+                                    f32x2 actv = zz;
+                                    if (bgelu) {
+                                        f32x2 gp;
+                                        gelu_both2(zz, actv, gp);
+                                        gz = v * gp;
+                                    }
+                                    avr[t] = actv[0];
+                                    avr[t + 1] = actv[1];
+                                } else if (bgelu) {
+                                    gz = v * gelu_grad2(pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be}));
+                                }
                                 if (a.write_gz) v = gz;
                                 gz = valid ? gz : pk2(0.f);
                                 ssum[t >> 1] += gz;
@@ -432,7 +565,12 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
                         } else {
                             st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
                         }
+                        if (WG) MBw[(4 * j + r) * 64] = __builtin_bit_cast(u32x4, avr);
                     }
+                }
+                if (WG) {
+                    ++wg_tiles;
+                    if (lane == 0) __hip_atomic_store(wg_fl, wg_tiles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             };
             if (last) epilogue(std::true_type{});
@@ -503,7 +641,7 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
         int q0 = 0, q1 = 0;
         advance(g1, q1);
         if (g0 < G) {
-            const long l0 = line_of(g0);
+            const long l0 = U(line_of(g0));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 issue_x(xaA, l0, 0, j, 0);
@@ -557,7 +695,8 @@ __global__ __launch_bounds__((DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)) * 64) v
     }
 }
 
-static size_t cmx_lds(int Wp, int waves, bool dft = false) {
+static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false) {
+    if (wg) return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (size_t)CMX_WG_PAIRS * 8 * 64 * 16 + 2 * CMX_WG_PAIRS * 4;
     return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0);
 }
 
@@ -585,6 +724,23 @@ bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bo
     static const bool off = getenv("RPB_CELL_MIX_F32") && atoi(getenv("RPB_CELL_MIX_F32")) == 1;   // exact-fp32 MFMA kernel
     return !off && spec && !gather && KC == 64 && CO == 64 && K2 > 0 && K2 <= 32 && Wp >= 32 && ncell % Wp == 0 &&
            cmx_lds(Wp, CMX_WAVES_A) <= 160 * 1024;
+}
+
+// ---- the STATS == 2 launch with the Conv3d weight gradient in wave pairs (WG)
+long rpb_cmx_wg_slots(long ncell, int Wp) {
+    const long G = ncell / Wp;
+    long grid = rpb_num_cus();
+    const long need = (G + CMX_WG_PAIRS - 1) / CMX_WG_PAIRS;
+    if (grid > need) grid = need;
+    return grid * CMX_WG_PAIRS;
+}
+int rpb_cmx_wg_launch(const CmxArgs& a, hipStream_t st) {
+    const size_t lds = cmx_lds(a.Wp, CMX_WG_PAIRS, false, true);
+    RPB_REQUIRE(lds <= 160 * 1024, "cell_mix_wgrad: Wp=%d does not fit LDS", a.Wp);
+    const int grid = (int)(rpb_cmx_wg_slots(a.ncell, a.Wp) / CMX_WG_PAIRS);
+    (void)hipFuncSetAttribute((const void*)cmx_kernel<2, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((cmx_kernel<2, false, false, false, true>), dim3(grid), dim3(2 * CMX_WG_PAIRS * 64), lds, st, a);
+    RPB_CHECK_LAUNCH("cell_mix_wgrad(bf16x3, wave pairs)");
 }
 
 long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {

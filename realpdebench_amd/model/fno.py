@@ -138,11 +138,11 @@ class _Workspace:
                               else ops.cell_wgrad_slots(d.ncell, C, C))
             self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
             self.wg_part = torch.empty(max(self.wg_rows_c * (C * C + C), self.wg_rows_p * (HID * C + HID)), **f)
-            # round 4 (RPB_CELL_MIX_WGRAD=1; built, tested, measured, OFF): d convs.l.weight of layers l >= 1 rides in the backward
-            # cell_mix of the same layer (csrc/rpb_cmw.hip), which streams gs_l and s_{l-1} anyway, and the row kernel no longer reads
-            # the layer input: 24.8 instead of 28.6 GB per layer, but the fused launch is bound by instruction issue at one wave per
-            # SIMD (3.48 + 2.25 ms against 2.40 + 3.04 ms for the round-3 split)
-            self.wg_in_cmx = (os.environ.get("RPB_CELL_MIX_WGRAD") == "1" and self.fused_bwd and C == 64
+            # round 4: d convs.l.weight of layers l >= 1 rides in the backward cell_mix of the same layer (wave pairs inside
+            # csrc/rpb_cmx.hip: the launch streams gs_l and s_{l-1} anyway), and the row kernel no longer reads the layer input: 24.8
+            # instead of 28.6 GB per layer.  The fused launch is bound by instruction issue (3.17 ms against 2.45 ms without the
+            # product) while bn_bwd_row drops 3.04 -> 2.25 ms: step 39.3 -> 38.9 ms.  RPB_CELL_MIX_WGRAD=0: the round-3 split.
+            self.wg_in_cmx = (os.environ.get("RPB_CELL_MIX_WGRAD", "1") != "0" and self.fused_bwd and C == 64
                               and ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True)
                               and ops.cell_mix_wgrad_supported(d.ncell, 2 * plan.KW, d.Wp))
             if self.wg_in_cmx:
