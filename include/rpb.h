@@ -377,6 +377,8 @@ int rpb_lift_feat(const float* x, const float* gt, const float* gh, const float*
 int rpb_cell_mix_feat(const float* phi, const float* Wcomp, const float* bias, const float* z2, const float* GWt, float* out,
                       float* stats_part, long ncell, int FW, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd,
                       const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, void* stream);
+/*     rpb_bn_bwd_row_feat with gs == NULL: the BatchNorm-backward tensor itself is not stored (layer 0 of the fused trainer: its data
+ *     gradient is never formed, so nothing reads gs_0; Y1 and the field moments are all that leaves the kernel). */
 int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float* phi, float* gs, const float* mean, const float* invstd,
                         const float* gamma, const float* beta, const float* sums, double count, int gelu, const float* GWt,
                         float* Y1, float* part, int G, int Wp, int C, int K2, int FW, void* stream);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
         const rsrc_t rs = make_rsrc(a.s + off, row_bytes);
         const rsrc_t ry = make_rsrc(a.gy + off, row_bytes);
         const rsrc_t rx = FEAT ? make_rsrc(a.x + g * (long)Wp * FW, (unsigned)Wp * FW * 4u) : make_rsrc(a.x + off, row_bytes);
-        const rsrc_t ro = make_rsrc(a.gs + off, row_bytes);
+        const rsrc_t ro = make_rsrc(a.gs ? a.gs + off : a.s, a.gs ? row_bytes : 0u);      // gs == NULL: an empty descriptor drops the stores (no traffic)
         f32x16 accw[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) accw[t] = zero16();
@@ -288,7 +288,9 @@ extern "C" int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float*
                                    const float* invstd, const float* gamma, const float* beta, const float* sums, double count,
                                    int gelu, const float* GWt, float* Y1, float* part, int G, int Wp, int C, int K2, int FW,
                                    void* stream) {
-    RPB_REQUIRE(s && gy && phi && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_feat: null pointer");
+    // gs == NULL: the BatchNorm-backward result itself is not stored -- layer 0's data gradient is never formed (csrc/rpb_feat.hip), so
+    // nothing reads gs_0: only Y1 and the field moments leave the kernel (9.1 instead of 12.9 GB at B = 32)
+    RPB_REQUIRE(s && gy && phi && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_feat: null pointer");
     RPB_REQUIRE(C == 64 && (FW == 8 || FW == 32), "bn_bwd_row_feat: C=%d FW=%d unsupported", C, FW);
     RPB_REQUIRE(G > 0 && Wp > 0 && K2 > 0 && K2 <= 32 && count > 0, "bn_bwd_row_feat: bad sizes G=%d Wp=%d K2=%d", G, Wp, K2);
     // (measured at B = 32: the feature-field variant of the bf16-pipe kernel 2.72 ms, this fp32 kernel 2.47 ms -- scalar field loads; off unless asked for)

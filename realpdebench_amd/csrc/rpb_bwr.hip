@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
         }
     };
     auto compute = [&](long g, int q, const u32x4 (&sv)[8], const u32x4 (&yv)[8], const u32x4 (&xv)[8], const float (&fv)[8]) {
-        const rsrc_t ro = make_rsrc(a.gs + g * (long)Wp * 64, row_bytes);
+        const rsrc_t ro = make_rsrc(a.gs ? a.gs + g * (long)Wp * 64 : a.s, a.gs ? row_bytes : 0u);   // gs == NULL: stores dropped
         f32x4v gsv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

@@ -581,7 +581,8 @@ class FNO3d(Model):
             feat_l0 = l == 0 and ws.featfull
             if feat_l0:
                 # layer 0: the weight-gradient operand is the feature tensor; the partial's C x C block holds the field moments
-                ops.bn_bwd_row_feat(ws.S[l], g, ws.phic, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
+                # (gs_0 itself is not stored: with the layer-0 algebra nothing reads it -- Y1 and the field moments are all that leaves)
+                ops.bn_bwd_row_feat(ws.S[l], g, ws.phic, None if ws.feat0 else g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
                                     float(d.ncell) * world, gelu, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp, d.Wp, C,
                                     2 * plan.KW, ws.FW)
             elif ws.fused_bwd:

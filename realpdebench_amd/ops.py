@@ -861,9 +861,11 @@ def cell_mix_feat(phi, Wcomp, bias, z2, GW, out, stats_part, ncell, FW, K2, Wp, 
 
 
 def bn_bwd_row_feat(s, gy, phi, gs, mean, invstd, gamma, beta, sums, count, gelu, GWt, Y1, part, G, Wp, C, K2, FW):
+    """``gs`` None: the BatchNorm-backward tensor is not stored (the fused trainer's layer 0: nothing reads it)."""
     _lib.call("rpb_bn_bwd_row_feat", _p(s), _p(gy), _p(phi), _p(gs), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums),
               float(count), int(gelu), _p(GWt), _p(Y1), _p(part), G, Wp, C, K2, FW, _stream(),
-              label=f"bn_bwd_row[C{C},feat{FW}]", nbytes=4 * (3 * G * Wp * C + G * Wp * FW + G * K2 * C),
+              label=f"bn_bwd_row[C{C},feat{FW}{'' if gs is not None else ',nogs'}]",
+              nbytes=4 * ((3 if gs is not None else 2) * G * Wp * C + G * Wp * FW + G * K2 * C),
               flops=2 * G * Wp * C * (FW + K2))
 
 

@@ -513,6 +513,40 @@ def test_cell_mix_with_the_conv_weight_gradient(ops, Wp, rows, K2, gelu, write_g
     assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
 
 
+@pytest.mark.parametrize("store_gs", [True, False])
+def test_bn_bwd_row_on_the_feature_fields(ops, store_gs):
+    """rpb_bn_bwd_row_feat (layer 0: the weight-gradient operand is the 8-float feature tensor) in fp64 terms -- gs, the adjoint W stage
+    and the field moments sum_cells gs (x) phi -- and its gs == NULL form: same Y1 and moments, the gradient tensor left untouched."""
+    torch.manual_seed(77)
+    C, G, Wp, K2, FW = 64, 11, 38, 24, 8
+    ncell = G * Wp
+    f8 = dict(dtype=torch.float64)
+    s = torch.randn(ncell, C, **f8) * 1.3 + 0.2
+    gy = torch.randn(ncell, C, **f8)
+    phi = torch.randn(ncell, FW, **f8)
+    mean, invstd = s.mean(0), 1 / torch.sqrt(s.var(0, unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    sh = (s - mean) * invstd
+    sums = torch.cat([gy.sum(0), (gy * sh).sum(0)])
+    gs_ref = gamma * invstd * (gy - sums[:C] / ncell - sh * sums[C:] / ncell)
+    GWt = torch.randn(K2, Wp, **f8)
+    g = dev(gy)
+    g0 = g.clone()
+    Y1 = torch.full((G, K2, C), float("nan"), device="cuda")
+    slots = ops.bn_bwd_row_slots(G)
+    part = torch.zeros(slots, C * C + C, device="cuda")
+    ops.bn_bwd_row_feat(dev(s), g, dev(phi), g if store_gs else None, dev(mean), dev(invstd), dev(gamma), dev(beta), dev(sums), ncell,
+                        False, dev(GWt.t()), Y1, part, G, Wp, C, K2, FW)
+    if store_gs:
+        assert rel_l2(g.cpu(), gs_ref) < 5e-6
+    else:
+        assert torch.equal(g, g0)
+    assert rel_l2(Y1.cpu(), torch.einsum("ok,gkc->goc", GWt, gs_ref.view(G, Wp, C))) < 5e-6
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(tot[:C * C].view(C, C)[:, :FW], gs_ref.t() @ phi) < 5e-6
+    assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
+
+
 def _bf16_ulps(a, b):
     """|a - b| in units of the bf16 spacing at |b| (both bf16 tensors)."""
     a, b = a.float(), b.float()
