@@ -131,6 +131,13 @@ class _Workspace:
             self.bnb_rows_conv = ops.cell_mix_stat_rows(d.ncell, C, C, 2 * plan.KW, d.Wp, True, True)
             self.bn_part = torch.empty(max(self.bnb_rows_gather, self.bnb_rows_conv, getattr(self, "pd_slots", 0)) * 2 * C, **f)
             self.bn_sums = torch.empty(2 * C, **f)
+            # width 128 (configs/fsi/fno.yaml, the Galerkin regressor): the fp32-MFMA cell_mix with the BatchNorm-backward sums in its
+            # epilogue spills (8.6 ms at the fsi shape against 2.5 ms without the sums: tools/fsi_probe.py); the plain launch plus the
+            # streaming reduction over (s, g) is 3.3 ms.  RPB_BNB_FUSED_128=1 restores the fused launch.
+            self.bnb_unfused = C == 128 and os.environ.get("RPB_BNB_FUSED_128") != "1"
+            if self.bnb_unfused:
+                self.bnr_rows = ops.bn_bwd_rows()
+                self.bnr_part = torch.empty(self.bnr_rows * 2 * C, **f)
             self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
             self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
             self.fused_bwd = C <= 64             # rpb_bn_bwd_row: BN-backward apply + adjoint W stage + conv wgrad in one pass
@@ -647,6 +654,12 @@ class FNO3d(Model):
                     ops.reduce_partials(ws.cmw_wpart, ws.cmw_slots, C * C, out_f32=GP(f"convs.{l}.weight").view(-1))
                     if self.dp is not None:
                         self.dp.small_ready(gflat, l)    # convs.l / bns.l (17 KB) are final only now: their own tiny all-reduce
+                elif ws.bnb_unfused:
+                    ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, None, d.ncell, C, C, 2 * plan.KW, d.Wp,
+                                 transpose_w=True)
+                    xfb = self._layer_xf(ws, l - 1, True)
+                    ops.bn_bwd_reduce(ws.S[l - 1], g2, xfb[0], xfb[1], xfb[2], xfb[3], ws.bnr_part, d.ncell, C, xfb[4])
+                    ops.reduce_partials(ws.bnr_part, ws.bnr_rows, 2 * C, out_f32=ws.bn_sums)
                 else:
                     ops.cell_mix(g, P(f"convs.{l}.weight"), None, ws.Y1, plan.FW, g2, ws.bn_part, d.ncell, C, C,
                                  2 * plan.KW, d.Wp, transpose_w=True, bnb=(ws.S[l - 1],) + self._layer_xf(ws, l - 1, True),
