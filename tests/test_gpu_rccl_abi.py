@@ -110,10 +110,11 @@ def _rcclcomm_worker(rank, world, port, two_comms, out):
         from realpdebench_amd.dp import RcclComm
         c = RcclComm()
         assert (c.small != c.handle) == bool(two_comms)
-        c.set_timing(True)
         g = torch.full((25 << 20,), float(rank + 1), device="cuda")              # a 100 MB bucket
         s = torch.full((128,), float(rank + 1), device="cuda", dtype=torch.float64)
-        for _ in range(3):                                                       # bucket in flight while the statistics reduce
+        for it in range(3):                                                      # bucket in flight while the statistics reduce
+            if it == 2:
+                c.set_timing(True)                                               # instrument the last step only (what bench.py does)
             g.fill_(float(rank + 1))
             s.fill_(float(rank + 1))
             c.enqueue(g)
