@@ -285,9 +285,143 @@ __global__ __launch_bounds__(256) void mode_mfma_kernel(const float* __restrict_
     }
 }
 
+// ---- C = 128 (configs/fsi/fno.yaml, the Galerkin regressor) on the same pipe: the composite per-mode GEMM is [B x 256] x [256 x 256];
+// the weight tile (128 KB) does not fit next to the coefficients, so the workgroup walks the 64-wide output halves (fwd: o halves with
+// all 128 rows i of the weights; dgrad: i halves with all 128 columns o), re-staging the weight half in LDS (66 KB) each time.  wgrad
+// keeps sixteen 32 x 32 (re, im) tiles in registers, four per wave.  The VALU kernels above ran these at 18-25 TF/s (10.5 of the
+// fsi step's 65 ms, tools/fsi_probe.py).
+#define MM_LD128 129
+template <int MODE>
+__global__ __launch_bounds__(256) void mode_mfma128_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ GY,
+                                                            float* __restrict__ OUT, int B, int M, int accumulate) {
+    constexpr int C = 128;
+    extern __shared__ float lds[];
+    float* Xs = lds;                               // [ri][b 32][c 128 (+1)]   fwd: X, dgrad: gY, wgrad: X
+    float* Ws = lds + 2 * 32 * MM_LD128;           // fwd: [ri][i 128][o-half 64 (+1)];  dgrad: [ri][i-half 64][o 128 (+1)];  wgrad: [ri][b 32][o 128 (+1)] = gY
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const long plane = (long)M * C;
+    const float* src = MODE == 1 ? GY : X;
+    const float* Wm = Wt + (long)m * C * C * 2;
+    f32x16 accA[4], accB[4];                       // wgrad: tile q = 4 * wave + j -> (i0, o0) = (32 (q >> 2), 32 (q & 3))
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accA[j] = accB[j] = zero16();
+    }
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        if (b0) __syncthreads();
+        for (int idx = tid; idx < 2 * 32 * (C / 4); idx += 256) {
+            const int c4 = idx % (C / 4), r = idx / (C / 4);     // r = bl * 2 + ri
+            const int bl = r >> 1, ri = r & 1, b = b0 + bl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                v = *reinterpret_cast<const f32x4*>(src + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+                if (MODE == 2) g = *reinterpret_cast<const f32x4*>(GY + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Xs[(ri * 32 + bl) * MM_LD128 + 4 * c4 + t] = v[t];
+                if (MODE == 2) Ws[(ri * 32 + bl) * MM_LD128 + 4 * c4 + t] = g[t];
+            }
+        }
+        if (MODE == 2) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * wave + j, i0 = 32 * (q >> 2), o0 = 32 * (q & 3);
+#pragma unroll 4
+                for (int s = 0; s < 16; ++s) {
+                    const int bl = 2 * s + half;
+                    const float xr = Xs[(0 * 32 + bl) * MM_LD128 + i0 + col], xi = Xs[(1 * 32 + bl) * MM_LD128 + i0 + col];
+                    const float gr = Ws[(0 * 32 + bl) * MM_LD128 + o0 + col], gi = Ws[(1 * 32 + bl) * MM_LD128 + o0 + col];
+                    accA[j] = mfma32(xr, gr, accA[j]);
+                    accA[j] = mfma32(xi, gi, accA[j]);
+                    accB[j] = mfma32(xr, gi, accB[j]);
+                    accB[j] = mfma32(-xi, gr, accB[j]);
+                }
+            }
+            continue;
+        }
+        for (int hf = 0; hf < 2; ++hf) {           // output half: columns (fwd: o, dgrad: i) 64 hf .. 64 hf + 63
+            __syncthreads();                       // Xs staged (first half) / the previous half's weight reads are done
+            if (MODE == 0) {                       // Ws[ri][i][o - 64 hf], 65 floats per row
+                for (int idx = tid; idx < C * 32; idx += 256) {          // 128 rows x 32 pairs of complex numbers
+                    const int i = idx >> 5, p2 = idx & 31, o = 64 * hf + 2 * p2;
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wm + ((long)i * C + o) * 2);
+                    Ws[(0 * C + i) * MM_LD + 2 * p2] = w[0];
+                    Ws[(1 * C + i) * MM_LD + 2 * p2] = w[1];
+                    Ws[(0 * C + i) * MM_LD + 2 * p2 + 1] = w[2];
+                    Ws[(1 * C + i) * MM_LD + 2 * p2 + 1] = w[3];
+                }
+            } else {                               // Ws[ri][i - 64 hf][o], 129 floats per row
+                for (int idx = tid; idx < 64 * 64; idx += 256) {         // 64 rows x 64 pairs of complex numbers
+                    const int il = idx >> 6, p2 = idx & 63, o = 2 * p2;
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wm + ((long)(64 * hf + il) * C + o) * 2);
+                    Ws[(0 * 64 + il) * MM_LD128 + o] = w[0];
+                    Ws[(1 * 64 + il) * MM_LD128 + o] = w[1];
+                    Ws[(0 * 64 + il) * MM_LD128 + o + 1] = w[2];
+                    Ws[(1 * 64 + il) * MM_LD128 + o + 1] = w[3];
+                }
+            }
+            __syncthreads();
+            const int ro = wave >> 1, n0 = (wave & 1) * 32;              // the wave's 32 columns of plane ro of this half
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                const int wp = ri ^ ro;
+                const bool neg = MODE == 0 ? (ri == 1 && ro == 0) : (ri == 0 && ro == 1);
+                const float* xa = Xs + (ri * 32 + col) * MM_LD128 + half;
+                // fwd: B[k][n] = W[i = k][o = n0 + col] (row pitch 65);  dgrad: B[k][n] = W[i = n0 + col][o = k] (row pitch 129)
+                const float* wb = MODE == 0 ? Ws + (wp * C + half) * MM_LD + n0 + col : Ws + (wp * 64 + n0 + col) * MM_LD128 + half;
+                constexpr int kstep = MODE == 0 ? 2 * MM_LD : 2;
+#pragma unroll 8
+                for (int s = 0; s < C / 2; ++s) {
+                    const float a = xa[2 * s];
+                    acc = mfma32(neg ? -a : a, wb[s * kstep], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = b0 + mfma_row(lane, r);
+                if (b < B) OUT[(long)(b * 2 + ro) * plane + (long)m * C + 64 * hf + n0 + col] = acc[r];
+            }
+        }
+    }
+    if (MODE == 2) {
+        float* Gm = OUT + (long)m * C * C * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = 4 * wave + j, i0 = 32 * (q >> 2), o0 = 32 * (q & 3);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                f32x2* dst = reinterpret_cast<f32x2*>(Gm + ((long)(i0 + mfma_row(lane, r)) * C + o0 + col) * 2);
+                f32x2 v = {accA[j][r], accB[j][r]};
+                if (accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+static size_t mode128_lds(int mode) {
+    const size_t xs = 2 * 32 * MM_LD128, ws = mode == 0 ? 2 * 128 * MM_LD : (mode == 1 ? 2 * 64 * MM_LD128 : 2 * 32 * MM_LD128);
+    return (xs + ws) * 4;
+}
+template <int MODE>
+static int launch_mode128(const float* X, const float* W, const float* GY, float* OUT, int B, int M, int accumulate, hipStream_t st) {
+    const size_t lds = mode128_lds(MODE);
+    (void)hipFuncSetAttribute((const void*)mode_mfma128_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mode_mfma128_kernel<MODE>), dim3(M), dim3(256), lds, st, X, W, GY, OUT, B, M, accumulate);
+    return RPB_OK;
+}
+
 static bool mode_mfma_on(int C) {
     static const bool off = getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1;
     return !off && C == 64;
+}
+static bool mode_mfma128_on(int C) {
+    static const bool off = getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1;
+    return !off && C == 128;
 }
 
 static int mc_check(const void* a, const void* b, const void* c, int B, int M, int C) {
@@ -303,6 +437,10 @@ extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, i
         hipLaunchKernelGGL((mode_mfma_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
         RPB_CHECK_LAUNCH("mode_contract_fwd");
     }
+    if (mode_mfma128_on(C)) {
+        (void)launch_mode128<0>(X, W, nullptr, Y, B, M, 0, (hipStream_t)stream);
+        RPB_CHECK_LAUNCH("mode_contract_fwd");
+    }
     const size_t lds = (size_t)B * 2 * C * 4;
     RPB_REQUIRE(lds <= 160 * 1024, "mode_contract_fwd: B*C too large for LDS");
     (void)hipFuncSetAttribute((const void*)mode_contract_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -316,6 +454,10 @@ extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* G
     if (int e = mc_check(GY, W, GX, B, M, C)) return e;
     if (mode_mfma_on(C)) {
         hipLaunchKernelGGL((mode_mfma_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        RPB_CHECK_LAUNCH("mode_contract_dgrad");
+    }
+    if (mode_mfma128_on(C)) {
+        (void)launch_mode128<1>(nullptr, W, GY, GX, B, M, 0, (hipStream_t)stream);
         RPB_CHECK_LAUNCH("mode_contract_dgrad");
     }
     if (C % MD_ROWS == 0) {
@@ -339,6 +481,10 @@ extern "C" int rpb_mode_contract_wgrad(const float* X, const float* GY, float* G
     if (int e = mc_check(X, GY, GW, B, M, C)) return e;
     if (mode_mfma_on(C)) {
         hipLaunchKernelGGL((mode_mfma_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        RPB_CHECK_LAUNCH("mode_contract_wgrad");
+    }
+    if (mode_mfma128_on(C)) {
+        (void)launch_mode128<2>(X, nullptr, GY, GW, B, M, accumulate, (hipStream_t)stream);
         RPB_CHECK_LAUNCH("mode_contract_wgrad");
     }
     const size_t lds = (size_t)B * 4 * C * 4;

@@ -43,7 +43,7 @@ def test_axis_gemm(ops, G, K, O, N, kv):
     assert rel_l2(out.cpu(), 2 * ref) < TOL
 
 
-@pytest.mark.parametrize("B,M,C", [(3, 10, 32), (32, 6, 64), (5, 7, 64), (70, 3, 64), (5, 4, 128), (32, 3, 128)])
+@pytest.mark.parametrize("B,M,C", [(3, 10, 32), (32, 6, 64), (5, 7, 64), (70, 3, 64), (5, 4, 128), (32, 3, 128), (70, 2, 128)])
 def test_mode_contract(ops, B, M, C):
     torch.manual_seed(B + M + C)
     X = torch.randn(B, 2, M, C, dtype=torch.float64)
