@@ -162,7 +162,9 @@ def cell_mix_family_bytes(per_kernel):
     3 x forward + BatchNorm sums, 1 x layer 0 on the feature fields, 3 x backward + BatchNorm-backward sums."""
     tot = {kn: t["rd"] + t["wr"] for kn, t in per_kernel.items() if "rd" in t and "wr" in t}
     pick = lambda sub: next(v for k, v in tot.items() if sub in k)
-    return (3 * pick("<1, false, false, false>") + pick("<1, false, true, false>") + 3 * pick("<2, false, false, false>")) / 7
+    # template arguments <STATS, BF, FEAT, DFT, WG>; round 4: the backward launch of the step is the wave-pair variant (WG) that also
+    # forms the Conv3d weight gradient (same algorithmic bytes as the plain STATS = 2 launch)
+    return (3 * pick("<1, false, false, false, false>") + pick("<1, false, true, false, false>") + 3 * pick("<2, false, false, false, true>")) / 7
 
 
 def live_pmc_traffic(family):
