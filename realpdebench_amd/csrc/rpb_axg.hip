@@ -49,6 +49,23 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m
     m = __builtin_bit_cast(bf16x8, um);
     l = __builtin_bit_cast(bf16x8, ul);
 }
+// the same with only the first `npairs` element pairs live (wave-uniform): the rest are zero planes at no vector cost
+__device__ __forceinline__ void split8n(const float (&v)[8], int npairs, bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 uh = {0u, 0u, 0u, 0u}, um = uh, ul = uh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= npairs) break;
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = pack_hi(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        um[q] = pack_hi(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        ul[q] = pack_hi(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
 __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -69,14 +86,21 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const int c16 = lane & 15, kg = lane >> 4;
     const int KS = (a.k_valid + 31) >> 5;                    // K-steps that hold non-zero input
     const int mtiles = (a.O + 15) >> 4;
+    // The LAST K-step usually holds few rows (Wp = 134: 6 of 32).  With the regular assignment k = 32 ks + 8 kg + e lane group 0 would
+    // carry all of them and every lane would still run the lazy BatchNorm + GELU and the split on 8 elements: a fifth of the forward W
+    // stage's vector work on zeros.  The tail step instead deals its rows `epl` per lane group, k = 32 ks + epl kg + e for e < epl, and
+    // elements e >= epl are compile-time-uniformly skipped (zero planes): 6 rows cost 2 / 8 of a step.  The matrix is laid out to match.
+    const int rem = a.k_valid - 32 * (KS - 1);
+    const int epl = BFIN ? 8 : (rem + 3) >> 2;               // rows per lane group in the last step (8 = the regular assignment)
     for (int idx = tid; idx < KS * mtiles * 64; idx += blockDim.x) {
         const int l = idx & 63, mt = (idx >> 6) % mtiles, ks = (idx >> 6) / mtiles;
         const int o = 16 * mt + (l & 15);
+        const int per = ks == KS - 1 ? epl : 8;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = 32 * ks + 8 * (l >> 4) + e;
-            v[e] = (o < a.O && k < a.k_valid) ? a.Mt[(long)k * a.O + o] : 0.f;
+            const int k = 32 * ks + per * (l >> 4) + e;
+            v[e] = (o < a.O && e < per && k < a.k_valid) ? a.Mt[(long)k * a.O + o] : 0.f;
         }
         bf16x8 h, md, lo;
         split8(v, h, md, lo);
@@ -100,6 +124,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * EB);
     const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * 4);
     const int ioff = (8 * kg) * (int)a.in_k * EB + c16 * 4 * EB;             // row 8 kg, columns 4 c .. 4 c + 3
+    const int ioff_tail = (epl * kg) * (int)a.in_k * EB + c16 * 4 * EB;      // last step: row epl kg
     const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;                 // row 4 mg, columns 4 c ..
     const int istep = (int)a.in_k * EB;                                      // bytes between consecutive k rows
 
@@ -121,6 +146,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                 for (int t = 0; t < 4; ++t) acc[i][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
             u32x4 zr[8];
             auto issue = [&](int ks) {
+                const bool tail = !BFIN && ks == KS - 1;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (BFIN) {
@@ -128,13 +154,17 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                         const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(ri, ioff + (32 * ks + e) * istep, 0, 0);
                         zr[e][0] = w[0];
                         zr[e][1] = w[1];
-                    } else {
+                    } else if (!tail) {
                         zr[e] = ld16(ri, ioff + (32 * ks + e) * istep);
+                    } else if (e < epl) {                                     // (uniform) rows past epl are not even requested
+                        zr[e] = ld16(ri, ioff_tail + (32 * ks + e) * istep);
                     }
                 }
             };
             issue(0);
             for (int ks = 0; ks < KS; ++ks) {
+                const bool tail = !BFIN && ks == KS - 1;
+                const int per = tail ? epl : 8;
                 // ---- this step's 8 x 4 values -> B planes of the 4 column tiles (lazy BN+GELU of the producer applied here)
                 bf16x8 Bh[4], Bm[4], Bl[4];
                 if (BFIN) {                 // word 0 = columns (0, 1), word 1 = columns (2, 3): gather each column's 8 rows
@@ -151,9 +181,14 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                     float v[4][8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
+                        if (e >= per) {                                       // uniform: only in the last step
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[t][e] = 0.f;
+                            continue;
+                        }
                         const f32x4v x4 = __builtin_bit_cast(f32x4v, zr[e]);
                         // rows past k_valid must stay zero: the transform of a masked load is not
-                        const bool live = !XF || (32 * ks + 8 * kg + e < a.k_valid);
+                        const bool live = !XF || (32 * ks + per * kg + e < a.k_valid);
 #pragma unroll
                         for (int t = 0; t < 4; t += 2) {                      // channel pairs: packed fp32 math
                             f32x2 x = f32x2{x4[t], x4[t + 1]};
@@ -167,8 +202,13 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                             v[t + 1][e] = x[1];
                         }
                     }
+                    if (tail) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) split8(v[t], Bh[t], Bm[t], Bl[t]);
+                        for (int t = 0; t < 4; ++t) split8n(v[t], (per + 1) >> 1, Bh[t], Bm[t], Bl[t]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) split8(v[t], Bh[t], Bm[t], Bl[t]);
+                    }
                 }
                 // ---- next step's loads go out now and are in flight during the MFMAs below
                 if (ks + 1 < KS) issue(ks + 1);

@@ -459,42 +459,47 @@ class DPOT(_ModelBase):
         A1 = new(B * 2 * mk * n * E)
         splits = ops.afno_wgrad_splits(ntok)
         wpart = new(splits * nb * 4 * bs * bs)
-        for blk, tp in zip(reversed(list(net.blocks)), reversed(sv["tapes"])):
-            fl, m0, m2 = blk.filter, blk.mlp[0], blk.mlp[2]
-            dWm2, dbm2 = _wgrad(g, tp["Hh"], Mt, E, hid)
-            grads[m2.weight], grads[m2.bias] = dWm2.reshape(m2.weight.shape), dbm2
-            gH = new(Mt, hid)
-            ops.gemm_nt(g, Tr(m2.weight.data.view(E, hid)), gH, Mt, hid, E, act=2, aux=tp["Hpre"])
-            dWm0, dbm0 = _wgrad(gH, tp["Y2"], Mt, hid, E)
-            grads[m0.weight], grads[m0.bias] = dWm0.reshape(m0.weight.shape), dbm0
-            gY2 = new(Mt, E)
-            ops.gemm_nt(gH, Tr(m0.weight.data.view(hid, E)), gY2, Mt, E, hid)
-            del gH
-            pg, pb = new(B, E), new(B, E)
-            gz = new(Mt, E)
-            ops.gn_tokens_bwd(tp["Fo"], tp["Y1"], blk.norm2.weight.data, tp["st2"], gY2, None, gz, pg, pb, B, n * n, E, 8)
-            grads[blk.norm2.weight], grads[blk.norm2.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
-            # AFNO: z = irfft2(mlp_c(rfft2(y1))) + y1
-            gO2 = new(ntok, 2 * E)
-            self._irfft2(gO2, A1, gz, B, pl, E, fwd=False)
-            W2t, W1t = new(nb, 2 * bs, 2 * bs), new(nb, 2 * bs, 2 * bs)
-            ops.afno_wprep(fl.w2.data, W2t, nb, bs, True)
-            ops.afno_wprep(fl.w1.data, W1t, nb, bs, True)
-            gHs, gS = new(ntok, 2 * E), new(ntok, 2 * E)
-            ops.afno_mlp(gO2, W2t, None, W1t, None, tp["Hs"], gHs, gS, ntok, nb, bs, 1)
-            dw2, dw1 = torch.empty_like(fl.w2), torch.empty_like(fl.w1)
-            ops.afno_wgrad(tp["Hs"], gO2, wpart, dw2, ntok, nb, bs, True)
-            ops.afno_wgrad(tp["S"], gHs, wpart, dw1, ntok, nb, bs, False)
-            grads[fl.w2], grads[fl.w1] = dw2, dw1
-            grads[fl.b2] = self._colsum(gO2, ntok, 2 * E).view(fl.b2.shape)
-            grads[fl.b1] = self._colsum(gHs, ntok, 2 * E).view(fl.b1.shape)
-            gY1 = new(Mt, E)
-            self._rfft2(gY1, A1, gS, B, pl, E, fwd=False)
-            gY1 = ops.add(gY1, gz)
-            gX = new(Mt, E)
-            ops.gn_tokens_bwd(tp["X"], None, blk.norm1.weight.data, tp["st1"], gY1, g, gX, pg, pb, B, n * n, E, 8)
-            grads[blk.norm1.weight], grads[blk.norm1.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
-            g = gX
+        # every block ends ~10 partial reductions (weight / bias / norm gradients) that nobody reads before the pass is over: they are
+        # queued and run as ONE grouped launch after the loop (68 launches of ~15 us were 1.0 of the 9.8 ms step)
+        defer = ops.deferred_reductions(os.environ.get("RPB_DPOT_DEFER_REDUCE", "1") != "0")
+        with defer:
+            for blk, tp in zip(reversed(list(net.blocks)), reversed(sv["tapes"])):
+                fl, m0, m2 = blk.filter, blk.mlp[0], blk.mlp[2]
+                dWm2, dbm2 = _wgrad(g, tp["Hh"], Mt, E, hid)
+                grads[m2.weight], grads[m2.bias] = dWm2.reshape(m2.weight.shape), dbm2
+                gH = new(Mt, hid)
+                ops.gemm_nt(g, Tr(m2.weight.data.view(E, hid)), gH, Mt, hid, E, act=2, aux=tp["Hpre"])
+                dWm0, dbm0 = _wgrad(gH, tp["Y2"], Mt, hid, E)
+                grads[m0.weight], grads[m0.bias] = dWm0.reshape(m0.weight.shape), dbm0
+                gY2 = new(Mt, E)
+                ops.gemm_nt(gH, Tr(m0.weight.data.view(hid, E)), gY2, Mt, E, hid)
+                del gH
+                pg, pb = new(B, E), new(B, E)
+                gz = new(Mt, E)
+                ops.gn_tokens_bwd(tp["Fo"], tp["Y1"], blk.norm2.weight.data, tp["st2"], gY2, None, gz, pg, pb, B, n * n, E, 8)
+                grads[blk.norm2.weight], grads[blk.norm2.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
+                # AFNO: z = irfft2(mlp_c(rfft2(y1))) + y1
+                gO2 = new(ntok, 2 * E)
+                self._irfft2(gO2, A1, gz, B, pl, E, fwd=False)
+                W2t, W1t = new(nb, 2 * bs, 2 * bs), new(nb, 2 * bs, 2 * bs)
+                ops.afno_wprep(fl.w2.data, W2t, nb, bs, True)
+                ops.afno_wprep(fl.w1.data, W1t, nb, bs, True)
+                gHs, gS = new(ntok, 2 * E), new(ntok, 2 * E)
+                ops.afno_mlp(gO2, W2t, None, W1t, None, tp["Hs"], gHs, gS, ntok, nb, bs, 1)
+                dw2, dw1 = torch.empty_like(fl.w2), torch.empty_like(fl.w1)
+                ops.afno_wgrad(tp["Hs"], gO2, wpart, dw2, ntok, nb, bs, True)
+                ops.afno_wgrad(tp["S"], gHs, wpart, dw1, ntok, nb, bs, False)
+                grads[fl.w2], grads[fl.w1] = dw2, dw1
+                grads[fl.b2] = self._colsum(gO2, ntok, 2 * E).view(fl.b2.shape)
+                grads[fl.b1] = self._colsum(gHs, ntok, 2 * E).view(fl.b1.shape)
+                gY1 = new(Mt, E)
+                self._rfft2(gY1, A1, gS, B, pl, E, fwd=False)
+                gY1 = ops.add(gY1, gz)
+                gX = new(Mt, E)
+                pg, pb = new(B, E), new(B, E)                  # (fresh partial rows: norm2's are still waiting for the grouped reduction)
+                ops.gn_tokens_bwd(tp["X"], None, blk.norm1.weight.data, tp["st1"], gY1, g, gX, pg, pb, B, n * n, E, 8)
+                grads[blk.norm1.weight], grads[blk.norm1.bias] = self._sum_rows(pg, B, E), self._sum_rows(pb, B, E)
+                g = gX
         # ---- TimeAggregator
         ta = net.time_agg_layer
         pe0, pe2 = net.patch_embed.proj[0], net.patch_embed.proj[2]
@@ -589,8 +594,8 @@ class DPOT(_ModelBase):
         while N % chunk:
             chunk //= 2
         out = torch.empty(N, device=x.device, dtype=torch.float32)
-        part = torch.empty(rows, chunk, device=x.device, dtype=torch.float32)
         for c0 in range(0, N, chunk):
+            part = torch.empty(rows, chunk, device=x.device, dtype=torch.float32)      # one per chunk: the reduction may be deferred
             ops.colsum(ops.Sub(x, c0), part, M, chunk, ld=N)
             ops.reduce_partials(part, rows, chunk, out_f32=ops.Sub(out, c0))
         return out

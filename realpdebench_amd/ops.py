@@ -222,9 +222,51 @@ def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1),
               label=f"cell_wgrad[CO{CO},CI{CI}]", nbytes=4 * ncell * (CO + CI), flops=2 * ncell * CO * CI)
 
 
+class deferred_reductions:
+    """Context manager: every plain ``reduce_partials`` issued inside (fp32 output, no scale / accumulate) is queued and all of them run
+    as ONE ``rpb_reduce_partials_grouped`` launch on exit.  For backward passes whose blocks each end in ~10 partial reductions of a few
+    microseconds whose results nobody reads before the pass is over (parameter gradients).  The caller guarantees that the partial buffers
+    are not overwritten and the outputs not read inside the block."""
+    active = None
+
+    def __init__(self, enabled=True):
+        self.enabled, self.items, self.keep = enabled, [], []
+
+    def __enter__(self):
+        if self.enabled:
+            self.prev, deferred_reductions.active = deferred_reductions.active, self
+        return self
+
+    def add(self, part_ptr, out_ptr, rows, L, stride, tensors):
+        self.items.append((part_ptr, out_ptr, rows, L, stride))
+        self.keep.extend(tensors)
+
+    def __exit__(self, *exc):
+        if not self.enabled:
+            return False
+        deferred_reductions.active = self.prev
+        if self.items and exc[0] is None:
+            import numpy as np
+            tab, chunk0 = np.empty((len(self.items), 6), dtype=np.int64), 0
+            for i, (pp, op, rows, L, stride) in enumerate(self.items):
+                tab[i] = (pp, op, rows, L, stride, chunk0)
+                chunk0 += (L + 63) // 64
+            dev = self.keep[0].device
+            d = torch.from_numpy(tab).to(dev)                   # ~3 KB, staged by the runtime: the host does not wait for the stream
+            _lib.call("rpb_reduce_partials_grouped", d.data_ptr(), len(self.items), chunk0, _stream(), label="reduce_partials_grouped")
+            self.keep.append(d)
+        self.items, self.keep = [], []
+        return False
+
+
 def reduce_partials(part, rows, L, out_f32=None, out_f64=None, scale=1.0, accumulate=False, row_stride=None,
                     col0=0):
     """out[j] (+)= scale * sum_r part[r*row_stride + col0 + j] for j < L."""
+    q = deferred_reductions.active
+    if q is not None and out_f64 is None and out_f32 is not None and scale == 1.0 and not accumulate:
+        q.add(_p(part) + 4 * col0, _p(out_f32), rows, L, L if row_stride is None else row_stride,
+              [part.t if isinstance(part, Sub) else part, out_f32.t if isinstance(out_f32, Sub) else out_f32])
+        return
     _lib.call("rpb_reduce_partials", _p(part) + 4 * col0, rows, L, L if row_stride is None else row_stride,
               _p(out_f32), _p(out_f64, torch.float64), float(scale), int(accumulate), _stream())
 

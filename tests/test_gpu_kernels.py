@@ -770,3 +770,31 @@ def test_reduce_partials_shapes(ops, rows, L, stride):
     assert rel_l2(o64.cpu(), ref32) < 1e-14 and rel_l2(o32.cpu(), ref32) < 2e-7
     ops.reduce_partials(p32, rows, L, out_f32=o32, row_stride=stride, scale=0.5, accumulate=True)
     assert rel_l2(o32.cpu(), 1.5 * ref32) < 3e-7
+
+
+def test_grouped_partial_reductions_equal_the_single_launches(ops):
+    """ops.deferred_reductions: reductions of different shapes / strides / column offsets queued inside the block run as ONE
+    rpb_reduce_partials_grouped launch and give bit-identical results to the per-item launches (same fp64 accumulation order)."""
+    torch.manual_seed(5)
+    shapes = [(7, 100, 100, 0), (300, 64, 64, 0), (12, 5000, 5064, 0), (33, 64, 5064, 5000), (1, 3, 3, 0), (64, 1024 * 33, 1024 * 33, 0)]
+    parts = [torch.randn(rows, stride, device="cuda") for rows, L, stride, c0 in shapes]
+    ref = []
+    for p, (rows, L, stride, c0) in zip(parts, shapes):
+        o = torch.empty(L, device="cuda")
+        ops.reduce_partials(p, rows, L, out_f32=o, row_stride=stride, col0=c0)
+        ref.append(o)
+    outs = [torch.full((L,), float("nan"), device="cuda") for rows, L, stride, c0 in shapes]
+    with ops.deferred_reductions():
+        for p, o, (rows, L, stride, c0) in zip(parts, outs, shapes):
+            ops.reduce_partials(p, rows, L, out_f32=o, row_stride=stride, col0=c0)
+        assert all(bool(torch.isnan(o).all()) for o in outs)          # nothing ran yet
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert torch.equal(o, r)
+    assert ops.deferred_reductions.active is None
+    # an exception inside the block drops the queue and restores immediate mode
+    with pytest.raises(RuntimeError):
+        with ops.deferred_reductions():
+            ops.reduce_partials(parts[0], 7, 100, out_f32=outs[0])
+            raise RuntimeError("boom")
+    assert ops.deferred_reductions.active is None
