@@ -109,8 +109,9 @@ int rpb_reduce_partials(const float* part, long rows, long L, long row_stride, f
 int rpb_reduce_partials_batched(const float* part, int nbatch, long rows, long L, long row_stride, long batch_stride,
                                 float* outf, void* stream);
 /*     n reductions of different shapes in one launch: items [n][6] int64 ON THE DEVICE = { part pointer, out pointer (fp32), rows, L,
- *     row_stride in floats, first 64-column chunk of the item }, total_chunks = sum over items of ceil(L / 64).  out[j] = sum_r part[r *
- *     row_stride + j] in fp64, fixed order (as rpb_reduce_partials). */
+ *     row_stride in floats, first grid block of the item }; a block covers rpb_reduce_partials_grouped_cols() columns, total_chunks =
+ *     sum over items of ceil(L / that).  out[j] = sum_r part[r * row_stride + j] in fp64, fixed order (as rpb_reduce_partials). */
+int rpb_reduce_partials_grouped_cols(void);
 int rpb_reduce_partials_grouped(const void* items, int n, long total_chunks, void* stream);
 int rpb_bn_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, int C, void* stream);

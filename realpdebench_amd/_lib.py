@@ -89,6 +89,7 @@ SIGNATURES = {
     "rpb_reduce_partials": (_I, "p" + "lll" + "pp" + "d" + "i" + "p"),
     "rpb_reduce_partials_batched": (_I, "p" + "i" + "llll" + "p" + "p"),
     "rpb_reduce_partials_grouped": (_I, "pilp"),
+    "rpb_reduce_partials_grouped_cols": (_I, ""),
     "rpb_bn_finalize": (_I, "p" + "d" + "ff" + "pppp" + "i" + "p"),
     "rpb_bn_eval_prep": (_I, "p" + "f" + "p" + "i" + "p"),
     "rpb_bn_act_fwd": (_I, "pppppp" + "l" + "ii" + "p"),

@@ -126,46 +126,40 @@ extern "C" int rpb_small_gemm(const float* A, const float* Bm, float* out, int M
 // Phi_c[cell][FW]: the feature fields per padded cell, channels-last -- (x_0 .. x_{Cin-1}, grid_t, grid_h, grid_w, 1, 0 ..) on the
 // cells of the data, all zeros in the pad margin.  It replaces the lifted tensor A0 = W0ext Phi_c (64 channels) as the input of
 // layer 0's channel mixing and of its weight gradient: 8 (or 32) floats per cell instead of 64.
-// A block walks whole (b,t,h) rows: the row decode (two divisions) is wave-uniform and done once per row, a thread writes one 16 B
-// piece of every (256 / q4)-th cell (round 3 decoded every piece with three 64-bit divisions: 0.29 ms at 1.9 TB/s).
+// One thread = one 16 B piece of the output, decoded with 32-bit divisions (the row-walking variant left most of a 256-thread block idle
+// on the second pass over a 268-piece row; round 3 decoded every piece with three 64-bit divisions).
 __global__ __launch_bounds__(256) void lift_feat_kernel(const float* __restrict__ x, const float* __restrict__ gt,
                                                         const float* __restrict__ gh, const float* __restrict__ gw,
-                                                        float* __restrict__ out, long nrows, int Cin, int FW, CropMap cm) {
-    const int q4 = FW >> 2, qs = FW == 8 ? 1 : 3;        // pieces per cell: 2 or 8
-    const int npiece = cm.Wp * q4;
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const unsigned ur = (unsigned)row;                // rows < 2^31
-        const unsigned bt = ur / (unsigned)cm.Hp, h = ur - bt * (unsigned)cm.Hp;
+                                                        float* __restrict__ out, unsigned total, int Cin, int FW, CropMap cm) {
+    const unsigned q4 = FW >> 2, qs = FW == 8 ? 1 : 3;   // pieces per cell: 2 or 8
+    const unsigned npiece = (unsigned)cm.Wp * q4;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned row = idx / npiece, i = idx - row * npiece;
+        const unsigned bt = row / (unsigned)cm.Hp, h = row - bt * (unsigned)cm.Hp;
         const unsigned b = bt / (unsigned)cm.Tp, t = bt - b * (unsigned)cm.Tp;
-        const bool rv = (int)h < cm.H && (int)t < cm.T;
-        const float* xrow = x + (((long)b * cm.T + t) * cm.H + h) * (long)cm.W * Cin;
-        float* orow = out + row * (long)cm.Wp * FW;
-        const float gtv = rv ? gt[t] : 0.f, ghv = rv ? gh[h] : 0.f;
-        for (int i = threadIdx.x; i < npiece; i += 256) {
-            const int w = i >> qs, f0 = (i & (q4 - 1)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (rv && w < cm.W) {
-                const float* xp = xrow + (long)w * Cin;
+        const int w = (int)(i >> qs), f0 = (int)(i & (q4 - 1)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((int)h < cm.H && (int)t < cm.T && w < cm.W) {
+            const float* xp = x + ((((long)b * cm.T + t) * cm.H + h) * (long)cm.W + w) * Cin;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int f = f0 + k;
-                    v[k] = f < Cin ? xp[f] : f == Cin ? gtv : f == Cin + 1 ? ghv : f == Cin + 2 ? gw[w] : f == Cin + 3 ? 1.f : 0.f;
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int f = f0 + k;
+                v[k] = f < Cin ? xp[f] : f == Cin ? gt[t] : f == Cin + 1 ? gh[h] : f == Cin + 2 ? gw[w] : f == Cin + 3 ? 1.f : 0.f;
             }
-            *reinterpret_cast<f32x4*>(orow + (long)i * 4) = v;
         }
+        *reinterpret_cast<f32x4*>(out + (long)idx * 4) = v;
     }
 }
 
 extern "C" int rpb_lift_feat(const float* x, const float* gt, const float* gh, const float* gw, float* out, int B, int T, int H,
                              int W, int Cin, int Tp, int Hp, int Wp, int FW, void* stream) {
     RPB_REQUIRE(x && gt && gh && gw && out && (FW == 8 || FW == 32) && Cin + 4 <= FW, "lift_feat: FW=%d must be 8 or 32 and hold Cin + 4 = %d fields", FW, Cin + 4);
-    const long nrows = (long)B * Tp * Hp;
-    RPB_REQUIRE(nrows < (1L << 31), "lift_feat: too many rows");
-    long grid = nrows;
-    const long cap = (long)rpb_num_cus() * 16;
+    const long total = (long)B * Tp * Hp * Wp * (FW / 4);
+    RPB_REQUIRE(total < (1L << 31), "lift_feat: too many cells");
+    long grid = (total + 255) / 256;
+    const long cap = (long)rpb_num_cus() * 32;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(lift_feat_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, gt, gh, gw, out, nrows, Cin,
+    hipLaunchKernelGGL(lift_feat_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, gt, gh, gw, out, (unsigned)total, Cin,
                        FW, CropMap{T, H, W, Tp, Hp, Wp});
     RPB_CHECK_LAUNCH("lift_feat");
 }

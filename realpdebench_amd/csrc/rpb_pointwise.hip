@@ -347,6 +347,9 @@ extern "C" int rpb_reduce_partials_batched(const float* part, int nbatch, long r
 // a partial reduction of a few microseconds each: 68 launches = 1.0 of DPOT-S's 9.8 ms step).  items [n][6] int64 on the device:
 // { part pointer, out pointer (fp32), rows, L, row_stride (floats), first 64-column chunk of this item in the launch's grid }.
 // Same arithmetic as rpb_reduce_partials (fp64 accumulation, fixed order: bit-reproducible).
+// A block owns RG_SUB consecutive 64-column chunks of ONE item (the item lookup -- a scan of the table by one lane -- is paid once per
+// 1024 columns, not once per 64: the first version spent 0.8 of its 1.6 ms on it).
+#define RG_SUB 16
 __global__ __launch_bounds__(1024) void reduce_grouped_kernel(const long* __restrict__ items, int n) {
     constexpr int CL = 64, RG = 1024 / CL;
     __shared__ double red[RG][CL];
@@ -363,25 +366,30 @@ __global__ __launch_bounds__(1024) void reduce_grouped_kernel(const long* __rest
     float* outf = reinterpret_cast<float*>(it[1]);
     const long rows = it[2], L = it[3], row_stride = it[4];
     const int cl = threadIdx.x % CL, rg = threadIdx.x / CL;
-    const long j = ((long)blockIdx.x - it[5]) * CL + cl;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (j < L) {
-        long r = rg;
-        for (; r + 3 * RG < rows; r += 4 * RG) {
-            s0 += (double)part[r * row_stride + j];
-            s1 += (double)part[(r + RG) * row_stride + j];
-            s2 += (double)part[(r + 2 * RG) * row_stride + j];
-            s3 += (double)part[(r + 3 * RG) * row_stride + j];
+    const long j0 = ((long)blockIdx.x - it[5]) * (CL * RG_SUB);
+    for (int sub = 0; sub < RG_SUB; ++sub) {
+        const long j = j0 + sub * CL + cl;
+        if (j0 + sub * CL >= L) break;                     // uniform
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (j < L) {
+            long r = rg;
+            for (; r + 3 * RG < rows; r += 4 * RG) {
+                s0 += (double)part[r * row_stride + j];
+                s1 += (double)part[(r + RG) * row_stride + j];
+                s2 += (double)part[(r + 2 * RG) * row_stride + j];
+                s3 += (double)part[(r + 3 * RG) * row_stride + j];
+            }
+            for (; r < rows; r += RG) s0 += (double)part[r * row_stride + j];
         }
-        for (; r < rows; r += RG) s0 += (double)part[r * row_stride + j];
-    }
-    red[rg][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (rg == 0 && j < L) {
-        double v = 0.0;
+        if (sub) __syncthreads();                          // the previous sub-chunk's reads of red[] are done
+        red[rg][cl] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (rg == 0 && j < L) {
+            double v = 0.0;
 #pragma unroll 8
-        for (int k = 0; k < RG; ++k) v += red[k][cl];
-        outf[j] = (float)v;
+            for (int k = 0; k < RG; ++k) v += red[k][cl];
+            outf[j] = (float)v;
+        }
     }
 }
 extern "C" int rpb_reduce_partials_grouped(const void* items, int n, long total_chunks, void* stream) {
@@ -389,6 +397,7 @@ extern "C" int rpb_reduce_partials_grouped(const void* items, int n, long total_
     hipLaunchKernelGGL(reduce_grouped_kernel, dim3((unsigned)total_chunks), dim3(1024), 0, (hipStream_t)stream, (const long*)items, n);
     RPB_CHECK_LAUNCH("reduce_partials_grouped");
 }
+extern "C" int rpb_reduce_partials_grouped_cols(void) { return 64 * RG_SUB; }      // columns per grid block: chunk0 counts blocks of this size
 
 // ---------------------------------------------------------------------------------- K6 BatchNorm3d (+GELU)
 // sums = [sum_c, sumsq_c] in fp64 over `count` cells (all ranks, after the optional SyncBN all-reduce).

@@ -247,10 +247,10 @@ class deferred_reductions:
         deferred_reductions.active = self.prev
         if self.items and exc[0] is None:
             import numpy as np
-            tab, chunk0 = np.empty((len(self.items), 6), dtype=np.int64), 0
+            tab, chunk0, cols = np.empty((len(self.items), 6), dtype=np.int64), 0, _lib.query("rpb_reduce_partials_grouped_cols")
             for i, (pp, op, rows, L, stride) in enumerate(self.items):
                 tab[i] = (pp, op, rows, L, stride, chunk0)
-                chunk0 += (L + 63) // 64
+                chunk0 += (L + cols - 1) // cols
             dev = self.keep[0].device
             d = torch.from_numpy(tab).to(dev)                   # ~3 KB, staged by the runtime: the host does not wait for the stream
             _lib.call("rpb_reduce_partials_grouped", d.data_ptr(), len(self.items), chunk0, _stream(), label="reduce_partials_grouped")
