@@ -285,6 +285,179 @@ __global__ __launch_bounds__(256) void mode_mfma_kernel(const float* __restrict_
     }
 }
 
+// ---- C = 64 on the bf16 matrix pipe from split fp32 operands (round 4; the fp32-grade arithmetic of rpb_cmx.hip: three truncation
+// planes per operand, six products, fp32 accumulation).  The fp32-MFMA kernel above needs 128 matrix instructions of 64 cycles per wave
+// and mode (8.2 k cycles) for a tile whose HBM time is ~2.5 k cycles: 0.06-0.095 ms per launch for 0.2 GB.  Here the same composite
+// GEMMs take 96 instructions of 16 cycles per wave; the operands are gathered from the fp32 tiles staged in LDS straight into MFMA
+// operand order (8 consecutive values of the contraction index per lane: 2 x ds_read_b128 where that index is contiguous in the tile,
+// 8 x ds_read_b32 where it is the row index) and split in registers.
+//   fwd    D[b][(ro,o)] = sum_(ri,i) X[b][(ri,i)] * s W[i][o][ri ^ ro]         s = -1 for (ri, ro) = (1, 0)      M = 32, N = 128, K = 128
+//   dgrad  D[b][(ri,i)] = sum_(ro,o) gY[b][(ro,o)] * s W[i][o][ro ^ ri]        s = -1 for (ro, ri) = (0, 1)
+//   wgrad  D[i][(part,o)] = sum_(ri,b) X[b][ri][i] * G(part)[(ri,b)][o]        G(re) = (gYr, gYi), G(im) = (gYi, -gYr)   M = 64, N = 128, K = 64
+typedef __attribute__((ext_vector_type(8))) __bf16 mbf16x8;
+typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
+namespace {
+__device__ __forceinline__ float m_trunc(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ unsigned m_pack(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+struct Planes {
+    mbf16x8 h, m, l;
+};
+__device__ __forceinline__ Planes m_split(const float (&v)[8]) {
+    mu32x4 uh, um, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = m_pack(a, b);
+        const float ra = a - m_trunc(a), rb = b - m_trunc(b);
+        um[q] = m_pack(ra, rb);
+        const float sa = ra - m_trunc(ra), sb = rb - m_trunc(rb);
+        ul[q] = m_pack(sa, sb);
+    }
+    return Planes{__builtin_bit_cast(mbf16x8, uh), __builtin_bit_cast(mbf16x8, um), __builtin_bit_cast(mbf16x8, ul)};
+}
+__device__ __forceinline__ Planes m_neg(Planes p) {            // -x: flip the sign of every plane (exact)
+    const mu32x4 sgn = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    return Planes{__builtin_bit_cast(mbf16x8, __builtin_bit_cast(mu32x4, p.h) ^ sgn), __builtin_bit_cast(mbf16x8, __builtin_bit_cast(mu32x4, p.m) ^ sgn),
+                  __builtin_bit_cast(mbf16x8, __builtin_bit_cast(mu32x4, p.l) ^ sgn)};
+}
+__device__ __forceinline__ f32x4 m_mac6(const Planes& a, const Planes& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+}  // namespace
+#define MB_XP 68        // row pitch (floats) of the coefficient tiles [ri][b 32][c 64]
+#define MB_WP 133       // row pitch (floats) of the weight tile [i 64][o 64][2]: odd, so that neither the row-strided gather of the forward
+                        // (8 rows per lane group: 8 * 133 = 8 mod 32) nor the column-strided one of the data gradient piles onto a few banks
+template <int MODE>
+__global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ GY,
+                                                         float* __restrict__ OUT, int B, int M, int accumulate) {
+    constexpr int C = 64;
+    __shared__ __attribute__((aligned(16))) float Xs[2 * 32 * MB_XP];                      // fwd / wgrad: X, dgrad: gY
+    __shared__ __attribute__((aligned(16))) float Ws[MODE == 2 ? 2 * 32 * MB_XP : 64 * MB_WP];   // fwd / dgrad: the mode's weight tile; wgrad: gY
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kg = lane >> 4;
+    const long plane = (long)M * C;
+    const float* src = MODE == 1 ? GY : X;
+    if (MODE != 2) {
+        const float* Wm = Wt + (long)m * C * C * 2;
+        for (int idx = tid; idx < C * C / 2; idx += 256) {       // two complex numbers per 16 B load: row i, columns o, o + 1
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wm + (long)idx * 4);
+            const int i = (2 * idx) / C, o = 2 * idx - i * C;
+            float* d = Ws + i * MB_WP + 2 * o;
+            d[0] = w[0], d[1] = w[1], d[2] = w[2], d[3] = w[3];
+        }
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accg[4][2];                                            // wgrad: [i tile][part] of the wave's o tile, summed over the batch passes
+    if (MODE == 2) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) accg[rt][0] = accg[rt][1] = z4;
+    }
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        if (b0) __syncthreads();
+        for (int idx = tid; idx < 2 * 32 * (C / 4); idx += 256) {
+            const int c4 = idx % (C / 4), r = idx / (C / 4);     // r = bl * 2 + ri
+            const int bl = r >> 1, ri = r & 1, b = b0 + bl;
+            f32x4 v = z4, g = z4;
+            if (b < B) {
+                v = *reinterpret_cast<const f32x4*>(src + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+                if (MODE == 2) g = *reinterpret_cast<const f32x4*>(GY + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(Xs + (ri * 32 + bl) * MB_XP + 4 * c4) = v;
+            if (MODE == 2) *reinterpret_cast<f32x4*>(Ws + (ri * 32 + bl) * MB_XP + 4 * c4) = g;
+        }
+        __syncthreads();
+        if (MODE != 2) {
+            // wave w: output columns n = 32 w .. 32 w + 31 of (plane, channel): plane po = w >> 1, channels 32 (w & 1) + 16 ct + n16
+            const int po = wave >> 1;
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[rt][0] = acc[rt][1] = z4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int pi = ks >> 1, k0 = 32 * (ks & 1) + 8 * kg;       // input plane, first of the lane's 8 contraction channels
+                Planes A[2], Bp[2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {                            // A: row b = 16 rt + n16, 8 consecutive channels
+                    const float* xp = Xs + (pi * 32 + 16 * rt + n16) * MB_XP + k0;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp), v1 = *reinterpret_cast<const f32x4*>(xp + 4);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    A[rt] = m_split(v);
+                }
+                const int wp = pi ^ po;                                     // real / imaginary part of the weight that this (pi, po) pair uses
+                const bool neg = MODE == 0 ? (pi == 1 && po == 0) : (pi == 0 && po == 1);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int cn = 32 * (wave & 1) + 16 * ct + n16;         // output channel (fwd: o, dgrad: i)
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)                             // fwd: W[i = k][o = cn];  dgrad: W[i = cn][o = k]
+                        v[e] = MODE == 0 ? Ws[(k0 + e) * MB_WP + 2 * cn + wp] : Ws[cn * MB_WP + 2 * (k0 + e) + wp];
+                    Bp[ct] = m_split(v);
+                    if (neg) Bp[ct] = m_neg(Bp[ct]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = m_mac6(A[rt], Bp[ct], acc[rt][ct]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = b0 + 16 * rt + 4 * kg + r;
+                        if (b < B) OUT[(long)(b * 2 + po) * plane + (long)m * C + 32 * (wave & 1) + 16 * ct + n16] = acc[rt][ct][r];
+                    }
+        } else {
+            // wave w: output columns o = 16 w + n16, both parts; rows i = 16 rt + ...; K = (ri, b): one K-step per input plane
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = Ws[(ri * 32 + 8 * kg + e) * MB_XP + 16 * wave + n16];      // gY[b = 8 kg + e][ri][o]
+                const Planes G = m_split(v);
+                // part re: + X_ri^T gY_ri ;  part im: ri = 0 -> + Xr^T gYi, ri = 1 -> - Xi^T gYr: the planes of gY_ri feed (re, ri) and (im, 1 - ri)
+                const Planes Gn = m_neg(G);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    float a[8], a2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        a[e] = Xs[(ri * 32 + 8 * kg + e) * MB_XP + 16 * rt + n16];               // X[b][ri][i]
+                        a2[e] = Xs[((1 - ri) * 32 + 8 * kg + e) * MB_XP + 16 * rt + n16];        // X[b][1 - ri][i]
+                    }
+                    const Planes A = m_split(a), A2 = m_split(a2);
+                    accg[rt][0] = m_mac6(A, G, accg[rt][0]);                                     // re += X_ri^T gY_ri
+                    accg[rt][1] = m_mac6(A2, ri == 0 ? Gn : G, accg[rt][1]);                     // im += Xr^T gYi (ri = 1) - Xi^T gYr (ri = 0)
+                }
+            }
+        }
+    }
+    if (MODE == 2) {
+        float* Gm = OUT + (long)m * C * C * 2;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x2* dst = reinterpret_cast<f32x2*>(Gm + ((long)(16 * rt + 4 * kg + r) * C + 16 * wave + n16) * 2);
+                f32x2 v = {accg[rt][0][r], accg[rt][1][r]};
+                if (accumulate) v += *dst;
+                *dst = v;
+            }
+    }
+}
+
 // ---- C = 128 (configs/fsi/fno.yaml, the Galerkin regressor) on the same pipe: the composite per-mode GEMM is [B x 256] x [256 x 256];
 // the weight tile (128 KB) does not fit next to the coefficients, so the workgroup walks the 64-wide output halves (fwd: o halves with
 // all 128 rows i of the weights; dgrad: i halves with all 128 columns o), re-staging the weight half in LDS (66 KB) each time.  wgrad
@@ -419,6 +592,11 @@ static bool mode_mfma_on(int C) {
     static const bool off = getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1;
     return !off && C == 64;
 }
+static bool mode_bf16_on(int C) {        // RPB_MODE_CONTRACT_F32=1: the fp32-MFMA kernel of round 2
+    static const bool off = (getenv("RPB_MODE_CONTRACT_F32") && atoi(getenv("RPB_MODE_CONTRACT_F32")) == 1) ||
+                            (getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1);
+    return !off && C == 64;
+}
 static bool mode_mfma128_on(int C) {
     static const bool off = getenv("RPB_MODE_CONTRACT_VALU") && atoi(getenv("RPB_MODE_CONTRACT_VALU")) == 1;
     return !off && C == 128;
@@ -433,6 +611,10 @@ static int mc_check(const void* a, const void* b, const void* c, int B, int M, i
 
 extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream) {
     if (int e = mc_check(X, W, Y, B, M, C)) return e;
+    if (mode_bf16_on(C)) {
+        hipLaunchKernelGGL((mode_bf16_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
+        RPB_CHECK_LAUNCH("mode_contract_fwd");
+    }
     if (mode_mfma_on(C)) {
         hipLaunchKernelGGL((mode_mfma_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
         RPB_CHECK_LAUNCH("mode_contract_fwd");
@@ -452,6 +634,10 @@ extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, i
 
 extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* GX, int B, int M, int C, void* stream) {
     if (int e = mc_check(GY, W, GX, B, M, C)) return e;
+    if (mode_bf16_on(C)) {
+        hipLaunchKernelGGL((mode_bf16_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        RPB_CHECK_LAUNCH("mode_contract_dgrad");
+    }
     if (mode_mfma_on(C)) {
         hipLaunchKernelGGL((mode_mfma_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
         RPB_CHECK_LAUNCH("mode_contract_dgrad");
@@ -479,6 +665,10 @@ extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* G
 extern "C" int rpb_mode_contract_wgrad(const float* X, const float* GY, float* GW, int B, int M, int C, int accumulate,
                                        void* stream) {
     if (int e = mc_check(X, GY, GW, B, M, C)) return e;
+    if (mode_bf16_on(C)) {
+        hipLaunchKernelGGL((mode_bf16_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        RPB_CHECK_LAUNCH("mode_contract_wgrad");
+    }
     if (mode_mfma_on(C)) {
         hipLaunchKernelGGL((mode_mfma_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
         RPB_CHECK_LAUNCH("mode_contract_wgrad");
