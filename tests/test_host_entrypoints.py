@@ -127,12 +127,13 @@ def test_dpot_registry_state_dict_and_loud_limits():
 
 def test_bench_pmc_csv_to_family_traffic(tmp_path):
     """bench.py's reading of rocprofv3 counter CSVs (roofline.traffic): bytes = request size x request count summed per dispatch, mean
-    over a kernel's dispatches, read + write passes combined, family average over one step's launch mix (3 x <1>, 1 x <1,feat>, 3 x <2>)."""
+    over a kernel's dispatches, read + write passes combined, family average over one step's launch mix (3 x <1>, 1 x <1,feat>, 3 x <2,WG>:
+    round 4's backward launch is the wave-pair variant that also forms the Conv3d weight gradient)."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    names = {"f": "void cmx_kernel<1, false, false, false>(CmxArgs)", "l0": "void cmx_kernel<1, false, true, false>(CmxArgs)",
-             "b": "void cmx_kernel<2, false, false, false>(CmxArgs)", "x": "void other_kernel(Args)"}
+    names = {"f": "void cmx_kernel<1, false, false, false, false>(CmxArgs)", "l0": "void cmx_kernel<1, false, true, false, false>(CmxArgs)",
+             "b": "void cmx_kernel<2, false, false, false, true>(CmxArgs)", "x": "void other_kernel(Args)"}
     def write(path, rows):
         with open(path, "w") as fh:
             fh.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
