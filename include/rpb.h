@@ -472,9 +472,14 @@ int rpb_lift_pad_fwd_bf16(const float* x, const float* gt, const float* gh, cons
                           void* out_bf16, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp, int Wp, void* stream);
 int rpb_axis_gemm_bf16in(const void* in_bf16, float* out, const float* Mt, int G, int K, int O, int N, long in_g, long in_k,
                          long out_g, long out_o, int k_valid, void* stream);
-int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out_bf16,
+/*      spectra_bf16 != 0 (round 4): the SPECTRAL intermediates next to the activations are bf16 too -- the z2 rows these launches read
+ *      (written by rpb_axis_gemm_bf16out, the inverse H stage) and the Y1 rows the fused W stage writes (read by rpb_axis_gemm_bf16in);
+ *      `z2` / `y1` then point to bf16 rows of 128 B.  Stated tolerance of the rollout unchanged (tests/test_gpu_configs.py). */
+int rpb_axis_gemm_bf16out(const float* in, void* out_bf16, const float* Mt, int G, int K, int O, int N, long in_g, long in_k,
+                          long out_g, long out_o, int k_valid, void* stream);
+int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const void* z2, const float* GWt, void* out_bf16,
                       long ncell, int C, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
-                      const float* oxf_beta, int oxf_gelu, void* stream);
+                      const float* oxf_beta, int oxf_gelu, int spectra_bf16, void* stream);
 int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
                       long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, int act, void* stream);
 
@@ -511,16 +516,17 @@ int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const float* bias, co
 
 /* the same on bf16-stored activations (BASELINE.json configs[4]): x, out bf16 [ncell][64]; the fused stage is applied to the ROUNDED
  * activations, i.e. y1 is what rpb_axis_gemm_bf16in(out, ...) would compute. */
-int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out_bf16,
+int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const void* z2, const float* GWt, void* out_bf16,
                                long ncell, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd, const float* oxf_gamma,
-                               const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1, void* scratch, void* stream);
+                               const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, void* y1, void* scratch, int spectra_bf16,
+                               void* stream);
 
 /* ---- rollout: eval cell_mix of the LAST Fourier layer (reference fno.py:117-121: BatchNorm without GELU, then the crop
  *      x[..., :-6, :-6, :-6, :] feeds fc1): only the B * T * H lines of the crop are produced and of each line the 32-cell tiles up to
  *      cell W - 1; pad cells of `out` are left untouched (rpb_proj_fwd reads the crop only).  bf16_io != 0: x / out bf16 [ncell][64]. */
-int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, const float* z2, const float* GWt, void* out, int B, int T,
+int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, const void* z2, const float* GWt, void* out, int B, int T,
                            int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
-                           const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io, void* stream);
+                           const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io, int spectra_bf16, void* stream);
 
 /* ---- DPOT: AFNO patch transformer (realpdebench/model/dpot.py + dpot_libs/models/dpot.py).  Tokens are
  *      channels-last rows; the dense layers run on rpb_gemm_nt / rpb_gemm_tn, the 2-D DFT stages on rpb_axis_gemm.

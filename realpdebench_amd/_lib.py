@@ -19,7 +19,8 @@ SIGNATURES = {
     "rpb_lift_pad_fwd": (_I, "ppppppp" + "iiiiiiiii" + "p"),
     "rpb_lift_pad_fwd_bf16": (_I, "ppppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm_bf16in": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),
-    "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "p"),
+    "rpb_cell_mix_bf16": (_I, "pppppp" + "l" + "iii" + "ppppi" + "i" + "p"),
+    "rpb_axis_gemm_bf16out": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),
     "rpb_proj_fwd_bf16": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "i" + "p"),
     "rpb_spectrum_bin": (_I, "ppiip"),
     "rpb_feat_mix": (_I, "pppp" + "iiiii" + "p"),
@@ -44,8 +45,8 @@ SIGNATURES = {
     "rpb_head_bwd": (_I, "ppppppp" + "ii" + "iiiiii" + "pppp" + "p"),
     "rpb_head_bwd_finalize": (_I, "pppp" + "i" + "ppppp" + "p"),
     "rpb_head_fwd_bwd": (_I, "pppppp" + "f" + "ppp" + "ii" + "iiiiii" + "pppp" + "p"),
-    "rpb_cell_mix_eval_dft_bf16": (_I, "pppppp" + "l" + "ii" + "ppppi" + "pip" + "pp"),
-    "rpb_cell_mix_eval_crop": (_I, "pppppp" + "iiiiiiii" + "ppppi" + "ip"),
+    "rpb_cell_mix_eval_dft_bf16": (_I, "pppppp" + "l" + "ii" + "ppppi" + "pip" + "pip"),
+    "rpb_cell_mix_eval_crop": (_I, "pppppp" + "iiiiiiii" + "ppppi" + "iip"),
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
     "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),
     "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),

@@ -11,6 +11,7 @@ struct AxgArgs {
     int k_valid;
     XForm xf;            // lazy BatchNorm(+GELU) on the input, channel = n (N <= 128)
     int in_bf16;         // `in` holds bf16 (strides in bf16 elements); plain stage, O <= 64
+    int out_bf16;        // `out` is stored as bf16, round to nearest even (strides in bf16 elements); the short-K "resident" kernel only
 };
 
 bool rpb_axg_supported(int G, int K, int O, int N, long in_g, long in_k, long out_g, long out_o, int k_valid, int accumulate,

@@ -292,9 +292,10 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
     const long nslots = (long)gridDim.x * AXG_WAVES;
     const int passes = (mtiles + MT - 1) / MT;
     const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * 4);
-    const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * 4);
+    const int OB = a.out_bf16 ? 2 : 4;                                       // bytes per output element
+    const unsigned out_bytes = (unsigned)(((long)(a.O - 1) * a.out_o + 64) * OB);
     const int ioff = (8 * kg) * (int)a.in_k * 4 + c16 * 16;
-    const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;
+    const int ooff = (4 * kg) * (int)a.out_o * OB + c16 * 4 * OB;
 
     u32x4 zr[2][8];
     auto issue = [&](long it) {
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
     for (; it < items; it += nslots) {
         const long g = it / strips;
         const int n0 = (int)(it - g * strips) << 6;
-        const rsrc_t ro = make_rsrc(a.out + g * a.out_g + n0, out_bytes);
+        const rsrc_t ro = make_rsrc(reinterpret_cast<char*>(a.out) + (g * a.out_g + n0) * OB, out_bytes);
         bf16x8 Bh[2][4], Bm[2][4], Bl[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -363,7 +364,17 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
                     f32x4v o;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = acc[i][t][r];
-                    st16(o, ro, ooff + (16 * mt + r) * (int)a.out_o * 4);
+                    if (a.out_bf16) {       // spectra stored as bf16 (round to nearest even): 8 B per lane, 128 B per row and strip
+                        typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                        typedef float f32x2v __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                        u32x2v pk;
+                        pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[0], o[1]}, bf16x2v));
+                        pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{o[2], o[3]}, bf16x2v));
+                        __builtin_amdgcn_raw_buffer_store_b64(pk, ro, ooff + (16 * mt + r) * (int)a.out_o * 2, 0, 0);
+                    } else {
+                        st16(o, ro, ooff + (16 * mt + r) * (int)a.out_o * 4);
+                    }
                 }
             }
         }
@@ -391,6 +402,8 @@ int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
     if (grid > need) grid = need;
     const size_t lds = axg_lds(a.k_valid, a.O);
     const bool xf = a.xf.mean != nullptr;
+    if (a.out_bf16 && (a.in_bf16 || xf || a.k_valid > 64 || mtiles <= 4))
+        RPB_FAIL(RPB_ERR_UNSUPPORTED, "axg: bf16 output is built for the short-K stages with many output rows (the inverse H stage)");
     if (a.in_bf16) {
         if (xf || mtiles > 4) RPB_FAIL(RPB_ERR_UNSUPPORTED, "axg: bf16 input supports plain stages with O <= 64 (the forward W stage)");
         (void)hipFuncSetAttribute((const void*)axg_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -278,6 +278,17 @@ extern "C" int rpb_axis_gemm_bf16in(const void* in_bf16, float* out, const float
     RPB_REQUIRE(in_bf16 && out && M, "axis_gemm_bf16in: null pointer");
     RPB_REQUIRE(G > 0 && K > 0 && O > 0 && O <= 64 && N > 0 && k_valid >= 1 && k_valid <= K, "axis_gemm_bf16in: bad sizes G=%d K=%d O=%d N=%d", G, K, O, N);
     RPB_REQUIRE(rpb_axg_supported(G, K, O, N, in_g, in_k, out_g, out_o, k_valid, 0, false), "axis_gemm_bf16in: unsupported layout (N=%d must be a multiple of 64, strides 16 B aligned)", N);
-    AxgArgs a{(const float*)in_bf16, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, XForm{nullptr, nullptr, nullptr, nullptr, 0}, 1};
+    AxgArgs a{(const float*)in_bf16, out, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, XForm{nullptr, nullptr, nullptr, nullptr, 0}, 1, 0};
+    return rpb_axg_launch(a, (hipStream_t)stream);
+}
+
+// inverse H stage writing the rows that cell_mix reads as bf16 (BASELINE.json configs[4] storage, spectra included): `out` holds bf16,
+// out_g / out_o count bf16 elements; short contractions with more than 64 output rows (the "resident" kernel)
+extern "C" int rpb_axis_gemm_bf16out(const float* in, void* out_bf16, const float* M, int G, int K, int O, int N, long in_g, long in_k,
+                                     long out_g, long out_o, int k_valid, void* stream) {
+    RPB_REQUIRE(in && out_bf16 && M, "axis_gemm_bf16out: null pointer");
+    RPB_REQUIRE(G > 0 && K > 0 && K <= 64 && O > 64 && N > 0 && k_valid >= 1 && k_valid <= K, "axis_gemm_bf16out: bad sizes G=%d K=%d O=%d N=%d", G, K, O, N);
+    RPB_REQUIRE(rpb_axg_supported(G, K, O, N, in_g, in_k, out_g, out_o, k_valid, 0, false), "axis_gemm_bf16out: unsupported layout (N=%d must be a multiple of 64, strides 16 B aligned)", N);
+    AxgArgs a{in, (float*)out_bf16, M, G, K, O, N, in_g, in_k, out_g, out_o, k_valid, XForm{nullptr, nullptr, nullptr, nullptr, 0}, 0, 1};
     return rpb_axg_launch(a, (hipStream_t)stream);
 }

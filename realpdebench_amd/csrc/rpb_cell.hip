@@ -453,21 +453,22 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
 
 // eval / rollout with bf16 activation storage (BASELINE.json configs[4]): x and out are bf16 [ncell][64]; the statistics are the
 // running ones, so BatchNorm(+GELU) is applied to the tile before it is rounded and stored (oxf_* = that layer's vectors)
-extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GW,
+extern "C" int rpb_cell_mix_bf16(const void* x_bf16, const float* Wm, const float* bias, const void* z2, const float* GW,
                                  void* out_bf16, long ncell, int C, int K2, int Wp, const float* oxf_mean,
                                  const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu,
-                                 void* stream) {
+                                 int spectra_bf16, void* stream) {
     RPB_REQUIRE(x_bf16 && Wm && z2 && GW && out_bf16, "cell_mix_bf16: null pointer");
     RPB_REQUIRE(rpb_cmx_supported(ncell, C, C, K2, Wp, true, false), "cell_mix_bf16: needs C = 64, K2 <= 32, Wp >= 32 (C=%d K2=%d Wp=%d)", C, K2, Wp);
     if (oxf_mean) RPB_REQUIRE(oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_bf16: the output transform needs all four vectors");
     CmxArgs c{};
-    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
+    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = (const float*)z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
     c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
     c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
     c.bnb_s = nullptr;
     c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
     c.write_gz = 0;
     c.bf16_io = 1;
+    c.spec_bf16 = spectra_bf16 != 0;
     c.feat_w = 0;
     c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0; c.gw_planes = nullptr;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
@@ -522,43 +523,45 @@ extern "C" int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const floa
 // Eval cell_mix of the LAST Fourier layer (fno.py:117-121: BatchNorm, no GELU, then x[..., :-6, :-6, :-6, :] -> fc1): only the
 // B * T * H lines of the crop are produced, each up to the tile that holds cell W - 1; the pad cells of `out` keep whatever they held
 // (nothing reads them: rpb_proj_fwd walks the crop).  bf16_io: x / out are bf16 [ncell][64].
-extern "C" int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, const float* z2, const float* GW, void* out,
+extern "C" int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, const void* z2, const float* GW, void* out,
                                       int B, int T, int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean,
                                       const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io,
-                                      void* stream) {
+                                      int spectra_bf16, void* stream) {
     RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_eval_crop: null pointer");
     RPB_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && T <= Tp && H <= Hp && W <= Wp, "cell_mix_eval_crop: bad crop (%d %d %d of %d %d %d)", T, H, W, Tp, Hp, Wp);
     const long ncell = (long)B * Tp * Hp * Wp;
     RPB_REQUIRE((long)B * T * H < (1l << 31), "cell_mix_eval_crop: too many lines");
     RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false), "cell_mix_eval_crop: needs C = 64, K2 <= 32, Wp >= 32 (K2=%d Wp=%d)", K2, Wp);
     CmxArgs c{};
-    c.x = (const float*)x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = (float*)out; c.stats_part = nullptr;
+    c.x = (const float*)x; c.Wm = Wm; c.bias = bias; c.z2 = (const float*)z2; c.GW = GW; c.out = (float*)out; c.stats_part = nullptr;
     c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
     c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
     c.bnb_s = nullptr;
     c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
     c.bf16_io = bf16_io != 0;
+    c.spec_bf16 = bf16_io != 0 && spectra_bf16 != 0;
     c.crop_T = T; c.crop_H = H; c.crop_W = W; c.Tp = Tp; c.Hp = Hp;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 // The same on bf16-stored activations (x, out bf16 [ncell][64]; y1 fp32): the stage sees the ROUNDED activations, i.e. exactly what
 // rpb_axis_gemm_bf16in would read back from `out`.
-extern "C" int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const float* z2, const float* GW,
+extern "C" int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const void* z2, const float* GW,
                                           void* out_bf16, long ncell, int K2, int Wp, const float* oxf_mean, const float* oxf_invstd,
                                           const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f,
-                                          float* y1, void* scratch, void* stream) {
+                                          void* y1, void* scratch, int spectra_bf16, void* stream) {
     RPB_REQUIRE(x_bf16 && Wm && z2 && GW && out_bf16 && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1 && scratch,
                 "cell_mix_eval_dft_bf16: null pointer");
     RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f),
                 "cell_mix_eval_dft_bf16: unsupported sizes (K2=%d Wp=%d K2f=%d)", K2, Wp, K2f);
     CmxArgs c{};
-    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
+    c.x = (const float*)x_bf16; c.Wm = Wm; c.bias = bias; c.z2 = (const float*)z2; c.GW = GW; c.out = (float*)out_bf16; c.stats_part = nullptr;
     c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
     c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
     c.bnb_s = nullptr;
     c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
     c.bf16_io = 1;
-    c.FWt = FWt; c.y1out = y1; c.K2f = K2f; c.gw_planes = scratch;
+    c.spec_bf16 = spectra_bf16 != 0;
+    c.FWt = FWt; c.y1out = (float*)y1; c.K2f = K2f; c.gw_planes = scratch;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
 extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K2f) {

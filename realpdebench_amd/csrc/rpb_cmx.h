@@ -25,6 +25,7 @@ struct CmxArgs {
     int crop_T, crop_H, crop_W, Tp, Hp;   // crop_T > 0 (eval, no statistics, no fused stage): only lines t < crop_T, h < crop_H of each [Tp][Hp] sample
                                           // are produced, and of each line the tiles up to cell crop_W - 1 (the projection head reads nothing else)
     void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
+    int spec_bf16;        // with bf16_io: z2 (input rows) and y1out (fused W stage) hold bf16 as well
     float* wg_part;       // rpb_cmw.hip only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
 };
 

@@ -101,8 +101,11 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       share a SIMD's issue slots, so the light wave runs in the stalls of the heavy one.
 #define CMX_WAVES_DFT 8
 #define CMX_WG_PAIRS 4
-template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false>
+// SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
+//       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
+template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false>
 __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS))) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!SB || BF, "bf16 spectra come with bf16 activation storage");
     static_assert(!WG || (STATS == 2 && !BF && !FEAT && !DFT), "weight-gradient pairs: the fp32 backward launch");
     static_assert(!DFT || STATS == 0, "fused forward W stage: eval path");
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
@@ -342,6 +345,17 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
     };
     u32x4 zr[8];
     auto issue_z = [&](long g) {        // z2 row in B-operand layout: lane (n, kg) holds k = 8 kg + e, channels 4 n .. 4 n + 3
+        if (SB) {                       // bf16 rows of 128 B: 8 B = channels 4 n .. 4 n + 3 per lane and k
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            const rsrc_t rz = make_rsrc(a.z2 + g * K2 * 32, (unsigned)K2 * 128u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(rz, (8 * kg + e) * 128 + m * 8, 0, 0);
+                zr[e][0] = w[0];
+                zr[e][1] = w[1];
+            }
+            return;
+        }
         const rsrc_t rz = make_rsrc(a.z2 + g * K2 * 64, (unsigned)K2 * 256u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * 256 + m * 16);
@@ -426,6 +440,14 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                     if (q == 0) {                  // new line: its z2 row (requested one tile ago) -> three bf16 planes per channel,
 #pragma unroll                                     // parked in the wave's own LDS slice (48 registers otherwise)
                         for (int t = 0; t < 4; ++t) {
+                            if (SB) {           // channel 4 n + t of rows (2 q, 2 q + 1): halves of word t >> 1 -> one exact plane
+                                u32x4 u;
+#pragma unroll
+                                for (int qq = 0; qq < 4; ++qq)
+                                    u[qq] = __builtin_amdgcn_perm(zr[2 * qq + 1][t >> 1], zr[2 * qq][t >> 1], (t & 1) ? 0x07060302u : 0x05040100u);
+                                Zw[(0 * 4 + t) * 64] = u;
+                                continue;
+                            }
                             float v[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(f32x4v, zr[e])[t];
@@ -483,13 +505,19 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         Zh[u] = __builtin_bit_cast(bf16x8, Zw[(0 * 4 + 2 * tp + u) * 64]);
-                        Zm[u] = __builtin_bit_cast(bf16x8, Zw[(1 * 4 + 2 * tp + u) * 64]);
-                        Zl[u] = __builtin_bit_cast(bf16x8, Zw[(2 * 4 + 2 * tp + u) * 64]);
+                        if (!SB) {
+                            Zm[u] = __builtin_bit_cast(bf16x8, Zw[(1 * 4 + 2 * tp + u) * 64]);
+                            Zl[u] = __builtin_bit_cast(bf16x8, Zw[(2 * 4 + 2 * tp + u) * 64]);
+                        }
                     }
 #define CMX_SPEC(AP, ZP)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)                                 \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], ZP[u], acc[j][2 * tp + u]);
-                    CMX_SPEC(ah, Zl) CMX_SPEC(al, Zh) CMX_SPEC(am, Zm) CMX_SPEC(ah, Zm) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+                    if (SB) {
+                        CMX_SPEC(al, Zh) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+                    } else {
+                        CMX_SPEC(ah, Zl) CMX_SPEC(al, Zh) CMX_SPEC(am, Zm) CMX_SPEC(ah, Zm) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+                    }
 #undef CMX_SPEC
                 }
             }
@@ -620,12 +648,28 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                     }
                 }
                 if (last) {                     // Y1[g][k = 16 i + 4 mg + r][channels 4 n ..]: 16 B per lane and row
+                    if (SB) {                   // the same rows as bf16 (round to nearest even): 8 B per lane, 128 B per row
+                        typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                        typedef float f32x2v __attribute__((ext_vector_type(2)));
+                        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+                        const rsrc_t ry = make_rsrc(a.y1out + g * a.K2f * 32, (unsigned)a.K2f * 128u);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                u32x2v pk;
+                                pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{Yacc[i][0][r], Yacc[i][1][r]}, bf16x2v));
+                                pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{Yacc[i][2][r], Yacc[i][3][r]}, bf16x2v));
+                                __builtin_amdgcn_raw_buffer_store_b64(pk, ry, (16 * i + 4 * kg + r) * 128 + m * 8, 0, 0);
+                            }
+                    } else {
                     const rsrc_t ry = make_rsrc(a.y1out + g * a.K2f * 64, (unsigned)a.K2f * 256u);   // rows >= K2f: dropped
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             st16(f32x4v{Yacc[i][0][r], Yacc[i][1][r], Yacc[i][2][r], Yacc[i][3][r]}, ry, (16 * i + 4 * kg + r) * 256 + m * 16);
+                    }
                 }
             }
         }
@@ -762,7 +806,10 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
         long grid = rpb_num_cus();
         if (grid > (G + waves - 1) / waves) grid = (G + waves - 1) / waves;
         const size_t lds = cmx_lds(a.Wp, waves, true);
-        if (a.bf16_io) {
+        if (a.bf16_io && a.spec_bf16) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, true, false, true, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        } else if (a.bf16_io) {
             (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((cmx_kernel<0, true, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
         } else if (a.feat_w) {
@@ -798,6 +845,11 @@ int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
     }
     if (a.bf16_io) {
         if (stats != 0) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: bf16 activation storage is an eval / rollout path (no statistics)");
+        if (a.spec_bf16) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, true, false, false, false, true>), dim3(grid), dim3(waves * 64), lds, st, a);
+            RPB_CHECK_LAUNCH("cell_mix(bf16x3, bf16 storage and spectra)");
+        }
         (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((cmx_kernel<0, true>), dim3(grid), dim3(waves * 64), lds, st, a);
         RPB_CHECK_LAUNCH("cell_mix(bf16x3, bf16 storage)");

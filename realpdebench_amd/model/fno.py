@@ -58,7 +58,13 @@ class _Workspace:
         # eval: cell_mix also applies the next layer's forward W stage (csrc/rpb_cmx.hip, DFT variant) into its own buffer
         self.fuse_w = (not training and C == 64 and os.environ.get("RPB_EVAL_FUSE_W", "1") != "0"
                        and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
-        self.Y1f = torch.empty(G1 * N1, **f) if self.fuse_w else None
+        # bf16 storage (BASELINE.json configs[4]), round 4: the spectral intermediates that are as large as the bf16 activations -- the
+        # fused W stage's rows Y1f and the inverse H stage's rows z2 -- are stored as bf16 as well (RPB_BF16_SPECTRA=0: fp32 as in round 3)
+        self.spec_bf16 = (self.bf16 and self.fuse_w and os.environ.get("RPB_BF16_SPECTRA", "1") != "0"
+                          and 2 * plan.KH <= 64 and 2 * d.Hp > 64 and (plan.KW * C) % 64 == 0)
+        self.Y1f = (torch.empty(G1 * N1, device=device, dtype=torch.bfloat16 if self.spec_bf16 else torch.float32)
+                    if self.fuse_w else None)
+        self.Z2 = torch.empty(G1 * N1, device=device, dtype=torch.bfloat16) if self.spec_bf16 else self.Y1
         # eval: the last layer's cell_mix produces the crop only (the head reads nothing else): 0.70 of the cells at the headline shape
         self.crop_last = (not training and C == 64 and model.n_layers > 1 and type(model)._lift_fwd is FNO3d._lift_fwd
                           and os.environ.get("RPB_EVAL_CROP_LAST", "1") != "0"
@@ -394,8 +400,12 @@ class FNO3d(Model):
         elif MW is not None:                    # None: y1 was already produced (fused backward row kernel / eval cell_mix)
             ops.axis_gemm(x, ws.Y1, MW, d.B * d.Tp * d.Hp, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C,
                           k_valid=d.W if first_layer else None, xf=xf)
-        ops.axis_gemm(y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
-                      k_valid=2 * d.H if first_layer else None)
+        if y1.dtype == torch.bfloat16:          # the fused W stage stored its rows as bf16 (ws.spec_bf16)
+            ops.axis_gemm_bf16in(y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
+                                 k_valid=2 * d.H if first_layer else None)
+        else:
+            ops.axis_gemm(y1, ws.Y2, MH, d.B * d.Tp, 2 * d.Hp, 2 * KH, N2, 2 * d.Hp * N2, N2, 2 * KH * N2, N2,
+                          k_valid=2 * d.H if first_layer else None)
         ops.axis_gemm(ws.Y2, xh, MT, d.B, 2 * d.Tp, 2 * KT, N3, 2 * d.Tp * N3, N3, 2 * KT * N3, N3,
                       k_valid=2 * d.T if first_layer else None)
 
@@ -406,7 +416,10 @@ class FNO3d(Model):
         MT, MH = mats
         N2, N3 = m3 * C, KH * m3 * C
         ops.axis_gemm(yh, ws.Y2, MT, d.B, 2 * KT, 2 * d.Tp, N3, 2 * KT * N3, N3, 2 * d.Tp * N3, N3)
-        ops.axis_gemm(ws.Y2, ws.Y1, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
+        if getattr(ws, "spec_bf16", False):     # eval on bf16 storage: the rows cell_mix reads are written as bf16
+            ops.axis_gemm_bf16out(ws.Y2, ws.Z2, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
+        else:
+            ops.axis_gemm(ws.Y2, ws.Y1, MH, d.B * d.Tp, 2 * KH, 2 * d.Hp, N2, 2 * KH * N2, N2, 2 * d.Hp * N2, N2)
 
     def _feature_spectrum(self, x, ws, plan):
         """ws.PhiH [2][M][NB] = truncated DFT of the Cin + 4 feature fields (x_j per sample, grid_t, grid_h, grid_w, 1; zero in
@@ -476,20 +489,20 @@ class FNO3d(Model):
                     # ... and the NEXT layer's forward W stage rides in the same launch: the activated line is never read for it
                     feat = l == 0 and ws.featfull
                     ops.cell_mix_eval_dft(ws.phic if feat else a_in, ws.wcomp if feat else P(f"convs.{l}.weight"), P(f"convs.{l}.bias"),
-                                          ws.Y1, plan.GWt, s, d.ncell, 2 * plan.KW, d.Wp, self._layer_xf(ws, l, False), plan.FWt,
+                                          ws.Z2, plan.GWt, s, d.ncell, 2 * plan.KW, d.Wp, self._layer_xf(ws, l, False), plan.FWt,
                                           2 * plan.KW, ws.Y1f, feat_w=ws.FW if feat else 0)
                     y1_ready = True
                 elif l == 0 and ws.featfull:
-                    ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Y1, plan.GWt, s, None, d.ncell, ws.FW,
+                    ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Z2, plan.GWt, s, None, d.ncell, ws.FW,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 elif ws.crop_last and l == L - 1:
-                    ops.cell_mix_eval_crop(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d, 2 * plan.KW,
+                    ops.cell_mix_eval_crop(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, d, 2 * plan.KW,
                                            self._layer_xf(ws, l, False))
                 elif ws.bf16:
-                    ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, d.ncell, C,
+                    ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, d.ncell, C,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 else:
-                    ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, None, d.ncell, C, C,
+                    ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, None, d.ncell, C, C,
                                  2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 a_in, xf = s, None
         if skip_head:

@@ -95,11 +95,26 @@ def axis_gemm_bf16in(inp, out, Mt, G, K, O, N, in_g, in_k, out_g, out_o, k_valid
               label=f"axis_gemm_bf16in[K{K}xO{O}]", nbytes=G * N * (2 * kv + 4 * O), flops=2 * G * N * kv * O)
 
 
+def axis_gemm_bf16out(inp, out, Mt, G, K, O, N, in_g, in_k, out_g, out_o, k_valid=None):
+    """The inverse H stage writing its rows as bf16 (``out`` bf16, out strides in bf16 elements): K <= 64, O > 64."""
+    assert out.dtype == torch.bfloat16
+    kv = K if k_valid is None else k_valid
+    _lib.call("rpb_axis_gemm_bf16out", _p(inp), _p(out, torch.bfloat16), _p(Mt), G, K, O, N, in_g, in_k, out_g, out_o, kv, _stream(),
+              label=f"axis_gemm_bf16out[K{K}xO{O}]", nbytes=G * N * (4 * kv + 2 * O), flops=2 * G * N * kv * O)
+
+
+def _zs(z2):
+    """(pointer, spectra_bf16 flag, bytes per element) of a z2 / y1 tensor that is fp32 or bf16."""
+    return _p(z2, z2.dtype), int(z2.dtype == torch.bfloat16), (2 if z2.dtype == torch.bfloat16 else 4)
+
+
 def cell_mix_bf16(x, Wm, bias, z2, GW, out, ncell, C, K2, Wp, oxf=None):
-    """Eval cell_mix on bf16-stored activations: x, out bf16 ``[ncell][C]``; ``oxf`` = (mean, invstd, gamma, beta, gelu)."""
+    """Eval cell_mix on bf16-stored activations: x, out bf16 ``[ncell][C]``; ``oxf`` = (mean, invstd, gamma, beta, gelu); ``z2`` fp32 or
+    bf16 (spectra stored as bf16 too)."""
     assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
-    _lib.call("rpb_cell_mix_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, torch.bfloat16), ncell, C, K2, Wp,
-              *_xf(oxf), _stream(), label="cell_mix_bf16", nbytes=4 * ncell * C + 4 * (ncell // Wp) * K2 * C,
+    zp, sb, zb = _zs(z2)
+    _lib.call("rpb_cell_mix_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), zp, _p(GW), _p(out, torch.bfloat16), ncell, C, K2, Wp,
+              *_xf(oxf), sb, _stream(), label="cell_mix_bf16", nbytes=4 * ncell * C + zb * (ncell // Wp) * K2 * C,
               flops=2 * ncell * C * (K2 + C))
 
 
@@ -109,9 +124,11 @@ def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf):
     assert out.dtype == x.dtype
     nl, tq = d.B * d.T * d.H, (d.W + 31) // 32
     ncell = nl * min(32 * tq, d.Wp)
-    _lib.call("rpb_cell_mix_eval_crop", _p(x, x.dtype), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, x.dtype), d.B, d.T, d.H, d.W, d.Tp, d.Hp,
-              d.Wp, K2, *_xf(oxf), int(bf), _stream(), label="cell_mix_bf16[crop]" if bf else "cell_mix[KC64->CO64,spec=1,stats=oxf,crop]",
-              nbytes=(4 if bf else 8) * ncell * 64 + 4 * nl * K2 * 64, flops=2 * ncell * 64 * (K2 + 64))
+    zp, sb, zb = _zs(z2)
+    assert bf or not sb
+    _lib.call("rpb_cell_mix_eval_crop", _p(x, x.dtype), _p(Wm), _p(bias), zp, _p(GW), _p(out, x.dtype), d.B, d.T, d.H, d.W, d.Tp, d.Hp,
+              d.Wp, K2, *_xf(oxf), int(bf), sb, _stream(), label="cell_mix_bf16[crop]" if bf else "cell_mix[KC64->CO64,spec=1,stats=oxf,crop]",
+              nbytes=(4 if bf else 8) * ncell * 64 + zb * nl * K2 * 64, flops=2 * ncell * 64 * (K2 + 64))
 
 
 _DFT_SCRATCH = {}
@@ -130,9 +147,11 @@ def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1
         _DFT_SCRATCH[key] = torch.empty(3 * Wp * 16, device=out.device, dtype=torch.float32)     # GW planes, rewritten by every launch
     if x.dtype == torch.bfloat16:
         assert out.dtype == torch.bfloat16 and not feat_w
-        _lib.call("rpb_cell_mix_eval_dft_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out, torch.bfloat16), ncell, K2, Wp,
-                  *_xf(oxf), _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label="cell_mix_bf16[+W]",
-                  nbytes=4 * ncell * 64 + 4 * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + 64 + K2f))
+        zp, sb, zb = _zs(z2)
+        assert y1.dtype == z2.dtype, "spectra are fp32 or bf16 on both sides of the launch"
+        _lib.call("rpb_cell_mix_eval_dft_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), zp, _p(GW), _p(out, torch.bfloat16), ncell, K2, Wp,
+                  *_xf(oxf), _p(FWt), K2f, _p(y1, y1.dtype), _p(_DFT_SCRATCH[key]), sb, _stream(), label="cell_mix_bf16[+W]",
+                  nbytes=4 * ncell * 64 + zb * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + 64 + K2f))
         return
     _lib.call("rpb_cell_mix_eval_dft", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), ncell, K2, Wp, int(feat_w), *_xf(oxf),
               _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W]",

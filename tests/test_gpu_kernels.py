@@ -590,6 +590,30 @@ def test_bf16_storage_kernels(ops, Wp, rows, K2):
         u = excess / (torch.clamp(refb.float().abs(), min=1e-30).log2().floor().exp2() * 2.0 ** -7)
         assert float(u.max()) <= 1.0 and float(((o.cpu() != refb) & (excess > 0)).float().mean()) < 0.02   # boundary cases only
         assert rel_l2(o.cpu().double(), ref) < 4e-3
+    # ---- round 4: the spectra next to the activations stored as bf16 too -- z2 rows read as one exact plane, the fused W stage's rows and
+    #      the inverse H stage's rows rounded once on store
+    z2b = z2.to(torch.bfloat16)
+    ref = _xf_ref(torch.einsum("wk,gkc->gwc", GW, z2b.double()).reshape(ncell, C) + x8 @ Wc.t() + bias, om, oi, og, ob, True)
+    o = torch.zeros(ncell, C, device="cuda", dtype=torch.bfloat16)
+    oxf = (dev(om), dev(oi), dev(og), dev(ob), True)
+    ops.cell_mix_bf16(xb.cuda(), dev(Wc), dev(bias), z2b.cuda(), dev(GW.t()), o, ncell, C, K2, Wp, oxf=oxf)
+    assert rel_l2(o.cpu().double(), ref) < 4e-3 and float((o.cpu().float() - ref.to(torch.bfloat16).float()).abs().max()) < 0.07
+    if ops.cell_mix_eval_dft_supported(ncell, K2, Wp, 32):
+        FWt = torch.randn(Wp, 32, **f8)
+        o2 = torch.zeros(ncell, C, device="cuda", dtype=torch.bfloat16)
+        y1 = torch.full((rows, 32, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.cell_mix_eval_dft(xb.cuda(), dev(Wc), dev(bias), z2b.cuda(), dev(GW.t()), o2, ncell, K2, Wp, oxf, dev(FWt), 32, y1)
+        assert torch.equal(o2, o)                                      # the same activations ...
+        y1_ref = torch.einsum("wk,gwc->gkc", FWt, o2.cpu().double().view(rows, Wp, C))       # ... and the stage applied to the ROUNDED ones
+        assert rel_l2(y1.cpu().double(), y1_ref) < 3e-3
+        assert float((y1.cpu().float() - y1_ref.to(torch.bfloat16).float()).abs().max()) <= 2.0 ** -7 * float(y1_ref.abs().max()) * 1.01
+    Mi = torch.randn(140, 48, **f8)                                     # inverse H stage shape: K = 48 -> O = 140, N = 2 strips
+    zin = torch.randn(rows, 48, 2 * C, **f8)
+    zo32 = torch.empty(rows, 140, 2 * C, device="cuda")
+    zo16 = torch.full((rows, 140, 2 * C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.axis_gemm(dev(zin), zo32, dev(Mi.t()), rows, 48, 140, 2 * C, 48 * 2 * C, 2 * C, 140 * 2 * C, 2 * C)
+    ops.axis_gemm_bf16out(dev(zin), zo16, dev(Mi.t()), rows, 48, 140, 2 * C, 48 * 2 * C, 2 * C, 140 * 2 * C, 2 * C)
+    assert torch.equal(zo16, zo32.to(torch.bfloat16))
     # ---- lift, bf16 out == round(fp32 lift)
     B, T, H, W, pad, Cin = 2, 3, 5, 34, 2, 3
     d = ops.Dims(B, T, H, W, Cin, C, pad)
