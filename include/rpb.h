@@ -93,6 +93,10 @@ int rpb_cell_mix_wgrad_supported(long ncell, int K2, int Wp);
 int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float* z2, const float* FWt, float* out, float* stats_part,
                        float* wg_part, long ncell, int K2, int Wp, const float* s_prev, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int gelu, void* stream);
+/*     diagnostics: buf != NULL makes every C = 64 cell_mix launch record, per line-walking wave, the constant-clock tick (100 MHz) at
+ *     its start and end in buf[(block * waves + wave) * 2 + {0, 1}] (8 B each; >= 256 * 8 * 2 entries); NULL switches it off.
+ *     tools/wave_times.py turns the records into the residency profile of a launch (how long the last wave runs past the mean). */
+int rpb_cmx_debug_wave_times(void* buf);
 
 /*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
  *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */

@@ -26,6 +26,9 @@ struct CmxArgs {
                                           // are produced, and of each line the tiles up to cell crop_W - 1 (the projection head reads nothing else)
     void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
     int spec_bf16;        // with bf16_io: z2 (input rows) and y1out (fused W stage) hold bf16 as well
+    int claim_mode;       // how the (b,t,h) lines reach the waves: 0 dealt round-robin | 1 claimed from a workgroup counter (LDS) | 2 claimed chip-wide
+    int* claim_ctr;       //   mode 2: zero on entry, left zero (the last claim resets it)
+    unsigned long long* wave_times;   // diagnostics (rpb_cmx_debug_wave_times): [block][wave][2] constant-clock ticks at wave start / end, or null
     float* wg_part;       // rpb_cmw.hip only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
 };
 

@@ -101,6 +101,9 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       share a SIMD's issue slots, so the light wave runs in the stalls of the heavy one.
 #define CMX_WAVES_DFT 8
 #define CMX_WG_PAIRS 4
+#ifndef CMX_DYNAMIC
+#define CMX_DYNAMIC 1
+#endif
 // SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
 //       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false>
@@ -129,6 +132,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kg = lane >> 4;         // A role: cell row m, k group kg;  B / D role: column n = m, row group mg = kg
     const bool has_xf = a.xf.mean != nullptr;
+    const unsigned long long t_wave0 = a.wave_times ? wall_clock64() : 0ull;
 
     // ---- per-workgroup operand preparation
     for (int idx = tid; idx < KSN * 4 * 64; idx += blockDim.x) {
@@ -189,6 +193,15 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
         xfp[64 + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
         xfp[128 + tid] = a.xf.beta[tid];
     }
+    // DYN: the workgroup's lines (b * waves + i % waves + (i / waves) * nslots, i = 0, 1, ...: the same set as the static walk) are CLAIMED
+    // by its waves from a counter in LDS instead of dealt round-robin.  Measured with rpb_cmx_debug_wave_times at the headline shape
+    // (tools/wave_times.py): under the static deal the waves of one workgroup finish up to 15 % apart (they share a SIMD's issue slots
+    // and the CU's memory path unevenly) and the mean wave lifetime is 0.87-0.92 of the launch.
+    //      Mode 2 claims from ONE counter in HBM (device-scope atomic, a line ahead of its use): that also evens out the workgroups
+    //      (those on odd XCDs run 3-8 % slower than those on even ones).
+    __shared__ int claim_s;
+    const int DYN = (WG || (CMX_PF2 && !DFT && !BF && STATS != 2)) ? 0 : a.claim_mode;
+    if (DYN == 1 && tid == 0) claim_s = CMX_WAVES;
     __syncthreads();
 
     if constexpr (WG) {
@@ -377,7 +390,8 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             const bool more = ngi < G;
             const long gn = U(more ? line_of(ngi) : 0);                      // the tile to request: (gn, qn)
             const int qn = nq;
-            const bool more_lines = gi + nslots < G;
+            const long gnl = DYN ? ngi : gi + nslots;                        // the wave's next line (DYN: meaningful on the line's last tile)
+            const bool more_lines = gnl < G;
             const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
             asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS operand reads inside the loop: hoisted, they cost 150 VGPRs
 
@@ -458,7 +472,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                             Zw[(2 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zl);
                         }
                     }
-                    if (last && more_lines) issue_z(U(line_of(gi + nslots)));   // next line's row: in flight for a whole tile
+                    if (last && more_lines) issue_z(U(line_of(gnl)));   // next line's row: in flight for a whole tile
                     if (STATS == 2) {              // pre-BN values at the output positions (needed by the epilogue)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
@@ -674,10 +688,30 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             }
         }
     };
+    int pend = 0;                   // claim mode 2: the wave's outstanding claim (lane 0)
+    if (DYN == 2 && slot < G && lane == 0) pend = __hip_atomic_fetch_add(a.claim_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto advance = [&](long& gi, int& q) {
         if (++q == TQ) {
             q = 0;
-            gi += nslots;
+            if (DYN == 1) {
+                int i = 0;
+                if (lane == 0) i = __hip_atomic_fetch_add(&claim_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                i = __builtin_amdgcn_readfirstlane(i);
+                gi = (long)blockIdx.x * CMX_WAVES + (i % CMX_WAVES) + (long)(i / CMX_WAVES) * nslots;
+            } else if (DYN == 2) {
+                // every wave with a first line claims until its first miss: G claims per launch in all, and the one that draws G - 1 made
+                // the last access to the counter -- it puts the zero back for the next launch.  The claim consumed here was issued a
+                // whole line earlier (the device-scope atomic takes microseconds under load: waited for in place it costs the layer-0
+                // launch 20 %)
+                if (gi < G) {
+                    const int i = __builtin_amdgcn_readfirstlane(pend);
+                    if (lane == 0 && i == (int)G - 1) __hip_atomic_store(a.claim_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gi = nslots + i;
+                    if (gi < G && lane == 0) pend = __hip_atomic_fetch_add(a.claim_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                gi += nslots;
+            }
         }
     };
     {
@@ -737,11 +771,45 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             }
         }
     }
+    if (a.wave_times && lane == 0) {
+        unsigned long long* wt = a.wave_times + ((long)blockIdx.x * CMX_WAVES + wave) * 2;
+        wt[0] = t_wave0;
+        wt[1] = wall_clock64();
+    }
+}
+
+// diagnostics: when set, every cmx launch records per mix wave its start / end tick (100 MHz constant clock); tools/wave_times.py
+// claim counters of mode 2: a ring, one per launch in flight (a launch leaves its counter at zero)
+#define CMX_CLAIM_RING 256
+static int* g_cmx_claim = nullptr;
+static unsigned g_cmx_claim_next = 0;
+static int g_cmx_claim_mode = -1;
+static void cmx_claim_setup(CmxArgs& a, hipStream_t st) {
+    g_cmx_claim_mode = rpb_line_claim_mode();
+    a.claim_mode = g_cmx_claim_mode;
+    a.claim_ctr = nullptr;
+    if (a.claim_mode == 2) {
+        if (!g_cmx_claim) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cs);
+            if (cs == hipStreamCaptureStatusNone && hipMalloc(&g_cmx_claim, CMX_CLAIM_RING * 64) == hipSuccess)
+                (void)hipMemset(g_cmx_claim, 0, CMX_CLAIM_RING * 64);
+            else
+                g_cmx_claim = nullptr;
+        }
+        if (g_cmx_claim) a.claim_ctr = g_cmx_claim + 16 * (g_cmx_claim_next++ % CMX_CLAIM_RING);
+        else a.claim_mode = 1;
+    }
+}
+static unsigned long long* g_cmx_wave_times = nullptr;
+extern "C" int rpb_cmx_debug_wave_times(void* buf) {
+    g_cmx_wave_times = static_cast<unsigned long long*>(buf);
+    return 0;
 }
 
 static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false) {
     if (wg) return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (size_t)CMX_WG_PAIRS * 8 * 64 * 16 + 2 * CMX_WG_PAIRS * 4;
-    return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0);
+    return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0) + 16;
 }
 
 // GW [K2][Wp] -> three bf16 planes in A-operand row order [plane][w][kg] (the DFT variant's inverse-stage operand, read through L1)
@@ -778,7 +846,10 @@ long rpb_cmx_wg_slots(long ncell, int Wp) {
     if (grid > need) grid = need;
     return grid * CMX_WG_PAIRS;
 }
-int rpb_cmx_wg_launch(const CmxArgs& a, hipStream_t st) {
+int rpb_cmx_wg_launch(const CmxArgs& a_in, hipStream_t st) {
+    CmxArgs a = a_in;
+    a.wave_times = g_cmx_wave_times;
+    cmx_claim_setup(a, st);
     const size_t lds = cmx_lds(a.Wp, CMX_WG_PAIRS, false, true);
     RPB_REQUIRE(lds <= 160 * 1024, "cell_mix_wgrad: Wp=%d does not fit LDS", a.Wp);
     const int grid = (int)(rpb_cmx_wg_slots(a.ncell, a.Wp) / CMX_WG_PAIRS);
@@ -796,7 +867,10 @@ long rpb_cmx_stat_rows(long ncell, int Wp, int stats) {
     return grid * waves;
 }
 
-int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st) {
+int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
+    CmxArgs a = a_in;
+    a.wave_times = g_cmx_wave_times;
+    cmx_claim_setup(a, st);
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
         if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || (a.bf16_io && a.feat_w) || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
             RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the eval path (output transform), a scratch buffer and K2f <= 32");

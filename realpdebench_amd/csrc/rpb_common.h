@@ -33,6 +33,14 @@ extern thread_local char rpb_err_buf[512];
     } while (0)
 
 int rpb_num_cus();   // cached hipDeviceAttributeMultiprocessorCount of the current device
+// How the (b,t,h) lines of the C = 64 cell_mix launches reach their waves (RPB_LINE_CLAIM, default 1):
+//   0  dealt round-robin: wave `slot` walks slot, slot + nslots, ...  -- every partial sum has a fixed order (bit-reproducible TRAINING
+//      runs; the eval launches have no per-wave sums and are bit-reproducible in every mode)
+//   1  the 8 waves of a workgroup CLAIM the workgroup's lines (the same set) from a counter in LDS: under the static deal the waves of
+//      one CU -- two per SIMD -- progress up to 15 % apart (tools/wave_times.py) and the launch waits for the slowest
+//   2  claimed chip-wide from a counter in HBM (perfectly level, but no faster than 1: see DESIGN.md)
+// The one-wave-per-SIMD kernels (bn_bwd_row, head, projection) and the axis GEMMs were measured with mode 1 as well: no change.
+int rpb_line_claim_mode();
 
 // ---------------------------------------------------------------------------------- MFMA
 typedef float f32x16 __attribute__((ext_vector_type(16)));
