@@ -377,6 +377,7 @@ static int launch_cell_mix(const CellMixArgs& a, int waves, int grid, hipStream_
 // number of [2][CO] stat partial rows cell_mix writes for this problem (== grid * waves)
 extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int bn_bwd_stats) {
     if (rpb_cmx_supported(ncell, KC, CO, K2, Wp, has_spec != 0, false)) return rpb_cmx_stat_rows(ncell, Wp, bn_bwd_stats ? 2 : 1);
+    if (rpb_cmx128_supported(ncell, KC, CO, K2, Wp, has_spec != 0, false)) return rpb_cmx128_stat_rows(ncell, Wp);
     const int waves = cell_mix_waves(KC, CO, K2, Wp, has_spec != 0, bn_bwd_stats != 0);
     if (waves == 0) return -1;
     const long ntiles = (ncell + 31) / 32;
@@ -387,7 +388,7 @@ extern "C" long rpb_cell_mix_stat_rows(long ncell, int KC, int CO, int K2, int W
 }
 
 extern "C" int rpb_cell_mix_writes_gz(long ncell, int KC, int CO, int K2, int Wp, int has_spec, int gather) {
-    return rpb_cmx_supported(ncell, KC, CO, K2, Wp, has_spec != 0, gather != 0) ? 1 : 0;
+    return (rpb_cmx_supported(ncell, KC, CO, K2, Wp, has_spec != 0, gather != 0) || rpb_cmx128_supported(ncell, KC, CO, K2, Wp, has_spec != 0, gather != 0)) ? 1 : 0;
 }
 
 extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW,
@@ -405,8 +406,10 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     if (spec) RPB_REQUIRE(GW && K2 > 0 && K2 <= 40 && Wp > 0 && ncell % Wp == 0, "cell_mix: bad spectral arguments (K2=%d)", K2);
     if (bnb_s) RPB_REQUIRE(stats_part && bnb_mean && bnb_invstd && bnb_gamma && bnb_beta, "cell_mix: BN-backward statistics need stats_part and all four vectors");
     if (!bnb_s && bnb_mean) RPB_REQUIRE(!stats_part && bnb_invstd && bnb_gamma && bnb_beta, "cell_mix: the output transform needs all four vectors and no statistics");
-    if (rpb_cmx_supported(ncell, KC, CO, K2, Wp, spec, gather != 0)) {      // C = 64 spectral instances: bf16 matrix pipe, split operands
+    const bool c128 = rpb_cmx128_supported(ncell, KC, CO, K2, Wp, spec, gather != 0);
+    if (c128 || rpb_cmx_supported(ncell, KC, CO, K2, Wp, spec, gather != 0)) {      // C = 64 / 128 spectral instances: bf16 matrix pipe, split operands
         CmxArgs c{};
+        c.c128 = c128;
         c.x = x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = stats_part;
         c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = transpose_w;
         c.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};

@@ -26,6 +26,7 @@ struct CmxArgs {
                                           // are produced, and of each line the tiles up to cell crop_W - 1 (the projection head reads nothing else)
     void* gw_planes;      //     scratch of 3 * Wp * 64 bytes: GW as bf16 planes in operand order (written by the launch)
     int spec_bf16;        // with bf16_io: z2 (input rows) and y1out (fused W stage) hold bf16 as well
+    int c128;             // x / out / z2 / bnb_s rows hold 128 channels, Wm is [128][128] (rpb_cmx128_supported); 0: the C = 64 instance
     int claim_mode;       // how the (b,t,h) lines reach the waves: 0 dealt round-robin | 1 claimed from a workgroup counter (LDS) | 2 claimed chip-wide
     int* claim_ctr;       //   mode 2: zero on entry, left zero (the last claim resets it)
     unsigned long long* wave_times;   // diagnostics (rpb_cmx_debug_wave_times): [block][wave][2] constant-clock ticks at wave start / end, or null
@@ -35,6 +36,8 @@ struct CmxArgs {
 bool rpb_cmx_dft_supported(int Wp, int K2f);
 bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather);
 long rpb_cmx_stat_rows(long ncell, int Wp, int stats);   // stats: 0 / 1 / 2 as in the kernel template
+bool rpb_cmx128_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather);   // the C = 128 instance (set CmxArgs::c128)
+long rpb_cmx128_stat_rows(long ncell, int Wp);           // partial rows of [2][128]
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);
 
 // csrc/rpb_cmw.hip: the STATS == 2 launch with the 1x1-conv weight gradient of the same layer riding along (x = gs of the layer,

@@ -106,25 +106,37 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #endif
 // SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
 //       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
-template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false>
-__global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS))) * 64) void cmx_kernel(CmxArgs a) {
+// C2:   6 or 8 (= waves per workgroup) -- the C = 128 instance (configs/fsi/fno.yaml, the Galerkin regressor): a cell row is 512 B, the
+//       channel mixing four K-steps, and a workgroup produces ONE 64-channel half of the output (workgroup b: half b & 1, line slots of
+//       b >> 1): the conv-weight planes of one half are 48 KB of LDS, both would not fit next to the z2 planes.  x is read by both
+//       halves (the second read mostly out of L2 / MALL: the pair walks the same lines).  The register image of the x tile stays 32
+//       registers: K-steps 2, 3 of THIS tile are requested into the slots of K-steps 0, 1 as soon as those are split, the next tile's
+//       K-steps 0, 1 into the slots of 2, 3 (half a tile of prefetch distance instead of a whole one).
+template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0>
+__global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!C2 || (!BF && !FEAT && !DFT && !WG && !SB), "C = 128: the plain fp32-storage launches");
     static_assert(!SB || BF, "bf16 spectra come with bf16 activation storage");
     static_assert(!WG || (STATS == 2 && !BF && !FEAT && !DFT), "weight-gradient pairs: the fp32 backward launch");
     static_assert(!DFT || STATS == 0, "fused forward W stage: eval path");
     static_assert(!BF || STATS == 0, "bf16 storage: eval / rollout path only");
     static_assert(!(BF && FEAT), "the feature tensor is fp32");
-    constexpr int KSN = FEAT ? 1 : 2;                    // K-steps of the channel mixing
+    constexpr int KSN = FEAT ? 1 : (C2 ? 4 : 2);         // K-steps of the channel mixing
+    constexpr int CC = C2 ? 128 : 64;                    // channels per cell row of x / out / z2 / bnb_s
+    constexpr int CB = CC * 4;                           // bytes per cell row
+    constexpr int BWN = (C2 ? 48 : 24) * 64;             // conv-weight planes in LDS (u32x4)
+    const int hsel = C2 ? (int)(blockIdx.x & 1) : 0;     // C = 128: which 64-channel half of the output this workgroup produces
+    const int bx = C2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, gx = C2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int FW = a.feat_w;
-    constexpr int CMX_WAVES = WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS));     // line-walking ("mix") waves
+    constexpr int CMX_WAVES = C2 ? C2 : (WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)));     // line-walking ("mix") waves
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
     // [plane 3][w Wp][kg 4]  last-stage DFT matrix, A-operand rows.  DFT variant: read from a prepared global buffer (26 KB, L1-resident)
     // instead, which is what lets 8 waves fit next to the forward-stage matrix
-    u32x4* GWs = DFT ? const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.gw_planes)) : Bw + 24 * 64;
-    u32x4* Zs = Bw + 24 * 64 + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
+    u32x4* GWs = DFT ? const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.gw_planes)) : Bw + BWN;
+    u32x4* Zs = Bw + BWN + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
     float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
-    u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * 64);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
+    u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * CC);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
     u32x4* MBs = FWs;                                                  // WG: [pair][row (j, r) 8][lane 64]  act(z) of the pair's current tile (fp32)
     int* flags = reinterpret_cast<int*>(MBs + CMX_WG_PAIRS * 8 * 64);  // WG: [pair][2]  tiles produced / tiles consumed
     const int tid = threadIdx.x;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             const int ci = (BF || FEAT) ? 32 * ks + 8 * kgb + e : 16 * (2 * ks + (e >> 2)) + 4 * kgb + (e & 3);
             const int co = 4 * n + t;
             if (FEAT) v[e] = ci < FW ? a.Wm[co * FW + ci] : 0.f;
-            else v[e] = a.transpose_w ? a.Wm[ci * 64 + co] : a.Wm[co * 64 + ci];
+            else v[e] = a.transpose_w ? a.Wm[ci * CC + 64 * hsel + co] : a.Wm[(64 * hsel + co) * CC + ci];
         }
         bf16x8 h, md, lo;
         split8(v, h, md, lo);
@@ -188,10 +200,10 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
         for (int idx = tid; idx < CMX_WG_PAIRS * 8 * 64; idx += blockDim.x) MBs[idx] = u32x4{0u, 0u, 0u, 0u};
         if (tid < 2 * CMX_WG_PAIRS) flags[tid] = 0;
     }
-    if (has_xf && tid < 64) {
+    if (has_xf && tid < CC) {
         xfp[tid] = a.xf.mean[tid];
-        xfp[64 + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
-        xfp[128 + tid] = a.xf.beta[tid];
+        xfp[CC + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
+        xfp[2 * CC + tid] = a.xf.beta[tid];
     }
     // DYN: the workgroup's lines (b * waves + i % waves + (i / waves) * nslots, i = 0, 1, ...: the same set as the static walk) are CLAIMED
     // by its waves from a counter in LDS instead of dealt round-robin.  Measured with rpb_cmx_debug_wave_times at the headline shape
@@ -200,7 +212,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
     //      Mode 2 claims from ONE counter in HBM (device-scope atomic, a line ahead of its use): that also evens out the workgroups
     //      (those on odd XCDs run 3-8 % slower than those on even ones).
     __shared__ int claim_s;
-    const int DYN = (WG || (CMX_PF2 && !DFT && !BF && STATS != 2)) ? 0 : a.claim_mode;
+    const int DYN = (WG || (CMX_PF2 && !DFT && !BF && STATS != 2)) ? 0 : ((C2 && a.claim_mode == 2) ? 1 : a.claim_mode);   // C2: both halves walk the workgroup pair's own lines
     if (DYN == 1 && tid == 0) claim_s = CMX_WAVES;
     __syncthreads();
 
@@ -307,8 +319,8 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
     ssum[0] = ssum[1] = ssq[0] = ssq[1] = pk2(0.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        bv[t] = a.bias ? a.bias[4 * m + t] : 0.f;
-        if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, 4 * m + t);
+        bv[t] = a.bias ? a.bias[64 * hsel + 4 * m + t] : 0.f;
+        if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, 64 * hsel + 4 * m + t);
     }
     const bool xgelu = a.xf.gelu != 0;
     const bool bgelu = a.bnb.gelu != 0;
@@ -327,18 +339,18 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
         const unsigned b = u / th, r = u - b * th, t = r / (unsigned)a.crop_H, h = r - t * (unsigned)a.crop_H;
         return ((long)b * a.Tp + t) * a.Hp + h;
     };
-    const long nslots = (long)gridDim.x * CMX_WAVES;
-    const long slot = (long)blockIdx.x * CMX_WAVES + wave;
-    const unsigned line_bytes = (unsigned)Wp * (BF ? 128u : 256u);
-    const long line_floats = (long)Wp * (BF ? 32 : 64);          // bf16 storage: two channels per float slot
+    const long nslots = (long)gx * CMX_WAVES;
+    const long slot = (long)bx * CMX_WAVES + wave;
+    const unsigned line_bytes = (unsigned)Wp * (BF ? 128u : (unsigned)CB);
+    const long line_floats = (long)Wp * (BF ? 32 : CC);          // bf16 storage: two channels per float slot
     const unsigned xline_bytes = FEAT ? (unsigned)Wp * FW * 4u : line_bytes;
     const long xline_floats = FEAT ? (long)Wp * FW : line_floats;
-    const int xoff = m * 256 + kg * 16;                  // byte offset of the lane's first 16 B inside a 16-cell block
-    const int ooff = (4 * kg) * 256 + m * 16;            // output: cell 4 mg + r, channels 4 n ..
+    const int xoff = m * CB + kg * 16;                   // byte offset of the lane's first 16 B inside a 16-cell block
+    const int ooff = (4 * kg) * CB + m * 16;             // output: cell 4 mg + r, channels 4 n ..
 
     // PF2 (compile-time experiment, off: see CMX_PF2): the x tiles requested TWO wave tiles ahead (two register images, the tile loop
     // unrolled by two) -- 128 instead of 64 KB of loads in flight per CU.  Not for STATS == 2 / the fused W stage (no registers left).
-    constexpr bool PF2 = CMX_PF2 && !DFT && !BF && STATS != 2;
+    constexpr bool PF2 = CMX_PF2 && !DFT && !BF && STATS != 2 && !C2;
     u32x4 xaA[2][4], xaB[2][4];
     // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
     auto issue_x = [&](u32x4 (&xa)[2][4], long g, int q, int j, int ks) {
@@ -353,7 +365,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             xa[j][ks] = ld16(rx, q * 4096 + j * 2048 + m * 128 + ks * 64 + kg * 16);
         } else {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) xa[j][2 * ks + hf] = ld16(rx, q * 8192 + xoff + j * 4096 + (2 * ks + hf) * 64);
+            for (int hf = 0; hf < 2; ++hf) xa[j][2 * (C2 ? (ks & 1) : ks) + hf] = ld16(rx, q * (32 * CB) + xoff + j * (16 * CB) + (2 * ks + hf) * 64);
         }
     };
     u32x4 zr[8];
@@ -369,9 +381,9 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             }
             return;
         }
-        const rsrc_t rz = make_rsrc(a.z2 + g * K2 * 64, (unsigned)K2 * 256u);
+        const rsrc_t rz = make_rsrc(a.z2 + g * K2 * CC + 64 * hsel, (unsigned)K2 * (unsigned)CB - 256u * (unsigned)hsel);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * 256 + m * 16);
+        for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * CB + m * 16);
     };
 
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
@@ -384,8 +396,8 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
     auto do_tile = [&](u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
         {
             const long g = U(line_of(gi));
-            const rsrc_t ro = make_rsrc(a.out + g * line_floats, line_bytes);
-            const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * 64 : a.out, line_bytes);
+            const rsrc_t ro = make_rsrc(a.out + g * line_floats + 64 * hsel, line_bytes - 256u * (unsigned)hsel);
+            const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * CC + 64 * hsel : a.out, line_bytes - 256u * (unsigned)hsel);
             const bool last = q + 1 == TQ;
             const bool more = ngi < G;
             const long gn = U(more ? line_of(ngi) : 0);                      // the tile to request: (gn, qn)
@@ -426,11 +438,11 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const int i = 2 * ks + hf;
-                        const f32x4v xv = __builtin_bit_cast(f32x4v, xa[j][i]);
+                        const f32x4v xv = __builtin_bit_cast(f32x4v, xa[j][C2 ? 2 * (ks & 1) + hf : i]);
                         if (has_xf) {
                             const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfp + 16 * i + 4 * kg);
-                            const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + 64 + 16 * i + 4 * kg);
-                            const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 128 + 16 * i + 4 * kg);
+                            const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + CC + 16 * i + 4 * kg);
+                            const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 2 * CC + 16 * i + 4 * kg);
 #pragma unroll
                             for (int c = 0; c < 4; c += 2) {         // channel pairs: packed fp32 math
                                 f32x2 z = pk_fma(f32x2{xv[c], xv[c + 1]} - f32x2{mu[c], mu[c + 1]}, f32x2{sc[c], sc[c + 1]},
@@ -446,9 +458,12 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                     }
                     split8(v, Ah[j], Am[j], Al[j]);
                 }
-                if (more) {
-                    issue_x(xa, gn, qn, 0, ks);
-                    issue_x(xa, gn, qn, 1, ks);
+                if (C2 && ks < 2) {                 // C = 128: this tile's K-steps 2, 3 take the slots of 0, 1
+                    issue_x(xa, g, q, 0, ks + 2);
+                    issue_x(xa, g, q, 1, ks + 2);
+                } else if (more) {
+                    issue_x(xa, gn, qn, 0, C2 ? ks - 2 : ks);
+                    issue_x(xa, gn, qn, 1, C2 ? ks - 2 : ks);
                 }
                 if (ks == 0) {
                     if (q == 0) {                  // new line: its z2 row (requested one tile ago) -> three bf16 planes per channel,
@@ -477,7 +492,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) spre[j][r] = ld16(rs, q * 8192 + ooff + j * 4096 + r * 256);
+                            for (int r = 0; r < 4; ++r) spre[j][r] = ld16(rs, q * (32 * CB) + ooff + j * (16 * CB) + r * CB);
                     }
                 }
 #pragma unroll
@@ -605,7 +620,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                                     acc[j][t][r] = __builtin_bit_cast(float, (pk[t >> 1] >> (16 * (t & 1))) << 16);
                             }
                         } else {
-                            st16(o, ro, q * 8192 + ooff + j * 4096 + r * 256);
+                            st16(o, ro, q * (32 * CB) + ooff + j * (16 * CB) + r * CB);
                         }
                         if (WG) MBw[(4 * j + r) * 64] = __builtin_bit_cast(u32x4, avr);
                     }
@@ -697,7 +712,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
                 int i = 0;
                 if (lane == 0) i = __hip_atomic_fetch_add(&claim_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 i = __builtin_amdgcn_readfirstlane(i);
-                gi = (long)blockIdx.x * CMX_WAVES + (i % CMX_WAVES) + (long)(i / CMX_WAVES) * nslots;
+                gi = (long)bx * CMX_WAVES + (i % CMX_WAVES) + (long)(i / CMX_WAVES) * nslots;
             } else if (DYN == 2) {
                 // every wave with a first line claims until its first miss: G claims per launch in all, and the one that draws G - 1 made
                 // the last access to the counter -- it puts the zero back for the next launch.  The claim consumed here was issued a
@@ -757,7 +772,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
         }
     }
     if (STATS != 0) {
-        float* part = a.stats_part + ((long)blockIdx.x * CMX_WAVES + wave) * 128;
+        float* part = a.stats_part + ((long)bx * CMX_WAVES + wave) * (2 * CC) + 64 * hsel;     // row [2][CC]: sums | second sums
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float s1 = ssum[t >> 1][t & 1], s2 = ssq[t >> 1][t & 1];
@@ -767,7 +782,7 @@ __global__ __launch_bounds__((WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX
             s2 += __shfl_xor(s2, 32, 64);
             if (kg == 0) {
                 part[4 * m + t] = s1;
-                part[64 + 4 * m + t] = s2;
+                part[CC + 4 * m + t] = s2;
             }
         }
     }
@@ -838,6 +853,39 @@ bool rpb_cmx_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bo
            cmx_lds(Wp, CMX_WAVES_A) <= 160 * 1024;
 }
 
+// ---- C = 128 (template parameter C2): workgroup pairs, one output half each
+static size_t cmx_lds128(int Wp, int waves) { return (size_t)(48 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 128 * 4 + 16; }
+static int cmx_waves128(int Wp) { return cmx_lds128(Wp, 8) <= 160 * 1024 ? 8 : (cmx_lds128(Wp, 6) <= 160 * 1024 ? 6 : 0); }
+bool rpb_cmx128_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec, bool gather) {
+    static const bool off = (getenv("RPB_CELL_MIX_F32") && atoi(getenv("RPB_CELL_MIX_F32")) == 1) ||
+                            (getenv("RPB_CELL_MIX_128_F32") && atoi(getenv("RPB_CELL_MIX_128_F32")) == 1);   // exact-fp32 MFMA kernel
+    return !off && spec && !gather && KC == 128 && CO == 128 && K2 > 0 && K2 <= 32 && Wp >= 32 && ncell % Wp == 0 && cmx_waves128(Wp) > 0;
+}
+long rpb_cmx128_stat_rows(long ncell, int Wp) {
+    const int waves = cmx_waves128(Wp);
+    const long G = ncell / Wp;
+    long pairs = rpb_num_cus() / 2;
+    const long need = (G + waves - 1) / waves;
+    if (pairs > need) pairs = need;
+    return pairs * waves;
+}
+static int cmx128_launch(const CmxArgs& a, int stats, hipStream_t st) {
+    if (a.bf16_io || a.feat_w || a.y1out || a.crop_T > 0)
+        RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx (C = 128): plain fp32-storage launches only (no bf16 storage, feature input, fused stage or crop)");
+    const int waves = cmx_waves128(a.Wp);
+    const int grid = 2 * (int)(rpb_cmx128_stat_rows(a.ncell, a.Wp) / waves);
+    const size_t lds = cmx_lds128(a.Wp, waves);
+#define RPB_CMX128(ST_, W_)                                                                                                                        \
+    if (stats == ST_ && waves == W_) {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_, false, false, false, false, false, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((cmx_kernel<ST_, false, false, false, false, false, W_>), dim3(grid), dim3(W_ * 64), lds, st, a);                      \
+        RPB_CHECK_LAUNCH("cell_mix(bf16x3, C = 128)");                                                                                             \
+    }
+    RPB_CMX128(0, 8) RPB_CMX128(1, 8) RPB_CMX128(2, 8) RPB_CMX128(0, 6) RPB_CMX128(1, 6) RPB_CMX128(2, 6)
+#undef RPB_CMX128
+    RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx (C = 128): bad stats mode %d", stats);
+}
+
 // ---- the STATS == 2 launch with the Conv3d weight gradient in wave pairs (WG)
 long rpb_cmx_wg_slots(long ncell, int Wp) {
     const long G = ncell / Wp;
@@ -871,6 +919,7 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
     CmxArgs a = a_in;
     a.wave_times = g_cmx_wave_times;
     cmx_claim_setup(a, st);
+    if (a.c128) return cmx128_launch(a, stats, st);
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
         if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || (a.bf16_io && a.feat_w) || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
             RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the eval path (output transform), a scratch buffer and K2f <= 32");

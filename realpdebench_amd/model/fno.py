@@ -140,7 +140,9 @@ class _Workspace:
             # width 128 (configs/fsi/fno.yaml, the Galerkin regressor): the fp32-MFMA cell_mix with the BatchNorm-backward sums in its
             # epilogue spills (8.6 ms at the fsi shape against 2.5 ms without the sums: tools/fsi_probe.py); the plain launch plus the
             # streaming reduction over (s, g) is 3.3 ms.  RPB_BNB_FUSED_128=1 restores the fused launch.
-            self.bnb_unfused = C == 128 and os.environ.get("RPB_BNB_FUSED_128") != "1"
+            # The bf16-pipe instance at C = 128 (csrc/rpb_cmx.hip, output halves) carries the sums again.
+            self.bnb_unfused = (C == 128 and os.environ.get("RPB_BNB_FUSED_128") != "1"
+                                and not ops.cell_mix_writes_gz(d.ncell, C, C, 2 * plan.KW, d.Wp, True))
             if self.bnb_unfused:
                 self.bnr_rows = ops.bn_bwd_rows()
                 self.bnr_part = torch.empty(self.bnr_rows * 2 * C, **f)

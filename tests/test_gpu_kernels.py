@@ -396,16 +396,19 @@ def test_fused_bn_bwd_row(ops, C, gelu, lazy_x):
     assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
 
 
-@pytest.mark.parametrize("Wp,rows,K2", [(134, 7, 32), (70, 11, 32), (38, 5, 24), (33, 3, 7), (134, 1, 32)])
-def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2):
-    """The C = 64 spectral cell_mix runs on the bf16 matrix pipe from operands split into three bf16 planes
+@pytest.mark.parametrize("Wp,rows,K2,C", [(134, 7, 32, 64), (70, 11, 32, 64), (38, 5, 24, 64), (33, 3, 7, 64), (134, 1, 32, 64),
+                                          (70, 11, 32, 128), (134, 7, 32, 128), (33, 3, 7, 128), (70, 300, 32, 128)])
+def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2, C):
+    """The C = 64 and C = 128 (one 64-channel output half per workgroup; configs/fsi/fno.yaml, the Galerkin regressor) spectral
+    cell_mix runs on the bf16 matrix pipe from operands split into three bf16 planes
     (csrc/rpb_cmx.hip): fp32-grade against fp64 in every mode -- plain / transposed weight, lazy input transform,
     BatchNorm forward sums, BatchNorm-backward sums (with and without GELU) and the eval output transform -- on row
     lengths that make tiles straddle (b,t,h) lines and on cell counts that are not a multiple of the 32-cell tile."""
     torch.manual_seed(Wp * 7 + K2)
-    C = 64
     ncell = rows * Wp
-    assert ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True) % 8 == 0          # the bf16-pipe kernel: 8 waves per workgroup
+    assert ops.cell_mix_writes_gz(ncell, C, C, K2, Wp, True)                   # = "this shape runs on the bf16-pipe kernel"
+    if C == 64:
+        assert ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True) % 8 == 0      # 8 waves per workgroup
     f8 = dict(dtype=torch.float64)
     s = torch.randn(ncell, C, **f8) * 1.5 + 0.3
     Wc, bias = torch.randn(C, C, **f8) / 8, torch.randn(C, **f8)
