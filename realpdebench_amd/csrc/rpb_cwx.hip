@@ -1,0 +1,169 @@
+// Weight / bias gradient of the 1x1x1 Conv3d at C = 128 on the bf16 matrix pipe ("cwx"; configs/fsi/fno.yaml: width 128):
+//     dW[co][ci] = sum_cells gs[cell][co] * a[cell][ci],   db[co] = sum_cells gs[cell][co],   a = act(BN(x)) applied on load
+// (autograd of fno.py:115 for layers l >= 1; rpb_cell_wgrad's (128, 128) instance without the crop -- the fp32-MFMA kernel of
+// csrc/rpb_cell.hip runs it at 61-69 TF/s, 1.8-2.0 ms per launch at the fsi shape, five launches per step).
+//
+// The product contracts over CELLS, so both factors are wanted as "8 cells of one channel per lane".  A lane (n = lane & 15,
+// mg = lane >> 4) loads, for the 32 cells of a tile, 16 B = channels 4 n .. 4 n + 3 (of one 64-channel half) of cells 16 j + 4 mg + r:
+// 8 loads per factor, each instruction 4 whole 256 B half rows -- the accumulator layout of csrc/rpb_cmx.hip, whose values for one channel
+// sub-index u are exactly an MFMA operand with k <-> cell.  Both factors are split into three bf16 planes in registers (truncation
+// splits, six products per fp32 product, fp32 accumulate: the arithmetic of rpb_cmx.hip) and a wave accumulates ONE 64 x 64 quadrant of
+// dW (16 tiles of 16 x 16, 96 MFMAs per 32 cells, 64 accumulator registers).  A workgroup is two tile streams of four quadrant waves;
+// the four waves of a stream read the same two cell tiles (the second to fourth read out of L1 / L2) and each factor half is split by
+// two of them.  Partial rows as rpb_cell_wgrad's: [stream][128 * 128 + 128], summed by rpb_reduce_partials.
+#include "rpb_cmx.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+// 8 fp32 -> three bf16x8 planes (exact: hi + mid + lo == v)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = pack_hi(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        um[q] = pack_hi(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        ul[q] = pack_hi(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+struct CwxArgs {
+    const float* gs;   // [ncell][128]
+    const float* x;    // [ncell][128]
+    float* part;       // [2 * gridDim.x][128 * 128 + 128]
+    long ncell;
+    XForm xf;          // lazy BatchNorm (+ GELU) of x, or mean == null
+};
+
+__global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, mg = lane >> 4;
+    const int stream = wave >> 2, oh = (wave >> 1) & 1, ih = wave & 1;     // quadrant (out half, in half) of this wave
+    const long ntiles = (a.ncell + 31) >> 5;
+    const long nstreams = (long)gridDim.x * 2, slot = (long)blockIdx.x * 2 + stream;
+    const bool has_xf = a.xf.mean != nullptr, xgelu = a.xf.gelu != 0;
+    f32x2 mu[2], sc[2], be[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = 64 * ih + 4 * n + 2 * p;
+        mu[p] = has_xf ? f32x2{a.xf.mean[c], a.xf.mean[c + 1]} : pk2(0.f);
+        sc[p] = has_xf ? f32x2{a.xf.invstd[c] * a.xf.gamma[c], a.xf.invstd[c + 1] * a.xf.gamma[c + 1]} : pk2(1.f);
+        be[p] = has_xf ? f32x2{a.xf.beta[c], a.xf.beta[c + 1]} : pk2(0.f);
+    }
+    const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4v accW[4][4];          // tile (uo, ui): row 4 mg + r <-> out channel 64 oh + 4 (4 mg + r) + uo, column n <-> in channel 64 ih + 4 n + ui
+#pragma unroll
+    for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+        for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = z4;
+    f32x4v bs = z4;             // sum of gs over this lane's cells, channels 64 oh + 4 n + u
+    u32x4 gb[2][4], xb[2][4];
+    const int ooff = (4 * mg) * 512 + n * 16;
+    auto issue = [&](long t) {  // rows past the end of the tensor: outside the descriptor -> 0 (gs = 0 removes them from every sum)
+        const long left = a.ncell - t * 32;
+        const unsigned bytes = (unsigned)(left < 32 ? left : 32) * 512u;
+        const rsrc_t rg = make_rsrc(a.gs + t * (32 * 128) + 64 * oh, bytes - 256u * (unsigned)oh);
+        const rsrc_t rx = make_rsrc(a.x + t * (32 * 128) + 64 * ih, bytes - 256u * (unsigned)ih);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gb[j][r] = ld16(rg, ooff + j * (16 * 512) + r * 512);
+                xb[j][r] = ld16(rx, ooff + j * (16 * 512) + r * 512);
+            }
+    };
+    long t = slot;
+    if (t < ntiles) issue(t);
+    while (t < ntiles) {
+        bf16x8 Gh[4], Gm[4], Gl[4], Xh[4], Xm[4], Xl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = __builtin_bit_cast(f32x4v, gb[j][r])[u];
+            if (ih == 0) bs[u] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            split8(v, Gh[u], Gm[u], Gl[u]);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {       // channel pairs: packed fp32 math for the lazy BatchNorm + GELU
+            float v0[8], v1[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4v xv = __builtin_bit_cast(f32x4v, xb[j][r]);
+                    f32x2 z = f32x2{xv[2 * p], xv[2 * p + 1]};
+                    if (has_xf) {
+                        z = pk_fma(z - mu[p], sc[p], be[p]);
+                        if (xgelu) z = gelu2(z);
+                    }
+                    v0[4 * j + r] = z[0];
+                    v1[4 * j + r] = z[1];
+                }
+            split8(v0, Xh[2 * p], Xm[2 * p], Xl[2 * p]);
+            split8(v1, Xh[2 * p + 1], Xm[2 * p + 1], Xl[2 * p + 1]);
+        }
+        const long tn = t + nstreams;
+        if (tn < ntiles) issue(tn);         // the next tile's loads fly during the 96 products below
+#pragma unroll
+        for (int uo = 0; uo < 4; ++uo) {
+#define CWX_W(AP, BP) _Pragma("unroll") for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = mfma16(AP[uo], BP[ui], accW[uo][ui]);
+            CWX_W(Gh, Xl) CWX_W(Gl, Xh) CWX_W(Gm, Xm) CWX_W(Gh, Xm) CWX_W(Gm, Xh) CWX_W(Gh, Xh)
+#undef CWX_W
+        }
+        t = tn;
+    }
+    float* wp = a.part + slot * (long)(128 * 128 + 128);
+#pragma unroll
+    for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = 64 * oh + 4 * (4 * mg + r) + uo;
+            *reinterpret_cast<f32x4v*>(wp + (long)o * 128 + 64 * ih + 4 * n) = f32x4v{accW[uo][0][r], accW[uo][1][r], accW[uo][2][r], accW[uo][3][r]};
+        }
+    if (ih == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = bs[u];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            bs[u] = s;
+        }
+        if (mg == 0) *reinterpret_cast<f32x4v*>(wp + 128 * 128 + 64 * oh + 4 * n) = bs;
+    }
+}
+
+bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop) {
+    static const bool off = getenv("RPB_CELL_WGRAD_128_F32") && atoi(getenv("RPB_CELL_WGRAD_128_F32")) == 1;     // the fp32-MFMA kernel
+    return !off && CO == 128 && CI == 128 && !crop && ncell > 0;
+}
+
+// slots = partial rows the caller allocated (rpb_cell_wgrad_slots: even, two streams per workgroup)
+int rpb_cwx128_launch(const float* gs, const float* x, float* part, long ncell, long slots, const XForm& xf, hipStream_t st) {
+    RPB_REQUIRE(slots >= 2 && slots % 2 == 0, "cell_wgrad (bf16 pipe, C = 128): %ld partial rows", slots);
+    CwxArgs a;
+    a.gs = gs; a.x = x; a.part = part; a.ncell = ncell; a.xf = xf;
+    hipLaunchKernelGGL(cwx128_kernel, dim3((unsigned)(slots / 2)), dim3(512), 0, st, a);
+    RPB_CHECK_LAUNCH("cell_wgrad(bf16x3, C = 128)");
+}

@@ -117,6 +117,27 @@ def test_cell_wgrad(ops, CO, CI, ncell):
     assert rel_l2(got[CO * CI:], gs.sum(0)) < TOL
 
 
+@pytest.mark.parametrize("ncell,gelu", [(70 * 77 + 7, True), (300, False), (33, True), (64 * 1024 + 1, None)])
+def test_cell_wgrad_c128_bf16_pipe(ops, ncell, gelu):
+    """(CO, CI) = (128, 128) without the crop runs on the bf16 matrix pipe (csrc/rpb_cwx.hip: quadrant waves, split operands): fp32-grade
+    against fp64 with the lazy BatchNorm (+ GELU) of the layer input, a cell count that ends inside a tile, fewer tiles than streams."""
+    torch.manual_seed(ncell)
+    C = 128
+    f8 = dict(dtype=torch.float64)
+    gs = torch.randn(ncell, C, **f8) * (torch.arange(C, **f8) % 7 + 1)          # a transposed result would not match
+    x = torch.randn(ncell, C, **f8) * 1.3 + 0.2
+    mean, invstd = torch.randn(C, **f8) * 0.2, torch.rand(C, **f8) + 0.5
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    a = x if gelu is None else _xf_ref(x, mean, invstd, gamma, beta, gelu)
+    xf = None if gelu is None else (dev(mean), dev(invstd), dev(gamma), dev(beta), gelu)
+    slots = ops.cell_wgrad_slots(ncell, C, C)
+    part = torch.full((slots, C * C + C), float("nan"), device="cuda")
+    ops.cell_wgrad(dev(gs), dev(x), part, ncell, C, C, xf=xf)
+    got = part.double().sum(0).cpu()
+    assert rel_l2(got[:C * C].view(C, C), gs.t() @ a) < 3e-6
+    assert rel_l2(got[C * C:], gs.sum(0)) < 3e-6
+
+
 def test_cell_wgrad_crop(ops):
     torch.manual_seed(5)
     B, T, H, W, pad, CO, CI = 2, 3, 4, 9, 3, 128, 64
