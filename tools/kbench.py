@@ -125,6 +125,10 @@ if "axis" in which:
     timeit("axis W fwd  K134xO32",
            lambda: ops.axis_gemm(x, Y1, plan.FWt, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C),
            4 * G * C * (d.Wp + 2 * m3), 2 * G * C * d.Wp * 2 * m3)
+    _z, _o = torch.zeros(C, **f), torch.ones(C, **f)
+    timeit("axis W fwd  K134xO32, lazy BN+GELU on load  [the step's forward variant]",
+           lambda: ops.axis_gemm(x, Y1, plan.FWt, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C, xf=(_z, _o, _o, _z, True)),
+           4 * G * C * (d.Wp + 2 * m3), 2 * G * C * d.Wp * 2 * m3)
     timeit("axis W fwd layer0 (k_valid=128)",
            lambda: ops.axis_gemm(x, Y1, plan.FWt, G, d.Wp, 2 * m3, C, d.Wp * C, C, 2 * m3 * C, C, k_valid=W),
            4 * G * C * (W + 2 * m3), 2 * G * C * W * 2 * m3)
