@@ -10,9 +10,9 @@ agg = collections.defaultdict(list)
 dur = collections.defaultdict(dict)
 for r in rows:
     if sub in r["Kernel_Name"]:
-        agg[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
-        dur[r["Kernel_Name"][:60]][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        agg[(r["Kernel_Name"][:78], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        dur[r["Kernel_Name"][:78]][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 for (k, c), v in sorted(agg.items()):
-    print(f"{k:60s} {c:28s} {sum(v) / len(v):16.0f}  x{len(v)}")
+    print(f"{k:78s}  {c:28s} {sum(v) / len(v):16.0f}  x{len(v)}")
 for k, d in sorted(dur.items()):
-    print(f"{k:60s} {'duration_ms (profiled pass)':28s} {sum(d.values()) / len(d):16.4f}  x{len(d)}")
+    print(f"{k:78s}  {'duration_ms (profiled pass)':28s} {sum(d.values()) / len(d):16.4f}  x{len(d)}")
