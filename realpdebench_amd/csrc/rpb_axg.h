@@ -12,7 +12,6 @@ struct AxgArgs {
     XForm xf;            // lazy BatchNorm(+GELU) on the input, channel = n (N <= 128)
     int in_bf16;         // `in` holds bf16 (strides in bf16 elements); plain stage, O <= 64
     int out_bf16;        // `out` is stored as bf16, round to nearest even (strides in bf16 elements); the short-K "resident" kernel only
-    int claim;           // rpb_line_claim_mode() != 0: items claimed per wave from a workgroup counter in LDS (set by rpb_axg_launch; LAST: the callers initialise positionally)
 };
 
 bool rpb_axg_supported(int G, int K, int O, int N, long in_g, long in_k, long out_g, long out_o, int k_valid, int accumulate,

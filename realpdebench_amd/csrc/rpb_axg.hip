@@ -72,14 +72,6 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 }  // namespace
 
 #define AXG_WAVES 8
-// the i-th claim of a workgroup (i >= AXG_WAVES: the first ones are the waves' own slots) -> item index; same item set as the static walk
-__device__ __forceinline__ long axg_claim(int* ctr, int lane, long nslots) {
-    int i = 0;
-    if (lane == 0) i = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    i = __builtin_amdgcn_readfirstlane(i);
-    return (long)blockIdx.x * AXG_WAVES + (i % AXG_WAVES) + (long)(i / AXG_WAVES) * nslots;
-}
-
 
 // MT = 16-row output tiles per pass (the accumulators of a pass: MT x 4 column tiles x 4 registers)
 // BFIN: the input is STORED as bf16 (in_g / in_k in bf16 elements; BASELINE.json configs[4]): the B operand is one exact bf16
@@ -116,8 +108,6 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
         Ml[((ks * 3 + 1) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, md);
         Ml[((ks * 3 + 2) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
-    __shared__ int claim_s;             // a.claim: the workgroup's items are claimed by its waves (rpb_line_claim_mode, csrc/rpb_cmx.hip DYN)
-    if (threadIdx.x == 0) claim_s = AXG_WAVES;
     __syncthreads();
 
     XParam xp[4];
@@ -138,7 +128,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;                 // row 4 mg, columns 4 c ..
     const int istep = (int)a.in_k * EB;                                      // bytes between consecutive k rows
 
-    for (long it = (long)blockIdx.x * AXG_WAVES + wave; it < items; it = a.claim ? axg_claim(&claim_s, lane, nslots) : it + nslots) {
+    for (long it = (long)blockIdx.x * AXG_WAVES + wave; it < items; it += nslots) {
         const long g = it / strips;
         const int n0 = (int)(it - g * strips) << 6;
         const rsrc_t ri = make_rsrc(reinterpret_cast<const char*>(a.in) + (g * a.in_g + n0) * EB, in_bytes);
@@ -296,8 +286,6 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
         Ml[((ks * 3 + 1) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, md);
         Ml[((ks * 3 + 2) * mtiles + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
-    __shared__ int claim_s;             // a.claim: the workgroup's items are claimed by its waves (rpb_line_claim_mode, csrc/rpb_cmx.hip DYN)
-    if (threadIdx.x == 0) claim_s = AXG_WAVES;
     __syncthreads();
     const int strips = a.N >> 6;
     const long items = (long)a.G * strips;
@@ -321,8 +309,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
     };
     long it = (long)blockIdx.x * AXG_WAVES + wave;
     if (it < items) issue(it);
-    while (it < items) {
-        const long itn = a.claim ? axg_claim(&claim_s, lane, nslots) : it + nslots;
+    for (; it < items; it += nslots) {
         const long g = it / strips;
         const int n0 = (int)(it - g * strips) << 6;
         const rsrc_t ro = make_rsrc(reinterpret_cast<char*>(a.out) + (g * a.out_g + n0) * OB, out_bytes);
@@ -336,7 +323,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
                 for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(f32x4v, zr[ks][e])[t];
                 split8(v, Bh[ks][t], Bm[ks][t], Bl[ks][t]);
             }
-        if (itn < items) issue(itn);                            // the next item's input is in flight during all passes below
+        if (it + nslots < items) issue(it + nslots);            // the next item's input is in flight during all passes below
         for (int p = 0; p < passes; ++p) {
             asm volatile("" ::: "memory");
             f32x4v acc[MT][4];
@@ -391,7 +378,6 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_resident_kernel(AxgArgs a)
                 }
             }
         }
-        it = itn;
     }
 }
 
@@ -408,9 +394,7 @@ bool rpb_axg_supported(int G, int K, int O, int N, long in_g, long in_k, long ou
     return axg_lds(k_valid, O) <= 160 * 1024;
 }
 
-int rpb_axg_launch(const AxgArgs& a_in, hipStream_t st) {
-    AxgArgs a = a_in;
-    a.claim = rpb_line_claim_mode() != 0;
+int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
     const int mtiles = (a.O + 15) / 16;
     const long items = (long)a.G * (a.N / 64);
     long grid = rpb_num_cus();

@@ -39,7 +39,9 @@ int rpb_num_cus();   // cached hipDeviceAttributeMultiprocessorCount of the curr
 //   1  the 8 waves of a workgroup CLAIM the workgroup's lines (the same set) from a counter in LDS: under the static deal the waves of
 //      one CU -- two per SIMD -- progress up to 15 % apart (tools/wave_times.py) and the launch waits for the slowest
 //   2  claimed chip-wide from a counter in HBM (perfectly level, but no faster than 1: see DESIGN.md)
-// The one-wave-per-SIMD kernels (bn_bwd_row, head, projection) and the axis GEMMs were measured with mode 1 as well: no change.
+// The one-wave-per-SIMD kernels (bn_bwd_row, head, projection) were measured with mode 1 as well: no change.  The axis GEMMs gain 1-2 % in
+// their plain instances and LOSE 12-17 % in the forward W stage with the lazy BatchNorm + GELU (1.40 -> 1.57-1.64 ms, same box: the claimed
+// item index changes the compiler's schedule of that instance), so they keep the static deal.
 int rpb_line_claim_mode();
 
 // ---------------------------------------------------------------------------------- MFMA
