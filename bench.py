@@ -590,12 +590,14 @@ def strong_scaling_proxy(dev, ms32, steps=5):
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     shape, modes, width, L = (20, 128, 128, 2), (4, 12, 16), 64, 4
-    res = {"how": "one-rank RCCL group, DataParallel + Trainer.step, 2 warm-up + %d timed steps per batch size" % steps,
+    res = {"how": "one-rank RCCL group, DataParallel + Trainer.step with the SyncBN reductions forced on (4 forward + 3 backward, inline on the "
+                  "compute stream), 2 warm-up + %d timed steps per batch size" % steps,
            "ms_per_step": {"32": ms32}, "note_32": "B = 32: the headline line itself (no DP wrapper; RPB_FORCE_DP=1 measured equal)"}
     try:
         torch.manual_seed(0)
         model = FNO3d(*modes, L, width, shape, shape).to(dev)
         DataParallel(model)
+        model.dp.sync_stats_always = True       # the 7 SyncBN reductions of an N-rank step run inline on the one-rank group as well
         tr = Trainer(model, lr=1e-4, num_update=4000)
         for B in (16, 8, 4):
             x, y = torch.randn(B, *shape, device=dev), torch.randn(B, *shape, device=dev)

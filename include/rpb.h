@@ -97,6 +97,11 @@ int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float* z2, const 
  *     its start and end in buf[(block * waves + wave) * 2 + {0, 1}] (8 B each; >= 256 * 8 * 2 entries); NULL switches it off.
  *     tools/wave_times.py turns the records into the residency profile of a launch (how long the last wave runs past the mean). */
 int rpb_cmx_debug_wave_times(void* buf);
+/*     How the (b,t,h) lines of a C = 64 / 128 cell_mix launch reach its waves: 0 dealt round-robin (every partial sum in a fixed order:
+ *     bit-reproducible training runs), 1 claimed by the waves of a workgroup from a counter in LDS (default), 2 claimed chip-wide from a
+ *     counter in HBM; -1 returns to the RPB_LINE_CLAIM environment variable / the default.  Outputs are identical in every mode; the
+ *     per-wave partial rows (BatchNorm sums, weight-gradient rows) differ in summation order only. */
+int rpb_line_claim_set(int mode);
 
 /*     weight / bias gradient of a per-cell linear layer (Conv3d 1x1x1 fno.py:115, fc1 fno.py:123):
  *     part[rpb_cell_wgrad_slots(...)][CO*CI + CO];  crop=1: x row = padded index of cropped cell. */

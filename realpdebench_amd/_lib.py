@@ -85,6 +85,7 @@ SIGNATURES = {
     "rpb_cell_mix_wgrad": (_I, "ppppppp" + "lii" + "ppppp" + "i" + "p"),
     "rpb_cell_mix_writes_gz": (_I, "liiiiii"),
     "rpb_cmx_debug_wave_times": (_I, "p"),
+    "rpb_line_claim_set": (_I, "i"),
     "rpb_cell_mix": (_I, "ppppppp" + "l" + "iiii" + "ii" + "iiiiii" + "ppppi" + "pppppi" + "p"),
     "rpb_cell_wgrad_slots": (_L, "lii"),
     "rpb_cell_wgrad": (_I, "ppp" + "l" + "iii" + "iiiiii" + "ppppi" + "p"),

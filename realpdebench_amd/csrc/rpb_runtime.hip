@@ -7,14 +7,19 @@ thread_local char rpb_err_buf[512] = "";
 extern "C" const char* rpb_last_error() { return rpb_err_buf; }
 extern "C" int rpb_abi_version() { return 1; }
 
+static int g_line_claim_mode = -1;
 int rpb_line_claim_mode() {
-    static int mode = -1;
-    if (mode < 0) {
+    if (g_line_claim_mode < 0) {
         const char* e = getenv("RPB_LINE_CLAIM");
-        mode = e ? atoi(e) : 1;
-        if (mode < 0 || mode > 2) mode = 1;
+        g_line_claim_mode = e ? atoi(e) : 1;
+        if (g_line_claim_mode < 0 || g_line_claim_mode > 2) g_line_claim_mode = 1;
     }
-    return mode;
+    return g_line_claim_mode;
+}
+extern "C" int rpb_line_claim_set(int mode) {          // 0 / 1 / 2, or -1: back to RPB_LINE_CLAIM / the default
+    if (mode < -1 || mode > 2) RPB_FAIL(RPB_ERR_ARG, "line_claim_set: mode %d (0 static deal, 1 workgroup counter, 2 chip-wide counter, -1 default)", mode);
+    g_line_claim_mode = mode;
+    return RPB_OK;
 }
 
 int rpb_num_cus() {

@@ -207,6 +207,9 @@ class DataParallel:
         self._works = []
         self._next = 0
         self._held = {}
+        # one-rank groups skip the SyncBN reductions (nothing to sum); the strong-scaling proxy of bench.py turns them on anyway so
+        # that the step it times contains every launch of the N-rank step (RPB_DP_SYNCBN_ALWAYS=1 does the same)
+        self.sync_stats_always = os.environ.get("RPB_DP_SYNCBN_ALWAYS") == "1"
         self.comm = RcclComm(process_group) if use_rccl_abi(model.flat, process_group) else None      # C-ABI RCCL on a side stream
         model.dp = self
         self.sync_parameters()

@@ -475,7 +475,7 @@ class FNO3d(Model):
                     ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Y1, plan.GWt, s, ws.stat_part,
                                  d.ncell, C, C, 2 * plan.KW, d.Wp, xf=xf)
                 ops.reduce_partials(ws.stat_part, ws.stat_rows, 2 * C, out_f64=ws.sums64)
-                if world > 1:
+                if world > 1 or (self.dp is not None and training and getattr(self.dp, "sync_stats_always", False)):
                     self.dp.all_reduce_sum(ws.sums64)
                 ops.bn_finalize(ws.sums64, float(d.ncell) * world, BN_EPS, BN_MOMENTUM, ws.mean[l], ws.invstd[l],
                                 self.bn_running_mean[l], self.bn_running_var[l], C)
@@ -596,7 +596,7 @@ class FNO3d(Model):
             # ws.bn_sums = (sum gz, sum gz*shat) of layer l, left by the kernel that produced g
             GP(f"bns.{l}.bias").copy_(ws.bn_sums[:C])          # local sums are this rank's d beta / d gamma
             GP(f"bns.{l}.weight").copy_(ws.bn_sums[C:])
-            if world > 1:
+            if world > 1 or (self.dp is not None and getattr(self.dp, "sync_stats_always", False)):
                 self.dp.all_reduce_sum(ws.bn_sums)
             a_in = ws.A0 if l == 0 else ws.S[l - 1]          # layer input = lazily activated output of layer l-1
             xf_in = None if l == 0 else self._layer_xf(ws, l - 1, True)

@@ -483,6 +483,42 @@ def test_cell_mix_bf16_pipe_all_modes(ops, Wp, rows, K2, C):
     assert rel_l2(out.cpu(), spec + g @ Wc) < 2e-6
 
 
+@pytest.mark.parametrize("C,Wp,rows", [(64, 134, 700), (64, 38, 3000), (128, 70, 900), (64, 134, 5)])
+def test_cell_mix_line_claim_modes_agree(ops, C, Wp, rows):
+    """rpb_line_claim_set: the lines of a cell_mix launch dealt round-robin (0), claimed from the workgroup's LDS counter (1) or from one
+    counter in HBM (2).  The OUTPUT tensor is bit-identical in every mode (a line's arithmetic does not depend on which wave walks it),
+    the statistics agree to fp32 summation order, every line is produced exactly once (NaN-prefilled output), and the chip-wide counter
+    is back at zero after each launch -- 300 launches wrap its ring of counters."""
+    from realpdebench_amd import _lib
+    torch.manual_seed(C + Wp)
+    K2, ncell = 32, rows * Wp
+    f = dict(device="cuda", dtype=torch.float32)
+    x, z2 = torch.randn(ncell, C, **f), torch.randn(rows, K2, C, **f)
+    Wc, bias, GWt = torch.randn(C, C, **f) / 8, torch.randn(C, **f), torch.randn(K2, Wp, **f)
+    xf = (torch.randn(C, **f) * 0.2, torch.rand(C, **f) + 0.5, torch.rand(C, **f) + 0.5, torch.randn(C, **f) * 0.3, True)
+    nrows = ops.cell_mix_stat_rows(ncell, C, C, K2, Wp, True)
+    outs, sums = {}, {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.call("rpb_line_claim_set", mode)
+            out = torch.full((ncell, C), float("nan"), **f)
+            part = torch.zeros(nrows, 2, C, **f)
+            ops.cell_mix(x, Wc, bias, z2, GWt, out, part, ncell, C, C, K2, Wp, xf=xf)
+            outs[mode], sums[mode] = out, part.double().sum(0)
+            assert not torch.isnan(out).any()
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+        for mode in (1, 2):
+            assert rel_l2(sums[mode].cpu(), sums[0].cpu()) < 1e-6
+        _lib.call("rpb_line_claim_set", 2)
+        out = torch.empty(ncell, C, **f)
+        for _ in range(300 if rows < 100 else 20):      # > the ring of 256 counters on the small case
+            out.fill_(float("nan"))
+            ops.cell_mix(x, Wc, bias, z2, GWt, out, None, ncell, C, C, K2, Wp, xf=xf)
+        assert torch.equal(out, outs[0])
+    finally:
+        _lib.call("rpb_line_claim_set", -1)
+
+
 @pytest.mark.parametrize("Wp,rows,K2", [(134, 9, 32), (70, 11, 32), (38, 5, 24), (33, 3, 7), (134, 1, 32)])
 @pytest.mark.parametrize("gelu,write_gz", [(True, True), (True, False), (False, False)])
 def test_cell_mix_with_the_conv_weight_gradient(ops, Wp, rows, K2, gelu, write_gz):
