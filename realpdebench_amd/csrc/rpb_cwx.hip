@@ -78,33 +78,36 @@ __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
     f32x4v bs = z4;             // sum of gs over this lane's cells, channels 64 oh + 4 n + u
     u32x4 gb[2][4], xb[2][4];
     const int ooff = (4 * mg) * 512 + n * 16;
-    auto issue = [&](long t) {  // rows past the end of the tensor: outside the descriptor -> 0 (gs = 0 removes them from every sum)
+    // rows past the end of the tensor lie outside the descriptors -> 0 (gs = 0 removes them from every sum)
+    // Register budget (two waves per SIMD: 256): the X planes (48) stay resident for the 96 products; the G planes are split per channel
+    // sub-index just before their 24 products (12 at a time), so the raw gs image is live until the end and ITS next tile is requested
+    // last -- the x image of the next tile is requested as soon as the X planes exist and flies during all 96 products, and the next
+    // iteration starts with the ~400 vector instructions on x, which cover the gs round trip.
+    auto issue_x = [&](long t) {
         const long left = a.ncell - t * 32;
         const unsigned bytes = (unsigned)(left < 32 ? left : 32) * 512u;
-        const rsrc_t rg = make_rsrc(a.gs + t * (32 * 128) + 64 * oh, bytes - 256u * (unsigned)oh);
         const rsrc_t rx = make_rsrc(a.x + t * (32 * 128) + 64 * ih, bytes - 256u * (unsigned)ih);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gb[j][r] = ld16(rg, ooff + j * (16 * 512) + r * 512);
-                xb[j][r] = ld16(rx, ooff + j * (16 * 512) + r * 512);
-            }
+            for (int r = 0; r < 4; ++r) xb[j][r] = ld16(rx, ooff + j * (16 * 512) + r * 512);
+    };
+    auto issue_g = [&](long t) {
+        const long left = a.ncell - t * 32;
+        const unsigned bytes = (unsigned)(left < 32 ? left : 32) * 512u;
+        const rsrc_t rg = make_rsrc(a.gs + t * (32 * 128) + 64 * oh, bytes - 256u * (unsigned)oh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gb[j][r] = ld16(rg, ooff + j * (16 * 512) + r * 512);
     };
     long t = slot;
-    if (t < ntiles) issue(t);
+    if (t < ntiles) {
+        issue_x(t);
+        issue_g(t);
+    }
     while (t < ntiles) {
-        bf16x8 Gh[4], Gm[4], Gl[4], Xh[4], Xm[4], Xl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * j + r] = __builtin_bit_cast(f32x4v, gb[j][r])[u];
-            if (ih == 0) bs[u] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            split8(v, Gh[u], Gm[u], Gl[u]);
-        }
+        bf16x8 Xh[4], Xm[4], Xl[4];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {       // channel pairs: packed fp32 math for the lazy BatchNorm + GELU
             float v0[8], v1[8];
@@ -125,13 +128,22 @@ __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
             split8(v1, Xh[2 * p + 1], Xm[2 * p + 1], Xl[2 * p + 1]);
         }
         const long tn = t + nstreams;
-        if (tn < ntiles) issue(tn);         // the next tile's loads fly during the 96 products below
+        if (tn < ntiles) issue_x(tn);
 #pragma unroll
         for (int uo = 0; uo < 4; ++uo) {
-#define CWX_W(AP, BP) _Pragma("unroll") for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = mfma16(AP[uo], BP[ui], accW[uo][ui]);
-            CWX_W(Gh, Xl) CWX_W(Gl, Xh) CWX_W(Gm, Xm) CWX_W(Gh, Xm) CWX_W(Gm, Xh) CWX_W(Gh, Xh)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = __builtin_bit_cast(f32x4v, gb[j][r])[uo];
+            if (ih == 0) bs[uo] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            bf16x8 gh, gm, gl;
+            split8(v, gh, gm, gl);
+#define CWX_W(AP, BP) _Pragma("unroll") for (int ui = 0; ui < 4; ++ui) accW[uo][ui] = mfma16(AP, BP[ui], accW[uo][ui]);
+            CWX_W(gh, Xl) CWX_W(gl, Xh) CWX_W(gm, Xm) CWX_W(gh, Xm) CWX_W(gm, Xh) CWX_W(gh, Xh)
 #undef CWX_W
         }
+        if (tn < ntiles) issue_g(tn);
         t = tn;
     }
     float* wp = a.part + slot * (long)(128 * 128 + 128);
