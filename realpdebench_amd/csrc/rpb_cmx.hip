@@ -443,14 +443,14 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                             const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfp + 16 * i + 4 * kg);
                             const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + CC + 16 * i + 4 * kg);
                             const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 2 * CC + 16 * i + 4 * kg);
-#pragma unroll
-                            for (int c = 0; c < 4; c += 2) {         // channel pairs: packed fp32 math
-                                f32x2 z = pk_fma(f32x2{xv[c], xv[c + 1]} - f32x2{mu[c], mu[c + 1]}, f32x2{sc[c], sc[c + 1]},
-                                                 f32x2{be[c], be[c + 1]});
-                                if (xgelu) z = gelu2(z);
-                                v[4 * hf + c] = z[0];
-                                v[4 * hf + c + 1] = z[1];
-                            }
+                            // channel pairs: packed fp32 math, the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
+                            f32x2 z0 = pk_fma(f32x2{xv[0], xv[1]} - f32x2{mu[0], mu[1]}, f32x2{sc[0], sc[1]}, f32x2{be[0], be[1]});
+                            f32x2 z1 = pk_fma(f32x2{xv[2], xv[3]} - f32x2{mu[2], mu[3]}, f32x2{sc[2], sc[3]}, f32x2{be[2], be[3]});
+                            if (xgelu) gelu2x2(z0, z1);
+                            v[4 * hf] = z0[0];
+                            v[4 * hf + 1] = z0[1];
+                            v[4 * hf + 2] = z1[0];
+                            v[4 * hf + 3] = z1[1];
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[4 * hf + c] = xv[c];
@@ -565,34 +565,44 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                     for (int r = 0; r < 4; ++r) {
                         const bool valid = !MASKED || (32 * q + 16 * j + 4 * kg + r < Wp);
                         f32x4v o, avr;
+                        // channel pairs (packed fp32 math); the erf polynomials of the two pairs run in lock-step (gelu2x2 / gelu_both2x2)
+                        f32x2 vv[2], shv[2], gpv[2], acv[2];
 #pragma unroll
-                        for (int t = 0; t < 4; t += 2) {             // channel pairs: packed fp32 math
-                            f32x2 v = f32x2{acc[j][t][r], acc[j][t + 1][r]};
-                            if (STATS == 0 && oxf) {
-                                v = pk_fma((v - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is},
-                                           f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
-                                if (bgelu) v = gelu2(v);
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const int t = 2 * tt;
+                            vv[tt] = f32x2{acc[j][t][r], acc[j][t + 1][r]};
+                            if (STATS == 0 && oxf)
+                                vv[tt] = pk_fma((vv[tt] - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is},
+                                                f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
+                            if (STATS == 2) {
+                                const f32x4v sp = __builtin_bit_cast(f32x4v, spre[j][r]);
+                                shv[tt] = (f32x2{sp[t], sp[t + 1]} - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is};
+                                acv[tt] = pk_fma(shv[tt], f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});      // z
+                                gpv[tt] = pk2(1.f);
                             }
+                        }
+                        if (STATS == 0 && oxf && bgelu) gelu2x2(vv[0], vv[1]);
+                        if (STATS == 2 && bgelu) {
+                            if (WG) {           // act(z) for the weight gradient: the same erf serves act and act'
+                                gelu_both2x2(acv[0], acv[1], acv[0], acv[1], gpv[0], gpv[1]);
+                            } else {
+                                gpv[0] = gelu_grad2(acv[0]);
+                                gpv[1] = gelu_grad2(acv[1]);
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; t += 2) {
+                            f32x2 v = vv[t >> 1];
                             if (STATS == 1) {
                                 const f32x2 vm = valid ? v : pk2(0.f);
                                 ssum[t >> 1] += vm;
                                 ssq[t >> 1] = pk_fma(vm, vm, ssq[t >> 1]);
                             } else if (STATS == 2) {
-                                const f32x4v sp = __builtin_bit_cast(f32x4v, spre[j][r]);
-                                const f32x2 sh = (f32x2{sp[t], sp[t + 1]} - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is};
-                                f32x2 gz = v;
-                                if (WG) {           // act(z) for the weight gradient: the same erf serves act and act'
-                                    const f32x2 zz = pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
-                                    f32x2 actv = zz;
-                                    if (bgelu) {
-                                        f32x2 gp;
-                                        gelu_both2(zz, actv, gp);
-                                        gz = v * gp;
-                                    }
-                                    avr[t] = actv[0];
-                                    avr[t + 1] = actv[1];
-                                } else if (bgelu) {
-                                    gz = v * gelu_grad2(pk_fma(sh, f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be}));
+                                const f32x2 sh = shv[t >> 1];
+                                f32x2 gz = bgelu ? v * gpv[t >> 1] : v;
+                                if (WG) {
+                                    avr[t] = acv[t >> 1][0];
+                                    avr[t + 1] = acv[t >> 1][1];
                                 }
                                 if (a.write_gz) v = gz;
                                 gz = valid ? gz : pk2(0.f);

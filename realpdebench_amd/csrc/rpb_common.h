@@ -151,6 +151,57 @@ __device__ __forceinline__ void gelu_both2(f32x2 x, f32x2& g, f32x2& gp) {
     gp = h + x * (pk2(0.39894228040143267794f) * e);
 }
 
+// TWO packed pairs in lock-step.  A dependent v_pk_fma_f32 needs a wait state after its producer (the compiler fills it with s_nop 0)
+// and cannot issue back to back; left alone the compiler evaluates one nine-term chain after the other (shortest live ranges), so a wave
+// spends the polynomial waiting on itself.  Written as two interleaved chains every instruction has an independent neighbour.
+// Element-wise the operations -- and therefore the results -- are those of fast_erf2 / gelu2 / gelu_both2.
+#ifndef RPB_ERF_ILP_FENCE
+#define RPB_ERF_ILP_FENCE 1     /* keep the interleaving: the scheduler may not move instructions across the step boundaries */
+#endif
+__device__ __forceinline__ void fast_erf2x2(f32x2 xa, f32x2 xb, f32x2& ra, f32x2& rb) {
+    const f32x2 ta = __builtin_elementwise_min(__builtin_elementwise_abs(xa), pk2(4.0f));
+    const f32x2 tb = __builtin_elementwise_min(__builtin_elementwise_abs(xb), pk2(4.0f));
+    f32x2 pa = pk2(1.160457393e-05f), pb = pk2(1.160457393e-05f);
+#if RPB_ERF_ILP_FENCE
+#define RPB_ERF_STEP(c) pa = pk_fma(pa, ta, pk2(c)); pb = pk_fma(pb, tb, pk2(c)); __builtin_amdgcn_sched_barrier(0);
+#else
+#define RPB_ERF_STEP(c) pa = pk_fma(pa, ta, pk2(c)); pb = pk_fma(pb, tb, pk2(c));
+#endif
+    RPB_ERF_STEP(-1.529619341e-04f)
+    RPB_ERF_STEP(8.482242992e-04f)
+    RPB_ERF_STEP(-2.274763673e-03f)
+    RPB_ERF_STEP(8.477856228e-05f)
+    RPB_ERF_STEP(2.772449465e-02f)
+    RPB_ERF_STEP(-1.483079179e-01f)
+    RPB_ERF_STEP(-9.184428993e-01f)
+    RPB_ERF_STEP(-1.627907267e+00f)
+#undef RPB_ERF_STEP
+    const f32x2 qa = pa * ta, qb = pb * tb;
+    const f32x2 ea = f32x2{__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])};
+    const f32x2 eb = f32x2{__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+    const f32x2 sa = pk2(1.0f) - ea, sb = pk2(1.0f) - eb;
+    ra = f32x2{copysignf(sa[0], xa[0]), copysignf(sa[1], xa[1])};
+    rb = f32x2{copysignf(sb[0], xb[0]), copysignf(sb[1], xb[1])};
+}
+__device__ __forceinline__ void gelu2x2(f32x2& xa, f32x2& xb) {
+    f32x2 ea, eb;
+    fast_erf2x2(xa * pk2(0.70710678118654752440f), xb * pk2(0.70710678118654752440f), ea, eb);
+    xa = (pk2(0.5f) * xa) * (pk2(1.0f) + ea);
+    xb = (pk2(0.5f) * xb) * (pk2(1.0f) + eb);
+}
+__device__ __forceinline__ void gelu_both2x2(f32x2 xa, f32x2 xb, f32x2& ga, f32x2& gb, f32x2& gpa, f32x2& gpb) {
+    f32x2 ea, eb;
+    fast_erf2x2(xa * pk2(0.70710678118654752440f), xb * pk2(0.70710678118654752440f), ea, eb);
+    const f32x2 ha = pk2(0.5f) * (pk2(1.0f) + ea), hb = pk2(0.5f) * (pk2(1.0f) + eb);
+    const f32x2 qa = (pk2(-0.72134752044448170368f) * xa) * xa, qb = (pk2(-0.72134752044448170368f) * xb) * xb;
+    const f32x2 pa = f32x2{__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])};
+    const f32x2 pb = f32x2{__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+    ga = (pk2(0.5f) * xa) * (pk2(1.0f) + ea);
+    gb = (pk2(0.5f) * xb) * (pk2(1.0f) + eb);
+    gpa = ha + xa * (pk2(0.39894228040143267794f) * pa);
+    gpb = hb + xb * (pk2(0.39894228040143267794f) * pb);
+}
+
 // four channels at once (two packed pairs)
 __device__ __forceinline__ f32x4 join4(f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; }
 __device__ __forceinline__ f32x4 gelu4(f32x4 x) { return join4(gelu2(x.lo), gelu2(x.hi)); }
