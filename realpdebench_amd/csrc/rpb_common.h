@@ -204,8 +204,20 @@ __device__ __forceinline__ void gelu_both2x2(f32x2 xa, f32x2 xb, f32x2& ga, f32x
 
 // four channels at once (two packed pairs)
 __device__ __forceinline__ f32x4 join4(f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; }
-__device__ __forceinline__ f32x4 gelu4(f32x4 x) { return join4(gelu2(x.lo), gelu2(x.hi)); }
-__device__ __forceinline__ f32x4 gelu_grad4(f32x4 x) { return join4(gelu_grad2(x.lo), gelu_grad2(x.hi)); }
+__device__ __forceinline__ f32x4 gelu4(f32x4 x) {
+    f32x2 a = x.lo, b = x.hi;
+    gelu2x2(a, b);
+    return join4(a, b);
+}
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 x) {
+    f32x2 ea, eb;
+    fast_erf2x2(x.lo * pk2(0.70710678118654752440f), x.hi * pk2(0.70710678118654752440f), ea, eb);
+    const f32x2 ca = pk2(0.5f) * (pk2(1.0f) + ea), cb = pk2(0.5f) * (pk2(1.0f) + eb);
+    const f32x2 qa = (pk2(-0.72134752044448170368f) * x.lo) * x.lo, qb = (pk2(-0.72134752044448170368f) * x.hi) * x.hi;
+    const f32x2 pa = f32x2{__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])};
+    const f32x2 pb = f32x2{__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+    return join4(ca + x.lo * (pk2(0.39894228040143267794f) * pa), cb + x.hi * (pk2(0.39894228040143267794f) * pb));
+}
 // shat = (x - mu) * is;  z = shat * ga + be
 __device__ __forceinline__ f32x4 bn4(f32x4 x, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, f32x4* shat = nullptr) {
     const f32x2 s0 = (x.lo - mu.lo) * is.lo, s1 = (x.hi - mu.hi) * is.hi;

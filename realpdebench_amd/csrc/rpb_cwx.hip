@@ -108,24 +108,28 @@ __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
     }
     while (t < ntiles) {
         bf16x8 Xh[4], Xm[4], Xl[4];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {       // channel pairs: packed fp32 math for the lazy BatchNorm + GELU
-            float v0[8], v1[8];
+        {                                   // channel pairs: packed fp32 math for the lazy BatchNorm + GELU, the two pairs' erf in lock-step
+            float v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const f32x4v xv = __builtin_bit_cast(f32x4v, xb[j][r]);
-                    f32x2 z = f32x2{xv[2 * p], xv[2 * p + 1]};
+                    f32x2 za = f32x2{xv[0], xv[1]}, zb = f32x2{xv[2], xv[3]};
                     if (has_xf) {
-                        z = pk_fma(z - mu[p], sc[p], be[p]);
-                        if (xgelu) z = gelu2(z);
+                        za = pk_fma(za - mu[0], sc[0], be[0]);
+                        zb = pk_fma(zb - mu[1], sc[1], be[1]);
+                        if (xgelu) gelu2x2(za, zb);
                     }
-                    v0[4 * j + r] = z[0];
-                    v1[4 * j + r] = z[1];
+                    v0[4 * j + r] = za[0];
+                    v1[4 * j + r] = za[1];
+                    v2[4 * j + r] = zb[0];
+                    v3[4 * j + r] = zb[1];
                 }
-            split8(v0, Xh[2 * p], Xm[2 * p], Xl[2 * p]);
-            split8(v1, Xh[2 * p + 1], Xm[2 * p + 1], Xl[2 * p + 1]);
+            split8(v0, Xh[0], Xm[0], Xl[0]);
+            split8(v1, Xh[1], Xm[1], Xl[1]);
+            split8(v2, Xh[2], Xm[2], Xl[2]);
+            split8(v3, Xh[3], Xm[3], Xl[3]);
         }
         const long tn = t + nstreams;
         if (tn < ntiles) issue_x(tn);

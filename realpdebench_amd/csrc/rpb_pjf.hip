@@ -316,7 +316,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
             // gh = (fc2^T gout) * gelu'(u) in place for hidden tile t of row tile j; d fc2, d b1: per-lane sums over the lane's cells
             auto act = [&](int j, int t) {
                 const f32x4v u = acc[j][t];                          // rows = cells 16 j + 4 kg + r  <->  go[4 j + r]
-                const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
+                f32x2 e0, e1;
+                        fast_erf2x2(u.lo * pk2(0.70710678118654752440f), u.hi * pk2(0.70710678118654752440f), e0, e1);
                 const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
                 const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
                 f32x4v ex;
@@ -376,7 +377,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void pjf_kernel(PjfArgs p) {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const f32x4v u = acc[j][t];
-                        const f32x2 e0 = fast_erf2(u.lo * pk2(0.70710678118654752440f)), e1 = fast_erf2(u.hi * pk2(0.70710678118654752440f));
+                        f32x2 e0, e1;
+                        fast_erf2x2(u.lo * pk2(0.70710678118654752440f), u.hi * pk2(0.70710678118654752440f), e0, e1);
                         const f32x4v cdf = join4(pk2(0.5f) * (pk2(1.0f) + e0), pk2(0.5f) * (pk2(1.0f) + e1));
                         const f32x4v q2 = (f32x4v{-0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f, -0.72134752044448170368f} * u) * u;
                         f32x4v ex;
