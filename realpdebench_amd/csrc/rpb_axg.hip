@@ -189,18 +189,19 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                         const f32x4v x4 = __builtin_bit_cast(f32x4v, zr[e]);
                         // rows past k_valid must stay zero: the transform of a masked load is not
                         const bool live = !XF || (32 * ks + per * kg + e < a.k_valid);
-#pragma unroll
-                        for (int t = 0; t < 4; t += 2) {                      // channel pairs: packed fp32 math
-                            f32x2 x = f32x2{x4[t], x4[t + 1]};
-                            if (XF) {
-                                x = pk_fma((x - f32x2{xp[t].mu, xp[t + 1].mu}) * f32x2{xp[t].is, xp[t + 1].is},
-                                           f32x2{xp[t].ga, xp[t + 1].ga}, f32x2{xp[t].be, xp[t + 1].be});
-                                if (xgelu) x = gelu2(x);
-                                x = live ? x : pk2(0.f);
-                            }
-                            v[t][e] = x[0];
-                            v[t + 1][e] = x[1];
+                        // channel pairs: packed fp32 math; the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
+                        f32x2 xa = f32x2{x4[0], x4[1]}, xb = f32x2{x4[2], x4[3]};
+                        if (XF) {
+                            xa = pk_fma((xa - f32x2{xp[0].mu, xp[1].mu}) * f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].ga, xp[1].ga}, f32x2{xp[0].be, xp[1].be});
+                            xb = pk_fma((xb - f32x2{xp[2].mu, xp[3].mu}) * f32x2{xp[2].is, xp[3].is}, f32x2{xp[2].ga, xp[3].ga}, f32x2{xp[2].be, xp[3].be});
+                            if (xgelu) gelu2x2(xa, xb);
+                            xa = live ? xa : pk2(0.f);
+                            xb = live ? xb : pk2(0.f);
                         }
+                        v[0][e] = xa[0];
+                        v[1][e] = xa[1];
+                        v[2][e] = xb[0];
+                        v[3][e] = xb[1];
                     }
                     if (tail) {
 #pragma unroll
