@@ -101,9 +101,6 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       share a SIMD's issue slots, so the light wave runs in the stalls of the heavy one.
 #define CMX_WAVES_DFT 8
 #define CMX_WG_PAIRS 4
-#ifndef CMX_DYNAMIC
-#define CMX_DYNAMIC 1
-#endif
 // SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
 //       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
 // C2:   6 or 8 (= waves per workgroup) -- the C = 128 instance (configs/fsi/fno.yaml, the Galerkin regressor): a cell row is 512 B, the
@@ -808,10 +805,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
 #define CMX_CLAIM_RING 256
 static int* g_cmx_claim = nullptr;
 static unsigned g_cmx_claim_next = 0;
-static int g_cmx_claim_mode = -1;
 static void cmx_claim_setup(CmxArgs& a, hipStream_t st) {
-    g_cmx_claim_mode = rpb_line_claim_mode();
-    a.claim_mode = g_cmx_claim_mode;
+    a.claim_mode = rpb_line_claim_mode();
     a.claim_ctr = nullptr;
     if (a.claim_mode == 2) {
         if (!g_cmx_claim) {
