@@ -132,7 +132,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     // instead, which is what lets 8 waves fit next to the forward-stage matrix
     u32x4* GWs = DFT ? const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.gw_planes)) : Bw + BWN;
     u32x4* Zs = Bw + BWN + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
-    float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [3][64]  input transform: mean, invstd*gamma, beta
+    float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [2][CC] (+ one unused row)  input transform: invstd*gamma, beta - mean*invstd*gamma
     u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * CC);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
     u32x4* MBs = FWs;                                                  // WG: [pair][row (j, r) 8][lane 64]  act(z) of the pair's current tile (fp32)
     int* flags = reinterpret_cast<int*>(MBs + CMX_WG_PAIRS * 8 * 64);  // WG: [pair][2]  tiles produced / tiles consumed
@@ -198,9 +198,10 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
         if (tid < 2 * CMX_WG_PAIRS) flags[tid] = 0;
     }
     if (has_xf && tid < CC) {
-        xfp[tid] = a.xf.mean[tid];
-        xfp[CC + tid] = a.xf.invstd[tid] * a.xf.gamma[tid];
-        xfp[2 * CC + tid] = a.xf.beta[tid];
+        // BatchNorm as ONE fused multiply-add per element: z = x * sc + sh,  sc = invstd * gamma,  sh = beta - mean * sc
+        const float sc_ = a.xf.invstd[tid] * a.xf.gamma[tid];
+        xfp[tid] = sc_;
+        xfp[CC + tid] = a.xf.beta[tid] - a.xf.mean[tid] * sc_;
     }
     // DYN: the workgroup's lines (b * waves + i % waves + (i / waves) * nslots, i = 0, 1, ...: the same set as the static walk) are CLAIMED
     // by its waves from a counter in LDS instead of dealt round-robin.  Measured with rpb_cmx_debug_wave_times at the headline shape
@@ -318,6 +319,10 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     for (int t = 0; t < 4; ++t) {
         bv[t] = a.bias ? a.bias[64 * hsel + 4 * m + t] : 0.f;
         if (STATS == 2 || oxf) bp[t] = xf_load(a.bnb, 64 * hsel + 4 * m + t);
+        if (STATS == 0 && oxf) {            // eval output transform as one fused multiply-add: .is <- invstd * gamma, .be <- beta - mean * that
+            bp[t].is *= bp[t].ga;
+            bp[t].be -= bp[t].mu * bp[t].is;
+        }
     }
     const bool xgelu = a.xf.gelu != 0;
     const bool bgelu = a.bnb.gelu != 0;
@@ -437,12 +442,11 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         const int i = 2 * ks + hf;
                         const f32x4v xv = __builtin_bit_cast(f32x4v, xa[j][C2 ? 2 * (ks & 1) + hf : i]);
                         if (has_xf) {
-                            const f32x4v mu = *reinterpret_cast<const f32x4v*>(xfp + 16 * i + 4 * kg);
-                            const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + CC + 16 * i + 4 * kg);
-                            const f32x4v be = *reinterpret_cast<const f32x4v*>(xfp + 2 * CC + 16 * i + 4 * kg);
+                            const f32x4v sc = *reinterpret_cast<const f32x4v*>(xfp + 16 * i + 4 * kg);
+                            const f32x4v sh = *reinterpret_cast<const f32x4v*>(xfp + CC + 16 * i + 4 * kg);
                             // channel pairs: packed fp32 math, the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
-                            f32x2 z0 = pk_fma(f32x2{xv[0], xv[1]} - f32x2{mu[0], mu[1]}, f32x2{sc[0], sc[1]}, f32x2{be[0], be[1]});
-                            f32x2 z1 = pk_fma(f32x2{xv[2], xv[3]} - f32x2{mu[2], mu[3]}, f32x2{sc[2], sc[3]}, f32x2{be[2], be[3]});
+                            f32x2 z0 = pk_fma(f32x2{xv[0], xv[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+                            f32x2 z1 = pk_fma(f32x2{xv[2], xv[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
                             if (xgelu) gelu2x2(z0, z1);
                             v[4 * hf] = z0[0];
                             v[4 * hf + 1] = z0[1];
@@ -568,9 +572,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         for (int tt = 0; tt < 2; ++tt) {
                             const int t = 2 * tt;
                             vv[tt] = f32x2{acc[j][t][r], acc[j][t + 1][r]};
-                            if (STATS == 0 && oxf)
-                                vv[tt] = pk_fma((vv[tt] - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is},
-                                                f32x2{bp[t].ga, bp[t + 1].ga}, f32x2{bp[t].be, bp[t + 1].be});
+                            if (STATS == 0 && oxf) vv[tt] = pk_fma(vv[tt], f32x2{bp[t].is, bp[t + 1].is}, f32x2{bp[t].be, bp[t + 1].be});
                             if (STATS == 2) {
                                 const f32x4v sp = __builtin_bit_cast(f32x4v, spre[j][r]);
                                 shv[tt] = (f32x2{sp[t], sp[t + 1]} - f32x2{bp[t].mu, bp[t + 1].mu}) * f32x2{bp[t].is, bp[t + 1].is};
