@@ -113,7 +113,11 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     XParam xp[4];
     if (XF) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xp[t] = xf_load(a.xf, 4 * c16 + t);       // N == channels == 64 * strips, strip 0 .. N/64
+        for (int t = 0; t < 4; ++t) {
+            xp[t] = xf_load(a.xf, 4 * c16 + t);       // N == channels == 64 * strips, strip 0 .. N/64
+            xp[t].is *= xp[t].ga;                     // BatchNorm as one fused multiply-add: x * (invstd gamma) + (beta - mean invstd gamma)
+            xp[t].be -= xp[t].mu * xp[t].is;
+        }
     }
     const bool xgelu = a.xf.gelu != 0;
     const int strips = a.N >> 6;
@@ -135,7 +139,11 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
         const rsrc_t ro = make_rsrc(a.out + g * a.out_g + n0, out_bytes);
         if (XF && strips > 1) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xp[t] = xf_load(a.xf, n0 + 4 * c16 + t);
+            for (int t = 0; t < 4; ++t) {
+                xp[t] = xf_load(a.xf, n0 + 4 * c16 + t);
+                xp[t].is *= xp[t].ga;
+                xp[t].be -= xp[t].mu * xp[t].is;
+            }
         }
         for (int p = 0; p < passes; ++p) {
             asm volatile("" ::: "memory");
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                         // channel pairs: packed fp32 math; the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
                         f32x2 xa = f32x2{x4[0], x4[1]}, xb = f32x2{x4[2], x4[3]};
                         if (XF) {
-                            xa = pk_fma((xa - f32x2{xp[0].mu, xp[1].mu}) * f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].ga, xp[1].ga}, f32x2{xp[0].be, xp[1].be});
-                            xb = pk_fma((xb - f32x2{xp[2].mu, xp[3].mu}) * f32x2{xp[2].is, xp[3].is}, f32x2{xp[2].ga, xp[3].ga}, f32x2{xp[2].be, xp[3].be});
+                            xa = pk_fma(xa, f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].be, xp[1].be});
+                            xb = pk_fma(xb, f32x2{xp[2].is, xp[3].is}, f32x2{xp[2].be, xp[3].be});
                             if (xgelu) gelu2x2(xa, xb);
                             xa = live ? xa : pk2(0.f);
                             xb = live ? xb : pk2(0.f);

@@ -61,13 +61,12 @@ __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
     const long ntiles = (a.ncell + 31) >> 5;
     const long nstreams = (long)gridDim.x * 2, slot = (long)blockIdx.x * 2 + stream;
     const bool has_xf = a.xf.mean != nullptr, xgelu = a.xf.gelu != 0;
-    f32x2 mu[2], sc[2], be[2];
+    f32x2 sc[2], be[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int c = 64 * ih + 4 * n + 2 * p;
-        mu[p] = has_xf ? f32x2{a.xf.mean[c], a.xf.mean[c + 1]} : pk2(0.f);
         sc[p] = has_xf ? f32x2{a.xf.invstd[c] * a.xf.gamma[c], a.xf.invstd[c + 1] * a.xf.gamma[c + 1]} : pk2(1.f);
-        be[p] = has_xf ? f32x2{a.xf.beta[c], a.xf.beta[c + 1]} : pk2(0.f);
+        be[p] = has_xf ? f32x2{a.xf.beta[c], a.xf.beta[c + 1]} - f32x2{a.xf.mean[c], a.xf.mean[c + 1]} * sc[p] : pk2(0.f);     // x * sc + be
     }
     const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4v accW[4][4];          // tile (uo, ui): row 4 mg + r <-> out channel 64 oh + 4 (4 mg + r) + uo, column n <-> in channel 64 ih + 4 n + ui
@@ -117,8 +116,8 @@ __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
                     const f32x4v xv = __builtin_bit_cast(f32x4v, xb[j][r]);
                     f32x2 za = f32x2{xv[0], xv[1]}, zb = f32x2{xv[2], xv[3]};
                     if (has_xf) {
-                        za = pk_fma(za - mu[0], sc[0], be[0]);
-                        zb = pk_fma(zb - mu[1], sc[1], be[1]);
+                        za = pk_fma(za, sc[0], be[0]);
+                        zb = pk_fma(zb, sc[1], be[1]);
                         if (xgelu) gelu2x2(za, zb);
                     }
                     v0[4 * j + r] = za[0];
