@@ -127,7 +127,11 @@ __global__ __launch_bounds__(512) void bwd_row_kernel(BwdRowArgs a) {
     const unsigned row_bytes = (unsigned)Wp * C * 4;
     vec sa[4], ya[4], xa[4], sb[4], yb[4], xb[4];
 
-    for (long g = slot; g < a.G; g += nslots) {
+    for (long g_ = slot; g_ < a.G; g_ += nslots) {
+        // the row index is wave-uniform, but the compiler carries it (and every descriptor derived from it) in vector registers and
+        // wraps each buffer access of the row in a waterfall loop (4 v_readfirstlane + 2 v_cmp + a branch per access, 76 per row in the
+        // layer-0 instance): pin it to a scalar register
+        const long g = (long)__builtin_amdgcn_readfirstlane((int)g_);
         const long off = g * (long)Wp * C;
         const rsrc_t rs = make_rsrc(a.s + off, row_bytes);
         const rsrc_t ry = make_rsrc(a.gy + off, row_bytes);
