@@ -14,6 +14,10 @@ FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
          + os.environ.get("RPB_HIPCC_FLAGS", "").split())
 
 
+# per-file flags: rpb_pjg.hip keeps every vector instruction in its scalar form (packed fp32 next to MFMAs waits for the matrix pipe)
+EXTRA = {"rpb_pjg.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -37,7 +41,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

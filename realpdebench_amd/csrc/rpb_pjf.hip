@@ -24,6 +24,7 @@
 // the fp32-grade arithmetic of rpb_cmx.hip / rpb_pjx.hip).  One wave owns a full 128 x 64 weight-gradient accumulator (128
 // registers), so the kernel runs one wave per SIMD with the 512-register budget; HBM traffic is s (crop) + gout in, g out.
 #include "rpb_common.h"
+#include "rpb_pjf.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -80,21 +81,6 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 __device__ __forceinline__ int chan_of(int ks, int kg, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * kg + (e & 3); }
 }  // namespace
 
-struct PjfArgs {
-    const float* s;       // padded pre-BN tensor of the last Fourier layer [B*Tp*Hp*Wp][64]
-    const float* w1;      // fc1.weight [128][64]
-    const float* b1;      // [128]
-    const float* w2;      // fc2.weight [DO][128]
-    const float* gout;    // [ncrop][DO]  (LOSS: the TARGET y instead -- the kernel forms out = fc2 gelu(u) + b2 and gout = gscale (out - y) itself)
-    const float* b2;      // LOSS: fc2.bias [DO]
-    float gscale;         // LOSS: 2 / (number of output elements over all ranks)
-    float* loss_part;     // LOSS: [slots] partial sums of (out - y)^2
-    float* g;             // [ncell][64] gradient w.r.t. the layer output, padded layout
-    float* part;          // [slots][128*64 + DO*128 + 128 + DO]   (M = gh^T shat | d fc2 | d b1 | d b2)
-    int B, DO;
-    CropMap cm;
-    XForm xf;             // BatchNorm of the last layer: mean, invstd, gamma, beta (gelu must be 0)
-};
 
 // six products of the three-plane split, small terms first, NC independent accumulation chains advancing together
 #define PF_MAC6(NC, ACC, AH, AM, AL, BH, BM, BL)                                       \
@@ -654,6 +640,7 @@ extern "C" int rpb_head_bwd_row(int DO) { return PF_HID * 64 + DO * PF_HID + PF_
 // d fc2.bias): reduce over rows, then rpb_head_bwd_finalize
 static int pjf_launch(PjfArgs& p, bool loss, hipStream_t st) {
     const int grid = (int)(rpb_head_bwd_slots(p.B, p.cm.T, p.cm.H) / PF_WAVES);
+    if (pjg_supported(p.DO)) return pjg_launch(p, loss, grid, st);       // fc2 width 2: the 32x32x16 organisation (rpb_pjg.hip)
     const size_t lds = pjf_lds();
     const int DO = p.DO;
 #define RPB_PJF(D_, E_, L_)                                                                                                   \
