@@ -114,7 +114,8 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
     u32x4* W1B = lds4;                                   // [ks 4][nt 4][plane 3][lane]   B of u:   W1'[32 nt + n][16 ks + 8 kg + e]
     u32x4* W1D = W1B + 4 * 4 * 3 * 64;                   // [ks3 8][mt 2][plane 3][lane]  A of g^T: W1[16 ks3 + 8 kg + e][32 mt + m]
     float* b1l = reinterpret_cast<float*>(W1D + 8 * 2 * 3 * 64);          // [128]  b1' = b1 + W1 beta
-    float* gball = b1l + PG_HID;                         // [waves][64]  gout of the tile, gathered for every lane
+    float* meanl = b1l + PG_HID;                         // [64]   BatchNorm mean
+    float* gball = meanl + 64;                           // [waves][64]  gout of the tile, gathered for every lane
     char* GHall = reinterpret_cast<char*>(gball + PG_WAVES * 64);         // [waves][buf 2][plane 3][hidden row 32][64 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
         for (int c = 0; c < 64; ++c) a = __builtin_fmaf(p.w1[h * 64 + c], p.xf.beta[c], a);
         b1l[h] = a;
     }
+    if (tid < 64) meanl[tid] = p.xf.mean[tid];
     __syncthreads();
 
     const CropMap cm = p.cm;
@@ -175,9 +177,6 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
     char* GHw = GHall + wave * PG_GH_WAVE;
     float* gb = gball + wave * 64;
     // per-lane constants
-    float meanA[32];                                     // [8 ks + e]: channel 16 ks + 8 hg + e  (A layout of the tile)
-#pragma unroll
-    for (int i = 0; i < 32; ++i) meanA[i] = p.xf.mean[16 * (i >> 3) + 8 * hg + (i & 7)];
     const float meanB0 = p.xf.mean[2 * n], meanB1 = p.xf.mean[2 * n + 1];          // B layout: the lane's channel pair
     float w2r[2][4], b1r[4];
 #pragma unroll
@@ -245,10 +244,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
             const bool last = q + 1 == TQ;
             const int pn = last ? pln : pl, qn = last ? 0 : q + 1;
             const unsigned pf = prefetch(pn, qn);
-            // ---- the tile's second view (lane = channel pair, 16 cells) and its fc2-side inputs: L1 / L2 hits, in flight during contraction 1
-            f32x2 xr[16];                                // [8 kstep + e]: cell 16 kstep + 8 (e >> 2) + 4 hg + (e & 3), channels 2 n, 2 n + 1
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xr[i] = ld8(rxl, (32 * q + 16 * (i >> 3) + 8 * ((i >> 2) & 1) + 4 * hg + (i & 3)) * 256 + n * 8);
+            // ---- the fc2-side inputs of the tile
             const float yv = buf_load_f32(rg, ((32 * q + celly) * 2 + (n & 1)) * 4, 0);                    // the lane's own (cell, feature) element
             f32x4v G4[8];                                // gout [register row r][feature]: G4[k] = (r = 2k: 0, 1 | r = 2k + 1: 0, 1)
             if (!LOSS) {
@@ -260,15 +256,16 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = b1r[nt];
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;               // (b1' is added at the activation: a resident splat costs 64 registers)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 float v[8];
                 const f32x4v x0 = __builtin_bit_cast(f32x4v, xa[2 * ks]), x1 = __builtin_bit_cast(f32x4v, xa[2 * ks + 1]);
+                const f32x4v m0 = *reinterpret_cast<const f32x4v*>(meanl + 16 * ks + 8 * hg), m1 = *reinterpret_cast<const f32x4v*>(meanl + 16 * ks + 8 * hg + 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    v[c] = x0[c] - meanA[8 * ks + c];
-                    v[4 + c] = x1[c] - meanA[8 * ks + 4 + c];
+                    v[c] = x0[c] - m0[c];
+                    v[4 + c] = x1[c] - m1[c];
                 }
                 bf16x8 Ah, Am, Al;
                 split8(v, Ah, Am, Al);
@@ -296,20 +293,14 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #undef PG_BL
             }
             asm volatile("" ::"v"(pf));
-            issue_xa(pn, qn);                            // the next tile's A-layout loads (its lines were pulled into L2 a tile ago)
-            // ---- planes of the second view: (s - mean) with lane = channel, the B operand of the weight gradient
-            bf16x8 Xh[2][2], Xm[2][2], Xl[2][2];         // [kstep][channel parity]
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the tile's second view (lane = channel pair, 16 cells): L1 / L2 hits, requested here so that only the hidden-tile loop
+            //      holds them (the activation phase needs its registers for v and gelu')
+            f32x2 xr[16];                                // [8 kstep + e]: cell 16 kstep + 8 (e >> 2) + 4 hg + (e & 3), channels 2 n, 2 n + 1
+            auto issue_xr = [&]() {
 #pragma unroll
-            for (int kstep = 0; kstep < 2; ++kstep) {
-                float v0[8], v1[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v0[e] = xr[8 * kstep + e][0] - meanB0;
-                    v1[e] = xr[8 * kstep + e][1] - meanB1;
-                }
-                split8(v0, Xh[kstep][0], Xm[kstep][0], Xl[kstep][0]);
-                split8(v1, Xh[kstep][1], Xm[kstep][1], Xl[kstep][1]);
-            }
+                for (int i = 0; i < 16; ++i) xr[i] = ld8(rxl, (32 * q + 16 * (i >> 3) + 8 * ((i >> 2) & 1) + 4 * hg + (i & 3)) * 256 + n * 8);
+            };
             // ---- activation: v = gelu(u) (kept for d fc2), gelu'(u) replaces u in the accumulators
             float VV[4][16];
             if (LOSS) {
@@ -321,11 +312,13 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float d;
-                        gelu_both_s(acc[nt][r], VV[nt][r], d);
+                        gelu_both_s(acc[nt][r] + b1r[nt], VV[nt][r], d);
                         acc[nt][r] = d;
                         po[2 * r] = __builtin_fmaf(VV[nt][r], w2r[0][nt], po[2 * r]);
                         po[2 * r + 1] = __builtin_fmaf(VV[nt][r], w2r[1][nt], po[2 * r + 1]);
                     }
+                __builtin_amdgcn_sched_barrier(0);
+                issue_xr();
                 // sum over the 32 lanes of the half, halving the value set at every step: lane n ends with element n = 2 r + feature
                 float q1[16], q2[8], q3[4], q4[2];
 #pragma unroll
@@ -358,10 +351,34 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float d;
-                        gelu_both_s(acc[nt][r], VV[nt][r], d);
+                        gelu_both_s(acc[nt][r] + b1r[nt], VV[nt][r], d);
                         acc[nt][r] = d;
                     }
+                __builtin_amdgcn_sched_barrier(0);
+                issue_xr();
             }
+            // ---- d fc2 += gout^T v  (here, so that v is dead before the planes and operands of the hidden-tile loop come alive)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dw2[0][nt] = __builtin_fmaf(G4[r >> 1][2 * (r & 1)], VV[nt][r], dw2[0][nt]);
+                    dw2[1][nt] = __builtin_fmaf(G4[r >> 1][2 * (r & 1) + 1], VV[nt][r], dw2[1][nt]);
+                }
+            // ---- planes of the second view: (s - mean) with lane = channel, the B operand of the weight gradient
+            bf16x8 Xh[2][2], Xm[2][2], Xl[2][2];         // [kstep][channel parity]
+#pragma unroll
+            for (int kstep = 0; kstep < 2; ++kstep) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v0[e] = xr[8 * kstep + e][0] - meanB0;
+                    v1[e] = xr[8 * kstep + e][1] - meanB1;
+                }
+                split8(v0, Xh[kstep][0], Xm[kstep][0], Xl[kstep][0]);
+                split8(v1, Xh[kstep][1], Xm[kstep][1], Xl[kstep][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- per hidden tile: gh, its planes (once), the weight gradient from registers, the data gradient through LDS
             f32x16v acc3[2];                             // g^T: [channel tile mt]: row = channel 32 mt + D row, column = cell slot n
 #pragma unroll
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                 for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
+                if (nt == 2) issue_xa(pn, qn);           // the next tile's A-layout loads (its lines were pulled into L2 a tile ago)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float g0 = G4[r >> 1][2 * (r & 1)], g1 = G4[r >> 1][2 * (r & 1) + 1];
@@ -377,8 +395,6 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                     const float gh = gp * acc[nt][r];                                   // cells >= W: gout == 0 -> gh == 0
                     acc[nt][r] = gh;
                     db1[nt] += gh;
-                    dw2[0][nt] = __builtin_fmaf(g0, VV[nt][r], dw2[0][nt]);
-                    dw2[1][nt] = __builtin_fmaf(g1, VV[nt][r], dw2[1][nt]);
                 }
                 bf16x8 Gh[2], Gm[2], Gl[2];              // [kstep]: register rows 8 kstep + e = cells 8 (2 kstep + (e >> 2)) + 4 hg + (e & 3)
 #pragma unroll
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
     }
 }
 
-size_t pjg_lds() { return (size_t)(4 * 4 * 3 * 64 + 8 * 2 * 3 * 64) * 16 + (PG_HID + PG_WAVES * 64) * 4 + (size_t)PG_WAVES * PG_GH_WAVE; }
+size_t pjg_lds() { return (size_t)(4 * 4 * 3 * 64 + 8 * 2 * 3 * 64) * 16 + (PG_HID + 64 + PG_WAVES * 64) * 4 + (size_t)PG_WAVES * PG_GH_WAVE; }
 
 int pjg_supported(int DO) {
     static const bool off = getenv("RPB_HEAD_PJG") && atoi(getenv("RPB_HEAD_PJG")) == 0;
