@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librpb_hip.so")
+LIB_PATH = os.environ.get("RPB_LIB_PATH") or os.path.join(_HERE, "csrc", "librpb_hip.so")     # RPB_LIB_PATH: an instrumented build (tools/dbg)
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 _T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}

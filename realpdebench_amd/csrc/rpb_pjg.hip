@@ -34,6 +34,25 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 #define PG_GH_PLANE 2048                   // bytes of one gh plane of 32 hidden units x 32 cells
 #define PG_GH_BUF (3 * PG_GH_PLANE)
 #define PG_GH_WAVE (2 * PG_GH_BUF)
+// PG_PIPE = n > 0: ask the scheduler for n vector instructions behind every MFMA of the hidden-tile loop (0: its own order)
+#ifndef PG_PIPE
+#define PG_PIPE 0
+#endif
+
+// -DPG_TIMING: s_memtime stamps at the phase boundaries of the tile body; the wave writes its per-phase cycle sums over the first floats of
+// its partial row (the results of such a build are garbage: tools/dbg/head_phases.py reads the stamps only)
+#ifdef PG_TIMING
+#define PG_T(i)                                    \
+    {                                              \
+        __builtin_amdgcn_sched_barrier(0);         \
+        const long long now_ = clock64();          \
+        __builtin_amdgcn_sched_barrier(0);         \
+        tacc[i] += (float)(now_ - tlast);          \
+        tlast = now_;                              \
+    }
+#else
+#define PG_T(i)
+#endif
 
 namespace {
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
@@ -86,6 +105,53 @@ __device__ __forceinline__ void gelu_both_s(float u, float& v, float& d) {
     v = __builtin_fmaf(au, h, 0.5f * u);
     const float w = __builtin_fmaf(au * e, 0.39894228040143267794f, h);               // Phi(|u|) - 1/2 + |u| phi(u): odd part of gelu'
     d = 0.5f + __builtin_copysignf(w, u);
+}
+// the same on a PAIR of values with packed fp32 instructions: the activation phase of a tile has no MFMA in flight, and one wave
+// per SIMD issues a v_pk_* at the price of a scalar instruction (issue_probe: 5.3 cycles either way) -- half the issue slots
+__device__ __forceinline__ void gelu_both_p(f32x2 u, f32x2& v, f32x2& d) {
+    const f32x2 au = __builtin_elementwise_abs(u);
+    const f32x2 den = pk_fma(au, pk2(0.23164189f), pk2(1.0f));
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 pl = pk_fma(pk2(0.5307027145f), t, pk2(-0.7265760135f));
+    pl = pk_fma(pl, t, pk2(0.7107068705f));
+    pl = pk_fma(pl, t, pk2(-0.142248368f));
+    pl = pk_fma(pl, t, pk2(0.127414796f));
+    const f32x2 q = (u * pk2(-0.72134752044448170368f)) * u;
+    const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const f32x2 Q = (pl * t) * e;
+    const f32x2 h = pk2(0.5f) - Q;
+    v = pk_fma(au, h, pk2(0.5f) * u);
+    const f32x2 w = pk_fma(au * e, pk2(0.39894228040143267794f), h);
+    d = pk2(0.5f) + f32x2{__builtin_copysignf(w[0], u[0]), __builtin_copysignf(w[1], u[1])};
+}
+// TWO pairs in lock-step (scheduling fences between the steps): a dependent v_pk_fma_f32 needs a wait state after its producer, and left
+// alone the compiler evaluates one chain after the other (shortest live ranges) with s_nop between the links
+#define PG_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void gelu_both_p2(f32x2 ua, f32x2 ub, f32x2& va, f32x2& da, f32x2& vb, f32x2& db) {
+    const f32x2 aa = __builtin_elementwise_abs(ua), ab = __builtin_elementwise_abs(ub);
+    const f32x2 dna = pk_fma(aa, pk2(0.23164189f), pk2(1.0f)), dnb = pk_fma(ab, pk2(0.23164189f), pk2(1.0f));
+    const f32x2 qa = (ua * pk2(-0.72134752044448170368f)) * ua, qb = (ub * pk2(-0.72134752044448170368f)) * ub;
+    const f32x2 ta = {__builtin_amdgcn_rcpf(dna[0]), __builtin_amdgcn_rcpf(dna[1])}, tb = {__builtin_amdgcn_rcpf(dnb[0]), __builtin_amdgcn_rcpf(dnb[1])};
+    const f32x2 ea = {__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])}, eb = {__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+    PG_FENCE();
+    f32x2 pa = pk_fma(pk2(0.5307027145f), ta, pk2(-0.7265760135f)), pb = pk_fma(pk2(0.5307027145f), tb, pk2(-0.7265760135f));
+    const f32x2 hua = pk2(0.5f) * ua, hub = pk2(0.5f) * ub;
+    PG_FENCE();
+    pa = pk_fma(pa, ta, pk2(0.7107068705f)), pb = pk_fma(pb, tb, pk2(0.7107068705f));
+    const f32x2 xa_ = aa * ea, xb_ = ab * eb;
+    PG_FENCE();
+    pa = pk_fma(pa, ta, pk2(-0.142248368f)), pb = pk_fma(pb, tb, pk2(-0.142248368f));
+    const f32x2 tea = ta * ea, teb = tb * eb;
+    PG_FENCE();
+    pa = pk_fma(pa, ta, pk2(0.127414796f)), pb = pk_fma(pb, tb, pk2(0.127414796f));
+    PG_FENCE();
+    const f32x2 ha = pk_fma(-pa, tea, pk2(0.5f)), hb = pk_fma(-pb, teb, pk2(0.5f));           // 1/2 - Phi(-|u|)
+    PG_FENCE();
+    va = pk_fma(aa, ha, hua), vb = pk_fma(ab, hb, hub);
+    const f32x2 wa = pk_fma(xa_, pk2(0.39894228040143267794f), ha), wb = pk_fma(xb_, pk2(0.39894228040143267794f), hb);
+    PG_FENCE();
+    da = pk2(0.5f) + f32x2{__builtin_copysignf(wa[0], ua[0]), __builtin_copysignf(wa[1], ua[1])};
+    db = pk2(0.5f) + f32x2{__builtin_copysignf(wb[0], ub[0]), __builtin_copysignf(wb[1], ub[1])};
 }
 __device__ __forceinline__ float dpp_add(float x, float y, const int ctrl) {           // x + y from the lane the DPP control names
     switch (ctrl) {
@@ -232,6 +298,12 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
         return __builtin_amdgcn_raw_buffer_load_b32(rx, 32 * q * 256 + lane * 128, 0, 0);
     };
     issue_xa(slot < GL ? line_of((int)slot) : -1, 0);
+#ifdef PG_TIMING
+    float tacc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tacc[i] = 0.f;
+    long long tlast = clock64();
+#endif
     for (long gl = slot; gl < GL; gl += nslots) {
         const int pl = line_of((int)gl);
         const int gln = gl + nslots < GL ? (int)(gl + nslots) : -1;
@@ -251,6 +323,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) G4[k] = __builtin_bit_cast(f32x4v, ld16(rg, (32 * q + 8 * (k >> 1) + 4 * hg + 2 * (k & 1)) * 8));
             }
+            PG_T(0)
             // ---- contraction 1: u = (s - mean) W1'^T + b1'
             f32x16v acc[4];
 #pragma unroll
@@ -294,6 +367,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
             }
             asm volatile("" ::"v"(pf));
             __builtin_amdgcn_sched_barrier(0);
+            PG_T(1)
             // ---- the tile's second view (lane = channel pair, 16 cells): L1 / L2 hits, requested here so that only the hidden-tile loop
             //      holds them (the activation phase needs its registers for v and gelu')
             f32x2 xr[16];                                // [8 kstep + e]: cell 16 kstep + 8 (e >> 2) + 4 hg + (e & 3), channels 2 n, 2 n + 1
@@ -304,19 +378,28 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
             // ---- activation: v = gelu(u) (kept for d fc2), gelu'(u) replaces u in the accumulators
             float VV[4][16];
             if (LOSS) {
-                float po[32];                            // [2 r + feature]: the lane's partial of out over its 4 hidden units
+                f32x2 pp[16];                            // [r] = (feature 0, feature 1): the lane's partial of out over its 4 hidden units
 #pragma unroll
-                for (int i = 0; i < 32; ++i) po[i] = 0.f;
+                for (int i = 0; i < 16; ++i) pp[i] = pk2(0.f);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x2 wp = {w2r[0][nt], w2r[1][nt]};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float d;
-                        gelu_both_s(acc[nt][r] + b1r[nt], VV[nt][r], d);
-                        acc[nt][r] = d;
-                        po[2 * r] = __builtin_fmaf(VV[nt][r], w2r[0][nt], po[2 * r]);
-                        po[2 * r + 1] = __builtin_fmaf(VV[nt][r], w2r[1][nt], po[2 * r + 1]);
+                    for (int r = 0; r < 16; r += 4) {
+                        f32x2 v, d, v2, d2;
+                        gelu_both_p2(f32x2{acc[nt][r], acc[nt][r + 1]} + pk2(b1r[nt]), f32x2{acc[nt][r + 2], acc[nt][r + 3]} + pk2(b1r[nt]), v, d, v2, d2);
+                        VV[nt][r] = v[0], VV[nt][r + 1] = v[1], VV[nt][r + 2] = v2[0], VV[nt][r + 3] = v2[1];
+                        acc[nt][r] = d[0], acc[nt][r + 1] = d[1], acc[nt][r + 2] = d2[0], acc[nt][r + 3] = d2[1];
+                        pp[r] = pk_fma(pk2(v[0]), wp, pp[r]);
+                        pp[r + 1] = pk_fma(pk2(v[1]), wp, pp[r + 1]);
+                        pp[r + 2] = pk_fma(pk2(v2[0]), wp, pp[r + 2]);
+                        pp[r + 3] = pk_fma(pk2(v2[1]), wp, pp[r + 3]);
                     }
+                }
+                float po[32];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) po[2 * i] = pp[i][0], po[2 * i + 1] = pp[i][1];
+                PG_T(2)
                 __builtin_amdgcn_sched_barrier(0);
                 issue_xr();
                 // sum over the 32 lanes of the half, halving the value set at every step: lane n ends with element n = 2 r + feature
@@ -349,22 +432,37 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float d;
-                        gelu_both_s(acc[nt][r] + b1r[nt], VV[nt][r], d);
-                        acc[nt][r] = d;
+                    for (int r = 0; r < 16; r += 4) {
+                        f32x2 v, d, v2, d2;
+                        gelu_both_p2(f32x2{acc[nt][r], acc[nt][r + 1]} + pk2(b1r[nt]), f32x2{acc[nt][r + 2], acc[nt][r + 3]} + pk2(b1r[nt]), v, d, v2, d2);
+                        VV[nt][r] = v[0], VV[nt][r + 1] = v[1], VV[nt][r + 2] = v2[0], VV[nt][r + 3] = v2[1];
+                        acc[nt][r] = d[0], acc[nt][r + 1] = d[1], acc[nt][r + 2] = d2[0], acc[nt][r + 3] = d2[1];
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 issue_xr();
             }
-            // ---- d fc2 += gout^T v  (here, so that v is dead before the planes and operands of the hidden-tile loop come alive)
+            PG_T(3)
+            // ---- d fc2 += gout^T v  (here, so that v is dead before the planes and operands of the hidden-tile loop come alive; packed:
+            //      no MFMA is in flight yet)
+            {
+                f32x2 dwp[4][2];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    dw2[0][nt] = __builtin_fmaf(G4[r >> 1][2 * (r & 1)], VV[nt][r], dw2[0][nt]);
-                    dw2[1][nt] = __builtin_fmaf(G4[r >> 1][2 * (r & 1) + 1], VV[nt][r], dw2[1][nt]);
+                for (int nt = 0; nt < 4; ++nt) {
+                    dwp[nt][0] = f32x2{dw2[0][nt], dw2[1][nt]};
+                    dwp[nt][1] = pk2(0.f);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)                         // 8 independent chains advance together
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        dwp[nt][r & 1] = pk_fma(f32x2{G4[r >> 1][2 * (r & 1)], G4[r >> 1][2 * (r & 1) + 1]}, pk2(VV[nt][r]), dwp[nt][r & 1]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x2 t2 = dwp[nt][0] + dwp[nt][1];
+                    dw2[0][nt] = t2[0], dw2[1][nt] = t2[1];
+                }
+            }
+            PG_T(4)
             // ---- planes of the second view: (s - mean) with lane = channel, the B operand of the weight gradient
             bf16x8 Xh[2][2], Xm[2][2], Xl[2][2];         // [kstep][channel parity]
 #pragma unroll
@@ -379,15 +477,17 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                 split8(v1, Xh[kstep][1], Xm[kstep][1], Xl[kstep][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            PG_T(5)
             // ---- per hidden tile: gh, its planes (once), the weight gradient from registers, the data gradient through LDS
             f32x16v acc3[2];                             // g^T: [channel tile mt]: row = channel 32 mt + D row, column = cell slot n
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc3[mt][r] = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (nt == 2) issue_xa(pn, qn);           // the next tile's A-layout loads (its lines were pulled into L2 a tile ago)
+            // software pipeline over the hidden tiles: the vector work of tile nt + 1 (gh, its split, the plane stores) is written
+            // AFTER the 48 MFMAs of tile nt and has no dependence on them, so it issues in their shadow (<= 5 scalar instructions per MFMA)
+            bf16x8 Gh[2][2], Gm[2][2], Gl[2][2];         // [nt & 1][kstep]: register rows 8 kstep + e = cells 8 (2 kstep + (e >> 2)) + 4 hg + (e & 3)
+            auto gh_stage = [&](int nt) {                // gh of hidden tile nt, its planes (once), the plane stores
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float g0 = G4[r >> 1][2 * (r & 1)], g1 = G4[r >> 1][2 * (r & 1) + 1];
@@ -396,69 +496,58 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                     acc[nt][r] = gh;
                     db1[nt] += gh;
                 }
-                bf16x8 Gh[2], Gm[2], Gl[2];              // [kstep]: register rows 8 kstep + e = cells 8 (2 kstep + (e >> 2)) + 4 hg + (e & 3)
 #pragma unroll
                 for (int kstep = 0; kstep < 2; ++kstep) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc[nt][8 * kstep + e];
-                    split8(v, Gh[kstep], Gm[kstep], Gl[kstep]);
+                    split8(v, Gh[nt & 1][kstep], Gm[nt & 1][kstep], Gl[nt & 1][kstep]);
                 }
                 char* ghb = GHw + (nt & 1) * PG_GH_BUF;
-                *reinterpret_cast<u32x4*>(ghb + 0 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gh[0]);
-                *reinterpret_cast<u32x4*>(ghb + 0 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gh[1]);
-                *reinterpret_cast<u32x4*>(ghb + 1 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gm[0]);
-                *reinterpret_cast<u32x4*>(ghb + 1 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gm[1]);
-                *reinterpret_cast<u32x4*>(ghb + 2 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gl[0]);
-                *reinterpret_cast<u32x4*>(ghb + 2 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gl[1]);
-                // M[nt] += gh^T (s - mean): contraction over the 32 cells, two K-steps, both channel parities
+                *reinterpret_cast<u32x4*>(ghb + 0 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gh[nt & 1][0]);
+                *reinterpret_cast<u32x4*>(ghb + 0 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gh[nt & 1][1]);
+                *reinterpret_cast<u32x4*>(ghb + 1 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gm[nt & 1][0]);
+                *reinterpret_cast<u32x4*>(ghb + 1 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gm[nt & 1][1]);
+                *reinterpret_cast<u32x4*>(ghb + 2 * PG_GH_PLANE + ghw0) = __builtin_bit_cast(u32x4, Gl[nt & 1][0]);
+                *reinterpret_cast<u32x4*>(ghb + 2 * PG_GH_PLANE + ghw1) = __builtin_bit_cast(u32x4, Gl[nt & 1][1]);
+            };
+            gh_stage(0);
+            PG_T(6)
 #pragma unroll
-                for (int kstep = 0; kstep < 2; ++kstep) {
-#define PG_ACC(c) accM[nt][c]
-#define PG_AH(c) Gh[kstep]
-#define PG_AM(c) Gm[kstep]
-#define PG_AL(c) Gl[kstep]
-#define PG_BH(c) Xh[kstep][c]
-#define PG_BM(c) Xm[kstep][c]
-#define PG_BL(c) Xl[kstep][c]
-                    PG_MAC6(2, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL)
-#undef PG_ACC
-#undef PG_AH
-#undef PG_AM
-#undef PG_AL
-#undef PG_BH
-#undef PG_BM
-#undef PG_BL
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // g^T += W1^T gh^T over the 32 hidden units of this tile (K-steps ks3 = 2 nt, 2 nt + 1)
+            for (int nt = 0; nt < 4; ++nt) {
+                asm volatile("" ::: "memory");           // the plane stores of this tile stay ahead of its transposing reads (LDS runs a wave's accesses in order)
+                if (nt == 2) issue_xa(pn, qn);           // the next tile's A-layout loads (its lines were pulled into L2 a tile ago)
+                char* ghb = GHw + (nt & 1) * PG_GH_BUF;
+                bf16x8 Bp[2][3], ah[2][2], am[2][2], al[2][2];          // [kk]: transposed gh planes (lane = cell), W1^T planes [kk][mt]
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    bf16x8 Bp[3];
 #pragma unroll
                     for (int pln_ = 0; pln_ < 3; ++pln_) {
                         typedef bf16x4 __attribute__((address_space(3))) * lds_b4;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(ghb + pln_ * PG_GH_PLANE + kk * 1024 + tro[0]));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(ghb + pln_ * PG_GH_PLANE + kk * 1024 + tro[1]));
-                        Bp[pln_] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        Bp[kk][pln_] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
-                    bf16x8 ah[2], am[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        ah[mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 0) * 64 + lane]);
-                        am[mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 1) * 64 + lane]);
-                        al[mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 2) * 64 + lane]);
+                        ah[kk][mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 0) * 64 + lane]);
+                        am[kk][mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 1) * 64 + lane]);
+                        al[kk][mt] = __builtin_bit_cast(bf16x8, W1D[(((2 * nt + kk) * 2 + mt) * 3 + 2) * 64 + lane]);
                     }
-#define PG_ACC(c) acc3[c]
-#define PG_AH(c) ah[c]
-#define PG_AM(c) am[c]
-#define PG_AL(c) al[c]
-#define PG_BH(c) Bp[0]
-#define PG_BM(c) Bp[1]
-#define PG_BL(c) Bp[2]
-                    PG_MAC6(2, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL)
+                }
+                asm volatile("" ::: "memory");           // ... and the next tile's plane stores behind these reads
+                // M[nt] += gh^T (s - mean) over the 32 cells (two K-steps, both channel parities), g^T += W1^T gh^T over the tile's 32 hidden
+                // units (K-steps ks3 = 2 nt, 2 nt + 1): four independent accumulators advance together
+#pragma unroll
+                for (int kstep = 0; kstep < 2; ++kstep) {
+#define PG_ACC(c) (*((c) < 2 ? &accM[nt][(c)] : &acc3[(c) - 2]))
+#define PG_AH(c) ((c) < 2 ? Gh[nt & 1][kstep] : ah[kstep][(c) - 2])
+#define PG_AM(c) ((c) < 2 ? Gm[nt & 1][kstep] : am[kstep][(c) - 2])
+#define PG_AL(c) ((c) < 2 ? Gl[nt & 1][kstep] : al[kstep][(c) - 2])
+#define PG_BH(c) ((c) < 2 ? Xh[kstep][(c)] : Bp[kstep][0])
+#define PG_BM(c) ((c) < 2 ? Xm[kstep][(c)] : Bp[kstep][1])
+#define PG_BL(c) ((c) < 2 ? Xl[kstep][(c)] : Bp[kstep][2])
+                    PG_MAC6(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL)
 #undef PG_ACC
 #undef PG_AH
 #undef PG_AM
@@ -467,7 +556,19 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #undef PG_BM
 #undef PG_BL
                 }
+                if (nt < 3) gh_stage(nt + 1);
+#if PG_PIPE
+                if (nt < 3) {
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, PG_PIPE, 0);     // PG_PIPE vector instructions
+                    }
+                }
+#endif
+                PG_T(8)
             }
+            PG_T(9)
             // ---- g rows: channels 32 mt + 8 a + 4 hg .. + 3 of cell slot n (16 B per lane)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -477,6 +578,7 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                     st16(o, ro, (32 * q + cells) * 256 + (32 * mt + 8 * a + 4 * hg) * 4);     // cells >= Wp: dropped; W .. Wp-1: zeros (gh == 0)
                 }
         }
+        PG_T(10)
         // margin cells 32 TQ .. Wp - 1 of the line (cells W .. 32 TQ - 1 were written as zeros by the last tile)
         for (int off = TQ * 32 * 256 + lane * 16; off < (int)line_bytes; off += 1024) st16(z4, ro, off);
     }
@@ -512,6 +614,14 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
             if (hg == 0) part[PG_HID * 64 + j * PG_HID + 32 * nt + n] = s2;
         }
     }
+#ifdef PG_TIMING
+    if (lane < 12) {
+        float tv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) tv = lane == i ? tacc[i] : tv;
+        part[lane] = tv;
+    }
+#endif
     {                                                    // d b2: lane n accumulated gout of feature n & 1
         float s3 = gacc;
 #pragma unroll
