@@ -28,6 +28,12 @@ extern "C" {
 #define RPB_ERR_LAUNCH (-2)
 #define RPB_ERR_UNSUPPORTED (-3)
 
+/* ABI version of THIS header.  rpb_abi_version() returns the version the library was built with: a caller compiled against another
+ * header must refuse to run (signatures changed under unchanged symbol names between versions -- see INTEGRATION.md "ABI versions").
+ *   1  rounds 1-3
+ *   2  round 4: rpb_cell_mix_bf16, rpb_cell_mix_eval_dft_bf16 and rpb_cell_mix_eval_crop gained `int spectra_bf16` before `stream`;
+ *      round 5: rpb_dp_reduce_scatter_* / rpb_dp_allgather_* / rpb_adam_step_range added (additions only) */
+#define RPB_ABI_VERSION 2
 const char* rpb_last_error(void);
 int rpb_abi_version(void);
 

@@ -7,6 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2          # RPB_ABI_VERSION of include/rpb.h
 LIB_PATH = os.environ.get("RPB_LIB_PATH") or os.path.join(_HERE, "csrc", "librpb_hip.so")     # RPB_LIB_PATH: an instrumented build (tools/dbg)
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
@@ -190,6 +191,9 @@ def load():
         # instance (two runtimes in one process cannot share streams / device pointers).
         import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
+        lib.rpb_abi_version.restype = ctypes.c_int
+        if lib.rpb_abi_version() != ABI_VERSION:            # the signature table below is for ONE version of include/rpb.h
+            raise RpbError(f"{LIB_PATH} reports ABI version {lib.rpb_abi_version()}, this binding is for {ABI_VERSION}: rebuild the library")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -61,7 +61,7 @@ Rccl* rccl() {
     return (r.lib && r.get_uid && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
 }
 
-#define DP_MAX_TIMED 32
+#define DP_MAX_TIMED 96        /* a step of the cylinder FNO: 4 x 7 chunks of 16 MB + the small buckets; 7-8 inline reductions */
 struct DpHandle {
     nccl_comm_t comm;
     hipStream_t side;

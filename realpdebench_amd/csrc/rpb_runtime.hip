@@ -5,7 +5,7 @@
 thread_local char rpb_err_buf[512] = "";
 
 extern "C" const char* rpb_last_error() { return rpb_err_buf; }
-extern "C" int rpb_abi_version() { return 1; }
+extern "C" int rpb_abi_version() { return 2; }          // == RPB_ABI_VERSION of include/rpb.h (tests/test_abi.py compares them)
 
 static int g_line_claim_mode = -1;
 int rpb_line_claim_mode() {

@@ -126,8 +126,8 @@ class RcclComm:
     def step_times(self):
         """After ``torch.cuda.synchronize()``: the last step's bucket schedule and the inline (SyncBN) reduction costs."""
         def read(h):
-            out = (ctypes.c_float * 256)()
-            n = self._lib.load().rpb_dp_step_times(h, ctypes.addressof(out), 256)
+            out = (ctypes.c_float * 1024)()
+            n = self._lib.load().rpb_dp_step_times(h, ctypes.addressof(out), 1024)
             if n < 0:
                 raise self._lib.RpbError("rpb_dp_step_times failed")
             return list(out[:n])
@@ -204,6 +204,10 @@ class DataParallel:
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.buckets = layer_buckets(model._seg, model.n_layers, model.flat.numel())
+        # a bucket travels as all-reduces of at most chunk_elems elements (16 MB): with ONE communicator RCCL runs operations in issue
+        # order, so an inline SyncBN reduction on the compute stream queues behind whatever is in flight -- at most one chunk (~0.1 ms over
+        # xGMI) instead of a whole 100 MB bucket (>= 0.5 ms, more than the kernels between two reductions of a B = 4 strong-scaling step)
+        self.chunk_elems = max(1, int(float(os.environ.get("RPB_DP_CHUNK_MB", "16")) * (1 << 20) / 4))
         self._works = []
         self._next = 0
         self._held = {}
@@ -233,11 +237,16 @@ class DataParallel:
         self._live()
         self._works, self._next, self._held = [], 0, {}
 
+    def chunks(self, s, e):
+        """[s, e) cut into pieces of at most ``chunk_elems`` elements (the same cut on every rank)."""
+        return [(a, min(a + self.chunk_elems, e)) for a in range(s, e, self.chunk_elems)]
+
     def _reduce(self, grad, s, e):
-        if self.comm is not None and grad.is_cuda:
-            self.comm.enqueue(grad[s:e])               # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
-        else:
-            self._works.append(dist.all_reduce(grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for a, b in self.chunks(s, e):
+            if self.comm is not None and grad.is_cuda:
+                self.comm.enqueue(grad[a:b])           # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
+            else:
+                self._works.append(dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def bucket_ready(self, grad, hold_small_of=None):
         """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete.  ``hold_small_of`` = l: the

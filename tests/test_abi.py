@@ -20,7 +20,8 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in include/rpb.h but not exported by librpb_hip.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in realpdebench_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.rpb_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "rpb.h")).read()
+    assert lib.rpb_abi_version() == int(re.search(r"#define RPB_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -33,6 +33,7 @@ def _worker(rank, world, port, out):
     try:
         model = _make_model(seed=100 + rank)             # different init per rank on purpose
         model.bn_running_mean.fill_(float(rank + 1))
+        os.environ["RPB_DP_CHUNK_MB"] = "0.05"           # 13107-element chunks: every spectral bucket of this model travels in several pieces
         dp = DataParallel(model)
         res = {}
         # 1. rank 0's parameters and buffers were broadcast
@@ -48,6 +49,10 @@ def _worker(rank, world, port, out):
         expect = torch.full_like(g, 3.0)
         expect[::7] = 30.0
         res["allreduce"] = bool(torch.equal(g, expect))
+        big = max(e - s0 for s0, e in dp.buckets)
+        res["chunked"] = big > dp.chunk_elems and all(b - a <= dp.chunk_elems for s0, e in dp.buckets for a, b in dp.chunks(s0, e)) \
+            and [c for s0, e in dp.buckets for c in dp.chunks(s0, e)][0][0] == dp.buckets[0][0] \
+            and sum(b - a for s0, e in dp.buckets for a, b in dp.chunks(s0, e)) == g.numel()
         # 3. small synchronous reduction used for the BatchNorm statistics (fp64)
         s = torch.tensor([1.0 + rank, 2.0], dtype=torch.float64)
         dp.all_reduce_sum(s)
@@ -88,5 +93,6 @@ def test_dataparallel_world2_gloo():
     for r in (0, 1):
         assert res[r]["bcast"], "parameters / buffers were not broadcast from rank 0"
         assert res[r]["allreduce"], "bucketed all-reduce != sum over ranks"
+        assert res[r]["chunked"], "buckets were not cut into <= chunk_elems pieces covering the arena"
         assert res[r]["bn"]
     assert res[0]["shard"] == [0, 1, 2, 3] and res[1]["shard"] == [4, 5, 6, 7]
