@@ -36,6 +36,10 @@ def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    live = {os.path.basename(s_)[:-4] + ".o" for s_ in sources()}
+    for f in os.listdir(objdir):                       # objects whose source is gone must not ship to the GPU box
+        if f.endswith(".o") and f not in live:
+            os.remove(os.path.join(objdir, f))
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
