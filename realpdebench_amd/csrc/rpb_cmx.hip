@@ -109,6 +109,11 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       halves (the second read mostly out of L2 / MALL: the pair walks the same lines).  The register image of the x tile stays 32
 //       registers: K-steps 2, 3 of THIS tile are requested into the slots of K-steps 0, 1 as soon as those are split, the next tile's
 //       K-steps 0, 1 into the slots of 2, 3 (half a tile of prefetch distance instead of a whole one).
+// CMX_WG_PRIO: s_setprio 1 for one role of the weight-gradient wave pairs (1: the wgrad wave, the second-dispatched half of the
+// workgroup; 2: the mix wave; 0: none).  Measured (profiles/r05_kbench_valu_variants.txt) -- see DESIGN.md section 4.0000
+#ifndef CMX_WG_PRIO
+#define CMX_WG_PRIO 0
+#endif
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0>
 __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
     static_assert(!C2 || (!BF && !FEAT && !DFT && !WG && !SB), "C = 128: the plain fp32-storage launches");
@@ -217,6 +222,9 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     if constexpr (WG) {
         if (wave >= CMX_WG_PAIRS) {
             // ================= "wgrad" wave of pair p = wave - 4: walks the same tiles as mix wave p
+#if CMX_WG_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);               // static priority for the second-dispatched half of the workgroup (A/B: see CMX_WG_PRIO)
+#endif
             const int pair = wave - CMX_WG_PAIRS;
             const int G = __builtin_amdgcn_readfirstlane((int)((unsigned)a.ncell / (unsigned)Wp));
             const int TQ = (Wp + 31) >> 5;
@@ -305,6 +313,9 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             return;
         }
     }
+#if CMX_WG_PRIO == 2
+    if (WG) __builtin_amdgcn_s_setprio(1);
+#endif
     int wg_tiles = 0;                                // WG, mix wave: tiles handed to the pair's wgrad wave so far
     u32x4* MBw = MBs + (WG ? wave : 0) * 8 * 64 + lane;
     int* wg_fl = flags + 2 * (WG ? wave : 0);
