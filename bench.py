@@ -632,9 +632,54 @@ def strong_scaling_proxy(dev, ms32, steps=5):
             torch.cuda.empty_cache()
         m = res["ms_per_step"]
         res["speedup_ceiling"] = {"2_ranks": ms32 / m["16"], "4_ranks": ms32 / m["8"], "8_ranks": ms32 / m["4"]}
-        res["byte_model_ceiling_8_ranks"] = (6.238 * 32 + 4.03) / (6.238 * 4 + 4.03)
+        # ---- the 8-rank step's shape on ONE GPU (B = 4): the sharded optimizer step with pieces sized for 8 ranks (this rank updates 1/8 of
+        # the arena: rpb_adam_step_ranges), and every collective idling its stream for the modelled ring transfer over 8 ranks
+        # (rpb_dp_set_model: bus rate RPB_PROXY_GBPS, default 200 GB/s -- what RCCL reaches on 16 MB messages over 7 xGMI links is an
+        # ESTIMATE until a node measures it -- plus RPB_PROXY_LAT_US = 15 us per phase), so that exposed communication shows up as time
         tr.close()
         del tr, model
+        torch.cuda.empty_cache()
+        gbps, lat = float(os.environ.get("RPB_PROXY_GBPS", "200")), float(os.environ.get("RPB_PROXY_LAT_US", "15"))
+        x, y = torch.randn(4, *shape, device=dev), torch.randn(4, *shape, device=dev)
+        variants = {}
+        for name, shard, modelled in (("allreduce_modelled_comm", False, True), ("sharded_adam", True, False),
+                                      ("sharded_adam_modelled_comm", True, True)):
+            torch.manual_seed(0)
+            model = FNO3d(*modes, L, width, shape, shape).to(dev)
+            DataParallel(model, shard_optimizer=shard, shard_world=8 if shard else None)
+            model.dp.sync_stats_always = True
+            comm = getattr(model.dp, "comm", None)
+            if modelled and comm is not None:
+                comm.set_model(8, gbps, lat)
+            tr = Trainer(model, lr=1e-4, num_update=4000)
+            for _ in range(2):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(x, y)
+            torch.cuda.synchronize()
+            v = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps}
+            if comm is not None:
+                comm.set_timing(True)
+                tr.step(x, y)
+                torch.cuda.synchronize()
+                tms = comm.step_times()
+                v.update(exposed_comm_ms=tms["exposed_ms"], collectives=len(tms["buckets"]),
+                         modelled_comm_ms=sum(b["ms"] for b in tms["buckets"]), syncbn_inline_ms_max=max(tms["inline_ms"] or [0.0]))
+                comm.set_timing(False)
+            v["speedup_ceiling_8_ranks"] = ms32 / v["ms_per_step"]
+            variants[name] = v
+            tr.close()
+            del tr, model
+            torch.cuda.empty_cache()
+        res["B4_8rank_shape"] = {"model": {"ranks": 8, "bus_GBps": gbps, "latency_us_per_phase": lat,
+                                           "note": "ring reduce-scatter / all-gather: bytes * 7/8 / rate + latency per phase; an all-reduce is two phases"},
+                                 "variants": variants}
+        res["speedup_ceiling"]["8_ranks_sharded_adam"] = variants["sharded_adam"]["speedup_ceiling_8_ranks"]
+        res["speedup_ceiling"]["8_ranks_sharded_adam_modelled_comm"] = variants["sharded_adam_modelled_comm"]["speedup_ceiling_8_ranks"]
+        tr = model = None
+        res["byte_model_ceiling_8_ranks"] = (6.238 * 32 + 4.03) / (6.238 * 4 + 4.03)
     finally:
         if own_group:
             dist.destroy_process_group()

@@ -32,7 +32,8 @@ extern "C" {
  * header must refuse to run (signatures changed under unchanged symbol names between versions -- see INTEGRATION.md "ABI versions").
  *   1  rounds 1-3
  *   2  round 4: rpb_cell_mix_bf16, rpb_cell_mix_eval_dft_bf16 and rpb_cell_mix_eval_crop gained `int spectra_bf16` before `stream`;
- *      round 5: rpb_dp_reduce_scatter_* / rpb_dp_allgather_* / rpb_adam_step_range added (additions only) */
+ *      round 5: rpb_dp_reduce_scatter_enqueue / rpb_dp_allgather_enqueue / rpb_dp_mark / rpb_dp_wait_mark / rpb_dp_set_model /
+ *      rpb_adam_step_ranges added (additions only) */
 #define RPB_ABI_VERSION 2
 const char* rpb_last_error(void);
 int rpb_abi_version(void);
@@ -172,6 +173,10 @@ int rpb_mse(const float* pred, const float* target, float* elem, float* gout, fl
 /* K8  Adam (torch.optim.Adam defaults, train.py:290,333; complex weights as 2 x fp32). */
 int rpb_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   long step, float gscale, void* stream);
+/*     the same update on a list of ranges of the arena: tab [nr][2] (device, int64) = (first element, float4 groups before the range),
+ *     starts and counts multiples of 4, total = elements over all ranges (the sharded optimizer step of the data-parallel path) */
+int rpb_adam_step_ranges(float* p, const float* g, float* m, float* v, const long* tab, int nr, long total, float lr, float beta1,
+                         float beta2, float eps, long step, float gscale, void* stream);
 
 /* K9  rollout step glue.  realpdebench/eval.py:316-318 + data/data_normalizer.py:50-62. */
 int rpb_rollout_affine(const float* pred, const float* para, float* out, long ncell, int Cp, int Cx,
@@ -510,6 +515,18 @@ int rpb_dp_allreduce_init(const void* id128, int rank, int world, void** handle)
 int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream);
 int rpb_dp_allreduce_wait(void* handle, void* consumer_stream);
 int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int dtype, void* stream);
+/*      Sharded optimizer step: rpb_dp_reduce_scatter_enqueue sums the gradient chunk buf[count] over the ranks IN PLACE so that rank r
+ *      holds the sum of its piece [r * count / world, (r + 1) * count / world) (count a multiple of world; side stream, ordered after
+ *      producer_stream like rpb_dp_allreduce_enqueue); rpb_adam_step_ranges updates the owned pieces; rpb_dp_allgather_enqueue hands every
+ *      rank's piece of the parameter chunk to all ranks, in place.  rpb_dp_mark(h, idx) records event idx (0 .. 15) on the side stream,
+ *      rpb_dp_wait_mark(h, idx, stream) makes a stream wait for it (the next forward waits per layer for its weights).
+ *      rpb_dp_set_model(h, world, gbps, lat_us): one-GPU proxy -- every collective of the handle idles its stream for the modelled ring
+ *      transfer over `world` ranks (0 = off). */
+int rpb_dp_reduce_scatter_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream);
+int rpb_dp_allgather_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream);
+int rpb_dp_mark(void* handle, int idx);
+int rpb_dp_wait_mark(void* handle, int idx, void* stream);
+int rpb_dp_set_model(void* handle, int model_world, float gbps, float lat_us);
 int rpb_dp_allreduce_destroy(void* handle);
 int rpb_dp_allreduce_abort(void* handle);   /* process exit: ncclCommAbort, never blocks on a collective whose peer is gone */
 /*      Instrumentation (the N > 1 bench line): rpb_dp_set_timing(h, 1) brackets every bucket / inline reduction with timing events and

@@ -72,6 +72,11 @@ SIGNATURES = {
     "rpb_dp_allreduce_inline": (_I, "pplip"),
     "rpb_dp_allreduce_destroy": (_I, "p"),
     "rpb_dp_allreduce_abort": (_I, "p"),
+    "rpb_dp_reduce_scatter_enqueue": (_I, "pplip"),
+    "rpb_dp_allgather_enqueue": (_I, "pplip"),
+    "rpb_dp_mark": (_I, "pi"),
+    "rpb_dp_wait_mark": (_I, "pip"),
+    "rpb_dp_set_model": (_I, "piff"),
     "rpb_dp_set_timing": (_I, "pi"),
     "rpb_dp_step_times": (_I, "ppi"),
     "rpb_lift_bwd_rows": (_I, ""),
@@ -108,6 +113,7 @@ SIGNATURES = {
     "rpb_mse_rows": (_I, ""),
     "rpb_mse": (_I, "ppppp" + "l" + "f" + "p"),
     "rpb_adam_step": (_I, "pppp" + "l" + "ffff" + "l" + "f" + "p"),
+    "rpb_adam_step_ranges": (_I, "pppp" + "pil" + "ffff" + "l" + "f" + "p"),
     "rpb_rollout_affine": (_I, "ppp" + "l" + "ii" + "pppp" + "p"),
     "rpb_channel_affine": (_I, "pp" + "l" + "i" + "pp" + "i" + "p"),
     "rpb_gemm_nt": (_I, "pppppp" + "l" + "iiiii" + "ppp" + "iiiii" + "lf" + "p"),

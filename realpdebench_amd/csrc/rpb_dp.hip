@@ -26,6 +26,8 @@ typedef int (*fn_get_uid)(nccl_uid_t*);
 typedef int (*fn_init_rank)(nccl_comm_t*, int, nccl_uid_t, int);
 typedef int (*fn_destroy)(nccl_comm_t);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_reducescatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
 typedef const char* (*fn_errstr)(int);
 
 struct Rccl {
@@ -35,6 +37,8 @@ struct Rccl {
     fn_destroy destroy = nullptr;
     fn_destroy abort = nullptr;
     fn_allreduce allreduce = nullptr;
+    fn_reducescatter reducescatter = nullptr;
+    fn_allgather allgather = nullptr;
     fn_errstr errstr = nullptr;
 };
 
@@ -55,12 +59,15 @@ Rccl* rccl() {
             r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
             r.abort = (fn_destroy)dlsym(r.lib, "ncclCommAbort");
             r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
+            r.reducescatter = (fn_reducescatter)dlsym(r.lib, "ncclReduceScatter");
+            r.allgather = (fn_allgather)dlsym(r.lib, "ncclAllGather");
             r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
         }
     }
     return (r.lib && r.get_uid && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
 }
 
+#define DP_MAX_MARKS 16
 #define DP_MAX_TIMED 96        /* a step of the cylinder FNO: 4 x 7 chunks of 16 MB + the small buckets; 7-8 inline reductions */
 struct DpHandle {
     nccl_comm_t comm;
@@ -75,6 +82,12 @@ struct DpHandle {
     hipEvent_t b0[DP_MAX_TIMED], b1[DP_MAX_TIMED], i0[DP_MAX_TIMED], i1[DP_MAX_TIMED], cwait, first;
     long bbytes[DP_MAX_TIMED];
     int have_wait;
+    hipEvent_t marks[DP_MAX_MARKS];                      // rpb_dp_mark / rpb_dp_wait_mark: points of the side stream other streams can wait for
+    int marks_made;
+    // modelled transfers (one-GPU proxy of an N-rank run, rpb_dp_set_model): after every collective the side stream idles for the time
+    // the operation would take over the interconnect of `model_world` ranks at `model_gbps` per direction and rank
+    int model_world;
+    float model_gbps, model_lat_us;
 };
 
 const int kNcclSum = 0, kNcclF32 = 7, kNcclF64 = 8;
@@ -90,6 +103,19 @@ const int kNcclSum = 0, kNcclF32 = 7, kNcclF64 = 8;
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) RPB_FAIL(RPB_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_));     \
     } while (0)
+
+// the side stream idles for `us` microseconds (s_memrealtime: the constant 100 MHz counter) -- the modelled duration of a transfer
+__global__ void dp_delay_kernel(long ticks) {
+    const unsigned long long s0 = wall_clock64();
+    while ((long)(wall_clock64() - s0) < ticks) __builtin_amdgcn_s_sleep(32);
+}
+// modelled time of a ring reduce-scatter or all-gather of `bytes` (the whole buffer) over `world` ranks: (world - 1) / world of it crosses
+// each link at `gbps`; an all-reduce is the two in sequence
+static void dp_model_delay(DpHandle* h, double bytes, int phases, hipStream_t st) {
+    if (h->model_world <= 1 || h->model_gbps <= 0.f) return;
+    const double us = phases * (bytes * (h->model_world - 1) / h->model_world / (h->model_gbps * 1e3) + h->model_lat_us);
+    hipLaunchKernelGGL(dp_delay_kernel, dim3(1), dim3(1), 0, st, (long)(us * 100.0));
+}
 
 extern "C" int rpb_dp_available(void) { return rccl() != nullptr; }
 
@@ -113,6 +139,9 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
     h->enqueued = 0;
     h->timing = h->events_made = 0;
     h->nb = h->ni = h->have_wait = 0;
+    h->marks_made = 0;
+    h->model_world = 0;
+    h->model_gbps = h->model_lat_us = 0.f;
     nccl_uid_t id;
     memcpy(&id, id128, sizeof(id));
     int rc = R->init_rank(&h->comm, world, id, rank);
@@ -145,6 +174,7 @@ extern "C" int rpb_dp_allreduce_enqueue(void* handle, void* buf, long count, int
         RPB_HIP(hipEventRecord(h->b0[h->nb], h->side), "dp record");
     }
     RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, h->side), "ncclAllReduce");
+    dp_model_delay(h, (double)count * (dtype == 0 ? 4 : 8), 2, h->side);
     if (timed) {
         RPB_HIP(hipEventRecord(h->b1[h->nb], h->side), "dp record");
         h->bbytes[h->nb] = count * (dtype == 0 ? 4 : 8);
@@ -173,10 +203,85 @@ extern "C" int rpb_dp_allreduce_inline(void* handle, void* buf, long count, int 
     const bool timed = h->timing && h->ni < DP_MAX_TIMED;
     if (timed) RPB_HIP(hipEventRecord(h->i0[h->ni], (hipStream_t)stream), "dp record");
     RPB_NCCL(R->allreduce(buf, buf, (size_t)count, dp_dtype(dtype), kNcclSum, h->comm, (hipStream_t)stream), "ncclAllReduce");
+    dp_model_delay(h, (double)count * (dtype == 0 ? 4 : 8), 2, (hipStream_t)stream);
     if (timed) {
         RPB_HIP(hipEventRecord(h->i1[h->ni], (hipStream_t)stream), "dp record");
         h->ni++;
     }
+    return RPB_OK;
+}
+
+// Sharded optimizer step (ZeRO-1 shape): the gradient chunk `buf` [count] is reduce-scattered IN PLACE -- rank r ends up with the sum
+// of its piece buf[r * count / world, (r + 1) * count / world) -- on the side stream, after everything enqueued on producer_stream so far.
+// count must be a multiple of world.  The matching rpb_dp_allgather_enqueue sends every rank's piece of the PARAMETER chunk to all ranks,
+// in place.  Same bytes on the wire as the all-reduce of the chunk; Adam runs on 1 / world of the arena in between.
+static int dp_side_op(void* handle, void* buf, long count, int dtype, void* producer_stream, int op) {
+    RPB_REQUIRE(handle && buf && count > 0 && dp_dtype(dtype) >= 0, "dp_%s_enqueue: bad arguments", op ? "allgather" : "reduce_scatter");
+    Rccl* R = rccl();
+    DpHandle* h = (DpHandle*)handle;
+    RPB_REQUIRE(R && R->reducescatter && R->allgather, "dp: this librccl.so has no ncclReduceScatter / ncclAllGather");
+    RPB_REQUIRE(count % h->world == 0, "dp_%s_enqueue: count %ld is not a multiple of the %d ranks", op ? "allgather" : "reduce_scatter", count, h->world);
+    if (h->timing && h->have_wait && op == 0) {          // first chunk of a new step: forget the previous step's records
+        h->nb = h->ni = 0;
+        h->have_wait = 0;
+    }
+    RPB_HIP(hipEventRecord(h->ready, (hipStream_t)producer_stream), "dp record");
+    RPB_HIP(hipStreamWaitEvent(h->side, h->ready, 0), "dp wait");
+    const bool timed = h->timing && h->nb < DP_MAX_TIMED;
+    if (timed) {
+        if (h->nb == 0) RPB_HIP(hipEventRecord(h->first, (hipStream_t)producer_stream), "dp record");
+        RPB_HIP(hipEventRecord(h->b0[h->nb], h->side), "dp record");
+    }
+    const long piece = count / h->world;
+    const size_t esz = dtype == 0 ? 4 : 8;
+    char* mine = (char*)buf + (size_t)h->rank * piece * esz;
+    if (op == 0) RPB_NCCL(R->reducescatter(buf, mine, (size_t)piece, dp_dtype(dtype), kNcclSum, h->comm, h->side), "ncclReduceScatter");
+    else RPB_NCCL(R->allgather(mine, buf, (size_t)piece, dp_dtype(dtype), h->comm, h->side), "ncclAllGather");
+    dp_model_delay(h, (double)count * esz, 1, h->side);
+    if (timed) {
+        RPB_HIP(hipEventRecord(h->b1[h->nb], h->side), "dp record");
+        h->bbytes[h->nb] = count * (long)esz;
+        h->nb++;
+    }
+    h->enqueued++;
+    return RPB_OK;
+}
+extern "C" int rpb_dp_reduce_scatter_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream) {
+    return dp_side_op(handle, buf, count, dtype, producer_stream, 0);
+}
+extern "C" int rpb_dp_allgather_enqueue(void* handle, void* buf, long count, int dtype, void* producer_stream) {
+    return dp_side_op(handle, buf, count, dtype, producer_stream, 1);
+}
+
+// rpb_dp_mark(h, idx): event idx (0 .. 15) is recorded on the side stream behind everything enqueued so far;
+// rpb_dp_wait_mark(h, idx, stream): `stream` waits for it -- the next forward pass waits per layer for the all-gather of that layer's weights
+extern "C" int rpb_dp_mark(void* handle, int idx) {
+    RPB_REQUIRE(handle && idx >= 0 && idx < DP_MAX_MARKS, "dp_mark: bad arguments");
+    DpHandle* h = (DpHandle*)handle;
+    if (!h->marks_made) {
+        for (int i = 0; i < DP_MAX_MARKS; ++i) RPB_HIP(hipEventCreateWithFlags(&h->marks[i], hipEventDisableTiming), "dp event");
+        h->marks_made = 1;
+    }
+    RPB_HIP(hipEventRecord(h->marks[idx], h->side), "dp record");
+    return RPB_OK;
+}
+extern "C" int rpb_dp_wait_mark(void* handle, int idx, void* stream) {
+    RPB_REQUIRE(handle && idx >= 0 && idx < DP_MAX_MARKS, "dp_wait_mark: bad arguments");
+    DpHandle* h = (DpHandle*)handle;
+    if (!h->marks_made) return RPB_OK;                   // nothing was ever marked
+    RPB_HIP(hipStreamWaitEvent((hipStream_t)stream, h->marks[idx], 0), "dp wait");
+    return RPB_OK;
+}
+
+// One-GPU proxy of an N-rank run: model_world > 1 makes every collective of this handle idle its stream for the modelled transfer time
+// (ring schedule, gbps per direction and rank, lat_us per phase); 0 turns the model off.  The collectives themselves still run
+// (no-ops on a one-rank communicator).
+extern "C" int rpb_dp_set_model(void* handle, int model_world, float gbps, float lat_us) {
+    RPB_REQUIRE(handle && model_world >= 0 && gbps >= 0.f && lat_us >= 0.f, "dp_set_model: bad arguments");
+    DpHandle* h = (DpHandle*)handle;
+    h->model_world = model_world;
+    h->model_gbps = gbps;
+    h->model_lat_us = lat_us;
     return RPB_OK;
 }
 
@@ -245,6 +350,8 @@ static int dp_teardown(void* handle, bool abort) {
     }
     (void)hipEventDestroy(h->ready);
     (void)hipEventDestroy(h->done);
+    if (h->marks_made)
+        for (int i = 0; i < DP_MAX_MARKS; ++i) (void)hipEventDestroy(h->marks[i]);
     if (h->events_made) {
         for (int i = 0; i < DP_MAX_TIMED; ++i) {
             (void)hipEventDestroy(h->b0[i]);

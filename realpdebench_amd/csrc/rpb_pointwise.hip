@@ -635,6 +635,19 @@ extern "C" int rpb_mse(const float* pred, const float* tgt, float* elem, float* 
 // ---------------------------------------------------------------------------------- K8 Adam
 // torch.optim.Adam defaults (train.py:290): complex parameters are updated as 2x fp32 (view_as_real).
 // lr / bias corrections are host scalars computed from the step count (no device sync, no .item()).
+// one element's update, shared by both kernels and compiled without FMA contraction: the plain and the ranged launch must agree bit
+// for bit (the sharded optimizer step of the data-parallel path is tested against the plain one), and the separate roundings are
+// torch.optim.Adam's own (it runs the update as a chain of element-wise kernels)
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float gscale, float b1, float b2, float eps,
+                                            float step_size, float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+    const float gk = g * gscale;
+    m = b1 * m + (1.f - b1) * gk;
+    v = b2 * v + (1.f - b2) * gk * gk;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p -= step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(PW_THREADS) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, long n,
                                                           float gscale, float b1, float b2, float eps, float step_size,
@@ -647,11 +660,9 @@ __global__ __launch_bounds__(PW_THREADS) void adam_kernel(float* __restrict__ p,
         f32x4 vv = reinterpret_cast<f32x4*>(v)[idx];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = gv[k] * gscale;
-            mv[k] = b1 * mv[k] + (1.f - b1) * gk;
-            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
-            const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
-            pv[k] -= step_size * (mv[k] / denom);
+            float pk = pv[k], mk = mv[k], vk = vv[k];
+            adam_update(pk, gv[k], mk, vk, gscale, b1, b2, eps, step_size, inv_sqrt_bc2);
+            pv[k] = pk, mv[k] = mk, vv[k] = vk;
         }
         reinterpret_cast<f32x4*>(p)[idx] = pv;
         reinterpret_cast<f32x4*>(m)[idx] = mv;
@@ -659,12 +670,11 @@ __global__ __launch_bounds__(PW_THREADS) void adam_kernel(float* __restrict__ p,
     }
     // tail
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gk = g[i] * gscale;
-        const float mk = b1 * m[i] + (1.f - b1) * gk;
-        const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        float pk = p[i], mk = m[i], vk = v[i];
+        adam_update(pk, g[i], mk, vk, gscale, b1, b2, eps, step_size, inv_sqrt_bc2);
         m[i] = mk;
         v[i] = vk;
-        p[i] -= step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+        p[i] = pk;
     }
 }
 
@@ -678,6 +688,49 @@ extern "C" int rpb_adam_step(float* p, const float* g, float* m, float* v, long 
     hipLaunchKernelGGL(adam_kernel, dim3(pw_grid((n + 3) / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, p, g, m, v, n,
                        gscale, beta1, beta2, eps, step_size, isb2);
     RPB_CHECK_LAUNCH("adam_step");
+}
+
+// The same update on a LIST of ranges of the arena (the sharded optimizer step of the data-parallel path: a rank updates the pieces of
+// the parameter arena it owns).  tab [nr][2] (device, int64) = (first element, float4 groups before this range); starts and counts are
+// multiples of 4; total4 = float4 groups over all ranges.
+__global__ __launch_bounds__(PW_THREADS) void adam_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                                 float* __restrict__ v, const long* __restrict__ tab, int nr, long total4,
+                                                                 float gscale, float b1, float b2, float eps, float step_size,
+                                                                 float inv_sqrt_bc2) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nr - 1;                         // last range whose prefix <= idx
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[2 * mid + 1] <= idx) lo = mid;
+            else hi = mid - 1;
+        }
+        const long e4 = (tab[2 * lo] >> 2) + (idx - tab[2 * lo + 1]);
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[e4];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[e4];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[e4];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[e4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = pv[k], mk = mv[k], vk = vv[k];
+            adam_update(pk, gv[k], mk, vk, gscale, b1, b2, eps, step_size, inv_sqrt_bc2);
+            pv[k] = pk, mv[k] = mk, vv[k] = vk;
+        }
+        reinterpret_cast<f32x4*>(p)[e4] = pv;
+        reinterpret_cast<f32x4*>(m)[e4] = mv;
+        reinterpret_cast<f32x4*>(v)[e4] = vv;
+    }
+}
+
+extern "C" int rpb_adam_step_ranges(float* p, const float* g, float* m, float* v, const long* tab, int nr, long total, float lr,
+                                    float beta1, float beta2, float eps, long step, float gscale, void* stream) {
+    RPB_REQUIRE(p && g && m && v && tab && nr > 0 && total > 0 && total % 4 == 0 && step >= 1, "adam_step_ranges: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float isb2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3(pw_grid(total / 4)), dim3(PW_THREADS), 0, (hipStream_t)stream, p, g, m, v, tab, nr,
+                       total / 4, gscale, beta1, beta2, eps, step_size, isb2);
+    RPB_CHECK_LAUNCH("adam_step_ranges");
 }
 
 // ---------------------------------------------------------------------------------- K9 rollout affine

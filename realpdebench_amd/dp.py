@@ -100,6 +100,33 @@ class RcclComm:
         self._live()
         self._lib.call("rpb_dp_allreduce_wait", self.handle, torch.cuda.current_stream().cuda_stream)
 
+    def reduce_scatter(self, t):
+        """Sum ``t`` over the ranks in place on the side stream; rank r keeps the sum of piece r (``t.numel()`` a multiple of the world size)."""
+        self._live()
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.call("rpb_dp_reduce_scatter_enqueue", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
+                       torch.cuda.current_stream().cuda_stream)
+
+    def all_gather(self, t):
+        """Every rank's piece of ``t`` reaches all ranks, in place, on the side stream (after the work queued on the current stream)."""
+        self._live()
+        assert t.is_cuda and t.is_contiguous()
+        self._lib.call("rpb_dp_allgather_enqueue", self.handle, t.data_ptr(), t.numel(), self._dtype(t),
+                       torch.cuda.current_stream().cuda_stream)
+
+    def mark(self, idx):
+        self._live()
+        self._lib.call("rpb_dp_mark", self.handle, int(idx))
+
+    def wait_mark(self, idx):
+        self._live()
+        self._lib.call("rpb_dp_wait_mark", self.handle, int(idx), torch.cuda.current_stream().cuda_stream)
+
+    def set_model(self, world, gbps, lat_us=0.0):
+        """One-GPU proxy of an N-rank run: every collective idles its stream for the modelled ring transfer (0 ranks = off)."""
+        for h in {self.handle, self.small}:
+            self._lib.call("rpb_dp_set_model", h, int(world), float(gbps), float(lat_us))
+
     def inline(self, t):
         self._live()
         assert t.is_cuda and t.is_contiguous()
@@ -196,7 +223,15 @@ class StatsSync:
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None):
+    """``shard_optimizer`` (or RPB_DP_SHARD_ADAM=1): the optimizer step is sharded over the ranks (ZeRO-1 shape).  Every chunk of a layer's
+    spectral gradient whose length divides by 4 * world is REDUCE-SCATTERED instead of all-reduced (rank r owns piece r), Adam runs on the
+    owned pieces only (1 / world of the arena: every rank otherwise repeats the same 2.8 GB update, 0.5 ms that no batch size shrinks),
+    and the parameter pieces are ALL-GATHERED on the side stream in the order the next forward pass needs them; that pass waits per
+    layer (``params_ready``).  The same bytes cross the links as with the all-reduce; the small pieces keep the all-reduce and are
+    updated by every rank.  ``shard_world`` > world_size is the one-GPU proxy of bench.py: pieces are sized for that many ranks (the
+    rank updates 1 / shard_world of the arena; the step is then no longer a valid training step)."""
+
+    def __init__(self, model, process_group=None, shard_optimizer=None, shard_world=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before DataParallel (one process per GPU)")
         self.model = model
@@ -207,7 +242,11 @@ class DataParallel:
         # a bucket travels as all-reduces of at most chunk_elems elements (16 MB): with ONE communicator RCCL runs operations in issue
         # order, so an inline SyncBN reduction on the compute stream queues behind whatever is in flight -- at most one chunk (~0.1 ms over
         # xGMI) instead of a whole 100 MB bucket (>= 0.5 ms, more than the kernels between two reductions of a B = 4 strong-scaling step)
-        self.chunk_elems = max(1, int(float(os.environ.get("RPB_DP_CHUNK_MB", "16")) * (1 << 20) / 4))
+        self.chunk_elems = max(256, int(float(os.environ.get("RPB_DP_CHUNK_MB", "16")) * (1 << 20) / 4) // 256 * 256)   # (1 KB granules)
+        self.shard_opt = bool(shard_optimizer) if shard_optimizer is not None else os.environ.get("RPB_DP_SHARD_ADAM") == "1"
+        self.shard_world = int(shard_world or self.world_size)
+        self._plan = None
+        self._pending = False         # sharded step: parameter all-gathers are in flight on the side stream
         self._works = []
         self._next = 0
         self._held = {}
@@ -241,26 +280,106 @@ class DataParallel:
         """[s, e) cut into pieces of at most ``chunk_elems`` elements (the same cut on every rank)."""
         return [(a, min(a + self.chunk_elems, e)) for a in range(s, e, self.chunk_elems)]
 
-    def _reduce(self, grad, s, e):
+    # ---- sharded optimizer step
+    def parts(self, bi):
+        """The pieces bucket ``bi`` travels in: a layer bucket is its 100 MB spectral range (``big``) and the 17 KB tail from
+        ``convs.l.weight`` on (final ~3 ms later in the backward pass, see ``bucket_ready``); the head and tail buckets are one piece."""
+        s, e = self.buckets[bi]
+        L = self.model.n_layers
+        if 1 <= bi <= L:
+            cut = self.model._seg[f"convs.{L - bi}.weight"][0]
+            if s < cut < e:
+                return [(s, cut, True), (cut, e, False)]
+        return [(s, e, False)]
+
+    def _sharded(self, a, b, big):
+        return self.shard_opt and big and (b - a) % (4 * self.shard_world) == 0
+
+    def shard_plan(self):
+        """(pieces, chunks): ``chunks[bi]`` = [(a, b, sharded)] for bucket ``bi``; ``pieces`` = the (start, count) ranges this rank
+        updates, in arena order: its piece of every sharded chunk and the whole of every other chunk (identical on all ranks there)."""
+        if self._plan is None:
+            W, r = self.shard_world, self.rank % self.shard_world
+            chunks, pieces = [], []
+            for bi in range(len(self.buckets)):
+                row = []
+                for s0, e0, big in self.parts(bi):
+                    for a, b in self.chunks(s0, e0):
+                        sh = self._sharded(a, b, big)
+                        row.append((a, b, sh))
+                        n = (b - a) // W if sh else b - a
+                        pieces.append((a + r * n if sh else a, n))
+                chunks.append(row)
+            pieces.sort()
+            self._plan = (pieces, chunks)
+        return self._plan
+
+    def owned_table(self, device):
+        """Device table for rpb_adam_step_ranges: [nr][2] int64 (first element, float4 groups before the range), and the element total."""
+        pieces, _ = self.shard_plan()
+        rows, pre = [], 0
+        for a, n in pieces:
+            assert a % 4 == 0 and n % 4 == 0, "arena segments are 256 B aligned and sharded chunks divide by 4 * world"
+            rows.append((a, pre))
+            pre += n // 4
+        return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), 4 * pre
+
+    def gather_params(self, flat):
+        """After Adam on the owned pieces: all-gather the sharded chunks of the parameter arena in FORWARD order (fc0 head, layers 0 ..
+        L-1, tail) on the side stream, one mark per bucket; the next forward waits per bucket (``params_ready``)."""
+        _, chunks = self.shard_plan()
+        on_side = self.comm is not None and flat.is_cuda
+        for bi in reversed(range(len(self.buckets))):
+            for a, b, sh in chunks[bi]:
+                if not sh:
+                    continue
+                if on_side:
+                    self.comm.all_gather(flat[a:b])       # (a one-rank proxy group: a no-op plus the modelled transfer)
+                else:
+                    assert self.shard_world == self.world_size
+                    n = (b - a) // self.world_size
+                    dist.all_gather_into_tensor(flat[a:b], flat[a + self.rank * n:a + (self.rank + 1) * n].clone(), group=self.group)
+            if on_side:
+                self.comm.mark(bi)
+        self._pending = on_side
+
+    def params_ready(self, bucket):
+        """The compute stream waits for the all-gather of bucket ``bucket`` (index into ``self.buckets``: 0 = tail, ``layer_bucket(l)``,
+        L + 1 = the fc0 head).  No-op unless a sharded step left gathers in flight."""
+        if self._pending:
+            self.comm.wait_mark(bucket)
+
+    def params_ready_all(self):
+        """Everything that reads the parameters outside a training forward (eval, checkpoints, tests) calls this first."""
+        if self._pending:
+            self.comm.wait()
+            self._pending = False
+
+    def layer_bucket(self, l):
+        return 1 + (self.model.n_layers - 1 - l)
+
+    def _reduce(self, grad, s, e, big=False):
         for a, b in self.chunks(s, e):
             if self.comm is not None and grad.is_cuda:
-                self.comm.enqueue(grad[a:b])           # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
-            else:
+                if self._sharded(a, b, big):
+                    self.comm.reduce_scatter(grad[a:b])    # rank r keeps the sum of piece r; same side stream, same ordering
+                else:
+                    self.comm.enqueue(grad[a:b])           # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward
+            else:                                          # gloo (CPU tests) has no reduce-scatter: the all-reduce leaves the owner's piece equal
                 self._works.append(dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def bucket_ready(self, grad, hold_small_of=None):
         """Called by the backward pass each time the next bucket (in ``self.buckets`` order) is complete.  ``hold_small_of`` = l: the
         bucket's tail from ``convs.l.weight`` on (the layer's Conv3d / BatchNorm gradients, 17 KB) is NOT final yet -- round 4 forms
         d convs.l.weight in the layer's data-gradient cell_mix, ~3 ms of kernels after the 100 MB spectral gradient -- and goes out
-        with ``small_ready(grad, l)``; the spectral part starts its all-reduce now, as before."""
-        s, e = self.buckets[self._next]
+        with ``small_ready(grad, l)``; the spectral part starts its reduction now, as before."""
+        bi = self._next
         self._next += 1
-        if hold_small_of is not None:
-            cut = self.model._seg[f"convs.{hold_small_of}.weight"][0]
-            if s < cut < e:
-                self._held[hold_small_of] = (cut, e)
-                e = cut
-        self._reduce(grad, s, e)
+        for s, e, big in self.parts(bi):
+            if hold_small_of is not None and not big and 1 <= bi <= self.model.n_layers:
+                self._held[hold_small_of] = (s, e)
+            else:
+                self._reduce(grad, s, e, big)
 
     def small_ready(self, grad, l):
         """The held tail of layer ``l``'s bucket is complete: its own (tiny) all-reduce."""

@@ -451,6 +451,15 @@ class FNO3d(Model):
         P = self.pview
         if training:
             ws.generation += 1
+        # a sharded optimizer step (dp.DataParallel.gather_params) leaves the parameter all-gathers in flight on the side stream: the
+        # training forward waits per bucket, right before the first kernel that reads the bucket's weights; everything else waits for all
+        dpw = self.dp if (self.dp is not None and getattr(self.dp, "_pending", False)) else None
+        if dpw is not None and not training:
+            dpw.params_ready_all()
+            dpw = None
+        if dpw is not None:
+            dpw.params_ready(L + 1)                  # fc0
+            dpw.params_ready(dpw.layer_bucket(0))    # (the layer-0 composite weight of the lift is formed from convs.0 as well)
         self._lift_fwd(x, ws)
         world = self.dp.world_size if (self.dp is not None and training) else 1
         a_in, xf = ws.A0, None                   # layer input tensor and its lazy transform
@@ -458,6 +467,8 @@ class FNO3d(Model):
         for l in range(L):
             s = ws.S[l] if training else ws.S[l % 2]
             xh = ws.Xh[l] if training else ws.Xh[0]
+            if dpw is not None:
+                dpw.params_ready(dpw.layer_bucket(l))
             if l == 0 and ws.feat0:
                 self._feature_spectrum(x, ws, plan)
                 ops.feat_mix(ws.PhiH, P("fc0.weight"), P("fc0.bias"), xh, d.B, 2 * plan.M, ws.NB, self.dim_in, C)
@@ -507,6 +518,9 @@ class FNO3d(Model):
                     ops.cell_mix(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, None, d.ncell, C, C,
                                  2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 a_in, xf = s, None
+        if dpw is not None:
+            dpw.params_ready(0)                      # fc1 / fc2 (read by the head, in this pass or fused into the backward launch)
+            self.dp._pending = False                 # every bucket has been waited for on this stream
         if skip_head:
             return None
         if not training and ws.bf16:

@@ -375,6 +375,12 @@ def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, gscale=1.0):
               label="adam_step", nbytes=28 * n, flops=12 * n)
 
 
+def adam_step_ranges(p, g, m, v, tab, nr, total, lr, beta1, beta2, eps, step, gscale=1.0):
+    """Adam on the ranges listed in ``tab`` (device int64 [nr][2]: first element, float4 groups before the range): the sharded optimizer step."""
+    _lib.call("rpb_adam_step_ranges", _p(p), _p(g), _p(m), _p(v), _p(tab, torch.int64), nr, total, lr, beta1, beta2, eps, step, gscale, _stream(),
+              label="adam_step", nbytes=28 * total, flops=12 * total)
+
+
 def rollout_affine(pred, para, out, ncell, Cp, Cx, mean_t, std_t, mean_i, std_i):
     _lib.call("rpb_rollout_affine", _p(pred), _p(para), _p(out), ncell, Cp, Cx, _p(mean_t), _p(std_t), _p(mean_i),
               _p(std_i), _stream())

@@ -29,6 +29,10 @@ class Trainer:
         self.grad = torch.zeros_like(flat.data)
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
+        self._owned = None           # sharded optimizer step: the device table of the ranges this rank updates
+        if model.dp is not None and getattr(model.dp, "shard_opt", False) and self.clip > 0:
+            raise ValueError("the sharded optimizer step has no gradient-norm clipping (the norm needs the whole reduced gradient): "
+                             "use DataParallel(model, shard_optimizer=False) with clip_grad_norm")
 
     # ---- learning-rate schedule (closed forms of CosineAnnealingLR(T_max=num_update) / StepLR(gamma=0.5))
     def current_lr(self):
@@ -74,8 +78,19 @@ class Trainer:
             gscale = min(1.0, self.clip / (norm + 1e-6))
         lr = self.current_lr()
         self.iteration += 1
-        ops.adam_step(model.flat.data, self.grad, self.exp_avg, self.exp_avg_sq, model.flat.numel(), lr,
-                      self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
+        if dp is not None and getattr(dp, "shard_opt", False) and self.clip == 0:
+            # sharded optimizer step (dp.DataParallel): the gradient chunks were reduce-scattered, this rank updates the pieces it owns
+            # (1 / world of the arena in ONE launch over the range table) and the parameter pieces travel back on the side stream while
+            # the next forward pass starts (it waits per layer: model._forward_impl -> dp.params_ready)
+            if self._owned is None:
+                self._owned = dp.owned_table(model.flat.device)
+            tab, nr, total = self._owned
+            ops.adam_step_ranges(model.flat.data, self.grad, self.exp_avg, self.exp_avg_sq, tab, nr, total, lr,
+                                 self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
+            dp.gather_params(model.flat.data)
+        else:
+            ops.adam_step(model.flat.data, self.grad, self.exp_avg, self.exp_avg_sq, model.flat.numel(), lr,
+                          self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
         return ws.loss
 
     def close(self):
@@ -85,6 +100,8 @@ class Trainer:
 
     # ---- checkpoint in the reference's format (train.py:410-418)
     def checkpoint(self, extra=None):
+        if self.model.dp is not None and hasattr(self.model.dp, "params_ready_all"):
+            self.model.dp.params_ready_all()                 # a sharded step may still be gathering parameter pieces on the side stream
         ck = {"model_state_dict": self.model.state_dict(), "iteration": self.iteration}
         if extra:
             ck.update(extra)

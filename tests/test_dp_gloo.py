@@ -96,3 +96,59 @@ def test_dataparallel_world2_gloo():
         assert res[r]["chunked"], "buckets were not cut into <= chunk_elems pieces covering the arena"
         assert res[r]["bn"]
     assert res[0]["shard"] == [0, 1, 2, 3] and res[1]["shard"] == [4, 5, 6, 7]
+
+
+def _shard_worker(rank, world, port, out):
+    """The sharded optimizer step's data movement on CPU tensors: reduce-scatter (gloo: all-reduce) of the spectral chunks, an update of
+    the OWNED pieces only, all-gather of the parameter pieces == all-reduce + update of the whole arena, bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        os.environ["RPB_DP_CHUNK_MB"] = "0.05"
+        res = {}
+        model = _make_model(seed=7)
+        dp = DataParallel(model, shard_optimizer=True)
+        torch.manual_seed(1000 + rank)
+        g = torch.randn_like(model.flat.data)
+        # reference: plain all-reduce of the whole arena, every rank updates everything
+        g_ref = g.clone()
+        dist.all_reduce(g_ref)
+        p_ref = model.flat.data.clone() - 0.1 * g_ref
+        # sharded: buckets announced in backward order with the held tails, as the backward pass does
+        dp.begin_step(g)
+        dp.bucket_ready(g)
+        for l in range(model.n_layers - 1, -1, -1):
+            dp.bucket_ready(g, hold_small_of=l if l > 0 else None)
+            dp.small_ready(g, l)
+        dp.finish_step(g)
+        pieces, chunks = dp.shard_plan()
+        n_sharded = sum(1 for row in chunks for _, _, sh in row if sh)
+        res["some_sharded"] = n_sharded >= model.n_layers
+        res["owned_fraction"] = sum(n for _, n in pieces) / g.numel()
+        p = model.flat.data
+        for a, n in pieces:                                   # the stand-in for rpb_adam_step_ranges: only the owned ranges move
+            p[a:a + n] -= 0.1 * g[a:a + n]
+        tab, nr, total = dp.owned_table("cpu")
+        res["table"] = nr == len(pieces) and total == sum(n for _, n in pieces) and [int(v) for v in tab[:, 0]] == [a for a, _ in pieces]
+        stale = float((p - p_ref).abs().max())                # before the gather the foreign pieces are still the old parameters
+        dp.gather_params(p)
+        res["stale_before_gather"] = stale > 0
+        res["equal"] = bool(torch.equal(p, p_ref))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_equals_allreduce_world2_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_shard_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for r in (0, 1):
+        assert res[r]["some_sharded"] and res[r]["table"]
+        assert 0.5 < res[r]["owned_fraction"] < 0.6, res[r]["owned_fraction"]       # half of the spectral ranges + all the small pieces
+        assert res[r]["stale_before_gather"]
+        assert res[r]["equal"], "reduce-scatter + owned update + all-gather != all-reduce + full update"

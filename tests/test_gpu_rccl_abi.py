@@ -165,3 +165,89 @@ def test_rcclcomm_buckets_and_statistics_two_ranks(two_comms):
     for r in (0, 1):
         assert res[r][0] == 3.0 and res[r][1] == 3.0       # 1 + 2
         assert res[r][2] == 6.0                            # two successive in-place sums: (1, 2) -> 3 on both ranks -> 6
+
+
+def test_reduce_scatter_allgather_marks_and_modelled_transfer_one_rank():
+    """rpb_dp_reduce_scatter_enqueue / rpb_dp_allgather_enqueue on a one-rank communicator are the identity, ordered against the compute
+    stream; rpb_dp_mark / rpb_dp_wait_mark let a stream wait for a point of the side stream; rpb_dp_set_model idles the side stream for
+    the modelled transfer (the one-GPU strong-scaling proxy) -- visible as time, not in the data."""
+    import time
+    L = _lib()
+    torch.cuda.set_device(0)
+    h = _comm(_unique_id(), 0, 1)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        g = torch.randn(1 << 22, device="cuda")
+        want = g.clone()
+        L.call("rpb_dp_reduce_scatter_enqueue", h, g.data_ptr(), g.numel(), 0, st)
+        L.call("rpb_dp_allgather_enqueue", h, g.data_ptr(), g.numel(), 0, st)
+        L.call("rpb_dp_mark", h, 3)
+        L.call("rpb_dp_wait_mark", h, 3, st)
+        b = g * 2.0
+        torch.cuda.synchronize()
+        assert torch.equal(g, want) and torch.equal(b, want * 2.0)
+        with pytest.raises(L.RpbError):
+            L.call("rpb_dp_mark", h, 99)
+        # modelled transfer: 64 MB over 8 ranks at 100 GB/s per link = 2 phases x 0.56 ms for the all-reduce
+        L.call("rpb_dp_set_model", h, 8, 100.0, 0.0)
+        big = torch.zeros(16 << 20, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L.call("rpb_dp_allreduce_enqueue", h, big.data_ptr(), big.numel(), 0, st)
+        L.call("rpb_dp_allreduce_wait", h, st)
+        torch.cuda.synchronize()
+        dt = 1e3 * (time.perf_counter() - t0)
+        assert 0.9 < dt < 3.0, dt
+        L.call("rpb_dp_set_model", h, 0, 0.0, 0.0)
+    finally:
+        L.call("rpb_dp_allreduce_destroy", h)
+
+
+def _sharded_step_worker(rank, port, out):
+    import torch.distributed as dist
+    from realpdebench_amd.dp import DataParallel
+    from realpdebench_amd.model.fno import FNO3d
+    from realpdebench_amd.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RPB_LINE_CLAIM="0",
+                      RPB_DP_CHUNK_MB="0.25")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        shape = (6, 16, 16, 2)
+        finals = []
+        for shard in (False, True):
+            torch.manual_seed(3)
+            m = FNO3d(2, 4, 4, 2, 64, shape, shape).to("cuda:0")
+            DataParallel(m, shard_optimizer=shard)
+            tr = Trainer(m, lr=1e-3, num_update=10)
+            torch.manual_seed(4)
+            x, y = torch.randn(2, *shape, device="cuda"), torch.randn(2, *shape, device="cuda")
+            losses = [float(tr.step(x, y)) for _ in range(3)]
+            ck = tr.checkpoint()                         # (waits for the parameter gathers of the sharded step)
+            finals.append((m.flat.data.clone().cpu(), losses))
+            if shard:
+                pieces, chunks = m.dp.shard_plan()
+                out["sharded_chunks"] = sum(1 for row in chunks for _, _, sh in row if sh)
+                out["ranges"] = len(pieces)
+            tr.close()
+        out["equal"] = bool(torch.equal(finals[0][0], finals[1][0])) and finals[0][1] == finals[1][1]
+        out["diag"] = (float((finals[0][0] - finals[1][0]).abs().max()), finals[0][1], finals[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_one_rank_equals_the_plain_step():
+    """Trainer.step with DataParallel(shard_optimizer=True) on a one-rank RCCL group: reduce-scatter per chunk, rpb_adam_step_ranges over
+    the owned ranges (here: the whole arena, in several ranges), all-gather + per-bucket waits in the next forward == the plain step,
+    bit for bit over three steps (RPB_LINE_CLAIM=0: bit-reproducible training launches)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sharded_step_worker, args=(port, out), nprocs=1, join=True)
+        res = dict(out)
+    assert res["sharded_chunks"] >= 2 and res["ranges"] > res["sharded_chunks"]
+    assert res["equal"], f"sharded optimizer step != plain step on one rank: {res['diag']}"
