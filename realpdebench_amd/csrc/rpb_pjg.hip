@@ -164,8 +164,12 @@ __device__ __forceinline__ float dpp_add(float x, float y, const int ctrl) {    
 }  // namespace
 
 // six products of the three-plane split, small terms first, NC independent accumulation chains advancing together
-#define PG_MAC6(NC, ACC, AH, AM, AL, BH, BM, BL)                                       \
-    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma32(AH(c_), BL(c_), ACC(c_)); \
+// (FIRST(c): the chain's first product of the tile takes a literal zero as its C operand -- an inline constant of the instruction -- instead
+// of a zeroed accumulator: the compiler otherwise builds a 16-register zero block and copies it into every accumulator, 128 moves per tile)
+#define PG_MAC6(NC, ACC, AH, AM, AL, BH, BM, BL) PG_MAC6F(NC, ACC, AH, AM, AL, BH, BM, BL, PG_NOTFIRST)
+#define PG_NOTFIRST(c) false
+#define PG_MAC6F(NC, ACC, AH, AM, AL, BH, BM, BL, FIRST)                               \
+    _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma32(AH(c_), BL(c_), FIRST(c_) ? f32x16v{} : ACC(c_)); \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma32(AL(c_), BH(c_), ACC(c_)); \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma32(AM(c_), BM(c_), ACC(c_)); \
     _Pragma("unroll") for (int c_ = 0; c_ < NC; ++c_) ACC(c_) = mfma32(AH(c_), BM(c_), ACC(c_)); \
@@ -356,7 +360,9 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #define PG_BH(c) bh[c]
 #define PG_BM(c) bm[c]
 #define PG_BL(c) bl[c]
-                PG_MAC6(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL)
+#define PG_FIRST(c) (ks == 0)
+                PG_MAC6F(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL, PG_FIRST)
+#undef PG_FIRST
 #undef PG_ACC
 #undef PG_AH
 #undef PG_AM
@@ -547,7 +553,9 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #define PG_BH(c) ((c) < 2 ? Xh[kstep][(c)] : Bp[kstep][0])
 #define PG_BM(c) ((c) < 2 ? Xm[kstep][(c)] : Bp[kstep][1])
 #define PG_BL(c) ((c) < 2 ? Xl[kstep][(c)] : Bp[kstep][2])
-                    PG_MAC6(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL)
+#define PG_FIRST(c) ((c) >= 2 && nt == 0 && kstep == 0)
+                    PG_MAC6F(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL, PG_FIRST)
+#undef PG_FIRST
 #undef PG_ACC
 #undef PG_AH
 #undef PG_AM
