@@ -20,6 +20,7 @@
 //    once per line (a tile-granular version fetched every row ~3x from HBM: 10.3 GB of traffic for 8.56 GB algorithmic);
 //    GW and the conv weights are split once per workgroup into LDS in operand order.
 #include "rpb_cmx.h"
+#include <atomic>
 #ifndef RPB_STREAM_AUX
 #define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (measured: no gain, tools/kbench.py A/B) */
 #endif
@@ -816,22 +817,35 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
 // diagnostics: when set, every cmx launch records per mix wave its start / end tick (100 MHz constant clock); tools/wave_times.py
 // claim counters of mode 2: a ring, one per launch in flight (a launch leaves its counter at zero)
 #define CMX_CLAIM_RING 256
-static int* g_cmx_claim = nullptr;
-static unsigned g_cmx_claim_next = 0;
+// chip-wide line claiming (mode 2, not the default): a ring of counters PER DEVICE (a process may drive several GPUs), handed out with an
+// atomic index (several host threads), and the slot a launch uses is zeroed on the launch stream right before it -- a kernel that
+// aborted cannot leave a counter behind.  The ring is allocated by rpb_line_claim_set(2) (an explicit call, like a communicator's init);
+// with RPB_LINE_CLAIM=2 from the environment the first launch on a device allocates it (never inside a stream capture).
+static int* g_cmx_claim[64] = {nullptr};
+static std::atomic<unsigned> g_cmx_claim_next{0};
+static int* cmx_claim_ring(hipStream_t st, bool may_alloc) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_cmx_claim[dev] && may_alloc) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st) (void)hipStreamIsCapturing(st, &cs);
+        int* ring = nullptr;
+        if (cs == hipStreamCaptureStatusNone && hipMalloc(&ring, CMX_CLAIM_RING * 64) == hipSuccess) g_cmx_claim[dev] = ring;
+    }
+    return g_cmx_claim[dev];
+}
+void rpb_cmx_claim_prealloc() { (void)cmx_claim_ring(nullptr, true); }
 static void cmx_claim_setup(CmxArgs& a, hipStream_t st) {
     a.claim_mode = rpb_line_claim_mode();
     a.claim_ctr = nullptr;
     if (a.claim_mode == 2) {
-        if (!g_cmx_claim) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cs);
-            if (cs == hipStreamCaptureStatusNone && hipMalloc(&g_cmx_claim, CMX_CLAIM_RING * 64) == hipSuccess)
-                (void)hipMemset(g_cmx_claim, 0, CMX_CLAIM_RING * 64);
-            else
-                g_cmx_claim = nullptr;
+        int* ring = cmx_claim_ring(st, true);
+        if (ring) {
+            a.claim_ctr = ring + 16 * (g_cmx_claim_next.fetch_add(1) % CMX_CLAIM_RING);
+            (void)hipMemsetAsync(a.claim_ctr, 0, 64, st);
+        } else {
+            a.claim_mode = 1;
         }
-        if (g_cmx_claim) a.claim_ctr = g_cmx_claim + 16 * (g_cmx_claim_next++ % CMX_CLAIM_RING);
-        else a.claim_mode = 1;
     }
 }
 static unsigned long long* g_cmx_wave_times = nullptr;

@@ -7,6 +7,7 @@ thread_local char rpb_err_buf[512] = "";
 extern "C" const char* rpb_last_error() { return rpb_err_buf; }
 extern "C" int rpb_abi_version() { return 2; }          // == RPB_ABI_VERSION of include/rpb.h (tests/test_abi.py compares them)
 
+void rpb_cmx_claim_prealloc();
 static int g_line_claim_mode = -1;
 int rpb_line_claim_mode() {
     if (g_line_claim_mode < 0) {
@@ -19,6 +20,7 @@ int rpb_line_claim_mode() {
 extern "C" int rpb_line_claim_set(int mode) {          // 0 / 1 / 2, or -1: back to RPB_LINE_CLAIM / the default
     if (mode < -1 || mode > 2) RPB_FAIL(RPB_ERR_ARG, "line_claim_set: mode %d (0 static deal, 1 workgroup counter, 2 chip-wide counter, -1 default)", mode);
     g_line_claim_mode = mode;
+    if (mode == 2) rpb_cmx_claim_prealloc();            // the counter ring of the current device (rpb_cmx.hip): allocated here, not in a launch
     return RPB_OK;
 }
 

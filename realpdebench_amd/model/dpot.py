@@ -577,13 +577,13 @@ class DPOT(_ModelBase):
         part = torch.empty(slots, CO * CI + CO, device=G.device, dtype=torch.float32)
         ops.cell_wgrad(G, A, part, M, CO, CI)
         tot = torch.empty(CO * CI + CO, device=G.device, dtype=torch.float32)
-        ops.reduce_partials(part, slots, CO * CI + CO, out_f32=tot)
+        ops.reduce_partials(part, slots, CO * CI + CO, out_f32=tot, deferrable=True)
         return tot[:CO * CI].view(CO, CI), tot[CO * CI:]
 
     @staticmethod
     def _sum_rows(part, rows, L):
         out = torch.empty(L, device=part.device, dtype=torch.float32)
-        ops.reduce_partials(part, rows, L, out_f32=out)
+        ops.reduce_partials(part, rows, L, out_f32=out, deferrable=True)
         return out
 
     @staticmethod
@@ -597,7 +597,7 @@ class DPOT(_ModelBase):
         for c0 in range(0, N, chunk):
             part = torch.empty(rows, chunk, device=x.device, dtype=torch.float32)      # one per chunk: the reduction may be deferred
             ops.colsum(ops.Sub(x, c0), part, M, chunk, ld=N)
-            ops.reduce_partials(part, rows, chunk, out_f32=ops.Sub(out, c0))
+            ops.reduce_partials(part, rows, chunk, out_f32=ops.Sub(out, c0), deferrable=True)
         return out
 
     # ------------------------------------------------------------------ Model protocol

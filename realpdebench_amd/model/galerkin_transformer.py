@@ -141,7 +141,7 @@ def _wgrad(G, A, M, N, K, ldg=None, lda=None):
     part = torch.empty(splits, N * K + N, device=base.device, dtype=torch.float32)
     ops.gemm_tn(G, A, part, M, N, K, ldg=ldg, lda=lda)
     tot = torch.empty(N * K + N, device=base.device, dtype=torch.float32)       # one reduction launch for [dW | db]
-    ops.reduce_partials(part, splits, N * K + N, out_f32=tot)
+    ops.reduce_partials(part, splits, N * K + N, out_f32=tot, deferrable=True)      # (queued only inside DPOT's deferred_reductions block)
     return tot[:N * K].view(N, K), tot[N * K:]
 
 

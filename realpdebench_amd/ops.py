@@ -4,6 +4,7 @@ PyTorch-ROCm tensors are storage only: every wrapper checks device / dtype / con
 ``data_ptr()``s plus the current HIP stream, and raises on any error.  No wrapper has a non-HIP path.
 """
 import os
+import threading
 
 import torch
 
@@ -242,18 +243,24 @@ def cell_wgrad(gs, x, part, ncell, CO, CI, crop=False, crop6=(0, 0, 0, 1, 1, 1),
 
 
 class deferred_reductions:
-    """Context manager: every plain ``reduce_partials`` issued inside (fp32 output, no scale / accumulate) is queued and all of them run
-    as ONE ``rpb_reduce_partials_grouped`` launch on exit.  For backward passes whose blocks each end in ~10 partial reductions of a few
-    microseconds whose results nobody reads before the pass is over (parameter gradients).  The caller guarantees that the partial buffers
-    are not overwritten and the outputs not read inside the block."""
-    active = None
+    """Context manager: every ``reduce_partials(..., deferrable=True)`` issued inside (fp32 output, no scale / accumulate) is queued and all
+    of them run as ONE ``rpb_reduce_partials_grouped`` launch on exit.  For backward passes whose blocks each end in ~10 partial reductions
+    of a few microseconds whose results nobody reads before the pass is over (parameter gradients).  Deferral is OPT-IN per call site: a
+    reduction whose output is read inside the block simply does not pass ``deferrable`` and runs at once; the caller of a deferrable one
+    guarantees that its partial buffer is not overwritten and its output not read inside the block.  The queue is per host thread."""
+    _tls = threading.local()
+    _staging = {}                    # device -> (pinned host table, device table): the item table travels without blocking the host
 
     def __init__(self, enabled=True):
         self.enabled, self.items, self.keep = enabled, [], []
 
+    @classmethod
+    def current(cls):
+        return getattr(cls._tls, "active", None)
+
     def __enter__(self):
         if self.enabled:
-            self.prev, deferred_reductions.active = deferred_reductions.active, self
+            self.prev, deferred_reductions._tls.active = deferred_reductions.current(), self
         return self
 
     def add(self, part_ptr, out_ptr, rows, L, stride, tensors):
@@ -263,25 +270,34 @@ class deferred_reductions:
     def __exit__(self, *exc):
         if not self.enabled:
             return False
-        deferred_reductions.active = self.prev
+        deferred_reductions._tls.active = self.prev
         if self.items and exc[0] is None:
-            import numpy as np
-            tab, chunk0, cols = np.empty((len(self.items), 6), dtype=np.int64), 0, _lib.query("rpb_reduce_partials_grouped_cols")
+            dev, n = self.keep[0].device, len(self.items)
+            key = (dev, threading.get_ident())
+            st = deferred_reductions._staging.get(key)
+            if st is None or st[0].shape[0] < n:              # pinned host table + device table, grown to the largest block seen
+                cap = max(256, 2 * n)
+                st = (torch.empty(cap, 6, dtype=torch.int64).pin_memory(), torch.empty(cap, 6, dtype=torch.int64, device=dev),
+                      torch.cuda.Event())
+                deferred_reductions._staging[key] = st
+            host, d, ev = st
+            ev.synchronize()                                  # the previous block's copy has left the pinned table (no-op the first time)
+            chunk0, cols = 0, _lib.query("rpb_reduce_partials_grouped_cols")
             for i, (pp, op, rows, L, stride) in enumerate(self.items):
-                tab[i] = (pp, op, rows, L, stride, chunk0)
+                host[i] = torch.tensor((pp, op, rows, L, stride, chunk0), dtype=torch.int64)
                 chunk0 += (L + cols - 1) // cols
-            dev = self.keep[0].device
-            d = torch.from_numpy(tab).to(dev)                   # ~3 KB, staged by the runtime: the host does not wait for the stream
-            _lib.call("rpb_reduce_partials_grouped", d.data_ptr(), len(self.items), chunk0, _stream(), label="reduce_partials_grouped")
-            self.keep.append(d)
+            d[:n].copy_(host[:n], non_blocking=True)          # pinned -> device on the current stream: the host does not wait for the stream
+            ev.record()
+            _lib.call("rpb_reduce_partials_grouped", d.data_ptr(), n, chunk0, _stream(), label="reduce_partials_grouped")
         self.items, self.keep = [], []
         return False
 
 
 def reduce_partials(part, rows, L, out_f32=None, out_f64=None, scale=1.0, accumulate=False, row_stride=None,
-                    col0=0):
-    """out[j] (+)= scale * sum_r part[r*row_stride + col0 + j] for j < L."""
-    q = deferred_reductions.active
+                    col0=0, deferrable=False):
+    """out[j] (+)= scale * sum_r part[r*row_stride + col0 + j] for j < L.  ``deferrable``: inside a ``deferred_reductions`` block the
+    reduction may run at the block's end (nobody reads ``out`` before that)."""
+    q = deferred_reductions.current() if deferrable else None
     if q is not None and out_f64 is None and out_f32 is not None and scale == 1.0 and not accumulate:
         q.add(_p(part) + 4 * col0, _p(out_f32), rows, L, L if row_stride is None else row_stride,
               [part.t if isinstance(part, Sub) else part, out_f32.t if isinstance(out_f32, Sub) else out_f32])
