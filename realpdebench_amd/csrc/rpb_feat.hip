@@ -13,6 +13,7 @@
 // Phi^ = D(phi) is laid out [2 (re, im)][M modes][NB columns]: columns b * Cin + j = field j of sample b, then the four
 // sample-independent fields (grid_t, grid_h, grid_w, 1) at columns B * Cin .. + 3 (NB = that, padded to a multiple of 64).
 #include "rpb_common.h"
+#include <stdlib.h>
 
 // Xh[b][ri][m][c] = sum_j W0[c][j] Phi[ri][m][b*Cin + j] + sum_j' W0[c][Cin + j'] Phi[ri][m][B*Cin + j']   (j' < 3)  + b0[c] Phi[..][B*Cin + 3]
 __global__ __launch_bounds__(256) void feat_mix_kernel(const float* __restrict__ Phi, const float* __restrict__ w0,
@@ -151,11 +152,56 @@ __global__ __launch_bounds__(256) void lift_feat_kernel(const float* __restrict_
     }
 }
 
+// The headline instance (Cin = 2, FW = 8): a wave walks whole rows of the padded tensor -- the (b, t, h) decode is paid once per row in
+// scalar registers, a lane's piece i of the row is cell i >> 1, half i & 1: (x0, x1, grid_t, grid_h) or (grid_w, 1, 0, 0), chosen with
+// selects (no divergence), one 8 B load of x and one 16 B store per piece.  The generic kernel above decodes every piece with three
+// divisions and a select chain per field: 0.29 ms for a 0.56 GB pass; this one is bound by its store.
+__global__ __launch_bounds__(256) void lift_feat2_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                         const float* __restrict__ gh, const float* __restrict__ gw,
+                                                         float* __restrict__ out, int nrows, CropMap cm) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int nwaves = (int)gridDim.x * 4;
+    const int npiece = 2 * cm.Wp;
+    for (int row = wave; row < nrows; row += nwaves) {
+        const unsigned bt = (unsigned)row / (unsigned)cm.Hp, h = (unsigned)row - bt * (unsigned)cm.Hp;
+        const unsigned b = bt / (unsigned)cm.Tp, t = bt - b * (unsigned)cm.Tp;
+        f32x4* orow = reinterpret_cast<f32x4*>(out) + (long)row * npiece;
+        const bool live = (int)h < cm.H && (int)t < cm.T;                  // uniform
+        const float* xrow = x + (((long)b * cm.T + (live ? t : 0)) * cm.H + (live ? h : 0)) * (long)cm.W * 2;
+        const float ft = live ? gt[t] : 0.f, fh = live ? gh[h] : 0.f;
+        for (int i = lane; i < npiece; i += 64) {
+            const int w = i >> 1;
+            const bool half = i & 1, in = live && w < cm.W;
+            const int wc = w < cm.W ? w : 0;
+            const float2 xv = *reinterpret_cast<const float2*>(xrow + 2 * wc);
+            const float g = gw[wc];
+            f32x4 v;
+            v[0] = half ? g : xv.x;
+            v[1] = half ? 1.f : xv.y;
+            v[2] = half ? 0.f : ft;
+            v[3] = half ? 0.f : fh;
+            if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            orow[i] = v;
+        }
+    }
+}
+
 extern "C" int rpb_lift_feat(const float* x, const float* gt, const float* gh, const float* gw, float* out, int B, int T, int H,
                              int W, int Cin, int Tp, int Hp, int Wp, int FW, void* stream) {
     RPB_REQUIRE(x && gt && gh && gw && out && (FW == 8 || FW == 32) && Cin + 4 <= FW, "lift_feat: FW=%d must be 8 or 32 and hold Cin + 4 = %d fields", FW, Cin + 4);
     const long total = (long)B * Tp * Hp * Wp * (FW / 4);
     RPB_REQUIRE(total < (1L << 31), "lift_feat: too many cells");
+    static const bool generic = getenv("RPB_LIFT_FEAT_GENERIC") && atoi(getenv("RPB_LIFT_FEAT_GENERIC")) == 1;
+    if (Cin == 2 && FW == 8 && !generic) {
+        const int nrows = B * Tp * Hp;
+        long g2 = ((long)nrows + 3) / 4;
+        const long cap2 = (long)rpb_num_cus() * 8;
+        if (g2 > cap2) g2 = cap2;
+        hipLaunchKernelGGL(lift_feat2_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, x, gt, gh, gw, out, nrows,
+                           CropMap{T, H, W, Tp, Hp, Wp});
+        RPB_CHECK_LAUNCH("lift_feat");
+    }
     long grid = (total + 255) / 256;
     const long cap = (long)rpb_num_cus() * 32;
     if (grid > cap) grid = cap;

@@ -882,3 +882,24 @@ def test_grouped_partial_reductions_equal_the_single_launches(ops):
             ops.reduce_partials(parts[0], 7, 100, out_f32=outs[0])
             raise RuntimeError("boom")
     assert ops.deferred_reductions.active is None
+
+
+@pytest.mark.parametrize("B,T,H,W,Cin,pad", [(2, 3, 5, 7, 2, 6), (1, 2, 4, 40, 2, 3), (3, 4, 6, 33, 2, 6), (2, 3, 5, 9, 3, 6)])
+def test_lift_feat_feature_fields(ops, B, T, H, W, Cin, pad):
+    """rpb_lift_feat: Phi_c[cell] = (x_0 .. x_{Cin-1}, grid_t, grid_h, grid_w, 1, 0 ..) on the data cells, zeros in the pad margin
+    (the input of layer 0's channel mixing, fno.py:106-111 with the lift folded into the layer): the row-walking Cin = 2 instance and the
+    generic kernel (Cin = 3), bit for bit against the construction in torch."""
+    torch.manual_seed(B + W)
+    d = ops.Dims(B, T, H, W, Cin, 64, pad)
+    x = torch.randn(B, T, H, W, Cin, device="cuda")
+    grids = [torch.linspace(0, 1, n, device="cuda") for n in (T, H, W)]
+    FW = 8
+    out = torch.full((d.ncell, FW), float("nan"), device="cuda")
+    ops.lift_feat(x, grids, out, d, FW)
+    ref = torch.zeros(B, d.Tp, d.Hp, d.Wp, FW, device="cuda")
+    ref[:, :T, :H, :W, :Cin] = x
+    ref[:, :T, :H, :W, Cin] = grids[0].view(1, T, 1, 1)
+    ref[:, :T, :H, :W, Cin + 1] = grids[1].view(1, 1, H, 1)
+    ref[:, :T, :H, :W, Cin + 2] = grids[2].view(1, 1, 1, W)
+    ref[:, :T, :H, :W, Cin + 3] = 1.0
+    assert torch.equal(out.view_as(ref), ref)

@@ -203,6 +203,8 @@ if "lift" in which:
     timeit("lift_pad_fwd", lambda: ops.lift_pad_fwd(xin, grids, w0, b0, y, d), 4 * (d.ncrop * Cin + d.ncell * C), 0)
     part = torch.empty(ops._lib.query("rpb_lift_bwd_rows") * (C * (Cin + 3) + C), **f)
     timeit("lift_bwd", lambda: ops.lift_bwd(x, xin, grids, part, d), 4 * d.ncrop * (Cin + C), 0)
+    phic = torch.empty(d.ncell, 8, **f)
+    timeit("lift_feat (feature fields, FW = 8)", lambda: ops.lift_feat(xin, grids, phic, d, 8), 4 * (d.ncrop * Cin + d.ncell * 8), 0)
 
 if "mode" in which:
     M = plan.M
