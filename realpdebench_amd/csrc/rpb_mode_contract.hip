@@ -576,12 +576,93 @@ __global__ __launch_bounds__(256) void mode_mfma128_kernel(const float* __restri
         }
     }
 }
+
+// ---- C = 128, second organisation of fwd / dgrad (round 5): the weights never pass through LDS.  The first organisation staged a 64-wide
+// half of the mode's 128 KB weight tile in LDS with four ds_write_b32 per 16 B load and ran ONE workgroup per CU (99 KB of LDS): 0.56 ms per
+// launch at the fsi shape for 0.54 GB of weights (1.4 TB/s) -- neither the matrix pipe (0.13 ms) nor the bytes (0.1 ms) but the staging.
+// Here a wave owns 32 output columns of BOTH planes and loads its B operands straight from global memory in MFMA layout: forward, lane
+// (col, half) reads the complex number W[i = 2 s + half][o = n0 + col] (8 B; 256 B contiguous per row across the lanes) and feeds four
+// products (re / im of both output planes); data gradient, the lane walks ITS row W[i = n0 + col][:] in 16 B pieces (two complex numbers =
+// two K-steps).  Only the coefficient tile (33 KB) is staged, so four workgroups share a CU and hide each other's load latency.
+template <int MODE>
+__global__ __launch_bounds__(256) void mode_mfma128d_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ GY,
+                                                             float* __restrict__ OUT, int B, int M) {
+    constexpr int C = 128;
+    __shared__ float Xs[2 * 32 * MM_LD128];        // [ri][b 32][c 128 (+1)]   fwd: X, dgrad: gY
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const long plane = (long)M * C;
+    const float* src = MODE == 1 ? GY : X;
+    const float* Wm = Wt + (long)m * C * C * 2;
+    const int n0 = 32 * wave;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        if (b0) __syncthreads();
+        for (int idx = tid; idx < 2 * 32 * (C / 4); idx += 256) {
+            const int c4 = idx % (C / 4), r = idx / (C / 4);     // r = bl * 2 + ri
+            const int bl = r >> 1, ri = r & 1, b = b0 + bl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) v = *reinterpret_cast<const f32x4*>(src + (long)(b * 2 + ri) * plane + (long)m * C + 4 * c4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Xs[(ri * 32 + bl) * MM_LD128 + 4 * c4 + t] = v[t];
+        }
+        __syncthreads();
+        f32x16 accR = zero16(), accI = zero16();
+        const float* xr_p = Xs + (0 * 32 + col) * MM_LD128;
+        const float* xi_p = Xs + (1 * 32 + col) * MM_LD128;
+        if (MODE == 0) {
+            // Yr = Xr Wr - Xi Wi,  Yi = Xr Wi + Xi Wr;  K-step s: i = 2 s + half
+            const f32x2* wp = reinterpret_cast<const f32x2*>(Wm) + (long)half * C + n0 + col;
+#pragma unroll 8
+            for (int s = 0; s < C / 2; ++s) {
+                const f32x2 w = wp[(long)(2 * s) * C];
+                const float xr = xr_p[2 * s + half], xi = xi_p[2 * s + half];
+                accR = mfma32(xr, w[0], accR);
+                accR = mfma32(-xi, w[1], accR);
+                accI = mfma32(xr, w[1], accI);
+                accI = mfma32(xi, w[0], accI);
+            }
+        } else {
+            // GXr = GYr Wr + GYi Wi,  GXi = -GYr Wi + GYi Wr;  K-steps 2 t, 2 t + 1: o = 4 t + 2 half + u
+            const f32x4* wp = reinterpret_cast<const f32x4*>(Wm + ((long)(n0 + col) * C + 2 * half) * 2);
+#pragma unroll 4
+            for (int t = 0; t < C / 4; ++t) {
+                const f32x4 w = wp[2 * t];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int o = 4 * t + 2 * half + u;
+                    const float gr = xr_p[o], gi = xi_p[o];
+                    accR = mfma32(gr, w[2 * u], accR);
+                    accR = mfma32(gi, w[2 * u + 1], accR);
+                    accI = mfma32(-gr, w[2 * u + 1], accI);
+                    accI = mfma32(gi, w[2 * u], accI);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = b0 + mfma_row(lane, r);
+            if (b < B) {
+                OUT[(long)(b * 2 + 0) * plane + (long)m * C + n0 + col] = accR[r];
+                OUT[(long)(b * 2 + 1) * plane + (long)m * C + n0 + col] = accI[r];
+            }
+        }
+    }
+}
+static bool mode128_direct() {            // RPB_MODE128_LDS=1: the first organisation (weight halves staged in LDS)
+    static const bool off = getenv("RPB_MODE128_LDS") && atoi(getenv("RPB_MODE128_LDS")) == 1;
+    return !off;
+}
 static size_t mode128_lds(int mode) {
     const size_t xs = 2 * 32 * MM_LD128, ws = mode == 0 ? 2 * 128 * MM_LD : (mode == 1 ? 2 * 64 * MM_LD128 : 2 * 32 * MM_LD128);
     return (xs + ws) * 4;
 }
 template <int MODE>
 static int launch_mode128(const float* X, const float* W, const float* GY, float* OUT, int B, int M, int accumulate, hipStream_t st) {
+    if (MODE != 2 && mode128_direct()) {
+        hipLaunchKernelGGL((mode_mfma128d_kernel<MODE>), dim3(M), dim3(256), 0, st, X, W, GY, OUT, B, M);
+        return RPB_OK;
+    }
     const size_t lds = mode128_lds(MODE);
     (void)hipFuncSetAttribute((const void*)mode_mfma128_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((mode_mfma128_kernel<MODE>), dim3(M), dim3(256), lds, st, X, W, GY, OUT, B, M, accumulate);
