@@ -857,8 +857,9 @@ def test_reduce_partials_shapes(ops, rows, L, stride):
 
 
 def test_grouped_partial_reductions_equal_the_single_launches(ops):
-    """ops.deferred_reductions: reductions of different shapes / strides / column offsets queued inside the block run as ONE
-    rpb_reduce_partials_grouped launch and give bit-identical results to the per-item launches (same fp64 accumulation order)."""
+    """ops.deferred_reductions: reductions of different shapes / strides / column offsets marked ``deferrable`` inside the block run as ONE
+    rpb_reduce_partials_grouped launch and give bit-identical results to the per-item launches (same fp64 accumulation order); a
+    reduction that does not opt in runs at once inside the block (its output may be read there)."""
     torch.manual_seed(5)
     shapes = [(7, 100, 100, 0), (300, 64, 64, 0), (12, 5000, 5064, 0), (33, 64, 5064, 5000), (1, 3, 3, 0), (64, 1024 * 33, 1024 * 33, 0)]
     parts = [torch.randn(rows, stride, device="cuda") for rows, L, stride, c0 in shapes]
@@ -870,18 +871,24 @@ def test_grouped_partial_reductions_equal_the_single_launches(ops):
     outs = [torch.full((L,), float("nan"), device="cuda") for rows, L, stride, c0 in shapes]
     with ops.deferred_reductions():
         for p, o, (rows, L, stride, c0) in zip(parts, outs, shapes):
-            ops.reduce_partials(p, rows, L, out_f32=o, row_stride=stride, col0=c0)
+            ops.reduce_partials(p, rows, L, out_f32=o, row_stride=stride, col0=c0, deferrable=True)
         assert all(bool(torch.isnan(o).all()) for o in outs)          # nothing ran yet
+        now = torch.full((100,), float("nan"), device="cuda")
+        ops.reduce_partials(parts[0], 7, 100, out_f32=now)            # not deferrable: runs inside the block
+        assert torch.equal(now, ref[0])
     torch.cuda.synchronize()
     for o, r in zip(outs, ref):
         assert torch.equal(o, r)
-    assert ops.deferred_reductions.active is None
+    assert ops.deferred_reductions.current() is None
+    with ops.deferred_reductions():                                   # a second block reuses the pinned / device tables
+        ops.reduce_partials(parts[1], 300, 64, out_f32=outs[1].fill_(float("nan")), deferrable=True)
+    assert torch.equal(outs[1], ref[1])
     # an exception inside the block drops the queue and restores immediate mode
     with pytest.raises(RuntimeError):
         with ops.deferred_reductions():
-            ops.reduce_partials(parts[0], 7, 100, out_f32=outs[0])
+            ops.reduce_partials(parts[0], 7, 100, out_f32=outs[0], deferrable=True)
             raise RuntimeError("boom")
-    assert ops.deferred_reductions.active is None
+    assert ops.deferred_reductions.current() is None
 
 
 @pytest.mark.parametrize("B,T,H,W,Cin,pad", [(2, 3, 5, 7, 2, 6), (1, 2, 4, 40, 2, 3), (3, 4, 6, 33, 2, 6), (2, 3, 5, 9, 3, 6)])
