@@ -332,6 +332,10 @@ __device__ __forceinline__ f32x4 m_mac6(const Planes& a, const Planes& b, f32x4 
     return c;
 }
 }  // namespace
+// MB_NT: non-temporal loads of the mode's weight tile (A/B: profiles/r05_kbench_valu_variants.txt)
+#ifndef MB_NT
+#define MB_NT 0
+#endif
 #define MB_XP 68        // row pitch (floats) of the coefficient tiles [ri][b 32][c 64]
 #define MB_WP 133       // row pitch (floats) of the weight tile [i 64][o 64][2]: odd, so that neither the row-strided gather of the forward
                         // (8 rows per lane group: 8 * 133 = 8 mod 32) nor the column-strided one of the data gradient piles onto a few banks
@@ -350,7 +354,11 @@ __global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict_
     if (MODE != 2) {
         const float* Wm = Wt + (long)m * C * C * 2;
         for (int idx = tid; idx < C * C / 2; idx += 256) {       // two complex numbers per 16 B load: row i, columns o, o + 1
+#if MB_NT
+            const f32x4 w = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Wm + (long)idx * 4));      // streamed once per launch by ONE workgroup
+#else
             const f32x4 w = *reinterpret_cast<const f32x4*>(Wm + (long)idx * 4);
+#endif
             const int i = (2 * idx) / C, o = 2 * idx - i * C;
             float* d = Ws + i * MB_WP + 2 * o;
             d[0] = w[0], d[1] = w[1], d[2] = w[2], d[3] = w[3];
