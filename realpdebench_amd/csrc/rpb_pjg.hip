@@ -38,6 +38,10 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 #ifndef PG_PIPE
 #define PG_PIPE 0
 #endif
+// PG_PIPE1 = n > 0: the same for contraction 1 (n vector instructions + one LDS read behind every MFMA of a K-step)
+#ifndef PG_PIPE1
+#define PG_PIPE1 2     /* measured: 3.79-3.85 -> 3.64 ms (the compiler lumps 7-9 instructions into some MFMA gaps and none into others) */
+#endif
 
 // -DPG_TIMING: s_memtime stamps at the phase boundaries of the tile body; the wave writes its per-phase cycle sums over the first floats of
 // its partial row (the results of such a build are garbage: tools/dbg/head_phases.py reads the stamps only)
@@ -334,8 +338,10 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;               // (b1' is added at the activation: a resident splat costs 64 registers)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            // software pipeline over the K-steps: the planes of step ks + 1 (the split of the tile's next 16 channels, the 12 weight-plane
+            // reads) are written BEFORE the 24 MFMAs of step ks and do not depend on them -- they issue in the shadow of the matrix pipe
+            bf16x8 Ah[2], Am[2], Al[2], bh[2][4], bm[2][4], bl[2][4];
+            auto prep = [&](int ks) {
                 float v[8];
                 const f32x4v x0 = __builtin_bit_cast(f32x4v, xa[2 * ks]), x1 = __builtin_bit_cast(f32x4v, xa[2 * ks + 1]);
                 const f32x4v m0 = *reinterpret_cast<const f32x4v*>(meanl + 16 * ks + 8 * hg), m1 = *reinterpret_cast<const f32x4v*>(meanl + 16 * ks + 8 * hg + 4);
@@ -344,22 +350,25 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
                     v[c] = x0[c] - m0[c];
                     v[4 + c] = x1[c] - m1[c];
                 }
-                bf16x8 Ah, Am, Al;
-                split8(v, Ah, Am, Al);
-                bf16x8 bh[4], bm[4], bl[4];
+                split8(v, Ah[ks & 1], Am[ks & 1], Al[ks & 1]);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    bh[nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 0) * 64 + lane]);
-                    bm[nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 1) * 64 + lane]);
-                    bl[nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 2) * 64 + lane]);
+                    bh[ks & 1][nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 0) * 64 + lane]);
+                    bm[ks & 1][nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 1) * 64 + lane]);
+                    bl[ks & 1][nt] = __builtin_bit_cast(bf16x8, W1B[((ks * 4 + nt) * 3 + 2) * 64 + lane]);
                 }
+            };
+            prep(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) prep(ks + 1);
 #define PG_ACC(c) acc[c]
-#define PG_AH(c) Ah
-#define PG_AM(c) Am
-#define PG_AL(c) Al
-#define PG_BH(c) bh[c]
-#define PG_BM(c) bm[c]
-#define PG_BL(c) bl[c]
+#define PG_AH(c) Ah[ks & 1]
+#define PG_AM(c) Am[ks & 1]
+#define PG_AL(c) Al[ks & 1]
+#define PG_BH(c) bh[ks & 1][c]
+#define PG_BM(c) bm[ks & 1][c]
+#define PG_BL(c) bl[ks & 1][c]
 #define PG_FIRST(c) (ks == 0)
                 PG_MAC6F(4, PG_ACC, PG_AH, PG_AM, PG_AL, PG_BH, PG_BM, PG_BL, PG_FIRST)
 #undef PG_FIRST
@@ -370,6 +379,17 @@ __global__ __launch_bounds__(PG_WAVES * 64, 1) void pjg_kernel(PjfArgs p) {
 #undef PG_BH
 #undef PG_BM
 #undef PG_BL
+#if PG_PIPE1
+                if (ks < 3) {                            // spread the next step's preparation evenly behind this step's MFMAs
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, PG_PIPE1, 0);
+                        if (i < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             asm volatile("" ::"v"(pf));
             __builtin_amdgcn_sched_barrier(0);
