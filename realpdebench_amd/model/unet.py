@@ -24,7 +24,6 @@ version-unpinned ``rotary_embedding_torch``; its published algorithm is restated
 that one function is unpinned, everything around it is pinned through ``oracle/unet_oracle.py``.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -42,11 +41,9 @@ def _new(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
-def _reduce(part, rows, L, scale=1.0, f64=False, later=False):
-    """``later``: a parameter gradient nobody reads before the backward pass is over -- inside the pass's ``ops.deferred_reductions``
-    block the reduction is queued (one grouped launch at the end); hand the result to ``_Tape.pacc`` as a thunk."""
+def _reduce(part, rows, L, scale=1.0, f64=False):
     out = torch.empty(L, device=part.device, dtype=torch.float64 if f64 else torch.float32)
-    ops.reduce_partials(part, rows, L, out_f64=out if f64 else None, out_f32=None if f64 else out, scale=scale, deferrable=later)
+    ops.reduce_partials(part, rows, L, out_f64=out if f64 else None, out_f32=None if f64 else out, scale=scale)
     return out
 
 
@@ -61,26 +58,25 @@ def _wgrad(G, A, M, N, K, conv=None, conv_mode=1, ldg=None, lda=None):
         part = _new(splits, N * K + N, like=G)
         ops.gemm_tn(G, A, part, M, N, K, conv=conv, conv_mode=conv_mode, ldg=ldg, lda=lda)
     dW, db = _new(N, K, like=G), _new(N, like=G)
-    # deferrable: the two reductions may run at the end of the backward pass (ops.deferred_reductions in _backward_hip); the CONTENT of
-    # dW / db is valid only after that, so callers hand them to _Tape.pacc inside thunks, through ``fix`` (the tap order of the reversed mesh)
-    ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N, deferrable=True)
-    ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K, deferrable=True)
-    fix = (lambda w: ops.conv3_taps_restore(w, N, K // 27)) if taps_rev else (lambda w: w)
-    return dW, db, fix
+    ops.reduce_partials(part, splits, N * K, out_f32=dW.view(-1), row_stride=N * K + N)
+    ops.reduce_partials(part, splits, N, out_f32=db, row_stride=N * K + N, col0=N * K)
+    if taps_rev:
+        dW = ops.conv3_taps_restore(dW, N, K // 27)
+    return dW, db
 
 
-def _colsum(x, M, N, later=False):
+def _colsum(x, M, N):
     rows = ops.colsum_rows()
     part = _new(rows, N, like=x)
     ops.colsum(x, part, M, N)
-    return _reduce(part, rows, N, later=later)
+    return _reduce(part, rows, N)
 
 
 class _Tape:
     """Reverse-mode bookkeeping over token tensors: gradients keyed by tensor identity, parameter gradients by name."""
 
     def __init__(self, record):
-        self.record, self.ops, self.g, self.pg, self.pl = record, [], {}, {}, []
+        self.record, self.ops, self.g, self.pg = record, [], {}, {}
 
     def add(self, fn):
         if self.record:
@@ -94,16 +90,7 @@ class _Tape:
         return self.g.pop(id(t))
 
     def pacc(self, name, g):
-        """``g``: a tensor, or a thunk for a gradient whose partial reduction was deferred to the end of the pass (``flush``)."""
-        if callable(g):
-            self.pl.append((name, g))
-        else:
-            self.pg[name] = g if name not in self.pg else self.pg[name] + g
-
-    def flush(self):
-        for name, fn in self.pl:
-            self.pacc(name, fn())
-        self.pl = []
+        self.pg[name] = g if name not in self.pg else self.pg[name] + g
 
 
 def _rotary_tables(freqs, T):
@@ -320,16 +307,16 @@ class Unet3d(_ModelBase):
             if N % 4:                                            # e.g. the 3-channel output head
                 gp = torch.zeros(M, (N + 3) // 4 * 4, device=gy.device)
                 gp[:, :N] = gy
-                dW, db, fix = _wgrad(gp, x, M, N, K, ldg=gp.shape[1])
+                dW, db = _wgrad(gp, x, M, N, K, ldg=gp.shape[1])
                 gx = _new(M, K, like=x)
                 ops.tokens_lift(gy, self._w("T", wname), torch.zeros(K, device=gy.device), gx, M, N, K, False)
             else:
-                dW, db, fix = _wgrad(gy, x, M, N, K)
+                dW, db = _wgrad(gy, x, M, N, K)
                 gx = _new(M, K, like=x)
                 ops.gemm_nt(gy, self._w("T", wname), gx, M, K, N)
-            tp.pacc(wname, lambda: fix(dW).view(self.p(wname).shape))
+            tp.pacc(wname, dW.view(self.p(wname).shape))
             if bname:
-                tp.pacc(bname, lambda: db)
+                tp.pacc(bname, db)
             tp.acc(x, gx)
 
         tp.add(bwd)
@@ -343,9 +330,9 @@ class Unet3d(_ModelBase):
 
         def bwd():
             gy = tp.grad(y)
-            dW, db, fix = _wgrad(gy, x, M, Co, 27 * Ci, conv=mesh)
-            tp.pacc(name + ".weight", lambda: fix(dW).view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3).contiguous())
-            tp.pacc(name + ".bias", lambda: db)
+            dW, db = _wgrad(gy, x, M, Co, 27 * Ci, conv=mesh)
+            tp.pacc(name + ".weight", dW.view(Co, 3, 3, 3, Ci).permute(0, 4, 1, 2, 3).contiguous())
+            tp.pacc(name + ".bias", db)
             gx = _new(M, Ci, like=x)
             ops.conv3(gy, self._w("conv3_dgrad", name + ".weight"), gx, M, Ci, Co, mesh)
             tp.acc(x, gx)
@@ -377,9 +364,9 @@ class Unet3d(_ModelBase):
 
         def bwd():
             gy = tp.grad(y)
-            dW, db, fix = _wgrad(gy, x, Mo, C, 16 * C, conv=mesh, conv_mode=2)
-            tp.pacc(name + ".weight", lambda: fix(dW).view(C, 4, 4, C).permute(0, 3, 1, 2).unsqueeze(2).contiguous())
-            tp.pacc(name + ".bias", lambda: db)
+            dW, db = _wgrad(gy, x, Mo, C, 16 * C, conv=mesh, conv_mode=2)
+            tp.pacc(name + ".weight", dW.view(C, 4, 4, C).permute(0, 3, 1, 2).unsqueeze(2).contiguous())
+            tp.pacc(name + ".bias", db)
             tp.acc(x, self._transposed(gy, self._w("up_from_down", name + ".weight"), None, B, (T, H // 2, W // 2), C, C))
 
         tp.add(bwd)
@@ -393,10 +380,9 @@ class Unet3d(_ModelBase):
         def bwd():
             gy = tp.grad(y)
             # d W[i][o][kh][kw] = sum_in x[in][i] * gy[2*in - 1 + k][o]: the strided gather with the roles swapped
-            dW, _, fix = _wgrad(x, gy, M, C, 16 * C, conv=(T, 2 * H, 2 * W), conv_mode=2)
-            tp.pacc(name + ".weight", lambda: fix(dW).view(C, 4, 4, C).permute(0, 3, 1, 2).unsqueeze(2).contiguous())
-            cs = _colsum(gy, 4 * M, C, later=True)
-            tp.pacc(name + ".bias", lambda: cs)
+            dW, _ = _wgrad(x, gy, M, C, 16 * C, conv=(T, 2 * H, 2 * W), conv_mode=2)
+            tp.pacc(name + ".weight", dW.view(C, 4, 4, C).permute(0, 3, 1, 2).unsqueeze(2).contiguous())
+            tp.pacc(name + ".bias", _colsum(gy, 4 * M, C))
             tp.acc(x, self._strided(gy, self._w("down_from_up", name + ".weight"), None, B, (T, 2 * H, 2 * W), C, C))
 
         tp.add(bwd)
@@ -425,9 +411,8 @@ class Unet3d(_ModelBase):
             dgam, dbet, Pc, Qc = (_new(B, C, like=x) for _ in range(4))
             dss = _new(B, 2 * C, like=x) if ss is not None else None
             ops.gn_affine_bwd(d, stat, gam, bet, ss, cnt, dgam, dbet, dss, Pc, Qc, B, C, GROUPS)
-            rg, rb = _reduce(dgam, B, C, later=True), _reduce(dbet, B, C, later=True)
-            tp.pacc(name + ".weight", lambda: rg)
-            tp.pacc(name + ".bias", lambda: rb)
+            tp.pacc(name + ".weight", _reduce(dgam, B, C))
+            tp.pacc(name + ".bias", _reduce(dbet, B, C))
             if ss is not None:
                 tp.acc(ss, dss)
             gx = _new(B * n, C, like=x)
@@ -449,8 +434,7 @@ class Unet3d(_ModelBase):
             part = _new(rows, 2 * C, like=x)
             gx = _new(M, C, like=x)
             ops.layernorm_bwd(x, gam, gy, None, gx, part, M, C, LN_EPS)
-            rr = _reduce(part, rows, 2 * C, later=True)
-            tp.pacc(name, lambda: rr[:C].view(self.p(name).shape))
+            tp.pacc(name, _reduce(part, rows, 2 * C)[:C].view(self.p(name).shape))
             tp.acc(x, gx)
 
         tp.add(bwd)
@@ -565,9 +549,9 @@ class Unet3d(_ModelBase):
 
             def bwd_ss():
                 g = tp.grad(ss)
-                dW, db, fix = _wgrad(g, temb, B, 2 * Co, TD)
-                tp.pacc(name + ".mlp.1.weight", lambda: fix(dW))
-                tp.pacc(name + ".mlp.1.bias", lambda: db)
+                dW, db = _wgrad(g, temb, B, 2 * Co, TD)
+                tp.pacc(name + ".mlp.1.weight", dW)
+                tp.pacc(name + ".mlp.1.bias", db)
                 gt = _new(B, TD, like=x)
                 ops.gemm_nt(g, Wl.t().contiguous(), gt, B, TD, 2 * Co)
                 tp.acc(temb, gt)
@@ -632,14 +616,14 @@ class Unet3d(_ModelBase):
             if id(temb) in tp.g:
                 gl = torch.empty(B, TD, **f)
                 ops.silu_bwd(tlin, tp.grad(temb), gl)
-                dW3, db3, _f3 = _wgrad(gl, h1, B, TD, TD)
+                dW3, db3 = _wgrad(gl, h1, B, TD, TD)
                 gh = torch.empty(B, TD, **f)
                 ops.gemm_nt(gl, W3.t().contiguous(), gh, B, TD, TD, act=2, aux=h1pre)
-                dW1, db1, _f1 = _wgrad(gh, emb, B, TD, dim)
-                tp.pacc("time_mlp.3.weight", lambda: dW3)
-                tp.pacc("time_mlp.3.bias", lambda: db3)
-                tp.pacc("time_mlp.1.weight", lambda: dW1)
-                tp.pacc("time_mlp.1.bias", lambda: db1)
+                dW1, db1 = _wgrad(gh, emb, B, TD, dim)
+                tp.pacc("time_mlp.3.weight", dW3)
+                tp.pacc("time_mlp.3.bias", db3)
+                tp.pacc("time_mlp.1.weight", dW1)
+                tp.pacc("time_mlp.1.bias", db1)
 
         tp.add(bwd_glue)
         mesh = (T, H, W)
@@ -656,10 +640,10 @@ class Unet3d(_ModelBase):
 
             def bwd_init():
                 gy = tp.grad(h0)
-                dW, db, fix = _wgrad(gy, col, M, dim, ldc)
+                dW, db = _wgrad(gy, col, M, dim, ldc)
                 k, cols = self.ks, self.ks ** 3 * Cin
-                tp.pacc("init_conv.weight", lambda: fix(dW)[:, :cols].reshape(dim, k, k, k, Cin).permute(0, 4, 1, 2, 3).contiguous())
-                tp.pacc("init_conv.bias", lambda: db)
+                tp.pacc("init_conv.weight", dW[:, :cols].reshape(dim, k, k, k, Cin).permute(0, 4, 1, 2, 3).contiguous())
+                tp.pacc("init_conv.bias", db)
 
             tp.add(bwd_init)
         else:
@@ -704,12 +688,8 @@ class Unet3d(_ModelBase):
     def _backward_hip(self, tp, g_out):
         """Gradients of every parameter given dLoss/d(out): reverse walk over the tape."""
         tp.acc(tp.out, g_out.reshape(tp.out.shape).contiguous())
-        # the ~340 partial reductions that end the weight / bias / norm gradients are read by nobody before the pass is over: queued
-        # (``deferrable``) and run as ONE grouped launch when the block exits; the re-layouts that read them wait in thunks (tp.flush)
-        with ops.deferred_reductions(os.environ.get("RPB_UNET_DEFER_REDUCE", "1") != "0"):
-            for fn in reversed(tp.ops):
-                fn()
-        tp.flush()
+        for fn in reversed(tp.ops):
+            fn()
         # the closures on the tape reference the tape (cycles): release the saved activations now, not at the next GC run
         pg = tp.pg
         tp.ops.clear()
