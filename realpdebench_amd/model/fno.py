@@ -595,6 +595,17 @@ class FNO3d(Model):
                 ops.proj_dgrad(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), None, g, ws.bn_part, d, DO, xf_last,
                                act=self.proj_act, gu=ws.gu)
                 ops.reduce_partials(ws.bn_part, ws.pd_slots, 2 * C, out_f32=ws.bn_sums)
+            elif C == 128 and os.environ.get("RPB_GATHER_BNB_FUSED_128") != "1":
+                # width 128: the fp32 gather instance with the BatchNorm-backward sums in its epilogue spills (3.2 ms at the fsi shape);
+                # the plain gather + the streaming reduction over (s, g) -- measured in tools/fsi_probe.py, RPB_GATHER_BNB_FUSED_128=1 restores
+                ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, None, d.ncell, HID, C, 0, 1, transpose_w=True,
+                             gather=True, crop6=d.crop6)
+                xfb = self._layer_xf(ws, L - 1, True)
+                if not hasattr(ws, "bnr_part"):
+                    ws.bnr_rows = ops.bn_bwd_rows()
+                    ws.bnr_part = torch.empty(ws.bnr_rows * 2 * C, device=g.device, dtype=torch.float32)
+                ops.bn_bwd_reduce(ws.S[L - 1], g, xfb[0], xfb[1], xfb[2], xfb[3], ws.bnr_part, d.ncell, C, xfb[4])
+                ops.reduce_partials(ws.bnr_part, ws.bnr_rows, 2 * C, out_f32=ws.bn_sums)
             else:
                 ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, ws.bn_part, d.ncell, HID, C, 0, 1, transpose_w=True,
                              gather=True, crop6=d.crop6, bnb=(ws.S[L - 1],) + self._layer_xf(ws, L - 1, True))
