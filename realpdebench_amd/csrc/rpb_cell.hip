@@ -764,7 +764,7 @@ extern "C" int rpb_cell_wgrad(const float* gs, const float* x, float* part, long
     a.cm = CropMap{T, H, W, Tp, Hp, Wp};
     a.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
     hipStream_t st = (hipStream_t)stream;
-    if (rpb_cwx128_supported(ncell, CO, CI, crop)) return rpb_cwx128_launch(gs, x, part, ncell, slots, a.xf, st);     // csrc/rpb_cwx.hip
+    if (rpb_cwx128_supported(ncell, CO, CI, crop, W)) return rpb_cwx128_launch(gs, x, part, ncell, slots, a.xf, crop, a.cm, st);     // csrc/rpb_cwx.hip
 #define RPB_WG(O_, I_)                                                                         \
     if (CO == O_ && CI == I_) {                                                                \
         hipLaunchKernelGGL((cell_wgrad_kernel<O_, I_>), dim3(grid), dim3(512), 0, st, a);      \

@@ -50,5 +50,6 @@ long rpb_cmw_slots(long ncell, int Wp);            // partial rows of stats_part
 int rpb_cmw_launch(const CmxArgs& a, hipStream_t st);
 
 // csrc/rpb_cwx.hip: rpb_cell_wgrad's (CO, CI) = (128, 128) instance without the crop on the bf16 matrix pipe (width-128 Fourier layers)
-bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop);
-int rpb_cwx128_launch(const float* gs, const float* x, float* part, long ncell, long slots, const XForm& xf, hipStream_t st);
+bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop, int W);
+int rpb_cwx128_launch(const float* gs, const float* x, float* part, long ncell, long slots, const XForm& xf, int crop, const CropMap& cm,
+                      hipStream_t st);

@@ -52,6 +52,8 @@ struct CwxArgs {
     float* part;       // [2 * gridDim.x][128 * 128 + 128]
     long ncell;
     XForm xf;          // lazy BatchNorm (+ GELU) of x, or mean == null
+    int crop;          // cwx128s only: gs is [ncell = B T H W][128] over the CROP, x the padded [B Tp Hp Wp][128] tensor (fc1, fno.py:121); W % 32 == 0
+    CropMap cm;
 };
 
 __global__ __launch_bounds__(512) void cwx128_kernel(CwxArgs a) {
@@ -211,7 +213,15 @@ __global__ __launch_bounds__(256, 2) void cwx128s_kernel(CwxArgs a) {
     auto issue = [&](long t) {
         const long left = a.ncell - t * 32;
         const unsigned bytes = (unsigned)(left < 32 ? left : 32) * 512u;
-        const rsrc_t rx = make_rsrc(a.x + t * (32 * 128) + 64 * ih, bytes - 256u * (unsigned)ih);
+        long xc = t * 32;                        // first cell of the tile in x
+        if (a.crop) {                            // a tile of 32 crop cells lies inside one w-row (W % 32 == 0): its cells are consecutive in the padded tensor
+            const unsigned q = (unsigned)xc;     // ncell < 2^31 (rpb_cell_wgrad)
+            const unsigned row = q / (unsigned)a.cm.W, w0 = q - row * (unsigned)a.cm.W;
+            const unsigned r2 = row / (unsigned)a.cm.H, h = row - r2 * (unsigned)a.cm.H;
+            const unsigned b = r2 / (unsigned)a.cm.T, tt = r2 - b * (unsigned)a.cm.T;
+            xc = (((long)b * a.cm.Tp + tt) * a.cm.Hp + h) * (long)a.cm.Wp + w0;
+        }
+        const rsrc_t rx = make_rsrc(a.x + xc * 128 + 64 * ih, bytes - 256u * (unsigned)ih);
         const rsrc_t rg = make_rsrc(a.gs + t * (32 * 128) + 64 * oh, bytes - 256u * (unsigned)oh);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -313,21 +323,27 @@ __global__ __launch_bounds__(256, 2) void cwx128s_kernel(CwxArgs a) {
     }
 }
 
-bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop) {
+static bool cwx_shared_off() {
+    static const bool off = getenv("RPB_CWX_SHARED") && atoi(getenv("RPB_CWX_SHARED")) == 0;
+    return off;
+}
+// crop (the fc1 weight gradient: gs over the crop, x padded): the shared-plane kernel only, and only when a 32-cell tile cannot straddle w-rows
+bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop, int W) {
     static const bool off = getenv("RPB_CELL_WGRAD_128_F32") && atoi(getenv("RPB_CELL_WGRAD_128_F32")) == 1;     // the fp32-MFMA kernel
-    return !off && CO == 128 && CI == 128 && !crop && ncell > 0;
+    if (crop && (cwx_shared_off() || W <= 0 || W % 32 != 0)) return false;
+    return !off && CO == 128 && CI == 128 && ncell > 0;
 }
 
 // slots = partial rows the caller allocated (rpb_cell_wgrad_slots: even, two streams per workgroup)
-int rpb_cwx128_launch(const float* gs, const float* x, float* part, long ncell, long slots, const XForm& xf, hipStream_t st) {
+int rpb_cwx128_launch(const float* gs, const float* x, float* part, long ncell, long slots, const XForm& xf, int crop, const CropMap& cm,
+                      hipStream_t st) {
     RPB_REQUIRE(slots >= 2 && slots % 2 == 0, "cell_wgrad (bf16 pipe, C = 128): %ld partial rows", slots);
     CwxArgs a;
-    a.gs = gs; a.x = x; a.part = part; a.ncell = ncell; a.xf = xf;
-    static const bool shared_off = getenv("RPB_CWX_SHARED") && atoi(getenv("RPB_CWX_SHARED")) == 0;
-    if (!shared_off) {
+    a.gs = gs; a.x = x; a.part = part; a.ncell = ncell; a.xf = xf; a.crop = crop; a.cm = cm;
+    if (!cwx_shared_off()) {
         const int lds = 2 * 2 * 4 * 3 * 64 * 16;      // X and G planes of one tile
         hipLaunchKernelGGL(cwx128s_kernel, dim3((unsigned)slots), dim3(256), lds, st, a);
-        RPB_CHECK_LAUNCH("cell_wgrad(bf16x3, C = 128, shared input planes)");
+        RPB_CHECK_LAUNCH("cell_wgrad(bf16x3, C = 128, shared planes)");
     }
     hipLaunchKernelGGL(cwx128_kernel, dim3((unsigned)(slots / 2)), dim3(512), 0, st, a);
     RPB_CHECK_LAUNCH("cell_wgrad(bf16x3, C = 128)");

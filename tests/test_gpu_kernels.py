@@ -152,6 +152,32 @@ def test_cell_wgrad_crop(ops):
     assert rel_l2(part.double().sum(0).cpu()[:CO * CI].view(CO, CI), ref) < TOL
 
 
+@pytest.mark.parametrize("W,gelu", [(32, True), (64, False), (40, True)])
+def test_cell_wgrad_crop_c128(ops, W, gelu):
+    """fc1 weight gradient at width 128 (configs/fsi/fno.yaml): gs over the crop, x = act(bn(.)) of the padded tensor.  W % 32 == 0 runs
+    on the shared-plane bf16-pipe kernel (csrc/rpb_cwx.hip, tiles inside w-rows), anything else on the fp32 MFMA kernel."""
+    torch.manual_seed(W)
+    B, T, H, pad, C = 2, 3, 5, 6, 128
+    Tp, Hp, Wp = T + pad, H + pad, W + pad
+    gs = torch.randn(B, T, H, W, C, dtype=torch.float64)
+    xp = torch.randn(B, Tp, Hp, Wp, C, dtype=torch.float64)
+    mean, var = torch.randn(C, dtype=torch.float64) * 0.1, torch.rand(C, dtype=torch.float64) + 0.5
+    gamma, beta = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.1
+    invstd = (var + 1e-5).rsqrt()
+    a = (xp - mean) * invstd * gamma + beta
+    if gelu:
+        a = torch.nn.functional.gelu(a)
+    ref = torch.einsum("bthwo,bthwi->oi", gs, a[:, :T, :H, :W])
+    ncrop = B * T * H * W
+    slots = ops.cell_wgrad_slots(ncrop, C, C)
+    part = torch.zeros(slots, C * C + C, device="cuda")
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), gelu)
+    ops.cell_wgrad(dev(gs).view(-1, C), dev(xp).view(-1, C), part, ncrop, C, C, crop=True, crop6=(T, H, W, Tp, Hp, Wp), xf=xf)
+    got = part.double().sum(0).cpu()
+    assert rel_l2(got[:C * C].view(C, C), ref) < 3e-6
+    assert rel_l2(got[C * C:], gs.sum((0, 1, 2, 3))) < 3e-6
+
+
 @pytest.mark.parametrize("C,DO,W", [(64, 2, 7), (64, 2, 40), (64, 1, 16), (64, 4, 21), (32, 3, 7), (128, 5, 7), (64, 16, 7), (64, 16, 70),
                                     (64, 12, 40), (64, 5, 21)])
 def test_proj_fwd_bwd(ops, C, DO, W):
