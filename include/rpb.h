@@ -408,6 +408,16 @@ int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float* phi, float
                         const float* gamma, const float* beta, const float* sums, double count, int gelu, const float* GWt,
                         float* Y1, float* part, int G, int Wp, int C, int K2, int FW, void* stream);
 
+/*     Width 128 (configs/fsi/fno.yaml; the Galerkin SpectralRegressor): BatchNorm3d(+GELU) backward apply + adjoint W stage in one pass,
+ *     run as the C = 64 row kernel on each 64-channel half of the 512-byte rows (autograd of fno.py:117-119 and of the last inverse
+ *     stage, fno.py:63).  s, gy, gs: [G*Wp][128] (gs may alias gy); per-channel vectors [128]; sums [2*128]; Y1 [G][K2][128];
+ *     part: scratch of 2 * rpb_bn_bwd_row_slots(G) rows of 64*64+64 floats.  No weight gradient (rpb_cell_wgrad).  Added in round 5
+ *     (additions do not change RPB_ABI_VERSION). */
+int rpb_bn_bwd_row_c128_supported(int Wp, int K2);
+int rpb_bn_bwd_row_c128(const float* s, const float* gy, float* gs, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* sums, double count, int gelu, const float* GWt, float* Y1, float* part,
+                        int G, int Wp, int K2, void* stream);
+
 /* ---- backward of the projection head without the gu round trips (fno.py:121-125 autograd; C = 64, DO <= 4, W >= 16):
  *      gh = (fc2^T gout) * act'(fc1 a + b1) is recomputed on the bf16 matrix pipe by each consumer instead of being written once
  *      ([ncrop][128] fp32) and read twice.  `s` is the PADDED pre-BatchNorm tensor of the last Fourier layer, a = xf(s) on the

@@ -106,6 +106,8 @@ SIGNATURES = {
     "rpb_bn_bwd_reduce": (_I, "ppppppp" + "l" + "ii" + "p"),
     "rpb_bn_bwd_apply": (_I, "ppppppp" + "d" + "p" + "l" + "ii" + "p"),
     "rpb_bn_bwd_row_slots": (_L, "i"),
+    "rpb_bn_bwd_row_c128_supported": (_I, "ii"),
+    "rpb_bn_bwd_row_c128": (_I, "pppppppp" + "d" + "i" + "ppp" + "iii" + "p"),
     "rpb_bn_bwd_row": (_I, "ppppppppp" + "d" + "i" + "ppppi" + "ppp" + "iiii" + "p"),
     "rpb_proj_slots": (_L, "lii"),
     "rpb_proj_fwd": (_I, "pppppp" + "l" + "ii" + "iiiiii" + "ppppi" + "i" + "p"),

@@ -270,7 +270,7 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
         BwrArgs b;
         b.s = s; b.gy = gy; b.x = x; b.gs = gs; b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.sums = sums;
         b.inv_count = (float)(1.0 / count); b.gelu = gelu; b.xf = XForm{xf_mean, xf_invstd, xf_gamma, xf_beta, xf_gelu};
-        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = 0;
+        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = 0; b.CS = 64; b.coff = 0;
         return rpb_bwr_launch(b, rpb_bn_bwd_row_slots(G), (hipStream_t)stream);
     }
     BwdRowArgs a;
@@ -284,6 +284,30 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
     if (C == 32) hipLaunchKernelGGL((bwd_row_kernel<32>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((bwd_row_kernel<64>), dim3(grid), dim3(512), lds, st, a);
     RPB_CHECK_LAUNCH("bn_bwd_row");
+}
+
+// Width 128 (configs/fsi/fno.yaml, the Galerkin regressor): BatchNorm3d(+GELU) backward apply and the adjoint W stage in ONE pass over gy / s
+// instead of rpb_bn_bwd_apply + an rpb_axis_gemm that reads gs back -- the C = 64 row kernel run on each 64-channel half of the 512 B rows
+// (both consumers are per channel; a half row is 256 contiguous bytes).  No weight gradient here (rpb_cell_wgrad forms it, with the bias
+// gradient); `part`: 2 x rpb_bn_bwd_row_slots(G) rows of 64 * 64 + 64 floats of scratch (per half: [64] sum gs behind an unwritten block).
+extern "C" int rpb_bn_bwd_row_c128_supported(int Wp, int K2) { return rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0; }
+extern "C" int rpb_bn_bwd_row_c128(const float* s, const float* gy, float* gs, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, const float* sums, double count, int gelu, const float* GWt, float* Y1, float* part,
+                                   int G, int Wp, int K2, void* stream) {
+    RPB_REQUIRE(s && gy && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_c128: null pointer");
+    RPB_REQUIRE(G > 0 && count > 0 && rpb_bwr_supported(64, Wp, K2, 0), "bn_bwd_row_c128: unsupported G=%d Wp=%d K2=%d", G, Wp, K2);
+    RPB_REQUIRE((long)Wp * 512 < (1L << 31), "bn_bwd_row_c128: row too long");
+    const long rows = rpb_bn_bwd_row_slots(G);
+    for (int h = 0; h < 2; ++h) {
+        BwrArgs b;
+        b.s = s; b.gy = gy; b.x = nullptr; b.gs = gs;
+        b.mean = mean + 64 * h; b.invstd = invstd + 64 * h; b.gamma = gamma + 64 * h; b.beta = beta + 64 * h; b.sums = sums + 64 * h;
+        b.inv_count = (float)(1.0 / count); b.gelu = gelu; b.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+        b.GW = GWt; b.Y1 = Y1; b.part = part + h * rows * (64 * 64 + 64); b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = 0; b.CS = 128; b.coff = 64 * h;
+        const int rc = rpb_bwr_launch(b, rows, (hipStream_t)stream);
+        if (rc != RPB_OK) return rc;
+    }
+    return RPB_OK;
 }
 
 // layer 0 of FNO3d on the feature fields: as rpb_bn_bwd_row with x = Phi_c [G*Wp][FW] (rpb_lift_feat, FW = 8 or 32); the partial's
@@ -302,7 +326,7 @@ extern "C" int rpb_bn_bwd_row_feat(const float* s, const float* gy, const float*
         BwrArgs b;
         b.s = s; b.gy = gy; b.x = phi; b.gs = gs; b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.beta = beta; b.sums = sums;
         b.inv_count = (float)(1.0 / count); b.gelu = gelu; b.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
-        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = FW;
+        b.GW = GWt; b.Y1 = Y1; b.part = part; b.G = G; b.Wp = Wp; b.K2 = K2; b.FW = FW; b.CS = 64; b.coff = 0;
         return rpb_bwr_launch(b, rpb_bn_bwd_row_slots(G), (hipStream_t)stream);
     }
     BwdRowArgs a;

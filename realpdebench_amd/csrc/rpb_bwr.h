@@ -19,6 +19,8 @@ struct BwrArgs {
     float* Y1;             // [G][K2][64]
     float* part;           // [slots][64*64 + 64]
     int G, Wp, K2, FW;
+    int CS, coff;          // floats per cell row of s / gy / gs / Y1 (64; 128: one 64-channel half of a width-128 layer per launch, NOX only) and the half's first channel;
+                           // the per-channel vectors (mean .. sums) are passed already offset, the second moment sits CS floats behind the first
 };
 
 bool rpb_bwr_supported(int C, int Wp, int K2, int FW);

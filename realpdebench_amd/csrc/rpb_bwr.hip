@@ -64,8 +64,10 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // GELU: gy is multiplied by gelu'(z) here (the producer did not store gz);  XGELU / XBN: the layer input is act(BN(x));  FEAT: x is the
 // feature tensor (layer 0): the weight-gradient columns are its FW <= 16 fields;  NOX: no weight gradient here (a.x == null: the
 // backward cell_mix of the same layer forms it, csrc/rpb_cmw.hip) -- the layer input is not read at all: 12.4 instead of 16.2 GB
-template <bool GELU, bool XBN, bool XGELU, bool FEAT, bool NOX = false>
+// CS: floats per cell row (64; 128 = one 64-channel half of a width-128 layer per launch, NOX only: BwrArgs::CS / coff)
+template <bool GELU, bool XBN, bool XGELU, bool FEAT, bool NOX = false, int CS = 64>
 __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
+    static_assert(CS == 64 || NOX, "width 128: the launch without the weight gradient");
     extern __shared__ u32x4 lds4[];                     // GW^T planes [q][plane 3][mt 2][lane]: A operand of Y1 = GW^T gs  (rows = mode 16 mt + n16)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
     const f32x4v mu = *reinterpret_cast<const f32x4v*>(a.mean + c0), is = *reinterpret_cast<const f32x4v*>(a.invstd + c0);
     const f32x4v ga = *reinterpret_cast<const f32x4v*>(a.gamma + c0), be = *reinterpret_cast<const f32x4v*>(a.beta + c0);
     const f32x4v m1 = *reinterpret_cast<const f32x4v*>(a.sums + c0) * a.inv_count;
-    const f32x4v m2 = *reinterpret_cast<const f32x4v*>(a.sums + 64 + c0) * a.inv_count;
+    const f32x4v m2 = *reinterpret_cast<const f32x4v*>(a.sums + CS + c0) * a.inv_count;
     const f32x4v gis = ga * is;
     f32x4v xmu = {0.f, 0.f, 0.f, 0.f}, xis = xmu, xga = xmu, xbe = xmu;
     if (XBN) {
@@ -118,7 +120,9 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
 
     const long nslots = (long)gridDim.x * BW_WAVES;
     const long slot = (long)blockIdx.x * BW_WAVES + wave;
-    const unsigned row_bytes = (unsigned)Wp * 256u;
+    constexpr int CB = CS * 4;                           // width 128: rows of 512 B, this launch's 256 B half at byte 4 coff
+    const int coff = CS == 64 ? 0 : a.coff;
+    const unsigned row_bytes = (unsigned)Wp * (unsigned)CB - 4u * (unsigned)coff;
     const int FW = a.FW;
 
     // one step = 32 cells of a row: cell (kg, e) = 32 q + 4 e + kg.  Loads of step k + 1 are issued before step k is computed.
@@ -126,12 +130,12 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
     float fA[8], fB[8];                                  // FEAT: field n16 of the lane's 8 cells
     auto issue = [&](long g, int q, u32x4 (&sv)[8], u32x4 (&yv)[8], u32x4 (&xv)[8], float (&fv)[8]) {
         const bool ok = g < a.G;
-        const long off = (ok ? g : 0) * (long)Wp * 64;
+        const long off = (ok ? g : 0) * (long)Wp * CS + coff;
         const unsigned nb = ok ? row_bytes : 0u;         // past the wave's last row: an empty descriptor, the loads return 0 without traffic
         const rsrc_t rs = make_rsrc(a.s + off, nb), ry = make_rsrc(a.gy + off, nb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int vo = (32 * q + 4 * e + kg) * 256 + n16 * 16;
+            const int vo = (32 * q + 4 * e + kg) * CB + n16 * 16;
             sv[e] = ld16(rs, vo);
             yv[e] = ld16(ry, vo);
         }
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
         }
     };
     auto compute = [&](long g, int q, const u32x4 (&sv)[8], const u32x4 (&yv)[8], const u32x4 (&xv)[8], const float (&fv)[8]) {
-        const rsrc_t ro = make_rsrc(a.gs ? a.gs + g * (long)Wp * 64 : a.s, a.gs ? row_bytes : 0u);   // gs == NULL: stores dropped
+        const rsrc_t ro = make_rsrc(a.gs ? a.gs + g * (long)Wp * CS + coff : a.s, a.gs ? row_bytes : 0u);   // gs == NULL: stores dropped
         f32x4v gsv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
             f32x4v v = gis * ((gz - m1) - sh * m2);
             v = (32 * q + 4 * e + kg < Wp) ? v : z4;     // cells past the row end read zeros, which BatchNorm does not map to zero
             gsv[e] = v;
-            st16(v, ro, (32 * q + 4 * e + kg) * 256 + n16 * 16);          // past the row end: dropped by the descriptor
+            st16(v, ro, (32 * q + 4 * e + kg) * CB + n16 * 16);          // past the row end: dropped by the descriptor
             bsum += v;
         }
         bf16x8 Gh[4], Gm[4], Gl[4];                      // gs planes: column / row n16 of tile u <-> channel 4 n16 + u, K = the lane group's 8 cells
@@ -250,13 +254,13 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
             }
         }
         if (q == nq - 1) {                               // row complete: Y1[g][mode][channel], 16 B per lane
-            float* yp = a.Y1 + g * (long)K2 * 64 + 4 * n16;
+            float* yp = a.Y1 + g * (long)K2 * CS + coff + 4 * n16;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * mt + 4 * kg + r;
-                    if (o < K2) *reinterpret_cast<f32x4v*>(yp + (long)o * 64) = f32x4v{accY[mt][0][r], accY[mt][1][r], accY[mt][2][r], accY[mt][3][r]};
+                    if (o < K2) *reinterpret_cast<f32x4v*>(yp + (long)o * CS) = f32x4v{accY[mt][0][r], accY[mt][1][r], accY[mt][2][r], accY[mt][3][r]};
                 }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -343,8 +347,16 @@ int rpb_bwr_launch(const BwrArgs& a, long part_rows, hipStream_t st) {
     if (part_rows > slots)
         (void)hipMemsetAsync(a.part + slots * (64 * 64 + 64), 0, (size_t)(part_rows - slots) * (64 * 64 + 64) * 4, st);
     const int grid = (int)(slots / BW_WAVES);
+    RPB_REQUIRE(a.CS == 64 || (a.CS == 128 && !a.x && (a.coff == 0 || a.coff == 64)), "bn_bwd_row (bf16 pipe): row stride %d", a.CS);
     const size_t lds = (size_t)((a.Wp + 31) / 32) * 3 * 2 * 64 * 16;
     const bool gelu = a.gelu != 0, xbn = a.xf.mean != nullptr, xgelu = xbn && a.xf.gelu != 0, feat = a.FW > 0, nox = a.x == nullptr;
+    if (nox && a.CS == 128) {
+        (void)hipFuncSetAttribute((const void*)bwr_kernel<true, false, false, false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)bwr_kernel<false, false, false, false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (gelu) hipLaunchKernelGGL((bwr_kernel<true, false, false, false, true, 128>), dim3(grid), dim3(BW_WAVES * 64), lds, st, a);
+        else hipLaunchKernelGGL((bwr_kernel<false, false, false, false, true, 128>), dim3(grid), dim3(BW_WAVES * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("bn_bwd_row (bf16 pipe, width 128, one 64-channel half)");
+    }
     if (nox) {
         (void)hipFuncSetAttribute((const void*)bwr_kernel<true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)bwr_kernel<false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -149,6 +149,12 @@ class _Workspace:
             self.proj_rows = ops.proj_slots(d.ncrop, C, model.dim_out)
             self.proj_part = torch.empty(self.proj_rows * (model.dim_out * HID + HID + model.dim_out), **f)
             self.fused_bwd = C <= 64             # rpb_bn_bwd_row: BN-backward apply + adjoint W stage + conv wgrad in one pass
+            # width 128: BN-backward apply + adjoint W stage in one pass as two 64-channel half launches of the C = 64 row kernel
+            # (rpb_bn_bwd_row_c128; the weight gradient stays with rpb_cell_wgrad).  RPB_BWD_ROW_128=0: bn_bwd_apply + axis_gemm.
+            self.row128 = (C == 128 and os.environ.get("RPB_BWD_ROW_128", "1") != "0"
+                           and ops.bn_bwd_row_c128_supported(d.Wp, 2 * plan.KW))
+            if self.row128:
+                self.row128_part = torch.empty(2 * ops.bn_bwd_row_slots(B * d.Tp * d.Hp) * (64 * 64 + 64), **f)
             self.wg_rows_c = (ops.bn_bwd_row_slots(B * d.Tp * d.Hp) if self.fused_bwd
                               else ops.cell_wgrad_slots(d.ncell, C, C))
             self.wg_rows_p = ops.cell_wgrad_slots(d.ncrop, HID, C)
@@ -639,6 +645,10 @@ class FNO3d(Model):
                 ops.bn_bwd_row(ws.S[l], g, None if wg_later else a_in, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums,
                                float(d.ncell) * world, gelu, xf_in, plan.GW, ws.Y1, ws.wg_part, d.B * d.Tp * d.Hp,
                                d.Wp, C, 2 * plan.KW)
+            elif ws.row128:
+                ops.bn_bwd_row_c128(ws.S[l], g, g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world, gelu,
+                                    plan.GW, ws.Y1, ws.row128_part, d.B * d.Tp * d.Hp, d.Wp, 2 * plan.KW)
+                ops.cell_wgrad(g, a_in, ws.wg_part, d.ncell, C, C, xf=xf_in)
             else:
                 ops.bn_bwd_apply(ws.S[l], g, ws.mean[l], ws.invstd[l], gam, bet, ws.bn_sums, float(d.ncell) * world,
                                  g, d.ncell, C, gelu)
@@ -652,7 +662,7 @@ class FNO3d(Model):
                 self._reduce_cols(partc, 0, C * C, GP(f"convs.{l}.weight"))
             self._reduce_cols(partc, C * C, C, GP(f"convs.{l}.bias"))
             # spectral branch: G^ = adjoint of the inverse stages applied to gs
-            self._spectral_forward_stages(g, ws, ws.Yh, (None if ws.fused_bwd else plan.GW, plan.GH, plan.GT),
+            self._spectral_forward_stages(g, ws, ws.Yh, (None if (ws.fused_bwd or ws.row128) else plan.GW, plan.GH, plan.GT),
                                           first_layer=False)
             ops.mode_contract_wgrad(ws.Xh[l], ws.Yh, GP(f"spec.{l}"), d.B, plan.M, C)
             if self.dp is not None:                          # layer l's 100 MB bucket overlaps the rest of backward

@@ -355,6 +355,18 @@ def bn_bwd_row(s, gy, x, gs, mean, invstd, gamma, beta, sums, count, gelu, xf, G
               flops=2 * ncell * C * ((0 if nox else C) + K2))
 
 
+def bn_bwd_row_c128_supported(Wp, K2):
+    return bool(_lib.query("rpb_bn_bwd_row_c128_supported", Wp, K2))
+
+
+def bn_bwd_row_c128(s, gy, gs, mean, invstd, gamma, beta, sums, count, gelu, GWt, Y1, part, G, Wp, K2):
+    """Width 128: BatchNorm(+GELU) backward apply + adjoint W stage in one pass (two 64-channel half launches of the C = 64 row kernel)."""
+    ncell, C = G * Wp, 128
+    _lib.call("rpb_bn_bwd_row_c128", _p(s), _p(gy), _p(gs), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(sums), float(count), int(gelu),
+              _p(GWt), _p(Y1), _p(part), G, Wp, K2, _stream(),
+              label=f"bn_bwd_row[C128,gelu={int(gelu)},nox]", nbytes=4 * (3 * ncell * C + G * K2 * C), flops=2 * ncell * C * K2)
+
+
 def proj_slots(ncrop, C, DO):
     return _lib.query("rpb_proj_slots", ncrop, C, DO)
 

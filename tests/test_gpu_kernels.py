@@ -633,6 +633,37 @@ def test_bn_bwd_row_on_the_feature_fields(ops, store_gs):
     assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
 
 
+@pytest.mark.parametrize("gelu,Wp", [(True, 70), (False, 38)])
+def test_bn_bwd_row_width_128(ops, gelu, Wp):
+    """rpb_bn_bwd_row_c128 (width 128: two 64-channel half launches of the C = 64 row kernel over 512-byte rows) in fp64 terms: the
+    BatchNorm(+GELU) backward apply, in place, and the adjoint W stage Y1 = GW^T gs."""
+    torch.manual_seed(128 + Wp)
+    C, G, K2 = 128, 13, 32
+    ncell = G * Wp
+    f8 = dict(dtype=torch.float64)
+    s = torch.randn(ncell, C, **f8) * 1.3 + 0.2
+    gy = torch.randn(ncell, C, **f8)
+    mean, invstd = s.mean(0), 1 / torch.sqrt(s.var(0, unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, **f8) + 0.5, torch.randn(C, **f8) * 0.3
+    sh = (s - mean) * invstd
+    gz = gy
+    if gelu:
+        z = (sh * gamma + beta).requires_grad_(True)
+        torch.nn.functional.gelu(z).backward(gy)
+        gz = z.grad
+    sums = torch.cat([gz.sum(0), (gz * sh).sum(0)])
+    gs_ref = gamma * invstd * (gz - sums[:C] / ncell - sh * sums[C:] / ncell)
+    GWt = torch.randn(K2, Wp, **f8)
+    assert ops.bn_bwd_row_c128_supported(Wp, K2)
+    g = dev(gy)
+    Y1 = torch.full((G, K2, C), float("nan"), device="cuda")
+    part = torch.empty(2 * ops.bn_bwd_row_slots(G) * (64 * 64 + 64), device="cuda")
+    ops.bn_bwd_row_c128(dev(s), g, g, dev(mean), dev(invstd), dev(gamma), dev(beta), dev(sums), ncell, gelu, dev(GWt.t()), Y1, part,
+                        G, Wp, K2)
+    assert rel_l2(g.cpu(), gs_ref) < 5e-6
+    assert rel_l2(Y1.cpu(), torch.einsum("ok,gkc->goc", GWt, gs_ref.view(G, Wp, C))) < 5e-6
+
+
 def _bf16_ulps(a, b):
     """|a - b| in units of the bf16 spacing at |b| (both bf16 tensors)."""
     a, b = a.float(), b.float()
