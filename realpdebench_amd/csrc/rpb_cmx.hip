@@ -70,6 +70,10 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #define CMX_WAVES_B 8
 #endif
 #define CMX_WAVES_OF(STATS) ((STATS) == 2 ? CMX_WAVES_B : CMX_WAVES_A)
+#ifndef CMX_PF2_BF
+#define CMX_PF2_BF 0    /* the same for the bf16-storage instances (half the bytes per tile in flight).  Measured (round 5, tools/fwd_probe.py 16 comb_bf16):
+                           eval + fused W stage 0.577 -> 0.60 ms, crop-only 0.270 -> 0.278: slower (the static line walk it needs loses more) */
+#endif
 #ifndef CMX_PF2
 #define CMX_PF2 0    /* 1: x tiles requested TWO wave tiles ahead where registers allow.  Measured (round 4, tools/kbench.py, B = 32): no change --
                         forward + stats 1.84-1.87 ms (1.80-1.86 one tile ahead), with the lazy GELU 2.18-2.24 (2.16-2.19), eval 1.83 (1.80-1.83):
@@ -216,7 +220,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     //      Mode 2 claims from ONE counter in HBM (device-scope atomic, a line ahead of its use): that also evens out the workgroups
     //      (those on odd XCDs run 3-8 % slower than those on even ones).
     __shared__ int claim_s;
-    const int DYN = (WG || (CMX_PF2 && !DFT && !BF && STATS != 2)) ? 0 : ((C2 && a.claim_mode == 2) ? 1 : a.claim_mode);   // C2: both halves walk the workgroup pair's own lines
+    const int DYN = (WG || (CMX_PF2 && !DFT && !BF && STATS != 2) || (CMX_PF2_BF && BF)) ? 0 : ((C2 && a.claim_mode == 2) ? 1 : a.claim_mode);   // C2: both halves walk the workgroup pair's own lines
     if (DYN == 1 && tid == 0) claim_s = CMX_WAVES;
     __syncthreads();
 
@@ -364,7 +368,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
 
     // PF2 (compile-time experiment, off: see CMX_PF2): the x tiles requested TWO wave tiles ahead (two register images, the tile loop
     // unrolled by two) -- 128 instead of 64 KB of loads in flight per CU.  Not for STATS == 2 / the fused W stage (no registers left).
-    constexpr bool PF2 = CMX_PF2 && !DFT && !BF && STATS != 2 && !C2;
+    constexpr bool PF2 = (CMX_PF2 && !DFT && !BF && STATS != 2 && !C2) || (CMX_PF2_BF && BF);
     u32x4 xaA[2][4], xaB[2][4];
     // loads i = 2 ks, 2 ks + 1 of MFMA tile j (its A operand of K-step ks) of wave tile q of line g
     auto issue_x = [&](u32x4 (&xa)[2][4], long g, int q, int j, int ks) {
