@@ -290,12 +290,12 @@ extern "C" int rpb_bn_bwd_row(const float* s, const float* gy, const float* x, f
 // instead of rpb_bn_bwd_apply + an rpb_axis_gemm that reads gs back -- the C = 64 row kernel run on each 64-channel half of the 512 B rows
 // (both consumers are per channel; a half row is 256 contiguous bytes).  No weight gradient here (rpb_cell_wgrad forms it, with the bias
 // gradient); `part`: 2 x rpb_bn_bwd_row_slots(G) rows of 64 * 64 + 64 floats of scratch (per half: [64] sum gs behind an unwritten block).
-extern "C" int rpb_bn_bwd_row_c128_supported(int Wp, int K2) { return rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0; }
+extern "C" int rpb_bn_bwd_row_c128_supported(int Wp, int K2) { return rpb_bwr_supported_c128(Wp, K2) ? 1 : 0; }
 extern "C" int rpb_bn_bwd_row_c128(const float* s, const float* gy, float* gs, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, const float* sums, double count, int gelu, const float* GWt, float* Y1, float* part,
                                    int G, int Wp, int K2, void* stream) {
     RPB_REQUIRE(s && gy && gs && mean && invstd && gamma && beta && sums && GWt && Y1 && part, "bn_bwd_row_c128: null pointer");
-    RPB_REQUIRE(G > 0 && count > 0 && rpb_bwr_supported(64, Wp, K2, 0), "bn_bwd_row_c128: unsupported G=%d Wp=%d K2=%d", G, Wp, K2);
+    RPB_REQUIRE(G > 0 && count > 0 && rpb_bwr_supported_c128(Wp, K2), "bn_bwd_row_c128: unsupported G=%d Wp=%d K2=%d", G, Wp, K2);
     RPB_REQUIRE((long)Wp * 512 < (1L << 31), "bn_bwd_row_c128: row too long");
     const long rows = rpb_bn_bwd_row_slots(G);
     for (int h = 0; h < 2; ++h) {

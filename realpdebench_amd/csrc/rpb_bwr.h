@@ -24,5 +24,6 @@ struct BwrArgs {
 };
 
 bool rpb_bwr_supported(int C, int Wp, int K2, int FW);
+bool rpb_bwr_supported_c128(int Wp, int K2);
 long rpb_bwr_slots(int G);
 int rpb_bwr_launch(const BwrArgs& a, long part_rows, hipStream_t st);

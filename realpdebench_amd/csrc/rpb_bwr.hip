@@ -65,17 +65,18 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // feature tensor (layer 0): the weight-gradient columns are its FW <= 16 fields;  NOX: no weight gradient here (a.x == null: the
 // backward cell_mix of the same layer forms it, csrc/rpb_cmw.hip) -- the layer input is not read at all: 12.4 instead of 16.2 GB
 // CS: floats per cell row (64; 128 = one 64-channel half of a width-128 layer per launch, NOX only: BwrArgs::CS / coff)
-template <bool GELU, bool XBN, bool XGELU, bool FEAT, bool NOX = false, int CS = 64>
+// MT: 16-mode row tiles of Y1 (2: K2 <= 32; 3: K2 <= 48, the Galerkin regressor's modes (4, 16, 20) -> K2 = 40)
+template <bool GELU, bool XBN, bool XGELU, bool FEAT, bool NOX = false, int CS = 64, int MT = 2>
 __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
     static_assert(CS == 64 || NOX, "width 128: the launch without the weight gradient");
-    extern __shared__ u32x4 lds4[];                     // GW^T planes [q][plane 3][mt 2][lane]: A operand of Y1 = GW^T gs  (rows = mode 16 mt + n16)
+    extern __shared__ u32x4 lds4[];                     // GW^T planes [q][plane 3][mt MT][lane]: A operand of Y1 = GW^T gs  (rows = mode 16 mt + n16)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;
     const int Wp = a.Wp, K2 = a.K2;
     const int nq = (Wp + 31) >> 5;
-    for (int idx = tid; idx < nq * 2 * 64; idx += blockDim.x) {
-        const int l = idx & 63, mt = (idx >> 6) & 1, q = idx >> 7;
+    for (int idx = tid; idx < nq * MT * 64; idx += blockDim.x) {
+        const int l = idx & 63, mt = (idx >> 6) % MT, q = (idx >> 6) / MT;
         const int o = 16 * mt + (l & 15);
         float v[8];
 #pragma unroll
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
         }
         bf16x8 h, m, lo;
         split8(v, h, m, lo);
-        lds4[((q * 3 + 0) * 2 + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
-        lds4[((q * 3 + 1) * 2 + mt) * 64 + l] = __builtin_bit_cast(u32x4, m);
-        lds4[((q * 3 + 2) * 2 + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+        lds4[((q * 3 + 0) * MT + mt) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        lds4[((q * 3 + 1) * MT + mt) * 64 + l] = __builtin_bit_cast(u32x4, m);
+        lds4[((q * 3 + 2) * MT + mt) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
     __syncthreads();
 
@@ -107,14 +108,14 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
     }
     const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4v accW[4][(FEAT || NOX) ? 1 : 4];               // d conv weight: tile (uo, ui): row 4 mg + r <-> out channel 4 (4 mg + r) + uo, column n16 <-> in channel 4 n16 + ui (FEAT: field n16)
-    f32x4v accY[2][4];                                   // Y1 of the current row: row 16 mt + 4 mg + r = mode, column n16 of tile u <-> channel 4 n16 + u
+    f32x4v accY[MT][4];                                   // Y1 of the current row: row 16 mt + 4 mg + r = mode, column n16 of tile u <-> channel 4 n16 + u
     f32x4v bsum = z4;
 #pragma unroll
     for (int uo = 0; uo < 4; ++uo)
 #pragma unroll
         for (int ui = 0; ui < ((FEAT || NOX) ? 1 : 4); ++ui) accW[uo][ui] = z4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int u = 0; u < 4; ++u) accY[mt][u] = z4;
 
@@ -175,10 +176,10 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
         }
         // ---- Y1[mode][channel] += GW^T gs
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 0) * 2 + mt) * 64 + lane]);
-            const bf16x8 am = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 1) * 2 + mt) * 64 + lane]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 2) * 2 + mt) * 64 + lane]);
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 0) * MT + mt) * 64 + lane]);
+            const bf16x8 am = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 1) * MT + mt) * 64 + lane]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, lds4[((q * 3 + 2) * MT + mt) * 64 + lane]);
 #define BW_ACC(c) accY[mt][c]
 #define BW_A1(c) ah
 #define BW_A2(c) am
@@ -256,14 +257,14 @@ __global__ __launch_bounds__(BW_WAVES * 64, 1) void bwr_kernel(BwrArgs a) {
         if (q == nq - 1) {                               // row complete: Y1[g][mode][channel], 16 B per lane
             float* yp = a.Y1 + g * (long)K2 * CS + coff + 4 * n16;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * mt + 4 * kg + r;
                     if (o < K2) *reinterpret_cast<f32x4v*>(yp + (long)o * CS) = f32x4v{accY[mt][0][r], accY[mt][1][r], accY[mt][2][r], accY[mt][3][r]};
                 }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) accY[mt][u] = z4;
         }
@@ -328,6 +329,10 @@ static bool bwr_off() {
     return off;
 }
 
+// K2 in 33 .. 48: three 16-mode row tiles, the width-128 half launches only (rpb_bwr_supported_c128)
+bool rpb_bwr_supported_c128(int Wp, int K2) {
+    return rpb_bwr_supported(64, Wp, K2 <= 32 ? K2 : 32, 0) && K2 >= 1 && K2 <= 48 && (size_t)((Wp + 31) / 32) * 9 * 1024 <= 150 * 1024;
+}
 bool rpb_bwr_supported(int C, int Wp, int K2, int FW) {
     return !bwr_off() && C == 64 && K2 >= 1 && K2 <= 32 && Wp >= 1 && (long)Wp * 256 < (1L << 30) && FW >= 0 && FW <= 16 &&
            (size_t)((Wp + 31) / 32) * 6 * 1024 <= 150 * 1024;
@@ -348,8 +353,17 @@ int rpb_bwr_launch(const BwrArgs& a, long part_rows, hipStream_t st) {
         (void)hipMemsetAsync(a.part + slots * (64 * 64 + 64), 0, (size_t)(part_rows - slots) * (64 * 64 + 64) * 4, st);
     const int grid = (int)(slots / BW_WAVES);
     RPB_REQUIRE(a.CS == 64 || (a.CS == 128 && !a.x && (a.coff == 0 || a.coff == 64)), "bn_bwd_row (bf16 pipe): row stride %d", a.CS);
-    const size_t lds = (size_t)((a.Wp + 31) / 32) * 3 * 2 * 64 * 16;
+    const int mt = a.K2 > 32 ? 3 : 2;
+    RPB_REQUIRE(mt == 2 || (a.CS == 128 && a.K2 <= 48), "bn_bwd_row (bf16 pipe): K2 = %d", a.K2);
+    const size_t lds = (size_t)((a.Wp + 31) / 32) * 3 * mt * 64 * 16;
     const bool gelu = a.gelu != 0, xbn = a.xf.mean != nullptr, xgelu = xbn && a.xf.gelu != 0, feat = a.FW > 0, nox = a.x == nullptr;
+    if (nox && a.CS == 128 && mt == 3) {
+        (void)hipFuncSetAttribute((const void*)bwr_kernel<true, false, false, false, true, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)bwr_kernel<false, false, false, false, true, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (gelu) hipLaunchKernelGGL((bwr_kernel<true, false, false, false, true, 128, 3>), dim3(grid), dim3(BW_WAVES * 64), lds, st, a);
+        else hipLaunchKernelGGL((bwr_kernel<false, false, false, false, true, 128, 3>), dim3(grid), dim3(BW_WAVES * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("bn_bwd_row (bf16 pipe, width 128, one 64-channel half, K2 <= 48)");
+    }
     if (nox && a.CS == 128) {
         (void)hipFuncSetAttribute((const void*)bwr_kernel<true, false, false, false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)bwr_kernel<false, false, false, false, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

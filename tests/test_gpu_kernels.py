@@ -633,12 +633,12 @@ def test_bn_bwd_row_on_the_feature_fields(ops, store_gs):
     assert float((tot[C * C:] - gs_ref.sum(0)).abs().max()) < 1e-4 * float(gs_ref.abs().sum(0).max())
 
 
-@pytest.mark.parametrize("gelu,Wp", [(True, 70), (False, 38)])
-def test_bn_bwd_row_width_128(ops, gelu, Wp):
+@pytest.mark.parametrize("gelu,Wp,K2", [(True, 70, 32), (False, 38, 32), (False, 134, 40), (True, 45, 48)])
+def test_bn_bwd_row_width_128(ops, gelu, Wp, K2):
     """rpb_bn_bwd_row_c128 (width 128: two 64-channel half launches of the C = 64 row kernel over 512-byte rows) in fp64 terms: the
     BatchNorm(+GELU) backward apply, in place, and the adjoint W stage Y1 = GW^T gs."""
-    torch.manual_seed(128 + Wp)
-    C, G, K2 = 128, 13, 32
+    torch.manual_seed(128 + Wp)          # K2 > 32 (the Galerkin regressor's modes (4, 16, 20)): three 16-mode row tiles
+    C, G = 128, 13
     ncell = G * Wp
     f8 = dict(dtype=torch.float64)
     s = torch.randn(ncell, C, **f8) * 1.3 + 0.2
