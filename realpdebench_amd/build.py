@@ -18,7 +18,7 @@ FLAGS = (["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # rpb_pjx.hip (the eval head rpb_proj_fwd): packed fp32 off -- measured 1.50 -> 1.37 ms (packed fp32 instructions wait for the matrix pipe;
 # the same flag costs the wave-pair weight-gradient cell_mix 8 %, so rpb_cmx.hip keeps its packed forms: profiles/r05_kbench_nopk_ab.txt)
 NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA = {"rpb_pjg.hip": ["-fno-slp-vectorize"], "rpb_pjx.hip": NOPK}
+EXTRA = {"rpb_pjg.hip": ["-fno-slp-vectorize"], "rpb_pjx.hip": NOPK, "rpb_pjh.hip": NOPK + ["-fno-slp-vectorize"]}
 
 
 def sources():

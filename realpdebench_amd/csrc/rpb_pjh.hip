@@ -1,0 +1,345 @@
+// The projection head's FORWARD for evaluation / rollout (fno.py:121-125: out = fc2 gelu(fc1 a + b1) + b2 on the cropped cells,
+// a = BN(s_{L-1}) applied while loading) -- third organisation ("pjh"), the default for fc2 widths <= 4 with fp32 storage.
+//
+// rpb_pjx.hip's forward (16x16x32 tiles, lane = cell) spends per 32 cells 192 MFMA issues, 96 LDS reads of weight planes and ~1 900
+// vector instructions, 17 of them per GELU: 1.37-1.42 ms at the headline shape for 2.77 GB (0.24 of the HBM peak, the worst kernel of the
+// rollout).  This kernel applies the rules DESIGN.md section 4.0000 read off tools/ubench/issue_probe.hip, and the forward half of rpb_pjg.hip:
+//
+//   * u = (s - mean) W1'^T on v_mfma_f32_32x32x16_bf16 (cells = rows: 96 MFMAs and 48 LDS reads per 32-cell tile), W1' = W1 diag(gamma invstd)
+//     and b1' = b1 + W1 beta formed per workgroup while the planes are staged: BatchNorm costs one subtraction per element;
+//   * two waves per SIMD (two workgroups of four waves per CU, 49 KB of LDS each): a wave alone issues one vector instruction per ~5 cycles,
+//     two issue one per 2.6; the weight planes of a K-step live in 48 registers (one buffer per plane kind, refilled behind its last use)
+//     instead of pjg's 96, so that the wave fits 256 registers;
+//   * every vector instruction in its scalar form (the file is compiled without packed fp32: a v_pk_* waits for the partner wave's MFMAs);
+//   * the bias rides in the two affine uses of u inside GELU (x / sqrt 2 and x / 2 become FMAs with per-lane constants): 14 instructions
+//     + one exponential per value (the sign transfer of erf is the |.| source modifier of the last FMA), same polynomial as fast_erf (rpb_common.h);
+//   * fc2 (DOT = 2 or 4 outputs, padded): DOT FMAs per value into 16 DOT per-lane partials, then the halving butterfly of rpb_pjg.hip over the 32 lanes of a half
+//     (v_permlane16_swap, row_mirror, row_half_mirror, two quad_perm adds): lane n ends with elements (DOT / 2) n .. = (cell, output) of the tile -- one
+//     or two dword stores per lane, contiguous over the wave.
+//
+// Layouts as in rpb_pjg.hip (32x32x16: A lane (m = l & 31, kg = l >> 5) holds k = 8 kg + e; D register r of lane (n, hg) is row
+// 8 (r >> 2) + 4 hg + (r & 3), column n).
+#include "rpb_pjx.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+#define PH_HID 128
+#define PH_WAVES 4
+// PH_PIPE = n > 0: ask the scheduler for n vector instructions behind every MFMA of contraction 1 (0: its own order)
+#ifndef PH_PIPE
+#define PH_PIPE 2
+#endif
+
+namespace {
+__device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float asf(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+// three-plane truncation split of 8 values (rpb_cmx.hip): v = h + m + l to 2^-24, each plane exact in bf16
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    u32x4 uh, um, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        uh[q] = pack_hi(a, b);
+        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
+        um[q] = pack_hi(ra, rb);
+        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
+        ul[q] = pack_hi(sa, sb);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    m = __builtin_bit_cast(bf16x8, um);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x16v mfma32(bf16x8 a, bf16x8 b, f32x16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// gelu(a + b) with the bias folded into the two affine uses of u: bs = b / sqrt 2, hb = b / 2.  The erf is fast_erf's (rpb_common.h):
+// erf(x) = sign(x) (1 - 2^(t S(t))), t = min(|x|, 4)
+__device__ __forceinline__ float gelu_bias(float a, float bs, float hb) {
+    const float xs = __builtin_fmaf(a, 0.70710678118654752440f, bs);
+    const float t = fminf(fabsf(xs), 4.0f);
+    float p = 1.160457393e-05f;
+    p = __builtin_fmaf(p, t, -1.529619341e-04f);
+    p = __builtin_fmaf(p, t, 8.482242992e-04f);
+    p = __builtin_fmaf(p, t, -2.274763673e-03f);
+    p = __builtin_fmaf(p, t, 8.477856228e-05f);
+    p = __builtin_fmaf(p, t, 2.772449465e-02f);
+    p = __builtin_fmaf(p, t, -1.483079179e-01f);
+    p = __builtin_fmaf(p, t, -9.184428993e-01f);
+    p = __builtin_fmaf(p, t, -1.627907267e+00f);
+    const float e = __builtin_amdgcn_exp2f(p * t);
+    const float hx = __builtin_fmaf(a, 0.5f, hb);          // x / 2 has the sign of x / sqrt 2:  hx erf(xs) = |hx| (1 - e)
+    return __builtin_fmaf(fabsf(hx), 1.0f - e, hx);
+}
+__device__ __forceinline__ float dpp_add(float x, float y, const int ctrl) {           // x + y from the lane the DPP control names
+    switch (ctrl) {
+    case 0: return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x140, 0xF, 0xF, true));   // row_mirror
+    case 1: return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    case 2: return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    default: return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    }
+}
+}  // namespace
+
+struct PjhFwdArgs {
+    const float* s;       // padded tensor of the last Fourier layer [B*Tp*Hp*Wp][64]
+    const float* w1;      // fc1.weight [128][64]
+    const float* b1;      // [128]
+    const float* w2;      // fc2.weight [DO][128]
+    const float* b2;      // [DO]
+    float* out;           // [ncrop][DO]
+    int B, DO;
+    CropMap cm;
+    XForm xf;             // BatchNorm of the last layer (mean == nullptr: plain tensor); gelu must be 0
+};
+
+// DOT: fc2 outputs padded to 2 or 4 (DO = 1 .. DOT of them are real; the others carry zero weights and are not stored)
+template <int DOT>
+__global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p) {
+    constexpr int NV = 16 * DOT;                         // fc2 partials per lane: [register row r][output j] = element DOT r + j
+    constexpr int EPL = NV / 32;                         // elements a lane owns after the butterfly: element EPL n + k
+    extern __shared__ u32x4 lds4[];
+    u32x4* W1B = lds4;                                   // [ks 4][nt 4][plane 3][lane]   B of u:   W1'[32 nt + n][16 ks + 8 kg + e]
+    float* b1l = reinterpret_cast<float*>(W1B + 4 * 4 * 3 * 64);          // [128]  b1' = b1 + W1 beta
+    float* meanl = b1l + PH_HID;                         // [64]   BatchNorm mean
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hg = lane >> 5;
+    const bool has_xf = p.xf.mean != nullptr;
+    for (int idx = tid; idx < 4 * 4 * 64; idx += blockDim.x) {
+        const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * (l >> 5) + e;
+            const float w = p.w1[(32 * nt + (l & 31)) * 64 + c];
+            v[e] = has_xf ? w * (p.xf.gamma[c] * p.xf.invstd[c]) : w;
+        }
+        bf16x8 h, m, lo;
+        split8(v, h, m, lo);
+        W1B[((ks * 4 + nt) * 3 + 0) * 64 + l] = __builtin_bit_cast(u32x4, h);
+        W1B[((ks * 4 + nt) * 3 + 1) * 64 + l] = __builtin_bit_cast(u32x4, m);
+        W1B[((ks * 4 + nt) * 3 + 2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
+    }
+    for (int h = tid; h < PH_HID; h += blockDim.x) {
+        float a = p.b1[h];
+        if (has_xf)
+            for (int c = 0; c < 64; ++c) a = __builtin_fmaf(p.w1[h * 64 + c], p.xf.beta[c], a);
+        b1l[h] = a;
+    }
+    if (tid < 64) meanl[tid] = has_xf ? p.xf.mean[tid] : 0.f;
+    __syncthreads();
+
+    const CropMap cm = p.cm;
+    const long nslots = (long)gridDim.x * PH_WAVES;
+    const long slot = (long)blockIdx.x * PH_WAVES + wave;
+    const long GL = (long)p.B * cm.T * cm.H;
+    const int TQ = (cm.W + 31) >> 5;
+    // per-lane constants: hidden unit 32 nt + n
+    const int DO = p.DO;
+    float bs[4], hb[4], w2r[DOT][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float b = b1l[32 * nt + n];
+        bs[nt] = b * 0.70710678118654752440f;
+        hb[nt] = 0.5f * b;
+#pragma unroll
+        for (int j = 0; j < DOT; ++j) w2r[j][nt] = j < DO ? p.w2[j * PH_HID + 32 * nt + n] : 0.f;
+    }
+    float meanr[32];                                     // BatchNorm mean of the lane's channels 16 ks + 8 hg + e  [8 ks + e]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) meanr[i] = meanl[16 * (i >> 3) + 8 * hg + (i & 7)];
+    // the lane's own output elements after the cross-lane reduction: EPL n + k = DOT ry + j -> register row ry = cell 8 (ry >> 2) + 4 hg + (ry & 3)
+    const int ry = (EPL * n) / DOT, jy = (EPL * n) % DOT;
+    const int celly = 8 * (ry >> 2) + 4 * hg + (ry & 3);
+    float b2y[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) b2y[k] = jy + k < DO ? p.b2[jy + k] : 0.f;
+    const bool bit3 = (n >> 3) & 1, bit2 = (n >> 2) & 1, bit1 = (n >> 1) & 1, bit0 = n & 1;
+
+    auto line_of = [&](int gl) {                         // cropped line -> padded line (32-bit: B * Tp * Hp lines)
+        const unsigned h = (unsigned)gl % (unsigned)cm.H, r2 = (unsigned)gl / (unsigned)cm.H;
+        return (int)(((r2 / (unsigned)cm.T) * cm.Tp + r2 % (unsigned)cm.T) * cm.Hp + h);
+    };
+    u32x4 xa[8];                                         // A layout: cell 32 q + n, channels 16 ks + 8 hg + 4 half ..   [2 ks + half]
+    auto issue_pair = [&](int pl, int q, int ks) {       // (past the wave's last tile the descriptor is empty: loads return 0, no branches)
+        const bool ok = pl >= 0;
+        const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * 64, ok ? (unsigned)cm.W * 256u : 0u);   // cells >= W read as 0
+        xa[2 * ks] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32);
+        xa[2 * ks + 1] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32 + 16);
+    };
+    {
+        const int pl0 = slot < GL ? line_of((int)slot) : -1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) issue_pair(pl0, 0, ks);
+    }
+    // weight planes of a K-step: one buffer per plane kind, refilled behind its last use (those of K-step 0 are loaded for the NEXT tile
+    // behind the last products of this one)
+    bf16x8 BL[4], BM[4], BH[4];
+#define PH_LOADB(DST, KS, PLANE) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) DST[nt_] = __builtin_bit_cast(bf16x8, W1B[(((KS) * 4 + nt_) * 3 + (PLANE)) * 64 + lane]);
+    PH_LOADB(BL, 0, 2)
+    PH_LOADB(BM, 0, 1)
+    PH_LOADB(BH, 0, 0)
+#ifdef PH_TIMING   /* timing-only build: the wave's shader cycles and 100 MHz ticks over its tile loop land in out[2 slot ..] (tools/dbg/pjh_clock.py) */
+    const long long tc0 = clock64(), tw0 = wall_clock64();
+#endif
+    // (lines are dealt statically.  Claimed chip-wide from a counter -- built and measured with -DPH_TIMING: every wave then ends within 4 %
+    // of the mean instead of 0.8 .. 1.2 of it, and the launch takes the same 1.57 ms: a workgroup that finishes early leaves its CU to its
+    // partner, which speeds up; the bound is per CU, not per wave)
+    for (long gl = slot; gl < GL;) {
+        const int pl = line_of((int)gl);
+        const long gnext = gl + nslots;
+        const int gln = gnext < GL ? (int)gnext : -1;
+        const int pln = gln >= 0 ? line_of(gln) : -1;
+        const rsrc_t rgo = make_rsrc(p.out + gl * cm.W * DO, (unsigned)(cm.W * DO) * 4u);
+        for (int q = 0; q < TQ; ++q) {
+            asm volatile("" ::: "memory");
+            const bool last = q + 1 == TQ;
+            const int pn = last ? pln : pl, qn = last ? 0 : q + 1;
+            // ---- contraction 1: u = (s - mean) W1'^T, software-pipelined over the K-steps: the split of step ks + 1 is written before the
+            //      24 MFMAs of step ks and does not depend on them
+            f32x16v acc[4];
+#ifdef PH_NOMFMA
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#endif
+            bf16x8 Ah[2], Am[2], Al[2];
+            auto prep = [&](int ks) {
+                float v[8];
+                const f32x4v x0 = __builtin_bit_cast(f32x4v, xa[2 * ks]), x1 = __builtin_bit_cast(f32x4v, xa[2 * ks + 1]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = x0[c] - meanr[8 * ks + c];
+                    v[4 + c] = x1[c] - meanr[8 * ks + 4 + c];
+                }
+                split8(v, Ah[ks & 1], Am[ks & 1], Al[ks & 1]);
+                issue_pair(pn, qn, ks);                  // the registers are free: the next tile's loads fly through the rest of this one
+            };
+            prep(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) prep(ks + 1);
+                const int kn = ks < 3 ? ks + 1 : 0;
+                // small terms first within a plane kind; BL, then BM, then BH
+#ifdef PH_NOMFMA   /* timing-only build: the products replaced by one vector instruction per group */
+#define PH_G(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_][0] = ((FIRST) ? 0.f : acc[nt_][0]) + __builtin_bit_cast(float, __builtin_bit_cast(u32x4, AP[ks & 1])[0] ^ __builtin_bit_cast(u32x4, BP[nt_])[1]);
+#else
+#define PH_G(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_] = mfma32(AP[ks & 1], BP[nt_], (FIRST) ? f32x16v{} : acc[nt_]);
+#endif
+                PH_G(Ah, BL, ks == 0)
+                PH_LOADB(BL, kn, 2)
+                PH_G(Am, BM, false)
+                PH_G(Ah, BM, false)
+                PH_LOADB(BM, kn, 1)
+                PH_G(Al, BH, false)
+                PH_G(Am, BH, false)
+                PH_G(Ah, BH, false)
+                PH_LOADB(BH, kn, 0)
+#undef PH_G
+#if PH_PIPE
+                // the order asked of the scheduler: every MFMA followed by PH_PIPE vector instructions of the next step's split; the
+                // refill of a plane buffer one read per MFMA behind the buffer's last product
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
+                    if ((i >= 4 && i < 8) || (i >= 12 && i < 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ks < 3 && (i == 8 || i == 16)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- activation + fc2 partials: the lane's hidden units 32 nt + n, cells = its 16 register rows
+            float po[NV];                                // [DOT r + j]
+#pragma unroll
+            for (int i = 0; i < NV; ++i) po[i] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#ifdef PH_NOACT   /* timing-only build */
+                    const float v = acc[nt][r] + bs[nt];
+#else
+                    const float v = gelu_bias(acc[nt][r], bs[nt], hb[nt]);
+#endif
+#pragma unroll
+                    for (int j = 0; j < DOT; ++j) po[DOT * r + j] = __builtin_fmaf(v, w2r[j][nt], po[DOT * r + j]);
+                }
+            // ---- sum over the 32 lanes of the half, halving the value set at every step: lane n ends with elements EPL n + k
+            float q1[NV / 2], q2[NV / 4], q3[NV / 8], q4[NV / 16], q5[EPL];
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) {           // lanes 16 apart: rows swap, then add (row 0 keeps i, row 1 keeps i + NV / 2)
+                const u32x2 sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, po[i]), __builtin_bit_cast(unsigned, po[i + NV / 2]), false, false);
+                q1[i] = asf(sw[0]) + asf(sw[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < NV / 4; ++i) q2[i] = dpp_add(bit3 ? q1[i + NV / 4] : q1[i], bit3 ? q1[i] : q1[i + NV / 4], 0);
+#pragma unroll
+            for (int i = 0; i < NV / 8; ++i) q3[i] = dpp_add(bit2 ? q2[i + NV / 8] : q2[i], bit2 ? q2[i] : q2[i + NV / 8], 1);
+#pragma unroll
+            for (int i = 0; i < NV / 16; ++i) q4[i] = dpp_add(bit1 ? q3[i + NV / 16] : q3[i], bit1 ? q3[i] : q3[i + NV / 16], 2);
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) q5[i] = dpp_add(bit0 ? q4[i + EPL] : q4[i], bit0 ? q4[i] : q4[i + EPL], 3) + b2y[i];
+#pragma unroll
+            for (int k = 0; k < EPL; ++k)                // cells >= W: dropped by the descriptor; padded outputs: not stored
+                if (jy + k < DO) buf_store_f32(q5[k], rgo, ((32 * q + celly) * DO + jy + k) * 4, 0);
+        }
+        gl = gnext;
+    }
+#ifdef PH_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long tc1 = clock64(), tw1 = wall_clock64();
+    if (lane == 0) {
+        p.out[2 * slot] = (float)(tc1 - tc0);
+        p.out[2 * slot + 1] = (float)(tw1 - tw0);
+    }
+#endif
+#undef PH_LOADB
+}
+
+static size_t pjh_lds() { return (size_t)(4 * 4 * 3 * 64) * 16 + (PH_HID + 64) * 4; }
+
+// 1 when this kernel takes the shape: C = 64, at most four fc2 outputs, exact-erf GELU, fp32 storage, no GELU inside the input transform
+bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16) {
+    static const bool off = getenv("RPB_HEAD_PJH") && atoi(getenv("RPB_HEAD_PJH")) == 0;
+    return !off && C == 64 && DO >= 1 && DO <= 4 && act == 0 && !a_bf16 && !(xf.mean && xf.gelu);
+}
+
+int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st) {
+    PjhFwdArgs p{};
+    p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.DO = DO;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    p.xf = xf;
+    const long GL = (long)B * T * H;
+#ifndef PH_WG_PER_CU
+#define PH_WG_PER_CU 2L
+#endif
+    long grid = PH_WG_PER_CU * rpb_num_cus();
+    const long need = (GL + PH_WAVES - 1) / PH_WAVES;
+    if (grid > need) grid = need;
+    const size_t lds = pjh_lds();
+    if (DO <= 2) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pjh_fwd_kernel<2>, dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(pjh_fwd_kernel<4>, dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    }
+    RPB_CHECK_LAUNCH("proj_fwd (pjh)");
+}

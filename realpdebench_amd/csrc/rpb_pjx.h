@@ -8,3 +8,9 @@ long rpb_pjx_head_slots(int B, int T, int H, bool bwd);
 int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
                         float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
                         const XForm& xf, int act, hipStream_t st, bool a_bf16 = false);
+
+// rpb_pjh.hip: the evaluation forward on 32x32x16 tiles at two waves per SIMD (C = 64, <= 4 fc2 outputs, GELU, fp32 storage; RPB_HEAD_PJH=0
+// keeps the kernel above)
+bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16);
+int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);

@@ -18,6 +18,7 @@
 //                                of a wave tile are the 8 contraction values {4 kg + r, 16 + 4 kg + r}); d fc2, d b1, d b2 are
 //                                per-lane sums over cells.  A wave owns one half of the hidden units (64): 64 accumulator registers.
 #include "rpb_common.h"
+#include "rpb_pjx.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -942,6 +943,8 @@ long rpb_pjx_head_slots(int B, int T, int H, bool bwd) {
 int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout,
                         float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
                         const XForm& xf, int act, hipStream_t st, bool a_bf16) {
+    if (!bwd && rpb_pjh_supported(64, DO, act, xf, a_bf16))                       // the evaluation forward, third organisation (csrc/rpb_pjh.hip)
+        return rpb_pjh_launch(s, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, xf, st);
     PjhArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.out = out; p.gu = gu; p.part = part;
     p.B = (int)(ncrop / ((long)T * H * W)); p.DO = DO; p.act = act;

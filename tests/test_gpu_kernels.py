@@ -213,6 +213,35 @@ def test_proj_fwd_bwd(ops, C, DO, W):
     assert rel_l2(s[DO * 128 + 128:], b2.grad) < 5e-6
 
 
+@pytest.mark.parametrize("B,T,H,W,pad,bn,DO", [(2, 3, 6, 40, 2, True, 2), (1, 2, 5, 70, 6, True, 2), (3, 2, 4, 32, 6, False, 2), (2, 2, 3, 5, 2, True, 2),
+                                                (2, 3, 5, 40, 2, True, 3), (1, 2, 5, 70, 6, True, 4), (2, 2, 4, 33, 2, False, 1), (2, 2, 3, 5, 6, True, 3)])
+def test_eval_head_up_to_four_outputs(ops, B, T, H, W, pad, bn, DO):
+    """The evaluation forward of the head at <= 4 fc2 outputs (csrc/rpb_pjh.hip: 32-cell tiles, BatchNorm folded into the staged fc1
+    planes, bias folded into GELU) against fp64, with and without the lazy BatchNorm of the last layer; partial last tiles, lines
+    shorter than a tile, more lines than waves; RPB_HEAD_PJH=0 (the 16x16x32 kernel) must agree with it."""
+    torch.manual_seed(B * 100 + W)
+    C = 64
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64) * 1.5 + 0.3
+    w1 = torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)
+    b1 = torch.randn(128, dtype=torch.float64)
+    w2 = torch.randn(DO, 128, dtype=torch.float64) / 11
+    b2 = torch.randn(DO, dtype=torch.float64)
+    mean, var = torch.randn(C, dtype=torch.float64) * 0.2 + 0.3, torch.rand(C, dtype=torch.float64) + 0.5
+    gamma, beta = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.1
+    gamma[5] = 0.0                                       # a dead channel: the folded scale is an exact zero
+    invstd = (var + 1e-5).rsqrt()
+    ac = a[:, :T, :H, :W].reshape(-1, C)
+    if bn:
+        ac = (ac - mean) * invstd * gamma + beta
+    ref = torch.nn.functional.gelu(ac @ w1.t() + b1) @ w2.t() + b2
+    out = torch.full((d.ncrop, DO), float("nan"), device="cuda")
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), 0) if bn else None
+    ops.proj_fwd(dev(a).view(-1, C), dev(w1), dev(b1), dev(w2), dev(b2), out, d, DO, xf=xf)
+    assert rel_l2(out.cpu(), ref) < TOL
+    assert (out.cpu().double() - ref).abs().max() < 2e-6 * ref.abs().max()
+
+
 def test_lift_fwd_bwd(ops):
     torch.manual_seed(9)
     B, T, H, W, Cin, C, pad = 2, 4, 5, 6, 3, 64, 6
