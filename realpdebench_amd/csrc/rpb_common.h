@@ -183,11 +183,51 @@ __device__ __forceinline__ void fast_erf2x2(f32x2 xa, f32x2 xb, f32x2& ra, f32x2
     ra = f32x2{copysignf(sa[0], xa[0]), copysignf(sa[1], xa[1])};
     rb = f32x2{copysignf(sb[0], xb[0]), copysignf(sb[1], xb[1])};
 }
+// h + |h| m as ONE v_fma_f32 with the |.| source modifier (written as asm: left to itself the vectoriser pairs two of them into
+// 2 x v_and + v_pk_fma_f32, which costs what the sign transfer it replaces cost)
+__device__ __forceinline__ float fma_abs(float h, float m) {
+    float d;
+    asm("v_fma_f32 %0, |%1|, %2, %1" : "=v"(d) : "v"(h), "v"(m));
+    return d;
+}
+// gelu(x) = x/2 + (x/2) erf(x / sqrt 2) = h + |h| (1 - e), h = x / 2 (h has the sign of the erf argument): the sign transfer of erf is the
+// |.| source modifier of the last FMA -- two packed instructions per pair fewer than (0.5 x) (1 + copysign(1 - e, x))
+#ifndef RPB_GELU_ABS_FMA
+#define RPB_GELU_ABS_FMA 1
+#endif
 __device__ __forceinline__ void gelu2x2(f32x2& xa, f32x2& xb) {
+#if RPB_GELU_ABS_FMA
+    const f32x2 sa_ = xa * pk2(0.70710678118654752440f), sb_ = xb * pk2(0.70710678118654752440f);
+    const f32x2 ta = __builtin_elementwise_min(__builtin_elementwise_abs(sa_), pk2(4.0f));
+    const f32x2 tb = __builtin_elementwise_min(__builtin_elementwise_abs(sb_), pk2(4.0f));
+    f32x2 pa = pk2(1.160457393e-05f), pb = pk2(1.160457393e-05f);
+#if RPB_ERF_ILP_FENCE
+#define RPB_ERF_STEP(c) pa = pk_fma(pa, ta, pk2(c)); pb = pk_fma(pb, tb, pk2(c)); __builtin_amdgcn_sched_barrier(0);
+#else
+#define RPB_ERF_STEP(c) pa = pk_fma(pa, ta, pk2(c)); pb = pk_fma(pb, tb, pk2(c));
+#endif
+    RPB_ERF_STEP(-1.529619341e-04f)
+    RPB_ERF_STEP(8.482242992e-04f)
+    RPB_ERF_STEP(-2.274763673e-03f)
+    RPB_ERF_STEP(8.477856228e-05f)
+    RPB_ERF_STEP(2.772449465e-02f)
+    RPB_ERF_STEP(-1.483079179e-01f)
+    RPB_ERF_STEP(-9.184428993e-01f)
+    RPB_ERF_STEP(-1.627907267e+00f)
+#undef RPB_ERF_STEP
+    const f32x2 qa = pa * ta, qb = pb * tb;
+    const f32x2 ea = f32x2{__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])};
+    const f32x2 eb = f32x2{__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+    const f32x2 ma = pk2(1.0f) - ea, mb = pk2(1.0f) - eb;
+    const f32x2 ha = pk2(0.5f) * xa, hb = pk2(0.5f) * xb;
+    xa = f32x2{fma_abs(ha[0], ma[0]), fma_abs(ha[1], ma[1])};
+    xb = f32x2{fma_abs(hb[0], mb[0]), fma_abs(hb[1], mb[1])};
+#else
     f32x2 ea, eb;
     fast_erf2x2(xa * pk2(0.70710678118654752440f), xb * pk2(0.70710678118654752440f), ea, eb);
     xa = (pk2(0.5f) * xa) * (pk2(1.0f) + ea);
     xb = (pk2(0.5f) * xb) * (pk2(1.0f) + eb);
+#endif
 }
 __device__ __forceinline__ void gelu_both2x2(f32x2 xa, f32x2 xb, f32x2& ga, f32x2& gb, f32x2& gpa, f32x2& gpb) {
     f32x2 ea, eb;
