@@ -501,6 +501,10 @@ def copy_ceiling(dev, n=14939392 * 64):
     return res
 
 
+def _num_cus(dev):
+    return torch.cuda.get_device_properties(dev).multi_processor_count
+
+
 def mfma_ceiling(dev):
     """Sustained bf16 MFMA rate of THIS chip (csrc/rpb_probe.hip: 4 independent 32x32x16 chains per wave, one wave per SIMD, register
     operands) with random operands -- the power-limited rate real data sees -- and with zeros (the datasheet-like rate).  TFLOP/s."""
@@ -1005,6 +1009,11 @@ def main():
             line["mfma_bf16_sustained"] = {"TFLOPs": mfma_peak, "datasheet_peak": MFMA_BF16_PEAK_TF,
                                            "frac_of_datasheet": {k: v / MFMA_BF16_PEAK_TF for k, v in mfma_peak.items()},
                                            "split_bf16_fp32_equivalent_TFLOPs": mfma_peak["random_operands"] / 6.0,
+                                           # the probe issues 32x32x16 MFMAs back to back, 32 matrix-pipe cycles each on every SIMD: the rate
+                                           # IS the shader clock the power management holds under that load (the
+                                           # evaluation head runs at 1.06-1.53 GHz by clock64 against the 100 MHz counter)
+                                           "implied_shader_clock_GHz": {k: v * 1e12 / (2.0 * 32 * 32 * 16) / (4.0 * _num_cus(dev)) * 32 / 1e9
+                                                                        for k, v in mfma_peak.items()},
                                            "how": "csrc/rpb_probe.hip: 4 independent v_mfma_f32_32x32x16_bf16 chains per wave, one wave per SIMD, "
                                                   "register operands; measured in this run.  The secondary models' split-bf16 kernels move real "
                                                   "(random-like) data: their ceiling is the random-operand rate, not the datasheet's"}
