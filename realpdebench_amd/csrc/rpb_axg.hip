@@ -229,8 +229,10 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                     const bf16x8 am = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 1) * mtiles + mt) * 64 + lane]);
                     const bf16x8 al = __builtin_bit_cast(bf16x8, Ml[((ks * 3 + 2) * mtiles + mt) * 64 + lane]);
                     if (BFIN) {
+                        if (RPB_BF16_CONST_PLANES > 2) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(al, Bh[t], acc[i][t]);
+                            for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(al, Bh[t], acc[i][t]);
+                        }
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[i][t] = mfma16(am, Bh[t], acc[i][t]);
 #pragma unroll

@@ -526,7 +526,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)  \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], BP[u], acc[j][2 * tp + u]);
                     if (BF) {
-                        CMX_PROD(Ah, Bl) CMX_PROD(Ah, Bm) CMX_PROD(Ah, Bh)
+                        if (RPB_BF16_CONST_PLANES > 2) { CMX_PROD(Ah, Bl) }
+                        CMX_PROD(Ah, Bm) CMX_PROD(Ah, Bh)
                     } else {
                         CMX_PROD(Ah, Bl) CMX_PROD(Al, Bh) CMX_PROD(Am, Bm) CMX_PROD(Ah, Bm) CMX_PROD(Am, Bh) CMX_PROD(Ah, Bh)
                     }
@@ -560,7 +561,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)                                 \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], ZP[u], acc[j][2 * tp + u]);
                     if (SB) {
-                        CMX_SPEC(al, Zh) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+                        if (RPB_BF16_CONST_PLANES > 2) { CMX_SPEC(al, Zh) }
+                        CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
                     } else {
                         CMX_SPEC(ah, Zl) CMX_SPEC(al, Zh) CMX_SPEC(am, Zm) CMX_SPEC(ah, Zm) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
                     }
@@ -683,7 +685,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         const bf16x8 yb = __builtin_bit_cast(bf16x8, u32x4{pack_hi(v[0], v[1]), pack_hi(v[2], v[3]), pack_hi(v[4], v[5]), pack_hi(v[6], v[7])});
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            Yacc[i][t] = mfma16(fl[i], yb, Yacc[i][t]);
+                            if (RPB_BF16_CONST_PLANES > 2) Yacc[i][t] = mfma16(fl[i], yb, Yacc[i][t]);
                             Yacc[i][t] = mfma16(fm[i], yb, Yacc[i][t]);
                             Yacc[i][t] = mfma16(fh[i], yb, Yacc[i][t]);
                         }

@@ -84,6 +84,14 @@ __device__ __forceinline__ unsigned tile_bytes(long rows_left, int tile_rows, in
     return (unsigned)((rows_left < tile_rows ? (rows_left < 0 ? 0 : rows_left) : tile_rows) * row_bytes);
 }
 
+// bf16 STORAGE (BASELINE.json configs[4]): an operand that was stored as bf16 carries a rounding of 2^-9 of its value, and it is multiplied
+// with the planes of an fp32 constant (conv / fc1 weights, DFT stage matrices).  The constant's third plane contributes 2^-16 of the product:
+// 1 / 128 of the error the stored operand already has.  RPB_BF16_CONST_PLANES = 2 (default) drops that product -- two MFMAs per stored plane
+// instead of three in every kernel of the bf16-storage forward; 3 keeps it (round 4).  fp32 storage is not touched.
+#ifndef RPB_BF16_CONST_PLANES
+#define RPB_BF16_CONST_PLANES 2
+#endif
+
 // ---------------------------------------------------------------------------------- math
 // Branch-free erf:  erf(x) = sign(x) * (1 - 2^(t*S(t))),  t = min(|x|, 4),  S = degree-8 weighted-minimax fit of
 // log2(erfc(t))/t (fitted offline against scipy in fp64; max |error| 9.5e-8 in fp32 arithmetic = the rounding of

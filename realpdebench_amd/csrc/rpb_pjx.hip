@@ -526,7 +526,8 @@ __global__ __launch_bounds__(PJ_WAVES * 64) void pjx_head_kernel(PjhArgs p) {
                     }
 #define PJ_ROW(AP, BP) _Pragma("unroll") for (int u = 0; u < MG; ++u) acc[m0 + u] = mfma16(AP[u], BP[ks], acc[m0 + u]);
                     if (BFIN) {
-                        PJ_ROW(al, Bh) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
+                        if (RPB_BF16_CONST_PLANES > 2) { PJ_ROW(al, Bh) }
+                        PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
                     } else {
                         PJ_ROW(ah, Bl) PJ_ROW(al, Bh) PJ_ROW(am, Bm) PJ_ROW(ah, Bm) PJ_ROW(am, Bh) PJ_ROW(ah, Bh)
                     }
