@@ -14,9 +14,7 @@
 // store is 16 B per lane / 256 B per row as well.  The matrix is split once per workgroup into LDS in A-operand order
 // (16-row tiles: O = 48 is exact).
 #include "rpb_axg.h"
-#ifndef RPB_STREAM_AUX
-#define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (measured: no gain, tools/kbench.py A/B) */
-#endif
+// (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -15,9 +15,7 @@
 // steps of the last chunk read zeros and their stores are dropped by the hardware).
 #include "rpb_common.h"
 #include "rpb_bwr.h"
-#ifndef RPB_STREAM_AUX
-#define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (experiment switch) */
-#endif
+// (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 #include <stdlib.h>
 
 template <int N>

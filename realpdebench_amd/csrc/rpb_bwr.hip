@@ -22,11 +22,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define BW_WAVES 4
 
 namespace {
+// (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_STREAM_AUX));
 }
 __device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, RPB_STREAM_AUX);
 }
 __device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {

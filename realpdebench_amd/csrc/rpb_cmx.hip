@@ -21,9 +21,7 @@
 //    GW and the conv weights are split once per workgroup into LDS in operand order.
 #include "rpb_cmx.h"
 #include <atomic>
-#ifndef RPB_STREAM_AUX
-#define RPB_STREAM_AUX 0   /* cache policy of the streaming loads / stores: 2 = nt (measured: no gain, tools/kbench.py A/B) */
-#endif
+// (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 #include <stdlib.h>
 #include <type_traits>
 

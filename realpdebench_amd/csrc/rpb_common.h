@@ -84,6 +84,15 @@ __device__ __forceinline__ unsigned tile_bytes(long rows_left, int tile_rows, in
     return (unsigned)((rows_left < tile_rows ? (rows_left < 0 ? 0 : rows_left) : tile_rows) * row_bytes);
 }
 
+// Cache policy of the STREAMING loads / stores of the line-walking kernels (the aux operand of raw_buffer_load / _store: 2 = nt,
+// nontemporal; 0 = default).  Round 5: a plain copy gains 5 % from nt on these boxes (tools/ubench/stream_pat: 5.66 -> 5.94-5.98 TB/s for
+// two / three reads + one write, 5.88 -> 6.26 for the contiguous copy), and inside the training step nt in the row kernels, cell_mix, the
+// DFT stages and Adam is worth 0.44 ms of 37.1 (A/B alternating on one box; per-kernel micro-benchmarks had shown nothing: what nt buys is
+// cache left to the operands that ARE reused).  -DRPB_STREAM_AUX=0 restores rounds 1-4.
+#ifndef RPB_STREAM_AUX
+#define RPB_STREAM_AUX 2
+#endif
+
 // bf16 STORAGE (BASELINE.json configs[4]): an operand that was stored as bf16 carries a rounding of 2^-9 of its value, and it is multiplied
 // with the planes of an fp32 constant (conv / fc1 weights, DFT stage matrices).  The constant's third plane contributes 2^-16 of the product:
 // 1 / 128 of the error the stored operand already has.  RPB_BF16_CONST_PLANES = 2 (default) drops that product -- two MFMAs per stored plane

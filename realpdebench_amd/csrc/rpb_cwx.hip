@@ -18,8 +18,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef RPB_CWX_AUX
+#define RPB_CWX_AUX 0   /* cache policy of the tile loads (2 = nt): experiment switch */
+#endif
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_CWX_AUX));
 }
 __device__ __forceinline__ float asf(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }

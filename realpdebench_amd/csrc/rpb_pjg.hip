@@ -58,9 +58,12 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 #define PG_T(i)
 #endif
 
+#ifndef RPB_HEAD_AUX
+#define RPB_HEAD_AUX 0   /* cache policy of the tile loads / stores (2 = nt): experiment switch */
+#endif
 namespace {
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_HEAD_AUX));
 }
 __device__ __forceinline__ f32x2 ld8(rsrc_t r, int voff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
@@ -69,7 +72,7 @@ __device__ __forceinline__ f32x2 ld8(rsrc_t r, int voff) {
 // dword and the row swap its second result); a scalar copy first is safe
 __device__ __forceinline__ float asf(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, RPB_HEAD_AUX);
 }
 __device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {

@@ -35,9 +35,12 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 #define PH_PIPE 2
 #endif
 
+#ifndef RPB_HEAD_AUX
+#define RPB_HEAD_AUX 0   /* cache policy of the tile loads / stores (2 = nt): experiment switch */
+#endif
 namespace {
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_HEAD_AUX));
 }
 __device__ __forceinline__ float asf(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }

@@ -5,6 +5,9 @@
 #include "rpb_common.h"
 
 #define PW_THREADS 256
+#ifndef RPB_ADAM_NT
+#define RPB_ADAM_NT (RPB_STREAM_AUX == 2)     /* Adam streams 2.8 GB once: nontemporal like the row kernels (rpb_common.h) */
+#endif
 
 static inline int pw_grid(long work_items, int per_cu = 8) {
     long g = (work_items + PW_THREADS - 1) / PW_THREADS;
@@ -654,19 +657,32 @@ __global__ __launch_bounds__(PW_THREADS) void adam_kernel(float* __restrict__ p,
                                                           float inv_sqrt_bc2) {
     const long n4 = n >> 2;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+#if RPB_ADAM_NT     /* nontemporal loads / stores */
+        f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + idx);
+        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + idx);
+        f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + idx);
+        f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + idx);
+#else
         f32x4 pv = reinterpret_cast<f32x4*>(p)[idx];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[idx];
         f32x4 mv = reinterpret_cast<f32x4*>(m)[idx];
         f32x4 vv = reinterpret_cast<f32x4*>(v)[idx];
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float pk = pv[k], mk = mv[k], vk = vv[k];
             adam_update(pk, gv[k], mk, vk, gscale, b1, b2, eps, step_size, inv_sqrt_bc2);
             pv[k] = pk, mv[k] = mk, vv[k] = vk;
         }
+#if RPB_ADAM_NT
+        __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p) + idx);
+        __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m) + idx);
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + idx);
+#else
         reinterpret_cast<f32x4*>(p)[idx] = pv;
         reinterpret_cast<f32x4*>(m)[idx] = mv;
         reinterpret_cast<f32x4*>(v)[idx] = vv;
+#endif
     }
     // tail
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
