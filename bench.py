@@ -991,7 +991,8 @@ def main():
             kern_floor = sum(v["bytes"] * v["calls"] / max(a.warmup, 1) for v in warm.values()) / best / 1e6
             line["roofline"].update(
                 copy_ceiling={"GBps": ceiling, "frac_of_peak": {k: v / HBM_PEAK_GBS for k, v in ceiling.items()},
-                              "how": "csrc/rpb_probe.hip: plain streaming kernel, 3.82 GB tensors, 16 B per lane, best of 256 / 512 threads; "
+                              "how": "csrc/rpb_probe.hip: plain streaming kernel (nontemporal loads / stores, the policy of the product kernels since round 5), "
+                                     "3.82 GB tensors, 16 B per lane, best of 256 / 512 threads; "
                                      "measured in this run after the timed region"},
                 frac_of_copy_ceiling=fam_floor / (dom["total_ms"] / a.steps),
                 floor_ms={"dominant_family_at_copy_ceiling": fam_floor,
