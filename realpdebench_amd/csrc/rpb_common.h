@@ -93,6 +93,14 @@ __device__ __forceinline__ unsigned tile_bytes(long rows_left, int tile_rows, in
 #define RPB_STREAM_AUX 2
 #endif
 
+// the same policy for kernels that stream through plain pointers (16 B per lane): x = sld4(p), sst4(p, v)
+#define RPB_SLD4(P) (RPB_STREAM_AUX == 2 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P)) : *reinterpret_cast<const f32x4*>(P))
+#define RPB_SST4(P, V)                                                                  \
+    do {                                                                                \
+        if (RPB_STREAM_AUX == 2) __builtin_nontemporal_store((V), reinterpret_cast<f32x4*>(P)); \
+        else *reinterpret_cast<f32x4*>(P) = (V);                                        \
+    } while (0)
+
 // bf16 STORAGE (BASELINE.json configs[4]): an operand that was stored as bf16 carries a rounding of 2^-9 of its value, and it is multiplied
 // with the planes of an fp32 constant (conv / fc1 weights, DFT stage matrices).  The constant's third plane contributes 2^-16 of the product:
 // 1 / 128 of the error the stored operand already has.  RPB_BF16_CONST_PLANES = 2 (default) drops that product -- two MFMAs per stored plane

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long m = idx / c8n;
         const int c8 = (int)(idx - m * c8n);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + m * ldx + c8 * 8);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + m * ldx + c8 * 8 + 4);
+        const f32x4 v0 = RPB_SLD4(x + m * ldx + c8 * 8);                 // (the planes are re-read nine times by the convolution: default policy)
+        const f32x4 v1 = RPB_SLD4(x + m * ldx + c8 * 8 + 4);
         unsigned h[8], md[8], lo[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -820,7 +820,7 @@ extern "C" int rpb_mul(const float* a, const float* b, float* out, long n, void*
 __global__ __launch_bounds__(PW_THREADS) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, long n4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+        RPB_SST4(out + 4 * i, RPB_SLD4(a + 4 * i) + RPB_SLD4(b + 4 * i));
 }
 extern "C" int rpb_add(const float* a, const float* b, float* out, long n, void* stream) {
     RPB_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "add: n must be a positive multiple of 4");
