@@ -32,6 +32,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_STREAM_AUX));
 }
+template <int AUX>
+__device__ __forceinline__ u32x4 ld16a(rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, AUX));
+}
 __device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, RPB_STREAM_AUX);
 }
@@ -381,7 +385,10 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             xa[j][ks] = ld16(rx, q * 4096 + j * 2048 + m * 128 + ks * 64 + kg * 16);
         } else {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) xa[j][2 * (C2 ? (ks & 1) : ks) + hf] = ld16(rx, q * (32 * CB) + xoff + j * (16 * CB) + (2 * ks + hf) * 64);
+            // (C = 128: the two workgroups of a pair read the same x lines, the second out of L2 / MALL -- default policy there; measured:
+            //  fsi step 43.0 -> 44.5 ms with nontemporal x loads)
+            for (int hf = 0; hf < 2; ++hf)
+                xa[j][2 * (C2 ? (ks & 1) : ks) + hf] = ld16a<C2 ? 0 : RPB_STREAM_AUX>(rx, q * (32 * CB) + xoff + j * (16 * CB) + (2 * ks + hf) * 64);
         }
     };
     u32x4 zr[8];
