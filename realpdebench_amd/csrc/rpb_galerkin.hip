@@ -45,22 +45,22 @@ __global__ __launch_bounds__(HN_THREADS) void headnorm_kernel(HeadNormArgs a) {
     if (!BWD) be = *reinterpret_cast<const f32x4*>(a.beta + 4 * lane);
     f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
     for (long m = w0; m < a.M; m += stride) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + m * a.ldx + 4 * lane);
+        const f32x4 v = RPB_SLD4(a.x + m * a.ldx + 4 * lane);
         f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-        if (BWD) g4 = *reinterpret_cast<const f32x4*>(a.gy + m * a.ldg + 4 * lane);
+        if (BWD) g4 = RPB_SLD4(a.gy + m * a.ldg + 4 * lane);
         const float mean = seg16_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 64.0f);
         const f32x4 d = v - mean;
         const float var = seg16_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / 64.0f);
         const float inv = 1.0f / sqrtf(var + a.eps);
         const f32x4 xh = d * inv;
         if (!BWD) {
-            *reinterpret_cast<f32x4*>(a.out + m * a.ldo + 4 * lane) = xh * ga + be;
+            RPB_SST4(a.out + m * a.ldo + 4 * lane, xh * ga + be);
         } else {
             const f32x4 dy = g4 * ga;
             const float m1 = seg16_sum(dy[0] + dy[1] + dy[2] + dy[3]) * (1.0f / 64.0f);
             const float m2 =
                 seg16_sum(dy[0] * xh[0] + dy[1] * xh[1] + dy[2] * xh[2] + dy[3] * xh[3]) * (1.0f / 64.0f);
-            *reinterpret_cast<f32x4*>(a.gx + m * a.ldgx + 4 * lane) = (dy - m1 - xh * m2) * inv;
+            RPB_SST4(a.gx + m * a.ldgx + 4 * lane, (dy - m1 - xh * m2) * inv);
             dg += g4 * xh;
             db += g4;
         }
@@ -401,7 +401,7 @@ extern "C" int rpb_head_apply(const float* X, int ldx, const float* Wm, float* o
 __global__ __launch_bounds__(256) void dropout_mul_kernel(const float* __restrict__ g, float* __restrict__ out, long n4,
                                                           DropSpec d) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(g)[i] * dropout4(d, (unsigned long long)i);
+        RPB_SST4(out + 4 * i, RPB_SLD4(g + 4 * i) * dropout4(d, (unsigned long long)i));
 }
 
 extern "C" int rpb_dropout_mul(const float* g, float* out, long n, long seed, float keep, void* stream) {
