@@ -208,11 +208,13 @@ __device__ __forceinline__ void fast_erf2x2(f32x2 xa, f32x2 xb, f32x2& ra, f32x2
     ra = f32x2{copysignf(sa[0], xa[0]), copysignf(sa[1], xa[1])};
     rb = f32x2{copysignf(sb[0], xb[0]), copysignf(sb[1], xb[1])};
 }
-// h + |h| m as ONE v_fma_f32 with the |.| source modifier (written as asm: left to itself the vectoriser pairs two of them into
-// 2 x v_and + v_pk_fma_f32, which costs what the sign transfer it replaces cost)
-__device__ __forceinline__ float fma_abs(float h, float m) {
-    float d;
-    asm("v_fma_f32 %0, |%1|, %2, %1" : "=v"(d) : "v"(h), "v"(m));
+// h + |h| m as ONE v_fma_f32 with the |.| source modifier.  Left to itself the vectoriser pairs two of them into 2 x v_and + v_pk_fma_f32
+// (what the sign transfer it replaces cost); an EMPTY asm on the first result keeps them apart.  (Not the instruction itself as asm: the hazard
+// recogniser does not see an asm statement as a vector instruction, so a DPP / permlane read of its result could lose its wait states.)
+__device__ __forceinline__ float fma_abs(float h, float m) { return __builtin_fmaf(__builtin_fabsf(h), m, h); }
+__device__ __forceinline__ float fma_abs_b(float h, float m) {      // the pair's first element: its RESULT passes the empty asm
+    float d = __builtin_fmaf(__builtin_fabsf(h), m, h);
+    asm("" : "+v"(d));
     return d;
 }
 // gelu(x) = x/2 + (x/2) erf(x / sqrt 2) = h + |h| (1 - e), h = x / 2 (h has the sign of the erf argument): the sign transfer of erf is the
@@ -245,8 +247,8 @@ __device__ __forceinline__ void gelu2x2(f32x2& xa, f32x2& xb) {
     const f32x2 eb = f32x2{__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
     const f32x2 ma = pk2(1.0f) - ea, mb = pk2(1.0f) - eb;
     const f32x2 ha = pk2(0.5f) * xa, hb = pk2(0.5f) * xb;
-    xa = f32x2{fma_abs(ha[0], ma[0]), fma_abs(ha[1], ma[1])};
-    xb = f32x2{fma_abs(hb[0], mb[0]), fma_abs(hb[1], mb[1])};
+    xa = f32x2{fma_abs_b(ha[0], ma[0]), fma_abs(ha[1], ma[1])};
+    xb = f32x2{fma_abs_b(hb[0], mb[0]), fma_abs(hb[1], mb[1])};
 #else
     f32x2 ea, eb;
     fast_erf2x2(xa * pk2(0.70710678118654752440f), xb * pk2(0.70710678118654752440f), ea, eb);
