@@ -32,6 +32,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 ld16(rsrc_t r, int voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, RPB_STREAM_AUX));
 }
+// CMX_WG_X_DEFAULT: the weight-gradient pairs' mix wave loads gs with the default policy (its wgrad wave fetches the same lines a tile later)
+#ifndef CMX_WG_X_DEFAULT
+#define CMX_WG_X_DEFAULT 1
+#endif
 template <int AUX>
 __device__ __forceinline__ u32x4 ld16a(rsrc_t r, int voff) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, AUX));
@@ -388,7 +392,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             // (C = 128: the two workgroups of a pair read the same x lines, the second out of L2 / MALL -- default policy there; measured:
             //  fsi step 43.0 -> 44.5 ms with nontemporal x loads)
             for (int hf = 0; hf < 2; ++hf)
-                xa[j][2 * (C2 ? (ks & 1) : ks) + hf] = ld16a<C2 ? 0 : RPB_STREAM_AUX>(rx, q * (32 * CB) + xoff + j * (16 * CB) + (2 * ks + hf) * 64);
+                xa[j][2 * (C2 ? (ks & 1) : ks) + hf] = ld16a<(C2 || (WG && CMX_WG_X_DEFAULT)) ? 0 : RPB_STREAM_AUX>(rx, q * (32 * CB) + xoff + j * (16 * CB) + (2 * ks + hf) * 64);
         }
     };
     u32x4 zr[8];
