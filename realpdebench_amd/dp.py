@@ -245,6 +245,14 @@ class DataParallel:
         self.chunk_elems = max(256, int(float(os.environ.get("RPB_DP_CHUNK_MB", "16")) * (1 << 20) / 4) // 256 * 256)   # (1 KB granules)
         self.shard_opt = bool(shard_optimizer) if shard_optimizer is not None else os.environ.get("RPB_DP_SHARD_ADAM") == "1"
         self.shard_world = int(shard_world or self.world_size)
+        if self.shard_world != self.world_size and self.world_size != 1:
+            # pieces are cut by shard_world, the collectives by the communicator's size: anything else than the one-rank proxy of bench.py
+            # would update the wrong pieces with unreduced gradients
+            raise ValueError(f"shard_world={self.shard_world} != world_size={self.world_size}: only a one-rank group may model a larger "
+                             "world (bench.py's proxy)")
+        if len(self.buckets) > 16:
+            raise ValueError(f"{len(self.buckets)} gradient buckets (n_layers + 2): rpb_dp_mark keeps 16 marks per communicator")
+        self._step_sharded = False    # this step's big chunks travel as reduce-scatter (only the fused Trainer can consume that)
         self._plan = None
         self._pending = False         # sharded step: parameter all-gathers are in flight on the side stream
         self._works = []
@@ -272,9 +280,14 @@ class DataParallel:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- bucketed, overlapped gradient reduction
-    def begin_step(self, grad):
+    def begin_step(self, grad, sharded=False):
+        """``sharded``: the caller consumes REDUCE-SCATTERED gradients (the fused ``Trainer.step``: Adam on the owned pieces, then
+        ``gather_params``).  Every other caller -- the autograd path (`_FNO3dFunction.backward` + a torch optimizer), a trainer that
+        clips by the whole gradient -- gets the plain all-reduce whatever ``shard_opt`` says: a reduce-scattered arena is only
+        summed in the piece this rank owns (round-5 advisor finding)."""
         self._live()
         self._works, self._next, self._held = [], 0, {}
+        self._step_sharded = bool(sharded) and self.shard_opt
 
     def chunks(self, s, e):
         """[s, e) cut into pieces of at most ``chunk_elems`` elements (the same cut on every rank)."""
@@ -324,6 +337,26 @@ class DataParallel:
             pre += n // 4
         return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), 4 * pre
 
+    def sharded_grad_norm(self, grad):
+        """2-norm of the rank-summed gradient after a SHARDED reduction (``clip_grad_norm`` with the sharded optimizer step): the squares
+        of the pieces this rank owns plus 1 / world of the chunks every rank holds whole, summed over ranks in ONE inline fp64
+        all-reduce.  Non-owned pieces of the arena (partial sums) are never read.  One host sync, like the unsharded clip."""
+        _, chunks = self.shard_plan()
+        W, r = self.shard_world, self.rank % self.shard_world
+        own, whole = [], []
+        for row in chunks:
+            for a, b, sh in row:
+                if sh:
+                    n = (b - a) // W
+                    own.append(grad[a + r * n:a + (r + 1) * n])
+                else:
+                    whole.append(grad[a:b])
+        sq = lambda ts: torch.stack(torch._foreach_norm(ts)).double().square().sum() if ts else torch.zeros((), dtype=torch.float64,
+                                                                                                            device=grad.device)
+        t = (sq(own) + sq(whole) / self.world_size).reshape(1)
+        self.all_reduce_sum(t)
+        return float(t.sqrt())
+
     def gather_params(self, flat):
         """After Adam on the owned pieces: all-gather the sharded chunks of the parameter arena in FORWARD order (fc0 head, layers 0 ..
         L-1, tail) on the side stream, one mark per bucket; the next forward waits per bucket (``params_ready``)."""
@@ -361,7 +394,7 @@ class DataParallel:
     def _reduce(self, grad, s, e, big=False):
         for a, b in self.chunks(s, e):
             if self.comm is not None and grad.is_cuda:
-                if self._sharded(a, b, big):
+                if self._step_sharded and self._sharded(a, b, big):
                     self.comm.reduce_scatter(grad[a:b])    # rank r keeps the sum of piece r; same side stream, same ordering
                 else:
                     self.comm.enqueue(grad[a:b])           # rpb_dp_allreduce_enqueue: side stream, overlaps the rest of backward

@@ -289,6 +289,7 @@ class FNO3d(Model):
 
     # ------------------------------------------------------------------ reference-compatible state dict
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        self._params_settled()
         sd = OrderedDict() if destination is None else destination
         C = self.width
         v = lambda n: self.pview(n).detach().clone()
@@ -312,6 +313,7 @@ class FNO3d(Model):
         return sd
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
+        self._params_settled()          # (in-flight gathers would otherwise land on top of the loaded weights)
         expected = set(self.state_dict().keys())
         missing = expected - set(state_dict.keys())
         unexpected = set(state_dict.keys()) - expected
@@ -784,6 +786,15 @@ class FNO3d(Model):
             raise ValueError(f"expected input [B,{','.join(map(str, self.shape_in))}], got {tuple(x.shape)}")
         return x.contiguous().float()
 
+    def _params_settled(self):
+        """A sharded optimizer step (dp.DataParallel.gather_params) leaves the parameter all-gathers in flight on the side stream.  The
+        training forward waits per bucket; EVERY other reader of the parameter arena -- eval forward (eager or a replayed hipGraph),
+        state_dict / load_state_dict, checkpoints -- makes the current stream wait for all of them here (round-5 advisor finding:
+        train.py validates and saves straight after trainer.step)."""
+        dp = self.dp
+        if dp is not None and getattr(dp, "_pending", False):
+            dp.params_ready_all()
+
     def forward(self, x):
         x = self._check_input(x)
         if torch.is_grad_enabled() and self.flat.requires_grad:
@@ -792,6 +803,8 @@ class FNO3d(Model):
                                           "evaluation in torch.no_grad() as the reference does (train.py:345-361)")
             return _FNO3dFunction.apply(x, self.flat, self)
         ws = self._workspace(x.shape[0], self.training, x.device)
+        if not self.training:
+            self._params_settled()      # a replayed eval graph never enters _forward_impl, where the per-bucket waits live
         if not self.training and _EVAL_GRAPH and _lib.PROFILE is None and type(self)._forward_impl is FNO3d._forward_impl:
             out = self._forward_graphed(x, ws)
         else:

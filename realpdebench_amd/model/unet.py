@@ -308,11 +308,12 @@ class Unet3d(_ModelBase):
                 gp = torch.zeros(M, (N + 3) // 4 * 4, device=gy.device)
                 gp[:, :N] = gy
                 dW, db = _wgrad(gp, x, M, N, K, ldg=gp.shape[1])
-                gx = _new(M, K, like=x)
-                ops.tokens_lift(gy, self._w("T", wname), torch.zeros(K, device=gy.device), gx, M, N, K, False)
             else:
                 dW, db = _wgrad(gy, x, M, N, K)
-                gx = _new(M, K, like=x)
+            gx = _new(M, K, like=x)
+            if N % 32 and N <= 32:                               # skinny contraction (3 or 16 output channels: configs/combustion/unet.yaml)
+                ops.tokens_lift(gy, self._w("T", wname), torch.zeros(K, device=gy.device), gx, M, N, K, False)
+            else:
                 ops.gemm_nt(gy, self._w("T", wname), gx, M, K, N)
             tp.pacc(wname, dW.view(self.p(wname).shape))
             if bname:

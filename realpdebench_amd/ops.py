@@ -249,7 +249,7 @@ class deferred_reductions:
     reduction whose output is read inside the block simply does not pass ``deferrable`` and runs at once; the caller of a deferrable one
     guarantees that its partial buffer is not overwritten and its output not read inside the block.  The queue is per host thread."""
     _tls = threading.local()
-    _staging = {}                    # device -> (pinned host table, device table): the item table travels without blocking the host
+    _staging = {}                    # (device, thread, stream) -> (pinned host table, device table, event): the item table travels without blocking the host
 
     def __init__(self, enabled=True):
         self.enabled, self.items, self.keep = enabled, [], []
@@ -259,6 +259,11 @@ class deferred_reductions:
         return getattr(cls._tls, "active", None)
 
     def __enter__(self):
+        # no deferral while the stream is being captured into a hipGraph: the H2D copy node of the item table would re-read the shared
+        # pinned buffer at REPLAY time (after later blocks have overwritten it) and an event recorded during capture cannot be
+        # synchronised on -- inside a capture every reduction runs at once, as if deferral were off (round-5 advisor finding)
+        if self.enabled and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.enabled = False
         if self.enabled:
             self.prev, deferred_reductions._tls.active = deferred_reductions.current(), self
         return self
@@ -273,7 +278,7 @@ class deferred_reductions:
         deferred_reductions._tls.active = self.prev
         if self.items and exc[0] is None:
             dev, n = self.keep[0].device, len(self.items)
-            key = (dev, threading.get_ident())
+            key = (dev, threading.get_ident(), _stream())     # per STREAM: the device table is reused in stream order only
             st = deferred_reductions._staging.get(key)
             if st is None or st[0].shape[0] < n:              # pinned host table + device table, grown to the largest block seen
                 cap = max(256, 2 * n)

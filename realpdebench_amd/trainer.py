@@ -30,9 +30,6 @@ class Trainer:
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
         self._owned = None           # sharded optimizer step: the device table of the ranges this rank updates
-        if model.dp is not None and getattr(model.dp, "shard_opt", False) and self.clip > 0:
-            raise ValueError("the sharded optimizer step has no gradient-norm clipping (the norm needs the whole reduced gradient): "
-                             "use DataParallel(model, shard_optimizer=False) with clip_grad_norm")
 
     # ---- learning-rate schedule (closed forms of CosineAnnealingLR(T_max=num_update) / StepLR(gamma=0.5))
     def current_lr(self):
@@ -50,6 +47,8 @@ class Trainer:
         ws = model._workspace(B, True, x.device)
         dp = model.dp
         world = dp.world_size if dp is not None else 1
+        # sharded optimizer step: THIS trainer consumes reduce-scattered gradients, so it is the one that asks for them (dp.begin_step)
+        sharded = dp is not None and bool(getattr(dp, "shard_opt", False))
         tgt = model._unshape_grad(target.contiguous().float(), B)
         n = tgt.numel()
         if getattr(ws, "head_fused", False) and ws.head_loss_fused:
@@ -57,7 +56,7 @@ class Trainer:
             # inside the head's backward kernel -- no rpb_proj_fwd, no rpb_mse, no pred tensor in the training step
             model._forward_impl(x, ws, training=True, skip_head=True)
             if dp is not None:
-                dp.begin_step(self.grad)
+                dp.begin_step(self.grad, sharded=sharded)
             model._backward_impl(x, None, ws, self.grad, target=tgt, gscale=2.0 / (n * world))
             ops.reduce_partials(ws.hb_loss_part, ws.hb_slots, 1, out_f32=ws.loss, scale=1.0 / n)
         else:
@@ -65,7 +64,7 @@ class Trainer:
             ops.mse(out, tgt, None, ws.gout, ws.mse_part, n, 2.0 / 2.0 / (n * world))   # gout = 2*(p-t)/N_global
             ops.reduce_partials(ws.mse_part, ws.mse_part.numel(), 1, out_f32=ws.loss, scale=1.0 / n)
             if dp is not None:
-                dp.begin_step(self.grad)
+                dp.begin_step(self.grad, sharded=sharded)
             model._backward_impl(x, ws.gout, ws, self.grad)
         if dp is not None:
             dp.finish_step(self.grad)
@@ -74,11 +73,13 @@ class Trainer:
             # torch.nn.utils.clip_grad_norm_ (train.py:330-331): total 2-norm over all parameters (complex weights count both
             # parts: the arena holds them as 2 x fp32), coefficient min(1, max_norm / (norm + 1e-6)) folded into the Adam kernel's
             # gradient scale; one host sync, only when clipping is on.  The arena's alignment gaps are zero.
-            norm = float(torch.linalg.vector_norm(self.grad))
+            # Sharded step: the arena is only summed in the pieces this rank owns -> norm^2 partial per owned range + one inline
+            # fp64 all-reduce (dp.sharded_grad_norm).
+            norm = dp.sharded_grad_norm(self.grad) if sharded else float(torch.linalg.vector_norm(self.grad))
             gscale = min(1.0, self.clip / (norm + 1e-6))
         lr = self.current_lr()
         self.iteration += 1
-        if dp is not None and getattr(dp, "shard_opt", False) and self.clip == 0:
+        if sharded:
             # sharded optimizer step (dp.DataParallel): the gradient chunks were reduce-scattered, this rank updates the pieces it owns
             # (1 / world of the arena in ONE launch over the range table) and the parameter pieces travel back on the side stream while
             # the next forward pass starts (it waits per layer: model._forward_impl -> dp.params_ready)

@@ -116,13 +116,25 @@ def _shard_worker(rank, world, port, out):
         dist.all_reduce(g_ref)
         p_ref = model.flat.data.clone() - 0.1 * g_ref
         # sharded: buckets announced in backward order with the held tails, as the backward pass does
-        dp.begin_step(g)
+        dp.begin_step(g, sharded=True)
+        res["step_sharded"] = dp._step_sharded
         dp.bucket_ready(g)
         for l in range(model.n_layers - 1, -1, -1):
             dp.bucket_ready(g, hold_small_of=l if l > 0 else None)
             dp.small_ready(g, l)
         dp.finish_step(g)
         pieces, chunks = dp.shard_plan()
+        # gloo all-reduces where RCCL reduce-scatters: poison every sharded piece this rank does NOT own, as a real reduce-scatter leaves
+        # them (partial sums) -- nothing below may read them
+        for row in chunks:
+            for a, b, sh in row:
+                if sh:
+                    n = (b - a) // world
+                    for q in range(world):
+                        if q != rank:
+                            g[a + q * n:a + (q + 1) * n] = float("nan")
+        res["norm"] = dp.sharded_grad_norm(g)                 # clip_grad_norm with the sharded step (fp64 partials, one all-reduce)
+        res["norm_ref"] = float(g_ref.double().norm())
         n_sharded = sum(1 for row in chunks for _, _, sh in row if sh)
         res["some_sharded"] = n_sharded >= model.n_layers
         res["owned_fraction"] = sum(n for _, n in pieces) / g.numel()
@@ -152,3 +164,36 @@ def test_sharded_optimizer_step_equals_allreduce_world2_gloo():
         assert 0.5 < res[r]["owned_fraction"] < 0.6, res[r]["owned_fraction"]       # half of the spectral ranges + all the small pieces
         assert res[r]["stale_before_gather"]
         assert res[r]["equal"], "reduce-scatter + owned update + all-gather != all-reduce + full update"
+        assert res[r]["step_sharded"]
+        assert abs(res[r]["norm"] - res[r]["norm_ref"]) < 1e-6 * res[r]["norm_ref"], (res[r]["norm"], res[r]["norm_ref"])
+
+
+def _unsharded_caller_worker(rank, world, port, out):
+    """A caller that did not opt in (the autograd path, a torch optimizer) gets plain all-reduces even with shard_optimizer=True."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _make_model(seed=7)
+        dp = DataParallel(model, shard_optimizer=True)
+        dp.begin_step(model.flat.data)
+        flag = dp._step_sharded
+        try:
+            DataParallel(_make_model(seed=8), shard_optimizer=True, shard_world=8)
+            refused = False
+        except ValueError:
+            refused = True
+        out[rank] = {"step_sharded": flag, "refused": refused}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_is_opt_in_per_step_and_shard_world_is_checked():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_unsharded_caller_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for r in (0, 1):
+        assert res[r]["step_sharded"] is False and res[r]["refused"]

@@ -215,23 +215,44 @@ def _sharded_step_worker(rank, port, out):
     try:
         shape = (6, 16, 16, 2)
         finals = []
-        for shard in (False, True):
+        for shard, clip in ((False, 0.0), (True, 0.0), (False, 0.05), (True, 0.05)):
             torch.manual_seed(3)
             m = FNO3d(2, 4, 4, 2, 64, shape, shape).to("cuda:0")
             DataParallel(m, shard_optimizer=shard)
-            tr = Trainer(m, lr=1e-3, num_update=10)
+            tr = Trainer(m, lr=1e-3, num_update=10, clip_grad_norm=clip)
             torch.manual_seed(4)
             x, y = torch.randn(2, *shape, device="cuda"), torch.randn(2, *shape, device="cuda")
             losses = [float(tr.step(x, y)) for _ in range(3)]
             ck = tr.checkpoint()                         # (waits for the parameter gathers of the sharded step)
             finals.append((m.flat.data.clone().cpu(), losses))
-            if shard:
+            if shard and clip == 0.0:
                 pieces, chunks = m.dp.shard_plan()
                 out["sharded_chunks"] = sum(1 for row in chunks for _, _, sh in row if sh)
                 out["ranges"] = len(pieces)
+                # validation straight after a sharded step (train.py): the eval forward -- eager, then replayed from its hipGraph
+                # (captured on the third call), which never enters _forward_impl -- and state_dict() must wait for the gathers
+                pend = []
+                for _ in range(5):
+                    tr.step(x, y)
+                    pend.append(m.dp._pending)
+                    m.eval()
+                    with torch.no_grad():
+                        m(x)
+                    pend.append(m.dp._pending)
+                    m.train()
+                tr.step(x, y)
+                m.state_dict()
+                pend.append(m.dp._pending)
+                out["pending"] = pend
             tr.close()
         out["equal"] = bool(torch.equal(finals[0][0], finals[1][0])) and finals[0][1] == finals[1][1]
-        out["diag"] = (float((finals[0][0] - finals[1][0]).abs().max()), finals[0][1], finals[1][1])
+        # (the clip coefficient comes from an fp64 sum of per-range norms in the sharded step, from one fp32 norm in the plain one: the
+        # same step up to the rounding of that one scalar)
+        out["equal_clip"] = (float((finals[2][0] - finals[3][0]).abs().max()) <= 2e-6 * float(finals[2][0].abs().max())
+                             and all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(finals[2][1], finals[3][1])))
+        out["clip_acts"] = not torch.equal(finals[0][0], finals[2][0])
+        out["diag"] = (float((finals[0][0] - finals[1][0]).abs().max()), float((finals[2][0] - finals[3][0]).abs().max()),
+                       finals[0][1], finals[1][1])
     finally:
         dist.destroy_process_group()
 
@@ -251,3 +272,6 @@ def test_sharded_optimizer_step_one_rank_equals_the_plain_step():
         res = dict(out)
     assert res["sharded_chunks"] >= 2 and res["ranges"] > res["sharded_chunks"]
     assert res["equal"], f"sharded optimizer step != plain step on one rank: {res['diag']}"
+    assert res["clip_acts"] and res["equal_clip"], f"sharded step with clip_grad_norm != plain step with it: {res['diag']}"
+    # after every sharded step gathers are pending; after an eval forward (eager or graph replay) / state_dict() they are not
+    assert res["pending"] == [True, False] * 5 + [False], res["pending"]
