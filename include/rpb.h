@@ -89,7 +89,7 @@ int rpb_cell_mix(const float* x, const float* Wm, const float* bias, const float
                  const float* xf_gamma, const float* xf_beta, int xf_gelu, const float* bnb_s, const float* bnb_mean,
                  const float* bnb_invstd, const float* bnb_gamma, const float* bnb_beta, int bnb_gelu, void* stream);
 
-/*     The backward launch of a Fourier layer at C = 64 with the layer's Conv3d weight gradient riding along (csrc/rpb_cmw.hip;
+/*     The backward launch of a Fourier layer at C = 64 with the layer's Conv3d weight gradient riding along (csrc/rpb_cmx.hip, wave pairs;
  *     autograd of fno.py:63,115-119): out = gs Wc + FW^T z2 (Wc = convs.l.weight [co][ci], FWt = the adjoint stage matrix [K2][Wp]),
  *     stored as gz = out * act'(BN(s_prev)) when gelu == 2 (gelu == 1: act' only enters the sums, 0: identity activation);
  *     stats_part[slot][2][64] = (sum gz, sum gz * shat) of the layer below;  wg_part[slot][64][64] = partial

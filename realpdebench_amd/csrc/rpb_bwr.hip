@@ -64,7 +64,7 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 
 // GELU: gy is multiplied by gelu'(z) here (the producer did not store gz);  XGELU / XBN: the layer input is act(BN(x));  FEAT: x is the
 // feature tensor (layer 0): the weight-gradient columns are its FW <= 16 fields;  NOX: no weight gradient here (a.x == null: the
-// backward cell_mix of the same layer forms it, csrc/rpb_cmw.hip) -- the layer input is not read at all: 12.4 instead of 16.2 GB
+// backward cell_mix of the same layer forms it, csrc/rpb_cmx.hip WG) -- the layer input is not read at all: 12.4 instead of 16.2 GB
 // CS: floats per cell row (64; 128 = one 64-channel half of a width-128 layer per launch, NOX only: BwrArgs::CS / coff)
 // MT: 16-mode row tiles of Y1 (2: K2 <= 32; 3: K2 <= 48, the Galerkin regressor's modes (4, 16, 20) -> K2 = 40)
 template <bool GELU, bool XBN, bool XGELU, bool FEAT, bool NOX = false, int CS = 64, int MT = 2>

@@ -571,12 +571,13 @@ extern "C" int rpb_cell_mix_eval_dft_supported(long ncell, int K2, int Wp, int K
     return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f);
 }
 
-// Backward cell_mix of a Fourier layer with the layer's Conv3d weight gradient riding along (csrc/rpb_cmw.hip; C = 64):
+// Backward cell_mix of a Fourier layer with the layer's Conv3d weight gradient riding along (wave pairs of csrc/rpb_cmx.hip, WG; C = 64;
+// the one-wave-per-SIMD organisation of round 4 lost every A/B since and is archived as tools/archive/rpb_cmw.hip):
 //   out  = gs Wc + FW^T z2, stored as gz = out * act'(BN(s_prev)) when gelu == 2        (as rpb_cell_mix with bnb_*)
 //   stats_part[slot][2][64] = partial (sum gz, sum gz * shat) of the layer below
 //   wg_part[slot][64][64]   = partial dWc[co][ci] = sum_cells gs[cell][co] * act(BN(s_prev))[cell][ci]
 // with slot < rpb_cell_mix_wgrad_slots(ncell, Wp).  Wc is convs.l.weight [co][ci]; FW the adjoint stage matrix [K2][Wp].
-extern "C" long rpb_cell_mix_wgrad_slots(long ncell, int Wp) { return Wp > 0 ? rpb_cmw_slots(ncell, Wp) : -1; }
+extern "C" long rpb_cell_mix_wgrad_slots(long ncell, int Wp) { return Wp > 0 ? rpb_cmx_wg_slots(ncell, Wp) : -1; }
 extern "C" int rpb_cell_mix_wgrad_supported(long ncell, int K2, int Wp) {
     return rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_bwr_supported(64, Wp, K2, 0) ? 1 : 0;
 }
@@ -593,7 +594,7 @@ extern "C" int rpb_cell_mix_wgrad(const float* gs, const float* Wc, const float*
     c.bnb_s = s_prev;
     c.bnb = XForm{mean, invstd, gamma, beta, gelu != 0};
     c.write_gz = gelu == 2;
-    return rpb_cmw_launch(c, (hipStream_t)stream);
+    return rpb_cmx_wg_launch(c, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------- cell_wgrad

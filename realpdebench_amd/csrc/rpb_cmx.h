@@ -30,7 +30,7 @@ struct CmxArgs {
     int claim_mode;       // how the (b,t,h) lines reach the waves: 0 dealt round-robin | 1 claimed from a workgroup counter (LDS) | 2 claimed chip-wide
     int* claim_ctr;       //   mode 2: zero on entry, left zero (the last claim resets it)
     unsigned long long* wave_times;   // diagnostics (rpb_cmx_debug_wave_times): [block][wave][2] constant-clock ticks at wave start / end, or null
-    float* wg_part;       // rpb_cmw.hip only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
+    float* wg_part;       // WG launch only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
 };
 
 bool rpb_cmx_dft_supported(int Wp, int K2f);
@@ -40,14 +40,12 @@ bool rpb_cmx128_supported(long ncell, int KC, int CO, int K2, int Wp, bool spec,
 long rpb_cmx128_stat_rows(long ncell, int Wp);           // partial rows of [2][128]
 int rpb_cmx_launch(const CmxArgs& a, int stats, hipStream_t st);
 
-// csrc/rpb_cmw.hip: the STATS == 2 launch with the 1x1-conv weight gradient of the same layer riding along (x = gs of the layer,
-// bnb_s = the pre-BN tensor whose activation is the layer input): dWc[co][ci] = sum_cells x[cell][co] * act(BN(bnb_s))[cell][ci]
-// two organisations: wave pairs inside the two-waves-per-SIMD kernel (rpb_cmx.hip, the default) and one wave per SIMD (rpb_cmw.hip,
-// RPB_CMW_VARIANT=1); the partial-row count is the same function of the problem for both
-long rpb_cmx_wg_slots(long ncell, int Wp);
+// The STATS == 2 launch with the 1x1-conv weight gradient of the same layer riding along (x = gs of the layer, bnb_s = the pre-BN tensor
+// whose activation is the layer input): dWc[co][ci] = sum_cells x[cell][co] * act(BN(bnb_s))[cell][ci] -- wave pairs inside the
+// two-waves-per-SIMD kernel (rpb_cmx.hip, template parameter WG).  (The one-wave-per-SIMD organisation of round 4, measured slower in
+// every A/B of rounds 4 and 5, is archived under tools/archive/rpb_cmw.hip and no longer compiled.)
+long rpb_cmx_wg_slots(long ncell, int Wp);         // partial rows of stats_part ([2][64]) and wg_part ([64][64])
 int rpb_cmx_wg_launch(const CmxArgs& a, hipStream_t st);
-long rpb_cmw_slots(long ncell, int Wp);            // partial rows of stats_part ([2][64]) and wg_part ([64][64])
-int rpb_cmw_launch(const CmxArgs& a, hipStream_t st);
 
 // csrc/rpb_cwx.hip: rpb_cell_wgrad's (CO, CI) = (128, 128) instance without the crop on the bf16 matrix pipe (width-128 Fourier layers)
 bool rpb_cwx128_supported(long ncell, int CO, int CI, int crop, int W);

@@ -103,7 +103,7 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       (x = gs of the layer, bnb_s = the pre-BN tensor whose activation is the layer input; autograd of fno.py:115).  The product
 //       contracts over CELLS, so it wants both factors as "8 cells of one channel per lane": act(z) has that form in the epilogue
 //       (accumulator layout), gs does not (it is this kernel's A operand, lane = cell).  A wave that did both would need 64 more
-//       accumulator registers than the 256 of a two-waves-per-SIMD kernel (the one-wave-per-SIMD version, csrc/rpb_cmw.hip, is
+//       accumulator registers than the 256 of a two-waves-per-SIMD kernel (the one-wave-per-SIMD version, tools/archive/rpb_cmw.hip, was
 //       bound by its own instruction stream: 3.4 ms against 2.4 ms for this launch without the product).  So the workgroup is
 //       FOUR PAIRS of waves: "mix" wave p (waves 0-3) is the STATS == 2 kernel and additionally leaves act(z) of its tile -- one erf
 //       serves act and act' -- in an 8 KB LDS mailbox; "wgrad" wave p + 4 fetches the same tile's gs in accumulator layout (L2 hits:
@@ -942,6 +942,10 @@ long rpb_cmx_wg_slots(long ncell, int Wp) {
     return grid * CMX_WG_PAIRS;
 }
 int rpb_cmx_wg_launch(const CmxArgs& a_in, hipStream_t st) {
+    RPB_REQUIRE(a_in.x && a_in.Wm && a_in.z2 && a_in.GW && a_in.out && a_in.stats_part && a_in.wg_part && a_in.bnb_s && a_in.bnb.mean,
+                "cell_mix_wgrad: null pointer");
+    RPB_REQUIRE(!a_in.bias && !a_in.xf.mean && !a_in.bf16_io && !a_in.feat_w && !a_in.y1out && a_in.crop_T == 0,
+                "cell_mix_wgrad: plain fp32 backward launch only");
     CmxArgs a = a_in;
     a.wave_times = g_cmx_wave_times;
     cmx_claim_setup(a, st);

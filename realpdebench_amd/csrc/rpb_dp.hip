@@ -84,6 +84,11 @@ struct DpHandle {
     int have_wait;
     hipEvent_t marks[DP_MAX_MARKS];                      // rpb_dp_mark / rpb_dp_wait_mark: points of the side stream other streams can wait for
     int marks_made;
+    // instrumentation of the marks (sharded step: the parameter all-gathers the NEXT forward waits for, per bucket): the moment the side
+    // stream passed mark idx (mk1) and the moment a consumer stream reached its wait for it (mw0); nb_at_wait = buckets recorded when the
+    // consumer's rpb_dp_allreduce_wait was issued (the gathers of a sharded step are recorded after it)
+    hipEvent_t mk1[DP_MAX_MARKS], mw0[DP_MAX_MARKS];
+    int mk_set[DP_MAX_MARKS], mw_set[DP_MAX_MARKS], nb_at_wait;
     // modelled transfers (one-GPU proxy of an N-rank run, rpb_dp_set_model): after every collective the side stream idles for the time
     // the operation would take over the interconnect of `model_world` ranks at `model_gbps` per direction and rank
     int model_world;
@@ -138,8 +143,9 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
     h->world = world;
     h->enqueued = 0;
     h->timing = h->events_made = 0;
-    h->nb = h->ni = h->have_wait = 0;
+    h->nb = h->ni = h->have_wait = h->nb_at_wait = 0;
     h->marks_made = 0;
+    for (int i = 0; i < DP_MAX_MARKS; ++i) h->mk_set[i] = h->mw_set[i] = 0;
     h->model_world = 0;
     h->model_gbps = h->model_lat_us = 0.f;
     nccl_uid_t id;
@@ -190,6 +196,7 @@ extern "C" int rpb_dp_allreduce_wait(void* handle, void* consumer_stream) {
     if (h->timing) {
         RPB_HIP(hipEventRecord(h->cwait, (hipStream_t)consumer_stream), "dp record");
         h->have_wait = 1;
+        h->nb_at_wait = h->nb;
     }
     RPB_HIP(hipEventRecord(h->done, h->side), "dp record");
     RPB_HIP(hipStreamWaitEvent((hipStream_t)consumer_stream, h->done, 0), "dp wait");
@@ -263,12 +270,20 @@ extern "C" int rpb_dp_mark(void* handle, int idx) {
         h->marks_made = 1;
     }
     RPB_HIP(hipEventRecord(h->marks[idx], h->side), "dp record");
+    if (h->timing && h->events_made && !h->mk_set[idx]) {   // one-shot per rpb_dp_set_timing(1): the first mark and the first wait for it
+        RPB_HIP(hipEventRecord(h->mk1[idx], h->side), "dp record");
+        h->mk_set[idx] = 1;
+    }
     return RPB_OK;
 }
 extern "C" int rpb_dp_wait_mark(void* handle, int idx, void* stream) {
     RPB_REQUIRE(handle && idx >= 0 && idx < DP_MAX_MARKS, "dp_wait_mark: bad arguments");
     DpHandle* h = (DpHandle*)handle;
     if (!h->marks_made) return RPB_OK;                   // nothing was ever marked
+    if (h->timing && h->events_made && h->mk_set[idx] && !h->mw_set[idx]) {
+        RPB_HIP(hipEventRecord(h->mw0[idx], (hipStream_t)stream), "dp record");
+        h->mw_set[idx] = 1;
+    }
     RPB_HIP(hipStreamWaitEvent((hipStream_t)stream, h->marks[idx], 0), "dp wait");
     return RPB_OK;
 }
@@ -296,12 +311,17 @@ extern "C" int rpb_dp_set_timing(void* handle, int on) {
             RPB_HIP(hipEventCreate(&h->i0[i]), "dp event");
             RPB_HIP(hipEventCreate(&h->i1[i]), "dp event");
         }
+        for (int i = 0; i < DP_MAX_MARKS; ++i) {
+            RPB_HIP(hipEventCreate(&h->mk1[i]), "dp event");
+            RPB_HIP(hipEventCreate(&h->mw0[i]), "dp event");
+        }
         RPB_HIP(hipEventCreate(&h->cwait), "dp event");
         RPB_HIP(hipEventCreate(&h->first), "dp event");
         h->events_made = 1;
     }
     h->timing = on ? 1 : 0;
-    h->nb = h->ni = h->have_wait = 0;                    // (re)start the records
+    h->nb = h->ni = h->have_wait = h->nb_at_wait = 0;    // (re)start the records
+    for (int i = 0; i < DP_MAX_MARKS; ++i) h->mk_set[i] = h->mw_set[i] = 0;
     return RPB_OK;
 }
 
@@ -309,7 +329,12 @@ extern "C" int rpb_dp_set_timing(void* handle, int on) {
 // buckets nb, out[1] = number of inline reductions ni, out[2] = exposed milliseconds (how long after the consumer stream reached its
 // wait the last bucket finished; 0 when the reduction was fully hidden), out[3] = milliseconds from the first bucket's
 // announcement to the end of the last bucket, then nb triples (start since the first announcement, duration, bytes) and ni inline
-// durations.  Returns the number of floats written, or a negative status.
+// durations.  The exposed time counts the buckets enqueued BEFORE the wait (a sharded step records its parameter all-gathers after it:
+// those end after the Adam launch by construction and are not "exposure" of the wait).  When there is room, one more float follows the
+// inline durations: the sum over the marks of how long a consumer stream that reached rpb_dp_wait_mark(idx) had to wait for the side stream
+// to pass the mark (the sharded step's exposed all-gather time in the NEXT forward pass: the first mark / first wait of every index since
+// rpb_dp_set_timing(1) -- turn timing on, run two steps, synchronise, read).
+// Returns the number of floats written, or a negative status.
 extern "C" int rpb_dp_step_times(void* handle, float* out, int max_out) {
     RPB_REQUIRE(handle && out && max_out >= 4, "dp_step_times: bad arguments");
     DpHandle* h = (DpHandle*)handle;
@@ -319,9 +344,10 @@ extern "C" int rpb_dp_step_times(void* handle, float* out, int max_out) {
     out[1] = (float)ni;
     out[2] = out[3] = 0.f;
     float ms = 0.f;
+    const int nw = h->nb_at_wait > 0 && h->nb_at_wait <= nb ? h->nb_at_wait : nb;
     if (nb > 0 && h->have_wait) {
-        if (hipEventElapsedTime(&ms, h->cwait, h->b1[nb - 1]) == hipSuccess) out[2] = ms > 0.f ? ms : 0.f;
-        if (hipEventElapsedTime(&ms, h->first, h->b1[nb - 1]) == hipSuccess) out[3] = ms;
+        if (hipEventElapsedTime(&ms, h->cwait, h->b1[nw - 1]) == hipSuccess) out[2] = ms > 0.f ? ms : 0.f;
+        if (hipEventElapsedTime(&ms, h->first, h->b1[nw - 1]) == hipSuccess) out[3] = ms;
     }
     for (int i = 0; i < nb; ++i) {
         out[4 + 3 * i] = hipEventElapsedTime(&ms, h->first, h->b0[i]) == hipSuccess ? ms : -1.f;
@@ -329,6 +355,14 @@ extern "C" int rpb_dp_step_times(void* handle, float* out, int max_out) {
         out[6 + 3 * i] = (float)h->bbytes[i];
     }
     for (int i = 0; i < ni; ++i) out[4 + 3 * nb + i] = hipEventElapsedTime(&ms, h->i0[i], h->i1[i]) == hipSuccess ? ms : -1.f;
+    if (4 + 3 * nb + ni + 1 <= max_out) {
+        float gsum = 0.f;
+        if (h->events_made)
+            for (int i = 0; i < DP_MAX_MARKS; ++i)
+                if (h->mk_set[i] && h->mw_set[i] && hipEventElapsedTime(&ms, h->mw0[i], h->mk1[i]) == hipSuccess && ms > 0.f) gsum += ms;
+        out[4 + 3 * nb + ni] = gsum;
+        return 4 + 3 * nb + ni + 1;
+    }
     return 4 + 3 * nb + ni;
 }
 
@@ -358,6 +392,10 @@ static int dp_teardown(void* handle, bool abort) {
             (void)hipEventDestroy(h->b1[i]);
             (void)hipEventDestroy(h->i0[i]);
             (void)hipEventDestroy(h->i1[i]);
+        }
+        for (int i = 0; i < DP_MAX_MARKS; ++i) {
+            (void)hipEventDestroy(h->mk1[i]);
+            (void)hipEventDestroy(h->mw0[i]);
         }
         (void)hipEventDestroy(h->cwait);
         (void)hipEventDestroy(h->first);

@@ -162,6 +162,9 @@ class RcclComm:
         nb = int(b[0])
         res = {"buckets": [{"start_ms": b[4 + 3 * i], "ms": b[5 + 3 * i], "MB": b[6 + 3 * i] / 1e6} for i in range(nb)],
                "exposed_ms": b[2], "first_announce_to_last_done_ms": b[3]}
+        ni_main = int(b[1])
+        if len(b) > 4 + 3 * nb + ni_main:       # sharded step: what the forward pass after it waited for parameter gathers (per-bucket marks)
+            res["gather_exposed_ms"] = b[4 + 3 * nb + ni_main]
         s = read(self.small)
         ni, off = int(s[1]), 4 + 3 * int(s[0])
         res["inline_ms"] = s[off:off + ni]

@@ -223,7 +223,7 @@ def cell_mix_wgrad_slots(ncell, Wp):
 
 
 def cell_mix_wgrad(gs, Wc, z2, FW, out, stats_part, wg_part, ncell, K2, Wp, bnb, write_gz=True):
-    """Backward cell_mix of a Fourier layer at C = 64 with d convs.l.weight riding along (csrc/rpb_cmw.hip): ``bnb`` = (s_prev, mean,
+    """Backward cell_mix of a Fourier layer at C = 64 with d convs.l.weight riding along (the wave pairs of csrc/rpb_cmx.hip): ``bnb`` = (s_prev, mean,
     invstd, gamma, beta, gelu) of the layer below, whose activation is this layer's input.  ``stats_part`` / ``wg_part``:
     ``cell_mix_wgrad_slots`` partial rows of [2][64] / [64][64]."""
     C = 64

@@ -173,7 +173,7 @@ def test_full_size_properties_b32():
 def test_conv_weight_gradient_in_the_backward_cell_mix_equals_the_row_kernel_path(monkeypatch):
     """The default path (d convs.l.weight formed by the data-gradient cell_mix of layers >= 1 in wave pairs, csrc/rpb_cmx.hip WG; the
     row kernel without its layer-input operand) against RPB_CELL_MIX_WGRAD=0 (the round-3 split: weight gradient in bn_bwd_row) and
-    against the one-wave-per-SIMD organisation (csrc/rpb_cmw.hip, RPB_CMW_VARIANT=1), at the headline shape: same loss, every gradient
+    at the headline shape: same loss, every gradient
     within fp32 round-off (the paths sum the same products in a different order)."""
     from realpdebench_amd.trainer import Trainer
     sd = headline_state_dict(seed=29)
