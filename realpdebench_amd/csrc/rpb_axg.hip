@@ -16,6 +16,7 @@
 #include "rpb_axg.h"
 // (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -184,38 +185,46 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
                     }
                 }
                 if (!BFIN) {
-                    float v[4][8];
+                    // TAIL_ is a compile-time copy of the wave-uniform `tail`: the masking of rows past k_valid (a compare and four selects per
+                    // row) and the partial split exist in the last K-step's instance only -- every row of an earlier step is < 32 (KS - 1) < k_valid
+                    auto planes = [&](auto tail_tag) {
+                        constexpr bool TAIL_ = decltype(tail_tag)::value;
+                        float v[4][8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (e >= per) {                                       // uniform: only in the last step
+                        for (int e = 0; e < 8; ++e) {
+                            if (TAIL_ && e >= per) {                              // uniform: only in the last step
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) v[t][e] = 0.f;
-                            continue;
+                                for (int t = 0; t < 4; ++t) v[t][e] = 0.f;
+                                continue;
+                            }
+                            const f32x4v x4 = __builtin_bit_cast(f32x4v, zr[e]);
+                            // channel pairs: packed fp32 math; the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
+                            f32x2 xa = f32x2{x4[0], x4[1]}, xb = f32x2{x4[2], x4[3]};
+                            if (XF) {
+                                xa = pk_fma(xa, f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].be, xp[1].be});
+                                xb = pk_fma(xb, f32x2{xp[2].is, xp[3].is}, f32x2{xp[2].be, xp[3].be});
+                                if (xgelu) gelu2x2(xa, xb);
+                                if (TAIL_) {                                      // rows past k_valid must stay zero: the transform of a masked load is not
+                                    const bool live = 32 * ks + per * kg + e < a.k_valid;
+                                    xa = live ? xa : pk2(0.f);
+                                    xb = live ? xb : pk2(0.f);
+                                }
+                            }
+                            v[0][e] = xa[0];
+                            v[1][e] = xa[1];
+                            v[2][e] = xb[0];
+                            v[3][e] = xb[1];
                         }
-                        const f32x4v x4 = __builtin_bit_cast(f32x4v, zr[e]);
-                        // rows past k_valid must stay zero: the transform of a masked load is not
-                        const bool live = !XF || (32 * ks + per * kg + e < a.k_valid);
-                        // channel pairs: packed fp32 math; the two pairs' erf polynomials in lock-step (rpb_common.h, gelu2x2)
-                        f32x2 xa = f32x2{x4[0], x4[1]}, xb = f32x2{x4[2], x4[3]};
-                        if (XF) {
-                            xa = pk_fma(xa, f32x2{xp[0].is, xp[1].is}, f32x2{xp[0].be, xp[1].be});
-                            xb = pk_fma(xb, f32x2{xp[2].is, xp[3].is}, f32x2{xp[2].be, xp[3].be});
-                            if (xgelu) gelu2x2(xa, xb);
-                            xa = live ? xa : pk2(0.f);
-                            xb = live ? xb : pk2(0.f);
+                        if (TAIL_) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) split8n(v[t], (per + 1) >> 1, Bh[t], Bm[t], Bl[t]);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) split8(v[t], Bh[t], Bm[t], Bl[t]);
                         }
-                        v[0][e] = xa[0];
-                        v[1][e] = xa[1];
-                        v[2][e] = xb[0];
-                        v[3][e] = xb[1];
-                    }
-                    if (tail) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) split8n(v[t], (per + 1) >> 1, Bh[t], Bm[t], Bl[t]);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) split8(v[t], Bh[t], Bm[t], Bl[t]);
-                    }
+                    };
+                    if (tail) planes(std::true_type{});
+                    else planes(std::false_type{});
                 }
                 // ---- next step's loads go out now and are in flight during the MFMAs below
                 if (ks + 1 < KS) issue(ks + 1);

@@ -43,6 +43,19 @@ __device__ __forceinline__ u32x4 ld16a(rsrc_t r, int voff) {
 __device__ __forceinline__ void st16(f32x4v v, rsrc_t r, int voff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, RPB_STREAM_AUX);
 }
+// per-tensor policies of the SMALL streams (round 6 sweep, tools/eval_policy_sweep.sh): the z2 rows this launch reads were written by the
+// inverse H stage right before it, the Y1 rows the fused W stage writes are read by the next H stage right after it (0.9 GB each at the
+// headline shape; the 256 MB MALL can hold the tail of the producer / the head of the consumer)
+#ifndef CMX_Z_AUX
+#define CMX_Z_AUX RPB_STREAM_AUX
+#endif
+#ifndef CMX_Y_AUX
+#define CMX_Y_AUX RPB_STREAM_AUX
+#endif
+template <int AUX>
+__device__ __forceinline__ void st16a(f32x4v v, rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, AUX);
+}
 __device__ __forceinline__ float trunc_bf16(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u); }
 // (a, b) fp32 -> one dword of two truncated bf16 (a low half, b high half)
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {
@@ -410,7 +423,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
         }
         const rsrc_t rz = make_rsrc(a.z2 + g * K2 * CC + 64 * hsel, (unsigned)K2 * (unsigned)CB - 256u * (unsigned)hsel);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) zr[e] = ld16(rz, (8 * kg + e) * CB + m * 16);
+        for (int e = 0; e < 8; ++e) zr[e] = ld16a<CMX_Z_AUX>(rz, (8 * kg + e) * CB + m * 16);
     };
 
     u32x4* Zw = Zs + wave * 12 * 64 + lane;
@@ -733,7 +746,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            st16(f32x4v{Yacc[i][0][r], Yacc[i][1][r], Yacc[i][2][r], Yacc[i][3][r]}, ry, (16 * i + 4 * kg + r) * 256 + m * 16);
+                            st16a<CMX_Y_AUX>(f32x4v{Yacc[i][0][r], Yacc[i][1][r], Yacc[i][2][r], Yacc[i][3][r]}, ry, (16 * i + 4 * kg + r) * 256 + m * 16);
                     }
                 }
             }

@@ -155,7 +155,13 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
         delete h;
         RPB_FAIL(RPB_ERR_LAUNCH, "ncclCommInitRank: RCCL error %d (%s)", rc, R->errstr ? R->errstr(rc) : "?");
     }
-    RPB_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), "dp side stream");
+    {
+        // highest priority: when a CU slot frees up between two compute kernels the collective's kernel takes it first (its result is on
+        // the step's critical path at the end of backward; the compute kernel that loses the slot loses microseconds)
+        int pr_least = 0, pr_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = pr_greatest = 0;
+        RPB_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest), "dp side stream");
+    }
     RPB_HIP(hipEventCreateWithFlags(&h->ready, hipEventDisableTiming), "dp event");
     RPB_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming), "dp event");
     *handle = h;

@@ -31,7 +31,16 @@ int rpb_num_cus() {
     if (cus[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
+        // RPB_RESERVE_CUS = r (data-parallel runs): every persistent kernel of the library launches n - r workgroups (they take one CU each:
+        // two waves per SIMD at 256 registers), which leaves r CUs to the collective kernels of the side stream -- otherwise a collective's
+        // kernel waits for a compute workgroup to retire (up to a kernel duration, ~1-3 ms) or, once running, delays the next compute
+        // kernel's last workgroups (both regimes were measured with the modelled transfers).  Read ONCE per process:
+        // partial-row counts handed to Python (rpb_*_rows / _slots) and launch grids must agree for the life of the workspaces.
+        const char* e = getenv("RPB_RESERVE_CUS");
+        int r = e ? atoi(e) : 0;
+        if (r < 0) r = 0;
+        if (r > n / 2) r = n / 2;
+        cus[dev] = n - r;
     }
     return cus[dev];
 }
