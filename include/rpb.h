@@ -545,6 +545,24 @@ int rpb_dp_allreduce_abort(void* handle);   /* process exit: ncclCommAbort, neve
  *      nb x (start ms since the first announcement, duration ms, bytes), ni x inline duration ms } and returns the count. */
 int rpb_dp_set_timing(void* handle, int on);
 int rpb_dp_step_times(void* handle, float* out, int max_out);
+/*      Opt-in: the optimizer step over PEER POINTERS instead of a collective library (csrc/rpb_p2p.hip; SURVEY.md section 5.8: direct
+ *      reduce-scatter + all-gather over the fully connected xGMI mesh).  The host exchanges IPC handles of every rank's gradient arena,
+ *      parameter arena and flag block (2 x 16 zeroed 8-byte words) and hands `world` device pointers each -- valid in the calling process,
+ *      entry `rank` its own -- to rpb_dp_p2p_init (status: one zeroed int of this rank; total: arena elements, a multiple of 4).
+ *      rpb_dp_p2p_adam(h, m, v, ..., step, gscale, stream), called where the all-reduce path calls rpb_adam_step: announces this rank's
+ *      gradients (flag GRAD_READY = step at every peer), waits for all peers', then for the slice rpb_dp_p2p_slice names sums the W
+ *      gradient arenas in rank order, applies rpb_adam_step's update to p / m / v and stores the new parameters into all W parameter
+ *      arenas, and announces PARAM_DONE = step.  rpb_dp_p2p_wait(h, 1, step, stream) before the next read of the parameters (and before
+ *      the next backward overwrites the gradient arena).  kind: 0 GRAD_READY, 1 PARAM_DONE.  A wait that sees no flag for timeout_ms sets
+ *      *status = 1 + the silent rank and returns control to the stream (the update kernel then leaves the parameters untouched). */
+int rpb_dp_p2p_init(int rank, int world, void* const* grads, void* const* params, void* const* flags, void* status, long total,
+                    int timeout_ms, void** handle);
+int rpb_dp_p2p_slice(void* handle, long* first, long* count);
+int rpb_dp_p2p_signal(void* handle, int kind, long step, void* stream);
+int rpb_dp_p2p_wait(void* handle, int kind, long step, void* stream);
+int rpb_dp_p2p_adam(void* handle, float* m, float* v, float lr, float beta1, float beta2, float eps, long step, float gscale,
+                    void* stream);
+int rpb_dp_p2p_destroy(void* handle);
 
 /* ---- rollout: eval cell_mix (output = act(BatchNorm(.)) of THIS layer, as rpb_cell_mix with oxf_* / rpb_cell_mix_feat) with the NEXT
  *      layer's forward W stage fused in: y1 [ncell / Wp][K2f][64] = sum_w FWt[w][k] out[line, w][c], i.e. what

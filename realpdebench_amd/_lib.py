@@ -79,6 +79,12 @@ SIGNATURES = {
     "rpb_dp_set_model": (_I, "piff"),
     "rpb_dp_set_timing": (_I, "pi"),
     "rpb_dp_step_times": (_I, "ppi"),
+    "rpb_dp_p2p_init": (_I, "iipppp" + "li" + "p"),
+    "rpb_dp_p2p_slice": (_I, "ppp"),
+    "rpb_dp_p2p_signal": (_I, "pilp"),
+    "rpb_dp_p2p_wait": (_I, "pilp"),
+    "rpb_dp_p2p_adam": (_I, "ppp" + "ffff" + "l" + "f" + "p"),
+    "rpb_dp_p2p_destroy": (_I, "p"),
     "rpb_lift_bwd_rows": (_I, ""),
     "rpb_lift_bwd": (_I, "pppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm": (_I, "ppp" + "iiii" + "llll" + "ii" + "ppppi" + "p"),

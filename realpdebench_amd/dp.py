@@ -225,6 +225,76 @@ class StatsSync:
         pass
 
 
+class PeerExchange:
+    """Opt-in gradient exchange + optimizer step over PEER POINTERS (``DataParallel(model, p2p=True)`` / RPB_DP_P2P=1; C ABI
+    ``rpb_dp_p2p_*``, csrc/rpb_p2p.hip; SURVEY.md section 5.8: direct reduce-scatter + all-gather over the fully connected xGMI mesh
+    instead of RCCL's ring).  Every rank exports its gradient arena, its parameter arena and a 256-byte flag block through CUDA IPC
+    (``torch.multiprocessing.reductions.reduce_tensor`` -- the same handles ``torch.multiprocessing`` ships tensors with; torch is the
+    memory plumbing, ``torch.distributed`` carries the pickled handles once), opens everyone else's, and hands the raw device pointers to
+    the library.  Per step: ``adam(...)`` where the all-reduce path calls ``rpb_adam_step`` (rank r sums slice r of all W gradient
+    arenas, updates it, stores the new parameters into all W parameter arenas), ``params_wait()`` before the parameters are read again.
+    Ranks may share one GPU (the protocol test: RCCL refuses that, peer pointers do not).  No gradient-norm clipping on this path."""
+
+    def __init__(self, flat, grad, process_group=None, timeout_ms=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _lib
+        self._lib = _lib
+        _lib.load()
+        self.group = process_group
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        assert flat.is_cuda and grad.is_cuda and flat.is_contiguous() and grad.is_contiguous() and flat.numel() == grad.numel()
+        self.flags = torch.zeros(2 * 16, dtype=torch.int64, device=flat.device)
+        self.status = torch.zeros(1, dtype=torch.int32, device=flat.device)
+        torch.cuda.synchronize(flat.device)
+        mine = [reduce_tensor(t) for t in (grad, flat, self.flags)]          # [(rebuild_fn, args)] -- picklable IPC handles
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=process_group)
+        self.views = []                                                       # the opened peer tensors must outlive the handle
+        for q in range(self.world):
+            self.views.append((grad, flat, self.flags) if q == self.rank else tuple(fn(*args) for fn, args in everyone[q]))
+        for g, p, f in self.views:
+            assert g.numel() == grad.numel() and p.numel() == flat.numel() and f.numel() == 32, "ranks disagree about the arena"
+        arr = lambda i: (ctypes.c_void_p * self.world)(*[v[i].data_ptr() for v in self.views])
+        self._arrs = (arr(0), arr(1), arr(2))
+        h = ctypes.c_void_p()
+        tmo = int(timeout_ms if timeout_ms is not None else os.environ.get("RPB_DP_P2P_TIMEOUT_MS", "20000"))
+        _lib.call("rpb_dp_p2p_init", self.rank, self.world, ctypes.addressof(self._arrs[0]), ctypes.addressof(self._arrs[1]),
+                  ctypes.addressof(self._arrs[2]), self.status.data_ptr(), flat.numel(), tmo, ctypes.addressof(h))
+        self.handle = h.value
+        self.step_done = 0            # last step whose PARAM_DONE this rank still has to wait for (0 = none pending)
+        dist.barrier(group=process_group)     # nobody writes a flag before everybody has mapped everybody
+
+    def owned(self):
+        a, n = ctypes.c_long(), ctypes.c_long()
+        self._lib.call("rpb_dp_p2p_slice", self.handle, ctypes.addressof(a), ctypes.addressof(n))
+        return a.value, n.value
+
+    def adam(self, m, v, lr, beta1, beta2, eps, step, gscale):
+        self._lib.call("rpb_dp_p2p_adam", self.handle, m.data_ptr(), v.data_ptr(), float(lr), float(beta1), float(beta2), float(eps),
+                       int(step), float(gscale), torch.cuda.current_stream().cuda_stream, label="dp_p2p_adam")
+        self.step_done = int(step)
+
+    def params_wait(self):
+        """The current stream waits until every rank has written its slice of THIS rank's parameter arena (and is done reading this
+        rank's gradient arena).  No-op when nothing is pending."""
+        if self.step_done:
+            self._lib.call("rpb_dp_p2p_wait", self.handle, 1, self.step_done, torch.cuda.current_stream().cuda_stream)
+            self.step_done = 0
+
+    def check(self):
+        """Host check of the status word (one sync): raises if a wait timed out on a silent peer."""
+        s = int(self.status.item())
+        if s:
+            raise RuntimeError(f"rpb_dp_p2p: rank {self.rank} timed out waiting for rank {s - 1} (its process is gone or stalled)")
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            self._lib.call("rpb_dp_p2p_destroy", self.handle)
+            self.handle = None
+            self.views = []
+
+
 class DataParallel:
     """``shard_optimizer`` (or RPB_DP_SHARD_ADAM=1): the optimizer step is sharded over the ranks (ZeRO-1 shape).  Every chunk of a layer's
     spectral gradient whose length divides by 4 * world is REDUCE-SCATTERED instead of all-reduced (rank r owns piece r), Adam runs on the
@@ -234,7 +304,7 @@ class DataParallel:
     updated by every rank.  ``shard_world`` > world_size is the one-GPU proxy of bench.py: pieces are sized for that many ranks (the
     rank updates 1 / shard_world of the arena; the step is then no longer a valid training step)."""
 
-    def __init__(self, model, process_group=None, shard_optimizer=None, shard_world=None):
+    def __init__(self, model, process_group=None, shard_optimizer=None, shard_world=None, p2p=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before DataParallel (one process per GPU)")
         self.model = model
@@ -256,6 +326,10 @@ class DataParallel:
         if len(self.buckets) > 16:
             raise ValueError(f"{len(self.buckets)} gradient buckets (n_layers + 2): rpb_dp_mark keeps 16 marks per communicator")
         self._step_sharded = False    # this step's big chunks travel as reduce-scatter (only the fused Trainer can consume that)
+        # p2p: the fused Trainer exchanges gradients and parameters over peer pointers (PeerExchange) -- no bucket travels at all
+        self.p2p_opt = bool(p2p) if p2p is not None else os.environ.get("RPB_DP_P2P") == "1"
+        self.peer = None              # PeerExchange, built by the trainer once it has its gradient arena
+        self._step_p2p = False
         self._plan = None
         self._pending = False         # sharded step: parameter all-gathers are in flight on the side stream
         self._works = []
@@ -283,7 +357,7 @@ class DataParallel:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- bucketed, overlapped gradient reduction
-    def begin_step(self, grad, sharded=False):
+    def begin_step(self, grad, sharded=False, p2p=False):
         """``sharded``: the caller consumes REDUCE-SCATTERED gradients (the fused ``Trainer.step``: Adam on the owned pieces, then
         ``gather_params``).  Every other caller -- the autograd path (`_FNO3dFunction.backward` + a torch optimizer), a trainer that
         clips by the whole gradient -- gets the plain all-reduce whatever ``shard_opt`` says: a reduce-scattered arena is only
@@ -291,6 +365,7 @@ class DataParallel:
         self._live()
         self._works, self._next, self._held = [], 0, {}
         self._step_sharded = bool(sharded) and self.shard_opt
+        self._step_p2p = bool(p2p) and self.peer is not None      # the caller reduces inside its optimizer step: nothing to enqueue
 
     def chunks(self, s, e):
         """[s, e) cut into pieces of at most ``chunk_elems`` elements (the same cut on every rank)."""
@@ -382,19 +457,33 @@ class DataParallel:
     def params_ready(self, bucket):
         """The compute stream waits for the all-gather of bucket ``bucket`` (index into ``self.buckets``: 0 = tail, ``layer_bucket(l)``,
         L + 1 = the fc0 head).  No-op unless a sharded step left gathers in flight."""
+        if self._pending and self.peer is not None:
+            self.peer.params_wait()            # one flag round covers the whole arena: the forward's first per-bucket wait does it
+            return
         if self._pending:
             self.comm.wait_mark(bucket)
 
     def params_ready_all(self):
         """Everything that reads the parameters outside a training forward (eval, checkpoints, tests) calls this first."""
         if self._pending:
-            self.comm.wait()
+            if self.peer is not None and self.peer.step_done:
+                self.peer.params_wait()
+            elif self.comm is not None:
+                self.comm.wait()
             self._pending = False
+
+    def peer_setup(self, flat, grad):
+        """Build the peer-pointer exchange once the trainer's gradient arena exists (collective: every rank calls it)."""
+        if self.peer is None:
+            self.peer = PeerExchange(flat, grad, self.group)
+        return self.peer
 
     def layer_bucket(self, l):
         return 1 + (self.model.n_layers - 1 - l)
 
     def _reduce(self, grad, s, e, big=False):
+        if self._step_p2p:
+            return
         for a, b in self.chunks(s, e):
             if self.comm is not None and grad.is_cuda:
                 if self._step_sharded and self._sharded(a, b, big):
@@ -438,6 +527,8 @@ class DataParallel:
         step raises instead of silently training unsynchronised (round-3 advisor finding)."""
         if self.comm is not None:
             self.comm.close()
+        if self.peer is not None:
+            self.peer.close()
         self.closed = True
 
     def _live(self):

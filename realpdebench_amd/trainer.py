@@ -49,6 +49,14 @@ class Trainer:
         world = dp.world_size if dp is not None else 1
         # sharded optimizer step: THIS trainer consumes reduce-scattered gradients, so it is the one that asks for them (dp.begin_step)
         sharded = dp is not None and bool(getattr(dp, "shard_opt", False))
+        # peer-pointer step (opt-in): no bucket travels during backward; the reduction happens inside the update kernel below
+        p2p = dp is not None and bool(getattr(dp, "p2p_opt", False))
+        if p2p:
+            if self.clip > 0:
+                raise NotImplementedError("DataParallel(p2p=True) has no gradient-norm clipping (the norm needs the reduced gradient "
+                                          "before the update); use the all-reduce or the sharded path with clip_grad_norm")
+            sharded = False
+            dp.peer_setup(model.flat.data, self.grad)
         tgt = model._unshape_grad(target.contiguous().float(), B)
         n = tgt.numel()
         if getattr(ws, "head_fused", False) and ws.head_loss_fused:
@@ -56,7 +64,7 @@ class Trainer:
             # inside the head's backward kernel -- no rpb_proj_fwd, no rpb_mse, no pred tensor in the training step
             model._forward_impl(x, ws, training=True, skip_head=True)
             if dp is not None:
-                dp.begin_step(self.grad, sharded=sharded)
+                dp.begin_step(self.grad, sharded=sharded, p2p=p2p)
             model._backward_impl(x, None, ws, self.grad, target=tgt, gscale=2.0 / (n * world))
             ops.reduce_partials(ws.hb_loss_part, ws.hb_slots, 1, out_f32=ws.loss, scale=1.0 / n)
         else:
@@ -64,7 +72,7 @@ class Trainer:
             ops.mse(out, tgt, None, ws.gout, ws.mse_part, n, 2.0 / 2.0 / (n * world))   # gout = 2*(p-t)/N_global
             ops.reduce_partials(ws.mse_part, ws.mse_part.numel(), 1, out_f32=ws.loss, scale=1.0 / n)
             if dp is not None:
-                dp.begin_step(self.grad, sharded=sharded)
+                dp.begin_step(self.grad, sharded=sharded, p2p=p2p)
             model._backward_impl(x, ws.gout, ws, self.grad)
         if dp is not None:
             dp.finish_step(self.grad)
@@ -79,7 +87,12 @@ class Trainer:
             gscale = min(1.0, self.clip / (norm + 1e-6))
         lr = self.current_lr()
         self.iteration += 1
-        if sharded:
+        if p2p:
+            # (finish_step above enqueued nothing: rank r's slice of the W gradient arenas is summed inside the update kernel, the new
+            #  parameters are stored into all W parameter arenas; the next reader of the parameters waits in dp.params_ready*)
+            dp.peer.adam(self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
+            dp._pending = True
+        elif sharded:
             # sharded optimizer step (dp.DataParallel): the gradient chunks were reduce-scattered, this rank updates the pieces it owns
             # (1 / world of the arena in ONE launch over the range table) and the parameter pieces travel back on the side stream while
             # the next forward pass starts (it waits per layer: model._forward_impl -> dp.params_ready)
