@@ -457,6 +457,11 @@ def bench_rollout_bf16(dev):
     res["rel_l2_vs_f32_step1"] = float(d[:, :T].norm() / outs["f32"][:, :T].double().norm())
     res["rel_l2_vs_f32_step20"] = float(d[:, -T:].norm() / outs["f32"][:, -T:].double().norm())
     res["config"] = f"FNO3d combustion volume [B={B},64,64,64,16] -> padded 70^3, modes (4,16,16), width 64, 4 layers, {n_ar} AR steps"
+    from realpdebench_amd import _lib
+    res["bf16_const_planes"] = _lib.query("rpb_bf16_const_planes")      # compile-time switch of the library (round-5 advisor finding: say it)
+    res["bf16_const_planes_note"] = ("planes of the fp32 constants multiplied with bf16-STORED operands (library build switch; 3 until round 4, "
+                                     "2 since round 5 with the end-to-end rel_l2_vs_f32_step1 measured unchanged at 3.3e-4); the rel_l2 "
+                                     "values of this object are THIS build's end-to-end rollout errors")
     m.set_storage("f32")
     del m
     torch.cuda.empty_cache()

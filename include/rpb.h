@@ -37,6 +37,10 @@ extern "C" {
 #define RPB_ABI_VERSION 2
 const char* rpb_last_error(void);
 int rpb_abi_version(void);
+/* bf16 activation STORAGE (BASELINE.json configs[4]; the opt-in rollout path): how many bf16 planes of the fp32 constants (conv / fc1 weights,
+ * DFT stage matrices) are multiplied with a bf16-stored operand -- 2 (default build: the third plane is 1 / 128 of the error the stored operand
+ * already carries) or 3 (-DRPB_BF16_CONST_PLANES=3).  The fp32-storage path always uses three planes of both operands. */
+int rpb_bf16_const_planes(void);
 
 /* K1  lift + zero-pad.  realpdebench/model/fno.py:106-111 (get_grid :135-143, cat, fc0, permute, F.pad).
  *     out[b,t,h,w,:] = fc0_w @ [x[b,t,h,w,:], gt[t], gh[h], gw[w]] + fc0_b inside T x H x W, 0 in the pad. */

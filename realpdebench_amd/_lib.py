@@ -17,6 +17,7 @@ _T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
 SIGNATURES = {
     "rpb_last_error": (ctypes.c_char_p, ""),
     "rpb_abi_version": (_I, ""),
+    "rpb_bf16_const_planes": (_I, ""),
     "rpb_lift_pad_fwd": (_I, "ppppppp" + "iiiiiiiii" + "p"),
     "rpb_lift_pad_fwd_bf16": (_I, "ppppppp" + "iiiiiiiii" + "p"),
     "rpb_axis_gemm_bf16in": (_I, "ppp" + "iiii" + "llll" + "i" + "p"),

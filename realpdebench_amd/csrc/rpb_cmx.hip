@@ -21,6 +21,7 @@
 //    GW and the conv weights are split once per workgroup into LDS in operand order.
 #include "rpb_cmx.h"
 #include <atomic>
+#include <mutex>
 // (cache policy of the streaming loads / stores: RPB_STREAM_AUX, rpb_common.h -- nt by default since round 5)
 #include <stdlib.h>
 #include <type_traits>
@@ -851,9 +852,11 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
 // with RPB_LINE_CLAIM=2 from the environment the first launch on a device allocates it (never inside a stream capture).
 static int* g_cmx_claim[64] = {nullptr};
 static std::atomic<unsigned> g_cmx_claim_next{0};
+static std::mutex g_cmx_claim_mu;                     // several host threads may launch on one device: allocate the ring once
 static int* cmx_claim_ring(hipStream_t st, bool may_alloc) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_cmx_claim_mu);
     if (!g_cmx_claim[dev] && may_alloc) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (st) (void)hipStreamIsCapturing(st, &cs);

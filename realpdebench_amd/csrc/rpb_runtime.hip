@@ -5,6 +5,7 @@
 thread_local char rpb_err_buf[512] = "";
 
 extern "C" const char* rpb_last_error() { return rpb_err_buf; }
+extern "C" int rpb_bf16_const_planes() { return RPB_BF16_CONST_PLANES; }   // planes of the fp32 constants multiplied with bf16-STORED operands
 extern "C" int rpb_abi_version() { return 2; }          // == RPB_ABI_VERSION of include/rpb.h (tests/test_abi.py compares them)
 
 void rpb_cmx_claim_prealloc();
