@@ -15,6 +15,7 @@
 // RCCL is resolved at run time (dlopen of the librccl already loaded into the process -- PyTorch-ROCm brings one -- else the
 // system one), so librpb_hip.so itself loads on hosts without RCCL and two RCCL copies never coexist in one process.
 #include "rpb_common.h"
+#include <stdlib.h>
 #include <dlfcn.h>
 
 namespace {
@@ -160,6 +161,8 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
         // the step's critical path at the end of backward; the compute kernel that loses the slot loses microseconds)
         int pr_least = 0, pr_greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = pr_greatest = 0;
+        const char* e = getenv("RPB_DP_SIDE_PRIORITY");                 // 0: a default-priority side stream (A/B switch)
+        if (e && atoi(e) == 0) pr_greatest = 0;
         RPB_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest), "dp side stream");
     }
     RPB_HIP(hipEventCreateWithFlags(&h->ready, hipEventDisableTiming), "dp event");

@@ -154,3 +154,31 @@ def test_bench_pmc_csv_to_family_traffic(tmp_path):
     assert per[names["f"]] == {"rd": ((10 * 128 + 2 * 64) + 14 * 128) / 2, "wr": 256.0}
     fam = bench.cell_mix_family_bytes(per)
     assert fam == pytest.approx((3 * f_bytes + (8 * 32 + 4 * 64) + 3 * (20 * 128 + 6 * 64)) / 7)
+
+
+def test_shipped_yamls_carry_the_references_values():
+    """Every YAML under realpdebench_amd/configs/<scenario>/ for the four north-star models has the reference's key set and values
+    (tests/golden/reference_configs.json: yaml.safe_load of realpdebench/configs/**, written by make_golden_configs.py), except the
+    documented dataset defaults (synthetic generator, no normaliser, no checkpoint) and the headline file's 128 x 128 shape / batch."""
+    import json
+
+    import yaml
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_configs.json")))
+    local = {"dataset_name", "dataset_root", "num_workers", "normalizer", "checkpoint_path", "shape_in", "shape_out", "n_train", "n_val",
+             "test_batch_size", "is_use_tb"}
+    n = 0
+    for scen, per in doc["configs"].items():
+        for stem in ("fno", "unet", "trainsolver", "galerkin_transformer"):
+            path = os.path.join(ROOT, "realpdebench_amd", "configs", scen, stem + ".yaml")
+            assert os.path.exists(path), path
+            mine = yaml.safe_load(open(path))
+            ref = per[stem]
+            missing = [k for k in ref if k not in mine and k not in local]
+            assert not missing, (scen, stem, missing)
+            for k, v in ref.items():
+                if k in local or k not in mine:
+                    continue
+                assert mine[k] == v or (isinstance(v, float) and abs(mine[k] - v) < 1e-12), (scen, stem, k, mine[k], v)
+            assert mine["model_name"] == ref["model_name"]
+            n += 1
+    assert n == 20

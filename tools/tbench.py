@@ -57,6 +57,6 @@ torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 3
 print(f"Transolver train step B={B}: {ms:.2f} ms -> {B / ms * 1e3:.2f} samples/s  (peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)")
 tot = sum(v["total_ms"] for v in _lib.profile_summary().values())
-for k, v in sorted(_lib.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"])[:14]:
+for k, v in sorted(_lib.profile_summary().items(), key=lambda kv: -kv[1]["total_ms"]):
     print(f"{k:40s} calls {v['calls'] / 3:5.1f} avg {v['avg_ms']:8.3f} ms {100 * v['total_ms'] / tot:5.1f}%  "
           f"{v['bytes'] / v['avg_ms'] / 1e6:8.1f} GB/s {v['flops'] / v['avg_ms'] / 1e9:7.2f} TF/s")
