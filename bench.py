@@ -53,6 +53,7 @@ def parse():
                     "now (default at N=1: two rocprofv3 --pmc request-size passes over tools/kbench.py cell_mix, --kernel-trace only, ~40 s)")
     ap.add_argument("--only-headline", action="store_true", help="the FNO train step only: no rollout, secondary models, PMC passes or CPU baseline")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--proxy-worker", type=float, default=None, help=argparse.SUPPRESS)     # child process of the scaling proxy: ms of the B = 32 step
     a = ap.parse_args()
     if a.only_headline:
         a.no_cpu_baseline = a.no_rollout = a.no_transolver = a.no_galerkin = a.no_dpot = a.no_unet = a.no_bf16 = a.no_pmc = True
@@ -769,6 +770,13 @@ def main():
         return cpu_baseline_worker()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    if a.proxy_worker is not None:
+        torch.cuda.set_device(0)
+        res = strong_scaling_proxy(torch.device("cuda", 0), float(a.proxy_worker))
+        sys.stdout.flush()
+        _flush_c_stdio()
+        print("PROXY_JSON " + json.dumps(res), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -955,8 +963,21 @@ def main():
         model = None
         torch.cuda.empty_cache()
         if not a.no_scaling_proxy and not force_dp:
+            # In its OWN process: the N-rank run the proxy stands for starts its data-parallel path in a fresh process too, and a process
+            # that has run the single-GPU sections first measures the DP steps differently (round 6: +4 .. +6 ms per step, DESIGN.md
+            # section 6).  This process frees its headline model first; the child reports a JSON object.
             try:
-                proxy = strong_scaling_proxy(dev, ms_per_step)
+                import subprocess
+                trainer = x = y = None
+                torch.cuda.empty_cache()
+                env = dict(os.environ, MASTER_PORT="29517")
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--proxy-worker", repr(float(ms_per_step))],
+                                   capture_output=True, text=True, timeout=900, env=env)
+                lines = [ln for ln in r.stdout.split("\n") if ln.startswith("PROXY_JSON ")]
+                if not lines:
+                    raise RuntimeError(f"proxy worker rc {r.returncode}: {r.stderr[-400:]}")
+                proxy = json.loads(lines[-1][len("PROXY_JSON "):])
+                proxy["process"] = "child process of bench.py (fresh HIP context), started after the timed regions"
             except Exception as e:                          # must never cost the bench line
                 proxy = {"error": repr(e)}
         for name, fn, flag in (("fno_native", bench_fno_native, a.no_fno_native), ("fno_fsi", bench_fno_fsi, a.no_fno_native),

@@ -157,12 +157,14 @@ extern "C" int rpb_dp_allreduce_init(const void* id128, int rank, int world, voi
         RPB_FAIL(RPB_ERR_LAUNCH, "ncclCommInitRank: RCCL error %d (%s)", rc, R->errstr ? R->errstr(rc) : "?");
     }
     {
-        // highest priority: when a CU slot frees up between two compute kernels the collective's kernel takes it first (its result is on
-        // the step's critical path at the end of backward; the compute kernel that loses the slot loses microseconds)
+        // RPB_DP_SIDE_PRIORITY=1: the side stream gets the highest stream priority (when a CU slot frees up between two compute kernels the
+        // collective's kernel takes it first).  OFF by default -- measured (round 6): in a fresh process it changes
+        // nothing (B = 4 step with the DP path 5.98 vs 6.09 ms), but inside bench.py, after the single-GPU sections have run in the same
+        // process, every DP step costs +4.2 ms with it (10.5 vs 6.1 ms at B = 4): a high-priority queue next to the queues the process
+        // already owns is not free on this runtime.
         int pr_least = 0, pr_greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_least = pr_greatest = 0;
-        const char* e = getenv("RPB_DP_SIDE_PRIORITY");                 // 0: a default-priority side stream (A/B switch)
-        if (e && atoi(e) == 0) pr_greatest = 0;
+        const char* e = getenv("RPB_DP_SIDE_PRIORITY");
+        if (!(e && atoi(e) == 1) || hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) pr_greatest = 0;
         RPB_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr_greatest), "dp side stream");
     }
     RPB_HIP(hipEventCreateWithFlags(&h->ready, hipEventDisableTiming), "dp event");
