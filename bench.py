@@ -903,7 +903,11 @@ def main():
         dp_info = {"ranks_in_process_group": dist.get_world_size(), "backend": backend,
                    "transport": (f"C-ABI rpb_dp_* (RCCL, side HIP stream, {'two communicators' if comm.small != comm.handle else 'one communicator'})"
                                  if comm is not None else f"torch.distributed {backend}"),
-                   "buckets_MB": [4e-6 * (e - s_) for s_, e in model.dp.buckets]}
+                   "buckets_MB": [4e-6 * (e - s_) for s_, e in model.dp.buckets],
+                   "optimizer_exchange": ("peer pointers: rpb_dp_p2p_* (no bucket travels; slice-owned reduce + Adam + broadcast)"
+                                          if getattr(model.dp, "p2p_opt", False) else
+                                          ("reduce-scatter + Adam on owned ranges + all-gather" if getattr(model.dp, "shard_opt", False)
+                                           else "all-reduce buckets + full-arena Adam"))}
         if comm is not None:
             comm.set_timing(True)
             trainer.step(x, y)

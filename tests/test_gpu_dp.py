@@ -282,3 +282,8 @@ def test_bench_two_ranks_self_launch_equals_single_rank():
     assert two["dp"]["ranks_in_process_group"] == 2 and len(two["dp"]["buckets_MB"]) == 6
     assert abs(two["first_step_loss"] - one["first_step_loss"]) < 1e-5 * abs(one["first_step_loss"])
     assert two["value"] > 0 and two["roofline"]["frac"] > 0
+    # the same two ranks with the optimizer step over peer pointers (RPB_DP_P2P=1: IPC-mapped arenas, no bucket travels): same losses --
+    # the first step's (computed before any update) and the last timed step's (after two peer-pointer updates; two ranks: a + b commutes)
+    p2p = run(2, {"RPB_BENCH_SHARE_GPU": "1", "RPB_DP_P2P": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert p2p["dp"]["optimizer_exchange"].startswith("peer pointers")
+    assert p2p["first_step_loss"] == two["first_step_loss"] and p2p["loss"] == two["loss"], (p2p["loss"], two["loss"])
