@@ -9,6 +9,7 @@ Adam launch over the flat parameter arena, closed-form LR schedule on the host. 
 device scalar; callers decide when to ``.item()`` it (the reference syncs 3-4 times per step, train.py:335-342).
 """
 import math
+import os
 
 import torch
 
@@ -142,7 +143,7 @@ class ArenaTrainer:
     BUCKET_ELEMS = 16 * 1024 * 1024          # 64 MB buckets: large enough for xGMI ring bandwidth, several in flight
 
     def __init__(self, model, lr, num_update, scheduler="cosine", step_size=1000, betas=(0.9, 0.999), eps=1e-8,
-                 clip_grad_norm=0.0, dp_group=None, micro_batch=None):
+                 clip_grad_norm=0.0, dp_group=None, micro_batch=None, p2p=None):
         if scheduler not in ("cosine", "step"):
             raise ValueError(f"Scheduler {scheduler} not supported")
         # micro_batch: a step over B samples runs as ceil(B / micro_batch) forward / backward passes whose gradients accumulate
@@ -189,15 +190,36 @@ class ArenaTrainer:
             core = getattr(model, "regressor", None)
             if core is not None and hasattr(core, "dp"):
                 core.dp = StatsSync(dp_group, comm=self.comm)       # BatchNorm3d over the global batch (SyncBN)
+        # p2p (opt-in, RPB_DP_P2P=1): gradients and parameters travel over peer pointers inside the update kernel (dp.PeerExchange,
+        # rpb_dp_p2p_*) instead of all-reduce buckets + a full-arena Adam on every rank; nothing is enqueued during backward
+        self.peer = None
+        want_p2p = bool(p2p) if p2p is not None else os.environ.get("RPB_DP_P2P") == "1"
+        if want_p2p and self.world > 1:
+            if self.clip > 0:
+                raise NotImplementedError("the peer-pointer optimizer step has no gradient-norm clipping; use the all-reduce path")
+            from .dp import PeerExchange
+            self.peer = PeerExchange(self.flat, self.grad, dp_group)
+            # evaluation through model(x) straight after a step must see every rank's slice (train_loss -> forward inside step() is
+            # covered by the explicit wait at the top of step())
+            model.register_forward_pre_hook(lambda _m, _a: self.settle())
         self._early = {}            # param -> its gradient tensor, all-reduce already in flight
         self._works = []
         self._had_grad = [False] * len(self.params)
+
+    def settle(self):
+        """Peer-pointer step: the current stream waits until every rank has stored its slice into this rank's parameter arena
+        (no-op otherwise / when nothing is pending).  Called before every read of the parameters outside ``step``."""
+        if self.peer is not None:
+            self.peer.params_wait()
 
     def close(self):
         """Teardown: destroy the RCCL communicators (also done at interpreter exit)."""
         if self.comm is not None:
             self.comm.close()
             self.comm = None
+        if self.peer is not None:
+            self.peer.close()
+            self.peer = None
 
     def current_lr(self):
         k = self.iteration
@@ -221,6 +243,7 @@ class ArenaTrainer:
     def step(self, input, target):
         model = self.model
         model.train()
+        self.settle()                                    # (peer-pointer step: the previous update's slices from the other ranks)
         for p in self.params:
             p.grad = None
         self._early, self._works = {}, []
@@ -234,7 +257,7 @@ class ArenaTrainer:
                 li.backward()                            # autograd accumulates into p.grad
                 loss = li.detach() if loss is None else loss + li.detach()
         else:
-            model._dp_early = self._dp_early if self.world > 1 else None
+            model._dp_early = self._dp_early if (self.world > 1 and self.peer is None) else None
             loss = model.train_loss(input, target).mean()
             loss.backward()
             model._dp_early = None
@@ -263,7 +286,7 @@ class ArenaTrainer:
                 self._had_grad[i] = True
         if late_dst:
             torch._foreach_copy_(late_dst, late_src)
-        if self.world > 1:
+        if self.world > 1 and self.peer is None:
             # everything not announced early: contiguous runs of the arena, cut into large buckets
             runs, start = [], None
             for p, o in zip(self.params, self.offsets):
@@ -295,8 +318,12 @@ class ArenaTrainer:
             gscale *= min(1.0, self.clip / (norm + 1e-6))
         lr = self.current_lr()
         self.iteration += 1
-        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.total, lr, self.betas[0], self.betas[1],
-                      self.eps, self.iteration, gscale)
+        if self.peer is not None:
+            # rank r sums slice r of the W gradient arenas, updates it and stores it into all W parameter arenas (rpb_dp_p2p_adam)
+            self.peer.adam(self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1], self.eps, self.iteration, gscale)
+        else:
+            ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.total, lr, self.betas[0], self.betas[1],
+                          self.eps, self.iteration, gscale)
         # the kernel wrote the arena through raw pointers: tell autograd's version counters, which the models' caches of
         # re-laid-out / split weights are keyed on (an in-place torch op would have done this)
         for p in self.params:
@@ -310,6 +337,7 @@ class ArenaTrainer:
     def checkpoint(self, extra=None, optimizer=False):
         """The reference's checkpoint (train.py:410-418: model weights + bookkeeping, NO optimizer state -- a resumed run starts Adam
         from zero moments there, and here).  ``optimizer=True`` adds the two moment arenas for callers that want an exact resume."""
+        self.settle()
         ck = {"model_state_dict": self.model.state_dict(), "iteration": self.iteration}
         if optimizer:
             ck["arena_adam_state"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}

@@ -128,3 +128,51 @@ def test_silent_peer_times_out_instead_of_hanging():
         mp.spawn(_timeout_worker, args=(world, port, out), nprocs=world, join=True)
         res = dict(out)
     assert res["raised"] is True and res["untouched"] is True
+
+
+# ------------------------------------------------------------------------------------------ the arena models (ArenaTrainer)
+def _arena_worker(rank, world, port, kind, p2p, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RPB_DP_P2P="1" if p2p else "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_gpu_dp import _small_model
+        from realpdebench_amd.trainer import ArenaTrainer, make_trainer
+        torch.cuda.set_device(0)
+        model, shape = _small_model(kind)
+        model = model.cuda()
+        tr = make_trainer(model, lr=1e-3, num_update=10)
+        assert isinstance(tr, ArenaTrainer) and tr.world == 2 and (tr.peer is not None) == p2p
+        g = torch.Generator().manual_seed(8)
+        x, y = torch.randn(4, *shape, generator=g), torch.randn(4, *shape, generator=g)
+        idx = list(range(rank * 2, rank * 2 + 2))
+        xs, ys = x[idx].cuda(), y[idx].cuda()
+        losses = [float(tr.step(xs, ys)) for _ in range(2)]
+        model.eval()
+        with torch.no_grad():
+            ev = model(xs).cpu()                          # the forward pre-hook waits for the peers' slices of the second update
+        ck = tr.checkpoint()
+        torch.cuda.synchronize()
+        if p2p:
+            tr.peer.check()
+        dist.barrier()
+        out[rank] = {"flat": tr.flat.cpu(), "loss": losses, "eval": ev}
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["transolver", "unet"])
+def test_arena_trainer_peer_pointer_step_equals_allreduce_step(kind):
+    """RPB_DP_P2P=1 with the nn.Parameter models (ArenaTrainer: one flat arena per rank, no buckets, rpb_dp_p2p_adam) == the gloo
+    all-reduce + rpb_adam_step path, bit for bit over two steps with two ranks on one GPU."""
+    res = {}
+    for p2p in (False, True):
+        world, port = 2, _free_port()
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_arena_worker, args=(world, port, kind, p2p, out), nprocs=world, join=True)
+            res[p2p] = {k: v for k, v in out.items()}
+    assert torch.equal(res[True][0]["flat"], res[True][1]["flat"])
+    assert torch.equal(res[True][0]["flat"], res[False][0]["flat"]), float((res[True][0]["flat"] - res[False][0]["flat"]).abs().max())
+    assert res[True][0]["loss"] == res[False][0]["loss"] and res[True][1]["loss"] == res[False][1]["loss"]
+    assert torch.equal(res[True][1]["eval"], res[False][1]["eval"])
