@@ -961,6 +961,40 @@ def main():
                                 "achieved": fwd_bytes / (1e9 * rt / a.rollout_steps), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": fwd_bytes / (1e9 * rt / a.rollout_steps) / HBM_PEAK_GBS}}
 
+    # ---- the same rollout on the OPT-IN f16x2 eval arithmetic (FNO3d.set_arith: two fp16 planes per operand, three products, dropped term
+    #      <= 2^-22 |a b| -- below the fp32 grade of the line above, which stays the headline): a labelled secondary line with its error
+    rollout_h2 = None
+    if rollout is not None and world == 1:
+        try:
+            ref_out = autoregressive_rollout(model, x, a.rollout_steps).clone()
+            model.set_arith("f16x2")
+            out_h2 = autoregressive_rollout(model, x, a.rollout_steps)          # warm-up at full length
+            err = float(torch.linalg.vector_norm((out_h2 - ref_out).double()) / torch.linalg.vector_norm(ref_out.double()))
+            err1 = float(torch.linalg.vector_norm((out_h2[:, :shape[0]] - ref_out[:, :shape[0]]).double())
+                         / torch.linalg.vector_norm(ref_out[:, :shape[0]].double()))
+            del ref_out, out_h2
+            rts2 = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                autoregressive_rollout(model, x, a.rollout_steps)
+                barrier()
+                rts2.append(time.perf_counter() - t0)
+            rt2 = sum(rts2) / len(rts2)
+            rollout_h2 = {"value": B * shape[0] * a.rollout_steps / rt2, "unit": "fields/s", "ms_per_forward": 1e3 * rt2 / a.rollout_steps,
+                          "ms_per_forward_min": 1e3 * min(rts2) / a.rollout_steps, "runs": len(rts2),
+                          "speedup_vs_default": rt / rt2,
+                          "frac": fwd_bytes / (1e9 * rt2 / a.rollout_steps) / HBM_PEAK_GBS,
+                          "rel_l2_vs_default_step1": err1, f"rel_l2_vs_default_{a.rollout_steps}_steps": err,
+                          "arithmetic": "OPT-IN (FNO3d.set_arith('f16x2')): eval cell_mix launches and the head with operands as two fp16 "
+                                        "planes (RNE, one fp32 ulp), three products per fp32 product, dropped term <= 2^-22 |a b|; "
+                                        "NOT the headline: the default rollout above drops <= 2^-24",
+                          "tolerance": "stated by this repo: Rel-L2 vs the default path < 5e-6 per forward (tests/test_gpu_f16x2.py)"}
+        except Exception as e:                                  # must never cost the bench line
+            rollout_h2 = {"error": repr(e)}
+        finally:
+            model.set_arith("f32")
+
     extra = {}
     proxy = None
     if world == 1:
@@ -1054,6 +1088,7 @@ def main():
             "rollout_ms_per_forward": rollout["ms_per_forward"] if rollout else None,
             "rollout_frac": rollout["roofline"]["frac"] if rollout else None,
             "rollout": rollout,
+            "rollout_f16x2": rollout_h2,
             "loss": float(loss),
             "first_step_loss": first_loss_global,
             "loss_check": loss_check,
@@ -1108,6 +1143,11 @@ def main():
             rf["rollout_ms_per_forward"] = rollout["ms_per_forward"]
             rf["rollout_frac"] = rollout["roofline"]["frac"]
             rf["rollout_GBps"] = rollout["roofline"]["achieved"]
+        if rollout_h2 and "error" not in rollout_h2:            # opt-in secondary arithmetic: flat, labelled by name
+            rf["rollout_f16x2_optin_fields_per_s"] = rollout_h2["value"]
+            rf["rollout_f16x2_optin_ms_per_forward"] = rollout_h2["ms_per_forward"]
+            rf["rollout_f16x2_optin_frac"] = rollout_h2["frac"]
+            rf["rollout_f16x2_optin_rel_l2_vs_default"] = rollout_h2["rel_l2_vs_default_step1"]
         if loss_check:
             rf["loss_check_rel_err"] = loss_check.get("rel_err")
         if dp_info:

@@ -592,6 +592,27 @@ int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, co
                            int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
                            const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io, int spectra_bf16, void* stream);
 
+/* ---- rollout, OPT-IN arithmetic "f16x2" (FNO3d.set_arith("f16x2"); never the default, never used by training): the two launches above
+ *      on fp32 storage with every operand as TWO fp16 planes rounded to nearest even (x = hi + lo to one fp32 unit in the last place) and
+ *      three products hi*lo + lo*hi + hi*hi per fp32 product on v_mfma_f32_16x16x32_f16 -- the dropped lo*lo term is <= 2^-22 |a b| (the
+ *      grade of 3xTF32; the default path's six bf16 products drop <= 2^-24).  Half the matrix-pipe time, 2.5 instead of 5.5 vector
+ *      instructions per split value.  fp16's range: the conv weights / bias carry 2^4 (undone in the output transform's scale), GWt is
+ *      multiplied by 2^spec_exp and the z2 rows by 2^-spec_exp before they are split -- all exact.  spec_exp = floor(log2(Tp Hp Wp)) - 1
+ *      (max |GWt| 2^spec_exp in (0.5, 1]).  With feat_w > 0 the K = feat_w mixing of the raw feature fields stays on bf16 planes.
+ *      Activations must lie inside fp16's range (|a| < 65504: they are BatchNorm (+GELU) outputs). */
+int rpb_cell_mix_eval_dft_f16x2(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out,
+                                long ncell, int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd,
+                                const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1,
+                                void* scratch, int spec_exp, void* stream);
+int rpb_cell_mix_eval_crop_f16x2(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out, int B,
+                                 int T, int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
+                                 const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int spec_exp, void* stream);
+
+/* the projection head's evaluation forward on the same opt-in arithmetic (C = 64, 1 <= DO <= 4, exact-erf GELU, plain fp32 activations;
+ * fc1.weight carries 2^4, undone inside GELU's two affine uses of the accumulator) */
+int rpb_proj_fwd_f16x2(const float* a, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, float* out,
+                       long ncrop, int DO, int T, int H, int W, int Tp, int Hp, int Wp, void* stream);
+
 /* ---- DPOT: AFNO patch transformer (realpdebench/model/dpot.py + dpot_libs/models/dpot.py).  Tokens are
  *      channels-last rows; the dense layers run on rpb_gemm_nt / rpb_gemm_tn, the 2-D DFT stages on rpb_axis_gemm.
  *      rpb_dpot_patch_tokens: PatchEmbed's input gather -- P[((b*nx + px)*ny + py)*T + t][(c*ps + i)*ps + j] for the conv weight

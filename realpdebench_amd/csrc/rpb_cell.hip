@@ -523,6 +523,51 @@ extern "C" int rpb_cell_mix_eval_dft(const float* x, const float* Wm, const floa
     c.FWt = FWt; c.y1out = y1; c.K2f = K2f; c.gw_planes = scratch;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
+// The same launch on the opt-in "f16x2" arithmetic (csrc/rpb_cmx.hip, template parameter H2): operands as two fp16 planes (round to nearest
+// even: one fp32 unit in the last place), three products per fp32 product, dropped term <= 2^-22 |a b| -- below the fp32 grade of the
+// default path, which is why it is a separate, explicitly named entry point.  spec_exp: floor(log2(Tp * Hp * Wp)) - 1 (the exact
+// power-of-two rescaling of GWt / z2 that keeps both inside fp16's range).
+extern "C" int rpb_cell_mix_eval_dft_f16x2(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+                                           long ncell, int K2, int Wp, int feat_w, const float* oxf_mean, const float* oxf_invstd,
+                                           const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, const float* FWt, int K2f, float* y1,
+                                           void* scratch, int spec_exp, void* stream) {
+    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta && FWt && y1 && scratch, "cell_mix_eval_dft_f16x2: null pointer");
+    RPB_REQUIRE(feat_w == 0 || feat_w == 8 || feat_w == 32, "cell_mix_eval_dft_f16x2: feat_w=%d", feat_w);
+    RPB_REQUIRE(spec_exp >= 0 && spec_exp <= 40, "cell_mix_eval_dft_f16x2: spec_exp=%d", spec_exp);
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false) && rpb_cmx_dft_supported(Wp, K2f),
+                "cell_mix_eval_dft_f16x2: unsupported sizes (K2=%d Wp=%d K2f=%d)", K2, Wp, K2f);
+    CmxArgs c{};
+    c.x = x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.feat_w = feat_w;
+    c.FWt = FWt; c.y1out = y1; c.K2f = K2f; c.gw_planes = scratch;
+    c.h2 = 1; c.spec_exp = spec_exp;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
+// ... and the crop-only last layer (fp32 storage)
+extern "C" int rpb_cell_mix_eval_crop_f16x2(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+                                            int B, int T, int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean,
+                                            const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu,
+                                            int spec_exp, void* stream) {
+    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_eval_crop_f16x2: null pointer");
+    RPB_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && T <= Tp && H <= Hp && W <= Wp, "cell_mix_eval_crop_f16x2: bad crop (%d %d %d of %d %d %d)", T, H, W, Tp, Hp, Wp);
+    RPB_REQUIRE(spec_exp >= 0 && spec_exp <= 40, "cell_mix_eval_crop_f16x2: spec_exp=%d", spec_exp);
+    const long ncell = (long)B * Tp * Hp * Wp;
+    RPB_REQUIRE((long)B * T * H < (1l << 31), "cell_mix_eval_crop_f16x2: too many lines");
+    RPB_REQUIRE(rpb_cmx_supported(ncell, 64, 64, K2, Wp, true, false), "cell_mix_eval_crop_f16x2: needs C = 64, K2 <= 32, Wp >= 32 (K2=%d Wp=%d)", K2, Wp);
+    CmxArgs c{};
+    c.x = x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.crop_T = T; c.crop_H = H; c.crop_W = W; c.Tp = Tp; c.Hp = Hp;
+    c.h2 = 1; c.spec_exp = spec_exp;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
 // Eval cell_mix of the LAST Fourier layer (fno.py:117-121: BatchNorm, no GELU, then x[..., :-6, :-6, :-6, :] -> fc1): only the
 // B * T * H lines of the crop are produced, each up to the tile that holds cell W - 1; the pad cells of `out` keep whatever they held
 // (nothing reads them: rpb_proj_fwd walks the crop).  bf16_io: x / out are bf16 [ncell][64].

@@ -30,6 +30,9 @@ struct CmxArgs {
     int claim_mode;       // how the (b,t,h) lines reach the waves: 0 dealt round-robin | 1 claimed from a workgroup counter (LDS) | 2 claimed chip-wide
     int* claim_ctr;       //   mode 2: zero on entry, left zero (the last claim resets it)
     unsigned long long* wave_times;   // diagnostics (rpb_cmx_debug_wave_times): [block][wave][2] constant-clock ticks at wave start / end, or null
+    int h2;               // eval launches on fp32 storage: the opt-in f16x2 arithmetic (two fp16 planes per operand, three products; rpb_cmx.hip "H2")
+    int spec_exp;         //   with h2: GW is multiplied by 2^spec_exp and the z2 rows by 2^-spec_exp before they are split (GW carries 1 / (Tp Hp Wp):
+                          //   subnormal in fp16; the caller passes floor(log2(Tp Hp Wp)) - 1 so that max |GW| 2^spec_exp lies in [0.5, 2))
     float* wg_part;       // WG launch only: [slots][64 x 64] partial rows of the 1x1-conv weight gradient  x^T act(BN(bnb_s))
 };
 

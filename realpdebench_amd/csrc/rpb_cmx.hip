@@ -81,6 +81,31 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m
 __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// H2 (the opt-in "f16x2" eval arithmetic, CmxArgs::h2): operands as TWO fp16 planes, both rounded to nearest even (x = hi + lo to one fp32
+// unit in the last place: 11 + 11 significand bits and the sign of lo), three products hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_f16;
+// the dropped lo*lo term is <= 2^-22 |a b| -- the grade of "3xTF32", NOT the 2^-24 grade of the default path.  Half the matrix-pipe time
+// and 2.5 instead of 5.5 vector instructions per split value.  The planes travel in the bf16x8 containers of the default path (bit
+// patterns only): plane slot 0 = hi, slot 1 = lo.  fp16's range is handled by exact power-of-two scalings, see CmxArgs::spec_exp.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8h(const float (&v)[8], bf16x8& h, bf16x8& l) {
+    u32x4 uh, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2w ab = {v[2 * q], v[2 * q + 1]};
+        const f16x2v hh = __builtin_convertvector(ab, f16x2v);                       // v_cvt_pk_f16_f32 (RNE)
+        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);                   // exact in fp32
+        const f16x2v ll = __builtin_convertvector(r, f16x2v);
+        uh[q] = __builtin_bit_cast(unsigned, hh);
+        ul[q] = __builtin_bit_cast(unsigned, ll);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 // waves per workgroup (= per CU): the z2 planes of a line take 12 KB of LDS per wave: 8 waves + operands = 147 KB
 #ifndef CMX_WAVES_A
@@ -139,8 +164,15 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 #ifndef CMX_WG_PRIO
 #define CMX_WG_PRIO 0
 #endif
-template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0>
+// H2:   eval only (STATS == 0 with the output transform), fp32 storage -- the f16x2 arithmetic above for the channel mixing (not with FEAT:
+//       the raw feature fields keep the range-safe bf16 planes, their mixing is one K-step), the last inverse stage and the fused W stage.
+//       Scalings (exact: powers of two): conv weights and bias x 2^H2W, GW x 2^(spec_exp + H2W), z2 x 2^-spec_exp, and 2^-H2W rides in the
+//       output transform's scale.
+template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0, bool H2 = false>
 __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
+    static_assert(!H2 || (STATS == 0 && !BF && !WG && !SB && !C2), "f16x2: the fp32-storage eval launches at C = 64");
+    constexpr bool H2X = H2 && !FEAT;                    // channel mixing on fp16 planes
+    constexpr int H2W = H2X ? 4 : 0;                     // log2 of the scale the accumulators carry
     static_assert(!C2 || (!BF && !FEAT && !DFT && !WG && !SB), "C = 128: the plain fp32-storage launches");
     static_assert(!SB || BF, "bf16 spectra come with bf16 activation storage");
     static_assert(!WG || (STATS == 2 && !BF && !FEAT && !DFT), "weight-gradient pairs: the fp32 backward launch");
@@ -184,9 +216,15 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             const int co = 4 * n + t;
             if (FEAT) v[e] = ci < FW ? a.Wm[co * FW + ci] : 0.f;
             else v[e] = a.transpose_w ? a.Wm[ci * CC + 64 * hsel + co] : a.Wm[(64 * hsel + co) * CC + ci];
+            if (H2X) v[e] *= (float)(1 << H2W);
         }
         bf16x8 h, md, lo;
-        split8(v, h, md, lo);
+        if (H2X) {
+            split8h(v, h, md);
+            lo = md;
+        } else {
+            split8(v, h, md, lo);
+        }
         Bw[((ks * 3 + 0) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, h);
         Bw[((ks * 3 + 1) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, md);
         Bw[((ks * 3 + 2) * 4 + t) * 64 + l] = __builtin_bit_cast(u32x4, lo);
@@ -198,9 +236,15 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
         for (int e = 0; e < 8; ++e) {
             const int k = 8 * kgw + e;
             v[e] = k < K2 ? a.GW[k * Wp + w] : 0.f;
+            if (H2) v[e] = __builtin_ldexpf(v[e], a.spec_exp + H2W);
         }
         bf16x8 h, md, lo;
-        split8(v, h, md, lo);
+        if (H2) {
+            split8h(v, h, md);
+            lo = md;
+        } else {
+            split8(v, h, md, lo);
+        }
         GWs[(0 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, h);
         GWs[(1 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, md);
         GWs[(2 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, lo);
@@ -217,7 +261,12 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                 v[e] = (k < a.K2f && w < Wp) ? a.FWt[w * a.K2f + k] : 0.f;        // cells past the line end contribute nothing
             }
             bf16x8 h, md, lo;
-            split8(v, h, md, lo);
+            if (H2) {
+                split8h(v, h, md);
+                lo = md;
+            } else {
+                split8(v, h, md, lo);
+            }
             FWs[((q * 3 + 0) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, h);
             FWs[((q * 3 + 1) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, md);
             FWs[((q * 3 + 2) * 2 + mt2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
@@ -359,6 +408,10 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             bp[t].is *= bp[t].ga;
             bp[t].be -= bp[t].mu * bp[t].is;
         }
+        if (H2W) {                          // the accumulators carry 2^H2W (scaled weights): the bias joins them, the transform's scale undoes it
+            bv[t] *= (float)(1 << H2W);
+            bp[t].is *= 1.0f / (float)(1 << H2W);
+        }
     }
     const bool xgelu = a.xf.gelu != 0;
     const bool bgelu = a.bnb.gelu != 0;
@@ -496,7 +549,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                             for (int c = 0; c < 4; ++c) v[4 * hf + c] = xv[c];
                         }
                     }
-                    split8(v, Ah[j], Am[j], Al[j]);
+                    if (H2X) split8h(v, Ah[j], Am[j]);
+                    else split8(v, Ah[j], Am[j], Al[j]);
                 }
                 if (C2 && ks < 2) {                 // C = 128: this tile's K-steps 2, 3 take the slots of 0, 1
                     issue_x(xa, g, q, 0, ks + 2);
@@ -521,6 +575,14 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(f32x4v, zr[e])[t];
                             bf16x8 zh, zm, zl;
+                            if (H2) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = __builtin_ldexpf(v[e], -a.spec_exp);
+                                split8h(v, zh, zm);
+                                Zw[(0 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zh);
+                                Zw[(1 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zm);
+                                continue;
+                            }
                             split8(v, zh, zm, zl);
                             Zw[(0 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zh);
                             Zw[(1 * 4 + t) * 64] = __builtin_bit_cast(u32x4, zm);
@@ -543,18 +605,24 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         const int t = 2 * tp + u;
                         Bh[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 0) * 4 + t) * 64 + lane]);
                         Bm[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 1) * 4 + t) * 64 + lane]);
-                        Bl[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 2) * 4 + t) * 64 + lane]);
+                        if (!H2X) Bl[u] = __builtin_bit_cast(bf16x8, Bw[((ks * 3 + 2) * 4 + t) * 64 + lane]);
                     }
+#define CMX_PRODH(AP, BP)                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16h(AP[j], BP[u], acc[j][2 * tp + u]);
 #define CMX_PROD(AP, BP)                                                     \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)  \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], BP[u], acc[j][2 * tp + u]);
                     if (BF) {
                         if (RPB_BF16_CONST_PLANES > 2) { CMX_PROD(Ah, Bl) }
                         CMX_PROD(Ah, Bm) CMX_PROD(Ah, Bh)
+                    } else if (H2X) {           // slot 1 (the "m" registers) holds the lo plane
+                        CMX_PRODH(Ah, Bm) CMX_PRODH(Am, Bh) CMX_PRODH(Ah, Bh)
                     } else {
                         CMX_PROD(Ah, Bl) CMX_PROD(Al, Bh) CMX_PROD(Am, Bm) CMX_PROD(Ah, Bm) CMX_PROD(Am, Bh) CMX_PROD(Ah, Bh)
                     }
 #undef CMX_PROD
+#undef CMX_PRODH
                 }
             }
             // ---- last inverse-DFT stage: A = GW row of the cell's w (LDS; rows past the line end are clamped: their results are
@@ -567,7 +635,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                     wl = wl < Wp ? wl : Wp - 1;
                     ah[j] = __builtin_bit_cast(bf16x8, GWs[(0 * Wp + wl) * 4 + kg]);
                     am[j] = __builtin_bit_cast(bf16x8, GWs[(1 * Wp + wl) * 4 + kg]);
-                    al[j] = __builtin_bit_cast(bf16x8, GWs[(2 * Wp + wl) * 4 + kg]);
+                    if (!H2) al[j] = __builtin_bit_cast(bf16x8, GWs[(2 * Wp + wl) * 4 + kg]);
                 }
 #pragma unroll
                 for (int tp = 0; tp < 2; ++tp) {
@@ -577,19 +645,25 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         Zh[u] = __builtin_bit_cast(bf16x8, Zw[(0 * 4 + 2 * tp + u) * 64]);
                         if (!SB) {
                             Zm[u] = __builtin_bit_cast(bf16x8, Zw[(1 * 4 + 2 * tp + u) * 64]);
-                            Zl[u] = __builtin_bit_cast(bf16x8, Zw[(2 * 4 + 2 * tp + u) * 64]);
+                            if (!H2) Zl[u] = __builtin_bit_cast(bf16x8, Zw[(2 * 4 + 2 * tp + u) * 64]);
                         }
                     }
+#define CMX_SPECH(AP, ZP)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)                                 \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16h(AP[j], ZP[u], acc[j][2 * tp + u]);
 #define CMX_SPEC(AP, ZP)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) if (j == 0 || !half_tile)                                 \
         _Pragma("unroll") for (int u = 0; u < 2; ++u) acc[j][2 * tp + u] = mfma16(AP[j], ZP[u], acc[j][2 * tp + u]);
                     if (SB) {
                         if (RPB_BF16_CONST_PLANES > 2) { CMX_SPEC(al, Zh) }
                         CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
+                    } else if (H2) {
+                        CMX_SPECH(ah, Zm) CMX_SPECH(am, Zh) CMX_SPECH(ah, Zh)
                     } else {
                         CMX_SPEC(ah, Zl) CMX_SPEC(al, Zh) CMX_SPEC(am, Zm) CMX_SPEC(ah, Zm) CMX_SPEC(am, Zh) CMX_SPEC(ah, Zh)
                     }
 #undef CMX_SPEC
+#undef CMX_SPECH
                 }
             }
             // ---- epilogue: cell 32 q + 16 j + 4 mg + r of the line, channels 4 n + t: one 16 B store per (j, r).  Only the last
@@ -694,7 +768,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                 for (int i = 0; i < 2; ++i) {
                     fh[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 0) * 2 + i) * 64 + lane]);
                     fm[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 1) * 2 + i) * 64 + lane]);
-                    fl[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 2) * 2 + i) * 64 + lane]);
+                    if (!H2) fl[i] = __builtin_bit_cast(bf16x8, FWs[((q * 3 + 2) * 2 + i) * 64 + lane]);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -715,6 +789,16 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         continue;
                     }
                     bf16x8 yh, ym, yl;
+                    if (H2) {
+                        split8h(v, yh, ym);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            Yacc[i][t] = mfma16h(fh[i], ym, Yacc[i][t]);
+                            Yacc[i][t] = mfma16h(fm[i], yh, Yacc[i][t]);
+                            Yacc[i][t] = mfma16h(fh[i], yh, Yacc[i][t]);
+                        }
+                        continue;
+                    }
                     split8(v, yh, ym, yl);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -891,7 +975,8 @@ static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false) {
 }
 
 // GW [K2][Wp] -> three bf16 planes in A-operand row order [plane][w][kg] (the DFT variant's inverse-stage operand, read through L1)
-__global__ void cmx_gw_prep_kernel(const float* __restrict__ GW, u32x4* __restrict__ out, int K2, int Wp) {
+// h2_exp >= 0 (f16x2): two fp16 planes of GW * 2^h2_exp in slots 0, 1 (slot 2 repeats slot 1)
+__global__ void cmx_gw_prep_kernel(const float* __restrict__ GW, u32x4* __restrict__ out, int K2, int Wp, int h2_exp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Wp * 4) return;
     const int w = idx >> 2, kgw = idx & 3;
@@ -900,9 +985,15 @@ __global__ void cmx_gw_prep_kernel(const float* __restrict__ GW, u32x4* __restri
     for (int e = 0; e < 8; ++e) {
         const int k = 8 * kgw + e;
         v[e] = k < K2 ? GW[k * Wp + w] : 0.f;
+        if (h2_exp >= 0) v[e] = __builtin_ldexpf(v[e], h2_exp);
     }
     bf16x8 h, md, lo;
-    split8(v, h, md, lo);
+    if (h2_exp >= 0) {
+        split8h(v, h, md);
+        lo = md;
+    } else {
+        split8(v, h, md, lo);
+    }
     out[(0 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, h);
     out[(1 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, md);
     out[(2 * Wp + w) * 4 + kgw] = __builtin_bit_cast(u32x4, lo);
@@ -990,7 +1081,10 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
     if (a.y1out) {                  // eval with the next layer's forward W stage fused in
         if (a.crop_T > 0 || stats != 0 || !a.bnb.mean || (a.bf16_io && a.feat_w) || !a.FWt || !a.gw_planes || !rpb_cmx_dft_supported(a.Wp, a.K2f))
             RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the fused W stage needs the eval path (output transform), a scratch buffer and K2f <= 32");
-        hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp);
+        if (a.h2 && a.bf16_io) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the f16x2 arithmetic is an fp32-storage path");
+        // (f16x2: the feature-field launch keeps unscaled accumulators, the C = 64 launch carries 2^4 -- H2W in the kernel)
+        hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp,
+                           a.h2 ? a.spec_exp + (a.feat_w ? 0 : 4) : -1);
         const int waves = CMX_WAVES_DFT;
         const long G = a.ncell / a.Wp;
         long grid = rpb_num_cus();
@@ -1002,6 +1096,12 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
         } else if (a.bf16_io) {
             (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((cmx_kernel<0, true, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        } else if (a.feat_w && a.h2) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, true, true, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, false, true, true, false, false, 0, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
+        } else if (a.h2) {
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, false, true, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cmx_kernel<0, false, false, true, false, false, 0, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
         } else if (a.feat_w) {
             (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((cmx_kernel<0, false, true, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);
@@ -1016,6 +1116,12 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
     const int waves = CMX_WAVES_OF(stats);
     const int grid = (int)(rpb_cmx_stat_rows(a.ncell, a.Wp, stats) / waves);
     const size_t lds = cmx_lds(a.Wp, waves);
+    if (a.h2) {                     // f16x2: the eval launches only (output transform; here: the crop-only last layer or a plain eval layer)
+        if (stats != 0 || !a.bnb.mean || a.bf16_io || a.feat_w) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: the f16x2 arithmetic covers the fp32-storage eval launches");
+        (void)hipFuncSetAttribute((const void*)cmx_kernel<0, false, false, false, false, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cmx_kernel<0, false, false, false, false, false, 0, true>), dim3(grid), dim3(waves * 64), lds, st, a);
+        RPB_CHECK_LAUNCH("cell_mix(f16x2)");
+    }
 #define RPB_CMX(ST_)                                                                                                  \
     if (stats == ST_) {                                                                                               \
         (void)hipFuncSetAttribute((const void*)cmx_kernel<ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

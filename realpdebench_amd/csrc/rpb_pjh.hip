@@ -66,10 +66,36 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m
 __device__ __forceinline__ f32x16v mfma32(bf16x8 a, bf16x8 b, f32x16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// H2 -- the opt-in "f16x2" eval arithmetic (rpb_cmx.hip, same contract): two fp16 planes per operand, both rounded to nearest even, three
+// products hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_f16 (dropped term <= 2^-22 |a b|); the planes travel in the bf16x8 containers,
+// slot 0 = hi, slot 1 = lo.  W1' carries 2^PH_H2W (fp16's range), undone in the two affine uses of u inside GELU.
+#define PH_H2W 4
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8h(const float (&v)[8], bf16x8& h, bf16x8& l) {
+    u32x4 uh, ul;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2w ab = {v[2 * q], v[2 * q + 1]};
+        const f16x2v hh = __builtin_convertvector(ab, f16x2v);
+        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);
+        const f16x2v ll = __builtin_convertvector(r, f16x2v);
+        uh[q] = __builtin_bit_cast(unsigned, hh);
+        ul[q] = __builtin_bit_cast(unsigned, ll);
+    }
+    h = __builtin_bit_cast(bf16x8, uh);
+    l = __builtin_bit_cast(bf16x8, ul);
+}
+__device__ __forceinline__ f32x16v mfma32h(bf16x8 a, bf16x8 b, f32x16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // gelu(a + b) with the bias folded into the two affine uses of u: bs = b / sqrt 2, hb = b / 2.  The erf is fast_erf's (rpb_common.h):
-// erf(x) = sign(x) (1 - 2^(t S(t))), t = min(|x|, 4)
+// erf(x) = sign(x) (1 - 2^(t S(t))), t = min(|x|, 4).  SC: the scale the accumulator carries (f16x2: 2^-PH_H2W), folded into both FMAs
+template <bool H2 = false>
 __device__ __forceinline__ float gelu_bias(float a, float bs, float hb) {
-    const float xs = __builtin_fmaf(a, 0.70710678118654752440f, bs);
+    constexpr float SC = H2 ? 1.0f / (float)(1 << PH_H2W) : 1.0f;
+    const float xs = __builtin_fmaf(a, 0.70710678118654752440f * SC, bs);
     const float t = fminf(fabsf(xs), 4.0f);
     float p = 1.160457393e-05f;
     p = __builtin_fmaf(p, t, -1.529619341e-04f);
@@ -81,7 +107,7 @@ __device__ __forceinline__ float gelu_bias(float a, float bs, float hb) {
     p = __builtin_fmaf(p, t, -9.184428993e-01f);
     p = __builtin_fmaf(p, t, -1.627907267e+00f);
     const float e = __builtin_amdgcn_exp2f(p * t);
-    const float hx = __builtin_fmaf(a, 0.5f, hb);          // x / 2 has the sign of x / sqrt 2:  hx erf(xs) = |hx| (1 - e)
+    const float hx = __builtin_fmaf(a, 0.5f * SC, hb);     // x / 2 has the sign of x / sqrt 2:  hx erf(xs) = |hx| (1 - e)
     return __builtin_fmaf(fabsf(hx), 1.0f - e, hx);
 }
 __device__ __forceinline__ float dpp_add(float x, float y, const int ctrl) {           // x + y from the lane the DPP control names
@@ -107,7 +133,7 @@ struct PjhFwdArgs {
 };
 
 // DOT: fc2 outputs padded to 2 or 4 (DO = 1 .. DOT of them are real; the others carry zero weights and are not stored)
-template <int DOT>
+template <int DOT, bool H2 = false>
 __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p) {
     constexpr int NV = 16 * DOT;                         // fc2 partials per lane: [register row r][output j] = element DOT r + j
     constexpr int EPL = NV / 32;                         // elements a lane owns after the butterfly: element EPL n + k
@@ -127,9 +153,15 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
             const int c = 16 * ks + 8 * (l >> 5) + e;
             const float w = p.w1[(32 * nt + (l & 31)) * 64 + c];
             v[e] = has_xf ? w * (p.xf.gamma[c] * p.xf.invstd[c]) : w;
+            if (H2) v[e] *= (float)(1 << PH_H2W);
         }
         bf16x8 h, m, lo;
-        split8(v, h, m, lo);
+        if (H2) {
+            split8h(v, h, m);
+            lo = m;
+        } else {
+            split8(v, h, m, lo);
+        }
         W1B[((ks * 4 + nt) * 3 + 0) * 64 + l] = __builtin_bit_cast(u32x4, h);
         W1B[((ks * 4 + nt) * 3 + 1) * 64 + l] = __builtin_bit_cast(u32x4, m);
         W1B[((ks * 4 + nt) * 3 + 2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
@@ -190,7 +222,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
     // behind the last products of this one)
     bf16x8 BL[4], BM[4], BH[4];
 #define PH_LOADB(DST, KS, PLANE) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) DST[nt_] = __builtin_bit_cast(bf16x8, W1B[(((KS) * 4 + nt_) * 3 + (PLANE)) * 64 + lane]);
-    PH_LOADB(BL, 0, 2)
+    if (!H2) { PH_LOADB(BL, 0, 2) }
     PH_LOADB(BM, 0, 1)
     PH_LOADB(BH, 0, 0)
 #ifdef PH_TIMING   /* timing-only build: the wave's shader cycles and 100 MHz ticks over its tile loop land in out[2 slot ..] (tools/dbg/pjh_clock.py) */
@@ -227,7 +259,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
                     v[c] = x0[c] - meanr[8 * ks + c];
                     v[4 + c] = x1[c] - meanr[8 * ks + 4 + c];
                 }
-                split8(v, Ah[ks & 1], Am[ks & 1], Al[ks & 1]);
+                if (H2) split8h(v, Ah[ks & 1], Am[ks & 1]);
+                else split8(v, Ah[ks & 1], Am[ks & 1], Al[ks & 1]);
                 issue_pair(pn, qn, ks);                  // the registers are free: the next tile's loads fly through the rest of this one
             };
             prep(0);
@@ -242,6 +275,26 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #else
 #define PH_G(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_] = mfma32(AP[ks & 1], BP[nt_], (FIRST) ? f32x16v{} : acc[nt_]);
 #endif
+#define PH_GH(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_] = mfma32h(AP[ks & 1], BP[nt_], (FIRST) ? f32x16v{} : acc[nt_]);
+                if (H2) {                       // slot 1 (the "m" registers) holds the lo plane
+                    PH_GH(Ah, BM, ks == 0)
+                    PH_LOADB(BM, kn, 1)
+                    PH_GH(Am, BH, false)
+                    PH_GH(Ah, BH, false)
+                    PH_LOADB(BH, kn, 0)
+#if PH_PIPE
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
+                        if (i >= 4 && i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (ks < 3 && (i == 4 || i == 8)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    continue;
+                }
                 PH_G(Ah, BL, ks == 0)
                 PH_LOADB(BL, kn, 2)
                 PH_G(Am, BM, false)
@@ -252,6 +305,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
                 PH_G(Ah, BH, false)
                 PH_LOADB(BH, kn, 0)
 #undef PH_G
+#undef PH_GH
 #if PH_PIPE
                 // the order asked of the scheduler: every MFMA followed by PH_PIPE vector instructions of the next step's split; the
                 // refill of a plane buffer one read per MFMA behind the buffer's last product
@@ -278,7 +332,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #ifdef PH_NOACT   /* timing-only build */
                     const float v = acc[nt][r] + bs[nt];
 #else
-                    const float v = gelu_bias(acc[nt][r], bs[nt], hb[nt]);
+                    const float v = gelu_bias<H2>(acc[nt][r], bs[nt], hb[nt]);
 #endif
 #pragma unroll
                     for (int j = 0; j < DOT; ++j) po[DOT * r + j] = __builtin_fmaf(v, w2r[j][nt], po[DOT * r + j]);
@@ -324,7 +378,7 @@ bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16) {
 }
 
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
-                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st) {
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2) {
     PjhFwdArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -337,7 +391,13 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
     const long need = (GL + PH_WAVES - 1) / PH_WAVES;
     if (grid > need) grid = need;
     const size_t lds = pjh_lds();
-    if (DO <= 2) {
+    if (f16x2 && DO <= 2) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pjh_fwd_kernel<2, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    } else if (f16x2) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pjh_fwd_kernel<4, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    } else if (DO <= 2) {
         (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(pjh_fwd_kernel<2>, dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
     } else {

@@ -378,6 +378,17 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
     return proj_launch(false, p, (hipStream_t)stream);
 }
 
+// The evaluation head on the opt-in "f16x2" arithmetic (csrc/rpb_pjh.hip, H2; the contract of rpb_cell_mix_eval_dft_f16x2): C = 64, at most
+// four fc2 outputs, exact-erf GELU, plain fp32 activations (the last layer's BatchNorm was applied by its eval cell_mix).
+extern "C" int rpb_proj_fwd_f16x2(const float* a, const float* w1, const float* b1, const float* w2, const float* b2, float* out, long ncrop,
+                                  int DO, int T, int H, int W, int Tp, int Hp, int Wp, void* stream) {
+    RPB_REQUIRE(a && w1 && b1 && w2 && b2 && out, "proj_fwd_f16x2: null pointer");
+    RPB_REQUIRE(T > 0 && H > 0 && W > 0 && ncrop > 0 && ncrop % ((long)T * H * W) == 0, "proj_fwd_f16x2: bad sizes");
+    const XForm xf{nullptr, nullptr, nullptr, nullptr, 0};
+    RPB_REQUIRE(rpb_pjh_supported(64, DO, 0, xf, false), "proj_fwd_f16x2: needs 1 <= DO <= 4 (DO=%d)", DO);
+    return rpb_pjh_launch(a, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, xf, (hipStream_t)stream, true);
+}
+
 extern "C" int rpb_proj_fwd_bf16(const void* a_bf16, const float* w1, const float* b1, const float* w2, const float* b2,
                                  float* out, long ncrop, int C, int DO, int T, int H, int W, int Tp, int Hp, int Wp, int act,
                                  void* stream) {

@@ -33,6 +33,8 @@ class _Workspace:
         d = ops.Dims(B, *model.shape_in[:3], model.dim_in, model.width, model.padding)
         self.d, self.training = d, training
         self.bf16 = (not training) and model.storage == "bf16"       # eval / rollout only: activations stored as bf16
+        # eval / rollout on fp32 storage only: the opt-in two-fp16-plane arithmetic of the fused eval launches (FNO3d.set_arith)
+        self.arith = model.arith if (not training and not self.bf16) else "f32"
         self.graph = self.graph_out = self.graph_x = self.graph_key = None      # eval: hipGraph of one forward (FNO3d._forward_graphed)
         self.graph_calls = 0
         self.generation = 0          # bumped by every training-mode forward: a backward whose graph saw an older value must not run
@@ -257,6 +259,7 @@ class FNO3d(Model):
         self._dev_cache = None
         self.dp = None            # set by realpdebench_amd.dp.DataParallel (RCCL)
         self.storage = "f32"      # activation storage of the eval / rollout forward, see set_storage
+        self.arith = "f32"        # arithmetic of the eval / rollout forward's fused launches, see set_arith
 
     # ------------------------------------------------------------------ parameters
     def reset_parameters(self):
@@ -377,6 +380,21 @@ class FNO3d(Model):
             self._ws = {k: v for k, v in self._ws.items() if k[1]}       # drop the eval workspaces (dtype changed)
         return self
 
+    def set_arith(self, arith):
+        """Arithmetic of the eval / rollout forward on fp32 storage: ``"f32"`` (default, the parity path: operands as three bf16 planes, six
+        products per fp32 product, dropped terms <= 2^-24) or ``"f16x2"`` (opt-in: operands as two fp16 planes rounded to nearest -- one fp32
+        unit in the last place --, three products, dropped term <= 2^-22: the grade of 3xTF32, half the matrix-pipe time).  ``"f16x2"``
+        covers the eval ``cell_mix`` launches and the projection head at width 64; activations must stay inside fp16's range (they are
+        BatchNorm outputs; the spectra and the inverse-stage matrix are rescaled by exact powers of two).  Training is not affected."""
+        if arith not in ("f32", "f16x2"):
+            raise ValueError(f"arith must be 'f32' or 'f16x2', got {arith!r}")
+        if arith == "f16x2" and (self.width != 64 or 2 * self.modes3 > 32 or type(self)._lift_fwd is not FNO3d._lift_fwd):
+            raise NotImplementedError("the f16x2 eval arithmetic is built for FNO3d at width 64 with modes3 <= 16")
+        if arith != self.arith:
+            self.arith = arith
+            self._ws = {k: v for k, v in self._ws.items() if k[1]}       # drop the eval workspaces (their graphs hold the old launches)
+        return self
+
     # ------------------------------------------------------------------ device-side constants
     def _consts(self, device):
         if self._dev_cache is None or self._dev_cache[0] != device:
@@ -388,7 +406,7 @@ class FNO3d(Model):
         return self._dev_cache[1], self._dev_cache[2]
 
     def _workspace(self, B, training, device):
-        key = (B, training, str(device), self.storage if not training else "f32")
+        key = (B, training, str(device), self.storage if not training else "f32", self.arith if not training else "f32")
         if key not in self._ws:
             self._consts(device)
             self._ws[key] = _Workspace(self, B, training, device)
@@ -511,14 +529,14 @@ class FNO3d(Model):
                     feat = l == 0 and ws.featfull
                     ops.cell_mix_eval_dft(ws.phic if feat else a_in, ws.wcomp if feat else P(f"convs.{l}.weight"), P(f"convs.{l}.bias"),
                                           ws.Z2, plan.GWt, s, d.ncell, 2 * plan.KW, d.Wp, self._layer_xf(ws, l, False), plan.FWt,
-                                          2 * plan.KW, ws.Y1f, feat_w=ws.FW if feat else 0)
+                                          2 * plan.KW, ws.Y1f, feat_w=ws.FW if feat else 0, arith=ws.arith, spec_e=ops.spec_exp(d))
                     y1_ready = True
                 elif l == 0 and ws.featfull:
                     ops.cell_mix_feat(ws.phic, ws.wcomp, P("convs.0.bias"), ws.Z2, plan.GWt, s, None, d.ncell, ws.FW,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
                 elif ws.crop_last and l == L - 1:
                     ops.cell_mix_eval_crop(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, d, 2 * plan.KW,
-                                           self._layer_xf(ws, l, False))
+                                           self._layer_xf(ws, l, False), arith=ws.arith)
                 elif ws.bf16:
                     ops.cell_mix_bf16(a_in, P(f"convs.{l}.weight"), P(f"convs.{l}.bias"), ws.Z2, plan.GWt, s, d.ncell, C,
                                       2 * plan.KW, d.Wp, oxf=self._layer_xf(ws, l, False))
@@ -534,6 +552,8 @@ class FNO3d(Model):
         if not training and ws.bf16:
             ops.proj_fwd_bf16(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
                               act=self.proj_act)
+        elif not training and ws.arith == "f16x2" and xf is None and self.proj_act == 0 and C == 64 and self.dim_out <= 4:
+            ops.proj_fwd_f16x2(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out)
         else:
             ops.proj_fwd(a_in, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), P("fc2.bias"), ws.out, d, self.dim_out,
                          xf=xf, act=self.proj_act)

@@ -119,14 +119,28 @@ def cell_mix_bf16(x, Wm, bias, z2, GW, out, ncell, C, K2, Wp, oxf=None):
               flops=2 * ncell * C * (K2 + C))
 
 
-def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf):
-    """Eval cell_mix of the last Fourier layer over the crop only (``d`` = the padded / cropped sizes); x / out f32 or bf16 ``[ncell][64]``."""
+def spec_exp(d):
+    """The power of two the opt-in f16x2 eval arithmetic moves from the last inverse-stage matrix (entries <= 2 / (Tp Hp Wp): subnormal in
+    fp16) to the z2 rows: floor(log2(Tp Hp Wp)) - 1, so that max |GW| 2^e lies in (0.5, 1]."""
+    return int(d.Tp * d.Hp * d.Wp).bit_length() - 2
+
+
+def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf, arith="f32"):
+    """Eval cell_mix of the last Fourier layer over the crop only (``d`` = the padded / cropped sizes); x / out f32 or bf16 ``[ncell][64]``.
+    ``arith="f16x2"``: the opt-in two-fp16-plane arithmetic (fp32 storage only; csrc/rpb_cmx.hip, H2)."""
     bf = x.dtype == torch.bfloat16
     assert out.dtype == x.dtype
     nl, tq = d.B * d.T * d.H, (d.W + 31) // 32
     ncell = nl * min(32 * tq, d.Wp)
     zp, sb, zb = _zs(z2)
     assert bf or not sb
+    if arith == "f16x2":
+        assert not bf and not sb
+        _lib.call("rpb_cell_mix_eval_crop_f16x2", _p(x), _p(Wm), _p(bias), zp, _p(GW), _p(out), d.B, d.T, d.H, d.W, d.Tp, d.Hp, d.Wp, K2,
+                  *_xf(oxf), spec_exp(d), _stream(), label="cell_mix[KC64->CO64,spec=1,stats=oxf,crop,f16x2]",
+                  nbytes=8 * ncell * 64 + zb * nl * K2 * 64, flops=2 * ncell * 64 * (K2 + 64))
+        return
+    assert arith == "f32"
     _lib.call("rpb_cell_mix_eval_crop", _p(x, x.dtype), _p(Wm), _p(bias), zp, _p(GW), _p(out, x.dtype), d.B, d.T, d.H, d.W, d.Tp, d.Hp,
               d.Wp, K2, *_xf(oxf), int(bf), sb, _stream(), label="cell_mix_bf16[crop]" if bf else "cell_mix[KC64->CO64,spec=1,stats=oxf,crop]",
               nbytes=(4 if bf else 8) * ncell * 64 + zb * nl * K2 * 64, flops=2 * ncell * 64 * (K2 + 64))
@@ -139,9 +153,11 @@ def cell_mix_eval_dft_supported(ncell, K2, Wp, K2f):
     return bool(_lib.query("rpb_cell_mix_eval_dft_supported", ncell, K2, Wp, K2f))
 
 
-def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1, feat_w=0):
-    """Eval cell_mix (C = 64, output transform ``oxf``) + the next layer's forward W stage: ``y1 [ncell/Wp][K2f][64]``."""
+def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1, feat_w=0, arith="f32", spec_e=None):
+    """Eval cell_mix (C = 64, output transform ``oxf``) + the next layer's forward W stage: ``y1 [ncell/Wp][K2f][64]``.
+    ``arith="f16x2"`` (with ``spec_e = spec_exp(d)``): the opt-in two-fp16-plane arithmetic, fp32 storage only."""
     assert tuple(FWt.shape) == (Wp, K2f)
+    assert arith in ("f32", "f16x2")
     KC = feat_w or 64
     key = (str(out.device), Wp)
     if key not in _DFT_SCRATCH:
@@ -153,6 +169,13 @@ def cell_mix_eval_dft(x, Wm, bias, z2, GW, out, ncell, K2, Wp, oxf, FWt, K2f, y1
         _lib.call("rpb_cell_mix_eval_dft_bf16", _p(x, torch.bfloat16), _p(Wm), _p(bias), zp, _p(GW), _p(out, torch.bfloat16), ncell, K2, Wp,
                   *_xf(oxf), _p(FWt), K2f, _p(y1, y1.dtype), _p(_DFT_SCRATCH[key]), sb, _stream(), label="cell_mix_bf16[+W]",
                   nbytes=4 * ncell * 64 + zb * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + 64 + K2f))
+        return
+    if arith == "f16x2":
+        assert spec_e is not None
+        _lib.call("rpb_cell_mix_eval_dft_f16x2", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), ncell, K2, Wp, int(feat_w), *_xf(oxf),
+                  _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), int(spec_e), _stream(),
+                  label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W,f16x2]",
+                  nbytes=4 * ncell * (KC + 64) + 4 * (ncell // Wp) * (K2 + K2f) * 64, flops=2 * ncell * 64 * (K2 + KC + K2f))
         return
     _lib.call("rpb_cell_mix_eval_dft", _p(x), _p(Wm), _p(bias), _p(z2), _p(GW), _p(out), ncell, K2, Wp, int(feat_w), *_xf(oxf),
               _p(FWt), K2f, _p(y1), _p(_DFT_SCRATCH[key]), _stream(), label=f"cell_mix[{'feat%d' % feat_w if feat_w else 'KC64'}->CO64,spec=1,stats=oxf+W]",
@@ -381,6 +404,13 @@ def proj_fwd(a, w1, b1, w2, b2, out, d, DO, xf=None, act=0):
     _lib.call("rpb_proj_fwd", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, d.C, DO, *d.crop6, *_xf(xf),
               int(act), _stream(),
               label="proj_fwd", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
+
+
+def proj_fwd_f16x2(a, w1, b1, w2, b2, out, d, DO):
+    """The evaluation head on the opt-in two-fp16-plane arithmetic (C = 64, DO <= 4, exact GELU, plain activations)."""
+    assert d.C == 64 and 1 <= DO <= 4
+    _lib.call("rpb_proj_fwd_f16x2", _p(a), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), d.ncrop, DO, *d.crop6, _stream(),
+              label="proj_fwd[f16x2]", nbytes=4 * d.ncrop * (d.C + DO), flops=2 * d.ncrop * 128 * (d.C + DO))
 
 
 def proj_fwd_bf16(a, w1, b1, w2, b2, out, d, DO, act=0):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel HIP-event table of one FNO3d eval forward at the headline shape:  python tools/fwd_probe.py [B]"""
+"""Per-kernel HIP-event table of one FNO3d eval forward at the headline shape:  python tools/fwd_probe.py [B]   (RPB_ARITH=f16x2: opt-in arithmetic)"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ if len(sys.argv) > 2 and sys.argv[2].startswith("comb"):       # BASELINE.json c
 else:
     m = FNO3d(4, 12, 16, 4, 64, (20, 128, 128, 2), (20, 128, 128, 2)).cuda().eval()
     x = torch.randn(B, 20, 128, 128, 2, device="cuda")
+if os.environ.get("RPB_ARITH"):                                 # e.g. RPB_ARITH=f16x2: the opt-in eval arithmetic
+    m.set_arith(os.environ["RPB_ARITH"])
 with torch.no_grad():
     for _ in range(2):
         m(x)
