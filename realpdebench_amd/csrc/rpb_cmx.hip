@@ -86,6 +86,9 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // the dropped lo*lo term is <= 2^-22 |a b| -- the grade of "3xTF32", NOT the 2^-24 grade of the default path.  Half the matrix-pipe time
 // and 2.5 instead of 5.5 vector instructions per split value.  The planes travel in the bf16x8 containers of the default path (bit
 // patterns only): plane slot 0 = hi, slot 1 = lo.  fp16's range is handled by exact power-of-two scalings, see CmxArgs::spec_exp.
+#ifndef RPB_H2_FMAMIX
+#define RPB_H2_FMAMIX 1
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
@@ -95,9 +98,20 @@ __device__ __forceinline__ void split8h(const float (&v)[8], bf16x8& h, bf16x8& 
     for (int q = 0; q < 4; ++q) {
         const f32x2w ab = {v[2 * q], v[2 * q + 1]};
         const f16x2v hh = __builtin_convertvector(ab, f16x2v);                       // v_cvt_pk_f16_f32 (RNE)
-        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);                   // exact in fp32
-        const f16x2v ll = __builtin_convertvector(r, f16x2v);
         uh[q] = __builtin_bit_cast(unsigned, hh);
+#if RPB_H2_FMAMIX
+        // residual a - float(hi) as ONE v_fma_mix_f32 per value (f16 half * -1 + f32; exact): 4 instead of 5 instructions per value pair
+        // (left alone the compiler converts both halves and subtracts packed: 2 x v_cvt_f32_f16 + v_pk_add_f32)
+        float r0, r1;
+        const unsigned hu = uh[q];
+        const float a0 = ab[0], a1 = ab[1];
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(a0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(a1));
+        const f32x2w r = {r0, r1};
+#else
+        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);                   // exact in fp32
+#endif
+        const f16x2v ll = __builtin_convertvector(r, f16x2v);
         ul[q] = __builtin_bit_cast(unsigned, ll);
     }
     h = __builtin_bit_cast(bf16x8, uh);
@@ -163,6 +177,20 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 // workgroup; 2: the mix wave; 0: none).  Measured (profiles/r05_kbench_valu_variants.txt) -- see DESIGN.md section 4.0000
 #ifndef CMX_WG_PRIO
 #define CMX_WG_PRIO 0
+#endif
+// CMX_WG_GELU_AS: act / act' of the weight-gradient pairs' mix wave from one exponential + one reciprocal (gelu_both_as2x2, rpb_common.h)
+// instead of the erf polynomial + two exponentials
+#ifndef CMX_WG_ONE_EPILOGUE
+#define CMX_WG_ONE_EPILOGUE 0    /* experiment: the wave pairs' mix wave always runs the masked epilogue (a smaller loop body for a few selects per tile) */
+#endif
+#ifndef CMX_ONE_EPILOGUE
+#define CMX_ONE_EPILOGUE 1
+#endif
+#ifndef CMX_SPLIT_LAST
+#define CMX_SPLIT_LAST 1
+#endif
+#ifndef CMX_WG_GELU_AS
+#define CMX_WG_GELU_AS 1
 #endif
 // H2:   eval only (STATS == 0 with the output transform), fp32 storage -- the f16x2 arithmetic above for the channel mixing (not with FEAT:
 //       the raw feature fields keep the range-safe bf16 planes, their mixing is one K-step), the last inverse stage and the fused W stage.
@@ -487,18 +515,27 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     // WG: pin the (wave-uniform) line indices to SGPRs -- with the second wave role in the kernel the compiler keeps them in VGPRs and
     // wraps every buffer access in a waterfall loop
     auto U = [&](long v) -> long { return WG ? (long)__builtin_amdgcn_readfirstlane((int)v) : v; };
-    auto do_tile = [&](u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
+    // CMX_SPLIT_LAST: the tile body exists twice -- for a line's last tile (the only one that can be a half tile or carry masked cells, and the
+    // one that requests the next line's z2 row) and for all the others, where `last` / `half_tile` are compile-time false: without the
+    // specialisation every group of four MFMAs ends in a branch on `half_tile` (36 basic blocks per tile that the scheduler cannot cross).
+    // Measured per variant (B = 32, two boxes' worth of A/B in profiles/r06b_ab2_split_last.txt): the training forward with the lazy
+    // BatchNorm + GELU 2.06-2.13 -> 1.96 ms, layer 0 1.013 -> 0.99, the plain forward / backward -0.5 .. -2 %; but the larger bodies LOSE --
+    // eval with the fused W stage 2.31 -> 2.56 ms, the wave-pair backward 2.88 -> 4.93 ms (the doubled body no longer sits in the
+    // instruction cache).  So: the STATS == 1 instances only.
+    auto do_tile = [&](auto last_tag, u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
+        constexpr bool LASTC = decltype(last_tag)::value;
+        constexpr bool SPLITL = CMX_SPLIT_LAST && STATS == 1;       // measured per variant (profiles/r06b_ab2_split_last.txt), see CMX_SPLIT_LAST
         {
             const long g = U(line_of(gi));
             const rsrc_t ro = make_rsrc(a.out + g * line_floats + 64 * hsel, line_bytes - 256u * (unsigned)hsel);
             const rsrc_t rs = make_rsrc(STATS == 2 ? a.bnb_s + g * Wp * CC + 64 * hsel : a.out, line_bytes - 256u * (unsigned)hsel);
-            const bool last = q + 1 == TQ;
+            const bool last = SPLITL ? LASTC : (q + 1 == TQ);
             const bool more = ngi < G;
             const long gn = U(more ? line_of(ngi) : 0);                      // the tile to request: (gn, qn)
             const int qn = nq;
             const long gnl = DYN ? ngi : gi + nslots;                        // the wave's next line (DYN: meaningful on the line's last tile)
             const bool more_lines = gnl < G;
-            const bool half_tile = 32 * q + 16 >= Wp;                        // uniform: the second MFMA tile lies past the line end
+            const bool half_tile = (SPLITL && !LASTC) ? false : (32 * q + 16 >= Wp);   // uniform: the second MFMA tile lies past the line end
             asm volatile("" ::: "memory");   // keep the (tile-invariant) LDS operand reads inside the loop: hoisted, they cost 150 VGPRs
 
             f32x4v acc[2][4];
@@ -698,7 +735,11 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                         if (STATS == 0 && oxf && bgelu) gelu2x2(vv[0], vv[1]);
                         if (STATS == 2 && bgelu) {
                             if (WG) {           // act(z) for the weight gradient: the same erf serves act and act'
+#if CMX_WG_GELU_AS
+                                gelu_both_as2x2(acv[0], acv[1], acv[0], acv[1], gpv[0], gpv[1]);
+#else
                                 gelu_both2x2(acv[0], acv[1], acv[0], acv[1], gpv[0], gpv[1]);
+#endif
                             } else {
                                 gpv[0] = gelu_grad2(acv[0]);
                                 gpv[1] = gelu_grad2(acv[1]);
@@ -754,7 +795,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                     if (lane == 0) __hip_atomic_store(wg_fl, wg_tiles, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             };
-            if (last) epilogue(std::true_type{});
+            if ((STATS == 0 && CMX_ONE_EPILOGUE) || (WG && CMX_WG_ONE_EPILOGUE)) epilogue(std::true_type{});   // STATS == 0: no sums to mask, one copy of the code instead of two identical ones
+            else if (last) epilogue(std::true_type{});
             else epilogue(std::false_type{});
             if (DFT) {
                 if (q == 0) {
@@ -837,6 +879,11 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
             }
         }
     };
+#define CMX_DO_TILE(XA, G_, Q_, NG_, NQ_)                                                                      \
+    do {                                                                                                       \
+        if ((CMX_SPLIT_LAST && STATS == 1) && (Q_) + 1 == TQ) do_tile(std::true_type{}, XA, G_, Q_, NG_, NQ_);     \
+        else do_tile(std::false_type{}, XA, G_, Q_, NG_, NQ_);                                                 \
+    } while (0)
     int pend = 0;                   // claim mode 2: the wave's outstanding claim (lane 0)
     if (DYN == 2 && slot < G && lane == 0) pend = __hip_atomic_fetch_add(a.claim_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto advance = [&](long& gi, int& q) {
@@ -889,17 +936,17 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
                 long g2 = g1;
                 int q2 = q1;
                 advance(g2, q2);
-                do_tile(xaA, g0, q0, g2, q2);
+                CMX_DO_TILE(xaA, g0, q0, g2, q2);
                 if (g1 >= G) break;
                 long g3 = g2;
                 int q3 = q2;
                 advance(g3, q3);
-                do_tile(xaB, g1, q1, g3, q3);
+                CMX_DO_TILE(xaB, g1, q1, g3, q3);
                 g0 = g2; q0 = q2; g1 = g3; q1 = q3;
             }
         } else {
             while (g0 < G) {
-                do_tile(xaA, g0, q0, g1, q1);
+                CMX_DO_TILE(xaA, g0, q0, g1, q1);
                 g0 = g1; q0 = q1;
                 advance(g1, q1);
             }

@@ -269,6 +269,42 @@ __device__ __forceinline__ void gelu_both2x2(f32x2 xa, f32x2 xb, f32x2& ga, f32x
     gpb = hb + xb * (pk2(0.39894228040143267794f) * pb);
 }
 
+// The same pair of results from ONE exponential and one reciprocal (Abramowitz-Stegun 26.2.17: Phi(-|u|) = phi(u) t P4(t), t = 1 / (1 + p |u|),
+// |error| < 7.5e-8 -- the grade of fast_erf; the density phi(u) is what gelu' needs anyway): 9.5 packed / scalar instructions + 2
+// transcendentals per value against 12 + 2 above.  Two pairs in lock-step, as gelu2x2.  (First used by the head, csrc/rpb_pjg.hip.)
+__device__ __forceinline__ void gelu_both_as2x2(f32x2 ua, f32x2 ub, f32x2& va, f32x2& vb, f32x2& da, f32x2& db) {
+    const f32x2 aa = __builtin_elementwise_abs(ua), ab = __builtin_elementwise_abs(ub);
+    const f32x2 dna = pk_fma(aa, pk2(0.23164189f), pk2(1.0f)), dnb = pk_fma(ab, pk2(0.23164189f), pk2(1.0f));
+    const f32x2 qa = (ua * pk2(-0.72134752044448170368f)) * ua, qb = (ub * pk2(-0.72134752044448170368f)) * ub;
+    const f32x2 ta = {__builtin_amdgcn_rcpf(dna[0]), __builtin_amdgcn_rcpf(dna[1])}, tb = {__builtin_amdgcn_rcpf(dnb[0]), __builtin_amdgcn_rcpf(dnb[1])};
+    const f32x2 ea = {__builtin_amdgcn_exp2f(qa[0]), __builtin_amdgcn_exp2f(qa[1])}, eb = {__builtin_amdgcn_exp2f(qb[0]), __builtin_amdgcn_exp2f(qb[1])};
+#if RPB_ERF_ILP_FENCE
+#define RPB_AS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RPB_AS_FENCE()
+#endif
+    RPB_AS_FENCE();
+    f32x2 pa = pk_fma(pk2(0.5307027145f), ta, pk2(-0.7265760135f)), pb = pk_fma(pk2(0.5307027145f), tb, pk2(-0.7265760135f));
+    const f32x2 hua = pk2(0.5f) * ua, hub = pk2(0.5f) * ub;
+    RPB_AS_FENCE();
+    pa = pk_fma(pa, ta, pk2(0.7107068705f)), pb = pk_fma(pb, tb, pk2(0.7107068705f));
+    const f32x2 xa_ = aa * ea, xb_ = ab * eb;
+    RPB_AS_FENCE();
+    pa = pk_fma(pa, ta, pk2(-0.142248368f)), pb = pk_fma(pb, tb, pk2(-0.142248368f));
+    const f32x2 tea = ta * ea, teb = tb * eb;
+    RPB_AS_FENCE();
+    pa = pk_fma(pa, ta, pk2(0.127414796f)), pb = pk_fma(pb, tb, pk2(0.127414796f));
+    RPB_AS_FENCE();
+    const f32x2 ha = pk_fma(-pa, tea, pk2(0.5f)), hb = pk_fma(-pb, teb, pk2(0.5f));           // 1/2 - Phi(-|u|)
+    RPB_AS_FENCE();
+    va = pk_fma(aa, ha, hua), vb = pk_fma(ab, hb, hub);
+    const f32x2 wa = pk_fma(xa_, pk2(0.39894228040143267794f), ha), wb = pk_fma(xb_, pk2(0.39894228040143267794f), hb);
+    RPB_AS_FENCE();
+    da = pk2(0.5f) + f32x2{__builtin_copysignf(wa[0], ua[0]), __builtin_copysignf(wa[1], ua[1])};
+    db = pk2(0.5f) + f32x2{__builtin_copysignf(wb[0], ub[0]), __builtin_copysignf(wb[1], ub[1])};
+#undef RPB_AS_FENCE
+}
+
 // four channels at once (two packed pairs)
 __device__ __forceinline__ f32x4 join4(f32x2 a, f32x2 b) { return f32x4{a[0], a[1], b[0], b[1]}; }
 __device__ __forceinline__ f32x4 gelu4(f32x4 x) {

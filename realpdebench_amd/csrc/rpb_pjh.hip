@@ -70,6 +70,9 @@ __device__ __forceinline__ f32x16v mfma32(bf16x8 a, bf16x8 b, f32x16v c) {
 // products hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_f16 (dropped term <= 2^-22 |a b|); the planes travel in the bf16x8 containers,
 // slot 0 = hi, slot 1 = lo.  W1' carries 2^PH_H2W (fp16's range), undone in the two affine uses of u inside GELU.
 #define PH_H2W 4
+#ifndef RPB_H2_FMAMIX
+#define RPB_H2_FMAMIX 0   /* measured (profiles/r06b_ab.txt): the head +1 % with v_fma_mix_f32, the eval cell_mix launches -1.5 .. -7 % (rpb_cmx.hip keeps 1) */
+#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
@@ -78,10 +81,21 @@ __device__ __forceinline__ void split8h(const float (&v)[8], bf16x8& h, bf16x8& 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x2w ab = {v[2 * q], v[2 * q + 1]};
-        const f16x2v hh = __builtin_convertvector(ab, f16x2v);
-        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);
-        const f16x2v ll = __builtin_convertvector(r, f16x2v);
+        const f16x2v hh = __builtin_convertvector(ab, f16x2v);                       // v_cvt_pk_f16_f32 (RNE)
         uh[q] = __builtin_bit_cast(unsigned, hh);
+#if RPB_H2_FMAMIX
+        // residual a - float(hi) as ONE v_fma_mix_f32 per value (f16 half * -1 + f32; exact): 4 instead of 5 instructions per value pair
+        // (left alone the compiler converts both halves and subtracts packed: 2 x v_cvt_f32_f16 + v_pk_add_f32)
+        float r0, r1;
+        const unsigned hu = uh[q];
+        const float a0 = ab[0], a1 = ab[1];
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(a0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(a1));
+        const f32x2w r = {r0, r1};
+#else
+        const f32x2w r = ab - __builtin_convertvector(hh, f32x2w);                   // exact in fp32
+#endif
+        const f16x2v ll = __builtin_convertvector(r, f16x2v);
         ul[q] = __builtin_bit_cast(unsigned, ll);
     }
     h = __builtin_bit_cast(bf16x8, uh);
