@@ -165,7 +165,8 @@ def cell_mix_family_bytes(per_kernel):
     pick = lambda sub: next(v for k, v in tot.items() if sub in k)
     # template arguments <STATS, BF, FEAT, DFT, WG>; round 4: the backward launch of the step is the wave-pair variant (WG) that also
     # forms the Conv3d weight gradient (same algorithmic bytes as the plain STATS = 2 launch)
-    return (3 * pick("<1, false, false, false, false, false, 0>") + pick("<1, false, true, false, false, false, 0>") + 3 * pick("<2, false, false, false, true, false, 0>")) / 7
+    # (prefix match: template parameters appended later -- H2 in round 6 -- must not break the lookup)
+    return (3 * pick("<1, false, false, false, false, false, 0") + pick("<1, false, true, false, false, false, 0") + 3 * pick("<2, false, false, false, true, false, 0")) / 7
 
 
 def live_pmc_traffic(family):

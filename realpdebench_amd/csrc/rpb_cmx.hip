@@ -189,6 +189,10 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 #ifndef CMX_SPLIT_LAST
 #define CMX_SPLIT_LAST 1
 #endif
+#ifndef CMX_SPLIT_LAST_EVAL
+#define CMX_SPLIT_LAST_EVAL 0    /* experiment: the same for the fp32-storage eval launches now that they hold one epilogue copy */
+#endif
+#define CMX_SPLITL(STATS_, BF_) (CMX_SPLIT_LAST && ((STATS_) == 1 || (CMX_SPLIT_LAST_EVAL && (STATS_) == 0 && !(BF_))))
 #ifndef CMX_WG_GELU_AS
 #define CMX_WG_GELU_AS 1
 #endif
@@ -524,7 +528,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     // instruction cache).  So: the STATS == 1 instances only.
     auto do_tile = [&](auto last_tag, u32x4 (&xa)[2][4], long gi, int q, long ngi, int nq) {
         constexpr bool LASTC = decltype(last_tag)::value;
-        constexpr bool SPLITL = CMX_SPLIT_LAST && STATS == 1;       // measured per variant (profiles/r06b_ab2_split_last.txt), see CMX_SPLIT_LAST
+        constexpr bool SPLITL = CMX_SPLITL(STATS, BF);              // measured per variant (profiles/r06b_ab2_split_last.txt), see CMX_SPLIT_LAST
         {
             const long g = U(line_of(gi));
             const rsrc_t ro = make_rsrc(a.out + g * line_floats + 64 * hsel, line_bytes - 256u * (unsigned)hsel);
@@ -881,7 +885,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     };
 #define CMX_DO_TILE(XA, G_, Q_, NG_, NQ_)                                                                      \
     do {                                                                                                       \
-        if ((CMX_SPLIT_LAST && STATS == 1) && (Q_) + 1 == TQ) do_tile(std::true_type{}, XA, G_, Q_, NG_, NQ_);     \
+        if (CMX_SPLITL(STATS, BF) && (Q_) + 1 == TQ) do_tile(std::true_type{}, XA, G_, Q_, NG_, NQ_);              \
         else do_tile(std::false_type{}, XA, G_, Q_, NG_, NQ_);                                                 \
     } while (0)
     int pend = 0;                   // claim mode 2: the wave's outstanding claim (lane 0)

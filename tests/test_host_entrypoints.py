@@ -132,8 +132,8 @@ def test_bench_pmc_csv_to_family_traffic(tmp_path):
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    names = {"f": "void cmx_kernel<1, false, false, false, false, false, 0>(CmxArgs)", "l0": "void cmx_kernel<1, false, true, false, false, false, 0>(CmxArgs)",
-             "b": "void cmx_kernel<2, false, false, false, true, false, 0>(CmxArgs)", "x": "void other_kernel(Args)"}
+    names = {"f": "void cmx_kernel<1, false, false, false, false, false, 0, false>(CmxArgs)", "l0": "void cmx_kernel<1, false, true, false, false, false, 0, false>(CmxArgs)",
+             "b": "void cmx_kernel<2, false, false, false, true, false, 0, false>(CmxArgs)", "x": "void other_kernel(Args)"}
     def write(path, rows):
         with open(path, "w") as fh:
             fh.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")

@@ -20,12 +20,12 @@ def load(fn):
 rd, wr, out_path = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
 ncell, ncrop, G = 32 * 26 * 134 * 134, 32 * 20 * 128 * 128, 32 * 26 * 134          # tools/kbench.py sizes = BASELINE configs[1], B = 32
 alg = {
-    # cmx_kernel<STATS, BF, FEAT, DFT, WG, SB, C2>
-    "void cmx_kernel<0, false, false, false, false, false, 0>(CmxArgs)": 4 * (2 * ncell * 64 + G * 32 * 64),
-    "void cmx_kernel<1, false, false, false, false, false, 0>(CmxArgs)": 4 * (2 * ncell * 64 + G * 32 * 64),
-    "void cmx_kernel<1, false, true, false, false, false, 0>(CmxArgs)": 4 * (ncell * (8 + 64) + G * 32 * 64),
-    "void cmx_kernel<2, false, false, false, false, false, 0>(CmxArgs)": 4 * (3 * ncell * 64 + G * 32 * 64),
-    "void cmx_kernel<2, false, false, false, true, false, 0>(CmxArgs)": 4 * (3 * ncell * 64 + G * 32 * 64),       # + the Conv3d weight gradient (wave pairs)
+    # cmx_kernel<STATS, BF, FEAT, DFT, WG, SB, C2, H2>
+    "void cmx_kernel<0, false, false, false, false, false, 0, false>(CmxArgs)": 4 * (2 * ncell * 64 + G * 32 * 64),
+    "void cmx_kernel<1, false, false, false, false, false, 0, false>(CmxArgs)": 4 * (2 * ncell * 64 + G * 32 * 64),
+    "void cmx_kernel<1, false, true, false, false, false, 0, false>(CmxArgs)": 4 * (ncell * (8 + 64) + G * 32 * 64),
+    "void cmx_kernel<2, false, false, false, false, false, 0, false>(CmxArgs)": 4 * (3 * ncell * 64 + G * 32 * 64),
+    "void cmx_kernel<2, false, false, false, true, false, 0, false>(CmxArgs)": 4 * (3 * ncell * 64 + G * 32 * 64),       # + the Conv3d weight gradient (wave pairs)
     "void bwd_row_kernel<64, false>(BwdRowArgs)": 4 * (4 * ncell * 64 + G * 32 * 64),
     "void bwd_row_kernel<64, true>(BwdRowArgs)": 4 * (3 * ncell * 64 + ncell * 8 + G * 32 * 64),         # layer 0 (kbench stores gs)
     # bwr_kernel<GELU, XBN, XGELU, FEAT, NOX>
@@ -54,8 +54,8 @@ for k, a in alg.items():
     wb = 64 * w.get("TCC_EA0_WRREQ_64B", 0)
     tr[k] = rb + wb
     out.append(f"  {k[5:57]:52s} {rb / 1e9:9.4f} {wb / 1e9:11.4f} {(rb + wb) / 1e9:9.4f} {a / 1e9:15.4f} {(rb + wb) / a:6.3f}")
-c1, cf, c2 = (tr.get(f"void cmx_kernel<{v}>(CmxArgs)") for v in ("1, false, false, false, false, false, 0", "1, false, true, false, false, false, 0",
-                                                                   "2, false, false, false, true, false, 0"))
+c1, cf, c2 = (tr.get(f"void cmx_kernel<{v}>(CmxArgs)") for v in ("1, false, false, false, false, false, 0, false", "1, false, true, false, false, false, 0, false",
+                                                                   "2, false, false, false, true, false, 0, false"))
 if c1 and cf and c2:
     fam = (3 * c1 + cf + 3 * c2) / 7
     out += ["#", f"# cell_mix family of one train step (3 x <1>, 1 x <1,feat>, 3 x <2,WG>): {fam / 1e9:.4f} GB per launch on average = roofline.traffic of bench.py"]
