@@ -38,11 +38,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& h, bf16x8& m
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float a = v[2 * q], b = v[2 * q + 1];
-        uh[q] = pack_hi(a, b);
-        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
-        um[q] = pack_hi(ra, rb);
-        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
-        ul[q] = pack_hi(sa, sb);
+        {
+            unsigned ph_, pm_, pl_;
+            rpb_split_pair(a, b, ph_, pm_, pl_);
+            uh[q] = ph_;
+            um[q] = pm_;
+            ul[q] = pl_;
+        }
     }
     h = __builtin_bit_cast(bf16x8, uh);
     m = __builtin_bit_cast(bf16x8, um);
@@ -55,11 +57,13 @@ __device__ __forceinline__ void split8n(const float (&v)[8], int npairs, bf16x8&
     for (int q = 0; q < 4; ++q) {
         if (q >= npairs) break;
         const float a = v[2 * q], b = v[2 * q + 1];
-        uh[q] = pack_hi(a, b);
-        const float ra = a - trunc_bf16(a), rb = b - trunc_bf16(b);
-        um[q] = pack_hi(ra, rb);
-        const float sa = ra - trunc_bf16(ra), sb = rb - trunc_bf16(rb);
-        ul[q] = pack_hi(sa, sb);
+        {
+            unsigned ph_, pm_, pl_;
+            rpb_split_pair(a, b, ph_, pm_, pl_);
+            uh[q] = ph_;
+            um[q] = pm_;
+            ul[q] = pl_;
+        }
     }
     h = __builtin_bit_cast(bf16x8, uh);
     m = __builtin_bit_cast(bf16x8, um);

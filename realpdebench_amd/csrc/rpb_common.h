@@ -109,6 +109,41 @@ __device__ __forceinline__ unsigned tile_bytes(long rows_left, int tile_rows, in
 #define RPB_BF16_CONST_PLANES 2
 #endif
 
+// ---------------------------------------------------------------------------------- the three-plane operand split
+// x = hi + mid + lo EXACTLY with three bf16 numbers, two ways:
+//   RPB_SPLIT_RNE = 0 (default)  truncation at every level (v_perm packs): mid < 2^-7 |x|, lo < 2^-15 |x|, so the three products the
+//       six-product scheme drops (mid*lo, lo*mid, lo*lo) are 2^-24 |a b| typically (rms 2^-24.1) and reach 2^-21.3 in the worst case;
+//   RPB_SPLIT_RNE = 1  round to nearest even at every level (gfx950: v_cvt_pk_bf16_f32 converts a pair): |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|,
+//       still exact (the last residual has at most 8 significant bits), dropped terms <= 2^-24.2 |a b| worst case, 2^-27.5 rms
+//       (tools/split_error.py).  Fewer instructions (4.5 against 5.5 per value) but NOT faster: the conversions and packed subtracts
+//       issue at the packed rate -- measured (profiles/r06b_ab4_split_rne.txt, A/B twice on one box): train step 35.63 / 35.67 ms with the
+//       truncating split, 36.04 / 36.09 with the rounding one (the wave-pair backward cell_mix 2.95 -> 3.05 ms), eval forward equal
+//       (11.35 ms).  Every parity test passes either way; the build switch is for a caller that wants the tighter worst case for 1.1 %.
+// (The split3 passes of csrc/rpb_conv3x.hip -- memory-bound -- have rounded since round 2.)
+#ifndef RPB_SPLIT_RNE
+#define RPB_SPLIT_RNE 0
+#endif
+typedef __bf16 rpb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rpb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rpb_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+#if RPB_SPLIT_RNE
+    const rpb_f32x2 ab = {a, b};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, rpb_bf16x2));
+    const rpb_f32x2 r = ab - rpb_f32x2{__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};        // exact
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rpb_bf16x2));
+    const rpb_f32x2 s = r - rpb_f32x2{__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};         // exact
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, rpb_bf16x2));                                                  // exact: <= 8 significant bits
+#else
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float ra = a - __builtin_bit_cast(float, ua & 0xffff0000u), rb = b - __builtin_bit_cast(float, ub & 0xffff0000u);
+    const unsigned uc = __builtin_bit_cast(unsigned, ra), ud = __builtin_bit_cast(unsigned, rb);
+    m = __builtin_amdgcn_perm(ud, uc, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, uc & 0xffff0000u), sb = rb - __builtin_bit_cast(float, ud & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+#endif
+}
+
 // ---------------------------------------------------------------------------------- math
 // Branch-free erf:  erf(x) = sign(x) * (1 - 2^(t*S(t))),  t = min(|x|, 4),  S = degree-8 weighted-minimax fit of
 // log2(erfc(t))/t (fitted offline against scipy in fp64; max |error| 9.5e-8 in fp32 arithmetic = the rounding of

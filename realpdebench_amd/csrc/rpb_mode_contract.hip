@@ -309,11 +309,13 @@ __device__ __forceinline__ Planes m_split(const float (&v)[8]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float a = v[2 * q], b = v[2 * q + 1];
-        uh[q] = m_pack(a, b);
-        const float ra = a - m_trunc(a), rb = b - m_trunc(b);
-        um[q] = m_pack(ra, rb);
-        const float sa = ra - m_trunc(ra), sb = rb - m_trunc(rb);
-        ul[q] = m_pack(sa, sb);
+        {
+            unsigned ph_, pm_, pl_;
+            rpb_split_pair(a, b, ph_, pm_, pl_);
+            uh[q] = ph_;
+            um[q] = pm_;
+            ul[q] = pl_;
+        }
     }
     return Planes{__builtin_bit_cast(mbf16x8, uh), __builtin_bit_cast(mbf16x8, um), __builtin_bit_cast(mbf16x8, ul)};
 }

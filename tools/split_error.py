@@ -2,6 +2,7 @@
 """Per-product and per-dot-product error of the operand splits this repo multiplies on the 16-bit matrix pipe (numpy, no GPU):
 
   bf16x3 x 6   the default: x = hi + mid + lo exactly (three TRUNCATED bf16 planes), six products, the three smallest dropped
+  bf16x3r x 6  the same with every plane ROUNDED to nearest even (build switch -DRPB_SPLIT_RNE=1, csrc/rpb_common.h)
   f16x2 x 3    the opt-in eval arithmetic (FNO3d.set_arith("f16x2")): two fp16 planes, both rounded to nearest even, lo*lo dropped
   f16x2 x 4    the same with the fourth product kept
   fp32         one rounded fp32 multiply / a sequential fp32 dot product (what a CPU fp32 reference does)
@@ -27,6 +28,20 @@ def bf3(x):
     return h.astype(np.float64), m.astype(np.float64), l.astype(np.float64)
 
 
+def rne_bf16(x):
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32).view(np.float32)
+
+
+def bf3r(x):
+    h = rne_bf16(x)
+    r = (x - h).astype(np.float32)
+    m = rne_bf16(r)
+    l = rne_bf16((r - m).astype(np.float32))
+    assert np.all(h.astype(np.float64) + m + l == x.astype(np.float64))      # exact
+    return h.astype(np.float64), m.astype(np.float64), l.astype(np.float64)
+
+
 def h2(x):
     h = x.astype(np.float16)
     l = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
@@ -47,6 +62,9 @@ a1, a2 = h2(a)
 b1, b2 = h2(b)
 p3 = a1 * b2 + a2 * b1 + a1 * b1
 print("bf16x3 x 6 :", stats(ah * bl + al * bh + am * bm + ah * bm + am * bh + ah * bh, ex))
+rh, rm, rl_ = bf3r(a)
+sh, sm, sl = bf3r(b)
+print("bf16x3r x 6:", stats(rh * sl + rl_ * sh + rm * sm + rh * sm + rm * sh + rh * sh, ex))
 print("f16x2  x 3 :", stats(p3, ex))
 print("f16x2  x 4 :", stats(p3 + a2 * b2, ex))
 print("fp32 mul   :", stats((a * b).astype(np.float64), ex))
