@@ -341,19 +341,62 @@ __device__ __forceinline__ f32x4 m_mac6(const Planes& a, const Planes& b, f32x4 
 #define MB_XP 68        // row pitch (floats) of the coefficient tiles [ri][b 32][c 64]
 #define MB_WP 133       // row pitch (floats) of the weight tile [i 64][o 64][2]: odd, so that neither the row-strided gather of the forward
                         // (8 rows per lane group: 8 * 133 = 8 mod 32) nor the column-strided one of the data gradient piles onto a few banks
-template <int MODE>
+// PERSIST (B <= 32, the default there): a workgroup walks modes m = blockIdx.x, + gridDim.x, ... and requests the NEXT mode's weight tile (8 x 16 B
+// per thread) and coefficient rows (4, wgrad 8) into registers before it computes the current one from LDS.  One workgroup per mode left
+// every global load's latency exposed -- the launch ran at 1-2 TB/s of a 100 MB weight read (0.095 ms cold, 0.046 warm, against 0.02 at the
+// copy rate) with three workgroups of 51 KB per CU and nothing in flight while they computed.
+template <int MODE, bool PERSIST = false>
 __global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ GY,
                                                          float* __restrict__ OUT, int B, int M, int accumulate) {
     constexpr int C = 64;
     __shared__ __attribute__((aligned(16))) float Xs[2 * 32 * MB_XP];                      // fwd / wgrad: X, dgrad: gY
     __shared__ __attribute__((aligned(16))) float Ws[MODE == 2 ? 2 * 32 * MB_XP : 64 * MB_WP];   // fwd / dgrad: the mode's weight tile; wgrad: gY
-    const int m = blockIdx.x;
+    int m = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kg = lane >> 4;
     const long plane = (long)M * C;
     const float* src = MODE == 1 ? GY : X;
-    if (MODE != 2) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wq[PERSIST && MODE != 2 ? 8 : 1], xq[PERSIST ? 4 : 1], gq[PERSIST && MODE == 2 ? 4 : 1];      // PERSIST: the next mode's tiles in flight
+    auto fetch = [&](int mm) {                                   // PERSIST: issue the loads of mode mm (B <= 32: one batch pass)
+        if (MODE != 2) {
+            const float* Wm = Wt + (long)mm * C * C * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wq[PERSIST && MODE != 2 ? j : 0] = *reinterpret_cast<const f32x4*>(Wm + (long)(tid + 256 * j) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, c4 = idx % (C / 4), r = idx / (C / 4), bl = r >> 1, ri = r & 1;
+            f32x4 v = z4, g = z4;
+            if (bl < B) {
+                v = *reinterpret_cast<const f32x4*>(src + (long)(bl * 2 + ri) * plane + (long)mm * C + 4 * c4);
+                if (MODE == 2) g = *reinterpret_cast<const f32x4*>(GY + (long)(bl * 2 + ri) * plane + (long)mm * C + 4 * c4);
+            }
+            xq[PERSIST ? j : 0] = v;
+            if (MODE == 2) gq[PERSIST && MODE == 2 ? j : 0] = g;
+        }
+    };
+    auto park = [&]() {                                          // PERSIST: registers -> LDS (waits for the loads)
+        if (MODE != 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + 256 * j, i = (2 * idx) / C, o = 2 * idx - i * C;
+                const f32x4 w = wq[PERSIST && MODE != 2 ? j : 0];
+                float* d = Ws + i * MB_WP + 2 * o;
+                d[0] = w[0], d[1] = w[1], d[2] = w[2], d[3] = w[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 256 * j, c4 = idx % (C / 4), r = idx / (C / 4), bl = r >> 1, ri = r & 1;
+            *reinterpret_cast<f32x4*>(Xs + (ri * 32 + bl) * MB_XP + 4 * c4) = xq[PERSIST ? j : 0];
+            if (MODE == 2) *reinterpret_cast<f32x4*>(Ws + (ri * 32 + bl) * MB_XP + 4 * c4) = gq[PERSIST && MODE == 2 ? j : 0];
+        }
+    };
+    if (PERSIST) fetch(m);
+  for (; m < M; m += (int)gridDim.x) {                           // (one pass without PERSIST: gridDim.x == M)
+    if (!PERSIST && MODE != 2) {
         const float* Wm = Wt + (long)m * C * C * 2;
         for (int idx = tid; idx < C * C / 2; idx += 256) {       // two complex numbers per 16 B load: row i, columns o, o + 1
 #if MB_NT
@@ -366,15 +409,19 @@ __global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict_
             d[0] = w[0], d[1] = w[1], d[2] = w[2], d[3] = w[3];
         }
     }
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 accg[4][2];                                            // wgrad: [i tile][part] of the wave's o tile, summed over the batch passes
+    if (PERSIST) {
+        park();
+        __syncthreads();
+        if (m + (int)gridDim.x < M) fetch(m + (int)gridDim.x);   // in flight during everything below
+    }
     if (MODE == 2) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) accg[rt][0] = accg[rt][1] = z4;
     }
     for (int b0 = 0; b0 < B; b0 += 32) {
         if (b0) __syncthreads();
-        for (int idx = tid; idx < 2 * 32 * (C / 4); idx += 256) {
+        for (int idx = tid; idx < (PERSIST ? 0 : 2 * 32 * (C / 4)); idx += 256) {
             const int c4 = idx % (C / 4), r = idx / (C / 4);     // r = bl * 2 + ri
             const int bl = r >> 1, ri = r & 1, b = b0 + bl;
             f32x4 v = z4, g = z4;
@@ -385,7 +432,7 @@ __global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict_
             *reinterpret_cast<f32x4*>(Xs + (ri * 32 + bl) * MB_XP + 4 * c4) = v;
             if (MODE == 2) *reinterpret_cast<f32x4*>(Ws + (ri * 32 + bl) * MB_XP + 4 * c4) = g;
         }
-        __syncthreads();
+        if (!PERSIST) __syncthreads();
         if (MODE != 2) {
             // wave w: output columns n = 32 w .. 32 w + 31 of (plane, channel): plane po = w >> 1, channels 32 (w & 1) + 16 ct + n16
             const int po = wave >> 1;
@@ -466,8 +513,32 @@ __global__ __launch_bounds__(256) void mode_bf16_kernel(const float* __restrict_
                 *dst = v;
             }
     }
+    if (PERSIST) __syncthreads();                                // every wave is done with this mode's tiles before the next ones are parked
+  }
 }
 
+// resident workgroups per CU of the persistent instances (registers: 184 / 180 for fwd / dgrad -> two waves per SIMD; 288 for wgrad -> one)
+static int mode_persist_wgs(int mode) {
+    static const int f = getenv("RPB_MODE_PERSIST_WGS") ? atoi(getenv("RPB_MODE_PERSIST_WGS")) : 0;
+    return f > 0 ? f : (mode == 2 ? 1 : 2);
+}
+// Measured (B = 32, profiles/r06b_mode_persist.txt): with the layer's 100 MB of weights in the Infinity Cache (rollout, micro-benchmark) the
+// persistent instances run 0.054 -> 0.048 ms (fwd) and 0.050 -> 0.044 ms (dgrad); inside the training step, where the forward reads its weights
+// COLD, the persistent forward takes 0.124 ms against 0.095 (two workgroups per CU with one tile in flight each keep fewer bytes outstanding than
+// three one-shot workgroups that the dispatcher staggers), dgrad 0.053 -> 0.047.  So: dgrad persistent, the forward only on request
+// (RPB_MODE_PERSIST_FWD=1: a rollout-only process gains 0.04 ms per forward), wgrad never (288 registers: one workgroup per CU, 0.044 -> 0.046).
+static bool mode_persist_fwd() {
+    static const bool on = getenv("RPB_MODE_PERSIST_FWD") && atoi(getenv("RPB_MODE_PERSIST_FWD")) == 1;
+    return on;
+}
+static bool mode_persist_wgrad() {
+    static const bool on = getenv("RPB_MODE_PERSIST_WGRAD") && atoi(getenv("RPB_MODE_PERSIST_WGRAD")) == 1;
+    return on;
+}
+static bool mode_persist_on() {
+    static const bool on = !(getenv("RPB_MODE_PERSIST") && atoi(getenv("RPB_MODE_PERSIST")) == 0);
+    return on;
+}
 // ---- C = 128 (configs/fsi/fno.yaml, the Galerkin regressor) on the same pipe: the composite per-mode GEMM is [B x 256] x [256 x 256];
 // the weight tile (128 KB) does not fit next to the coefficients, so the workgroup walks the 64-wide output halves (fwd: o halves with
 // all 128 rows i of the weights; dgrad: i halves with all 128 columns o), re-staging the weight half in LDS (66 KB) each time.  wgrad
@@ -703,7 +774,12 @@ static int mc_check(const void* a, const void* b, const void* c, int B, int M, i
 extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream) {
     if (int e = mc_check(X, W, Y, B, M, C)) return e;
     if (mode_bf16_on(C)) {
-        hipLaunchKernelGGL((mode_bf16_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
+        if (B <= 32 && mode_persist_on() && mode_persist_fwd()) {        // warm weights only (rollout): see mode_persist_fwd
+            const int grid = M < mode_persist_wgs(0) * rpb_num_cus() ? M : mode_persist_wgs(0) * rpb_num_cus();
+            hipLaunchKernelGGL((mode_bf16_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
+        } else {
+            hipLaunchKernelGGL((mode_bf16_kernel<0>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
+        }
         RPB_CHECK_LAUNCH("mode_contract_fwd");
     }
     if (mode_mfma_on(C)) {
@@ -726,7 +802,12 @@ extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, i
 extern "C" int rpb_mode_contract_dgrad(const float* GY, const float* W, float* GX, int B, int M, int C, void* stream) {
     if (int e = mc_check(GY, W, GX, B, M, C)) return e;
     if (mode_bf16_on(C)) {
-        hipLaunchKernelGGL((mode_bf16_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        if (B <= 32 && mode_persist_on()) {
+            const int grid = M < mode_persist_wgs(0) * rpb_num_cus() ? M : mode_persist_wgs(0) * rpb_num_cus();
+            hipLaunchKernelGGL((mode_bf16_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        } else {
+            hipLaunchKernelGGL((mode_bf16_kernel<1>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, W, GY, GX, B, M, 0);
+        }
         RPB_CHECK_LAUNCH("mode_contract_dgrad");
     }
     if (mode_mfma_on(C)) {
@@ -757,7 +838,12 @@ extern "C" int rpb_mode_contract_wgrad(const float* X, const float* GY, float* G
                                        void* stream) {
     if (int e = mc_check(X, GY, GW, B, M, C)) return e;
     if (mode_bf16_on(C)) {
-        hipLaunchKernelGGL((mode_bf16_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        if (B <= 32 && mode_persist_on() && mode_persist_wgrad()) {      // measured slower (288 registers: one workgroup per CU): off
+            const int grid = M < mode_persist_wgs(2) * rpb_num_cus() ? M : mode_persist_wgs(2) * rpb_num_cus();
+            hipLaunchKernelGGL((mode_bf16_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        } else {
+            hipLaunchKernelGGL((mode_bf16_kernel<2>), dim3(M), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, GY, GW, B, M, accumulate);
+        }
         RPB_CHECK_LAUNCH("mode_contract_wgrad");
     }
     if (mode_mfma_on(C)) {
