@@ -51,6 +51,15 @@ def main(argv=None):
     if args.checkpoint_path:
         meta = model.load_checkpoint(args.checkpoint_path, device)                     # eval.py:284
         logging.info(f"Checkpoint {args.checkpoint_path} loaded (iteration {meta['iteration']}).")
+    # optional YAML keys (not in the reference; FNO3d at width 64 only, both default to the parity path): `eval_storage: bf16` stores the
+    # activations between kernels as bf16 (BASELINE.json configs[4]), `eval_arith: f16x2` runs the eval launches on two fp16 planes
+    for key, setter in (("eval_storage", "set_storage"), ("eval_arith", "set_arith")):
+        val = getattr(args, key, None)
+        if val:
+            if not hasattr(model, setter):
+                raise SystemExit(f"{key}: {type(model).__name__} has no {setter} (FNO3d only)")
+            getattr(model, setter)(str(val))
+            logging.info(f"{key} = {val}")
     results, _, _ = evaluate(model, loader, normalizer, int(args.N_autoregressive), args.test_batch_size)
     logging.info(f"Results saved at {exp_path}")
     return results

@@ -128,3 +128,41 @@ def test_rollout_f16x2_stays_with_the_default(monkeypatch):
         m.set_arith("f16x2")
         b = rollout(m, x, 10).clone()
     assert rel_l2(b.cpu(), a.cpu()) < 2e-5
+
+
+def test_eval_entrypoint_takes_eval_arith(tmp_path):
+    """`python -m realpdebench_amd.eval` with the optional YAML key `eval_arith: f16x2` (width 64, lines long enough for the fused launches):
+    the 13 metrics agree with the default arithmetic's to 1e-4 relative (they are means over errors of ~1e-7 relative size)."""
+    import glob
+    import os
+    import yaml
+    from realpdebench_amd import eval as ev
+    from realpdebench_amd import train as tr
+    cfg = dict(exp_name="t", gpu=0, seed=0, results_path=str(tmp_path), dataset_name="synthetic", dataset_root="",
+               num_workers=0, normalizer="none", shape_in=[4, 12, 40, 2], shape_out=[4, 12, 40, 2], n_train=8, n_val=4,
+               model_name="fno", checkpoint_path="", modes1=2, modes2=3, modes3=8, n_layers=3, width=64, is_use_tb=None,
+               scheduler="cosine", step_size=10, num_update=100, train_batch_size=4, test_batch_size=4, lr=1e-3,
+               clip_grad_norm=0.0, N_autoregressive=1)
+    path = tmp_path / "fno.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    exp = tr.main(["--config", str(path), "--max_updates", "3"])
+    ck = sorted(glob.glob(os.path.join(exp, "model_*.pth")))[-1]
+    base = ev.main(["--config", str(path), "--checkpoint_path", ck])
+    path2 = tmp_path / "fno_f16x2.yaml"
+    path2.write_text(yaml.safe_dump(dict(cfg, eval_arith="f16x2")))
+    fast = ev.main(["--config", str(path2), "--checkpoint_path", ck])
+    assert set(base) == set(fast)
+    n = 0
+    for k in base:
+        if not isinstance(base[k], (int, float)):
+            assert base[k] == fast[k]
+            continue
+        a, b = float(base[k]), float(fast[k])
+        if a == a and b == b:                   # band means over empty bin ranges are NaN on tiny grids (as in the reference)
+            assert abs(a - b) <= 1e-4 * max(abs(a), 1e-12), (k, a, b)
+            n += 1
+    assert n >= 5
+    path3 = tmp_path / "bad.yaml"
+    path3.write_text(yaml.safe_dump(dict(cfg, eval_arith="fp8")))
+    with pytest.raises(ValueError):
+        ev.main(["--config", str(path3), "--checkpoint_path", ck])
