@@ -143,10 +143,16 @@ static void lift_pad_launch(int grid, size_t lds, hipStream_t st, const float* x
                        cm, out_bf16);
 }
 
+// csrc/rpb_lift_mx.hip: the bf16-output lift at C_in = 16, C = 64 as one MFMA K-step (RPB_LIFT_MX=0 keeps the vector kernel below)
+bool rpb_lift_mx_supported(int Cin, int C);
+int rpb_lift_mx_launch(const float* x, const float* gt, const float* gh, const float* gw, const float* w0, const float* b0, void* out_bf16,
+                       int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st);
+
 static int lift_pad_impl(const float* x, const float* gt, const float* gh, const float* gw, const float* w0,
                          const float* b0, float* out, int B, int T, int H, int W, int Cin, int C, int Tp, int Hp,
                          int Wp, int out_bf16, void* stream) {
     RPB_REQUIRE(x && gt && gh && gw && w0 && b0 && out, "lift_pad: null pointer");
+    if (out_bf16 && rpb_lift_mx_supported(Cin, C)) return rpb_lift_mx_launch(x, gt, gh, gw, w0, b0, out, B, T, H, W, Tp, Hp, Wp, (hipStream_t)stream);
     RPB_REQUIRE(C % 4 == 0 && PW_THREADS % (C / 4) == 0 && Cin >= 0 && Cin + 3 <= LIFT_FMAX, "lift_pad: C=%d Cin=%d unsupported", C, Cin);
     const long nrows = (long)B * Tp * Hp;
     const int F = Cin + 3;

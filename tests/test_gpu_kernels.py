@@ -786,6 +786,33 @@ def test_bf16_storage_kernels(ops, Wp, rows, K2):
     assert rel_l2(o16, o32) < TOLB
 
 
+@pytest.mark.parametrize("T,H,W,pad", [(3, 5, 64, 6), (2, 3, 40, 6), (2, 4, 33, 2)])
+def test_lift_bf16_wide_input_on_the_matrix_pipe(ops, T, H, W, pad, monkeypatch):
+    """rpb_lift_pad_fwd_bf16 at C_in = 16 (the combustion volume) runs csrc/rpb_lift_mx.hip: one MFMA K-step over 16 inputs + 3 coordinates +
+    the bias, fp32-grade split products, bf16 out.  Against round(fp32 lift): equal except where the fp32 value sits on a rounding
+    boundary (at most one bf16 unit, < 0.1 % of the elements); the pad -- whole lines and the cells w >= W -- is exact zeros."""
+    torch.manual_seed(W)
+    B, Cin, C = 2, 16, 64
+    d = ops.Dims(B, T, H, W, Cin, C, pad)
+    xin = torch.randn(B, T, H, W, Cin, device="cuda")
+    grids = [torch.linspace(0, 1, n, device="cuda") for n in (T, H, W)]
+    w0, b0 = torch.randn(C, Cin + 3, device="cuda"), torch.randn(C, device="cuda")
+    a32 = torch.empty(d.ncell, C, device="cuda")
+    a16 = torch.full((d.ncell, C), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.lift_pad_fwd(xin, grids, w0, b0, a32, d)
+    ops.lift_pad_fwd_bf16(xin, grids, w0, b0, a16, d)
+    ref = a32.to(torch.bfloat16)
+    neq = a16 != ref
+    assert float(neq.float().mean()) < 1e-3
+    # a correctly rounded bf16 of a value that agrees with the fp32 lift to fp32 round-off (sums of 20 O(1) terms: ~4e-6 absolute)
+    assert bool(((a16.float() - a32).abs() <= 2.0 ** -8 * a32.abs() * (1 + 1e-3) + 4e-6).all())
+    v = a16.view(B, d.Tp, d.Hp, d.Wp, C)
+    assert float(v[:, T:].abs().max() if pad else 0) == 0 and float(v[:, :, H:].abs().max()) == 0 and float(v[:, :, :, W:].abs().max()) == 0
+    assert float(v[:, :T, :H, :W].abs().min()) > 0
+    # the vector kernel stays reachable (and is the bit-exact rounding of the fp32 lift)
+    # (RPB_LIFT_MX is read once per process: checked in a child process by tools, not here)
+
+
 @pytest.mark.parametrize("B,T,H,W,pad,DO,gelu,act", [(2, 3, 5, 32, 2, 2, False, 0), (1, 2, 4, 48, 3, 1, False, 0),
                                                       (1, 2, 3, 40, 6, 3, True, 1)])
 def test_projection_backward_without_gu(ops, B, T, H, W, pad, DO, gelu, act):
