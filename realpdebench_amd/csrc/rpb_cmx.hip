@@ -166,6 +166,13 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 //       accumulator.  Hand-off per tile through two monotonic LDS counters per pair (produced / consumed); the two waves of a pair
 //       share a SIMD's issue slots, so the light wave runs in the stalls of the heavy one.
 #define CMX_WAVES_DFT 8
+// bf16 activations AND bf16 spectra with the fused W stage (configs[4]): the kernel holds 168 registers and moves half the bytes per tile,
+// so one tile of loads in flight per wave leaves the memory system short (3.8 TB/s at 8 waves); its z2 slice is one plane (4 KB per wave
+// instead of 12), which makes room for THREE waves per SIMD
+#ifndef CMX_WAVES_DFT_SB
+#define CMX_WAVES_DFT_SB 12
+#endif
+#define CMX_WAVES_DFTX(SB_) ((SB_) ? CMX_WAVES_DFT_SB : CMX_WAVES_DFT)
 #define CMX_WG_PAIRS 4
 // SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
 //       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
@@ -203,7 +210,7 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 //       Scalings (exact: powers of two): conv weights and bias x 2^H2W, GW x 2^(spec_exp + H2W), z2 x 2^-spec_exp, and 2^-H2W rides in the
 //       output transform's scale.
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0, bool H2 = false>
-__global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
+__global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
     static_assert(!H2 || (STATS == 0 && !BF && !WG && !SB && !C2), "f16x2: the fp32-storage eval launches at C = 64");
     constexpr bool H2X = H2 && !FEAT;                    // channel mixing on fp16 planes
     constexpr int H2W = H2X ? 4 : 0;                     // log2 of the scale the accumulators carry
@@ -220,7 +227,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     const int hsel = C2 ? (int)(blockIdx.x & 1) : 0;     // C = 128: which 64-channel half of the output this workgroup produces
     const int bx = C2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, gx = C2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int FW = a.feat_w;
-    constexpr int CMX_WAVES = C2 ? C2 : (WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFT : CMX_WAVES_OF(STATS)));     // line-walking ("mix") waves
+    constexpr int CMX_WAVES = C2 ? C2 : (WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OF(STATS)));     // line-walking ("mix") waves
+    constexpr int ZST = (DFT && SB) ? 4 : 12;            // u32x4 rows of a wave's z2 slice (bf16 spectra: one plane)
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
@@ -228,7 +236,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     // instead, which is what lets 8 waves fit next to the forward-stage matrix
     u32x4* GWs = DFT ? const_cast<u32x4*>(reinterpret_cast<const u32x4*>(a.gw_planes)) : Bw + BWN;
     u32x4* Zs = Bw + BWN + (DFT ? 0 : 3 * Wp * 4);   // [wave][plane 3][t 4][lane 64]   the current line's z2 row, B-operand order
-    float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * 12 * 64);   // [2][CC] (+ one unused row)  input transform: invstd*gamma, beta - mean*invstd*gamma
+    float* xfp = reinterpret_cast<float*>(Zs + CMX_WAVES * ZST * 64);   // [2][CC] (+ one unused row)  input transform: invstd*gamma, beta - mean*invstd*gamma
     u32x4* FWs = reinterpret_cast<u32x4*>(xfp + 3 * CC);               // DFT: [tile q][plane 3][mt2 2][lane 64]  forward W-stage matrix, A-operand rows
     u32x4* MBs = FWs;                                                  // WG: [pair][row (j, r) 8][lane 64]  act(z) of the pair's current tile (fp32)
     int* flags = reinterpret_cast<int*>(MBs + CMX_WG_PAIRS * 8 * 64);  // WG: [pair][2]  tiles produced / tiles consumed
@@ -514,7 +522,7 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
         for (int e = 0; e < 8; ++e) zr[e] = ld16a<CMX_Z_AUX>(rz, (8 * kg + e) * CB + m * 16);
     };
 
-    u32x4* Zw = Zs + wave * 12 * 64 + lane;
+    u32x4* Zw = Zs + wave * ZST * 64 + lane;
     f32x4v Yacc[DFT ? 2 : 1][DFT ? 4 : 1];
     // one wave tile: (gi, q) = the tile computed from the register image `xa`; (ngi, nq) = the tile whose loads take the image's place
     // (the next tile, or with PF2 the one after it; ngi >= G: none)
@@ -1022,7 +1030,8 @@ extern "C" int rpb_cmx_debug_wave_times(void* buf) {
     return 0;
 }
 
-static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false) {
+static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false, bool dft_sb = false) {
+    if (dft_sb) return (size_t)(24 * 64 + waves * 4 * 64) * 16 + 3 * 64 * 4 + (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 + 16;
     if (wg) return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (size_t)CMX_WG_PAIRS * 8 * 64 * 16 + 2 * CMX_WG_PAIRS * 4;
     return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0) + 16;
 }
@@ -1138,11 +1147,12 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
         // (f16x2: the feature-field launch keeps unscaled accumulators, the C = 64 launch carries 2^4 -- H2W in the kernel)
         hipLaunchKernelGGL(cmx_gw_prep_kernel, dim3((a.Wp * 4 + 255) / 256), dim3(256), 0, st, a.GW, (u32x4*)a.gw_planes, a.K2, a.Wp,
                            a.h2 ? a.spec_exp + (a.feat_w ? 0 : 4) : -1);
-        const int waves = CMX_WAVES_DFT;
+        const bool dsb = a.bf16_io && a.spec_bf16;
+        const int waves = dsb ? CMX_WAVES_DFT_SB : CMX_WAVES_DFT;
         const long G = a.ncell / a.Wp;
         long grid = rpb_num_cus();
         if (grid > (G + waves - 1) / waves) grid = (G + waves - 1) / waves;
-        const size_t lds = cmx_lds(a.Wp, waves, true);
+        const size_t lds = cmx_lds(a.Wp, waves, true, false, dsb);
         if (a.bf16_io && a.spec_bf16) {
             (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((cmx_kernel<0, true, false, true, false, true>), dim3((unsigned)grid), dim3(waves * 64), lds, st, a);

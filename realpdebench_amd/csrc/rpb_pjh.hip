@@ -149,8 +149,12 @@ struct PjhFwdArgs {
 };
 
 // DOT: fc2 outputs padded to 2 or 4 (DO = 1 .. DOT of them are real; the others carry zero weights and are not stored)
-template <int DOT, bool H2 = false>
+// BFIN: the activations are STORED as bf16 (BASELINE.json configs[4]; `s` is then a bf16 [cells][64] tensor): a lane's 16 B load is its
+//       whole A operand of a K-step (one exact plane: no mean subtraction -- the caller passes plain activations --, no split), and it meets
+//       RPB_BF16_CONST_PLANES planes of fc1.weight: 8 (12) MFMAs per K-step instead of 24.
+template <int DOT, bool H2 = false, bool BFIN = false>
 __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p) {
+    static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
     constexpr int NV = 16 * DOT;                         // fc2 partials per lane: [register row r][output j] = element DOT r + j
     constexpr int EPL = NV / 32;                         // elements a lane owns after the butterfly: element EPL n + k
     extern __shared__ u32x4 lds4[];
@@ -225,6 +229,11 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
     u32x4 xa[8];                                         // A layout: cell 32 q + n, channels 16 ks + 8 hg + 4 half ..   [2 ks + half]
     auto issue_pair = [&](int pl, int q, int ks) {       // (past the wave's last tile the descriptor is empty: loads return 0, no branches)
         const bool ok = pl >= 0;
+        if (BFIN) {                                      // 128 B cell rows; channels 16 ks + 8 hg .. + 7 = 16 B
+            const rsrc_t rb = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * 32, ok ? (unsigned)cm.W * 128u : 0u);
+            xa[2 * ks] = ld16(rb, (32 * q + n) * 128 + ks * 32 + hg * 16);
+            return;
+        }
         const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * 64, ok ? (unsigned)cm.W * 256u : 0u);   // cells >= W read as 0
         xa[2 * ks] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32);
         xa[2 * ks + 1] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32 + 16);
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
     // behind the last products of this one)
     bf16x8 BL[4], BM[4], BH[4];
 #define PH_LOADB(DST, KS, PLANE) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) DST[nt_] = __builtin_bit_cast(bf16x8, W1B[(((KS) * 4 + nt_) * 3 + (PLANE)) * 64 + lane]);
-    if (!H2) { PH_LOADB(BL, 0, 2) }
+    if (!H2 && !(BFIN && RPB_BF16_CONST_PLANES <= 2)) { PH_LOADB(BL, 0, 2) }
     PH_LOADB(BM, 0, 1)
     PH_LOADB(BH, 0, 0)
 #ifdef PH_TIMING   /* timing-only build: the wave's shader cycles and 100 MHz ticks over its tile loop land in out[2 slot ..] (tools/dbg/pjh_clock.py) */
@@ -268,6 +277,11 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #endif
             bf16x8 Ah[2], Am[2], Al[2];
             auto prep = [&](int ks) {
+                if (BFIN) {                              // the load IS the operand
+                    Ah[ks & 1] = __builtin_bit_cast(bf16x8, xa[2 * ks]);
+                    issue_pair(pn, qn, ks);
+                    return;
+                }
                 float v[8];
                 const f32x4v x0 = __builtin_bit_cast(f32x4v, xa[2 * ks]), x1 = __builtin_bit_cast(f32x4v, xa[2 * ks + 1]);
 #pragma unroll
@@ -292,6 +306,17 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #define PH_G(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_] = mfma32(AP[ks & 1], BP[nt_], (FIRST) ? f32x16v{} : acc[nt_]);
 #endif
 #define PH_GH(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_] = mfma32h(AP[ks & 1], BP[nt_], (FIRST) ? f32x16v{} : acc[nt_]);
+                if (BFIN) {                     // one stored plane x the planes of the constants, small terms first
+                    if (RPB_BF16_CONST_PLANES > 2) {
+                        PH_G(Ah, BL, ks == 0)
+                        PH_LOADB(BL, kn, 2)
+                    }
+                    PH_G(Ah, BM, ks == 0 && RPB_BF16_CONST_PLANES <= 2)
+                    PH_LOADB(BM, kn, 1)
+                    PH_G(Ah, BH, false)
+                    PH_LOADB(BH, kn, 0)
+                    continue;
+                }
                 if (H2) {                       // slot 1 (the "m" registers) holds the lo plane
                     PH_GH(Ah, BM, ks == 0)
                     PH_LOADB(BM, kn, 1)
@@ -390,11 +415,13 @@ static size_t pjh_lds() { return (size_t)(4 * 4 * 3 * 64) * 16 + (PH_HID + 64) *
 // 1 when this kernel takes the shape: C = 64, at most four fc2 outputs, exact-erf GELU, fp32 storage, no GELU inside the input transform
 bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16) {
     static const bool off = getenv("RPB_HEAD_PJH") && atoi(getenv("RPB_HEAD_PJH")) == 0;
-    return !off && C == 64 && DO >= 1 && DO <= 4 && act == 0 && !a_bf16 && !(xf.mean && xf.gelu);
+    static const bool bf_off = getenv("RPB_HEAD_PJH_BF16") && atoi(getenv("RPB_HEAD_PJH_BF16")) == 0;
+    if (a_bf16 && (bf_off || xf.mean)) return false;     // bf16 storage: plain activations only (the eval cell_mix applied the BatchNorm)
+    return !off && C == 64 && DO >= 1 && DO <= 4 && act == 0 && !(xf.mean && xf.gelu);
 }
 
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
-                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2) {
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2, bool a_bf16) {
     PjhFwdArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -407,7 +434,14 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
     const long need = (GL + PH_WAVES - 1) / PH_WAVES;
     if (grid > need) grid = need;
     const size_t lds = pjh_lds();
-    if (f16x2 && DO <= 2) {
+    if (a_bf16 && f16x2) RPB_FAIL(RPB_ERR_UNSUPPORTED, "proj_fwd (pjh): f16x2 is an fp32-storage arithmetic");
+    if (a_bf16 && DO <= 2) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    } else if (a_bf16) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((pjh_fwd_kernel<4, false, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
+    } else if (f16x2 && DO <= 2) {
         (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((pjh_fwd_kernel<2, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
     } else if (f16x2) {

@@ -947,7 +947,7 @@ int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* 
                         float* out, float* gu, float* part, long part_rows, int DO, int T, int H, int W, int Tp, int Hp, int Wp, long ncrop,
                         const XForm& xf, int act, hipStream_t st, bool a_bf16) {
     if (!bwd && rpb_pjh_supported(64, DO, act, xf, a_bf16))                       // the evaluation forward, third organisation (csrc/rpb_pjh.hip)
-        return rpb_pjh_launch(s, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, xf, st);
+        return rpb_pjh_launch(s, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, xf, st, false, a_bf16);
     PjhArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.gout = gout; p.out = out; p.gu = gu; p.part = part;
     p.B = (int)(ncrop / ((long)T * H * W)); p.DO = DO; p.act = act;
