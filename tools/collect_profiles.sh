@@ -13,7 +13,7 @@ DB=$(find /tmp/prof_$TAG -name "*_results.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/${TAG}_train_step_kernel_stats.txt
 tools/pmc_run.sh $TAG python tools/kbench.py cell_mix proj bwd_row axis > gpurun_out/${TAG}_pmc.log 2>&1
 tools/pmc_run2.sh ${TAG}b python tools/kbench.py proj bwd_row > gpurun_out/${TAG}_pmc2.log 2>&1
-(echo "## eval forward, headline shape B=32"; python tools/fwd_probe.py 32; echo; echo "## eval forward, combustion volume B=16 fp32 storage"; python tools/fwd_probe.py 16 comb;
+(echo "## eval forward, headline shape B=32"; python tools/fwd_probe.py 32; echo; echo "## eval forward, headline shape B=32, OPT-IN f16x2 arithmetic"; RPB_ARITH=f16x2 python tools/fwd_probe.py 32; echo; echo "## eval forward, combustion volume B=16 fp32 storage"; python tools/fwd_probe.py 16 comb;
  echo; echo "## eval forward, combustion volume B=16 bf16 storage"; python tools/fwd_probe.py 16 comb_bf16;
  echo; echo "## hipGraph replay vs eager launches"; for w in headline comb comb_bf16; do python tools/graph_probe.py $w; done) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_rollout_kernel_table.txt
 ./tools/ubench/stream_pat > gpurun_out/${TAG}_ubench_stream_pat.txt 2>&1
