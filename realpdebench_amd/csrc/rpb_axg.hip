@@ -79,8 +79,13 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 // MT = 16-row output tiles per pass (the accumulators of a pass: MT x 4 column tiles x 4 registers)
 // BFIN: the input is STORED as bf16 (in_g / in_k in bf16 elements; BASELINE.json configs[4]): the B operand is one exact bf16
 //       plane, so a (row tile, column tile) costs 3 products instead of 6; a lane's 8 loads are 8 B each (4 columns).
-template <int MT, bool XF, bool BFIN = false>
-__global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
+// NW: waves per workgroup (= per CU).  The bf16-input instance (156 registers) at three waves per SIMD measured SLOWER (0.144 -> 0.162 ms,
+//     combustion forward; the same change gained 11 % in rpb_cmx.hip's fused launch, profiles/r06b_ab5_waves_dft_sb.txt): 8 stays
+#ifndef AXG_WAVES_BFIN
+#define AXG_WAVES_BFIN 8
+#endif
+template <int MT, bool XF, bool BFIN = false, int NW = AXG_WAVES>
+__global__ __launch_bounds__(NW * 64) void axg_kernel(AxgArgs a) {
     static_assert(!(BFIN && XF), "bf16 storage holds materialised activations: no lazy transform");
     extern __shared__ u32x4 Ml[];            // [ks][plane 3][mt][lane 64]   M in A-operand order
     const int tid = threadIdx.x;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const bool xgelu = a.xf.gelu != 0;
     const int strips = a.N >> 6;
     const long items = (long)a.G * strips;
-    const long nslots = (long)gridDim.x * AXG_WAVES;
+    const long nslots = (long)gridDim.x * NW;
     const int passes = (mtiles + MT - 1) / MT;
     constexpr int EB = BFIN ? 2 : 4;                                         // bytes per input element
     const unsigned in_bytes = (unsigned)(((long)(a.k_valid - 1) * a.in_k + 64) * EB);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(AXG_WAVES * 64) void axg_kernel(AxgArgs a) {
     const int ooff = (4 * kg) * (int)a.out_o * 4 + c16 * 16;                 // row 4 mg, columns 4 c ..
     const int istep = (int)a.in_k * EB;                                      // bytes between consecutive k rows
 
-    for (long it = (long)blockIdx.x * AXG_WAVES + wave; it < items; it += nslots) {
+    for (long it = (long)blockIdx.x * NW + wave; it < items; it += nslots) {
         const long g = it / strips;
         const int n0 = (int)(it - g * strips) << 6;
         const rsrc_t ri = make_rsrc(reinterpret_cast<const char*>(a.in) + (g * a.in_g + n0) * EB, in_bytes);
@@ -428,8 +433,11 @@ int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
         RPB_FAIL(RPB_ERR_UNSUPPORTED, "axg: bf16 output is built for the short-K stages with many output rows (the inverse H stage)");
     if (a.in_bf16) {
         if (xf || mtiles > 4) RPB_FAIL(RPB_ERR_UNSUPPORTED, "axg: bf16 input supports plain stages with O <= 64 (the forward W stage)");
-        (void)hipFuncSetAttribute((const void*)axg_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((axg_kernel<4, false, true>), dim3((unsigned)grid), dim3(AXG_WAVES * 64), lds, st, a);
+        long gridb = rpb_num_cus();
+        const long needb = (items + AXG_WAVES_BFIN - 1) / AXG_WAVES_BFIN;
+        if (gridb > needb) gridb = needb;
+        (void)hipFuncSetAttribute((const void*)axg_kernel<4, false, true, AXG_WAVES_BFIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((axg_kernel<4, false, true, AXG_WAVES_BFIN>), dim3((unsigned)gridb), dim3(AXG_WAVES_BFIN * 64), lds, st, a);
         RPB_CHECK_LAUNCH("axis_gemm(bf16x3, bf16 input)");
     }
 #define RPB_AXG(MT_, XF_)                                                                                                  \

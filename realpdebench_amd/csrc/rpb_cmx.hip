@@ -173,6 +173,10 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 #define CMX_WAVES_DFT_SB 12
 #endif
 #define CMX_WAVES_DFTX(SB_) ((SB_) ? CMX_WAVES_DFT_SB : CMX_WAVES_DFT)
+#ifndef CMX_WAVES_SB
+#define CMX_WAVES_SB 8           /* the plain / crop-only launch on bf16 activations + spectra (128 registers): 12 waves measured SLOWER (0.285 -> 0.315 ms) */
+#endif
+#define CMX_WAVES_OFX(STATS_, SB_) ((SB_) ? CMX_WAVES_SB : CMX_WAVES_OF(STATS_))
 #define CMX_WG_PAIRS 4
 // SB:   with BF -- the SPECTRA are stored as bf16 too: the z2 rows this launch reads (written by rpb_axis_gemm_bf16out) and the Y1 rows
 //       the fused W stage writes (read by rpb_axis_gemm_bf16in).  A z2 row is then exactly one bf16 plane: no split, three products.
@@ -210,7 +214,7 @@ __device__ __forceinline__ f32x4v mfma16h(bf16x8 a, bf16x8 b, f32x4v c) {
 //       Scalings (exact: powers of two): conv weights and bias x 2^H2W, GW x 2^(spec_exp + H2W), z2 x 2^-spec_exp, and 2^-H2W rides in the
 //       output transform's scale.
 template <int STATS, bool BF = false, bool FEAT = false, bool DFT = false, bool WG = false, bool SB = false, int C2 = 0, bool H2 = false>
-__global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OF(STATS)))) * 64) void cmx_kernel(CmxArgs a) {
+__global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OFX(STATS, SB)))) * 64) void cmx_kernel(CmxArgs a) {
     static_assert(!H2 || (STATS == 0 && !BF && !WG && !SB && !C2), "f16x2: the fp32-storage eval launches at C = 64");
     constexpr bool H2X = H2 && !FEAT;                    // channel mixing on fp16 planes
     constexpr int H2W = H2X ? 4 : 0;                     // log2 of the scale the accumulators carry
@@ -227,8 +231,8 @@ __global__ __launch_bounds__((C2 ? C2 : (WG ? 2 * CMX_WG_PAIRS : (DFT ? CMX_WAVE
     const int hsel = C2 ? (int)(blockIdx.x & 1) : 0;     // C = 128: which 64-channel half of the output this workgroup produces
     const int bx = C2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, gx = C2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int FW = a.feat_w;
-    constexpr int CMX_WAVES = C2 ? C2 : (WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OF(STATS)));     // line-walking ("mix") waves
-    constexpr int ZST = (DFT && SB) ? 4 : 12;            // u32x4 rows of a wave's z2 slice (bf16 spectra: one plane)
+    constexpr int CMX_WAVES = C2 ? C2 : (WG ? CMX_WG_PAIRS : (DFT ? CMX_WAVES_DFTX(SB) : CMX_WAVES_OFX(STATS, SB)));     // line-walking ("mix") waves
+    constexpr int ZST = SB ? 4 : 12;                     // u32x4 rows of a wave's z2 slice (bf16 spectra: one plane)
     extern __shared__ u32x4 lds4[];
     const int Wp = a.Wp, K2 = a.K2;
     u32x4* Bw = lds4;                        // [ks 2][plane 3][t 4][lane 64]   conv weights, B-operand order
@@ -1030,7 +1034,8 @@ extern "C" int rpb_cmx_debug_wave_times(void* buf) {
     return 0;
 }
 
-static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false, bool dft_sb = false) {
+static size_t cmx_lds(int Wp, int waves, bool dft = false, bool wg = false, bool dft_sb = false, bool sb = false) {
+    if (sb) return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 4 * 64) * 16 + 3 * 64 * 4 + 16;      // bf16 spectra without the fused stage: one-plane z2 slices
     if (dft_sb) return (size_t)(24 * 64 + waves * 4 * 64) * 16 + 3 * 64 * 4 + (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 + 16;
     if (wg) return (size_t)(24 * 64 + 3 * Wp * 4 + waves * 12 * 64) * 16 + 3 * 64 * 4 + (size_t)CMX_WG_PAIRS * 8 * 64 * 16 + 2 * CMX_WG_PAIRS * 4;
     return (size_t)(24 * 64 + (dft ? 0 : 3 * Wp * 4) + waves * 12 * 64) * 16 + 3 * 64 * 4 + (dft ? (size_t)((Wp + 31) / 32) * 3 * 2 * 64 * 16 : 0) + 16;
@@ -1205,8 +1210,13 @@ int rpb_cmx_launch(const CmxArgs& a_in, int stats, hipStream_t st) {
     if (a.bf16_io) {
         if (stats != 0) RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx: bf16 activation storage is an eval / rollout path (no statistics)");
         if (a.spec_bf16) {
-            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((cmx_kernel<0, true, false, false, false, true>), dim3(grid), dim3(waves * 64), lds, st, a);
+            const int wsb = CMX_WAVES_SB;
+            const long Gl = a.crop_T > 0 ? (a.ncell / ((long)a.Wp * a.Hp * a.Tp)) * a.crop_T * a.crop_H : a.ncell / a.Wp;
+            long gsb = rpb_num_cus();
+            if (gsb > (Gl + wsb - 1) / wsb) gsb = (Gl + wsb - 1) / wsb;
+            const size_t ldsb = cmx_lds(a.Wp, wsb, false, false, false, true);
+            (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipLaunchKernelGGL((cmx_kernel<0, true, false, false, false, true>), dim3((unsigned)gsb), dim3(wsb * 64), ldsb, st, a);
             RPB_CHECK_LAUNCH("cell_mix(bf16x3, bf16 storage and spectra)");
         }
         (void)hipFuncSetAttribute((const void*)cmx_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
