@@ -33,7 +33,8 @@ extern "C" {
  *   1  rounds 1-3
  *   2  round 4: rpb_cell_mix_bf16, rpb_cell_mix_eval_dft_bf16 and rpb_cell_mix_eval_crop gained `int spectra_bf16` before `stream`;
  *      round 5: rpb_dp_reduce_scatter_enqueue / rpb_dp_allgather_enqueue / rpb_dp_mark / rpb_dp_wait_mark / rpb_dp_set_model /
- *      rpb_adam_step_ranges added (additions only) */
+ *      rpb_adam_step_ranges added (additions only);
+ *      round 6: rpb_dp_p2p_*, rpb_cell_mix_eval_dft_f16x2, rpb_cell_mix_eval_crop_f16x2, rpb_proj_fwd_f16x2 added (additions only) */
 #define RPB_ABI_VERSION 2
 const char* rpb_last_error(void);
 int rpb_abi_version(void);
