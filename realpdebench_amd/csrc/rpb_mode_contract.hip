@@ -522,13 +522,14 @@ static int mode_persist_wgs(int mode) {
     static const int f = getenv("RPB_MODE_PERSIST_WGS") ? atoi(getenv("RPB_MODE_PERSIST_WGS")) : 0;
     return f > 0 ? f : (mode == 2 ? 1 : 2);
 }
-// Measured (B = 32, profiles/r06b_mode_persist.txt): with the layer's 100 MB of weights in the Infinity Cache (rollout, micro-benchmark) the
-// persistent instances run 0.054 -> 0.048 ms (fwd) and 0.050 -> 0.044 ms (dgrad); inside the training step, where the forward reads its weights
-// COLD, the persistent forward takes 0.124 ms against 0.095 (two workgroups per CU with one tile in flight each keep fewer bytes outstanding than
-// three one-shot workgroups that the dispatcher staggers), dgrad 0.053 -> 0.047.  So: dgrad persistent, the forward only on request
-// (RPB_MODE_PERSIST_FWD=1: a rollout-only process gains 0.04 ms per forward), wgrad never (288 registers: one workgroup per CU, 0.044 -> 0.046).
+// Measured (B = 32, profiles/r06b_mode_persist.txt, tools/mode_cold_probe.py): the persistent instances run 0.054 -> 0.048 ms (fwd) and
+// 0.050 -> 0.044 ms (dgrad) with warm weights and 0.055 -> 0.047 / 0.055 -> 0.049 with COLD ones (six 100 MB weight buffers cycled through the
+// 256 MB Infinity Cache).  (A first reading of "0.124 ms persistent against 0.095 one-shot inside the step" came from HIP events around 50 us
+// launches: that is the host's launch gap, not device time -- rocprofv3's kernel trace of the step gives 57 us one-shot, 45 us persistent.)
+// So: forward and dgrad persistent (RPB_MODE_PERSIST_FWD=0 / RPB_MODE_PERSIST=0: one workgroup per mode), wgrad never (288 registers: one
+// workgroup per CU, 0.044 -> 0.046).
 static bool mode_persist_fwd() {
-    static const bool on = getenv("RPB_MODE_PERSIST_FWD") && atoi(getenv("RPB_MODE_PERSIST_FWD")) == 1;
+    static const bool on = !(getenv("RPB_MODE_PERSIST_FWD") && atoi(getenv("RPB_MODE_PERSIST_FWD")) == 0);
     return on;
 }
 static bool mode_persist_wgrad() {
@@ -774,7 +775,7 @@ static int mc_check(const void* a, const void* b, const void* c, int B, int M, i
 extern "C" int rpb_mode_contract_fwd(const float* X, const float* W, float* Y, int B, int M, int C, void* stream) {
     if (int e = mc_check(X, W, Y, B, M, C)) return e;
     if (mode_bf16_on(C)) {
-        if (B <= 32 && mode_persist_on() && mode_persist_fwd()) {        // warm weights only (rollout): see mode_persist_fwd
+        if (B <= 32 && mode_persist_on() && mode_persist_fwd()) {
             const int grid = M < mode_persist_wgs(0) * rpb_num_cus() ? M : mode_persist_wgs(0) * rpb_num_cus();
             hipLaunchKernelGGL((mode_bf16_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, W, (const float*)nullptr, Y, B, M, 0);
         } else {
