@@ -81,6 +81,10 @@ __device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) {
 //       plane, so a (row tile, column tile) costs 3 products instead of 6; a lane's 8 loads are 8 B each (4 columns).
 // NW: waves per workgroup (= per CU).  The bf16-input instance (156 registers) at three waves per SIMD measured SLOWER (0.144 -> 0.162 ms,
 //     combustion forward; the same change gained 11 % in rpb_cmx.hip's fused launch, profiles/r06b_ab5_waves_dft_sb.txt): 8 stays
+#ifndef AXG_WAVES_XF
+#define AXG_WAVES_XF 8      /* 12 (three waves per SIMD at 165 registers): the micro-benchmark gains 3-6 % (1.19-1.23 -> 1.16 ms), the train step loses
+                               0.1 ms (34.24 / 34.26 -> 34.34 / 34.40 ms, A/B twice, tools/r6b_ab7.sh): 8 stays */
+#endif
 #ifndef AXG_WAVES_BFIN
 #define AXG_WAVES_BFIN 8
 #endif
@@ -454,7 +458,14 @@ int rpb_axg_launch(const AxgArgs& a, hipStream_t st) {
     if (mtiles <= 1) {
         if (xf) RPB_AXG(1, true) else RPB_AXG(1, false)
     } else if (mtiles == 2) {
-        if (xf) RPB_AXG(2, true) else RPB_AXG(2, false)
+        if (xf) {       // the training forward's W stage with the lazy BatchNorm + GELU (165 registers): AXG_WAVES_XF waves per CU
+            long gridx = rpb_num_cus();
+            const long needx = (items + AXG_WAVES_XF - 1) / AXG_WAVES_XF;
+            if (gridx > needx) gridx = needx;
+            (void)hipFuncSetAttribute((const void*)axg_kernel<2, true, false, AXG_WAVES_XF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((axg_kernel<2, true, false, AXG_WAVES_XF>), dim3((unsigned)gridx), dim3(AXG_WAVES_XF * 64), lds, st, a);
+            RPB_CHECK_LAUNCH("axis_gemm(bf16x3, lazy transform)");
+        } else RPB_AXG(2, false)
     } else if (mtiles == 3) {
         if (xf) RPB_AXG(3, true) else RPB_AXG(3, false)
     } else {
