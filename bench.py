@@ -996,6 +996,66 @@ def main():
         finally:
             model.set_arith("f32")
 
+    # ---- the STRONG parity guard (the loss equality above is a weak discriminator -- with N(0,1) targets an error that is
+    #      uncorrelated with the target moves the loss at second order): one fused Trainer.step at the headline shape, B = 2, through the same
+    #      kernels, against what the IMPORTED reference produced for the same seeded weights and batch -- the Frobenius norm and 256 sampled
+    #      entries of EVERY parameter gradient (tests/golden/fno3d_headline.npz, b2/*; tests/test_gpu_headline.py holds the same check)
+    grad_check = None
+    if world == 1 and rank == 0 and not a.only_headline:
+        try:
+            import numpy as np
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            import headline_common as HC
+            gz = np.load(os.path.join(ROOT, "tests", "golden", "fno3d_headline.npz"))
+            sd2 = HC.headline_state_dict()
+            x2, y2 = HC.headline_batch(2)
+            same = (np.allclose(HC.checksum(x2), gz["b2/x_checksum"], rtol=1e-12, atol=1e-9)
+                    and np.allclose(HC.checksum(y2), gz["b2/y_checksum"], rtol=1e-12, atol=1e-9)
+                    and np.allclose(np.array([HC.checksum(v) for k, v in sorted(sd2.items()) if v.dtype != torch.int64]), gz["b2/w_checksum"],
+                                    rtol=1e-12, atol=1e-9))
+            if not same:
+                grad_check = {"skipped": "the seeded streams differ on this host: fixture not applicable"}
+            else:
+                m2 = FNO3d(*HC.MODES, HC.N_LAYERS, HC.WIDTH, HC.SHAPE, HC.SHAPE)
+                m2.load_state_dict(sd2)
+                m2 = m2.to(dev)
+                tr2 = Trainer(m2, lr=0.0, num_update=4000)
+                l2 = float(tr2.step(x2.to(dev), y2.to(dev)))
+                grads = m2.grads_as_state_dict(tr2.grad)
+                names = [k[len("b2/gnorm/"):] for k in gz.files if k.startswith("b2/gnorm/")]
+                worst_n = worst_s = 0.0
+                worst_n_name = worst_s_name = ""
+                for k in names:
+                    g = grads[k].cpu()
+                    g = torch.view_as_real(g) if g.is_complex() else g
+                    if k.startswith("convs.") and k.endswith(".bias"):       # true gradient 0 (BatchNorm cancels it): noise on both sides
+                        continue
+                    gn = float(gz[f"b2/gnorm/{k}"])
+                    en = abs(float(g.double().norm()) - gn) / gn
+                    samp = g.flatten()[HC.sample_index(g.numel(), k)].double()
+                    rs = torch.from_numpy(gz[f"b2/gsamp/{k}"]).double()
+                    es = float(torch.linalg.vector_norm(samp - rs) / torch.linalg.vector_norm(rs))
+                    if en > worst_n:
+                        worst_n, worst_n_name = en, k
+                    if es > worst_s:
+                        worst_s, worst_s_name = es, k
+                lref = float(gz["b2/loss"])
+                grad_check = {"tensors": len(names), "max_rel_err_of_gradient_norms": worst_n, "max_rel_l2_of_256_samples": worst_s,
+                              "worst_norm_tensor": worst_n_name, "worst_samples_tensor": worst_s_name,
+                              "loss_rel_err": abs(l2 - lref) / abs(lref), "tol_norms": 5e-5, "tol_samples": 2e-4,
+                              "fatal_above": "10 x the tolerances (the test suite holds the tolerances themselves; fp32 CPU autograd of the "
+                                             "reference carries ~1e-5 on the smallest gradients)",
+                              "source": "tests/golden/fno3d_headline.npz b2/* (imported reference, headline shape, B = 2, same seeds)"}
+                del m2, tr2, grads
+                torch.cuda.empty_cache()
+                grad_check["within_tolerance"] = bool(worst_n < 5e-5 and worst_s < 2e-4 and grad_check["loss_rel_err"] < 1e-5)
+                if not (worst_n < 5e-4 and worst_s < 2e-3 and grad_check["loss_rel_err"] < 1e-4):
+                    raise SystemExit(f"bench.py: gradient check against the reference fixture failed ({grad_check}); refusing to report a number")
+        except SystemExit:
+            raise
+        except Exception as e:                                  # a missing fixture must not cost the bench line
+            grad_check = {"error": repr(e)}
+
     extra = {}
     proxy = None
     if world == 1:
@@ -1093,6 +1153,7 @@ def main():
             "loss": float(loss),
             "first_step_loss": first_loss_global,
             "loss_check": loss_check,
+            "grad_check": grad_check,
         }
         if ceiling:
             # which mix each cell_mix variant streams: forward = 1 read + 1 write (+ the small z2 rows), backward with the BatchNorm
@@ -1151,6 +1212,9 @@ def main():
             rf["rollout_f16x2_optin_rel_l2_vs_default"] = rollout_h2["rel_l2_vs_default_step1"]
         if loss_check:
             rf["loss_check_rel_err"] = loss_check.get("rel_err")
+        if grad_check and "max_rel_err_of_gradient_norms" in grad_check:
+            rf["grad_check_max_rel_err_norms"] = grad_check["max_rel_err_of_gradient_norms"]
+            rf["grad_check_max_rel_l2_samples"] = grad_check["max_rel_l2_of_256_samples"]
         if dp_info:
             line["dp"] = dp_info
         if proxy:
