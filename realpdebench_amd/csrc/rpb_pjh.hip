@@ -152,26 +152,30 @@ struct PjhFwdArgs {
 // BFIN: the activations are STORED as bf16 (BASELINE.json configs[4]; `s` is then a bf16 [cells][64] tensor): a lane's 16 B load is its
 //       whole A operand of a K-step (one exact plane: no mean subtraction -- the caller passes plain activations --, no split), and it meets
 //       RPB_BF16_CONST_PLANES planes of fc1.weight: 8 (12) MFMAs per K-step instead of 24.
-template <int DOT, bool H2 = false, bool BFIN = false>
-__global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p) {
+// CW:   input channels, 64 or 128 (configs/fsi/fno.yaml; round 6b).  At 128 the fc1 planes are 96 KB of LDS: ONE workgroup of four waves per CU
+//       (one wave per SIMD, the whole register file: 8 K-steps of inputs in flight), fp32 storage and the default arithmetic only.
+template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64>
+__global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kernel(PjhFwdArgs p) {
     static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
+    static_assert(CW == 64 || (CW == 128 && !H2 && !BFIN), "C = 128: fp32 storage, default arithmetic");
+    constexpr int KS = CW / 16;                          // K-steps of contraction 1
     constexpr int NV = 16 * DOT;                         // fc2 partials per lane: [register row r][output j] = element DOT r + j
     constexpr int EPL = NV / 32;                         // elements a lane owns after the butterfly: element EPL n + k
     extern __shared__ u32x4 lds4[];
     u32x4* W1B = lds4;                                   // [ks 4][nt 4][plane 3][lane]   B of u:   W1'[32 nt + n][16 ks + 8 kg + e]
-    float* b1l = reinterpret_cast<float*>(W1B + 4 * 4 * 3 * 64);          // [128]  b1' = b1 + W1 beta
-    float* meanl = b1l + PH_HID;                         // [64]   BatchNorm mean
+    float* b1l = reinterpret_cast<float*>(W1B + KS * 4 * 3 * 64);         // [128]  b1' = b1 + W1 beta
+    float* meanl = b1l + PH_HID;                         // [CW]   BatchNorm mean
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hg = lane >> 5;
     const bool has_xf = p.xf.mean != nullptr;
-    for (int idx = tid; idx < 4 * 4 * 64; idx += blockDim.x) {
+    for (int idx = tid; idx < KS * 4 * 64; idx += blockDim.x) {
         const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 16 * ks + 8 * (l >> 5) + e;
-            const float w = p.w1[(32 * nt + (l & 31)) * 64 + c];
+            const float w = p.w1[(32 * nt + (l & 31)) * CW + c];
             v[e] = has_xf ? w * (p.xf.gamma[c] * p.xf.invstd[c]) : w;
             if (H2) v[e] *= (float)(1 << PH_H2W);
         }
@@ -189,10 +193,10 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
     for (int h = tid; h < PH_HID; h += blockDim.x) {
         float a = p.b1[h];
         if (has_xf)
-            for (int c = 0; c < 64; ++c) a = __builtin_fmaf(p.w1[h * 64 + c], p.xf.beta[c], a);
+            for (int c = 0; c < CW; ++c) a = __builtin_fmaf(p.w1[h * CW + c], p.xf.beta[c], a);
         b1l[h] = a;
     }
-    if (tid < 64) meanl[tid] = has_xf ? p.xf.mean[tid] : 0.f;
+    if (tid < CW) meanl[tid] = has_xf ? p.xf.mean[tid] : 0.f;
     __syncthreads();
 
     const CropMap cm = p.cm;
@@ -211,9 +215,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #pragma unroll
         for (int j = 0; j < DOT; ++j) w2r[j][nt] = j < DO ? p.w2[j * PH_HID + 32 * nt + n] : 0.f;
     }
-    float meanr[32];                                     // BatchNorm mean of the lane's channels 16 ks + 8 hg + e  [8 ks + e]
+    float meanr[8 * KS];                                 // BatchNorm mean of the lane's channels 16 ks + 8 hg + e  [8 ks + e]
 #pragma unroll
-    for (int i = 0; i < 32; ++i) meanr[i] = meanl[16 * (i >> 3) + 8 * hg + (i & 7)];
+    for (int i = 0; i < 8 * KS; ++i) meanr[i] = meanl[16 * (i >> 3) + 8 * hg + (i & 7)];
     // the lane's own output elements after the cross-lane reduction: EPL n + k = DOT ry + j -> register row ry = cell 8 (ry >> 2) + 4 hg + (ry & 3)
     const int ry = (EPL * n) / DOT, jy = (EPL * n) % DOT;
     const int celly = 8 * (ry >> 2) + 4 * hg + (ry & 3);
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
         const unsigned h = (unsigned)gl % (unsigned)cm.H, r2 = (unsigned)gl / (unsigned)cm.H;
         return (int)(((r2 / (unsigned)cm.T) * cm.Tp + r2 % (unsigned)cm.T) * cm.Hp + h);
     };
-    u32x4 xa[8];                                         // A layout: cell 32 q + n, channels 16 ks + 8 hg + 4 half ..   [2 ks + half]
+    u32x4 xa[2 * KS];                                    // A layout: cell 32 q + n, channels 16 ks + 8 hg + 4 half ..   [2 ks + half]
     auto issue_pair = [&](int pl, int q, int ks) {       // (past the wave's last tile the descriptor is empty: loads return 0, no branches)
         const bool ok = pl >= 0;
         if (BFIN) {                                      // 128 B cell rows; channels 16 ks + 8 hg .. + 7 = 16 B
@@ -234,14 +238,14 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
             xa[2 * ks] = ld16(rb, (32 * q + n) * 128 + ks * 32 + hg * 16);
             return;
         }
-        const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * 64, ok ? (unsigned)cm.W * 256u : 0u);   // cells >= W read as 0
-        xa[2 * ks] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32);
-        xa[2 * ks + 1] = ld16(rx, (32 * q + n) * 256 + ks * 64 + hg * 32 + 16);
+        const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * CW, ok ? (unsigned)cm.W * (CW * 4u) : 0u);   // cells >= W read as 0
+        xa[2 * ks] = ld16(rx, (32 * q + n) * (CW * 4) + ks * 64 + hg * 32);
+        xa[2 * ks + 1] = ld16(rx, (32 * q + n) * (CW * 4) + ks * 64 + hg * 32 + 16);
     };
     {
         const int pl0 = slot < GL ? line_of((int)slot) : -1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) issue_pair(pl0, 0, ks);
+        for (int ks = 0; ks < KS; ++ks) issue_pair(pl0, 0, ks);
     }
     // weight planes of a K-step: one buffer per plane kind, refilled behind its last use (those of K-step 0 are loaded for the NEXT tile
     // behind the last products of this one)
@@ -296,9 +300,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
             prep(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) prep(ks + 1);
-                const int kn = ks < 3 ? ks + 1 : 0;
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < KS - 1) prep(ks + 1);
+                const int kn = ks < KS - 1 ? ks + 1 : 0;
                 // small terms first within a plane kind; BL, then BM, then BH
 #ifdef PH_NOMFMA   /* timing-only build: the products replaced by one vector instruction per group */
 #define PH_G(AP, BP, FIRST) _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_) acc[nt_][0] = ((FIRST) ? 0.f : acc[nt_][0]) + __builtin_bit_cast(float, __builtin_bit_cast(u32x4, AP[ks & 1])[0] ^ __builtin_bit_cast(u32x4, BP[nt_])[1]);
@@ -327,9 +331,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #pragma unroll
                     for (int i = 0; i < 12; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
+                        if (ks < KS - 1) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
                         if (i >= 4 && i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (ks < 3 && (i == 4 || i == 8)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (ks < KS - 1 && (i == 4 || i == 8)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -353,9 +357,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
+                    if (ks < KS - 1) __builtin_amdgcn_sched_group_barrier(0x002, PH_PIPE, 0);
                     if ((i >= 4 && i < 8) || (i >= 12 && i < 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (ks < 3 && (i == 8 || i == 16)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (ks < KS - 1 && (i == 8 || i == 16)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -410,18 +414,20 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pjh_fwd_kernel(PjhFwdArgs p)
 #undef PH_LOADB
 }
 
-static size_t pjh_lds() { return (size_t)(4 * 4 * 3 * 64) * 16 + (PH_HID + 64) * 4; }
+static size_t pjh_lds(int CW = 64) { return (size_t)((CW / 16) * 4 * 3 * 64) * 16 + (PH_HID + CW) * 4; }
 
 // 1 when this kernel takes the shape: C = 64, at most four fc2 outputs, exact-erf GELU, fp32 storage, no GELU inside the input transform
 bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16) {
     static const bool off = getenv("RPB_HEAD_PJH") && atoi(getenv("RPB_HEAD_PJH")) == 0;
     static const bool bf_off = getenv("RPB_HEAD_PJH_BF16") && atoi(getenv("RPB_HEAD_PJH_BF16")) == 0;
     if (a_bf16 && (bf_off || xf.mean)) return false;     // bf16 storage: plain activations only (the eval cell_mix applied the BatchNorm)
+    static const bool c128_off = getenv("RPB_HEAD_PJH_128") && atoi(getenv("RPB_HEAD_PJH_128")) == 0;
+    if (C == 128) return !off && !c128_off && !a_bf16 && DO >= 1 && DO <= 4 && act == 0 && !(xf.mean && xf.gelu);
     return !off && C == 64 && DO >= 1 && DO <= 4 && act == 0 && !(xf.mean && xf.gelu);
 }
 
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
-                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2, bool a_bf16) {
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2, bool a_bf16, int C) {
     PjhFwdArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -433,6 +439,20 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
     long grid = PH_WG_PER_CU * rpb_num_cus();
     const long need = (GL + PH_WAVES - 1) / PH_WAVES;
     if (grid > need) grid = need;
+    if (C == 128) {                                      // one workgroup of four waves per CU (96 KB of fc1 planes)
+        if (a_bf16 || f16x2) RPB_FAIL(RPB_ERR_UNSUPPORTED, "proj_fwd (pjh, C = 128): fp32 storage, default arithmetic");
+        long g128 = rpb_num_cus();
+        if (g128 > need) g128 = need;
+        const size_t lds128 = pjh_lds(128);
+        if (DO <= 2) {
+            (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128>), dim3((int)g128), dim3(PH_WAVES * 64), lds128, st, p);
+        } else {
+            (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128>), dim3((int)g128), dim3(PH_WAVES * 64), lds128, st, p);
+        }
+        RPB_CHECK_LAUNCH("proj_fwd (pjh, C = 128)");
+    }
     const size_t lds = pjh_lds();
     if (a_bf16 && f16x2) RPB_FAIL(RPB_ERR_UNSUPPORTED, "proj_fwd (pjh): f16x2 is an fp32-storage arithmetic");
     if (a_bf16 && DO <= 2) {

@@ -14,4 +14,5 @@ int rpb_pjx_head_launch(bool bwd, const float* s, const float* w1, const float* 
 bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16);
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
                    int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2 = false,    // f16x2: the opt-in two-fp16-plane arithmetic
-                   bool a_bf16 = false);                                  // a_bf16: `s` holds bf16 [cells][64] (bf16 activation storage)
+                   bool a_bf16 = false,                                   // a_bf16: `s` holds bf16 [cells][64] (bf16 activation storage)
+                   int C = 64);                                           // C = 128: the width-128 instance (fp32 storage, default arithmetic)

@@ -375,6 +375,11 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
         return rpb_pjx_head_launch(false, a, w1, b1, w2, b2, nullptr, out, nullptr, nullptr, 0, DO, T, H, W, Tp, Hp, Wp, ncrop, p.xf, act,
                                    (hipStream_t)stream);
     }
+    if (C == 128 && a && w1 && b1 && w2 && b2 && ncrop % ((long)T * H * W) == 0 && rpb_pjh_supported(128, DO, act, p.xf, false))
+        // width 128 (configs/fsi/fno.yaml), at most four outputs, GELU: csrc/rpb_pjh.hip's C = 128 instance (round 6b; the fp32-pipe kernel
+        // below ran it at 0.68 TB/s)
+        return rpb_pjh_launch(a, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, p.xf, (hipStream_t)stream, false,
+                              false, 128);
     return proj_launch(false, p, (hipStream_t)stream);
 }
 

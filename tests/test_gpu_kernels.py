@@ -213,14 +213,15 @@ def test_proj_fwd_bwd(ops, C, DO, W):
     assert rel_l2(s[DO * 128 + 128:], b2.grad) < 5e-6
 
 
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("B,T,H,W,pad,bn,DO", [(2, 3, 6, 40, 2, True, 2), (1, 2, 5, 70, 6, True, 2), (3, 2, 4, 32, 6, False, 2), (2, 2, 3, 5, 2, True, 2),
                                                 (2, 3, 5, 40, 2, True, 3), (1, 2, 5, 70, 6, True, 4), (2, 2, 4, 33, 2, False, 1), (2, 2, 3, 5, 6, True, 3)])
-def test_eval_head_up_to_four_outputs(ops, B, T, H, W, pad, bn, DO):
+def test_eval_head_up_to_four_outputs(ops, B, T, H, W, pad, bn, DO, C):
     """The evaluation forward of the head at <= 4 fc2 outputs (csrc/rpb_pjh.hip: 32-cell tiles, BatchNorm folded into the staged fc1
     planes, bias folded into GELU) against fp64, with and without the lazy BatchNorm of the last layer; partial last tiles, lines
-    shorter than a tile, more lines than waves; RPB_HEAD_PJH=0 (the 16x16x32 kernel) must agree with it."""
+    shorter than a tile, more lines than waves; RPB_HEAD_PJH=0 (the 16x16x32 kernel) must agree with it.  C = 128 (configs/fsi/fno.yaml):
+    the same kernel's width-128 instance (one workgroup per CU, eight K-steps)."""
     torch.manual_seed(B * 100 + W)
-    C = 64
     d = ops.Dims(B, T, H, W, 2, C, pad)
     a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64) * 1.5 + 0.3
     w1 = torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)
