@@ -143,6 +143,9 @@ struct PjhFwdArgs {
     const float* w2;      // fc2.weight [DO][128]
     const float* b2;      // [DO]
     float* out;           // [ncrop][DO]
+    const float* gout;    // BWD: dLoss/dout [ncrop][DO]
+    float* gu;            // BWD: (fc2^T gout) * gelu'(u)  [ncrop][128]
+    float* part;          // BWD: one row per wave [DO*128 (d fc2.weight) | 128 (d fc1.bias) | DO (d fc2.bias)] -- rpb_proj_bwd's format
     int B, DO;
     CropMap cm;
     XForm xf;             // BatchNorm of the last layer (mean == nullptr: plain tensor); gelu must be 0
@@ -154,8 +157,13 @@ struct PjhFwdArgs {
 //       RPB_BF16_CONST_PLANES planes of fc1.weight: 8 (12) MFMAs per K-step instead of 24.
 // CW:   input channels, 64 or 128 (configs/fsi/fno.yaml; round 6b).  At 128 the fc1 planes are 96 KB of LDS: ONE workgroup of four waves per CU
 //       (one wave per SIMD, the whole register file: 8 K-steps of inputs in flight), fp32 storage and the default arithmetic only.
-template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64>
+// BWD:  rpb_proj_bwd's job at C = 128 (round 6b): u is recomputed on the matrix pipe as in the forward, then per lane (hidden unit 32 nt + n, its 16
+//       cells) gu = (fc2^T gout) * gelu'(u) is stored for the data / weight gradient kernels and d fc2.weight, d fc1.bias, d fc2.bias
+//       accumulate in registers (one partial row per wave, the format of csrc/rpb_proj.hip).  gelu / gelu' from one erf + one exponential,
+//       the arithmetic of that kernel.
+template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, bool BWD = false>
 __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kernel(PjhFwdArgs p) {
+    static_assert(!BWD || (CW == 128 && !H2 && !BFIN), "the backward instance serves width 128 (width 64 has the one-launch head)");
     static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
     static_assert(CW == 64 || (CW == 128 && !H2 && !BFIN), "C = 128: fp32 storage, default arithmetic");
     constexpr int KS = CW / 16;                          // K-steps of contraction 1
@@ -225,6 +233,16 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #pragma unroll
     for (int k = 0; k < EPL; ++k) b2y[k] = jy + k < DO ? p.b2[jy + k] : 0.f;
     const bool bit3 = (n >> 3) & 1, bit2 = (n >> 2) & 1, bit1 = (n >> 1) & 1, bit0 = n & 1;
+    float dw2[BWD ? DOT : 1][4], db1a[4], db2a[BWD ? DOT : 1], b1r[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        db1a[nt] = 0.f;
+        b1r[nt] = b1l[32 * nt + n];
+#pragma unroll
+        for (int j = 0; j < (BWD ? DOT : 1); ++j) dw2[j][nt] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < (BWD ? DOT : 1); ++j) db2a[j] = 0.f;
 
     auto line_of = [&](int gl) {                         // cropped line -> padded line (32-bit: B * Tp * Hp lines)
         const unsigned h = (unsigned)gl % (unsigned)cm.H, r2 = (unsigned)gl / (unsigned)cm.H;
@@ -366,6 +384,39 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BWD) {
+                // ---- gu[cell][hid] = (sum_j gout[cell][j] w2[j][hid]) gelu'(u);  d w2, d b1, d b2 (cells >= W: gout reads 0, the store is dropped)
+                const long row0 = gl * cm.W + 32 * q;
+                const rsrc_t gr = make_rsrc(p.gout + row0 * DO, tile_bytes((long)cm.W - 32 * q, 32, DO * 4));
+                const rsrc_t ur = make_rsrc(p.gu + row0 * PH_HID, tile_bytes((long)cm.W - 32 * q, 32, PH_HID * 4));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cell = 8 * (r >> 2) + 4 * hg + (r & 3);
+                    float g[DOT];
+#pragma unroll
+                    for (int j = 0; j < DOT; ++j) {
+                        g[j] = j < DO ? buf_load_f32(gr, (cell * DO + j) * 4, 0) : 0.f;
+                        db2a[j] += g[j];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const float u = acc[nt][r] + b1r[nt];
+                        const float cdf = 0.5f * (1.0f + fast_erf(u * 0.70710678118654752440f));
+                        const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+                        const float v = u * cdf, dd = __builtin_fmaf(u, pdf, cdf);
+                        float gvs = 0.f;
+#pragma unroll
+                        for (int j = 0; j < DOT; ++j) {
+                            gvs = __builtin_fmaf(g[j], w2r[j][nt], gvs);
+                            dw2[j][nt] = __builtin_fmaf(g[j], v, dw2[j][nt]);
+                        }
+                        const float guv = gvs * dd;
+                        buf_store_f32(guv, ur, (cell * PH_HID + 32 * nt + n) * 4, 0);
+                        db1a[nt] += guv;
+                    }
+                }
+                continue;
+            }
             // ---- activation + fc2 partials: the lane's hidden units 32 nt + n, cells = its 16 register rows
             float po[NV];                                // [DOT r + j]
 #pragma unroll
@@ -403,6 +454,26 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
         }
         gl = gnext;
     }
+    if constexpr (BWD) {
+        float* part = p.part + slot * ((long)DO * PH_HID + PH_HID + DO);
+#pragma unroll
+        for (int j = 0; j < DOT; ++j) {
+            if (j < DO) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float v = dw2[j][nt] + __shfl_xor(dw2[j][nt], 32, 64);
+                    if (hg == 0) part[j * PH_HID + 32 * nt + n] = v;
+                }
+                const float b = db2a[j] + __shfl_xor(db2a[j], 32, 64);     // every lane of a half holds the same row sums
+                if (lane == 0) part[DO * PH_HID + PH_HID + j] = b;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float v = db1a[nt] + __shfl_xor(db1a[nt], 32, 64);
+            if (hg == 0) part[DO * PH_HID + 32 * nt + n] = v;
+        }
+    }
 #ifdef PH_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     const long long tc1 = clock64(), tw1 = wall_clock64();
@@ -414,6 +485,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #undef PH_LOADB
 }
 
+int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);
 static size_t pjh_lds(int CW = 64) { return (size_t)((CW / 16) * 4 * 3 * 64) * 16 + (PH_HID + CW) * 4; }
 
 // 1 when this kernel takes the shape: C = 64, at most four fc2 outputs, exact-erf GELU, fp32 storage, no GELU inside the input transform
@@ -475,4 +548,32 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
         hipLaunchKernelGGL(pjh_fwd_kernel<4>, dim3((int)grid), dim3(PH_WAVES * 64), lds, st, p);
     }
     RPB_CHECK_LAUNCH("proj_fwd (pjh)");
+}
+
+// rpb_proj_bwd at C = 128 (configs/fsi/fno.yaml): gu + the fc2 / bias partial rows on this file's matrix-pipe organisation.  part_rows rows of
+// [DO*128 + 128 + DO] floats were allocated by the caller (rpb_proj_slots); rows this launch does not write are zeroed.
+int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st) {
+    PjhFwdArgs p{};
+    p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = nullptr; p.gout = gout; p.gu = gu; p.part = part; p.B = B; p.DO = DO;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    p.xf = xf;
+    const long GL = (long)B * T * H;
+    long grid = rpb_num_cus();
+    const long need = (GL + PH_WAVES - 1) / PH_WAVES;
+    if (grid > need) grid = need;
+    if (grid * PH_WAVES > part_rows) grid = part_rows / PH_WAVES;
+    RPB_REQUIRE(grid >= 1, "proj_bwd (pjh, C = 128): no partial rows");
+    const long row = (long)DO * PH_HID + PH_HID + DO;
+    if (part_rows > grid * PH_WAVES)
+        (void)hipMemsetAsync(part + grid * PH_WAVES * row, 0, (size_t)(part_rows - grid * PH_WAVES) * row * 4, st);
+    const size_t lds128 = pjh_lds(128);
+    if (DO <= 2) {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+    } else {
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+    }
+    RPB_CHECK_LAUNCH("proj_bwd (pjh, C = 128)");
 }

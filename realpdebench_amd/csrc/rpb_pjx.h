@@ -16,3 +16,6 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
                    int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2 = false,    // f16x2: the opt-in two-fp16-plane arithmetic
                    bool a_bf16 = false,                                   // a_bf16: `s` holds bf16 [cells][64] (bf16 activation storage)
                    int C = 64);                                           // C = 128: the width-128 instance (fp32 storage, default arithmetic)
+// ... and rpb_proj_bwd's job at C = 128 (gu + the fc2 / bias partial rows) on the same organisation
+int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);

@@ -11,6 +11,7 @@
 // B=32), produces gu = (fc2^T g) * gelu'(u) for the downstream dgrad / wgrad kernels and accumulates
 // d fc2.weight, d fc2.bias, d fc1.bias in registers.
 #include "rpb_common.h"
+#include <stdlib.h>
 #include "rpb_pjx.h"
 
 #define HID 128
@@ -428,5 +429,9 @@ extern "C" int rpb_proj_bwd(const float* a, const float* w1, const float* b1, co
         return rpb_pjx_head_launch(true, a, w1, b1, w2, b2, gout, nullptr, gu, part, rpb_proj_slots(ncrop, C, DO), DO, T, H, W, Tp, Hp, Wp,
                                    ncrop, p.xf, act, (hipStream_t)stream);
     }
+    if (C == 128 && a && w1 && b1 && w2 && b2 && ncrop % ((long)T * H * W) == 0 && rpb_pjh_supported(128, DO, act, p.xf, false) &&
+        !(getenv("RPB_HEAD_PJH_128_BWD") && atoi(getenv("RPB_HEAD_PJH_128_BWD")) == 0))
+        return rpb_pjh_bwd128_launch(a, w1, b1, w2, b2, gout, gu, part, rpb_proj_slots(ncrop, C, DO), (int)(ncrop / ((long)T * H * W)), DO, T, H, W,
+                                     Tp, Hp, Wp, p.xf, (hipStream_t)stream);
     return proj_launch(true, p, (hipStream_t)stream);
 }

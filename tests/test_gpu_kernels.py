@@ -1030,3 +1030,44 @@ def test_lift_feat_feature_fields(ops, B, T, H, W, Cin, pad):
     ref[:, :T, :H, :W, Cin + 2] = grids[2].view(1, 1, 1, W)
     ref[:, :T, :H, :W, Cin + 3] = 1.0
     assert torch.equal(out.view_as(ref), ref)
+
+
+@pytest.mark.parametrize("B,T,H,W,pad,bn,DO", [(2, 3, 6, 40, 2, True, 2), (1, 2, 5, 70, 6, True, 3), (3, 2, 4, 32, 6, False, 4), (2, 2, 3, 5, 2, True, 1)])
+def test_proj_bwd_width_128_on_the_matrix_pipe(ops, B, T, H, W, pad, bn, DO, monkeypatch):
+    """rpb_proj_bwd at C = 128 (configs/fsi/fno.yaml) runs csrc/rpb_pjh.hip's backward instance: gu = (fc2^T gout) gelu'(fc1 a + b1) and the
+    partial rows of d fc2.weight / d fc1.bias / d fc2.bias, against fp64 and against the fp32-pipe kernel it replaces (RPB_HEAD_PJH_128_BWD=0)."""
+    torch.manual_seed(B * 100 + W + DO)
+    C = 128
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64) * 1.5 + 0.3
+    w1 = torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)
+    b1 = torch.randn(128, dtype=torch.float64)
+    w2 = torch.randn(DO, 128, dtype=torch.float64) / 11
+    b2 = torch.randn(DO, dtype=torch.float64)
+    mean, var = torch.randn(C, dtype=torch.float64) * 0.2 + 0.3, torch.rand(C, dtype=torch.float64) + 0.5
+    gamma, beta = torch.rand(C, dtype=torch.float64) + 0.5, torch.randn(C, dtype=torch.float64) * 0.1
+    invstd = (var + 1e-5).rsqrt()
+    ac = a[:, :T, :H, :W].reshape(-1, C)
+    if bn:
+        ac = (ac - mean) * invstd * gamma + beta
+    gout = torch.randn(d.ncrop, DO, dtype=torch.float64)
+    u = (ac @ w1.t() + b1).requires_grad_(True)
+    act = torch.nn.functional.gelu(u)
+    (act @ w2.t() * gout).sum().backward()
+    gu_ref = u.grad
+    dw2_ref, db1_ref, db2_ref = gout.t() @ act.detach(), gu_ref.sum(0), gout.sum(0)
+    xf = (dev(mean), dev(invstd), dev(gamma), dev(beta), 0) if bn else None
+    slots = ops.proj_slots(d.ncrop, C, DO)
+    row = DO * 128 + 128 + DO
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RPB_HEAD_PJH_128_BWD", flag)
+        gu = torch.full((d.ncrop, 128), float("nan"), device="cuda")
+        part = torch.full((slots, row), float("nan"), device="cuda")
+        ops.proj_bwd(dev(a).view(-1, C), dev(w1), dev(b1), dev(w2), dev(b2), dev(gout), gu, part, d, DO, xf=xf)
+        tot = part.double().sum(0).cpu()
+        res[flag] = (gu.cpu(), tot)
+        assert rel_l2(gu.cpu(), gu_ref) < 2e-5
+        assert rel_l2(tot[:DO * 128].view(DO, 128), dw2_ref) < 2e-5
+        assert rel_l2(tot[DO * 128:DO * 128 + 128], db1_ref) < 2e-5 and rel_l2(tot[DO * 128 + 128:], db2_ref) < 2e-5
+    assert rel_l2(res["1"][0], res["0"][0]) < 2e-5
