@@ -15,6 +15,7 @@
 // ds_read_b32); weights / DFT matrix sit in block-shared LDS with the MFMA column index contiguous.
 #include "rpb_common.h"
 #include "rpb_cmx.h"
+#include "rpb_pjx.h"
 #include "rpb_bwr.h"
 
 // ---------------------------------------------------------------------------------- cell_mix
@@ -421,6 +422,12 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
         c.FWt = nullptr; c.y1out = nullptr; c.K2f = 0; c.gw_planes = nullptr;
         return rpb_cmx_launch(c, stats_part == nullptr ? 0 : (bnb_s ? 2 : 1), (hipStream_t)stream);
     }
+    // the fc1 data gradient of the width-128 head (configs/fsi/fno.yaml): gu [ncrop][128] x fc1.weight [128][128] gathered into the padded
+    // layout, no statistics -- csrc/rpb_pjh.hip's MODE 2 on the bf16 matrix pipe (round 6b; RPB_GATHER_128_PJH=0: the fp32-pipe kernel below)
+    if (gather && !spec && KC == 128 && CO == 128 && transpose_w && !bias && !stats_part && !xf_mean && !bnb_s && !bnb_mean &&
+        ncell % ((long)Tp * Hp * Wp_pad) == 0 && (long)Wp_pad * 512 < (1l << 31) &&
+        !(getenv("RPB_GATHER_128_PJH") && atoi(getenv("RPB_GATHER_128_PJH")) == 0))
+        return rpb_pjh_dgrad128_launch(x, Wm, out, (int)(ncell / ((long)Tp * Hp * Wp_pad)), T, H, W, Tp, Hp, Wp_pad, (hipStream_t)stream);
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
     const int waves = cell_mix_waves(KC, CO, K2, Wp, spec, bnb_s != nullptr);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);

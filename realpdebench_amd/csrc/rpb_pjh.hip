@@ -161,9 +161,13 @@ struct PjhFwdArgs {
 //       cells) gu = (fc2^T gout) * gelu'(u) is stored for the data / weight gradient kernels and d fc2.weight, d fc1.bias, d fc2.bias
 //       accumulate in registers (one partial row per wave, the format of csrc/rpb_proj.hip).  gelu / gelu' from one erf + one exponential,
 //       the arithmetic of that kernel.
-template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, bool BWD = false>
+// MODE 2 ("DG"): the fc1 DATA gradient at C = 128 -- g[padded cell][ch] = sum_hid gu[cropped cell][hid] fc1.weight[hid][ch], zeros in the pad
+//       (rpb_cell_mix(gather) on the fp32 pipe before): `s` is gu [ncrop][128], `w1` fc1.weight [128 hid][128 ch] read transposed, `out`
+//       the padded gradient tensor [cells][128]; no bias, no activation: the accumulators are stored as they are.
+template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, int MODE = 0>
 __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kernel(PjhFwdArgs p) {
-    static_assert(!BWD || (CW == 128 && !H2 && !BFIN), "the backward instance serves width 128 (width 64 has the one-launch head)");
+    constexpr bool BWD = MODE == 1, DG = MODE == 2;
+    static_assert(MODE == 0 || (CW == 128 && !H2 && !BFIN), "the backward instances serve width 128 (width 64 has the one-launch head)");
     static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
     static_assert(CW == 64 || (CW == 128 && !H2 && !BFIN), "C = 128: fp32 storage, default arithmetic");
     constexpr int KS = CW / 16;                          // K-steps of contraction 1
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = 16 * ks + 8 * (l >> 5) + e;
-            const float w = p.w1[(32 * nt + (l & 31)) * CW + c];
+            const float w = DG ? p.w1[c * CW + 32 * nt + (l & 31)] : p.w1[(32 * nt + (l & 31)) * CW + c];
             v[e] = has_xf ? w * (p.xf.gamma[c] * p.xf.invstd[c]) : w;
             if (H2) v[e] *= (float)(1 << PH_H2W);
         }
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
         W1B[((ks * 4 + nt) * 3 + 2) * 64 + l] = __builtin_bit_cast(u32x4, lo);
     }
     for (int h = tid; h < PH_HID; h += blockDim.x) {
-        float a = p.b1[h];
+        float a = DG ? 0.f : p.b1[h];
         if (has_xf)
             for (int c = 0; c < CW; ++c) a = __builtin_fmaf(p.w1[h * CW + c], p.xf.beta[c], a);
         b1l[h] = a;
@@ -256,12 +260,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
             xa[2 * ks] = ld16(rb, (32 * q + n) * 128 + ks * 32 + hg * 16);
             return;
         }
-        const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * cm.Wp * CW, ok ? (unsigned)cm.W * (CW * 4u) : 0u);   // cells >= W read as 0
+        // (DG: `pl` is the CROPPED line index, the rows are gu's)
+        const rsrc_t rx = make_rsrc(p.s + (long)(ok ? pl : 0) * (DG ? cm.W : cm.Wp) * CW, ok ? (unsigned)cm.W * (CW * 4u) : 0u);   // cells >= W read as 0
         xa[2 * ks] = ld16(rx, (32 * q + n) * (CW * 4) + ks * 64 + hg * 32);
         xa[2 * ks + 1] = ld16(rx, (32 * q + n) * (CW * 4) + ks * 64 + hg * 32 + 16);
     };
     {
-        const int pl0 = slot < GL ? line_of((int)slot) : -1;
+        const int pl0 = slot < GL ? (DG ? (int)slot : line_of((int)slot)) : -1;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) issue_pair(pl0, 0, ks);
     }
@@ -278,6 +283,15 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
     // (lines are dealt statically.  Claimed chip-wide from a counter -- built and measured with -DPH_TIMING: every wave then ends within 4 %
     // of the mean instead of 0.8 .. 1.2 of it, and the launch takes the same 1.57 ms: a workgroup that finishes early leaves its CU to its
     // partner, which speeds up; the bound is per CU, not per wave)
+    if constexpr (DG) {                                  // the pad lines of the gradient tensor: zeros, 1 KB per instruction
+        const long nl = (long)p.B * cm.Tp * cm.Hp;
+        for (long g = slot; g < nl; g += nslots) {
+            const int h = (int)(g % cm.Hp), t = (int)((g / cm.Hp) % cm.Tp);
+            if (h < cm.H && t < cm.T) continue;
+            const rsrc_t rz = make_rsrc(p.out + g * cm.Wp * CW, (unsigned)cm.Wp * (CW * 4u));
+            for (int off = lane * 16; off < cm.Wp * CW * 4; off += 64 * 16) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, off, 0, 0);
+        }
+    }
     for (long gl = slot; gl < GL;) {
         const int pl = line_of((int)gl);
         const long gnext = gl + nslots;
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
         for (int q = 0; q < TQ; ++q) {
             asm volatile("" ::: "memory");
             const bool last = q + 1 == TQ;
-            const int pn = last ? pln : pl, qn = last ? 0 : q + 1;
+            const int pn = DG ? (last ? gln : (int)gl) : (last ? pln : pl), qn = last ? 0 : q + 1;
             // ---- contraction 1: u = (s - mean) W1'^T, software-pipelined over the K-steps: the split of step ks + 1 is written before the
             //      24 MFMAs of step ks and does not depend on them
             f32x16v acc[4];
@@ -384,6 +398,19 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DG) {
+                // ---- g[padded cell 32 q + row][channel 32 nt + n] = the accumulator (cells >= W: gu read 0 -> exact zeros; cells >= Wp dropped)
+                const rsrc_t rg = make_rsrc(p.out + (long)pl * cm.Wp * CW, (unsigned)cm.Wp * (CW * 4u));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store_f32(acc[nt][r], rg, ((32 * q + 8 * (r >> 2) + 4 * hg + (r & 3)) * CW + 32 * nt + n) * 4, 0);
+                if (last)                                // the rest of the w pad
+                    for (int off = 32 * TQ * CW * 4 + lane * 16; off < cm.Wp * CW * 4; off += 64 * 16)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rg, off, 0, 0);
+                continue;
+            }
             if constexpr (BWD) {
                 // ---- gu[cell][hid] = (sum_j gout[cell][j] w2[j][hid]) gelu'(u);  d w2, d b1, d b2 (cells >= W: gout reads 0, the store is dropped)
                 const long row0 = gl * cm.W + 32 * q;
@@ -569,11 +596,28 @@ int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, cons
         (void)hipMemsetAsync(part + grid * PH_WAVES * row, 0, (size_t)(part_rows - grid * PH_WAVES) * row * 4, st);
     const size_t lds128 = pjh_lds(128);
     if (DO <= 2) {
-        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, 1>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
     } else {
-        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128, true>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128, 1>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
     }
     RPB_CHECK_LAUNCH("proj_bwd (pjh, C = 128)");
+}
+
+// The fc1 data gradient at C = 128 gathered into the padded layout (rpb_cell_mix(..., gather = 1) without statistics): MODE 2 of the kernel above.
+int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st) {
+    PjhFwdArgs p{};
+    p.s = gu; p.w1 = w1; p.out = g; p.B = B; p.DO = 0;
+    p.cm = CropMap{T, H, W, Tp, Hp, Wp};
+    p.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    RPB_REQUIRE((long)Wp * 512 < (1l << 31), "proj dgrad (pjh, C = 128): line too long");
+    const long GL = (long)B * T * H;
+    long grid = rpb_num_cus();
+    const long need = (GL + PH_WAVES - 1) / PH_WAVES;
+    if (grid > need) grid = need;
+    const size_t lds128 = pjh_lds(128);
+    (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+    hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, 2>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+    RPB_CHECK_LAUNCH("fc1 data gradient (pjh, C = 128)");
 }

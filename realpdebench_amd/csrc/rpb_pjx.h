@@ -19,3 +19,5 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
 // ... and rpb_proj_bwd's job at C = 128 (gu + the fc2 / bias partial rows) on the same organisation
 int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
                           float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);
+// ... and the fc1 data gradient at C = 128, gathered into the padded layout (rpb_cell_mix with gather = 1, no statistics)
+int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st);

@@ -1071,3 +1071,26 @@ def test_proj_bwd_width_128_on_the_matrix_pipe(ops, B, T, H, W, pad, bn, DO, mon
         assert rel_l2(tot[:DO * 128].view(DO, 128), dw2_ref) < 2e-5
         assert rel_l2(tot[DO * 128:DO * 128 + 128], db1_ref) < 2e-5 and rel_l2(tot[DO * 128 + 128:], db2_ref) < 2e-5
     assert rel_l2(res["1"][0], res["0"][0]) < 2e-5
+
+
+@pytest.mark.parametrize("B,T,H,W,pad", [(2, 3, 6, 40, 2), (1, 2, 5, 64, 6), (3, 2, 4, 32, 6), (2, 2, 3, 5, 2), (1, 2, 3, 70, 6)])
+def test_fc1_data_gradient_width_128_on_the_matrix_pipe(ops, B, T, H, W, pad, monkeypatch):
+    """rpb_cell_mix(gather) at 128 -> 128 channels without statistics (the fc1 data gradient of configs/fsi/fno.yaml) runs csrc/rpb_pjh.hip's
+    MODE 2: g[padded cell] = gu[cropped cell] fc1.weight, exact zeros in the whole pad; against fp64 and the fp32-pipe kernel it replaces."""
+    torch.manual_seed(B * 100 + W)
+    C = 128
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    gu = torch.randn(d.ncrop, 128, dtype=torch.float64)
+    w1 = torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)
+    ref = torch.zeros(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64)
+    ref[:, :T, :H, :W] = (gu @ w1).view(B, T, H, W, C)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RPB_GATHER_128_PJH", flag)
+        g = torch.full((d.ncell, C), float("nan"), device="cuda")
+        ops.cell_mix(dev(gu), dev(w1), None, None, None, g, None, d.ncell, 128, C, 0, 1, transpose_w=True, gather=True, crop6=d.crop6)
+        outs[flag] = g.cpu().view(B, d.Tp, d.Hp, d.Wp, C)
+        assert rel_l2(outs[flag], ref) < TOL
+        assert float(outs[flag][:, T:].abs().max() if pad else 0) == 0 and float(outs[flag][:, :, H:].abs().max()) == 0
+        assert float(outs[flag][:, :, :, W:].abs().max()) == 0
+    assert rel_l2(outs["1"], outs["0"]) < 2e-6
