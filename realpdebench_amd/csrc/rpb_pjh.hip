@@ -164,8 +164,11 @@ struct PjhFwdArgs {
 // MODE 2 ("DG"): the fc1 DATA gradient at C = 128 -- g[padded cell][ch] = sum_hid gu[cropped cell][hid] fc1.weight[hid][ch], zeros in the pad
 //       (rpb_cell_mix(gather) on the fp32 pipe before): `s` is gu [ncrop][128], `w1` fc1.weight [128 hid][128 ch] read transposed, `out`
 //       the padded gradient tensor [cells][128]; no bias, no activation: the accumulators are stored as they are.
-template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, int MODE = 0>
+// SILU: the activation of the Galerkin SpectralRegressor's head (galerkin_transformer_libs/model.py:631-632) instead of the exact GELU; width 128
+//       forward / backward instances only (that head is 128 wide).
+template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, int MODE = 0, bool SILU = false>
 __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kernel(PjhFwdArgs p) {
+    static_assert(!SILU || (CW == 128 && MODE != 2), "SiLU: the width-128 head");
     constexpr bool BWD = MODE == 1, DG = MODE == 2;
     static_assert(MODE == 0 || (CW == 128 && !H2 && !BFIN), "the backward instances serve width 128 (width 64 has the one-launch head)");
     static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
@@ -428,9 +431,17 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float u = acc[nt][r] + b1r[nt];
-                        const float cdf = 0.5f * (1.0f + fast_erf(u * 0.70710678118654752440f));
-                        const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
-                        const float v = u * cdf, dd = __builtin_fmaf(u, pdf, cdf);
+                        float v, dd;
+                        if (SILU) {                      // silu(u) = u sig(u), silu'(u) = sig (1 + u (1 - sig))   (csrc/rpb_proj.hip silu_pair)
+                            const float sig = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * u));
+                            v = u * sig;
+                            dd = sig * (1.0f + u * (1.0f - sig));
+                        } else {
+                            const float cdf = 0.5f * (1.0f + fast_erf(u * 0.70710678118654752440f));
+                            const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
+                            v = u * cdf;
+                            dd = __builtin_fmaf(u, pdf, cdf);
+                        }
                         float gvs = 0.f;
 #pragma unroll
                         for (int j = 0; j < DOT; ++j) {
@@ -455,7 +466,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 #ifdef PH_NOACT   /* timing-only build */
                     const float v = acc[nt][r] + bs[nt];
 #else
-                    const float v = gelu_bias<H2>(acc[nt][r], bs[nt], hb[nt]);
+                    float v;
+                    if (SILU) {
+                        const float u = acc[nt][r] + b1r[nt];
+                        v = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * u));
+                    } else {
+                        v = gelu_bias<H2>(acc[nt][r], bs[nt], hb[nt]);
+                    }
 #endif
 #pragma unroll
                     for (int j = 0; j < DOT; ++j) po[DOT * r + j] = __builtin_fmaf(v, w2r[j][nt], po[DOT * r + j]);
@@ -513,7 +530,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
 }
 
 int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
-                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st,
+                          bool silu);
 static size_t pjh_lds(int CW = 64) { return (size_t)((CW / 16) * 4 * 3 * 64) * 16 + (PH_HID + CW) * 4; }
 
 // 1 when this kernel takes the shape: C = 64, at most four fc2 outputs, exact-erf GELU, fp32 storage, no GELU inside the input transform
@@ -522,12 +540,12 @@ bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16) {
     static const bool bf_off = getenv("RPB_HEAD_PJH_BF16") && atoi(getenv("RPB_HEAD_PJH_BF16")) == 0;
     if (a_bf16 && (bf_off || xf.mean)) return false;     // bf16 storage: plain activations only (the eval cell_mix applied the BatchNorm)
     static const bool c128_off = getenv("RPB_HEAD_PJH_128") && atoi(getenv("RPB_HEAD_PJH_128")) == 0;
-    if (C == 128) return !off && !c128_off && !a_bf16 && DO >= 1 && DO <= 4 && act == 0 && !(xf.mean && xf.gelu);
+    if (C == 128) return !off && !c128_off && !a_bf16 && DO >= 1 && DO <= 4 && (act == 0 || act == 1) && !(xf.mean && xf.gelu);
     return !off && C == 64 && DO >= 1 && DO <= 4 && act == 0 && !(xf.mean && xf.gelu);
 }
 
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
-                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2, bool a_bf16, int C) {
+                   int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2, bool a_bf16, int C, bool silu) {
     PjhFwdArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = out; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -544,13 +562,15 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
         long g128 = rpb_num_cus();
         if (g128 > need) g128 = need;
         const size_t lds128 = pjh_lds(128);
-        if (DO <= 2) {
-            (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128>), dim3((int)g128), dim3(PH_WAVES * 64), lds128, st, p);
-        } else {
-            (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-            hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128>), dim3((int)g128), dim3(PH_WAVES * 64), lds128, st, p);
-        }
+#define PH_L128(D_, M_, S_)                                                                                                          \
+    {                                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<D_, false, false, 128, M_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128); \
+        hipLaunchKernelGGL((pjh_fwd_kernel<D_, false, false, 128, M_, S_>), dim3((int)g128), dim3(PH_WAVES * 64), lds128, st, p);       \
+    }
+        if (DO <= 2 && !silu) PH_L128(2, 0, false)
+        else if (DO <= 2) PH_L128(2, 0, true)
+        else if (!silu) PH_L128(4, 0, false)
+        else PH_L128(4, 0, true)
         RPB_CHECK_LAUNCH("proj_fwd (pjh, C = 128)");
     }
     const size_t lds = pjh_lds();
@@ -580,7 +600,8 @@ int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float
 // rpb_proj_bwd at C = 128 (configs/fsi/fno.yaml): gu + the fc2 / bias partial rows on this file's matrix-pipe organisation.  part_rows rows of
 // [DO*128 + 128 + DO] floats were allocated by the caller (rpb_proj_slots); rows this launch does not write are zeroed.
 int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
-                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st) {
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st,
+                          bool silu) {
     PjhFwdArgs p{};
     p.s = s; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.out = nullptr; p.gout = gout; p.gu = gu; p.part = part; p.B = B; p.DO = DO;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
@@ -595,13 +616,11 @@ int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, cons
     if (part_rows > grid * PH_WAVES)
         (void)hipMemsetAsync(part + grid * PH_WAVES * row, 0, (size_t)(part_rows - grid * PH_WAVES) * row * 4, st);
     const size_t lds128 = pjh_lds(128);
-    if (DO <= 2) {
-        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, 1>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
-    } else {
-        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<4, false, false, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
-        hipLaunchKernelGGL((pjh_fwd_kernel<4, false, false, 128, 1>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
-    }
+    const long g128 = grid;
+    if (DO <= 2 && !silu) PH_L128(2, 1, false)
+    else if (DO <= 2) PH_L128(2, 1, true)
+    else if (!silu) PH_L128(4, 1, false)
+    else PH_L128(4, 1, true)
     RPB_CHECK_LAUNCH("proj_bwd (pjh, C = 128)");
 }
 

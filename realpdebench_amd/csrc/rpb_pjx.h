@@ -15,9 +15,11 @@ bool rpb_pjh_supported(int C, int DO, int act, const XForm& xf, bool a_bf16);
 int rpb_pjh_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* out, int B, int DO, int T, int H,
                    int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st, bool f16x2 = false,    // f16x2: the opt-in two-fp16-plane arithmetic
                    bool a_bf16 = false,                                   // a_bf16: `s` holds bf16 [cells][64] (bf16 activation storage)
-                   int C = 64);                                           // C = 128: the width-128 instance (fp32 storage, default arithmetic)
+                   int C = 64,                                            // C = 128: the width-128 instance (fp32 storage, default arithmetic)
+                   bool silu = false);                                    //   ... with SiLU instead of GELU (the Galerkin regressor's head)
 // ... and rpb_proj_bwd's job at C = 128 (gu + the fc2 / bias partial rows) on the same organisation
 int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, const float* gout, float* gu,
-                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st);
+                          float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st,
+                          bool silu = false);
 // ... and the fc1 data gradient at C = 128, gathered into the padded layout (rpb_cell_mix with gather = 1, no statistics)
 int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st);

@@ -380,7 +380,7 @@ extern "C" int rpb_proj_fwd(const float* a, const float* w1, const float* b1, co
         // width 128 (configs/fsi/fno.yaml), at most four outputs, GELU: csrc/rpb_pjh.hip's C = 128 instance (round 6b; the fp32-pipe kernel
         // below ran it at 0.68 TB/s)
         return rpb_pjh_launch(a, w1, b1, w2, b2, out, (int)(ncrop / ((long)T * H * W)), DO, T, H, W, Tp, Hp, Wp, p.xf, (hipStream_t)stream, false,
-                              false, 128);
+                              false, 128, act == 1);
     return proj_launch(false, p, (hipStream_t)stream);
 }
 
@@ -432,6 +432,6 @@ extern "C" int rpb_proj_bwd(const float* a, const float* w1, const float* b1, co
     if (C == 128 && a && w1 && b1 && w2 && b2 && ncrop % ((long)T * H * W) == 0 && rpb_pjh_supported(128, DO, act, p.xf, false) &&
         !(getenv("RPB_HEAD_PJH_128_BWD") && atoi(getenv("RPB_HEAD_PJH_128_BWD")) == 0))
         return rpb_pjh_bwd128_launch(a, w1, b1, w2, b2, gout, gu, part, rpb_proj_slots(ncrop, C, DO), (int)(ncrop / ((long)T * H * W)), DO, T, H, W,
-                                     Tp, Hp, Wp, p.xf, (hipStream_t)stream);
+                                     Tp, Hp, Wp, p.xf, (hipStream_t)stream, act == 1);
     return proj_launch(true, p, (hipStream_t)stream);
 }

@@ -1094,3 +1094,34 @@ def test_fc1_data_gradient_width_128_on_the_matrix_pipe(ops, B, T, H, W, pad, mo
         assert float(outs[flag][:, T:].abs().max() if pad else 0) == 0 and float(outs[flag][:, :, H:].abs().max()) == 0
         assert float(outs[flag][:, :, :, W:].abs().max()) == 0
     assert rel_l2(outs["1"], outs["0"]) < 2e-6
+
+
+@pytest.mark.parametrize("B,T,H,W,pad,DO", [(2, 3, 6, 40, 2, 2), (1, 2, 5, 70, 6, 3), (2, 2, 3, 5, 2, 4)])
+def test_width_128_head_with_silu(ops, B, T, H, W, pad, DO):
+    """The Galerkin SpectralRegressor's head (SiLU, 128 channels; galerkin_transformer_libs/model.py:631-632) on csrc/rpb_pjh.hip's width-128
+    instances: forward and rpb_proj_bwd's outputs against fp64."""
+    torch.manual_seed(B * 10 + W + DO)
+    C = 128
+    d = ops.Dims(B, T, H, W, 2, C, pad)
+    a = torch.randn(B, d.Tp, d.Hp, d.Wp, C, dtype=torch.float64) * 1.5 + 0.3
+    w1 = torch.randn(128, C, dtype=torch.float64) / math.sqrt(C)
+    b1 = torch.randn(128, dtype=torch.float64)
+    w2 = torch.randn(DO, 128, dtype=torch.float64) / 11
+    b2 = torch.randn(DO, dtype=torch.float64)
+    ac = a[:, :T, :H, :W].reshape(-1, C)
+    u = (ac @ w1.t() + b1).requires_grad_(True)
+    act = torch.nn.functional.silu(u)
+    ref = act @ w2.t() + b2
+    gout = torch.randn(d.ncrop, DO, dtype=torch.float64)
+    (ref * gout).sum().backward()
+    out = torch.full((d.ncrop, DO), float("nan"), device="cuda")
+    ops.proj_fwd(dev(a).view(-1, C), dev(w1), dev(b1), dev(w2), dev(b2), out, d, DO, act=1)
+    assert rel_l2(out.cpu(), ref.detach()) < TOL
+    slots, row = ops.proj_slots(d.ncrop, C, DO), DO * 128 + 128 + DO
+    gu = torch.full((d.ncrop, 128), float("nan"), device="cuda")
+    part = torch.full((slots, row), float("nan"), device="cuda")
+    ops.proj_bwd(dev(a).view(-1, C), dev(w1), dev(b1), dev(w2), dev(b2), dev(gout), gu, part, d, DO, act=1)
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(gu.cpu(), u.grad) < 2e-5
+    assert rel_l2(tot[:DO * 128].view(DO, 128), gout.t() @ act.detach()) < 2e-5
+    assert rel_l2(tot[DO * 128:DO * 128 + 128], u.grad.sum(0)) < 2e-5 and rel_l2(tot[DO * 128 + 128:], gout.sum(0)) < 2e-5
