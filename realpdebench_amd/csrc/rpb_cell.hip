@@ -424,10 +424,12 @@ extern "C" int rpb_cell_mix(const float* x, const float* Wm, const float* bias, 
     }
     // the fc1 data gradient of the width-128 head (configs/fsi/fno.yaml): gu [ncrop][128] x fc1.weight [128][128] gathered into the padded
     // layout, no statistics -- csrc/rpb_pjh.hip's MODE 2 on the bf16 matrix pipe (round 6b; RPB_GATHER_128_PJH=0: the fp32-pipe kernel below)
-    if (gather && !spec && KC == 128 && CO == 128 && transpose_w && !bias && !stats_part && !xf_mean && !bnb_s && !bnb_mean &&
+    // (with bnb_* and stats_part and no GELU in that layer: the BatchNorm-backward sums ride in the same launch -- MODE 3)
+    if (gather && !spec && KC == 128 && CO == 128 && transpose_w && !bias && !xf_mean && ((!stats_part && !bnb_s && !bnb_mean) || (stats_part && bnb_s && bnb_gelu == 0)) &&
         ncell % ((long)Tp * Hp * Wp_pad) == 0 && (long)Wp_pad * 512 < (1l << 31) &&
         !(getenv("RPB_GATHER_128_PJH") && atoi(getenv("RPB_GATHER_128_PJH")) == 0))
-        return rpb_pjh_dgrad128_launch(x, Wm, out, (int)(ncell / ((long)Tp * Hp * Wp_pad)), T, H, W, Tp, Hp, Wp_pad, (hipStream_t)stream);
+        return rpb_pjh_dgrad128_launch(x, Wm, out, (int)(ncell / ((long)Tp * Hp * Wp_pad)), T, H, W, Tp, Hp, Wp_pad, (hipStream_t)stream, bnb_s,
+                                       bnb_mean, bnb_invstd, stats_part, stats_part ? rpb_cell_mix_stat_rows(ncell, KC, CO, 0, 1, 0, 1) : 0);
     RPB_REQUIRE(bnb_gelu != 2, "cell_mix: this shape runs on the fp32 kernel, which does not store gz (ask rpb_cell_mix_writes_gz)");
     const int waves = cell_mix_waves(KC, CO, K2, Wp, spec, bnb_s != nullptr);
     RPB_REQUIRE(waves > 0, "cell_mix: tiles do not fit LDS (KC=%d CO=%d K2=%d Wp=%d)", KC, CO, K2, Wp);

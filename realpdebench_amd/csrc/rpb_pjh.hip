@@ -168,8 +168,11 @@ struct PjhFwdArgs {
 //       forward / backward instances only (that head is 128 wide).
 template <int DOT, bool H2 = false, bool BFIN = false, int CW = 64, int MODE = 0, bool SILU = false>
 __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kernel(PjhFwdArgs p) {
-    static_assert(!SILU || (CW == 128 && MODE != 2), "SiLU: the width-128 head");
-    constexpr bool BWD = MODE == 1, DG = MODE == 2;
+    static_assert(!SILU || (CW == 128 && MODE < 2), "SiLU: the width-128 head");
+    constexpr bool BWD = MODE == 1, DG = MODE == 2 || MODE == 3, DGS = MODE == 3;
+    // MODE 3: MODE 2 + the BatchNorm-backward sums of the last Fourier layer in the epilogue -- per channel sum g and sum g * shat with
+    //         shat = (s - mean) invstd read from `gout` (= the pre-BN tensor s, padded layout) and `xf` (that layer's statistics); one
+    //         partial row [2][128] per wave in `part` (rpb_cell_mix's STATS = 2 format): bn_bwd_reduce's pass over (s, g) disappears
     static_assert(MODE == 0 || (CW == 128 && !H2 && !BFIN), "the backward instances serve width 128 (width 64 has the one-launch head)");
     static_assert(!(H2 && BFIN), "f16x2 is an fp32-storage arithmetic");
     static_assert(CW == 64 || (CW == 128 && !H2 && !BFIN), "C = 128: fp32 storage, default arithmetic");
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hg = lane >> 5;
-    const bool has_xf = p.xf.mean != nullptr;
+    const bool has_xf = !DG && p.xf.mean != nullptr;     // (DG: `xf` carries the statistics of the sums, not an input transform)
     for (int idx = tid; idx < KS * 4 * 64; idx += blockDim.x) {
         const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
         float v[8];
@@ -250,6 +253,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
     }
 #pragma unroll
     for (int j = 0; j < (BWD ? DOT : 1); ++j) db2a[j] = 0.f;
+    float smu[4], sis[4], sg1[4], sg2[4];                // DGS: mean / invstd of channel 32 nt + n, the two sums
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        smu[nt] = DGS ? p.xf.mean[32 * nt + n] : 0.f;
+        sis[nt] = DGS ? p.xf.invstd[32 * nt + n] : 0.f;
+        sg1[nt] = sg2[nt] = 0.f;
+    }
 
     auto line_of = [&](int gl) {                         // cropped line -> padded line (32-bit: B * Tp * Hp lines)
         const unsigned h = (unsigned)gl % (unsigned)cm.H, r2 = (unsigned)gl / (unsigned)cm.H;
@@ -305,6 +315,15 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
             asm volatile("" ::: "memory");
             const bool last = q + 1 == TQ;
             const int pn = DG ? (last ? gln : (int)gl) : (last ? pln : pl), qn = last ? 0 : q + 1;
+            float sp[DGS ? 4 : 1][DGS ? 16 : 1];         // DGS: s at the lane's output positions, requested before the products
+            if constexpr (DGS) {
+                const rsrc_t rs = make_rsrc(p.gout + (long)pl * cm.Wp * CW, (unsigned)cm.Wp * (CW * 4u));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sp[nt][r] = buf_load_f32(rs, ((32 * q + 8 * (r >> 2) + 4 * hg + (r & 3)) * CW + 32 * nt + n) * 4, 0);
+            }
             // ---- contraction 1: u = (s - mean) W1'^T, software-pipelined over the K-steps: the split of step ks + 1 is written before the
             //      24 MFMAs of step ks and does not depend on them
             f32x16v acc[4];
@@ -408,7 +427,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
+                    {
                         buf_store_f32(acc[nt][r], rg, ((32 * q + 8 * (r >> 2) + 4 * hg + (r & 3)) * CW + 32 * nt + n) * 4, 0);
+                        if constexpr (DGS) {             // (cells >= W: g == 0 exactly, whatever s holds there)
+                            sg1[nt] += acc[nt][r];
+                            sg2[nt] = __builtin_fmaf(acc[nt][r], (sp[nt][r] - smu[nt]) * sis[nt], sg2[nt]);
+                        }
+                    }
                 if (last)                                // the rest of the w pad
                     for (int off = 32 * TQ * CW * 4 + lane * 16; off < cm.Wp * CW * 4; off += 64 * 16)
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rg, off, 0, 0);
@@ -497,6 +522,17 @@ __global__ __launch_bounds__(PH_WAVES * 64, CW == 64 ? 2 : 1) void pjh_fwd_kerne
                 if (jy + k < DO) buf_store_f32(q5[k], rgo, ((32 * q + celly) * DO + jy + k) * 4, 0);
         }
         gl = gnext;
+    }
+    if constexpr (DGS) {
+        float* part = p.part + slot * (2 * CW);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float a1 = sg1[nt] + __shfl_xor(sg1[nt], 32, 64), a2 = sg2[nt] + __shfl_xor(sg2[nt], 32, 64);
+            if (hg == 0) {
+                part[32 * nt + n] = a1;
+                part[CW + 32 * nt + n] = a2;
+            }
+        }
     }
     if constexpr (BWD) {
         float* part = p.part + slot * ((long)DO * PH_HID + PH_HID + DO);
@@ -625,17 +661,29 @@ int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, cons
 }
 
 // The fc1 data gradient at C = 128 gathered into the padded layout (rpb_cell_mix(..., gather = 1) without statistics): MODE 2 of the kernel above.
-int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st) {
+int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st,
+                            const float* bnb_s, const float* mean, const float* invstd, float* stats_part, long stats_rows) {
     PjhFwdArgs p{};
     p.s = gu; p.w1 = w1; p.out = g; p.B = B; p.DO = 0;
     p.cm = CropMap{T, H, W, Tp, Hp, Wp};
-    p.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    p.xf = XForm{mean, invstd, nullptr, nullptr, 0};
+    p.gout = bnb_s; p.part = stats_part;
     RPB_REQUIRE((long)Wp * 512 < (1l << 31), "proj dgrad (pjh, C = 128): line too long");
     const long GL = (long)B * T * H;
     long grid = rpb_num_cus();
     const long need = (GL + PH_WAVES - 1) / PH_WAVES;
     if (grid > need) grid = need;
     const size_t lds128 = pjh_lds(128);
+    if (stats_part) {                                    // MODE 3: + the BatchNorm-backward sums; rows this launch does not write are zeroed
+        RPB_REQUIRE(bnb_s && mean && invstd, "fc1 data gradient (pjh, C = 128): the sums need s, mean, invstd");
+        if (grid * PH_WAVES > stats_rows) grid = stats_rows / PH_WAVES;
+        RPB_REQUIRE(grid >= 1, "fc1 data gradient (pjh, C = 128): no partial rows");
+        if (stats_rows > grid * PH_WAVES)
+            (void)hipMemsetAsync(stats_part + grid * PH_WAVES * 256, 0, (size_t)(stats_rows - grid * PH_WAVES) * 256 * 4, st);
+        (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, 3>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
+        RPB_CHECK_LAUNCH("fc1 data gradient + BN-backward sums (pjh, C = 128)");
+    }
     (void)hipFuncSetAttribute((const void*)pjh_fwd_kernel<2, false, false, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
     hipLaunchKernelGGL((pjh_fwd_kernel<2, false, false, 128, 2>), dim3((int)grid), dim3(PH_WAVES * 64), lds128, st, p);
     RPB_CHECK_LAUNCH("fc1 data gradient (pjh, C = 128)");

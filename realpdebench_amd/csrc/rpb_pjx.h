@@ -22,4 +22,7 @@ int rpb_pjh_bwd128_launch(const float* s, const float* w1, const float* b1, cons
                           float* part, long part_rows, int B, int DO, int T, int H, int W, int Tp, int Hp, int Wp, const XForm& xf, hipStream_t st,
                           bool silu = false);
 // ... and the fc1 data gradient at C = 128, gathered into the padded layout (rpb_cell_mix with gather = 1, no statistics)
-int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st);
+// (stats_part != NULL: + the BatchNorm-backward sums (sum g, sum g * shat) of the layer whose pre-BN tensor is bnb_s, one [2][128] row per wave)
+int rpb_pjh_dgrad128_launch(const float* gu, const float* w1, float* g, int B, int T, int H, int W, int Tp, int Hp, int Wp, hipStream_t st,
+                            const float* bnb_s = nullptr, const float* mean = nullptr, const float* invstd = nullptr, float* stats_part = nullptr,
+                            long stats_rows = 0);

@@ -623,9 +623,10 @@ class FNO3d(Model):
                 ops.proj_dgrad(a_last, P("fc1.weight"), P("fc1.bias"), P("fc2.weight"), None, g, ws.bn_part, d, DO, xf_last,
                                act=self.proj_act, gu=ws.gu)
                 ops.reduce_partials(ws.bn_part, ws.pd_slots, 2 * C, out_f32=ws.bn_sums)
-            elif C == 128 and os.environ.get("RPB_GATHER_BNB_FUSED_128") != "1":
-                # width 128: the fp32 gather instance with the BatchNorm-backward sums in its epilogue spills (3.2 ms at the fsi shape);
-                # the plain gather + the streaming reduction over (s, g) -- measured in tools/fsi_probe.py, RPB_GATHER_BNB_FUSED_128=1 restores
+            elif C == 128 and os.environ.get("RPB_GATHER_BNB_FUSED_128", "1") == "0":
+                # width 128, rounds 5-6a: the fp32 gather instance with the BatchNorm-backward sums in its epilogue spilled (3.2 ms at the
+                # fsi shape), so the plain gather + a streaming reduction over (s, g) ran instead.  Round 6b: the gather is csrc/rpb_pjh.hip's
+                # matrix-pipe kernel and carries the sums (MODE 3) -- the branch below; RPB_GATHER_BNB_FUSED_128=0 keeps the two launches
                 ops.cell_mix(ws.gu, P("fc1.weight"), None, None, None, g, None, d.ncell, HID, C, 0, 1, transpose_w=True,
                              gather=True, crop6=d.crop6)
                 xfb = self._layer_xf(ws, L - 1, True)

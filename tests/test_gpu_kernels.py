@@ -1094,6 +1094,20 @@ def test_fc1_data_gradient_width_128_on_the_matrix_pipe(ops, B, T, H, W, pad, mo
         assert float(outs[flag][:, T:].abs().max() if pad else 0) == 0 and float(outs[flag][:, :, H:].abs().max()) == 0
         assert float(outs[flag][:, :, :, W:].abs().max()) == 0
     assert rel_l2(outs["1"], outs["0"]) < 2e-6
+    # ... and with the BatchNorm-backward sums of the last layer in the same launch (MODE 3): sum g, sum g * shat per channel
+    monkeypatch.setenv("RPB_GATHER_128_PJH", "1")
+    sl = torch.randn(d.ncell, C, dtype=torch.float64) * 1.3 + 0.2
+    mean, invstd = torch.randn(C, dtype=torch.float64) * 0.2, torch.rand(C, dtype=torch.float64) + 0.5
+    rows = ops.cell_mix_stat_rows(d.ncell, 128, C, 0, 1, False, True)
+    part = torch.full((rows, 2 * C), float("nan"), device="cuda")
+    g = torch.full((d.ncell, C), float("nan"), device="cuda")
+    ops.cell_mix(dev(gu), dev(w1), None, None, None, g, part, d.ncell, 128, C, 0, 1, transpose_w=True, gather=True, crop6=d.crop6,
+                 bnb=(dev(sl), dev(mean), dev(invstd), dev(torch.ones(C)), dev(torch.zeros(C)), False))
+    assert torch.equal(g.cpu().view(B, d.Tp, d.Hp, d.Wp, C), outs["1"])
+    tot = part.double().sum(0).cpu()
+    gref = ref.view(-1, C)
+    assert rel_l2(tot[:C], gref.sum(0)) < 2e-5
+    assert rel_l2(tot[C:], (gref * ((sl - mean) * invstd)).sum(0)) < 2e-5
 
 
 @pytest.mark.parametrize("B,T,H,W,pad,DO", [(2, 3, 6, 40, 2, 2), (1, 2, 5, 70, 6, 3), (2, 2, 3, 5, 2, 4)])
