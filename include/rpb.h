@@ -593,6 +593,12 @@ int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const float* bias, co
                            int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
                            const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, int bf16_io, int spectra_bf16, void* stream);
 
+/* the same at width 128 (configs/fsi/fno.yaml, the Galerkin regressor; fp32 storage, K2 <= 32): x / out [cells][128], Wm [128][128] */
+int rpb_cell_mix_eval_crop_c128_supported(long ncell, int K2, int Wp);
+int rpb_cell_mix_eval_crop_c128(const float* x, const float* Wm, const float* bias, const float* z2, const float* GWt, float* out, int B, int T,
+                                int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean, const float* oxf_invstd,
+                                const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, void* stream);
+
 /* ---- rollout, OPT-IN arithmetic "f16x2" (FNO3d.set_arith("f16x2"); never the default, never used by training): the two launches above
  *      on fp32 storage with every operand as TWO fp16 planes rounded to nearest even (x = hi + lo to one fp32 unit in the last place) and
  *      three products hi*lo + lo*hi + hi*hi per fp32 product on v_mfma_f32_16x16x32_f16 -- the dropped lo*lo term is <= 2^-22 |a b| (the

@@ -52,6 +52,8 @@ SIGNATURES = {
     "rpb_cell_mix_eval_dft_supported": (_I, "liii"),
     "rpb_cell_mix_eval_dft": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "pp"),
     "rpb_cell_mix_eval_dft_f16x2": (_I, "pppppp" + "l" + "iii" + "ppppi" + "pip" + "p" + "i" + "p"),
+    "rpb_cell_mix_eval_crop_c128": (_I, "pppppp" + "iiiiiiii" + "ppppi" + "p"),
+    "rpb_cell_mix_eval_crop_c128_supported": (_I, "lii"),
     "rpb_proj_fwd_f16x2": (_I, "pppppp" + "l" + "iiiiiii" + "p"),
     "rpb_cell_mix_eval_crop_f16x2": (_I, "pppppp" + "iiiiiiii" + "ppppi" + "i" + "p"),
     "rpb_dpot_patch_tokens": (_I, "ppppp" + "iiiiiii" + "p"),

@@ -600,6 +600,26 @@ extern "C" int rpb_cell_mix_eval_crop(const void* x, const float* Wm, const floa
     c.crop_T = T; c.crop_H = H; c.crop_W = W; c.Tp = Tp; c.Hp = Hp;
     return rpb_cmx_launch(c, 0, (hipStream_t)stream);
 }
+// ... at width 128 (configs/fsi/fno.yaml, the Galerkin regressor; fp32 storage): the C = 128 instance of csrc/rpb_cmx.hip over the crop's lines
+extern "C" int rpb_cell_mix_eval_crop_c128(const float* x, const float* Wm, const float* bias, const float* z2, const float* GW, float* out,
+                                           int B, int T, int H, int W, int Tp, int Hp, int Wp, int K2, const float* oxf_mean,
+                                           const float* oxf_invstd, const float* oxf_gamma, const float* oxf_beta, int oxf_gelu, void* stream) {
+    RPB_REQUIRE(x && Wm && z2 && GW && out && oxf_mean && oxf_invstd && oxf_gamma && oxf_beta, "cell_mix_eval_crop_c128: null pointer");
+    RPB_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && T <= Tp && H <= Hp && W <= Wp, "cell_mix_eval_crop_c128: bad crop (%d %d %d of %d %d %d)", T, H, W, Tp, Hp, Wp);
+    const long ncell = (long)B * Tp * Hp * Wp;
+    RPB_REQUIRE((long)B * T * H < (1l << 31), "cell_mix_eval_crop_c128: too many lines");
+    RPB_REQUIRE(rpb_cmx128_supported(ncell, 128, 128, K2, Wp, true, false), "cell_mix_eval_crop_c128: needs K2 <= 32, Wp >= 32 (K2=%d Wp=%d)", K2, Wp);
+    CmxArgs c{};
+    c.c128 = 1;
+    c.x = x; c.Wm = Wm; c.bias = bias; c.z2 = z2; c.GW = GW; c.out = out; c.stats_part = nullptr;
+    c.ncell = ncell; c.K2 = K2; c.Wp = Wp; c.transpose_w = 0;
+    c.xf = XForm{nullptr, nullptr, nullptr, nullptr, 0};
+    c.bnb_s = nullptr;
+    c.bnb = XForm{oxf_mean, oxf_invstd, oxf_gamma, oxf_beta, oxf_gelu != 0};
+    c.crop_T = T; c.crop_H = H; c.crop_W = W; c.Tp = Tp; c.Hp = Hp;
+    return rpb_cmx_launch(c, 0, (hipStream_t)stream);
+}
+extern "C" int rpb_cell_mix_eval_crop_c128_supported(long ncell, int K2, int Wp) { return rpb_cmx128_supported(ncell, 128, 128, K2, Wp, true, false) ? 1 : 0; }
 // The same on bf16-stored activations (x, out bf16 [ncell][64]; y1 fp32): the stage sees the ROUNDED activations, i.e. exactly what
 // rpb_axis_gemm_bf16in would read back from `out`.
 extern "C" int rpb_cell_mix_eval_dft_bf16(const void* x_bf16, const float* Wm, const float* bias, const void* z2, const float* GW,

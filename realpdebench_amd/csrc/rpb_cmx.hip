@@ -1091,8 +1091,10 @@ long rpb_cmx128_stat_rows(long ncell, int Wp) {
     return pairs * waves;
 }
 static int cmx128_launch(const CmxArgs& a, int stats, hipStream_t st) {
-    if (a.bf16_io || a.feat_w || a.y1out || a.crop_T > 0)
-        RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx (C = 128): plain fp32-storage launches only (no bf16 storage, feature input, fused stage or crop)");
+    if (a.bf16_io || a.feat_w || a.y1out)
+        RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx (C = 128): plain fp32-storage launches only (no bf16 storage, feature input or fused stage)");
+    if (a.crop_T > 0 && (stats != 0 || !a.bnb.mean || a.crop_H <= 0 || a.crop_W <= 0 || a.ncell % ((long)a.Wp * a.Hp * a.Tp) != 0))
+        RPB_FAIL(RPB_ERR_UNSUPPORTED, "cmx (C = 128): the crop-only mode is an eval path (output transform, no statistics)");
     const int waves = cmx_waves128(a.Wp);
     const int grid = 2 * (int)(rpb_cmx128_stat_rows(a.ncell, a.Wp) / waves);
     const size_t lds = cmx_lds128(a.Wp, waves);

@@ -71,6 +71,9 @@ class _Workspace:
         self.crop_last = (not training and C == 64 and model.n_layers > 1 and type(model)._lift_fwd is FNO3d._lift_fwd
                           and os.environ.get("RPB_EVAL_CROP_LAST", "1") != "0"
                           and ops.cell_mix_eval_dft_supported(d.ncell, 2 * plan.KW, d.Wp, 2 * plan.KW))
+        if (not training and C == 128 and not self.bf16 and model.n_layers > 1 and type(model)._lift_fwd is FNO3d._lift_fwd
+                and os.environ.get("RPB_EVAL_CROP_LAST", "1") != "0" and ops.cell_mix_eval_crop_c128_supported(d.ncell, 2 * plan.KW, d.Wp)):
+            self.crop_last = True            # width 128 (configs/fsi/fno.yaml): rpb_cell_mix_eval_crop_c128
         self.Xh = [torch.empty(B * 2 * plan.M * C, **f) for _ in range(L if training else 1)]
         self.Yh = torch.empty(B * 2 * plan.M * C, **f)
         self.mean = torch.empty(L, C, **f)

@@ -134,6 +134,12 @@ def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf, arith="f32"):
     ncell = nl * min(32 * tq, d.Wp)
     zp, sb, zb = _zs(z2)
     assert bf or not sb
+    if x.shape[-1] == 128:          # width 128 (fsi FNO, the Galerkin regressor): the C = 128 instance, fp32 storage
+        assert not bf and arith == "f32"
+        _lib.call("rpb_cell_mix_eval_crop_c128", _p(x), _p(Wm), _p(bias), zp, _p(GW), _p(out), d.B, d.T, d.H, d.W, d.Tp, d.Hp, d.Wp, K2,
+                  *_xf(oxf), _stream(), label="cell_mix[KC128->CO128,spec=1,stats=oxf,crop]",
+                  nbytes=8 * ncell * 128 + zb * nl * K2 * 128, flops=2 * ncell * 128 * (K2 + 128))
+        return
     if arith == "f16x2":
         assert not bf and not sb
         _lib.call("rpb_cell_mix_eval_crop_f16x2", _p(x), _p(Wm), _p(bias), zp, _p(GW), _p(out), d.B, d.T, d.H, d.W, d.Tp, d.Hp, d.Wp, K2,
@@ -147,6 +153,10 @@ def cell_mix_eval_crop(x, Wm, bias, z2, GW, out, d, K2, oxf, arith="f32"):
 
 
 _DFT_SCRATCH = {}
+
+
+def cell_mix_eval_crop_c128_supported(ncell, K2, Wp):
+    return bool(_lib.query("rpb_cell_mix_eval_crop_c128_supported", ncell, K2, Wp))
 
 
 def cell_mix_eval_dft_supported(ncell, K2, Wp, K2f):

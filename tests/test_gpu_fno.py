@@ -239,3 +239,32 @@ def test_eval_forward_from_hipgraph_equals_eager(monkeypatch):
         y_graph = m(xs[0]).clone()
         monkeypatch.setattr(F, "_EVAL_GRAPH", False)
         assert torch.equal(m(xs[0]), y_graph)
+
+
+def test_eval_last_layer_crop_only_width_128(monkeypatch):
+    """Width 128 (configs/fsi/fno.yaml): the last layer's eval cell_mix over the crop only (rpb_cell_mix_eval_crop_c128) is bit-equal to the
+    launch over whole padded lines, and the forward is the oracle's."""
+    from oracle import fno3d_oracle as O
+    from realpdebench_amd.model.fno import FNO3d
+    torch.manual_seed(12)
+    shape, modes, L, width, B = (3, 9, 40, 2), (2, 4, 8), 3, 128, 2
+    sd = O.init_state_dict(modes, L, width, shape, shape, seed=6)
+    for l in range(L):
+        sd[f"bns.{l}.weight"] = torch.rand(width) + 0.5
+        sd[f"bns.{l}.bias"] = torch.randn(width) * 0.2
+        sd[f"bns.{l}.running_mean"] = torch.randn(width) * 0.1
+        sd[f"bns.{l}.running_var"] = torch.rand(width) + 0.5
+    x = torch.randn(B, *shape)
+    ref, _ = O.fno3d_forward(sd, x, modes, L, shape, shape, training=False)
+    m = FNO3d(*modes, L, width, shape, shape)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    outs = {}
+    for crop in ("1", "0"):
+        monkeypatch.setenv("RPB_EVAL_CROP_LAST", crop)
+        m._ws = {}
+        with torch.no_grad():
+            outs[crop] = m(x.cuda()).cpu().clone()
+        assert next(iter(m._ws.values())).crop_last == (crop == "1")
+    assert torch.equal(outs["1"], outs["0"])
+    assert rel_l2(outs["1"], ref) < OUT_TOL
