@@ -66,3 +66,29 @@ def test_weight_layout_roundtrip():
     back = mode_major_to_ref_weights(ref_weights_to_mode_major(*ws), modes)
     for a, b in zip(ws, back):
         assert torch.equal(a, b)
+
+
+def test_f16x2_spec_exp_puts_the_inverse_stage_matrix_in_fp16_range():
+    """ops.spec_exp (the power of two the opt-in f16x2 eval arithmetic moves from the last inverse-stage matrix onto the z2 rows): for the
+    shapes of the reference's FNO YAMLs and a tiny grid, max |GW| 2^e lies in (0.5, 1] and no entry that matters turns subnormal in fp16;
+    set_arith validates its argument without a GPU."""
+    import torch
+    from realpdebench_amd import ops
+    from realpdebench_amd.dft import SpectralPlan
+    for (T, H, W), modes in (((20, 128, 128), (4, 12, 16)), ((20, 64, 128), (4, 12, 16)), ((20, 64, 64), (4, 16, 16)), ((64, 64, 64), (4, 16, 16)),
+                              ((3, 9, 40), (2, 4, 8))):
+        d = ops.Dims(2, T, H, W, 2, 64, 6)
+        plan = SpectralPlan(d.Tp, d.Hp, d.Wp, modes)
+        e = ops.spec_exp(d)
+        m = float(plan.GWt.abs().max()) * 2.0 ** e
+        assert 0.5 < m <= 1.0 + 1e-6, (T, H, W, e, m)
+        big = plan.GWt.abs() * 2.0 ** e
+        assert float(big[big > 2.0 ** -10].min()) > 6.2e-5          # fp16's smallest normal: entries above 1e-3 of the maximum stay normal
+    from realpdebench_amd.model.fno import FNO3d
+    mdl = FNO3d(2, 4, 8, 2, 64, (3, 9, 40, 2), (3, 9, 40, 2))
+    assert mdl.set_arith("f16x2").arith == "f16x2" and mdl.set_arith("f32").arith == "f32"
+    import pytest
+    with pytest.raises(ValueError):
+        mdl.set_arith("fp8")
+    with pytest.raises(NotImplementedError):
+        FNO3d(2, 4, 8, 2, 128, (3, 9, 40, 2), (3, 9, 40, 2)).set_arith("f16x2")
